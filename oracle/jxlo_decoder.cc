@@ -1,0 +1,745 @@
+// ORACLE (test infrastructure, not product code): whole-frame scalar decoder with intermediate dumps.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
+//
+// Parity status: the entropy/bitstream/Modular layers are pinned by streams produced by the reference's own
+// standalone encoder (oracle/_ref, built from lib/jxl/enc_fast_lossless.cc) and by the 1x1 codestream embedded in
+// the reference's decode_test.cc; the VarDCT layer is "parity unpinned" against reference *pixels* (the
+// reference decoder cannot be built in this image) and is pinned instead by the closed-form definitions the
+// reference's tests use (see tests/ and DESIGN.md).
+//
+// Follows the frame walk of reference lib/jxl/dec_frame.cc:135-733 (InitFrame, ProcessDCGlobal, ProcessDCGroup,
+// FinalizeDC, ProcessACGlobal, ProcessACGroup), lib/jxl/dec_modular.cc:209-562, lib/jxl/dec_group.cc:183-460,
+// lib/jxl/dec_cache.cc:117-371 (stage order), lib/jxl/decode.cc:115-150 (signature).
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <string>
+
+#include "jxlo_bits.h"
+#include "jxlo_entropy.h"
+#include "jxlo_headers.h"
+#include "jxlo_modular.h"
+#include "jxlo_render.h"
+#include "jxlo_vardct.h"
+
+namespace jxlo {
+
+struct Decoded {
+  ImageHeader ih;
+  FrameHeader fh;
+  FrameDim dim;
+  int out_channels = 3;
+  std::vector<uint8_t> rgb8;   // interleaved, xsize*ysize*out_channels
+  std::vector<float> rgbf;     // planar 3 x ysize x xsize (after transfer function, before uint8)
+  // VarDCT intermediates
+  std::vector<int32_t> coeffs;     // [group][c][65536], block-contiguous per varblock
+  std::vector<int32_t> nzeros;     // [group][c][32*32]
+  std::vector<float> xyb_idct;     // 3 planes, ysize_padded x xsize_padded (storage order X, Y, B)
+  std::vector<float> xyb_filtered; // 3 planes, ysize x xsize, stride xsize_padded
+  std::vector<float> dc;           // 3 planes, ysize_blocks x xsize_blocks (after smoothing)
+  std::vector<uint8_t> acs;        // ysize_blocks x xsize_blocks: (strategy<<1)|is_first
+  std::vector<int32_t> quant;      // raw quant field (valid at first blocks)
+  std::vector<uint8_t> sharpness;
+  std::vector<int8_t> ytox, ytob;
+  std::vector<float> inv_sigma;
+  std::vector<uint8_t> quant_dc;
+  std::vector<int32_t> modular;    // planar decoded integer channels for Modular frames
+  uint32_t used_acs = 0;
+  uint64_t ac_symbols = 0;
+};
+
+struct FrameState {
+  Decoded* out;
+  const ImageHeader* ih;
+  FrameHeader fh;
+  FrameDim dim;
+  // DC global
+  DequantTables dq;
+  uint32_t global_scale = 1, quant_dc = 16;
+  BlockCtxMap bctx;
+  uint32_t color_factor = 84;
+  float base_corr_x = 0.0f, base_corr_b = 1.0f;
+  int32_t ytox_dc = 0, ytob_dc = 0;
+  MGlobal mglobal;
+  MImage full;  // global modular image (extra channels, or colour for Modular frames)
+  size_t modular_color_channels = 0;
+  // AC global
+  size_t num_histograms = 1;
+  std::vector<std::vector<uint32_t>> orders;  // per pass
+  std::vector<EntropyCode> ac_codes;          // per pass
+  // planes
+  size_t xb, yb;
+  Planes3 idct;  // padded
+};
+
+static void DecodeDcGlobal(BitReader& br, FrameState* s) {
+  const FrameHeader& fh = s->fh;
+  JXLO_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kNoise)),
+             "unsupported: patches/splines/noise");
+  JXLO_CHECK(!(fh.flags & FrameHeader::kUseDcFrame), "unsupported: DC frames");
+  // DequantMatrices::DecodeDC
+  if (!br.ReadBool()) {
+    for (int c = 0; c < 3; c++) {
+      s->dq.dc_quant[c] = ReadF16(br) * (1.0f / 128.0f);
+      JXLO_CHECK(s->dq.dc_quant[c] >= 1e-8f, "invalid DC quant");
+    }
+  }
+  if (!fh.modular) {
+    s->global_scale = ReadU32(br, BitsOffset(11, 1), BitsOffset(11, 2049), BitsOffset(12, 4097), BitsOffset(16, 8193));
+    s->quant_dc = ReadU32(br, Val(16), BitsOffset(5, 1), BitsOffset(8, 1), BitsOffset(16, 1));
+    ReadBlockCtxMap(br, &s->bctx);
+    if (!br.ReadBool()) {  // ColorCorrelation::DecodeDC
+      s->color_factor = ReadU32(br, Val(84), Val(256), BitsOffset(8, 2), BitsOffset(16, 258));
+      s->base_corr_x = ReadF16(br);
+      s->base_corr_b = ReadF16(br);
+      JXLO_CHECK(std::fabs(s->base_corr_x) <= 4.0f && std::fabs(s->base_corr_b) <= 4.0f, "CfL base out of range");
+      s->ytox_dc = int32_t(br.Read(8)) - 128;
+      s->ytob_dc = int32_t(br.Read(8)) - 128;
+    }
+  }
+  // Modular global info
+  if (br.ReadBool()) {
+    size_t nb = (fh.modular ? (s->ih->gray ? 1 : 3) : 0) + s->ih->extra.size();
+    size_t limit = std::min<size_t>(size_t(1) << 22, 1024 + s->dim.xsize * s->dim.ysize * std::max<size_t>(nb, 1) / 16);
+    DecodeTree(br, &s->mglobal.tree, limit);
+    DecodeHistograms(br, (s->mglobal.tree.size() + 1) / 2, &s->mglobal.code);
+    s->mglobal.have = true;
+  }
+  size_t nb_color = 0;
+  if (fh.modular) nb_color = (s->ih->gray && !fh.ycbcr) ? 1 : 3;
+  s->modular_color_channels = nb_color;
+  s->full.ch.clear();
+  s->full.bitdepth = int(s->ih->bits);
+  for (size_t c = 0; c < nb_color; c++) s->full.ch.emplace_back(s->dim.xsize, s->dim.ysize);
+  for (size_t e = 0; e < s->ih->extra.size(); e++) {
+    uint32_t ups = s->fh.ec_upsampling.empty() ? 1 : s->fh.ec_upsampling[e];
+    JXLO_CHECK(ups == 1 && fh.upsampling == 1, "unsupported: upsampling");
+    s->full.ch.emplace_back(s->dim.xsize, s->dim.ysize);
+  }
+  // Stream 0: channels no larger than a group are coded here; transforms stay pending on the full image.
+  ModularDecode(br, &s->full, 0, &s->mglobal, s->dim.group_dim, /*undo_transforms=*/false);
+}
+
+// Decodes the part of the global modular image covered by `rect` whose channels fall in the shift bracket.
+static void DecodeModularGroup(BitReader& br, FrameState* s, size_t x0, size_t y0, size_t xs, size_t ys, int min_shift,
+                               int max_shift, int stream_id) {
+  MImage& full = s->full;
+  size_t c = full.nb_meta;
+  for (; c < full.ch.size(); c++)
+    if (full.ch[c].w > s->dim.group_dim || full.ch[c].h > s->dim.group_dim) break;
+  size_t beginc = c;
+  MImage gi;
+  gi.bitdepth = full.bitdepth;
+  std::vector<size_t> map;
+  struct R { size_t x0, y0, w, h; };
+  std::vector<R> rects;
+  for (; c < full.ch.size(); c++) {
+    MChannel& fc = full.ch[c];
+    int shift = std::min(fc.hshift, fc.vshift);
+    if (shift > max_shift || shift < min_shift) continue;
+    size_t rx0 = x0 >> fc.hshift, ry0 = y0 >> fc.vshift;
+    if (rx0 >= fc.w || ry0 >= fc.h) continue;
+    size_t rw = std::min(xs >> fc.hshift, fc.w - rx0), rh = std::min(ys >> fc.vshift, fc.h - ry0);
+    if (rw == 0 || rh == 0) continue;
+    gi.ch.emplace_back(rw, rh, fc.hshift, fc.vshift);
+    map.push_back(c);
+    rects.push_back({rx0, ry0, rw, rh});
+  }
+  (void)beginc;
+  if (gi.ch.empty()) return;
+  ModularDecode(br, &gi, stream_id, &s->mglobal);
+  for (size_t i = 0; i < map.size(); i++) {
+    MChannel& fc = full.ch[map[i]];
+    for (size_t y = 0; y < rects[i].h; y++)
+      memcpy(fc.Row(rects[i].y0 + y) + rects[i].x0, gi.ch[i].Row(y), rects[i].w * sizeof(int32_t));
+  }
+}
+
+static void DecodeDcGroup(BitReader& br, FrameState* s, size_t g) {
+  Decoded* o = s->out;
+  const FrameDim& d = s->dim;
+  const size_t gx = g % d.xsize_dc_groups, gy = g / d.xsize_dc_groups;
+  const size_t bx0 = gx * d.group_dim, by0 = gy * d.group_dim;  // in blocks
+  const size_t bw = std::min(d.group_dim, d.xsize_blocks - bx0), bh = std::min(d.group_dim, d.ysize_blocks - by0);
+  const size_t ndc = d.num_dc_groups;
+  if (!s->fh.modular) {
+    // VarDCT DC: three channels in Y, X, B order (dec_modular.cc:427-465)
+    uint32_t extra_precision = uint32_t(br.Read(2));
+    float mul = 1.0f / float(1 << extra_precision);
+    MImage img;
+    img.bitdepth = s->full.bitdepth;
+    for (int c = 0; c < 3; c++) img.ch.emplace_back(bw, bh);
+    ModularDecode(br, &img, int(1 + g), &s->mglobal);
+    // DequantDC (compressed_dc.cc:201-296)
+    const float inv_global_scale = 65536.0f / float(s->global_scale);
+    const float inv_quant_dc = inv_global_scale / float(s->quant_dc);
+    float fac[3];
+    for (int c = 0; c < 3; c++) fac[c] = (inv_quant_dc * s->dq.dc_quant[c]) * mul;
+    const float color_scale = 1.0f / float(s->color_factor);
+    const float cfl_x = s->base_corr_x + s->ytox_dc * color_scale, cfl_b = s->base_corr_b + s->ytob_dc * color_scale;
+    const size_t plane = d.xsize_blocks * d.ysize_blocks;
+    for (size_t y = 0; y < bh; y++) {
+      const int32_t *qx = img.ch[1].Row(y), *qy = img.ch[0].Row(y), *qb = img.ch[2].Row(y);
+      for (size_t x = 0; x < bw; x++) {
+        size_t idx = (by0 + y) * d.xsize_blocks + bx0 + x;
+        float in_x = float(qx[x]) * fac[0], in_y = float(qy[x]) * fac[1], in_b = float(qb[x]) * fac[2];
+        o->dc[plane * 1 + idx] = in_y;
+        o->dc[plane * 0 + idx] = in_y * cfl_x + in_x;
+        o->dc[plane * 2 + idx] = in_y * cfl_b + in_b;
+        uint8_t bucket = 0;
+        if (s->bctx.num_dc_ctxs > 1) {
+          int bxk = 0, byk = 0, bbk = 0;
+          for (int t : s->bctx.dc_thresholds[0]) if (qx[x] > t) bxk++;
+          for (int t : s->bctx.dc_thresholds[1]) if (qy[x] > t) byk++;
+          for (int t : s->bctx.dc_thresholds[2]) if (qb[x] > t) bbk++;
+          int b = bxk;
+          b = b * int(s->bctx.dc_thresholds[2].size() + 1) + bbk;
+          b = b * int(s->bctx.dc_thresholds[1].size() + 1) + byk;
+          bucket = uint8_t(b);
+        }
+        o->quant_dc[idx] = bucket;
+      }
+    }
+  }
+  // Modular DC: channels of the global image with shift >= 3
+  DecodeModularGroup(br, s, bx0 * 8, by0 * 8, d.dc_group_dim, d.dc_group_dim, 3, 1000, int(1 + ndc + g));
+  if (!s->fh.modular) {
+    // AC metadata (dec_modular.cc:467-562)
+    size_t upper = bw * bh;
+    size_t count = size_t(br.Read(CeilLog2(upper))) + 1;
+    MImage img;
+    img.bitdepth = s->full.bitdepth;
+    size_t cw = (bw + 7) >> 3, chh = (bh + 7) >> 3;
+    img.ch.emplace_back(cw, chh, 3, 3);
+    img.ch.emplace_back(cw, chh, 3, 3);
+    img.ch.emplace_back(count, 2, 0, 0);
+    img.ch.emplace_back(bw, bh, 0, 0);
+    ModularDecode(br, &img, int(1 + 2 * ndc + g), &s->mglobal);
+    const size_t tiles_x = DivCeil(d.xsize_blocks, 8);
+    for (size_t y = 0; y < chh; y++)
+      for (size_t x = 0; x < cw; x++) {
+        size_t idx = (by0 / 8 + y) * tiles_x + bx0 / 8 + x;
+        o->ytox[idx] = int8_t(std::max(-128, std::min(127, img.ch[0].Row(y)[x])));
+        o->ytob[idx] = int8_t(std::max(-128, std::min(127, img.ch[1].Row(y)[x])));
+      }
+    size_t num = 0;
+    const int32_t *r1 = img.ch[2].Row(0), *r2 = img.ch[2].Row(1);
+    for (size_t iy = 0; iy < bh; iy++) {
+      size_t y = by0 + iy;
+      for (size_t ix = 0; ix < bw; ix++) {
+        size_t x = bx0 + ix;
+        int sharp = img.ch[3].Row(iy)[ix];
+        JXLO_CHECK(sharp >= 0 && sharp < 8, "corrupted sharpness field");
+        o->sharpness[y * d.xsize_blocks + x] = uint8_t(sharp);
+        if (o->acs[y * d.xsize_blocks + x] != 0xFF) continue;
+        JXLO_CHECK(num < count, "AC metadata: too few strategies");
+        int raw = r1[num];
+        JXLO_CHECK(raw >= 0 && raw < 27, "invalid AC strategy");
+        o->used_acs |= 1u << raw;
+        size_t cx = kCoveredX[raw], cy = kCoveredY[raw];
+        size_t nx = (x / 32 + 1) * 32, ny = (y / 32 + 1) * 32;
+        JXLO_CHECK(x + cx <= nx && x + cx <= std::min(d.xsize_blocks, bx0 + bw), "AC strategy x overflow");
+        JXLO_CHECK(y + cy <= ny && y + cy <= std::min(d.ysize_blocks, by0 + bh), "AC strategy y overflow");
+        for (size_t jy = 0; jy < cy; jy++)
+          for (size_t jx = 0; jx < cx; jx++) {
+            uint8_t& a = o->acs[(y + jy) * d.xsize_blocks + x + jx];
+            JXLO_CHECK(a == 0xFF, "AC strategy overlap");
+            a = uint8_t((raw << 1) | ((jx | jy) == 0 ? 1 : 0));
+          }
+        o->quant[y * d.xsize_blocks + x] = 1 + std::max(0, std::min(255, r2[num]));
+        num++;
+      }
+    }
+  }
+}
+
+static void FinalizeDc(FrameState* s) {
+  Decoded* o = s->out;
+  const FrameDim& d = s->dim;
+  const size_t xs = d.xsize_blocks, ys = d.ysize_blocks, plane = xs * ys;
+  // EPF sigma (epf.cc:39-133); stored as 1/sigma per 8x8 block
+  if (s->fh.lf.epf_iters > 0) {
+    const float quant_scale = float(s->global_scale) * (1.0f / 65536.0f);
+    for (size_t by = 0; by < ys; by++)
+      for (size_t bx = 0; bx < xs; bx++) {
+        uint8_t a = o->acs[by * xs + bx];
+        if (!(a & 1)) continue;
+        int st = a >> 1;
+        float sigma_quant = s->fh.lf.epf_quant_mul / (quant_scale * float(o->quant[by * xs + bx]) * kInvSigmaNum);
+        for (size_t iy = 0; iy < kCoveredY[st]; iy++)
+          for (size_t ix = 0; ix < kCoveredX[st]; ix++) {
+            float sigma = sigma_quant * s->fh.lf.epf_sharp_lut[o->sharpness[(by + iy) * xs + bx + ix]];
+            sigma = std::min(-1e-4f, sigma);
+            o->inv_sigma[(by + iy) * xs + bx + ix] = 1.0f / sigma;
+          }
+      }
+  }
+  // Adaptive DC smoothing (compressed_dc.cc:128-198)
+  if (!(s->fh.flags & FrameHeader::kSkipDcSmoothing) && xs > 2 && ys > 2) {
+    const float inv_global_scale = 65536.0f / float(s->global_scale);
+    const float inv_quant_dc = inv_global_scale / float(s->quant_dc);
+    float dcf[3];
+    for (int c = 0; c < 3; c++) dcf[c] = inv_quant_dc * s->dq.dc_quant[c];
+    const float w1 = 0.20345139757231578f, w2 = 0.0334829185968739f, w0 = 1.0f - 4.0f * (w1 + w2);
+    std::vector<float> sm(o->dc);
+    for (size_t y = 1; y + 1 < ys; y++)
+      for (size_t x = 1; x + 1 < xs; x++) {
+        float mc[3], smv[3], gap = 0.5f;
+        for (int c = 0; c < 3; c++) {
+          const float* p = o->dc.data() + plane * c;
+          const float *t = p + (y - 1) * xs, *m = p + y * xs, *b = p + (y + 1) * xs;
+          float corner = (t[x - 1] + t[x + 1]) + (b[x - 1] + b[x + 1]);
+          float side = (m[x - 1] + m[x + 1]) + (t[x] + b[x]);
+          mc[c] = m[x];
+          smv[c] = corner * w2 + (side * w1 + mc[c] * w0);
+          gap = std::max(gap, std::fabs((mc[c] - smv[c]) / dcf[c]));
+        }
+        float factor = -4.0f * gap + 3.0f;
+        if (factor < 0) factor = 0;
+        for (int c = 0; c < 3; c++) sm[plane * c + y * xs + x] = (smv[c] - mc[c]) * factor + mc[c];
+      }
+    o->dc.swap(sm);
+  }
+}
+
+static void DecodeAcGlobal(BitReader& br, FrameState* s) {
+  if (s->fh.modular) return;
+  if (!br.ReadBool()) {
+    for (int k = 0; k < 17; k++) {
+      ReadQuantEncoding(br, k, &s->dq.enc[k]);
+      s->dq.table[k].clear();
+    }
+  }
+  s->num_histograms = 1 + size_t(br.Read(CeilLog2(s->dim.num_groups)));
+  s->orders.resize(s->fh.num_passes);
+  s->ac_codes.resize(s->fh.num_passes);
+  for (uint32_t p = 0; p < s->fh.num_passes; p++) {
+    uint32_t used_orders = ReadU32(br, Val(0x5F), Val(0x13), Val(0), Bits(13));
+    DecodeCoeffOrders(br, used_orders, s->out->used_acs, &s->orders[p]);
+    size_t nctx = s->num_histograms * s->bctx.NumACContexts();
+    DecodeHistograms(br, nctx, &s->ac_codes[p]);
+    s->ac_codes[p].ctx_map.resize(nctx + 16, 0);  // slack for out-of-range contexts of invalid streams
+  }
+}
+
+static inline int32_t PredictNz(const int32_t* top, const int32_t* cur, size_t x) {
+  if (x == 0) return top ? top[x] : 32;
+  if (!top) return cur[x - 1];
+  return (top[x] + cur[x - 1] + 1) / 2;
+}
+
+// AC group: entropy-decode quantised coefficients (dec_group.cc:469-542, 594-639), one pass.
+static void DecodeAcGroupPass(BitReader& br, FrameState* s, size_t g, uint32_t pass, int32_t* coeffs /*[3][65536]*/,
+                              int32_t* nz /*[3][1024]*/) {
+  Decoded* o = s->out;
+  const FrameDim& d = s->dim;
+  const size_t gx = g % d.xsize_groups, gy = g / d.xsize_groups;
+  const size_t bx0 = gx * 32, by0 = gy * 32;
+  const size_t bw = std::min<size_t>(32, d.xsize_blocks - bx0), bh = std::min<size_t>(32, d.ysize_blocks - by0);
+  size_t hbits = CeilLog2(s->num_histograms);
+  size_t sel = hbits ? size_t(br.Read(hbits)) : 0;
+  JXLO_CHECK(sel < s->num_histograms, "invalid histogram selector");
+  const size_t ctx_offset = sel * s->bctx.NumACContexts();
+  const EntropyCode& code = s->ac_codes[pass];
+  SymbolReader rd(&code, &br);
+  const std::vector<uint32_t>& orders = s->orders[pass];
+  const uint32_t shift = s->fh.pass_shift[pass];
+  size_t offset = 0;
+  for (size_t by = 0; by < bh; by++) {
+    for (size_t bx = 0; bx < bw; bx++) {
+      uint8_t a = o->acs[(by0 + by) * d.xsize_blocks + bx0 + bx];
+      if (!(a & 1)) continue;
+      const int st = a >> 1;
+      const size_t cx = kCoveredX[st], cy = kCoveredY[st];
+      const size_t log2c = kLog2Covered[st], covered = size_t(1) << log2c, size = covered * 64;
+      const int ord = kStrategyOrder[st];
+      const uint32_t qf = uint32_t(o->quant[(by0 + by) * d.xsize_blocks + bx0 + bx]);
+      const uint8_t qdc = o->quant_dc[(by0 + by) * d.xsize_blocks + bx0 + bx];
+      static const int kChanOrder[3] = {1, 0, 2};
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = kChanOrder[ci];
+        int32_t* nzc = nz + c * 1024;
+        const int32_t* top = by ? nzc + (by - 1) * 32 : nullptr;
+        int32_t* cur = nzc + by * 32;
+        int32_t predicted = PredictNz(top, cur, bx);
+        size_t block_ctx = s->bctx.Context(qdc, qf, ord, c);
+        size_t nzctx = s->bctx.NonZeroContext(uint32_t(predicted), block_ctx) + ctx_offset;
+        size_t nzeros = rd.Read(nzctx);
+        JXLO_CHECK(nzeros <= size - covered, "invalid AC: nzeros too large");
+        for (size_t y = 0; y < cy; y++)
+          for (size_t x = 0; x < cx; x++) cur[bx + x + y * 32] = int32_t((nzeros + covered - 1) >> log2c);
+        const size_t histo_offset = ctx_offset + s->bctx.ZeroDensityOffset(block_ctx);
+        const uint32_t* order = &orders[CoeffOrderOffset(ord, c)];
+        int32_t* block = coeffs + c * 65536 + offset;
+        size_t prev = nzeros > size / 16 ? 0 : 1;
+        for (size_t k = covered; k < size && nzeros != 0; ++k) {
+          size_t ctx = histo_offset + ZeroDensityContext(nzeros, k, covered, log2c, prev);
+          uint32_t u = rd.Read(ctx);
+          o->ac_symbols++;
+          uint32_t mag = u >> 1, neg = (~u) & 1;
+          int32_t coeff = int32_t((mag ^ (neg - 1)) << shift);
+          block[order[k]] += coeff;
+          prev = u != 0;
+          nzeros -= prev;
+        }
+        JXLO_CHECK(nzeros == 0, "invalid AC: nzeros at end of block != 0");
+      }
+      offset += size;
+    }
+  }
+  JXLO_CHECK(rd.FinalStateOk(), "AC group: bad ANS final state");
+}
+
+// Dequantise + CfL + LLF + inverse transform for all varblocks of a group (dec_group.cc:115-181, 433-450).
+static void ReconstructGroup(FrameState* s, size_t g, const int32_t* coeffs) {
+  Decoded* o = s->out;
+  const FrameDim& d = s->dim;
+  const size_t gx = g % d.xsize_groups, gy = g / d.xsize_groups;
+  const size_t bx0 = gx * 32, by0 = gy * 32;
+  const size_t bw = std::min<size_t>(32, d.xsize_blocks - bx0), bh = std::min<size_t>(32, d.ysize_blocks - by0);
+  const float inv_global_scale = 65536.0f / float(s->global_scale);
+  const float x_dm = std::pow(1.25f, 2.0f - float(s->fh.x_qm_scale)), b_dm = std::pow(1.25f, 2.0f - float(s->fh.b_qm_scale));
+  const float color_scale = 1.0f / float(s->color_factor);
+  const size_t tiles_x = DivCeil(d.xsize_blocks, 8), plane = d.xsize_blocks * d.ysize_blocks;
+  std::vector<float> block;
+  size_t offset = 0;
+  for (size_t by = 0; by < bh; by++)
+    for (size_t bx = 0; bx < bw; bx++) {
+      const size_t abx = bx0 + bx, aby = by0 + by;
+      uint8_t a = o->acs[aby * d.xsize_blocks + abx];
+      if (!(a & 1)) continue;
+      const int st = a >> 1;
+      const size_t size = (size_t(1) << kLog2Covered[st]) * 64;
+      block.assign(3 * size, 0.0f);
+      const float scaled = inv_global_scale / float(o->quant[aby * d.xsize_blocks + abx]);
+      const float sx = scaled * x_dm, sy = scaled, sb = scaled * b_dm;
+      const float x_cc = s->base_corr_x + float(o->ytox[(aby / 8) * tiles_x + abx / 8]) * color_scale;
+      const float b_cc = s->base_corr_b + float(o->ytob[(aby / 8) * tiles_x + abx / 8]) * color_scale;
+      const float *mx = s->dq.Matrix(st, 0), *my = s->dq.Matrix(st, 1), *mb = s->dq.Matrix(st, 2);
+      const float* biases = s->ih->quant_bias;
+      for (size_t k = 0; k < size; k++) {
+        float dx = AdjustQuantBias(0, coeffs[0 * 65536 + offset + k], biases) * (mx[k] * sx);
+        float dy = AdjustQuantBias(1, coeffs[1 * 65536 + offset + k], biases) * (my[k] * sy);
+        float db = AdjustQuantBias(2, coeffs[2 * 65536 + offset + k], biases) * (mb[k] * sb);
+        block[k] = x_cc * dy + dx;
+        block[size + k] = dy;
+        block[2 * size + k] = b_cc * dy + db;
+      }
+      for (int c = 0; c < 3; c++) {
+        LowestFrequenciesFromDC(st, o->dc.data() + plane * c + aby * d.xsize_blocks + abx, d.xsize_blocks,
+                                block.data() + c * size);
+        TransformToPixels(st, block.data() + c * size, s->idct.p[c].data() + aby * 8 * s->idct.stride + abx * 8,
+                          s->idct.stride);
+      }
+      offset += size;
+    }
+}
+
+static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool want_dumps) {
+  FrameState st;
+  FrameState* s = &st;
+  s->out = out;
+  s->ih = &ih;
+  ReadFrameHeader(br, ih, &s->fh);
+  const FrameHeader& fh = s->fh;
+  JXLO_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
+  JXLO_CHECK(fh.upsampling == 1, "unsupported: upsampling");
+  JXLO_CHECK(!fh.custom_size, "unsupported: cropped frames");
+  JXLO_CHECK(fh.is_last, "unsupported: multiple frames");
+  JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
+  JXLO_CHECK(fh.modular || ih.xyb_encoded, "unsupported: non-XYB VarDCT");
+  JXLO_CHECK(!(fh.modular && ih.xyb_encoded), "unsupported: XYB Modular frames");
+  s->dim = MakeFrameDim(fh);
+  const FrameDim& d = s->dim;
+  out->fh = fh;
+  out->dim = d;
+  const size_t np = fh.num_passes;
+  const size_t entries = (d.num_groups == 1 && np == 1) ? 1 : 2 + d.num_dc_groups + d.num_groups * np;
+  Toc toc;
+  ReadToc(br, entries, &toc);
+  const size_t base = br.BitPos() / 8;
+  JXLO_CHECK(base + toc.total <= br.size(), "truncated frame");
+  const uint8_t* data = br.data();
+  const size_t xb = d.xsize_blocks, yb = d.ysize_blocks;
+  if (!fh.modular) {
+    out->dc.assign(3 * xb * yb, 0.0f);
+    out->acs.assign(xb * yb, 0xFF);
+    out->quant.assign(xb * yb, 0);
+    out->sharpness.assign(xb * yb, 0);
+    out->quant_dc.assign(xb * yb, 0);
+    out->ytox.assign(DivCeil(xb, 8) * DivCeil(yb, 8), 0);
+    out->ytob.assign(DivCeil(xb, 8) * DivCeil(yb, 8), 0);
+    out->inv_sigma.assign(xb * yb, 0.0f);
+    out->coeffs.assign(d.num_groups * 3 * 65536, 0);
+    out->nzeros.assign(d.num_groups * 3 * 1024, 0);
+    s->idct.Alloc(d.xsize, d.ysize, d.xsize_padded);
+    for (auto& v : s->idct.p) v.assign(d.xsize_padded * d.ysize_padded, 0.0f);
+  }
+  auto check_section = [&](BitReader& r, const char* what) {
+    JXLO_CHECK(!r.Overread(), std::string("section over-read: ") + what);
+  };
+  if (entries == 1) {
+    BitReader r(data + base + toc.offset[0], toc.size[0]);
+    DecodeDcGlobal(r, s);
+    DecodeDcGroup(r, s, 0);
+    if (!fh.modular) FinalizeDc(s);
+    DecodeAcGlobal(r, s);
+    if (!fh.modular) DecodeAcGroupPass(r, s, 0, 0, out->coeffs.data(), out->nzeros.data());
+    DecodeModularGroup(r, s, 0, 0, d.group_dim, d.group_dim, 0, 2, int(1 + 3 * d.num_dc_groups + 17 + 0));
+    check_section(r, "single");
+  } else {
+    {
+      BitReader r(data + base + toc.offset[0], toc.size[0]);
+      DecodeDcGlobal(r, s);
+      check_section(r, "DC global");
+    }
+    for (size_t g = 0; g < d.num_dc_groups; g++) {
+      BitReader r(data + base + toc.offset[1 + g], toc.size[1 + g]);
+      DecodeDcGroup(r, s, g);
+      check_section(r, "DC group");
+    }
+    if (!fh.modular) FinalizeDc(s);
+    {
+      size_t i = 1 + d.num_dc_groups;
+      BitReader r(data + base + toc.offset[i], toc.size[i]);
+      DecodeAcGlobal(r, s);
+      check_section(r, "AC global");
+    }
+    for (size_t p = 0; p < np; p++) {
+      // Downsampling bracket (frame_header.h:268-284) for streams without progressive-downsampling info:
+      // the last pass carries shifts 0..2, earlier passes carry no Modular data.
+      const int min_shift = 0, max_shift = 2;
+      for (size_t g = 0; g < d.num_groups; g++) {
+        size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
+        BitReader r(data + base + toc.offset[i], toc.size[i]);
+        if (!fh.modular)
+          DecodeAcGroupPass(r, s, g, uint32_t(p), out->coeffs.data() + g * 3 * 65536, out->nzeros.data() + g * 3 * 1024);
+        size_t gx = g % d.xsize_groups, gy = g / d.xsize_groups;
+        if (np == 1 || p + 1 == np)
+          DecodeModularGroup(r, s, gx * d.group_dim, gy * d.group_dim, d.group_dim, d.group_dim, min_shift, max_shift,
+                             int(1 + 3 * d.num_dc_groups + 17 + d.num_groups * p + g));
+        check_section(r, "AC group");
+      }
+    }
+  }
+  br.Skip(base * 8 + toc.total * 8 - br.BitPos());
+  // Undo the global modular transforms
+  for (size_t i = s->full.transforms.size(); i-- > 0;) InverseTransform(&s->full, s->full.transforms[i]);
+  s->full.transforms.clear();
+
+  // ---- render
+  const size_t xs = d.xsize, ys = d.ysize;
+  const bool has_alpha = !ih.extra.empty() && ih.extra[0].type == 0;
+  out->out_channels = has_alpha ? 4 : 3;
+  out->rgbf.assign(3 * xs * ys, 0.0f);
+  if (!fh.modular) {
+    for (size_t g = 0; g < d.num_groups; g++) ReconstructGroup(s, g, out->coeffs.data() + g * 3 * 65536);
+    if (want_dumps) {
+      out->xyb_idct.resize(3 * d.xsize_padded * d.ysize_padded);
+      for (int c = 0; c < 3; c++)
+        memcpy(out->xyb_idct.data() + c * d.xsize_padded * d.ysize_padded, s->idct.p[c].data(),
+               d.xsize_padded * d.ysize_padded * sizeof(float));
+    }
+    Planes3 a, b;
+    const Planes3* cur = &s->idct;
+    if (fh.lf.gab) {
+      Gaborish(*cur, fh.lf, &a);
+      cur = &a;
+    }
+    auto run_epf = [&](int stage) {
+      Planes3* dst = (cur == &a) ? &b : &a;
+      EpfPass(stage, *cur, fh.lf, out->inv_sigma, xb, dst);
+      cur = dst;
+    };
+    if (fh.lf.epf_iters >= 3) run_epf(0);
+    if (fh.lf.epf_iters >= 1) run_epf(1);
+    if (fh.lf.epf_iters >= 2) run_epf(2);
+    if (want_dumps) {
+      out->xyb_filtered.resize(3 * d.xsize_padded * ys);
+      for (int c = 0; c < 3; c++)
+        memcpy(out->xyb_filtered.data() + c * d.xsize_padded * ys, cur->p[c].data(), d.xsize_padded * ys * sizeof(float));
+    }
+    OpsinParams op = MakeOpsinParams(ih);
+    for (size_t y = 0; y < ys; y++)
+      for (size_t x = 0; x < xs; x++) {
+        size_t i = y * cur->stride + x;
+        float r, g, bb;
+        XybToRgb(op, cur->p[0][i], cur->p[1][i], cur->p[2][i], &r, &g, &bb);
+        if (!ih.linear_tf) {
+          r = LinearToSrgb(r);
+          g = LinearToSrgb(g);
+          bb = LinearToSrgb(bb);
+        }
+        out->rgbf[0 * xs * ys + y * xs + x] = r;
+        out->rgbf[1 * xs * ys + y * xs + x] = g;
+        out->rgbf[2 * xs * ys + y * xs + x] = bb;
+      }
+  } else {
+    const float factor = float(1.0 / double((1u << s->full.bitdepth) - 1));
+    const size_t ncol = s->modular_color_channels;
+    for (int c = 0; c < 3; c++) {
+      const MChannel& ch = s->full.ch[ncol == 1 ? 0 : c];
+      for (size_t i = 0; i < xs * ys; i++) out->rgbf[c * xs * ys + i] = float(ch.d[i]) * factor;
+    }
+    if (want_dumps) {
+      out->modular.resize(s->full.ch.size() * xs * ys);
+      for (size_t c = 0; c < s->full.ch.size(); c++)
+        memcpy(out->modular.data() + c * xs * ys, s->full.ch[c].d.data(), xs * ys * sizeof(int32_t));
+    }
+  }
+  const int oc = out->out_channels;
+  out->rgb8.resize(xs * ys * oc);
+  std::vector<float> alpha;
+  if (has_alpha) {
+    const MChannel& ch = s->full.ch[s->modular_color_channels];
+    const float af = float(1.0 / double((1u << ih.extra[0].bits) - 1));
+    alpha.resize(xs * ys);
+    for (size_t i = 0; i < xs * ys; i++) alpha[i] = float(ch.d[i]) * af;
+  }
+  for (size_t y = 0; y < ys; y++)
+    for (size_t x = 0; x < xs; x++) {
+      for (int c = 0; c < 3; c++) out->rgb8[(y * xs + x) * oc + c] = ToU8(out->rgbf[c * xs * ys + y * xs + x], x, y, c);
+      if (has_alpha) out->rgb8[(y * xs + x) * oc + 3] = ToU8(alpha[y * xs + x], x, y, 3);
+    }
+}
+
+static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dumps) {
+  // bare codestream, or a container whose first codestream box is `jxlc`
+  static const uint8_t kContainer[12] = {0, 0, 0, 0xC, 'J', 'X', 'L', ' ', 0xD, 0xA, 0x87, 0xA};
+  if (size >= 12 && !memcmp(data, kContainer, 12)) {
+    size_t pos = 12;
+    bool found = false;
+    while (pos + 8 <= size) {
+      uint64_t bsize = (uint64_t(data[pos]) << 24) | (data[pos + 1] << 16) | (data[pos + 2] << 8) | data[pos + 3];
+      size_t hdr = 8;
+      if (bsize == 1) {
+        JXLO_CHECK(pos + 16 <= size, "truncated box");
+        bsize = 0;
+        for (int i = 0; i < 8; i++) bsize = (bsize << 8) | data[pos + 8 + i];
+        hdr = 16;
+      }
+      if (bsize == 0) bsize = size - pos;
+      JXLO_CHECK(bsize >= hdr && pos + bsize <= size, "bad box size");
+      if (!memcmp(data + pos + 4, "jxlc", 4)) {
+        data += pos + hdr;
+        size = bsize - hdr;
+        found = true;
+        break;
+      }
+      JXLO_CHECK(memcmp(data + pos + 4, "jxlp", 4) != 0, "unsupported: jxlp boxes");
+      pos += bsize;
+    }
+    JXLO_CHECK(found, "no codestream box");
+  }
+  JXLO_CHECK(size >= 2 && data[0] == 0xFF && data[1] == 0x0A, "not a JPEG XL codestream");
+  BitReader br(data, size);
+  br.Skip(16);
+  ReadImageHeader(br, &out->ih);
+  DecodeFrame(br, out->ih, out, want_dumps);
+}
+
+}  // namespace jxlo
+
+// ------------------------------------------------------------------ C interface (ctypes / tests)
+extern "C" {
+
+struct JxloHandle {
+  jxlo::Decoded d;
+  std::string error;
+};
+
+// flags: bit0 = keep intermediate dumps. Returns a handle (never NULL); check jxlo_error().
+JxloHandle* jxlo_decode(const uint8_t* data, size_t size, int flags) {
+  JxloHandle* h = new JxloHandle;
+  try {
+    jxlo::Decode(data, size, &h->d, (flags & 1) != 0);
+  } catch (const std::exception& e) {
+    h->error = e.what();
+    if (h->error.empty()) h->error = "unknown error";
+  }
+  return h;
+}
+const char* jxlo_error(JxloHandle* h) { return h->error.empty() ? nullptr : h->error.c_str(); }
+void jxlo_free(JxloHandle* h) { delete h; }
+// info[0..15]: xsize, ysize, out_channels, is_modular, xsize_blocks, ysize_blocks, xsize_padded, ysize_padded,
+// num_groups, num_dc_groups, epf_iters, gab, num_passes, used_acs, bits, ac_symbols(low 32)
+void jxlo_info(JxloHandle* h, uint32_t* info) {
+  const jxlo::Decoded& d = h->d;
+  info[0] = uint32_t(d.dim.xsize);
+  info[1] = uint32_t(d.dim.ysize);
+  info[2] = uint32_t(d.out_channels);
+  info[3] = d.fh.modular;
+  info[4] = uint32_t(d.dim.xsize_blocks);
+  info[5] = uint32_t(d.dim.ysize_blocks);
+  info[6] = uint32_t(d.dim.xsize_padded);
+  info[7] = uint32_t(d.dim.ysize_padded);
+  info[8] = uint32_t(d.dim.num_groups);
+  info[9] = uint32_t(d.dim.num_dc_groups);
+  info[10] = d.fh.lf.epf_iters;
+  info[11] = d.fh.lf.gab;
+  info[12] = d.fh.num_passes;
+  info[13] = d.used_acs;
+  info[14] = d.ih.bits;
+  info[15] = uint32_t(d.ac_symbols);
+}
+// Named buffers: "rgb8","rgbf","coeffs","nzeros","xyb_idct","xyb_filtered","dc","acs","quant","sharpness","ytox",
+// "ytob","inv_sigma","quant_dc","modular". Returns pointer and byte size (0 if absent).
+const void* jxlo_buffer(JxloHandle* h, const char* name, size_t* nbytes) {
+  jxlo::Decoded& d = h->d;
+  std::string n(name);
+#define JXLO_BUF(field)                                         \
+  if (n == #field) {                                            \
+    *nbytes = d.field.size() * sizeof(d.field[0]);              \
+    return d.field.empty() ? nullptr : (const void*)d.field.data(); \
+  }
+  JXLO_BUF(rgb8) JXLO_BUF(rgbf) JXLO_BUF(coeffs) JXLO_BUF(nzeros) JXLO_BUF(xyb_idct) JXLO_BUF(xyb_filtered) JXLO_BUF(dc)
+  JXLO_BUF(acs) JXLO_BUF(quant) JXLO_BUF(sharpness) JXLO_BUF(ytox) JXLO_BUF(ytob) JXLO_BUF(inv_sigma) JXLO_BUF(quant_dc)
+  JXLO_BUF(modular)
+#undef JXLO_BUF
+  *nbytes = 0;
+  return nullptr;
+}
+
+}  // extern "C"
+
+#ifdef JXLO_MAIN
+#include <chrono>
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    fprintf(stderr, "usage: %s in.jxl [out.ppm] [reps]\n", argv[0]);
+    return 2;
+  }
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  std::vector<uint8_t> buf;
+  uint8_t tmp[65536];
+  size_t n;
+  while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  fclose(f);
+  int reps = argc > 3 ? atoi(argv[3]) : 1;
+  for (int r = 0; r < reps; r++) {
+    auto t0 = std::chrono::steady_clock::now();
+    JxloHandle* h = jxlo_decode(buf.data(), buf.size(), 0);
+    auto t1 = std::chrono::steady_clock::now();
+    if (jxlo_error(h)) {
+      fprintf(stderr, "error: %s\n", jxlo_error(h));
+      return 1;
+    }
+    uint32_t info[16];
+    jxlo_info(h, info);
+    double sec = std::chrono::duration<double>(t1 - t0).count();
+    fprintf(stderr, "%ux%u decoded in %.3f s = %.2f MP/s\n", info[0], info[1], sec, info[0] * double(info[1]) * 1e-6 / sec);
+    if (r == reps - 1 && argc > 2 && info[2] == 3) {
+      FILE* o = fopen(argv[2], "wb");
+      fprintf(o, "P6\n%u %u\n255\n", info[0], info[1]);
+      size_t nb;
+      const void* p = jxlo_buffer(h, "rgb8", &nb);
+      fwrite(p, 1, nb, o);
+      fclose(o);
+    }
+    jxlo_free(h);
+  }
+  return 0;
+}
+#endif

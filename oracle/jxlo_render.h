@@ -1,0 +1,167 @@
+// ORACLE (test infrastructure): post-IDCT stages — Gaborish, edge-preserving filter (EPF0/1/2),
+// XYB -> linear RGB, sRGB transfer function, float -> uint8 with blue-noise dither.
+// Follows: reference lib/jxl/render_pipeline/stage_gaborish.cc:33-100, stage_epf.cc:47-494, lib/jxl/epf.h:19-22,
+// stage_xyb.cc:80-92 + lib/jxl/dec_xyb-inl.h:38-86 + lib/jxl/dec_xyb.cc:144-250 + lib/jxl/opsin_params.cc:35-45,
+// stage_from_linear.cc:42-54 + lib/jxl/cms/transfer_functions-inl.h:245-268, stage_write.cc:266-286,548-590.
+// Image edges: every stage reads its input mirrored about the frame size (lib/jxl/image_ops.h:184-196,
+// render_pipeline/low_memory_render_pipeline.cc:475-517); see DESIGN.md for why this equals the reference's
+// row-streaming behaviour for these (reflection-symmetric) kernels.
+#ifndef JXLO_RENDER_H_
+#define JXLO_RENDER_H_
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "jxlo_headers.h"
+
+namespace jxlo {
+
+#include "dither.inc"
+
+static inline int64_t Mirror(int64_t x, int64_t n) {
+  while (x < 0 || x >= n) {
+    if (x < 0) x = -x - 1;
+    else x = 2 * n - 1 - x;
+  }
+  return x;
+}
+
+// A planar 3-channel float image with row stride `stride`; only [0,xs) x [0,ys) is meaningful.
+struct Planes3 {
+  size_t xs = 0, ys = 0, stride = 0;
+  std::vector<float> p[3];
+  void Alloc(size_t x, size_t y, size_t st) {
+    xs = x; ys = y; stride = st;
+    for (auto& v : p) v.assign(st * y, 0.0f);
+  }
+  float At(int c, int64_t x, int64_t y) const { return p[c][size_t(Mirror(y, ys)) * stride + size_t(Mirror(x, xs))]; }
+};
+
+static inline void Gaborish(const Planes3& in, const LoopFilter& lf, Planes3* out) {
+  out->Alloc(in.xs, in.ys, in.stride);
+  for (int c = 0; c < 3; c++) {
+    float w0 = 1.0f, w1 = lf.gab_w[c][0], w2 = lf.gab_w[c][1];
+    const float mul = 1.0f / (w0 + 4 * (w1 + w2));
+    w0 *= mul; w1 *= mul; w2 *= mul;
+    for (int64_t y = 0; y < int64_t(in.ys); y++)
+      for (int64_t x = 0; x < int64_t(in.xs); x++) {
+        float m = in.At(c, x, y);
+        float s1 = (in.At(c, x - 1, y) + in.At(c, x + 1, y)) + (in.At(c, x, y - 1) + in.At(c, x, y + 1));
+        float s2 = (in.At(c, x - 1, y - 1) + in.At(c, x + 1, y - 1)) + (in.At(c, x - 1, y + 1) + in.At(c, x + 1, y + 1));
+        out->p[c][size_t(y) * in.stride + size_t(x)] = s2 * w2 + (s1 * w1 + m * w0);
+      }
+  }
+}
+
+static const float kMinSigma = -3.90524291751269967465540850526868f;
+static const float kInvSigmaNum = -1.1715728752538099024f;
+
+// One EPF pass. stage: 0, 1 or 2. inv_sigma: per 8x8 block (xblocks wide), holds 1/sigma (negative).
+static inline void EpfPass(int stage, const Planes3& in, const LoopFilter& lf, const std::vector<float>& inv_sigma,
+                           size_t xblocks, Planes3* out) {
+  out->Alloc(in.xs, in.ys, in.stride);
+  const float pass_scale = stage == 0 ? lf.epf_pass0_sigma_scale : stage == 2 ? lf.epf_pass2_sigma_scale : 1.0f;
+  const float sm = stage == 1 ? 1.65f : float(pass_scale * 1.65);
+  const float bsm = sm * lf.epf_border_sad_mul;
+  static const int kOff0[12][2] = {{-2, 0}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1},
+                                   {0, 1},  {0, 2},   {1, -1}, {1, 0},  {1, 1},  {2, 0}};  // {dy, dx}
+  static const int kOff1[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+  static const int kPlus[5][2] = {{0, 0}, {-1, 0}, {0, -1}, {1, 0}, {0, 1}};
+  const int noff = stage == 0 ? 12 : 4;
+  const int(*offs)[2] = stage == 0 ? kOff0 : kOff1;
+  for (int64_t y = 0; y < int64_t(in.ys); y++)
+    for (int64_t x = 0; x < int64_t(in.xs); x++) {
+      const size_t o = size_t(y) * in.stride + size_t(x);
+      const float is = inv_sigma[size_t(y / 8) * xblocks + size_t(x / 8)];
+      if (is < kMinSigma) {
+        for (int c = 0; c < 3; c++) out->p[c][o] = in.p[c][o];
+        continue;
+      }
+      const bool border = (x % 8 == 0) || (x % 8 == 7) || (y % 8 == 0) || (y % 8 == 7);
+      const float inv_sig = is * (border ? bsm : sm);
+      float w = 1.0f;
+      float acc[3] = {in.p[0][o], in.p[1][o], in.p[2][o]};
+      for (int i = 0; i < noff; i++) {
+        const int dy = offs[i][0], dx = offs[i][1];
+        float sad = 0.0f;
+        if (stage == 2) {
+          sad = std::fabs(in.At(0, x + dx, y + dy) - in.p[0][o]) * lf.epf_channel_scale[0];
+          sad = std::fabs(in.At(1, x + dx, y + dy) - in.p[1][o]) * lf.epf_channel_scale[1] + sad;
+          sad = std::fabs(in.At(2, x + dx, y + dy) - in.p[2][o]) * lf.epf_channel_scale[2] + sad;
+        } else {
+          for (int c = 0; c < 3; c++) {
+            float s = 0.0f;
+            for (int k = 0; k < 5; k++) {
+              const int py = kPlus[k][0], px = kPlus[k][1];
+              s += std::fabs(in.At(c, x + px, y + py) - in.At(c, x + dx + px, y + dy + py));
+            }
+            sad = s * lf.epf_channel_scale[c] + sad;
+          }
+        }
+        float weight = sad * inv_sig + 1.0f;
+        if (weight < 0.0f) weight = 0.0f;
+        w += weight;
+        for (int c = 0; c < 3; c++) acc[c] = weight * in.At(c, x + dx, y + dy) + acc[c];
+      }
+      const float inv_w = 1.0f / w;
+      for (int c = 0; c < 3; c++) out->p[c][o] = acc[c] * inv_w;
+    }
+}
+
+struct OpsinParams {
+  float inv[9];
+  float bias[3], bias_cbrt[3];
+};
+static inline OpsinParams MakeOpsinParams(const ImageHeader& h) {
+  OpsinParams o;
+  for (int i = 0; i < 9; i++) o.inv[i] = h.inv_opsin[i] * (255.0f / h.intensity_target);
+  for (int i = 0; i < 3; i++) {
+    o.bias[i] = h.opsin_bias[i];
+    o.bias_cbrt[i] = cbrtf(h.opsin_bias[i]);
+  }
+  return o;
+}
+static inline void XybToRgb(const OpsinParams& op, float X, float Y, float B, float* r, float* g, float* b) {
+  float gr = (Y + X) - op.bias_cbrt[0];
+  float gg = (Y - X) - op.bias_cbrt[1];
+  float gb = B - op.bias_cbrt[2];
+  float mr = (gr * gr) * gr + op.bias[0];
+  float mg = (gg * gg) * gg + op.bias[1];
+  float mb = (gb * gb) * gb + op.bias[2];
+  *r = op.inv[2] * mb + (op.inv[1] * mg + op.inv[0] * mr);
+  *g = op.inv[5] * mb + (op.inv[4] * mg + op.inv[3] * mr);
+  *b = op.inv[8] * mb + (op.inv[7] * mg + op.inv[6] * mr);
+}
+
+static inline float LinearToSrgb(float v) {
+  float a = std::fabs(v);
+  float r;
+  if (a > 0.0031308f) {
+    float s = std::sqrt(a);
+    float yp = 7.352629620e-01f * s + 1.474205315e+00f;
+    yp = yp * s + 3.903842876e-01f;
+    yp = yp * s + 5.287254571e-03f;
+    yp = yp * s + -5.135152395e-04f;
+    float yq = 2.424867759e-02f * s + 9.258482155e-01f;
+    yq = yq * s + 1.340816930e+00f;
+    yq = yq * s + 3.036675394e-01f;
+    yq = yq * s + 1.004519624e-02f;
+    r = yp / yq;
+  } else {
+    r = a * 12.92f;
+  }
+  return std::copysign(r, v);
+}
+
+// Float sample (nominal range [0,1]) -> uint8 with dither; c = interleaved channel index.
+static inline uint8_t ToU8(float v, size_t x, size_t y, size_t c) {
+  v = v * 255.0f;
+  v += kDither32[(y + c * 13) % 32][(x + c * 23) % 32];
+  if (!(v >= 0.0f)) v = 0.0f;  // also maps NaN to 0 like Clamp(Zero, v, mul)
+  if (v > 255.0f) v = 255.0f;
+  return uint8_t(std::nearbyint(v));
+}
+
+}  // namespace jxlo
+#endif  // JXLO_RENDER_H_
