@@ -1,0 +1,1209 @@
+// libjxl_amd synthetic-stream encoder: produces valid JPEG XL VarDCT codestreams for tests and benchmarks.
+//
+// There are no .jxl fixtures in the reference tree and the reference encoder cannot be built in this image, so the
+// decode path is exercised with streams written here. Two modes:
+//   * image mode  : RGB8 -> XYB -> AC-strategy choice (DCT family 8..64) -> quantisation at a butteraugli-style
+//                   distance (same initial parameters as the reference: kAcQuant/kDcQuant, enc_adaptive_quantization.cc
+//                   :835-837,1250-1262; quantizer.cc:45-76) -> rANS-coded sections.
+//   * random mode : random varblock tilings over all 27 strategies with random quantised coefficients, DC, quant
+//                   field, colour-correlation map and sharpness (exercises every decoder branch; not a real image).
+// The bitstream layout written here mirrors what the decoder reads: reference lib/jxl/headers.cc:129-152,
+// image_metadata.cc:283-356, frame_header.cc:215-439, loop_filter.cc:20-100, toc.cc:29-73, dec_frame.cc:269-434,
+// dec_modular.cc:427-562, dec_group.cc:469-639, dec_ans.cc:58-376, dec_context_map.cc:48-95, dec_ma.cc:107-159.
+// This is a growth seed for the "VarDCT encoder forward path" row of SURVEY.md §8f, not a quality-tuned encoder.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <queue>
+#include <vector>
+
+#include "../host/jxh_bits.h"
+#include "../host/jxh_entropy.h"
+#include "../host/jxh_vardct.h"
+
+namespace jxe {
+using jxh::BitWriter;
+using jxh::CeilLog2;
+using jxh::DivCeil;
+using jxh::FloorLog2;
+
+struct Rng {  // xorshift128+
+  uint64_t s[2];
+  explicit Rng(uint64_t seed) {
+    s[0] = seed * 0x9E3779B97F4A7C15ull + 1;
+    s[1] = (seed ^ 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull + 7;
+    for (int i = 0; i < 8; i++) Next();
+  }
+  uint64_t Next() {
+    uint64_t a = s[0], b = s[1];
+    s[0] = b;
+    a ^= a << 23;
+    s[1] = a ^ b ^ (a >> 17) ^ (b >> 26);
+    return s[1] + b;
+  }
+  uint32_t Below(uint32_t n) { return uint32_t((Next() >> 11) % n); }
+  float Uniform() { return float((Next() >> 40) * (1.0 / 16777216.0)); }
+};
+
+struct Token {
+  uint32_t ctx;
+  uint32_t value;
+};
+
+static inline uint32_t PackSigned(int32_t v) { return v >= 0 ? uint32_t(v) * 2 : uint32_t(-(v + 1)) * 2 + 1; }
+
+static inline void HybridEncode(const jxh::HybridCfg& c, uint32_t value, uint32_t* token, uint32_t* nbits, uint32_t* bits) {
+  if (value < c.split_token) {
+    *token = value;
+    *nbits = 0;
+    *bits = 0;
+    return;
+  }
+  uint32_t n = uint32_t(FloorLog2(value));
+  uint32_t m = value - (1u << n);
+  *token = c.split_token + ((n - c.split_exp) << (c.msb + c.lsb)) + ((m >> (n - c.msb)) << c.lsb) + (m & ((1u << c.lsb) - 1));
+  *nbits = n - c.msb - c.lsb;
+  *bits = (value >> c.lsb) & ((1u << *nbits) - 1);
+}
+
+static void WriteVarLenU8(BitWriter& bw, uint32_t n) {
+  if (n == 0) {
+    bw.Write(1, 0);
+    return;
+  }
+  bw.Write(1, 1);
+  uint32_t nb = uint32_t(FloorLog2(n));
+  bw.Write(3, nb);
+  bw.Write(nb, n - (1u << nb));
+}
+
+// Writes a histogram that sums to 4096 (dec_ans.cc:58-191 reads it back).
+static void WriteHistogram(BitWriter& bw, const std::vector<int32_t>& counts) {
+  std::vector<int> nz;
+  for (size_t i = 0; i < counts.size(); i++)
+    if (counts[i]) nz.push_back(int(i));
+  if (nz.size() <= 2) {
+    bw.Write(1, 1);
+    bw.Write(1, nz.size() == 2 ? 1 : 0);
+    if (nz.empty()) {
+      WriteVarLenU8(bw, 0);
+      return;
+    }
+    for (int s : nz) WriteVarLenU8(bw, s);
+    if (nz.size() == 2) bw.Write(12, counts[nz[0]]);
+    return;
+  }
+  bw.Write(1, 0);  // not simple
+  bw.Write(1, 0);  // not flat
+  bw.Write(3, 7);  // shift code: three 1s ...
+  bw.Write(3, 6);  // ... then (shift+1) - 8 = 6  => shift = 13 (exact counts)
+  size_t length = std::max<size_t>(3, size_t(nz.back()) + 1);
+  WriteVarLenU8(bw, uint32_t(length - 3));
+  static const uint8_t kLC[14][3] = {{0, 3, 10}, {1, 7, 12}, {2, 3, 7},  {3, 4, 3},  {4, 3, 6},   {5, 3, 8},  {6, 3, 9},
+                                     {7, 4, 5},  {9, 4, 4},  {11, 4, 1}, {15, 4, 2}, {17, 5, 0},  {33, 6, 11}, {65, 7, 13}};
+  std::vector<int> logc(length, -1);
+  int omit_log = -1, omit_pos = -1;
+  for (size_t i = 0; i < length; i++) {
+    int32_t c = i < counts.size() ? counts[i] : 0;
+    int val = c == 0 ? 0 : FloorLog2(uint32_t(c)) + 1;
+    logc[i] = val - 1;
+    for (int k = 0; k < 14; k++)
+      if (kLC[k][2] == val) bw.Write(kLC[k][1], kLC[k][0]);
+    if (logc[i] > omit_log) {
+      omit_log = logc[i];
+      omit_pos = int(i);
+    }
+  }
+  for (size_t i = 0; i < length; i++) {
+    if (int(i) == omit_pos || logc[i] <= 0) continue;
+    bw.Write(unsigned(logc[i]), uint32_t(counts[i]) - (1u << logc[i]));
+  }
+}
+
+static void WriteHybridCfg(BitWriter& bw, const jxh::HybridCfg& c, int log_alpha) {
+  bw.Write(CeilLog2(log_alpha + 1), c.split_exp);
+  if (int(c.split_exp) != log_alpha) {
+    bw.Write(CeilLog2(c.split_exp + 1), c.msb);
+    bw.Write(CeilLog2(c.split_exp - c.msb + 1), c.lsb);
+  }
+}
+
+// Normalises counts to sum 4096 with every used symbol >= 1.
+static std::vector<int32_t> Normalize(const std::vector<uint32_t>& h) {
+  uint64_t total = 0;
+  for (uint32_t c : h) total += c;
+  std::vector<int32_t> n(h.size(), 0);
+  if (total == 0) {
+    n.assign(1, 4096);
+    return n;
+  }
+  int64_t sum = 0;
+  size_t big = 0;
+  for (size_t i = 0; i < h.size(); i++) {
+    if (!h[i]) continue;
+    int64_t v = int64_t(double(h[i]) * 4096.0 / double(total) + 0.5);
+    if (v < 1) v = 1;
+    n[i] = int32_t(v);
+    sum += v;
+    if (h[i] > h[big] || !h[big]) big = i;
+  }
+  int64_t diff = 4096 - sum;
+  while (diff != 0) {
+    // adjust the largest entries, keeping everything >= 1
+    size_t best = big;
+    for (size_t i = 0; i < n.size(); i++)
+      if (n[i] > n[best]) best = i;
+    int64_t step = diff > 0 ? diff : std::max<int64_t>(diff, -(int64_t(n[best]) - 1));
+    if (step == 0) break;
+    n[best] += int32_t(step);
+    diff -= step;
+  }
+  while (!n.empty() && n.back() == 0) n.pop_back();
+  return n;
+}
+
+struct EncCode {
+  size_t num_ctx = 0;
+  std::vector<uint8_t> ctx_map;
+  size_t num_clusters = 1;
+  jxh::HybridCfg cfg;
+  int log_alpha = 5;
+  std::vector<std::vector<int32_t>> norm;          // [cluster][symbol]
+  std::vector<std::vector<uint32_t>> rev_start;    // [cluster][symbol] -> start in rev
+  std::vector<std::vector<uint16_t>> rev;          // [cluster] slot of (symbol, offset)
+};
+
+static void BuildReverseMaps(EncCode* code) {
+  code->rev.assign(code->num_clusters, {});
+  code->rev_start.assign(code->num_clusters, {});
+  std::vector<jxh::AliasEntry> alias(size_t(1) << code->log_alpha);
+  const int log_entry = 12 - code->log_alpha;
+  for (size_t c = 0; c < code->num_clusters; c++) {
+    jxh::InitAliasTable(code->norm[c], code->log_alpha, alias.data());
+    std::vector<int32_t> dist = code->norm[c];
+    if (dist.empty()) dist.push_back(4096);
+    std::vector<uint32_t>& start = code->rev_start[c];
+    start.assign(dist.size() + 1, 0);
+    for (size_t s = 0; s < dist.size(); s++) start[s + 1] = start[s] + uint32_t(dist[s]);
+    code->rev[c].assign(4096, 0);
+    for (uint32_t slot = 0; slot < 4096; slot++) {
+      const jxh::AliasEntry& e = alias[slot >> log_entry];
+      uint32_t pos = slot & ((1u << log_entry) - 1);
+      uint32_t sym, off;
+      if (pos >= e.cutoff) {
+        sym = e.right_value;
+        off = e.offsets1 + pos;
+      } else {
+        sym = slot >> log_entry;
+        off = pos;
+      }
+      code->rev[c][start[sym] + off] = uint16_t(slot);
+    }
+  }
+}
+
+// Builds clustered, normalised histograms for a token set over `num_ctx` contexts.
+static void BuildCode(const std::vector<const std::vector<Token>*>& streams, size_t num_ctx, size_t max_clusters,
+                      jxh::HybridCfg cfg, EncCode* code) {
+  code->num_ctx = num_ctx;
+  code->cfg = cfg;
+  uint32_t max_tok = 0;
+  std::vector<std::vector<uint32_t>> hist(num_ctx);
+  for (const auto* st : streams)
+    for (const Token& t : *st) {
+      uint32_t tok, nb, bits;
+      HybridEncode(cfg, t.value, &tok, &nb, &bits);
+      max_tok = std::max(max_tok, tok);
+      auto& h = hist[t.ctx];
+      if (h.size() <= tok) h.resize(tok + 1, 0);
+      h[tok]++;
+    }
+  code->log_alpha = std::max(5, CeilLog2(max_tok + 1));
+  if (code->log_alpha > 8) abort();
+  const size_t A = max_tok + 1;
+  // greedy clustering, largest contexts first
+  std::vector<size_t> order;
+  std::vector<uint64_t> total(num_ctx, 0);
+  for (size_t c = 0; c < num_ctx; c++) {
+    for (uint32_t v : hist[c]) total[c] += v;
+    if (total[c]) order.push_back(c);
+  }
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return total[a] != total[b] ? total[a] > total[b] : a < b; });
+  std::vector<std::vector<double>> csum;  // cluster histograms
+  std::vector<double> ctot;
+  code->ctx_map.assign(num_ctx, 0);
+  auto cost_in = [&](const std::vector<uint32_t>& h, const std::vector<double>& cs, double ct) {
+    double bits = 0;
+    for (size_t s = 0; s < h.size(); s++)
+      if (h[s]) bits -= h[s] * std::log2((cs[s] + 0.5) / (ct + 0.5 * A));
+    return bits;
+  };
+  for (size_t c : order) {
+    std::vector<double> self(A, 0.0);
+    for (size_t s = 0; s < hist[c].size(); s++) self[s] = hist[c][s];
+    double self_cost = cost_in(hist[c], self, double(total[c]));
+    int best = -1;
+    double best_cost = 1e300;
+    for (size_t k = 0; k < csum.size(); k++) {
+      double cst = cost_in(hist[c], csum[k], ctot[k]);
+      if (cst < best_cost) {
+        best_cost = cst;
+        best = int(k);
+      }
+    }
+    bool merge = best >= 0 && (csum.size() >= max_clusters || best_cost < self_cost * 1.08 + 64.0);
+    if (!merge) {
+      csum.push_back(self);
+      ctot.push_back(double(total[c]));
+      code->ctx_map[c] = uint8_t(csum.size() - 1);
+    } else {
+      for (size_t s = 0; s < hist[c].size(); s++) csum[best][s] += hist[c][s];
+      ctot[best] += double(total[c]);
+      code->ctx_map[c] = uint8_t(best);
+    }
+  }
+  if (csum.empty()) {
+    csum.push_back(std::vector<double>(A, 0.0));
+    ctot.push_back(0);
+  }
+  code->num_clusters = csum.size();
+  code->norm.resize(code->num_clusters);
+  for (size_t k = 0; k < code->num_clusters; k++) {
+    std::vector<uint32_t> h(A);
+    for (size_t s = 0; s < A; s++) h[s] = uint32_t(csum[k][s]);
+    code->norm[k] = Normalize(h);
+  }
+  BuildReverseMaps(code);
+}
+
+// rANS-encodes tokens (all contexts via code->ctx_map); writes the 32-bit initial state first.
+static void WriteTokens(BitWriter& bw, const Token* tk, size_t n, const EncCode& code) {
+  struct Out { uint32_t tok, nbits, bits; uint16_t chunk; bool has_chunk; uint8_t cluster; };
+  std::vector<Out> o(n);
+  for (size_t i = 0; i < n; i++) {
+    HybridEncode(code.cfg, tk[i].value, &o[i].tok, &o[i].nbits, &o[i].bits);
+    o[i].cluster = code.ctx_map[tk[i].ctx];
+    o[i].has_chunk = false;
+  }
+  uint32_t state = jxh::kAnsSignature << 16;
+  for (size_t i = n; i-- > 0;) {
+    const auto& norm = code.norm[o[i].cluster];
+    uint32_t freq = o[i].tok < norm.size() ? uint32_t(norm[o[i].tok]) : 0;
+    if (freq == 0) abort();  // token without probability mass: internal error
+    if ((state >> (32 - 12)) >= freq) {
+      o[i].chunk = uint16_t(state & 0xFFFF);
+      o[i].has_chunk = true;
+      state >>= 16;
+    }
+    uint32_t slot = code.rev[o[i].cluster][code.rev_start[o[i].cluster][o[i].tok] + state % freq];
+    state = ((state / freq) << 12) + slot;
+  }
+  bw.Write(32, state);
+  for (size_t i = 0; i < n; i++) {
+    if (o[i].has_chunk) bw.Write(16, o[i].chunk);
+    bw.Write(o[i].nbits, o[i].bits);
+  }
+}
+
+static void WriteCodeHeader(BitWriter& bw, const EncCode& code);
+
+static void WriteContextMap(BitWriter& bw, const EncCode& code) {
+  if (code.num_clusters <= 8) {
+    int bits = CeilLog2(code.num_clusters);
+    bw.Write(1, 1);
+    bw.Write(2, bits);
+    if (bits)
+      for (uint8_t e : code.ctx_map) bw.Write(bits, e);
+    return;
+  }
+  bw.Write(1, 0);  // not simple
+  bw.Write(1, 0);  // no MTF
+  std::vector<Token> t(code.ctx_map.size());
+  for (size_t i = 0; i < t.size(); i++) t[i] = {0, code.ctx_map[i]};
+  EncCode inner;
+  jxh::HybridCfg cfg;
+  cfg.split_exp = 4; cfg.split_token = 16; cfg.msb = 2; cfg.lsb = 0;
+  BuildCode({&t}, 1, 1, cfg, &inner);
+  WriteCodeHeader(bw, inner);
+  WriteTokens(bw, t.data(), t.size(), inner);
+}
+
+// Everything DecodeHistograms() reads (dec_ans.cc:341-376).
+static void WriteCodeHeader(BitWriter& bw, const EncCode& code) {
+  bw.Write(1, 0);  // lz77 disabled
+  if (code.num_ctx > 1) WriteContextMap(bw, code);
+  bw.Write(1, 0);  // ANS, not prefix codes
+  bw.Write(2, code.log_alpha - 5);
+  for (size_t k = 0; k < code.num_clusters; k++) WriteHybridCfg(bw, code.cfg, code.log_alpha);
+  for (size_t k = 0; k < code.num_clusters; k++) WriteHistogram(bw, code.norm[k]);
+}
+
+static void WriteU32Sel(BitWriter& bw, uint32_t v, const uint32_t bits[4], const uint32_t offs[4]) {
+  for (int s = 0; s < 4; s++) {
+    if (bits[s] == 0) {
+      if (v == offs[s]) {
+        bw.Write(2, s);
+        return;
+      }
+    } else if (v >= offs[s] && uint64_t(v - offs[s]) < (uint64_t(1) << bits[s])) {
+      bw.Write(2, s);
+      bw.Write(bits[s], v - offs[s]);
+      return;
+    }
+  }
+  abort();
+}
+
+// ---------------------------------------------------------------- Modular (DC + AC metadata) tokeniser
+struct TreeSpec {
+  struct Node { int prop; int32_t split; int l, r; uint32_t predictor; };
+  std::vector<Node> nodes;  // BFS order
+  std::vector<int> leaf_ctx;
+};
+
+// Fixed tree: splits on stream kind (property 1) and channel (property 0); see header comment.
+static TreeSpec MakeTree(size_t ndc) {
+  TreeSpec t;
+  // explicit BFS layout
+  // 0: p1 > 2*ndc ? 1 : 2
+  // 1 (AC meta): p0 > 1 ? 3 : 4(leaf cmap)
+  // 2 (DC): p0 > 0 ? 5 : 6(leaf Y)
+  // 3: p0 > 2 ? 7(leaf sharpness) : 8(leaf acs/qf)
+  // 5: p0 > 1 ? 9(leaf B) : 10(leaf X)
+  t.nodes = {{1, int32_t(2 * ndc), 1, 2, 0}, {0, 1, 3, 4, 0}, {0, 0, 5, 6, 0}, {0, 2, 7, 8, 0}, {-1, 0, 0, 0, 5},
+             {0, 1, 9, 10, 0},              {-1, 0, 0, 0, 5}, {-1, 0, 0, 0, 5}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 5},
+             {-1, 0, 0, 0, 5}};
+  t.leaf_ctx.assign(t.nodes.size(), -1);
+  int leaf = 0;
+  for (size_t i = 0; i < t.nodes.size(); i++)
+    if (t.nodes[i].prop < 0) t.leaf_ctx[i] = leaf++;
+  return t;
+}
+static void TreeLookup(const TreeSpec& t, int chan, int stream, int* ctx, uint32_t* predictor) {
+  int pos = 0;
+  while (t.nodes[pos].prop >= 0) {
+    int v = t.nodes[pos].prop == 0 ? chan : stream;
+    pos = v > t.nodes[pos].split ? t.nodes[pos].l : t.nodes[pos].r;
+  }
+  *ctx = t.leaf_ctx[pos];
+  *predictor = t.nodes[pos].predictor;
+}
+static void TreeTokens(const TreeSpec& t, std::vector<Token>* out) {
+  for (const auto& n : t.nodes) {
+    if (n.prop < 0) {
+      out->push_back({1, 0});            // property+1 = 0 => leaf
+      out->push_back({2, n.predictor});  // predictor
+      out->push_back({3, 0});            // offset
+      out->push_back({4, 0});            // multiplier log
+      out->push_back({5, 0});            // multiplier bits
+    } else {
+      out->push_back({1, uint32_t(n.prop + 1)});
+      out->push_back({0, PackSigned(n.split)});
+    }
+  }
+}
+
+static inline int32_t ClampedGradient(int32_t n, int32_t w, int32_t l) {
+  int32_t m = std::min(n, w), M = std::max(n, w);
+  int32_t grad = n + w - l;
+  return l > M ? m : (l < m ? M : grad);
+}
+
+static void ModularTokens(const TreeSpec& tree, const int32_t* px, size_t w, size_t h, int chan, int stream,
+                          std::vector<Token>* out) {
+  int ctx;
+  uint32_t predictor;
+  TreeLookup(tree, chan, stream, &ctx, &predictor);
+  for (size_t y = 0; y < h; y++)
+    for (size_t x = 0; x < w; x++) {
+      const int32_t* p = px + y * w + x;
+      int32_t left = x ? p[-1] : (y ? p[-ptrdiff_t(w)] : 0);
+      int32_t top = y ? p[-ptrdiff_t(w)] : left;
+      int32_t topleft = (x && y) ? p[-1 - ptrdiff_t(w)] : left;
+      int32_t pred = predictor == 5 ? ClampedGradient(left, top, topleft) : 0;
+      out->push_back({uint32_t(ctx), PackSigned(*p - pred)});
+    }
+}
+
+// ---------------------------------------------------------------- colour + transforms
+static inline float SrgbToLinear(float v) {
+  return v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
+}
+static void RgbToXyb(const uint8_t* rgb, size_t xs, size_t ys, size_t xp, size_t yp, std::vector<float> planes[3]) {
+  static const float kM[9] = {0.30f, 1.0f - 0.078f - 0.30f, 0.078f, 0.23f, 1.0f - 0.078f - 0.23f, 0.078f,
+                              0.24342268924547819f, 0.20476744424496821f, 1.0f - 0.24342268924547819f - 0.20476744424496821f};
+  const float bias = 0.0037930732552754493f, cb = std::cbrt(bias);
+  float lut[256];
+  for (int i = 0; i < 256; i++) lut[i] = SrgbToLinear(i / 255.0f);
+  for (int c = 0; c < 3; c++) planes[c].assign(xp * yp, 0.0f);
+  for (size_t y = 0; y < yp; y++) {
+    size_t sy = std::min(y, ys - 1);
+    for (size_t x = 0; x < xp; x++) {
+      size_t sx = std::min(x, xs - 1);
+      const uint8_t* p = rgb + (sy * xs + sx) * 3;
+      float r = lut[p[0]], g = lut[p[1]], b = lut[p[2]];
+      float mr = kM[0] * r + kM[1] * g + kM[2] * b + bias;
+      float mg = kM[3] * r + kM[4] * g + kM[5] * b + bias;
+      float mb = kM[6] * r + kM[7] * g + kM[8] * b + bias;
+      float gr = std::cbrt(mr) - cb, gg = std::cbrt(mg) - cb, gb = std::cbrt(mb) - cb;
+      planes[0][y * xp + x] = 0.5f * (gr - gg);
+      planes[1][y * xp + x] = 0.5f * (gr + gg);
+      planes[2][y * xp + x] = gb;
+    }
+  }
+}
+
+struct Basis {
+  std::vector<float> m[9];
+  Basis() {
+    for (int l = 0; l <= 8; l++) {
+      int N = 1 << l;
+      m[l].resize(size_t(N) * N);
+      for (int n = 0; n < N; n++)
+        for (int k = 0; k < N; k++) m[l][size_t(n) * N + k] = float((k ? std::sqrt(2.0) : 1.0) * std::cos((n + 0.5) * k * M_PI / N));
+    }
+  }
+};
+static const Basis& GetBasis() {
+  static const Basis b;
+  return b;
+}
+// Forward scaled DCT of an R x C block into the codestream coefficient layout (rows = short side).
+static void ForwardDct(const float* in, size_t stride, int R, int C, float* coef, std::vector<float>& tmp) {
+  const float* br = GetBasis().m[FloorLog2(R)].data();
+  const float* bc = GetBasis().m[FloorLog2(C)].data();
+  tmp.resize(size_t(R) * C);
+  for (int y = 0; y < R; y++)
+    for (int kx = 0; kx < C; kx++) {
+      float s = 0;
+      for (int x = 0; x < C; x++) s += in[y * stride + x] * bc[size_t(x) * C + kx];
+      tmp[size_t(y) * C + kx] = s;
+    }
+  const float norm = 1.0f / (float(R) * float(C));
+  for (int ky = 0; ky < R; ky++)
+    for (int kx = 0; kx < C; kx++) {
+      float s = 0;
+      for (int y = 0; y < R; y++) s += tmp[size_t(y) * C + kx] * br[size_t(y) * R + ky];
+      s *= norm;
+      if (R < C) coef[ky * C + kx] = s;
+      else coef[kx * R + ky] = s;
+    }
+}
+static inline float ResampleScale(int n, int i) {
+  double N = 8.0 * n;
+  return float(1.0 / (std::cos(i / (2 * N) * M_PI) * std::cos(i / N * M_PI) * std::cos(i / (N / 2) * M_PI)));
+}
+
+// ---------------------------------------------------------------- frame model shared by both modes
+struct FrameModel {
+  size_t xs, ys, xb, yb;  // pixels, blocks
+  std::vector<uint8_t> acs;        // (strategy<<1)|first, 0xFF = unset
+  std::vector<int32_t> qf;         // 1..256 at first blocks
+  std::vector<uint8_t> sharp;      // per block
+  std::vector<int8_t> ytox, ytob;  // per 64x64 tile
+  std::vector<int32_t> dc[3];      // quantised DC ints per block, stored X, Y, B
+  // quantised AC, per group: [c][65536] block-contiguous
+  std::vector<std::vector<int32_t>> coeffs;
+  uint32_t global_scale, quant_dc;
+  int epf_iters, gab;
+  uint64_t flags;
+};
+
+struct Params {
+  float distance;
+  int32_t epf_iters;       // -1 = choose from distance like the reference (enc_frame.cc:317-341)
+  int32_t gab;             // -1 = on
+  int32_t strategy_mode;   // 0 = DCT8 only, 1 = heuristic mix (8..64), 2 = uniform random over `strategy_mask`
+  uint32_t strategy_mask;  // bit per strategy for mode 2 (0 = all 27)
+  uint32_t seed;
+  int32_t max_clusters;    // 0 = default (64)
+  int32_t skip_dc_smoothing;
+  int32_t random_cmap;     // random chroma-from-luma factors (always on in random mode)
+  int32_t reserved[6];
+};
+
+static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
+  size_t cx = jxh::kCoveredX[st], cy = jxh::kCoveredY[st];
+  if (bx + cx > f.xb || by + cy > f.yb) return false;
+  if ((bx % 32) + cx > 32 || (by % 32) + cy > 32) return false;
+  for (size_t y = 0; y < cy; y++)
+    for (size_t x = 0; x < cx; x++)
+      if (f.acs[(by + y) * f.xb + bx + x] != 0xFF) return false;
+  return true;
+}
+static void Place(FrameModel& f, size_t bx, size_t by, int st) {
+  size_t cx = jxh::kCoveredX[st], cy = jxh::kCoveredY[st];
+  for (size_t y = 0; y < cy; y++)
+    for (size_t x = 0; x < cx; x++) f.acs[(by + y) * f.xb + bx + x] = uint8_t((st << 1) | ((x | y) == 0));
+}
+
+// ---------------------------------------------------------------- bitstream assembly
+static void WriteSizeDim(BitWriter& bw, uint32_t v) {
+  static const uint32_t bits[4] = {9, 13, 18, 30}, offs[4] = {1, 1, 1, 1};
+  WriteU32Sel(bw, v, bits, offs);
+}
+
+static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>* out) {
+  const size_t xg = DivCeil(f.xs, 256), yg = DivCeil(f.ys, 256), num_groups = xg * yg;
+  const size_t xdg = DivCeil(f.xb, 256), ydg = DivCeil(f.yb, 256), ndc = xdg * ydg;
+  const TreeSpec tree = MakeTree(ndc);
+  // ---- tokenise modular streams
+  std::vector<Token> tree_tokens;
+  TreeTokens(tree, &tree_tokens);
+  std::vector<std::vector<Token>> dc_tokens(ndc), meta_tokens(ndc);
+  std::vector<size_t> meta_count(ndc);
+  for (size_t g = 0; g < ndc; g++) {
+    size_t bx0 = (g % xdg) * 256, by0 = (g / xdg) * 256;
+    size_t bw_ = std::min<size_t>(256, f.xb - bx0), bh = std::min<size_t>(256, f.yb - by0);
+    std::vector<int32_t> tmp(bw_ * bh);
+    static const int kDcChan[3] = {1, 0, 2};  // stream channel order Y, X, B
+    for (int ch = 0; ch < 3; ch++) {
+      for (size_t y = 0; y < bh; y++)
+        for (size_t x = 0; x < bw_; x++) tmp[y * bw_ + x] = f.dc[kDcChan[ch]][(by0 + y) * f.xb + bx0 + x];
+      ModularTokens(tree, tmp.data(), bw_, bh, ch, int(1 + g), &dc_tokens[g]);
+    }
+    // AC metadata
+    size_t cw = (bw_ + 7) / 8, chh = (bh + 7) / 8, tiles_x = DivCeil(f.xb, 8);
+    std::vector<int32_t> cm(cw * chh);
+    for (int which = 0; which < 2; which++) {
+      for (size_t y = 0; y < chh; y++)
+        for (size_t x = 0; x < cw; x++) cm[y * cw + x] = (which ? f.ytob : f.ytox)[(by0 / 8 + y) * tiles_x + bx0 / 8 + x];
+      ModularTokens(tree, cm.data(), cw, chh, which, int(1 + 2 * ndc + g), &meta_tokens[g]);
+    }
+    std::vector<int32_t> l0, l1;
+    for (size_t y = 0; y < bh; y++)
+      for (size_t x = 0; x < bw_; x++) {
+        uint8_t a = f.acs[(by0 + y) * f.xb + bx0 + x];
+        if (a & 1) {
+          l0.push_back(a >> 1);
+          l1.push_back(f.qf[(by0 + y) * f.xb + bx0 + x] - 1);
+        }
+      }
+    meta_count[g] = l0.size();
+    std::vector<int32_t> lst(l0);
+    lst.insert(lst.end(), l1.begin(), l1.end());
+    ModularTokens(tree, lst.data(), l0.size(), 2, 2, int(1 + 2 * ndc + g), &meta_tokens[g]);
+    std::vector<int32_t> sh(bw_ * bh);
+    for (size_t y = 0; y < bh; y++)
+      for (size_t x = 0; x < bw_; x++) sh[y * bw_ + x] = f.sharp[(by0 + y) * f.xb + bx0 + x];
+    ModularTokens(tree, sh.data(), bw_, bh, 3, int(1 + 2 * ndc + g), &meta_tokens[g]);
+  }
+  jxh::HybridCfg cfg420;
+  cfg420.split_exp = 4; cfg420.split_token = 16; cfg420.msb = 2; cfg420.lsb = 0;
+  EncCode tree_code, mod_code;
+  BuildCode({&tree_tokens}, 6, 6, cfg420, &tree_code);
+  {
+    std::vector<const std::vector<Token>*> all;
+    for (auto& t : dc_tokens) all.push_back(&t);
+    for (auto& t : meta_tokens) all.push_back(&t);
+    size_t nleaf = 0;
+    for (int c : tree.leaf_ctx) nleaf += c >= 0;
+    BuildCode(all, nleaf, 8, cfg420, &mod_code);
+  }
+  // ---- tokenise AC groups
+  jxh::BlockCtxMap bctx;
+  const size_t nctx = bctx.NumACContexts();
+  std::vector<std::vector<Token>> ac_tokens(num_groups);
+  std::vector<std::vector<uint32_t>> natural(13);
+  for (int s = 0; s < 27; s++)
+    if (natural[jxh::kStrategyOrder[s]].empty()) jxh::NaturalOrder(s, &natural[jxh::kStrategyOrder[s]]);
+#pragma omp parallel for schedule(dynamic)
+  for (size_t g = 0; g < num_groups; g++) {
+    const size_t bx0 = (g % xg) * 32, by0 = (g / xg) * 32;
+    const size_t gw = std::min<size_t>(32, f.xb - bx0), gh = std::min<size_t>(32, f.yb - by0);
+    std::vector<int32_t> nzmap(3 * 1024, 0);
+    std::vector<Token>& out_t = ac_tokens[g];
+    size_t offset = 0;
+    for (size_t by = 0; by < gh; by++)
+      for (size_t bx = 0; bx < gw; bx++) {
+        uint8_t a = f.acs[(by0 + by) * f.xb + bx0 + bx];
+        if (!(a & 1)) continue;
+        const int st = a >> 1;
+        const size_t cx = jxh::kCoveredX[st], cy = jxh::kCoveredY[st], log2c = jxh::kLog2Covered[st];
+        const size_t covered = size_t(1) << log2c, size = covered * 64;
+        const int ord = jxh::kStrategyOrder[st];
+        const uint32_t qf = uint32_t(f.qf[(by0 + by) * f.xb + bx0 + bx]);
+        static const int kOrder[3] = {1, 0, 2};
+        for (int ci = 0; ci < 3; ci++) {
+          const int c = kOrder[ci];
+          const int32_t* q = f.coeffs[g].data() + size_t(c) * 65536 + offset;
+          int32_t* nzc = nzmap.data() + c * 1024;
+          const int32_t* top = by ? nzc + (by - 1) * 32 : nullptr;
+          int32_t* cur = nzc + by * 32;
+          int32_t pred = bx == 0 ? (top ? top[0] : 32) : (!top ? cur[bx - 1] : (top[bx] + cur[bx - 1] + 1) / 2);
+          const uint32_t* order = natural[ord].data();
+          size_t nz = 0;
+          for (size_t k = covered; k < size; k++) nz += q[order[k]] != 0;
+          size_t bc = bctx.Context(0, qf, ord, c);
+          out_t.push_back({uint32_t(bctx.NonZeroContext(uint32_t(pred), bc)), uint32_t(nz)});
+          for (size_t y = 0; y < cy; y++)
+            for (size_t x = 0; x < cx; x++) cur[bx + x + y * 32] = int32_t((nz + covered - 1) >> log2c);
+          const size_t hoff = bctx.ZeroDensityOffset(bc);
+          size_t prev = nz > size / 16 ? 0 : 1, left = nz;
+          for (size_t k = covered; k < size && left != 0; k++) {
+            size_t ctx = hoff + jxh::ZeroDensityContext(left, k, covered, log2c, prev);
+            int32_t v = q[order[k]];
+            out_t.push_back({uint32_t(ctx), PackSigned(v)});
+            prev = v != 0;
+            left -= prev;
+          }
+        }
+        offset += size;
+      }
+  }
+  EncCode ac_code;
+  {
+    std::vector<const std::vector<Token>*> all;
+    for (auto& t : ac_tokens) all.push_back(&t);
+    BuildCode(all, nctx, p.max_clusters > 0 ? size_t(p.max_clusters) : 64, cfg420, &ac_code);
+  }
+  // ---- sections
+  auto write_dc_global = [&](BitWriter& bw) {
+    bw.Write(1, 1);  // DC dequant all_default
+    {
+      static const uint32_t bits[4] = {11, 11, 12, 16}, offs[4] = {1, 2049, 4097, 8193};
+      WriteU32Sel(bw, f.global_scale, bits, offs);
+    }
+    {
+      static const uint32_t bits[4] = {0, 5, 8, 16}, offs[4] = {16, 1, 1, 1};
+      WriteU32Sel(bw, f.quant_dc, bits, offs);
+    }
+    bw.Write(1, 1);  // default block context map
+    bw.Write(1, 1);  // default colour correlation
+    bw.Write(1, 1);  // has global tree
+    WriteCodeHeader(bw, tree_code);
+    WriteTokens(bw, tree_tokens.data(), tree_tokens.size(), tree_code);
+    WriteCodeHeader(bw, mod_code);
+  };
+  auto write_group_header = [&](BitWriter& bw) {
+    bw.Write(1, 1);  // use global tree
+    bw.Write(1, 1);  // default weighted-predictor header
+    bw.Write(2, 0);  // no transforms
+  };
+  auto write_dc_group = [&](BitWriter& bw, size_t g) {
+    bw.Write(2, 0);  // extra precision
+    write_group_header(bw);
+    WriteTokens(bw, dc_tokens[g].data(), dc_tokens[g].size(), mod_code);
+    size_t bx0 = (g % xdg) * 256, by0 = (g / xdg) * 256;
+    size_t bw_ = std::min<size_t>(256, f.xb - bx0), bh = std::min<size_t>(256, f.yb - by0);
+    bw.Write(CeilLog2(bw_ * bh), meta_count[g] - 1);
+    write_group_header(bw);
+    WriteTokens(bw, meta_tokens[g].data(), meta_tokens[g].size(), mod_code);
+  };
+  auto write_ac_global = [&](BitWriter& bw) {
+    bw.Write(1, 1);                            // default dequant tables
+    bw.Write(CeilLog2(num_groups), 0);         // one histogram set
+    bw.Write(2, 2);                            // used_orders = 0
+    WriteCodeHeader(bw, ac_code);
+  };
+  auto write_ac_group = [&](BitWriter& bw, size_t g) { WriteTokens(bw, ac_tokens[g].data(), ac_tokens[g].size(), ac_code); };
+
+  std::vector<std::vector<uint8_t>> sections;
+  if (num_groups == 1) {
+    BitWriter bw;
+    write_dc_global(bw);
+    write_dc_group(bw, 0);
+    write_ac_global(bw);
+    write_ac_group(bw, 0);
+    bw.ZeroPad();
+    sections.push_back(bw.bytes());
+  } else {
+    sections.resize(2 + ndc + num_groups);
+    {
+      BitWriter bw;
+      write_dc_global(bw);
+      bw.ZeroPad();
+      sections[0] = bw.bytes();
+    }
+    for (size_t g = 0; g < ndc; g++) {
+      BitWriter bw;
+      write_dc_group(bw, g);
+      bw.ZeroPad();
+      sections[1 + g] = bw.bytes();
+    }
+    {
+      BitWriter bw;
+      write_ac_global(bw);
+      bw.ZeroPad();
+      sections[1 + ndc] = bw.bytes();
+    }
+#pragma omp parallel for schedule(dynamic)
+    for (size_t g = 0; g < num_groups; g++) {
+      BitWriter bw;
+      write_ac_group(bw, g);
+      bw.ZeroPad();
+      sections[2 + ndc + g] = bw.bytes();
+    }
+  }
+  // ---- headers
+  BitWriter bw;
+  bw.Write(16, 0x0AFF);
+  bw.Write(1, 0);  // not "small"
+  WriteSizeDim(bw, uint32_t(f.ys));
+  bw.Write(3, 0);  // no aspect-ratio shortcut
+  WriteSizeDim(bw, uint32_t(f.xs));
+  bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
+  bw.Write(1, 1);  // CustomTransformData all_default
+  bw.ZeroPad();
+  // FrameHeader
+  bw.Write(1, 0);  // not all_default
+  bw.Write(2, 0);  // regular frame
+  bw.Write(1, 0);  // VarDCT
+  if (f.flags == 0) {
+    bw.Write(2, 0);
+  } else {  // U64 selector 2: 17 + 8 bits
+    bw.Write(2, 2);
+    bw.Write(8, f.flags - 17);
+  }
+  bw.Write(2, 0);  // upsampling 1
+  bw.Write(3, 3);  // x_qm_scale
+  bw.Write(3, 2);  // b_qm_scale
+  bw.Write(2, 0);  // one pass
+  bw.Write(1, 0);  // no custom size/origin
+  bw.Write(2, 0);  // blend mode: replace
+  bw.Write(1, 1);  // is_last
+  bw.Write(2, 0);  // no name
+  bw.Write(1, 0);  // loop filter not all_default
+  bw.Write(1, f.gab ? 1 : 0);
+  if (f.gab) bw.Write(1, 0);  // default gaborish weights
+  bw.Write(2, f.epf_iters);
+  if (f.epf_iters > 0) {
+    bw.Write(1, 0);  // default sharpness LUT
+    bw.Write(1, 0);  // default channel weights
+    bw.Write(1, 0);  // default sigma parameters
+  }
+  bw.Write(2, 0);  // no loop-filter extensions
+  bw.Write(2, 0);  // no frame-header extensions
+  // TOC
+  bw.Write(1, 0);  // not permuted
+  bw.ZeroPad();
+  for (const auto& s : sections) {
+    static const uint32_t bits[4] = {10, 14, 22, 30}, offs[4] = {0, 1024, 17408, 4211712};
+    WriteU32Sel(bw, uint32_t(s.size()), bits, offs);
+  }
+  bw.ZeroPad();
+  *out = bw.bytes();
+  for (const auto& s : sections) out->insert(out->end(), s.begin(), s.end());
+}
+
+// ---------------------------------------------------------------- image mode
+static void QuantParams(float distance, FrameModel* f, float* quant_ac) {
+  const float kAcQuant = 0.765f, kDcQuant = 1.095924047623553f, kDcMul = 0.3f, kDcQuantPow = 0.83f;
+  float target_dc = std::max(0.5f * distance, std::min(distance, kDcMul * std::pow((1.0f / kDcMul) * distance, kDcQuantPow)));
+  float qdc = std::min(kDcQuant / target_dc, 50.0f);
+  float qac = kAcQuant / distance;
+  float scale = 65536.0f * qac / 5.0f;
+  scale = std::max(1.0f, std::min(32768.0f, scale));
+  int gs = int(scale);
+  int scaled_qdc = int(qdc * 4096 * 1.6);
+  if (gs > scaled_qdc) gs = std::max(1, scaled_qdc);
+  f->global_scale = uint32_t(gs);
+  float inv_gs = 65536.0f / float(gs);
+  f->quant_dc = uint32_t(std::min<float>(65536.0f, qdc * inv_gs + 0.5f));
+  if (f->quant_dc < 1) f->quant_dc = 1;
+  *quant_ac = qac;
+}
+
+static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out) {
+  FrameModel f;
+  f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
+  const size_t xp = f.xb * 8, yp = f.yb * 8;
+  std::vector<float> xyb[3];
+  RgbToXyb(rgb, xs, ys, xp, yp, xyb);
+  float quant_ac;
+  QuantParams(p.distance, &f, &quant_ac);
+  f.gab = p.gab < 0 ? 1 : p.gab;
+  if (f.gab) {
+    // Approximate inverse of the decoder's Gaborish blur K (3x3, default weights): y <- y + (x - K*y), 4 rounds.
+    const float w1 = 1.1f * 0.104699568f, w2 = 1.1f * 0.055680538f, nrm = 1.0f / (1.0f + 4 * (w1 + w2));
+    for (int c = 0; c < 3; c++) {
+      std::vector<float> y = xyb[c], t(xp * yp);
+      for (int it = 0; it < 4; it++) {
+#pragma omp parallel for
+        for (size_t yy = 0; yy < yp; yy++) {
+          size_t y0 = yy ? yy - 1 : 0, y1 = yy + 1 < yp ? yy + 1 : yp - 1;
+          for (size_t xx = 0; xx < xp; xx++) {
+            size_t x0 = xx ? xx - 1 : 0, x1 = xx + 1 < xp ? xx + 1 : xp - 1;
+            float side = y[yy * xp + x0] + y[yy * xp + x1] + y[y0 * xp + xx] + y[y1 * xp + xx];
+            float corner = y[y0 * xp + x0] + y[y0 * xp + x1] + y[y1 * xp + x0] + y[y1 * xp + x1];
+            float blur = (y[yy * xp + xx] + w1 * side + w2 * corner) * nrm;
+            t[yy * xp + xx] = y[yy * xp + xx] + (xyb[c][yy * xp + xx] - blur);
+          }
+        }
+        y.swap(t);
+      }
+      xyb[c].swap(y);
+    }
+  }
+  f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
+  f.flags = p.skip_dc_smoothing ? 128 : 0;
+  f.acs.assign(f.xb * f.yb, 0xFF);
+  f.qf.assign(f.xb * f.yb, 0);
+  f.sharp.assign(f.xb * f.yb, 4);
+  f.ytox.assign(DivCeil(f.xb, 8) * DivCeil(f.yb, 8), 0);
+  f.ytob.assign(f.ytox.size(), 0);
+  Rng rng(p.seed + 12345);
+  if (p.random_cmap)
+    for (size_t i = 0; i < f.ytox.size(); i++) {
+      f.ytox[i] = int8_t(int(rng.Below(17)) - 8);
+      f.ytob[i] = int8_t(int(rng.Below(17)) - 8);
+    }
+  for (auto& d : f.dc) d.assign(f.xb * f.yb, 0);
+  // per-block activity of Y (mean abs deviation from the block mean)
+  std::vector<float> act(f.xb * f.yb);
+#pragma omp parallel for
+  for (size_t by = 0; by < f.yb; by++)
+    for (size_t bx = 0; bx < f.xb; bx++) {
+      const float* s = xyb[1].data() + by * 8 * xp + bx * 8;
+      float mean = 0;
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) mean += s[y * xp + x];
+      mean /= 64;
+      float a = 0;
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) a += std::fabs(s[y * xp + x] - mean);
+      act[by * f.xb + bx] = a / 64;
+    }
+  auto region_max = [&](size_t bx, size_t by, size_t w, size_t h) {
+    float m = 0;
+    for (size_t y = 0; y < h; y++)
+      for (size_t x = 0; x < w; x++) m = std::max(m, act[(by + y) * f.xb + bx + x]);
+    return m;
+  };
+  // strategy selection
+  const float T64 = 0.004f * p.distance, T32 = 0.008f * p.distance, T16 = 0.016f * p.distance, TR = 0.011f * p.distance;
+  uint32_t mask = p.strategy_mask ? p.strategy_mask : 0x7FFFFFFu;
+  for (size_t by = 0; by < f.yb; by++)
+    for (size_t bx = 0; bx < f.xb; bx++) {
+      if (f.acs[by * f.xb + bx] != 0xFF) continue;
+      int st = 0;
+      if (p.strategy_mode == 2) {
+        // uniformly random strategy among those allowed that fit; restricted to the DCT family in image mode
+        static const int kFam[18] = {0, 4, 5, 6, 7, 8, 9, 10, 11, 18, 19, 20, 21, 22, 23, 24, 25, 26};
+        for (int tries = 0; tries < 8; tries++) {
+          int cand = kFam[rng.Below(18)];
+          if (!(mask & (1u << cand))) continue;
+          size_t cx = jxh::kCoveredX[cand], cy = jxh::kCoveredY[cand];
+          if (bx % cx || by % cy) continue;
+          if (Fits(f, bx, by, cand)) {
+            st = cand;
+            break;
+          }
+        }
+      } else if (p.strategy_mode == 1) {
+        auto ok = [&](int cand, float thr) {
+          size_t cx = jxh::kCoveredX[cand], cy = jxh::kCoveredY[cand];
+          return bx % cx == 0 && by % cy == 0 && Fits(f, bx, by, cand) && region_max(bx, by, cx, cy) < thr;
+        };
+        if (ok(18, T64)) st = 18;
+        else if (ok(20, T64 * 1.3f)) st = 20;  // 32x64
+        else if (ok(19, T64 * 1.3f)) st = 19;  // 64x32
+        else if (ok(5, T32)) st = 5;
+        else if (ok(11, TR)) st = 11;  // 16x32
+        else if (ok(10, TR)) st = 10;  // 32x16
+        else if (ok(4, T16)) st = 4;
+        else if (ok(9, T16 * 0.8f)) st = 9;   // 8x32
+        else if (ok(8, T16 * 0.8f)) st = 8;   // 32x8
+        else if (ok(7, T16 * 1.5f)) st = 7;   // 8x16
+        else if (ok(6, T16 * 1.5f)) st = 6;   // 16x8
+      }
+      Place(f, bx, by, st);
+    }
+  // adaptive quant field
+  for (size_t by = 0; by < f.yb; by++)
+    for (size_t bx = 0; bx < f.xb; bx++) {
+      uint8_t a = f.acs[by * f.xb + bx];
+      if (!(a & 1)) continue;
+      int st = a >> 1;
+      float m = region_max(bx, by, jxh::kCoveredX[st], jxh::kCoveredY[st]);
+      float mul = 1.35f - 0.12f * std::log2(1.0f + m * 400.0f);
+      mul = std::max(0.8f, std::min(1.4f, mul));
+      float inv_gs = 65536.0f / float(f.global_scale);
+      int q = int(quant_ac * mul * inv_gs + 0.5f);
+      f.qf[by * f.xb + bx] = std::max(1, std::min(256, q));
+    }
+  // transform + quantise per group
+  const size_t xg = DivCeil(xs, 256), yg = DivCeil(ys, 256);
+  f.coeffs.assign(xg * yg, {});
+  jxh::DequantTables dq;
+  for (int s = 0; s < 27; s++) dq.Matrix(s, 0);  // precompute (not thread-safe lazily)
+  const float inv_gs = 65536.0f / float(f.global_scale);
+  const float x_dm = std::pow(1.25f, 2.0f - 3.0f), b_dm = std::pow(1.25f, 2.0f - 2.0f);
+  const float inv_quant_dc = inv_gs / float(f.quant_dc);
+  const float dc_step[3] = {inv_quant_dc / 4096.0f, inv_quant_dc / 512.0f, inv_quant_dc / 256.0f};
+  const size_t tiles_x = DivCeil(f.xb, 8);
+  const float biases[4] = {1.0f - 0.05465007330715401f, 1.0f - 0.07005449891748593f, 1.0f - 0.049935103337343655f, 0.145f};
+#pragma omp parallel for schedule(dynamic)
+  for (size_t g = 0; g < xg * yg; g++) {
+    std::vector<int32_t>& co = f.coeffs[g];
+    co.assign(3 * 65536, 0);
+    const size_t bx0 = (g % xg) * 32, by0 = (g / xg) * 32;
+    const size_t gw = std::min<size_t>(32, f.xb - bx0), gh = std::min<size_t>(32, f.yb - by0);
+    std::vector<float> coef[3], tmp, llf, dcb;
+    size_t offset = 0;
+    for (size_t by = 0; by < gh; by++)
+      for (size_t bx = 0; bx < gw; bx++) {
+        const size_t abx = bx0 + bx, aby = by0 + by;
+        uint8_t a = f.acs[aby * f.xb + abx];
+        if (!(a & 1)) continue;
+        const int st = a >> 1;
+        const int cx = jxh::kCoveredX[st], cy = jxh::kCoveredY[st];
+        const int R = cy * 8, C = cx * 8;
+        const size_t size = size_t(R) * C;
+        const size_t cstride = size_t(std::max(cx, cy)) * 8;  // coefficient columns
+        for (int c = 0; c < 3; c++) {
+          coef[c].resize(size);
+          ForwardDct(xyb[c].data() + aby * 8 * xp + abx * 8, xp, R, C, coef[c].data(), tmp);
+        }
+        // DC samples of the covered blocks from the LLF corner (inverse of LowestFrequenciesFromDC)
+        float dcv[3][32 * 32];
+        for (int c = 0; c < 3; c++) {
+          llf.assign(size_t(cx) * cy, 0.0f);
+          for (int ky = 0; ky < cy; ky++)
+            for (int kx = 0; kx < cx; kx++) {
+              float cf = (R < C) ? coef[c][ky * cstride + kx] : coef[c][kx * cstride + ky];
+              llf[ky * cx + kx] = cf / (ResampleScale(cy, ky) * ResampleScale(cx, kx));
+            }
+          // scaled IDCT of size cy x cx (natural ky,kx layout here)
+          const float* brr = GetBasis().m[FloorLog2(cy)].data();
+          const float* bcc = GetBasis().m[FloorLog2(cx)].data();
+          for (int y = 0; y < cy; y++)
+            for (int x = 0; x < cx; x++) {
+              float s = 0;
+              for (int ky = 0; ky < cy; ky++)
+                for (int kx = 0; kx < cx; kx++) s += llf[ky * cx + kx] * brr[y * cy + ky] * bcc[x * cx + kx];
+              dcv[c][y * cx + x] = s;
+            }
+        }
+        for (int y = 0; y < cy; y++)
+          for (int x = 0; x < cx; x++) {
+            size_t bi = (aby + y) * f.xb + abx + x;
+            int32_t qy = int32_t(std::lround(dcv[1][y * cx + x] / dc_step[1]));
+            float yd = qy * dc_step[1];
+            f.dc[1][bi] = qy;
+            f.dc[0][bi] = int32_t(std::lround((dcv[0][y * cx + x] - 0.0f * yd) / dc_step[0]));
+            f.dc[2][bi] = int32_t(std::lround((dcv[2][y * cx + x] - 1.0f * yd) / dc_step[2]));
+          }
+        // AC quantisation (Y first: X and B are coded as residuals of the chroma-from-luma prediction)
+        const float scaled = inv_gs / float(f.qf[aby * f.xb + abx]);
+        const float mulc[3] = {scaled * x_dm, scaled, scaled * b_dm};
+        const float x_cc = 0.0f + float(f.ytox[(aby / 8) * tiles_x + abx / 8]) / 84.0f;
+        const float b_cc = 1.0f + float(f.ytob[(aby / 8) * tiles_x + abx / 8]) / 84.0f;
+        const float *my = dq.Matrix(st, 1), *mx = dq.Matrix(st, 0), *mb = dq.Matrix(st, 2);
+        int32_t* qx = co.data() + 0 * 65536 + offset;
+        int32_t* qyv = co.data() + 1 * 65536 + offset;
+        int32_t* qb = co.data() + 2 * 65536 + offset;
+        const size_t lrows = size_t(std::min(cx, cy)), lcols = size_t(std::max(cx, cy));
+        for (size_t k = 0; k < size; k++) {
+          size_t row = k / cstride, col = k % cstride;
+          if (row < lrows && col < lcols) continue;  // LLF corner comes from DC
+          auto quant = [](float v) {
+            float r = std::nearbyint(v);
+            return std::fabs(v) < 0.58f ? 0 : int32_t(r);
+          };
+          int32_t iy = quant(coef[1][k] / (my[k] * mulc[1]));
+          qyv[k] = iy;
+          float ybias = iy == 0 ? 0.0f : (iy == 1 ? biases[1] : iy == -1 ? -biases[1] : float(iy) - biases[3] / float(iy));
+          float ydeq = ybias * (my[k] * mulc[1]);
+          qx[k] = quant((coef[0][k] - x_cc * ydeq) / (mx[k] * mulc[0]));
+          qb[k] = quant((coef[2][k] - b_cc * ydeq) / (mb[k] * mulc[2]));
+        }
+        offset += size;
+      }
+  }
+  Assemble(f, p, out);
+}
+
+// ---------------------------------------------------------------- random mode
+static void EncodeRandom(size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out) {
+  FrameModel f;
+  f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
+  Rng rng(p.seed);
+  f.global_scale = 3000 + rng.Below(9000);
+  f.quant_dc = 8 + rng.Below(16);
+  f.gab = p.gab < 0 ? 1 : p.gab;
+  f.epf_iters = p.epf_iters < 0 ? 1 : p.epf_iters;
+  f.flags = p.skip_dc_smoothing ? 128 : 0;
+  f.acs.assign(f.xb * f.yb, 0xFF);
+  f.qf.assign(f.xb * f.yb, 0);
+  f.sharp.assign(f.xb * f.yb, 0);
+  f.ytox.assign(DivCeil(f.xb, 8) * DivCeil(f.yb, 8), 0);
+  f.ytob.assign(f.ytox.size(), 0);
+  for (size_t i = 0; i < f.ytox.size(); i++) {
+    f.ytox[i] = int8_t(int(rng.Below(17)) - 8);
+    f.ytob[i] = int8_t(int(rng.Below(17)) - 8);
+  }
+  for (auto& s : f.sharp) s = uint8_t(rng.Below(8));
+  uint32_t mask = p.strategy_mask ? p.strategy_mask : 0x7FFFFFFu;
+  std::vector<int> allowed;
+  for (int s = 0; s < 27; s++)
+    if (mask & (1u << s)) allowed.push_back(s);
+  for (size_t by = 0; by < f.yb; by++)
+    for (size_t bx = 0; bx < f.xb; bx++) {
+      if (f.acs[by * f.xb + bx] != 0xFF) continue;
+      int st = -1;
+      for (int tries = 0; tries < 6 && st < 0; tries++) {
+        int cand = allowed[rng.Below(uint32_t(allowed.size()))];
+        // big transforms are rarer so that small ones get space too
+        size_t area = size_t(jxh::kCoveredX[cand]) * jxh::kCoveredY[cand];
+        if (area >= 64 && allowed.size() > 1 && rng.Below(uint32_t(area / 16)) != 0) continue;
+        if (Fits(f, bx, by, cand)) st = cand;
+      }
+      if (st < 0) st = (mask & 1) ? 0 : (Fits(f, bx, by, allowed[0]) ? allowed[0] : 0);
+      if (!Fits(f, bx, by, st)) st = 0;
+      Place(f, bx, by, st);
+      f.qf[by * f.xb + bx] = 1 + int32_t(rng.Below(16));
+    }
+  const float inv_gs = 65536.0f / float(f.global_scale);
+  const float inv_quant_dc = inv_gs / float(f.quant_dc);
+  const float dc_step[3] = {inv_quant_dc / 4096.0f, inv_quant_dc / 512.0f, inv_quant_dc / 256.0f};
+  // smooth-ish random DC in a plausible XYB range
+  for (auto& d : f.dc) d.assign(f.xb * f.yb, 0);
+  {
+    float vy = 0.4f, vx = 0.0f, vb = 0.0f;
+    for (size_t by = 0; by < f.yb; by++)
+      for (size_t bx = 0; bx < f.xb; bx++) {
+        vy = std::max(0.05f, std::min(0.8f, vy + (rng.Uniform() - 0.5f) * 0.08f));
+        vx = std::max(-0.02f, std::min(0.02f, vx + (rng.Uniform() - 0.5f) * 0.004f));
+        vb = std::max(-0.2f, std::min(0.2f, vb + (rng.Uniform() - 0.5f) * 0.03f));
+        size_t i = by * f.xb + bx;
+        f.dc[1][i] = int32_t(std::lround(vy / dc_step[1]));
+        f.dc[0][i] = int32_t(std::lround(vx / dc_step[0]));
+        f.dc[2][i] = int32_t(std::lround(vb / dc_step[2]));
+      }
+  }
+  const size_t xg = DivCeil(xs, 256), yg = DivCeil(ys, 256);
+  f.coeffs.assign(xg * yg, {});
+  for (size_t g = 0; g < xg * yg; g++) {
+    std::vector<int32_t>& co = f.coeffs[g];
+    co.assign(3 * 65536, 0);
+    const size_t bx0 = (g % xg) * 32, by0 = (g / xg) * 32;
+    const size_t gw = std::min<size_t>(32, f.xb - bx0), gh = std::min<size_t>(32, f.yb - by0);
+    size_t offset = 0;
+    for (size_t by = 0; by < gh; by++)
+      for (size_t bx = 0; bx < gw; bx++) {
+        uint8_t a = f.acs[(by0 + by) * f.xb + bx0 + bx];
+        if (!(a & 1)) continue;
+        const int st = a >> 1;
+        const size_t cx = jxh::kCoveredX[st], cy = jxh::kCoveredY[st];
+        const size_t size = cx * cy * 64, cstride = std::max(cx, cy) * 8, lrows = std::min(cx, cy), lcols = std::max(cx, cy);
+        const float density = 0.02f + 0.25f * rng.Uniform();  // per-block sparsity
+        for (int c = 0; c < 3; c++) {
+          int32_t* q = co.data() + size_t(c) * 65536 + offset;
+          for (size_t k = 0; k < size; k++) {
+            size_t row = k / cstride, col = k % cstride;
+            if (row < lrows && col < lcols) continue;
+            float freq = float(row * (lcols / lrows) + col) / float(cstride);  // 0..~2
+            if (rng.Uniform() < density * std::exp(-2.5f * freq)) {
+              int mag = 1 + int(rng.Below(3) == 0 ? rng.Below(6) : 0);
+              if (rng.Below(64) == 0) mag += int(rng.Below(40));
+              q[k] = rng.Below(2) ? mag : -mag;
+            }
+          }
+        }
+        offset += size;
+      }
+  }
+  Assemble(f, p, out);
+}
+
+}  // namespace jxe
+
+extern "C" {
+
+struct JxlEncParams {
+  float distance;
+  int32_t epf_iters, gab, strategy_mode;
+  uint32_t strategy_mask, seed;
+  int32_t max_clusters, skip_dc_smoothing, random_cmap;
+  int32_t reserved[6];
+};
+
+static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
+  *out = static_cast<uint8_t*>(malloc(v.size()));
+  if (!*out) return -1;
+  memcpy(*out, v.data(), v.size());
+  *n = v.size();
+  return 0;
+}
+
+int jxlenc_encode_rgb8(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, uint8_t** out, size_t* n) {
+  if (!rgb || !xs || !ys || !p || p->distance <= 0) return -1;
+  jxe::Params q;
+  static_assert(sizeof(jxe::Params) == sizeof(JxlEncParams), "param layout");
+  memcpy(&q, p, sizeof(q));
+  std::vector<uint8_t> v;
+  try {
+    jxe::EncodeImage(rgb, xs, ys, q, &v);
+  } catch (...) {
+    return -2;
+  }
+  return Finish(v, out, n);
+}
+
+int jxlenc_encode_random(uint32_t xs, uint32_t ys, const JxlEncParams* p, uint8_t** out, size_t* n) {
+  if (!xs || !ys || !p) return -1;
+  jxe::Params q;
+  memcpy(&q, p, sizeof(q));
+  std::vector<uint8_t> v;
+  try {
+    jxe::EncodeRandom(xs, ys, q, &v);
+  } catch (...) {
+    return -2;
+  }
+  return Finish(v, out, n);
+}
+
+void jxlenc_free(uint8_t* p) { free(p); }
+
+// Deterministic synthetic test image: dark gradient background, seeded rectangles, discs, texture and noise
+// (structure after the reference's GetSomeTestImage, lib/jxl/test_image.cc:147-200; not the same pixels).
+void jxlenc_synth_image(uint32_t xs, uint32_t ys, uint32_t seed, uint8_t* rgb) {
+  jxe::Rng rng(seed);
+  struct Shape { int x0, y0, x1, y1, kind; uint8_t col[3]; float freq; };
+  std::vector<Shape> shapes(24 + (uint64_t(xs) * ys) / (512 * 512) * 6);
+  for (auto& s : shapes) {
+    int w = 16 + int(rng.Below(std::max(17u, xs / 3))), h = 16 + int(rng.Below(std::max(17u, ys / 3)));
+    s.x0 = int(rng.Below(xs)) - w / 2;
+    s.y0 = int(rng.Below(ys)) - h / 2;
+    s.x1 = s.x0 + w;
+    s.y1 = s.y0 + h;
+    s.kind = int(rng.Below(4));
+    for (auto& c : s.col) c = uint8_t(rng.Below(256));
+    s.freq = 0.05f + rng.Uniform() * 0.9f;
+  }
+  // bucket shapes by 64-row bands to keep this O(pixels)
+  std::vector<std::vector<int>> band((ys + 63) / 64);
+  for (size_t i = 0; i < shapes.size(); i++)
+    for (int b = std::max(0, shapes[i].y0 / 64); b <= std::min<int>(int(band.size()) - 1, shapes[i].y1 / 64); b++)
+      band[b].push_back(int(i));
+#pragma omp parallel for
+  for (uint32_t y = 0; y < ys; y++) {
+    jxe::Rng r2(seed * 7919u + y);
+    for (uint32_t x = 0; x < xs; x++) {
+      float v[3] = {20.0f + 60.0f * x / xs, 30.0f + 50.0f * y / ys, 25.0f + 40.0f * (x + y) / float(xs + ys)};
+      for (int i : band[y / 64]) {
+        const Shape& s = shapes[i];
+        if (int(x) < s.x0 || int(x) >= s.x1 || int(y) < s.y0 || int(y) >= s.y1) continue;
+        float cxm = 0.5f * (s.x0 + s.x1), cym = 0.5f * (s.y0 + s.y1);
+        float dx = (x - cxm) / (0.5f * (s.x1 - s.x0)), dy = (y - cym) / (0.5f * (s.y1 - s.y0));
+        if (s.kind == 1 && dx * dx + dy * dy > 1.0f) continue;
+        for (int c = 0; c < 3; c++) {
+          float t = s.col[c];
+          if (s.kind == 2) t *= 0.5f + 0.5f * std::sin(s.freq * (x + 2 * y));  // texture
+          if (s.kind == 3) t *= 1.0f - 0.5f * (dx * dx + dy * dy);             // soft blob
+          v[c] = t;
+        }
+      }
+      for (int c = 0; c < 3; c++) {
+        float n = (r2.Uniform() - 0.5f) * 6.0f;
+        rgb[(size_t(y) * xs + x) * 3 + c] = uint8_t(std::max(0.0f, std::min(255.0f, v[c] + n)));
+      }
+    }
+  }
+}
+
+}  // extern "C"
