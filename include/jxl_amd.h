@@ -1,0 +1,32 @@
+/* libjxl_amd — frame-level C ABI between the host front-end and the HIP layer. Used by the JxlDecoder
+ * implementation, by bench.py and by the parity tests to time the device stages separately from host parsing.
+ *
+ * jxlamd_frame_parse() does what the reference does once per frame on the host before any group is decoded
+ * (lib/jxl/dec_frame.cc:135-434: headers, TOC, DC global, DC groups through the JxlParallelRunner, AC global);
+ * jxlamd_frame_upload() hands the resulting tables and the still-compressed AC sections to a JxlHipContext. */
+#ifndef JXL_AMD_H_
+#define JXL_AMD_H_
+#include <jxl/parallel_runner.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "jxl_amd_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct JxlAmdFrame JxlAmdFrame;
+
+/* Parses the first frame of a codestream (bare or in a `jxlc` container). `data` must stay valid until the frame
+ * has been uploaded. runner may be NULL (sequential). Returns 0 or a non-zero code; see jxlamd_last_error(). */
+int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runner, void* runner_opaque, JxlAmdFrame** frame);
+void jxlamd_frame_free(JxlAmdFrame* frame);
+/* info[0..11]: xsize, ysize, xsize_blocks, ysize_blocks, num_groups, num_dc_groups, num_passes, used_acs mask,
+ * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes. */
+void jxlamd_frame_info(const JxlAmdFrame* frame, uint32_t* info);
+int jxlamd_frame_upload(const JxlAmdFrame* frame, JxlHipContext* ctx);
+/* Thread-local description of the last failure of a jxlamd_* call ("" if none). */
+const char* jxlamd_last_error(void);
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_AMD_H_ */

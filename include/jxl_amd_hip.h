@@ -1,0 +1,155 @@
+/* libjxl_amd — thin extern "C" HIP layer for the JPEG XL VarDCT decode hot path on MI355X (gfx950).
+ *
+ * Plain C ABI: pointers and sizes only, no C++ or torch types. One JxlHipContext owns one HIP stream and the
+ * device buffers of one frame; all calls on a context are asynchronous on its stream unless noted.
+ *
+ * This is the internal seam of the reference that the GPU path replaces:
+ *   - jxlhip_run_entropy()      replaces the entropy half of DecodeGroup():
+ *                               lib/jxl/dec_group.cc:469-542 (DecodeACVarBlock), :594-660 (GetBlockFromBitstream),
+ *                               lib/jxl/dec_ans.h:170-257 (rANS + hybrid uint), lib/jxl/dec_bit_reader.h:84-144.
+ *   - jxlhip_run_transform()    replaces the reconstruction half of DecodeGroupImpl():
+ *                               lib/jxl/dec_group.cc:115-181 (dequant + chroma-from-luma), :433-450,
+ *                               lib/jxl/dec_transforms-inl.h:456-818 (TransformToPixels, LowestFrequenciesFromDC),
+ *                               lib/jxl/dct-inl.h:376-397.
+ *   - jxlhip_run_filter_color() replaces RenderPipelineInput::Done() for the VarDCT stage list:
+ *                               lib/jxl/render_pipeline/stage_gaborish.cc:56-100, stage_epf.cc:82-494,
+ *                               stage_xyb.cc:80-92, stage_from_linear.cc:114-144, stage_write.cc:266-286,548-590,
+ *                               low_memory_render_pipeline.cc:475-517 (edge mirroring).
+ * The public drop-in boundary (JxlDecoder* / JxlParallelRunner) is declared in include/jxl/decode.h and
+ * include/jxl/parallel_runner.h and is implemented on top of this layer.
+ *
+ * All functions return 0 on success, a negative hipError_t on a HIP failure, or a positive JXLHIP_ERR_* code.
+ */
+#ifndef JXL_AMD_HIP_H_
+#define JXL_AMD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JXLHIP_ERR_INVALID_ARGUMENT 1
+#define JXLHIP_ERR_NO_FRAME 2
+#define JXLHIP_ERR_STREAM 3 /* the entropy kernel flagged a corrupt AC section; see jxlhip_get_errors */
+#define JXLHIP_ERR_UNSUPPORTED 4
+
+typedef struct JxlHipContext JxlHipContext;
+
+/* One varblock in the decode order of its 256x256 group. */
+typedef struct JxlHipVarBlock {
+  uint16_t bx, by;      /* absolute position of the top-left 8x8 block */
+  uint8_t strategy;     /* AcStrategy raw value 0..26 */
+  uint8_t quant_dc_ctx; /* DC-derived bucket of the block context map */
+  uint16_t qf;          /* raw quant field 1..256 */
+  uint32_t coef_offset; /* offset of the block's coefficients in its group's per-channel plane */
+} JxlHipVarBlock;
+
+/* Entropy-code tables of one pass (rANS only). */
+typedef struct JxlHipPassDesc {
+  uint32_t log_alpha;
+  uint32_t num_clusters;
+  const uint8_t* ctx_map;     /* num_histograms * num_ac_contexts + 16 */
+  uint32_t ctx_map_size;
+  const void* alias;          /* num_clusters << log_alpha entries of 8 bytes:
+                                 u8 cutoff, u8 right_value, u16 freq0, u16 offsets1, u16 freq1 */
+  const uint32_t* uint_cfg;   /* per cluster: split_exponent | msb_in_token << 8 | lsb_in_token << 16 */
+  const uint16_t* orders;     /* coefficient orders of the used (bucket, channel) pairs */
+  uint32_t orders_size;
+  uint32_t order_offset[39];  /* [bucket * 3 + channel] -> first entry in `orders` */
+  uint32_t shift;             /* left shift applied to this pass's coefficients */
+} JxlHipPassDesc;
+
+typedef struct JxlHipFrameDesc {
+  uint32_t xsize, ysize;
+  uint32_t xsize_blocks, ysize_blocks;
+  uint32_t xsize_groups, num_groups;
+  uint32_t num_passes;
+  uint32_t coef_bits; /* 16 or 32: storage type of quantised coefficients */
+  /* compressed AC sections; index pass * num_groups + group */
+  const uint8_t* codestream;
+  const uint64_t* section_offset;
+  const uint32_t* section_size;
+  uint32_t first_section_bit_offset; /* single-section frames only, else 0 */
+  const JxlHipPassDesc* passes;
+  /* varblocks */
+  const JxlHipVarBlock* blocks;
+  uint32_t num_blocks;
+  const uint32_t* group_block_begin; /* num_groups + 1 */
+  /* block context map */
+  const uint8_t* block_ctx_lut; /* [c][order bucket][qf bucket][dc bucket] */
+  uint32_t block_ctx_lut_size;
+  uint32_t num_block_ctxs, num_dc_ctxs, num_qf_thresholds;
+  uint32_t qf_thresholds[16];
+  uint32_t num_histograms;
+  /* dequantisation tables: for table kind k, channel c: dequant[dequant_offset[k] + c * dequant_size[k] + i] */
+  const float* dequant;
+  uint32_t dequant_floats;
+  uint32_t dequant_offset[17], dequant_size[17];
+  /* block-resolution planes */
+  const float* dc;        /* 3 planes X, Y, B of xsize_blocks * ysize_blocks */
+  const float* inv_sigma; /* xsize_blocks * ysize_blocks */
+  const int8_t* ytox;     /* ceil(xsize_blocks / 8) * ceil(ysize_blocks / 8) */
+  const int8_t* ytob;
+  /* scalars */
+  float inv_global_scale, x_dm, b_dm;
+  float color_scale, base_corr_x, base_corr_b;
+  float quant_biases[4];
+  /* loop filter */
+  int32_t gab;
+  float gab_w[6]; /* per channel {w1, w2} */
+  int32_t epf_iters;
+  float epf_channel_scale[3];
+  float epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul;
+  /* colour */
+  float opsin_inv[9]; /* inverse opsin matrix, already scaled by 255 / intensity_target */
+  float opsin_bias[3];
+  int32_t linear_output; /* 0 = sRGB transfer function, 1 = linear */
+} JxlHipFrameDesc;
+
+int jxlhip_device_count(void);
+int jxlhip_ctx_create(int device, JxlHipContext** ctx);
+void jxlhip_ctx_destroy(JxlHipContext* ctx);
+
+/* Copies every table and the AC sections of the frame to the device (asynchronously on the context's stream;
+ * the host arrays may be released after jxlhip_sync). Re-uses device buffers across frames when they fit. */
+int jxlhip_frame_upload(JxlHipContext* ctx, const JxlHipFrameDesc* desc);
+
+/* The three stages of the hot path. Inputs must be resident (jxlhip_frame_upload). */
+int jxlhip_run_entropy(JxlHipContext* ctx);
+int jxlhip_run_transform(JxlHipContext* ctx);
+int jxlhip_run_filter_color(JxlHipContext* ctx);
+/* Convenience: all three, in order. */
+int jxlhip_run_all(JxlHipContext* ctx);
+
+/* Blocks until the context's stream is idle. */
+int jxlhip_sync(JxlHipContext* ctx);
+
+/* Copies the interleaved RGB8 result (row stride in bytes) to host memory; synchronous. */
+int jxlhip_download_rgb8(JxlHipContext* ctx, uint8_t* dst, size_t stride);
+/* Device pointer of the RGB8 result (xsize * 3 bytes per row, tightly packed). */
+const uint8_t* jxlhip_rgb8_device_ptr(JxlHipContext* ctx);
+
+/* Per-group error flags written by the entropy kernel: bit0 invalid nzeros, bit1 ANS final state,
+ * bit2 section over-read, bit3 invalid histogram selector. Synchronous. `flags` has num_groups entries.
+ * Returns JXLHIP_ERR_STREAM if any flag is set. */
+int jxlhip_get_errors(JxlHipContext* ctx, uint32_t* flags, size_t n);
+
+/* Test/debug access to intermediates; synchronous copies to host.
+ *   "coeffs"       quantised coefficients, int16 or int32 [num_groups][3][65536]
+ *   "xyb_idct"     float [3][ysize_padded][xsize_padded] after the inverse transforms
+ *   "xyb_filtered" float [3][ysize_padded][xsize_padded] after Gaborish/EPF (rows < ysize valid)
+ * Returns the number of bytes the buffer needs through *needed when dst is NULL. */
+int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_size, size_t* needed);
+
+/* Timing of the last run of each stage in milliseconds (HIP events on the context's stream);
+ * which: 0 entropy, 1 transform, 2 filter+colour. Synchronous. */
+int jxlhip_last_stage_ms(JxlHipContext* ctx, int which, float* ms);
+
+const char* jxlhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JXL_AMD_HIP_H_ */

@@ -1,0 +1,260 @@
+"""libjxl_amd — MI355X-native JPEG XL VarDCT decode path (Python plumbing over the C ABI).
+
+The product is the shared library ``libjxl_amd/_build/libjxl_amd.so`` (HIP kernels + ``extern "C"`` layer declared in
+``include/jxl_amd_hip.h``, ``include/jxl_amd.h`` and ``include/jxl/decode.h``).  This module only binds it with
+ctypes for tests and ``bench.py``; it contains no decode logic and there is no CPU fallback: if the library or a HIP
+device is missing, calls raise.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libjxl_amd.so")
+ENC_PATH = os.path.join(_HERE, "_build", "libjxlenc.so")
+
+_lib = None
+_enc = None
+
+
+class JxlAmdError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compiles the in-tree shared libraries (hipcc --offload-arch=gfx950)."""
+    r = subprocess.run(["make", "-C", _HERE], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise JxlAmdError("building libjxl_amd failed")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise JxlAmdError("%s is missing: run libjxl_amd.build() (hipcc) first; there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, cp, u32p = ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)
+        L.jxlhip_version.restype = cp
+        L.jxlhip_device_count.restype = ctypes.c_int
+        L.jxlhip_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+        L.jxlhip_ctx_destroy.argtypes = [vp]
+        for name in ("jxlhip_run_entropy", "jxlhip_run_transform", "jxlhip_run_filter_color", "jxlhip_run_all", "jxlhip_sync"):
+            getattr(L, name).argtypes = [vp]
+        L.jxlhip_download_rgb8.argtypes = [vp, vp, ctypes.c_size_t]
+        L.jxlhip_rgb8_device_ptr.argtypes = [vp]
+        L.jxlhip_rgb8_device_ptr.restype = vp
+        L.jxlhip_get_errors.argtypes = [vp, u32p, ctypes.c_size_t]
+        L.jxlhip_download.argtypes = [vp, cp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        L.jxlhip_last_stage_ms.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        L.jxlamd_frame_parse.argtypes = [cp, ctypes.c_size_t, vp, vp, ctypes.POINTER(vp)]
+        L.jxlamd_frame_free.argtypes = [vp]
+        L.jxlamd_frame_info.argtypes = [vp, u32p]
+        L.jxlamd_frame_upload.argtypes = [vp, vp]
+        L.jxlamd_last_error.restype = cp
+        L.JxlThreadParallelRunnerCreate.restype = vp
+        L.JxlThreadParallelRunnerCreate.argtypes = [vp, ctypes.c_size_t]
+        L.JxlThreadParallelRunnerDestroy.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def _check(r, what):
+    if r != 0:
+        err = lib().jxlamd_last_error()
+        raise JxlAmdError("%s failed: code %d %s" % (what, r, err.decode() if err else ""))
+
+
+class Frame:
+    """Host-parsed frame (headers, DC, tables); AC sections stay compressed."""
+
+    INFO = ("xsize", "ysize", "xsize_blocks", "ysize_blocks", "num_groups", "num_dc_groups", "num_passes", "used_acs",
+            "epf_iters", "gab", "coef_bits", "ac_bytes")
+
+    def __init__(self, data, threads=0):
+        L = lib()
+        self._data = bytes(data)  # must outlive upload
+        self._h = ctypes.c_void_p()
+        runner = None
+        pool = None
+        if threads > 0:
+            pool = L.JxlThreadParallelRunnerCreate(None, threads)
+            runner = ctypes.cast(L.JxlThreadParallelRunner, ctypes.c_void_p)
+        try:
+            _check(L.jxlamd_frame_parse(self._data, len(self._data), runner, pool, ctypes.byref(self._h)), "jxlamd_frame_parse")
+        finally:
+            if pool:
+                L.JxlThreadParallelRunnerDestroy(pool)
+        info = (ctypes.c_uint32 * 12)()
+        L.jxlamd_frame_info(self._h, info)
+        self.info = dict(zip(self.INFO, list(info)))
+
+    def close(self):
+        if self._h:
+            lib().jxlamd_frame_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipContext:
+    """One HIP stream + the device buffers of one frame (include/jxl_amd_hip.h)."""
+
+    def __init__(self, device=0):
+        L = lib()
+        if L.jxlhip_device_count() <= 0:
+            raise JxlAmdError("no HIP device visible: the decode path has no CPU implementation")
+        self._h = ctypes.c_void_p()
+        _check(L.jxlhip_ctx_create(device, ctypes.byref(self._h)), "jxlhip_ctx_create")
+        self.frame_info = None
+
+    def close(self):
+        if self._h:
+            lib().jxlhip_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, frame):
+        _check(lib().jxlamd_frame_upload(frame._h, self._h), "jxlamd_frame_upload")
+        self.frame_info = dict(frame.info)
+
+    def run_entropy(self):
+        _check(lib().jxlhip_run_entropy(self._h), "jxlhip_run_entropy")
+
+    def run_transform(self):
+        _check(lib().jxlhip_run_transform(self._h), "jxlhip_run_transform")
+
+    def run_filter_color(self):
+        _check(lib().jxlhip_run_filter_color(self._h), "jxlhip_run_filter_color")
+
+    def run_all(self):
+        _check(lib().jxlhip_run_all(self._h), "jxlhip_run_all")
+
+    def sync(self):
+        _check(lib().jxlhip_sync(self._h), "jxlhip_sync")
+
+    def errors(self):
+        n = self.frame_info["num_groups"]
+        flags = (ctypes.c_uint32 * n)()
+        r = lib().jxlhip_get_errors(self._h, flags, n)
+        return r, list(flags)
+
+    def stage_ms(self, which):
+        ms = ctypes.c_float()
+        _check(lib().jxlhip_last_stage_ms(self._h, which, ctypes.byref(ms)), "jxlhip_last_stage_ms")
+        return ms.value
+
+    def rgb8(self):
+        fi = self.frame_info
+        out = np.empty((fi["ysize"], fi["xsize"], 3), np.uint8)
+        _check(lib().jxlhip_download_rgb8(self._h, out.ctypes.data, fi["xsize"] * 3), "jxlhip_download_rgb8")
+        return out
+
+    def download(self, name):
+        fi = self.frame_info
+        need = ctypes.c_size_t()
+        _check(lib().jxlhip_download(self._h, name.encode(), None, 0, ctypes.byref(need)), "jxlhip_download")
+        buf = np.empty(need.value, np.uint8)
+        _check(lib().jxlhip_download(self._h, name.encode(), buf.ctypes.data, need.value, None), "jxlhip_download")
+        if name == "coeffs":
+            dt = np.int16 if fi["coef_bits"] == 16 else np.int32
+            return buf.view(dt).reshape(fi["num_groups"], 3, 65536)
+        return buf.view(np.float32).reshape(3, fi["ysize_blocks"] * 8, fi["xsize_blocks"] * 8)
+
+
+def decode_rgb8(data, device=0, threads=0):
+    """One-shot helper: codestream bytes -> HxWx3 uint8 through the GPU path."""
+    f = Frame(data, threads)
+    c = HipContext(device)
+    try:
+        c.upload(f)
+        c.run_all()
+        r, flags = c.errors()
+        if r:
+            raise JxlAmdError("corrupt AC sections: %r" % [(g, e) for g, e in enumerate(flags) if e])
+        return c.rgb8()
+    finally:
+        c.close()
+        f.close()
+
+
+# ----------------------------------------------------------------------------------------------- synthetic streams
+class EncParams(ctypes.Structure):
+    _fields_ = [("distance", ctypes.c_float), ("epf_iters", ctypes.c_int32), ("gab", ctypes.c_int32),
+                ("strategy_mode", ctypes.c_int32), ("strategy_mask", ctypes.c_uint32), ("seed", ctypes.c_uint32),
+                ("max_clusters", ctypes.c_int32), ("skip_dc_smoothing", ctypes.c_int32), ("random_cmap", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 6)]
+
+
+def _enc_lib():
+    global _enc
+    if _enc is None:
+        if not os.path.exists(ENC_PATH):
+            raise JxlAmdError("%s is missing: run libjxl_amd.build()" % ENC_PATH)
+        E = ctypes.CDLL(ENC_PATH)
+        pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8))
+        E.jxlenc_encode_rgb8.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), pp,
+                                         ctypes.POINTER(ctypes.c_size_t)]
+        E.jxlenc_encode_random.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), pp,
+                                           ctypes.POINTER(ctypes.c_size_t)]
+        E.jxlenc_synth_image.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        E.jxlenc_free.argtypes = [ctypes.POINTER(ctypes.c_uint8)]
+        _enc = E
+    return _enc
+
+
+def _params(**kw):
+    p = EncParams()
+    p.distance, p.epf_iters, p.gab, p.strategy_mode, p.strategy_mask, p.seed = 1.0, -1, -1, 1, 0, 1
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def synth_image(xsize, ysize, seed=177):
+    """Deterministic synthetic RGB8 test image (gradient background, rectangles, discs, texture, noise)."""
+    a = np.zeros((ysize, xsize, 3), np.uint8)
+    _enc_lib().jxlenc_synth_image(xsize, ysize, seed, a.ctypes.data)
+    return a
+
+
+def _finish(E, r, out, n, what):
+    if r:
+        raise JxlAmdError("%s failed: %d" % (what, r))
+    b = ctypes.string_at(out, n.value)
+    E.jxlenc_free(out)
+    return b
+
+
+def encode_rgb8(img, **kw):
+    """RGB8 image -> VarDCT codestream (distance=1.0, strategy_mode=1 by default)."""
+    E = _enc_lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    p = _params(**kw)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    r = E.jxlenc_encode_rgb8(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), ctypes.byref(out), ctypes.byref(n))
+    return _finish(E, r, out, n, "jxlenc_encode_rgb8")
+
+
+def encode_random(xsize, ysize, **kw):
+    """Random valid VarDCT codestream exercising the strategies in strategy_mask (0 = all 27)."""
+    E = _enc_lib()
+    p = _params(**kw)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    r = E.jxlenc_encode_random(xsize, ysize, ctypes.byref(p), ctypes.byref(out), ctypes.byref(n))
+    return _finish(E, r, out, n, "jxlenc_encode_random")

@@ -1,0 +1,588 @@
+// libjxl_amd — implementation of the thin extern "C" HIP layer declared in include/jxl_amd_hip.h.
+// One context = one HIP stream + the device buffers of one frame. Launch functions never allocate or synchronise
+// (jxlhip_frame_upload does the allocation), so a caller may capture jxlhip_run_* into a hipGraph.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../../include/jxl_amd_hip.h"
+#include "jxl_hip_kernels.h"
+
+namespace {
+#include "../host/afv_basis.inc"
+#include "../host/dither.inc"
+
+#define HIP_TRY(expr)                          \
+  do {                                         \
+    hipError_t e_ = (expr);                    \
+    if (e_ != hipSuccess) return -int(e_);     \
+  } while (0)
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int Ensure(size_t n) {
+    if (n <= cap && p) return 0;
+    if (p) {
+      hipError_t e = hipFree(p);
+      p = nullptr;
+      cap = 0;
+      if (e != hipSuccess) return -int(e);
+    }
+    size_t want = n < 256 ? 256 : n;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return -int(e);
+    }
+    cap = want;
+    return 0;
+  }
+  void Free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const { return static_cast<T*>(p); }
+};
+
+struct PassBufs {
+  Buf ctx_map, alias, cfg, orders;
+};
+
+}  // namespace
+
+struct JxlHipContext {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+  bool ev_valid[3] = {false, false, false};
+  Buf basis;
+  bool have_frame = false;
+  // geometry
+  uint32_t xs = 0, ys = 0, xb = 0, yb = 0, xg = 0, ng = 0, np = 0, xp = 0, yp = 0, coef_bits = 16;
+  int gab = 0, epf_iters = 0;
+  float epf_pass0 = 0.9f, epf_pass2 = 6.5f, epf_border = 2.0f / 3;
+  // buffers
+  Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
+  Buf plane[3], rgb, tlist, scratch;
+  std::vector<PassBufs> pass_bufs;
+  uint32_t list_begin[27] = {}, list_count[27] = {};
+  jxlhip::EntropyParams ep;
+  jxlhip::TransformParams tp;
+  jxlhip::FilterParams fp;
+  size_t lds_entropy = 0;
+  bool alias_lds = false;
+  int final_plane = 0;  // which plane set holds the filtered XYB after jxlhip_run_filter_color
+};
+
+extern "C" {
+
+const char* jxlhip_version(void) { return "libjxl_amd 0.1 (gfx950)"; }
+
+int jxlhip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int jxlhip_ctx_create(int device, JxlHipContext** out) {
+  if (!out) return JXLHIP_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  JxlHipContext* c = new (std::nothrow) JxlHipContext;
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return -int(e);
+  }
+  for (auto& ev : c->ev) {
+    e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+      delete c;
+      return -int(e);
+    }
+  }
+  // static tables
+  std::vector<float> bt(87381);
+  for (int l = 0; l <= 8; l++) {
+    const int N = 1 << l;
+    float* dst = bt.data() + (size_t(N) * N - 1) / 3;
+    for (int k = 0; k < N; k++)
+      for (int n = 0; n < N; n++) dst[size_t(k) * N + n] = float((k ? std::sqrt(2.0) : 1.0) * std::cos((n + 0.5) * k * M_PI / N));
+  }
+  int r = c->basis.Ensure(bt.size() * sizeof(float));
+  if (r) {
+    jxlhip_ctx_destroy(c);
+    return r;
+  }
+  float resample[63];
+  for (int n = 1; n <= 32; n *= 2)
+    for (int i = 0; i < n; i++) {
+      const double N = 8.0 * n;
+      resample[n - 1 + i] = float(1.0 / (std::cos(i / (2 * N) * M_PI) * std::cos(i / N * M_PI) * std::cos(i / (N / 2) * M_PI)));
+    }
+  e = hipMemcpy(c->basis.p, bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(jxlhip::c_afv_basis), kAfvBasis, sizeof(kAfvBasis));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(jxlhip::c_dither), kDither32, sizeof(kDither32));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(jxlhip::c_resample), resample, sizeof(resample));
+  if (e != hipSuccess) {
+    jxlhip_ctx_destroy(c);
+    return -int(e);
+  }
+  *out = c;
+  return 0;
+}
+
+void jxlhip_ctx_destroy(JxlHipContext* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
+                &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch};
+  for (Buf* b : all) b->Free();
+  for (auto& pb : c->pass_bufs) {
+    pb.ctx_map.Free();
+    pb.alias.Free();
+    pb.cfg.Free();
+    pb.orders.Free();
+  }
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int Upload(JxlHipContext* c, Buf& b, const void* src, size_t bytes) {
+  int r = b.Ensure(bytes ? bytes : 16);
+  if (r) return r;
+  if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
+  if (!c || !d) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!d->xsize || !d->ysize || !d->num_groups || !d->num_passes || d->num_passes > 11) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (d->coef_bits != 16 && d->coef_bits != 32) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (d->xsize_blocks != (d->xsize + 7) / 8 || d->ysize_blocks != (d->ysize + 7) / 8) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (d->num_groups != d->xsize_groups * ((d->ysize + 255) / 256) || d->xsize_groups != (d->xsize + 255) / 256)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (d->num_qf_thresholds > 15 || d->num_block_ctxs == 0 || d->num_block_ctxs > 16 || d->num_dc_ctxs == 0)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  c->have_frame = false;
+  c->xs = d->xsize; c->ys = d->ysize; c->xb = d->xsize_blocks; c->yb = d->ysize_blocks;
+  c->xg = d->xsize_groups; c->ng = d->num_groups; c->np = d->num_passes;
+  c->xp = c->xb * 8; c->yp = c->yb * 8;
+  c->coef_bits = d->coef_bits;
+  c->gab = d->gab; c->epf_iters = d->epf_iters;
+  // ---- validate varblocks against the geometry (the kernels index with these)
+  {
+    uint32_t prev_end = 0;
+    for (uint32_t g = 0; g < d->num_groups; g++) {
+      const uint32_t b0 = d->group_block_begin[g], b1 = d->group_block_begin[g + 1];
+      if (b0 != prev_end || b1 < b0 || b1 > d->num_blocks) return JXLHIP_ERR_INVALID_ARGUMENT;
+      prev_end = b1;
+      uint32_t off = 0;
+      const uint32_t gx0 = (g % d->xsize_groups) * 32, gy0 = (g / d->xsize_groups) * 32;
+      for (uint32_t i = b0; i < b1; i++) {
+        const JxlHipVarBlock& v = d->blocks[i];
+        if (v.strategy >= 27 || v.qf == 0 || v.qf > 256 || v.quant_dc_ctx >= d->num_dc_ctxs) return JXLHIP_ERR_INVALID_ARGUMENT;
+        static const uint8_t cx[27] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
+        static const uint8_t cy[27] = {1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1, 1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16};
+        if (v.bx < gx0 || v.by < gy0 || v.bx + cx[v.strategy] > gx0 + 32 || v.by + cy[v.strategy] > gy0 + 32 ||
+            v.bx + cx[v.strategy] > d->xsize_blocks || v.by + cy[v.strategy] > d->ysize_blocks)
+          return JXLHIP_ERR_INVALID_ARGUMENT;
+        if (v.coef_offset != off) return JXLHIP_ERR_INVALID_ARGUMENT;
+        off += 64u * cx[v.strategy] * cy[v.strategy];
+        if (off > 65536) return JXLHIP_ERR_INVALID_ARGUMENT;
+      }
+    }
+    if (prev_end != d->num_blocks) return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
+  // ---- pack the AC sections at 16-byte aligned offsets
+  const size_t nsec = size_t(d->num_groups) * d->num_passes;
+  std::vector<uint32_t> sec_word(nsec), sec_size(nsec);
+  size_t total = 0;
+  for (size_t i = 0; i < nsec; i++) {
+    sec_word[i] = uint32_t(total / 4);
+    sec_size[i] = d->section_size[i];
+    total += (size_t(d->section_size[i]) + 15 + 4) & ~size_t(15);
+  }
+  std::vector<uint8_t> packed(total + 16, 0);
+  for (size_t i = 0; i < nsec; i++) memcpy(packed.data() + size_t(sec_word[i]) * 4, d->codestream + d->section_offset[i], d->section_size[i]);
+  int r;
+  if ((r = Upload(c, c->sections, packed.data(), packed.size()))) return r;
+  if ((r = Upload(c, c->sec_word, sec_word.data(), nsec * 4))) return r;
+  if ((r = Upload(c, c->sec_size, sec_size.data(), nsec * 4))) return r;
+  // the staging vectors die at the end of this call: finish these copies now
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((r = Upload(c, c->blocks, d->blocks, size_t(d->num_blocks) * sizeof(JxlHipVarBlock)))) return r;
+  if ((r = Upload(c, c->gbb, d->group_block_begin, (size_t(d->num_groups) + 1) * 4))) return r;
+  if ((r = Upload(c, c->bctx_lut, d->block_ctx_lut, d->block_ctx_lut_size))) return r;
+  if ((r = Upload(c, c->dequant, d->dequant, size_t(d->dequant_floats) * 4))) return r;
+  const size_t nblk = size_t(c->xb) * c->yb;
+  if ((r = Upload(c, c->dc, d->dc, nblk * 3 * 4))) return r;
+  if ((r = Upload(c, c->inv_sigma, d->inv_sigma, nblk * 4))) return r;
+  const size_t ntiles = size_t((c->xb + 7) / 8) * ((c->yb + 7) / 8);
+  if ((r = Upload(c, c->ytox, d->ytox, ntiles))) return r;
+  if ((r = Upload(c, c->ytob, d->ytob, ntiles))) return r;
+  // ---- per-pass tables
+  if (c->pass_bufs.size() < d->num_passes) c->pass_bufs.resize(d->num_passes);
+  std::vector<jxlhip::PassDev> pd(d->num_passes);
+  const uint32_t nctx = d->num_block_ctxs * 495;
+  size_t alias_bytes_max = 0;
+  for (uint32_t p = 0; p < d->num_passes; p++) {
+    const JxlHipPassDesc& s = d->passes[p];
+    if (s.log_alpha < 5 || s.log_alpha > 8 || s.num_clusters == 0 || s.num_clusters > 256) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (s.ctx_map_size < size_t(d->num_histograms) * nctx + 16) return JXLHIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < s.ctx_map_size; i++)
+      if (s.ctx_map[i] >= s.num_clusters) return JXLHIP_ERR_INVALID_ARGUMENT;
+    PassBufs& pb = c->pass_bufs[p];
+    const size_t alias_bytes = (size_t(s.num_clusters) << s.log_alpha) * 8;
+    alias_bytes_max = alias_bytes > alias_bytes_max ? alias_bytes : alias_bytes_max;
+    if ((r = Upload(c, pb.ctx_map, s.ctx_map, s.ctx_map_size))) return r;
+    if ((r = Upload(c, pb.alias, s.alias, alias_bytes))) return r;
+    if ((r = Upload(c, pb.cfg, s.uint_cfg, size_t(s.num_clusters) * 4))) return r;
+    if ((r = Upload(c, pb.orders, s.orders, size_t(s.orders_size) * 2))) return r;
+    pd[p].ctx_map = pb.ctx_map.as<uint8_t>();
+    pd[p].alias = pb.alias.as<uint2>();
+    pd[p].cfg = pb.cfg.as<uint32_t>();
+    pd[p].orders = pb.orders.as<uint16_t>();
+    memcpy(pd[p].order_offset, s.order_offset, sizeof(s.order_offset));
+    pd[p].log_alpha = s.log_alpha;
+    pd[p].num_clusters = s.num_clusters;
+    pd[p].shift = s.shift;
+    pd[p].alias_lds = 0;
+  }
+  if ((r = Upload(c, c->passes_dev, pd.data(), pd.size() * sizeof(jxlhip::PassDev)))) return r;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // `pd` is a local
+  // ---- work buffers
+  const size_t coef_bytes = size_t(d->num_groups) * 3 * 65536 * (d->coef_bits / 8);
+  if ((r = c->coeffs.Ensure(coef_bytes))) return r;
+  if ((r = c->errors.Ensure(size_t(d->num_groups) * 4))) return r;
+  const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
+  for (auto& pl : c->plane)
+    if ((r = pl.Ensure(plane_bytes))) return r;
+  if ((r = c->rgb.Ensure(size_t(c->xs) * c->ys * 3))) return r;
+  // ---- transform work lists (block indices bucketed by strategy)
+  {
+    std::vector<uint32_t> count(27, 0);
+    for (uint32_t i = 0; i < d->num_blocks; i++) count[d->blocks[i].strategy]++;
+    uint32_t acc = 0;
+    for (int s = 0; s < 27; s++) {
+      c->list_begin[s] = acc;
+      c->list_count[s] = count[s];
+      acc += count[s];
+    }
+    std::vector<uint32_t> list(d->num_blocks ? d->num_blocks : 1), fill(27, 0);
+    for (uint32_t i = 0; i < d->num_blocks; i++) {
+      const int s = d->blocks[i].strategy;
+      list[c->list_begin[s] + fill[s]++] = i;
+    }
+    if ((r = Upload(c, c->tlist, list.data(), list.size() * 4))) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t big = 0;
+    for (int s = 21; s < 27; s++) big = big > count[s] ? big : count[s];
+    if (big) {
+      const uint32_t chunk = big < 32 ? big : 32;
+      if ((r = c->scratch.Ensure(size_t(chunk) * 3 * 2 * 65536 * 4))) return r;
+    }
+  }
+  // ---- kernel parameter blocks
+  jxlhip::EntropyParams& ep = c->ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.sections = c->sections.as<uint32_t>();
+  ep.sec_word = c->sec_word.as<uint32_t>();
+  ep.sec_size = c->sec_size.as<uint32_t>();
+  ep.first_bit_offset = d->first_section_bit_offset;
+  ep.blocks = c->blocks.as<JxlHipVarBlock>();
+  ep.gbb = c->gbb.as<uint32_t>();
+  ep.bctx_lut = c->bctx_lut.as<uint8_t>();
+  ep.nq = d->num_qf_thresholds + 1;
+  ep.ndc = d->num_dc_ctxs;
+  ep.num_bctx = d->num_block_ctxs;
+  for (uint32_t i = 0; i < d->num_qf_thresholds; i++) ep.qf_thr[i] = d->qf_thresholds[i];
+  ep.num_hist = d->num_histograms;
+  ep.nctx = nctx;
+  ep.passes = c->passes_dev.as<jxlhip::PassDev>();
+  ep.num_passes = d->num_passes;
+  ep.num_groups = d->num_groups;
+  ep.coeffs = c->coeffs.p;
+  ep.errors = c->errors.as<uint32_t>();
+  ep.lds_ctx_bytes = (nctx + 16 + 15) & ~15u;
+  const size_t lds_budget = 150 * 1024;
+  c->alias_lds = ep.lds_ctx_bytes + alias_bytes_max + 3072 <= lds_budget;
+  ep.lds_alias_bytes = c->alias_lds ? uint32_t((alias_bytes_max + 15) & ~size_t(15)) : 0;
+  c->lds_entropy = ep.lds_ctx_bytes + ep.lds_alias_bytes + 3072;
+  if (size_t(d->block_ctx_lut_size) < size_t(3) * 13 * ep.nq * ep.ndc) return JXLHIP_ERR_INVALID_ARGUMENT;
+
+  jxlhip::TransformParams& tp = c->tp;
+  memset(&tp, 0, sizeof(tp));
+  tp.coeffs = c->coeffs.p;
+  tp.coef_bits = d->coef_bits;
+  tp.blocks = c->blocks.as<JxlHipVarBlock>();
+  tp.dequant = c->dequant.as<float>();
+  memcpy(tp.dq_offset, d->dequant_offset, sizeof(tp.dq_offset));
+  memcpy(tp.dq_size, d->dequant_size, sizeof(tp.dq_size));
+  for (int s = 0; s < 27; s++) {
+    static const uint8_t qt[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+    static const uint16_t areas[27] = {1, 1, 1, 1, 4, 16, 2, 2, 4, 4, 8, 8, 1, 1, 1, 1, 1, 1, 64, 32, 32, 256, 128, 128, 1024, 512, 512};
+    if (c->list_count[s] == 0) continue;
+    const uint32_t k = qt[s];
+    if (d->dequant_size[k] != 64u * areas[s] || size_t(d->dequant_offset[k]) + 3 * size_t(d->dequant_size[k]) > d->dequant_floats)
+      return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
+  tp.dc = c->dc.as<float>();
+  tp.ytox = c->ytox.as<int8_t>();
+  tp.ytob = c->ytob.as<int8_t>();
+  tp.basis_t = c->basis.as<float>();
+  tp.inv_global_scale = d->inv_global_scale;
+  tp.x_dm = d->x_dm;
+  tp.b_dm = d->b_dm;
+  tp.color_scale = d->color_scale;
+  tp.base_x = d->base_corr_x;
+  tp.base_b = d->base_corr_b;
+  memcpy(tp.biases, d->quant_biases, sizeof(tp.biases));
+  tp.xb = c->xb; tp.yb = c->yb; tp.xg = c->xg; tp.xp = c->xp; tp.yp = c->yp;
+  tp.out = c->plane[0].as<float>();
+  tp.scratch = c->scratch.as<float>();
+
+  jxlhip::FilterParams& fp = c->fp;
+  memset(&fp, 0, sizeof(fp));
+  fp.xs = c->xs; fp.ys = c->ys; fp.xp = c->xp; fp.yp = c->yp; fp.xb = c->xb;
+  fp.inv_sigma = c->inv_sigma.as<float>();
+  for (int ch = 0; ch < 3; ch++) {
+    const float w1 = d->gab_w[ch * 2], w2 = d->gab_w[ch * 2 + 1];
+    const float mul = 1.0f / (1.0f + 4 * (w1 + w2));
+    fp.gab_w[ch * 3] = mul;
+    fp.gab_w[ch * 3 + 1] = w1 * mul;
+    fp.gab_w[ch * 3 + 2] = w2 * mul;
+    fp.ch_scale[ch] = d->epf_channel_scale[ch];
+    fp.opsin_bias[ch] = d->opsin_bias[ch];
+    fp.opsin_bias_cbrt[ch] = cbrtf(d->opsin_bias[ch]);
+  }
+  memcpy(fp.opsin_inv, d->opsin_inv, sizeof(fp.opsin_inv));
+  fp.linear_output = d->linear_output;
+  fp.rgb = c->rgb.as<uint8_t>();
+  c->epf_pass0 = d->epf_pass0_sigma_scale;
+  c->epf_pass2 = d->epf_pass2_sigma_scale;
+  c->epf_border = d->epf_border_sad_mul;
+  c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = false;
+  c->have_frame = true;
+  return 0;
+}
+
+}  // extern "C"
+
+template <typename CoefT>
+static int LaunchEntropy(JxlHipContext* c) {
+  const dim3 grid(c->ng), block(64);
+  if (c->alias_lds) {
+    auto k = jxlhip::k_entropy_ans<CoefT, true>;
+    if (c->lds_entropy > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_entropy)));
+    hipLaunchKernelGGL(k, grid, block, c->lds_entropy, c->stream, c->ep);
+  } else {
+    auto k = jxlhip::k_entropy_ans<CoefT, false>;
+    hipLaunchKernelGGL(k, grid, block, c->lds_entropy, c->stream, c->ep);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(c->ng) * 4, c->stream));
+  int r = c->coef_bits == 16 ? LaunchEntropy<int16_t>(c) : LaunchEntropy<int32_t>(c);
+  if (r) return r;
+  HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+  c->ev_valid[0] = true;
+  return 0;
+}
+
+template <typename CoefT, int CX, int CY>
+static void LaunchDct(JxlHipContext* c, int s) {
+  constexpr int SIZE = CX * CY * 64;
+  constexpr int TPB = SIZE >= 256 ? 256 : SIZE;
+  constexpr int BPW = 256 / TPB;
+  const uint32_t n = c->list_count[s];
+  const dim3 grid((n + BPW - 1) / BPW), block(256);
+  const size_t lds = size_t(BPW) * 2 * SIZE * sizeof(float);
+  hipLaunchKernelGGL((jxlhip::k_dct<CoefT, CX, CY>), grid, block, lds, c->stream, c->tp, c->tlist.as<uint32_t>() + c->list_begin[s], n,
+                     uint32_t(s));
+}
+
+template <typename CoefT>
+static int LaunchTransforms(JxlHipContext* c) {
+  for (int s = 0; s < 27; s++) {
+    const uint32_t n = c->list_count[s];
+    if (!n) continue;
+    const uint32_t* list = c->tlist.as<uint32_t>() + c->list_begin[s];
+    switch (s) {
+      case 0: LaunchDct<CoefT, 1, 1>(c, s); break;
+      case 4: LaunchDct<CoefT, 2, 2>(c, s); break;
+      case 5: LaunchDct<CoefT, 4, 4>(c, s); break;
+      case 6: LaunchDct<CoefT, 1, 2>(c, s); break;
+      case 7: LaunchDct<CoefT, 2, 1>(c, s); break;
+      case 8: LaunchDct<CoefT, 1, 4>(c, s); break;
+      case 9: LaunchDct<CoefT, 4, 1>(c, s); break;
+      case 10: LaunchDct<CoefT, 2, 4>(c, s); break;
+      case 11: LaunchDct<CoefT, 4, 2>(c, s); break;
+      case 18: LaunchDct<CoefT, 8, 8>(c, s); break;
+      case 19: LaunchDct<CoefT, 4, 8>(c, s); break;
+      case 20: LaunchDct<CoefT, 8, 4>(c, s); break;
+      case 21: case 22: case 23: case 24: case 25: case 26: {
+        for (uint32_t i = 0; i < n; i += 32) {
+          const uint32_t m = n - i < 32 ? n - i : 32;
+          hipLaunchKernelGGL((jxlhip::k_dct_big<CoefT>), dim3(m * 3), dim3(256), 0, c->stream, c->tp, list + i, m, uint32_t(s));
+        }
+        break;
+      }
+      default:
+        hipLaunchKernelGGL((jxlhip::k_special<CoefT>), dim3((n + 3) / 4), dim3(256), 0, c->stream, c->tp, list, n, uint32_t(s));
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" {
+
+int jxlhip_run_transform(JxlHipContext* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+  int r = c->coef_bits == 16 ? LaunchTransforms<int16_t>(c) : LaunchTransforms<int32_t>(c);
+  if (r) return r;
+  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
+  c->ev_valid[1] = true;
+  return 0;
+}
+
+int jxlhip_run_filter_color(JxlHipContext* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->ev[4], c->stream));
+  const dim3 grid((c->xs + 63) / 64, (c->ys + 3) / 4), block(256);
+  int cur = 0;
+  jxlhip::FilterParams fp = c->fp;
+  auto next = [&](int a) { return a == 1 ? 2 : 1; };
+  if (c->gab) {
+    fp.in = c->plane[cur].as<float>();
+    fp.out = c->plane[next(cur)].as<float>();
+    hipLaunchKernelGGL(jxlhip::k_gaborish, grid, block, 0, c->stream, fp);
+    cur = next(cur);
+  }
+  for (int stage = 0; stage < 3; stage++) {
+    const bool run = (stage == 0 && c->epf_iters >= 3) || (stage == 1 && c->epf_iters >= 1) || (stage == 2 && c->epf_iters >= 2);
+    if (!run) continue;
+    const float scale = stage == 0 ? c->epf_pass0 : stage == 2 ? c->epf_pass2 : 1.0f;
+    fp.sm = stage == 1 ? 1.65f : float(scale * 1.65);
+    fp.bsm = fp.sm * c->epf_border;
+    fp.in = c->plane[cur].as<float>();
+    fp.out = c->plane[next(cur)].as<float>();
+    if (stage == 0) hipLaunchKernelGGL(jxlhip::k_epf<0>, grid, block, 0, c->stream, fp);
+    if (stage == 1) hipLaunchKernelGGL(jxlhip::k_epf<1>, grid, block, 0, c->stream, fp);
+    if (stage == 2) hipLaunchKernelGGL(jxlhip::k_epf<2>, grid, block, 0, c->stream, fp);
+    cur = next(cur);
+  }
+  c->final_plane = cur;
+  fp.in = c->plane[cur].as<float>();
+  hipLaunchKernelGGL(jxlhip::k_color, grid, block, 0, c->stream, fp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[5], c->stream));
+  c->ev_valid[2] = true;
+  return 0;
+}
+
+int jxlhip_run_all(JxlHipContext* c) {
+  int r = jxlhip_run_entropy(c);
+  if (!r) r = jxlhip_run_transform(c);
+  if (!r) r = jxlhip_run_filter_color(c);
+  return r;
+}
+
+int jxlhip_sync(JxlHipContext* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
+  if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  if (stride < size_t(c->xs) * 3) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, size_t(c->xs) * 3, size_t(c->xs) * 3, c->ys, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+const uint8_t* jxlhip_rgb8_device_ptr(JxlHipContext* c) { return c && c->have_frame ? c->rgb.as<uint8_t>() : nullptr; }
+
+int jxlhip_get_errors(JxlHipContext* c, uint32_t* flags, size_t n) {
+  if (!c || !flags) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  if (n < c->ng) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(flags, c->errors.p, size_t(c->ng) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (uint32_t g = 0; g < c->ng; g++)
+    if (flags[g]) return JXLHIP_ERR_STREAM;
+  return 0;
+}
+
+int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_size, size_t* needed) {
+  if (!c || !name) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  const std::string n(name);
+  const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
+  if (n == "coeffs") {
+    src = c->coeffs.p;
+    bytes = size_t(c->ng) * 3 * 65536 * (c->coef_bits / 8);
+  } else if (n == "xyb_idct") {
+    src = c->plane[0].p;
+    bytes = plane_bytes;
+  } else if (n == "xyb_filtered") {
+    src = c->plane[c->final_plane].p;
+    bytes = plane_bytes;
+  } else {
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
+  if (needed) *needed = bytes;
+  if (!dst) return 0;
+  if (dst_size < bytes) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int jxlhip_last_stage_ms(JxlHipContext* c, int which, float* ms) {
+  if (!c || !ms || which < 0 || which > 2) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->ev_valid[which]) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->ev[which * 2 + 1]));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev[which * 2], c->ev[which * 2 + 1]));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,759 @@
+// libjxl_amd — HIP kernels of the VarDCT decode hot path for gfx950 (MI355X). Device code only; the C ABI that
+// launches it is in jxl_hip_api.hip. No CPU implementation of these stages exists in the product.
+//
+// Kernels and the reference code they replace:
+//   k_entropy_ans   lib/jxl/dec_group.cc:469-542,594-639 + dec_ans.h:170-257 + ans_common.h:102-142
+//   k_dct<CX,CY>    lib/jxl/dec_group.cc:115-181 (dequant, CfL), dec_transforms-inl.h:691-818 (LLF from DC),
+//                   dct-inl.h:376-397 (scaled IDCT, evaluated here in its separable matrix form)
+//   k_special       dec_transforms-inl.h:66-93,95-454,463-568 (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3)
+//   k_dct_big       same as k_dct for 128/256-class transforms (global scratch instead of LDS)
+//   k_gaborish      render_pipeline/stage_gaborish.cc:56-100
+//   k_epf<STAGE>    render_pipeline/stage_epf.cc:82-494
+//   k_color         stage_xyb.cc:80-92, dec_xyb-inl.h:38-86, stage_from_linear.cc:114-144,
+//                   cms/transfer_functions-inl.h:245-268, stage_write.cc:266-286,548-590
+#ifndef JXL_HIP_KERNELS_H_
+#define JXL_HIP_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/jxl_amd_hip.h"
+
+namespace jxlhip {
+
+// ---------------------------------------------------------------------------------------------- constants
+__constant__ uint8_t c_covered_x[27] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
+__constant__ uint8_t c_covered_y[27] = {1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1, 1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16};
+__constant__ uint8_t c_log2_covered[27] = {0, 0, 0, 0, 2, 4, 1, 1, 2, 2, 3, 3, 0, 0, 0, 0, 0, 0, 6, 5, 5, 8, 7, 7, 10, 9, 9};
+__constant__ uint8_t c_strategy_order[27] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+__constant__ uint8_t c_strategy_qtable[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+__constant__ uint16_t c_coeff_freq_ctx[64] = {
+    0,  0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 15, 16, 16, 17, 17,
+    18, 18, 19, 19, 20, 20, 21, 21, 22, 22, 23, 23, 23, 23, 24, 24, 24, 24, 25, 25, 25, 25,
+    26, 26, 26, 26, 27, 27, 27, 27, 28, 28, 28, 28, 29, 29, 29, 29, 30, 30, 30, 30};
+__constant__ uint16_t c_coeff_nnz_ctx[64] = {
+    0,   0,   31,  62,  62,  93,  93,  93,  93,  123, 123, 123, 123, 152, 152, 152, 152, 152, 152, 152, 152, 180,
+    180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
+    206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206};
+// AFV basis and dither tables are uploaded at context creation (see jxl_hip_api.hip).
+__constant__ float c_afv_basis[16 * 16];
+__constant__ float c_dither[32 * 32];
+// Resample scales mapping coefficient i of an n-point DCT to an 8n-point DCT; entry [n - 1 + i], n in {1,2,4,8,16,32}.
+__constant__ float c_resample[63];
+
+static const uint32_t kErrNzeros = 1, kErrFinalState = 2, kErrOverread = 4, kErrSelector = 8;
+
+struct PassDev {
+  const uint8_t* ctx_map;
+  const uint2* alias;
+  const uint32_t* cfg;
+  const uint16_t* orders;
+  uint32_t order_offset[39];
+  uint32_t log_alpha, num_clusters, shift, alias_lds;
+};
+
+struct EntropyParams {
+  const uint32_t* sections;   // all AC sections, each starting at a 16-byte aligned offset
+  const uint32_t* sec_word;   // [pass * num_groups + group] start, in 32-bit words
+  const uint32_t* sec_size;   // bytes
+  uint32_t first_bit_offset;
+  const JxlHipVarBlock* blocks;
+  const uint32_t* gbb;
+  const uint8_t* bctx_lut;
+  uint32_t nq, ndc, num_bctx;
+  uint32_t qf_thr[16];
+  uint32_t num_hist, nctx;  // nctx = num_bctx * 495
+  const PassDev* passes;
+  uint32_t num_passes, num_groups;
+  void* coeffs;
+  uint32_t* errors;
+  uint32_t lds_ctx_bytes, lds_alias_bytes;
+};
+
+struct BitReader {
+  const uint32_t* p;
+  uint32_t idx, nwords;
+  uint64_t buf;
+  int bits;
+};
+__device__ __forceinline__ void BrRefill(BitReader& b) {
+  if (b.bits < 32) {
+    uint32_t w = b.idx < b.nwords ? b.p[b.idx] : 0u;
+    b.idx++;
+    b.buf |= uint64_t(w) << b.bits;
+    b.bits += 32;
+  }
+}
+__device__ __forceinline__ uint32_t BrRead(BitReader& b, uint32_t n) {  // n <= 32, caller refilled
+  uint32_t v = uint32_t(b.buf & ((uint64_t(1) << n) - 1));
+  b.buf >>= n;
+  b.bits -= int(n);
+  return v;
+}
+
+// One rANS symbol + hybrid-uint extra bits from `cluster`.
+template <bool ALIAS_LDS>
+__device__ __forceinline__ uint32_t ReadHybrid(BitReader& br, uint32_t& state, uint32_t cluster, const uint2* alias_g,
+                                               const uint2* alias_l, const uint32_t* cfg, uint32_t log_alpha) {
+  const uint32_t log_entry = 12 - log_alpha;
+  const uint32_t res = state & 0xFFFu;
+  const uint32_t i = res >> log_entry;
+  const uint32_t pos = res & ((1u << log_entry) - 1);
+  const uint2 e = ALIAS_LDS ? alias_l[(cluster << log_alpha) + i] : alias_g[(cluster << log_alpha) + i];
+  const uint32_t cutoff = e.x & 0xFF, right = (e.x >> 8) & 0xFF, freq0 = e.x >> 16;
+  const uint32_t offsets1 = e.y & 0xFFFF, freq1 = e.y >> 16;
+  const bool greater = pos >= cutoff;
+  const uint32_t token = greater ? right : i;
+  const uint32_t off = (greater ? offsets1 : 0u) + pos;
+  const uint32_t freq = greater ? freq1 : freq0;
+  state = freq * (state >> 12) + off;
+  BrRefill(br);
+  if (state < (1u << 16)) state = (state << 16) | BrRead(br, 16);
+  const uint32_t c = cfg[cluster];
+  const uint32_t split_exp = c & 0xFF, msb = (c >> 8) & 0xFF, lsb = (c >> 16) & 0xFF;
+  const uint32_t split_token = 1u << split_exp;
+  if (token < split_token) return token;
+  uint32_t nbits = split_exp - (msb + lsb) + ((token - split_token) >> (msb + lsb));
+  nbits &= 31u;
+  const uint32_t low = token & ((1u << lsb) - 1);
+  const uint32_t hi = token >> lsb;
+  BrRefill(br);
+  const uint32_t bits = BrRead(br, nbits);
+  return (((((1u << msb) | (hi & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
+}
+
+// One 64-lane workgroup per 256x256 group. All lanes zero the group's coefficient planes and stage the entropy
+// tables in LDS; lane 0 then walks the (inherently serial) adaptive-context rANS stream.
+template <typename CoefT, bool ALIAS_LDS>
+__global__ __launch_bounds__(64) void k_entropy_ans(EntropyParams P) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  const uint32_t g = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  uint8_t* l_ctx = lds_raw;
+  uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + P.lds_ctx_bytes);
+  uint8_t* l_nz = lds_raw + P.lds_ctx_bytes + P.lds_alias_bytes;  // 3 * 1024
+  const uint32_t b0 = P.gbb[g], b1 = P.gbb[g + 1];
+  CoefT* gco = static_cast<CoefT*>(P.coeffs) + size_t(g) * 3 * 65536;
+  // total coefficients per channel in this group
+  uint32_t total = 0;
+  if (b1 > b0) {
+    const JxlHipVarBlock last = P.blocks[b1 - 1];
+    total = last.coef_offset + (64u << c_log2_covered[last.strategy]);
+  }
+  for (uint32_t pass = 0; pass < P.num_passes; pass++) {
+    const PassDev& T = P.passes[pass];
+    const uint32_t sec = pass * P.num_groups + g;
+    __syncthreads();
+    if (pass == 0) {
+      // zero fill (16-byte stores)
+      const uint32_t n16 = (total * uint32_t(sizeof(CoefT))) / 16;
+      for (int c = 0; c < 3; c++) {
+        uint4* dst = reinterpret_cast<uint4*>(gco + size_t(c) * 65536);
+        for (uint32_t i = lane; i < n16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    for (uint32_t i = lane; i < 3 * 1024; i += 64) l_nz[i] = 0;
+    // histogram selector is read by lane 0 first; all lanes then stage that slice of the context map
+    __shared__ uint32_t s_sel, s_state;
+    __shared__ BitReader s_br;
+    if (lane == 0) {
+      BitReader br;
+      br.p = P.sections + P.sec_word[sec];
+      br.nwords = (P.sec_size[sec] + 3) / 4;
+      br.idx = 0;
+      br.buf = 0;
+      br.bits = 0;
+      BrRefill(br);
+      if (sec == 0 && P.first_bit_offset) BrRead(br, P.first_bit_offset);
+      uint32_t hb = 0;
+      while ((1u << hb) < P.num_hist) hb++;
+      BrRefill(br);
+      uint32_t sel = hb ? BrRead(br, hb) : 0;
+      if (sel >= P.num_hist) {
+        atomicOr(&P.errors[g], kErrSelector);
+        sel = 0;
+      }
+      BrRefill(br);
+      uint32_t st = BrRead(br, 16);
+      BrRefill(br);
+      st |= BrRead(br, 16) << 16;
+      s_sel = sel;
+      s_state = st;
+      s_br = br;
+    }
+    __syncthreads();
+    {
+      const uint8_t* src = T.ctx_map + size_t(s_sel) * P.nctx;
+      for (uint32_t i = lane; i < P.nctx + 16; i += 64) l_ctx[i] = src[i];
+      if (ALIAS_LDS) {
+        const uint32_t n = T.num_clusters << T.log_alpha;
+        for (uint32_t i = lane; i < n; i += 64) l_alias[i] = T.alias[i];
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane != 0) continue;
+
+    BitReader br = s_br;
+    uint32_t state = s_state;
+    const uint32_t log_alpha = T.log_alpha;
+    const uint32_t shift = T.shift;
+    uint32_t err = 0;
+    for (uint32_t bi = b0; bi < b1 && !err; bi++) {
+      const JxlHipVarBlock vb = P.blocks[bi];
+      const uint32_t st = vb.strategy;
+      const uint32_t cx = c_covered_x[st], cy = c_covered_y[st], log2c = c_log2_covered[st];
+      const uint32_t covered = 1u << log2c, size = covered * 64;
+      const uint32_t ord = c_strategy_order[st];
+      uint32_t qfi = 0;
+      for (uint32_t t = 0; t + 1 < P.nq; t++) qfi += vb.qf > P.qf_thr[t];
+      const uint32_t lbx = vb.bx & 31, lby = vb.by & 31;
+#pragma unroll 1
+      for (int ci = 0; ci < 3 && !err; ci++) {
+        const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+        uint8_t* nzc = l_nz + c * 1024;
+        uint32_t pred;
+        if (lbx == 0) pred = lby ? nzc[(lby - 1) * 32] : 32;
+        else if (lby == 0) pred = nzc[lbx - 1];
+        else pred = (uint32_t(nzc[(lby - 1) * 32 + lbx]) + nzc[lby * 32 + lbx - 1] + 1) >> 1;
+        const uint32_t bctx = P.bctx_lut[((c * 13 + ord) * P.nq + qfi) * P.ndc + vb.quant_dc_ctx];
+        uint32_t nzb = pred >= 64 ? 64 : pred;
+        nzb = nzb < 8 ? nzb : 4 + nzb / 2;
+        uint32_t nzeros = ReadHybrid<ALIAS_LDS>(br, state, l_ctx[nzb * P.num_bctx + bctx], T.alias, l_alias, T.cfg, log_alpha);
+        if (nzeros > size - covered) {
+          err = kErrNzeros;
+          break;
+        }
+        const uint8_t nzv = uint8_t((nzeros + covered - 1) >> log2c);
+        for (uint32_t y = 0; y < cy; y++)
+          for (uint32_t x = 0; x < cx; x++) nzc[(lby + y) * 32 + lbx + x] = nzv;
+        const uint32_t hoff = P.num_bctx * 37 + 458 * bctx;
+        const uint16_t* order = T.orders + T.order_offset[ord * 3 + c];
+        CoefT* dst = gco + size_t(c) * 65536 + vb.coef_offset;
+        uint32_t prev = nzeros > size / 16 ? 0 : 1;
+        for (uint32_t k = covered; k < size && nzeros != 0; ++k) {
+          const uint32_t nzl = (nzeros + covered - 1) >> log2c;
+          const uint32_t ctx = hoff + (uint32_t(c_coeff_nnz_ctx[nzl & 63]) + c_coeff_freq_ctx[(k >> log2c) & 63]) * 2 + prev;
+          const uint32_t u = ReadHybrid<ALIAS_LDS>(br, state, l_ctx[ctx], T.alias, l_alias, T.cfg, log_alpha);
+          const uint32_t mag = u >> 1, neg = (~u) & 1;
+          const int32_t coeff = int32_t((mag ^ (neg - 1)) << shift);
+          if (u) {
+            const uint32_t pos = order[k];
+            if (pass == 0) dst[pos] = CoefT(coeff);
+            else dst[pos] = CoefT(dst[pos] + coeff);
+          }
+          prev = u != 0;
+          nzeros -= prev;
+        }
+        if (nzeros != 0) err = kErrNzeros;
+      }
+    }
+    if (!err && state != (0x13u << 16)) err |= kErrFinalState;
+    {
+      const uint64_t consumed = uint64_t(br.idx) * 32 - uint64_t(br.bits);
+      if (consumed > uint64_t(P.sec_size[sec]) * 8) err |= kErrOverread;
+    }
+    if (err) atomicOr(&P.errors[g], err);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- transforms
+struct TransformParams {
+  const void* coeffs;
+  uint32_t coef_bits;
+  const JxlHipVarBlock* blocks;
+  const float* dequant;
+  uint32_t dq_offset[17], dq_size[17];
+  const float* dc;  // 3 planes
+  const int8_t* ytox;
+  const int8_t* ytob;
+  const float* basis_t;  // BT_N[k * N + n], N = 1..256, offset (N*N-1)/3
+  float inv_global_scale, x_dm, b_dm, color_scale, base_x, base_b;
+  float biases[4];
+  uint32_t xb, yb, xg, xp, yp;
+  float* out;  // 3 planes of xp * yp
+  float* scratch;
+};
+
+__device__ __forceinline__ float QuantBias(int c, int q, const float* b) {
+  if (q == 0) return 0.0f;
+  if (q == 1) return b[c];
+  if (q == -1) return -b[c];
+  const float qf = float(q);
+  return qf - b[3] * (1.0f / qf);
+}
+
+template <typename CoefT>
+__device__ __forceinline__ float DequantOne(const TransformParams& P, const CoefT* gq, uint32_t k, int c, const float* m,
+                                            uint32_t msize, float sc, float x_cc, float b_cc) {
+  // channel c of coefficient k; X and B add the chroma-from-luma term derived from the dequantised Y
+  const int qy = int(gq[65536 + k]);
+  const float dy = QuantBias(1, qy, P.biases) * (m[msize + k] * sc);
+  if (c == 1) return dy;
+  if (c == 0) return x_cc * dy + QuantBias(0, int(gq[k]), P.biases) * (m[k] * (sc * P.x_dm));
+  return b_cc * dy + QuantBias(2, int(gq[2 * 65536 + k]), P.biases) * (m[2 * msize + k] * (sc * P.b_dm));
+}
+
+__device__ __forceinline__ uint32_t BasisOffset(uint32_t n) { return (n * n - 1) / 3; }
+
+// Lowest-frequency coefficient (ky, kx) of a CY x CX varblock from the DC image (scaled forward DCT of the
+// covered DC samples times the resample scales).
+template <int CX, int CY>
+__device__ __forceinline__ float LlfFromDc(const TransformParams& P, const float* dc, int ky, int kx) {
+  const float* bty = P.basis_t + BasisOffset(CY);
+  const float* btx = P.basis_t + BasisOffset(CX);
+  float s = 0.0f;
+  for (int y = 0; y < CY; y++) {
+    float r = 0.0f;
+    for (int x = 0; x < CX; x++) r += dc[y * P.xb + x] * btx[kx * CX + x];
+    s += r * bty[ky * CY + y];
+  }
+  s *= 1.0f / float(CX * CY);
+  return s * c_resample[CY - 1 + ky] * c_resample[CX - 1 + kx];
+}
+
+// DCT-family strategies up to 64x64: per channel, dequantised coefficients are staged in LDS and the separable
+// inverse transform is evaluated as two matrix passes (LDS-resident tile, coalesced plane writes).
+template <typename CoefT, int CX, int CY>
+__global__ __launch_bounds__(256) void k_dct(TransformParams P, const uint32_t* list, uint32_t n, uint32_t strategy) {
+  constexpr int R = CY * 8, C = CX * 8, SIZE = R * C;
+  constexpr int TPB = SIZE >= 256 ? 256 : SIZE;
+  constexpr int BPW = 256 / TPB;
+  extern __shared__ __align__(16) float lds_f[];
+  const int sub = threadIdx.x / TPB, t = threadIdx.x % TPB;
+  float* l_coef = lds_f + sub * 2 * SIZE;
+  float* l_tmp = l_coef + SIZE;
+  const uint32_t li = blockIdx.x * BPW + sub;
+  const bool active = li < n;
+  JxlHipVarBlock vb;
+  const CoefT* gq = nullptr;
+  const float* m = nullptr;
+  uint32_t msize = 0;
+  float sc = 0, x_cc = 0, b_cc = 0;
+  if (active) {
+    vb = P.blocks[list[li]];
+    const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
+    gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
+    const uint32_t kind = c_strategy_qtable[strategy];
+    m = P.dequant + P.dq_offset[kind];
+    msize = P.dq_size[kind];
+    sc = P.inv_global_scale / float(vb.qf);
+    const uint32_t tiles_x = (P.xb + 7) / 8;
+    const uint32_t tile = (vb.by / 8) * tiles_x + vb.bx / 8;
+    x_cc = P.base_x + float(P.ytox[tile]) * P.color_scale;
+    b_cc = P.base_b + float(P.ytob[tile]) * P.color_scale;
+  }
+  const float* btc = P.basis_t + BasisOffset(C);
+  const float* btr = P.basis_t + BasisOffset(R);
+  for (int c = 0; c < 3; c++) {
+    if (active) {
+      for (int k = t; k < SIZE; k += TPB) l_coef[k] = DequantOne<CoefT>(P, gq, k, c, m, msize, sc, x_cc, b_cc);
+    }
+    __syncthreads();
+    if (active && t < CX * CY) {
+      const float* dc = P.dc + size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
+      // LLF corner: rows = short side
+      constexpr int LC = CX > CY ? CX : CY;  // long side
+      const int row = t / LC, col = t % LC;
+      int ky, kx;
+      if (CY < CX) { ky = row; kx = col; } else { kx = row; ky = col; }
+      l_coef[row * (LC * 8) + col] = LlfFromDc<CX, CY>(P, dc, ky, kx);
+    }
+    __syncthreads();
+    if (active) {
+      // pass A: tmp[ky][x] = sum_kx coef(ky,kx) * B_C[x][kx]
+      for (int i = t; i < SIZE; i += TPB) {
+        const int ky = i / C, x = i % C;
+        float s = 0.0f;
+        if (R < C) {
+#pragma unroll 8
+          for (int kx = 0; kx < C; kx++) s += l_coef[ky * C + kx] * btc[kx * C + x];
+        } else {
+#pragma unroll 8
+          for (int kx = 0; kx < C; kx++) s += l_coef[kx * R + ky] * btc[kx * C + x];
+        }
+        l_tmp[i] = s;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      float* out = P.out + size_t(c) * P.xp * P.yp + size_t(vb.by) * 8 * P.xp + size_t(vb.bx) * 8;
+      for (int i = t; i < SIZE; i += TPB) {
+        const int y = i / C, x = i % C;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int ky = 0; ky < R; ky++) s += l_tmp[ky * C + x] * btr[ky * R + y];
+        out[size_t(y) * P.xp + x] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// 128/256-class transforms: one workgroup per (varblock, channel), intermediates in global scratch.
+template <typename CoefT>
+__global__ __launch_bounds__(256) void k_dct_big(TransformParams P, const uint32_t* list, uint32_t n, uint32_t strategy) {
+  const uint32_t li = blockIdx.x / 3;
+  const int c = blockIdx.x % 3;
+  if (li >= n) return;
+  const uint32_t CX = c_covered_x[strategy], CY = c_covered_y[strategy];
+  const uint32_t R = CY * 8, C = CX * 8, SIZE = R * C;
+  const JxlHipVarBlock vb = P.blocks[list[li]];
+  const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
+  const CoefT* gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
+  const uint32_t kind = c_strategy_qtable[strategy];
+  const float* m = P.dequant + P.dq_offset[kind];
+  const uint32_t msize = P.dq_size[kind];
+  const float sc = P.inv_global_scale / float(vb.qf);
+  const uint32_t tiles_x = (P.xb + 7) / 8;
+  const uint32_t tile = (vb.by / 8) * tiles_x + vb.bx / 8;
+  const float x_cc = P.base_x + float(P.ytox[tile]) * P.color_scale;
+  const float b_cc = P.base_b + float(P.ytob[tile]) * P.color_scale;
+  float* s_coef = P.scratch + size_t(blockIdx.x) * 2 * 65536;
+  float* s_tmp = s_coef + 65536;
+  for (uint32_t k = threadIdx.x; k < SIZE; k += 256) s_coef[k] = DequantOne<CoefT>(P, gq, k, c, m, msize, sc, x_cc, b_cc);
+  __threadfence_block();
+  __syncthreads();
+  {
+    const float* dc = P.dc + size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
+    const float* bty = P.basis_t + BasisOffset(CY);
+    const float* btx = P.basis_t + BasisOffset(CX);
+    const uint32_t LC = CX > CY ? CX : CY;
+    for (uint32_t i = threadIdx.x; i < CX * CY; i += 256) {
+      const uint32_t row = i / LC, col = i % LC;
+      uint32_t ky, kx;
+      if (CY < CX) { ky = row; kx = col; } else { kx = row; ky = col; }
+      float s = 0.0f;
+      for (uint32_t y = 0; y < CY; y++) {
+        float r = 0.0f;
+        for (uint32_t x = 0; x < CX; x++) r += dc[y * P.xb + x] * btx[kx * CX + x];
+        s += r * bty[ky * CY + y];
+      }
+      s *= 1.0f / float(CX * CY);
+      s_coef[row * (LC * 8) + col] = s * c_resample[CY - 1 + ky] * c_resample[CX - 1 + kx];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const float* btc = P.basis_t + BasisOffset(C);
+  const float* btr = P.basis_t + BasisOffset(R);
+  for (uint32_t i = threadIdx.x; i < SIZE; i += 256) {
+    const uint32_t ky = i / C, x = i % C;
+    float s = 0.0f;
+    if (R < C) {
+      for (uint32_t kx = 0; kx < C; kx++) s += s_coef[ky * C + kx] * btc[kx * C + x];
+    } else {
+      for (uint32_t kx = 0; kx < C; kx++) s += s_coef[kx * R + ky] * btc[kx * C + x];
+    }
+    s_tmp[i] = s;
+  }
+  __threadfence_block();
+  __syncthreads();
+  float* out = P.out + size_t(c) * P.xp * P.yp + size_t(vb.by) * 8 * P.xp + size_t(vb.bx) * 8;
+  for (uint32_t i = threadIdx.x; i < SIZE; i += 256) {
+    const uint32_t y = i / C, x = i % C;
+    float s = 0.0f;
+    for (uint32_t ky = 0; ky < R; ky++) s += s_tmp[ky * C + x] * btr[ky * R + y];
+    out[size_t(y) * P.xp + x] = s;
+  }
+}
+
+// 4-point / 8-point scaled IDCT basis value C_N(n, k).
+__device__ __forceinline__ float B4(const float* bt4, int n, int k) { return bt4[k * 4 + n]; }
+__device__ __forceinline__ float B8(const float* bt8, int n, int k) { return bt8[k * 8 + n]; }
+
+// 8x8-coverage special transforms; 64 threads per varblock (one per pixel), 4 varblocks per workgroup.
+template <typename CoefT>
+__global__ __launch_bounds__(256) void k_special(TransformParams P, const uint32_t* list, uint32_t n, uint32_t strategy) {
+  __shared__ float l_all[4][2][64];
+  const int sub = threadIdx.x >> 6, t = threadIdx.x & 63;
+  float* co = l_all[sub][0];
+  float* buf = l_all[sub][1];
+  const uint32_t li = blockIdx.x * 4 + sub;
+  const bool active = li < n;
+  JxlHipVarBlock vb;
+  const CoefT* gq = nullptr;
+  const float* m = nullptr;
+  uint32_t msize = 0;
+  float sc = 0, x_cc = 0, b_cc = 0;
+  if (active) {
+    vb = P.blocks[list[li]];
+    const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
+    gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
+    const uint32_t kind = c_strategy_qtable[strategy];
+    m = P.dequant + P.dq_offset[kind];
+    msize = P.dq_size[kind];
+    sc = P.inv_global_scale / float(vb.qf);
+    const uint32_t tiles_x = (P.xb + 7) / 8;
+    const uint32_t tile = (vb.by / 8) * tiles_x + vb.bx / 8;
+    x_cc = P.base_x + float(P.ytox[tile]) * P.color_scale;
+    b_cc = P.base_b + float(P.ytob[tile]) * P.color_scale;
+  }
+  const float* bt4 = P.basis_t + BasisOffset(4);
+  const float* bt8 = P.basis_t + BasisOffset(8);
+  const int py = t >> 3, px = t & 7;
+  for (int c = 0; c < 3; c++) {
+    if (active) {
+      float v = DequantOne<CoefT>(P, gq, t, c, m, msize, sc, x_cc, b_cc);
+      if (t == 0) v = P.dc[size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx];
+      co[t] = v;
+    }
+    __syncthreads();
+    float result = 0.0f;
+    if (strategy == 1) {  // IDENTITY
+      if (active) {
+        const int y = py >> 2, x = px >> 2, iy = py & 3, ix = px & 3;
+        const float b00 = co[0], b01 = co[1], b10 = co[8], b11 = co[9];
+        const float sy = y ? -1.0f : 1.0f, sx = x ? -1.0f : 1.0f;
+        // dcs[y*2+x] = b00 + sy*b01 + sx*b10 + sy*sx*b11
+        const float block_dc = b00 + sy * b01 + sx * b10 + sx * sy * b11;
+        float rs = 0.0f;
+        for (int jy = 0; jy < 4; jy++)
+          for (int jx = 0; jx < 4; jx++)
+            if (jx || jy) rs += co[(y + jy * 2) * 8 + x + jx * 2];
+        const float base = block_dc - rs * (1.0f / 16);
+        if (iy == 1 && ix == 1) result = base;
+        else if (iy == 0 && ix == 0) result = co[(y + 2) * 8 + x + 2] + base;
+        else result = co[(y + iy * 2) * 8 + x + ix * 2] + base;
+      }
+    } else if (strategy == 2) {  // DCT2X2: three 2x2 Hadamard stages
+      float* src = co;
+      float* dst = buf;
+      for (int S = 2; S <= 8; S *= 2) {
+        const int h = S / 2;
+        float v = 0.0f;
+        if (active) {
+          v = src[t];
+          if (py < S && px < S) {
+            const int y = py >> 1, x = px >> 1;
+            const float c00 = src[y * 8 + x], c01 = src[y * 8 + h + x], c10 = src[(y + h) * 8 + x], c11 = src[(y + h) * 8 + h + x];
+            // output parity (py&1, px&1): (0,0) + + + +, (0,1) + + - -, (1,0) + - + -, (1,1) + - - +
+            const float s01 = (py & 1) ? -1.0f : 1.0f, s10 = (px & 1) ? -1.0f : 1.0f;
+            v = c00 + s01 * c01 + s10 * c10 + (s01 * s10) * c11;
+          }
+          dst[t] = v;
+        }
+        __syncthreads();
+        float* tmp = src;
+        src = dst;
+        dst = tmp;
+      }
+      if (active) result = src[t];
+    } else if (strategy == 3) {  // DCT4X4
+      if (active) {
+        const int y = py >> 2, x = px >> 2, iy = py & 3, ix = px & 3;
+        const float b00 = co[0], b01 = co[1], b10 = co[8], b11 = co[9];
+        const float sy = y ? -1.0f : 1.0f, sx = x ? -1.0f : 1.0f;
+        const float dcq = b00 + sy * b01 + sx * b10 + sx * sy * b11;
+        float s = 0.0f;
+        for (int ky = 0; ky < 4; ky++)
+          for (int kx = 0; kx < 4; kx++) {
+            // sub-block element [a*4+b] = co[(y + a*2)*8 + x + b*2]; layout of a 4x4 IDCT input is [kx*4+ky]
+            const float cf = (kx == 0 && ky == 0) ? dcq : co[(y + kx * 2) * 8 + x + ky * 2];
+            s += cf * B4(bt4, iy, ky) * B4(bt4, ix, kx);
+          }
+        result = s;
+      }
+    } else if (strategy == 12) {  // DCT4X8: two 4-row x 8-col halves stacked
+      if (active) {
+        const int y = py >> 2, iy = py & 3;
+        const float b0 = co[0], b1 = co[8];
+        const float dcq = y ? b0 - b1 : b0 + b1;
+        float s = 0.0f;
+        for (int ky = 0; ky < 4; ky++)
+          for (int kx = 0; kx < 8; kx++) {
+            const float cf = (kx == 0 && ky == 0) ? dcq : co[(y + ky * 2) * 8 + kx];
+            s += cf * B4(bt4, iy, ky) * B8(bt8, px, kx);
+          }
+        result = s;
+      }
+    } else if (strategy == 13) {  // DCT8X4: two 8-row x 4-col halves side by side
+      if (active) {
+        const int x = px >> 2, ix = px & 3;
+        const float b0 = co[0], b1 = co[8];
+        const float dcq = x ? b0 - b1 : b0 + b1;
+        float s = 0.0f;
+        for (int kx = 0; kx < 4; kx++)
+          for (int ky = 0; ky < 8; ky++) {
+            // sub-block [a*8+b] = co[(x + a*2)*8 + b]; an 8x4 IDCT reads its input as [kx*8+ky]
+            const float cf = (kx == 0 && ky == 0) ? dcq : co[(x + kx * 2) * 8 + ky];
+            s += cf * B8(bt8, py, ky) * B4(bt4, ix, kx);
+          }
+        result = s;
+      }
+    } else {  // AFV0..3
+      if (active) {
+        const int kind = int(strategy) - 14;
+        const int afv_x = kind & 1, afv_y = kind >> 1;
+        const float b00 = co[0], b01 = co[1], b10 = co[8];
+        const float dcs0 = (b00 + b10 + b01) * 4.0f, dcs1 = b00 + b10 - b01, dcs2 = b00 - b10;
+        const int qy = py >> 2, qx = px >> 2, iy = py & 3, ix = px & 3;
+        if (qy == afv_y && qx == afv_x) {
+          const int by_ = afv_y ? 3 - iy : iy, bx_ = afv_x ? 3 - ix : ix;
+          const int pi = by_ * 4 + bx_;
+          float s = 0.0f;
+          for (int j = 0; j < 16; j++) {
+            const float cf = j == 0 ? dcs0 : co[(j >> 2) * 2 * 8 + (j & 3) * 2];
+            s += cf * c_afv_basis[j * 16 + pi];
+          }
+          result = s;
+        } else if (qy == afv_y) {  // 4x4 DCT next to the AFV corner
+          float s = 0.0f;
+          for (int ky = 0; ky < 4; ky++)
+            for (int kx = 0; kx < 4; kx++) {
+              const float cf = (kx == 0 && ky == 0) ? dcs1 : co[kx * 2 * 8 + ky * 2 + 1];
+              s += cf * B4(bt4, iy, ky) * B4(bt4, ix, kx);
+            }
+          result = s;
+        } else {  // 4x8 DCT in the other half
+          float s = 0.0f;
+          for (int ky = 0; ky < 4; ky++)
+            for (int kx = 0; kx < 8; kx++) {
+              const float cf = (kx == 0 && ky == 0) ? dcs2 : co[(1 + ky * 2) * 8 + kx];
+              s += cf * B4(bt4, iy, ky) * B8(bt8, px, kx);
+            }
+          result = s;
+        }
+      }
+    }
+    if (active) P.out[size_t(c) * P.xp * P.yp + (size_t(vb.by) * 8 + py) * P.xp + size_t(vb.bx) * 8 + px] = result;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- filters + colour
+struct FilterParams {
+  const float* in;   // 3 planes, stride xp, plane size xp * yp
+  float* out;
+  uint32_t xs, ys, xp, yp, xb;
+  const float* inv_sigma;
+  float gab_w[9];  // normalised {w0,w1,w2} per channel
+  float ch_scale[3];
+  float sm, bsm;   // sigma multipliers (centre / border) of the current EPF stage
+  // colour
+  float opsin_inv[9], opsin_bias[3], opsin_bias_cbrt[3];
+  int32_t linear_output;
+  uint8_t* rgb;
+};
+
+__device__ __forceinline__ int MirrorI(int x, int n) {
+  while (x < 0 || x >= n) x = x < 0 ? -x - 1 : 2 * n - 1 - x;
+  return x;
+}
+__device__ __forceinline__ float At(const float* plane, const FilterParams& P, int x, int y) {
+  return plane[size_t(MirrorI(y, int(P.ys))) * P.xp + MirrorI(x, int(P.xs))];
+}
+
+__global__ __launch_bounds__(256) void k_gaborish(FilterParams P) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= int(P.xs) || y >= int(P.ys)) return;
+  for (int c = 0; c < 3; c++) {
+    const float* p = P.in + size_t(c) * P.xp * P.yp;
+    const float m = At(p, P, x, y);
+    const float s1 = (At(p, P, x - 1, y) + At(p, P, x + 1, y)) + (At(p, P, x, y - 1) + At(p, P, x, y + 1));
+    const float s2 = (At(p, P, x - 1, y - 1) + At(p, P, x + 1, y - 1)) + (At(p, P, x - 1, y + 1) + At(p, P, x + 1, y + 1));
+    P.out[size_t(c) * P.xp * P.yp + size_t(y) * P.xp + x] = s2 * P.gab_w[c * 3 + 2] + (s1 * P.gab_w[c * 3 + 1] + m * P.gab_w[c * 3]);
+  }
+}
+
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_epf(FilterParams P) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= int(P.xs) || y >= int(P.ys)) return;
+  const size_t plane = size_t(P.xp) * P.yp, o = size_t(y) * P.xp + x;
+  const float is = P.inv_sigma[size_t(y >> 3) * P.xb + (x >> 3)];
+  const float c0 = P.in[o], c1 = P.in[plane + o], c2 = P.in[2 * plane + o];
+  if (is < -3.90524291751269967465540850526868f) {
+    P.out[o] = c0;
+    P.out[plane + o] = c1;
+    P.out[2 * plane + o] = c2;
+    return;
+  }
+  const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
+  const float inv_sig = is * (border ? P.bsm : P.sm);
+  constexpr int NOFF = STAGE == 0 ? 12 : 4;
+  const int off0[12][2] = {{-2, 0}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 1}, {0, 2}, {1, -1}, {1, 0}, {1, 1}, {2, 0}};
+  const int off1[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+  const int plus[5][2] = {{0, 0}, {-1, 0}, {0, -1}, {1, 0}, {0, 1}};
+  float w = 1.0f, a0 = c0, a1 = c1, a2 = c2;
+#pragma unroll
+  for (int i = 0; i < NOFF; i++) {
+    const int dy = STAGE == 0 ? off0[i][0] : off1[i][0], dx = STAGE == 0 ? off0[i][1] : off1[i][1];
+    float sad = 0.0f;
+    if (STAGE == 2) {
+      sad = fabsf(At(P.in, P, x + dx, y + dy) - c0) * P.ch_scale[0];
+      sad = fabsf(At(P.in + plane, P, x + dx, y + dy) - c1) * P.ch_scale[1] + sad;
+      sad = fabsf(At(P.in + 2 * plane, P, x + dx, y + dy) - c2) * P.ch_scale[2] + sad;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float* p = P.in + size_t(c) * plane;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+          s += fabsf(At(p, P, x + plus[k][1], y + plus[k][0]) - At(p, P, x + dx + plus[k][1], y + dy + plus[k][0]));
+        sad = s * P.ch_scale[c] + sad;
+      }
+    }
+    float weight = sad * inv_sig + 1.0f;
+    weight = weight < 0.0f ? 0.0f : weight;
+    w += weight;
+    a0 = weight * At(P.in, P, x + dx, y + dy) + a0;
+    a1 = weight * At(P.in + plane, P, x + dx, y + dy) + a1;
+    a2 = weight * At(P.in + 2 * plane, P, x + dx, y + dy) + a2;
+  }
+  const float inv_w = 1.0f / w;
+  P.out[o] = a0 * inv_w;
+  P.out[plane + o] = a1 * inv_w;
+  P.out[2 * plane + o] = a2 * inv_w;
+}
+
+__device__ __forceinline__ float LinearToSrgb(float v) {
+  const float a = fabsf(v);
+  float r;
+  if (a > 0.0031308f) {
+    const float s = sqrtf(a);
+    float yp = 7.352629620e-01f * s + 1.474205315e+00f;
+    yp = yp * s + 3.903842876e-01f;
+    yp = yp * s + 5.287254571e-03f;
+    yp = yp * s + -5.135152395e-04f;
+    float yq = 2.424867759e-02f * s + 9.258482155e-01f;
+    yq = yq * s + 1.340816930e+00f;
+    yq = yq * s + 3.036675394e-01f;
+    yq = yq * s + 1.004519624e-02f;
+    r = yp / yq;
+  } else {
+    r = a * 12.92f;
+  }
+  return copysignf(r, v);
+}
+__device__ __forceinline__ uint8_t ToU8(float v, int x, int y, int c) {
+  v = v * 255.0f + c_dither[((y + c * 13) & 31) * 32 + ((x + c * 23) & 31)];
+  v = v >= 0.0f ? v : 0.0f;
+  v = v > 255.0f ? 255.0f : v;
+  return uint8_t(__float2int_rn(v));
+}
+
+__global__ __launch_bounds__(256) void k_color(FilterParams P) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= int(P.xs) || y >= int(P.ys)) return;
+  const size_t plane = size_t(P.xp) * P.yp, o = size_t(y) * P.xp + x;
+  const float X = P.in[o], Y = P.in[plane + o], B = P.in[2 * plane + o];
+  const float gr = (Y + X) - P.opsin_bias_cbrt[0], gg = (Y - X) - P.opsin_bias_cbrt[1], gb = B - P.opsin_bias_cbrt[2];
+  const float mr = (gr * gr) * gr + P.opsin_bias[0], mg = (gg * gg) * gg + P.opsin_bias[1], mb = (gb * gb) * gb + P.opsin_bias[2];
+  float r = P.opsin_inv[2] * mb + (P.opsin_inv[1] * mg + P.opsin_inv[0] * mr);
+  float g = P.opsin_inv[5] * mb + (P.opsin_inv[4] * mg + P.opsin_inv[3] * mr);
+  float b = P.opsin_inv[8] * mb + (P.opsin_inv[7] * mg + P.opsin_inv[6] * mr);
+  if (!P.linear_output) {
+    r = LinearToSrgb(r);
+    g = LinearToSrgb(g);
+    b = LinearToSrgb(b);
+  }
+  uint8_t* dst = P.rgb + (size_t(y) * P.xs + x) * 3;
+  dst[0] = ToU8(r, x, y, 0);
+  dst[1] = ToU8(g, x, y, 1);
+  dst[2] = ToU8(b, x, y, 2);
+}
+
+}  // namespace jxlhip
+#endif  // JXL_HIP_KERNELS_H_

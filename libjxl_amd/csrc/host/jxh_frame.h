@@ -1,0 +1,504 @@
+// libjxl_amd host front-end: parses one VarDCT frame up to (not including) the AC group sections and produces a
+// FramePlan — the flat, GPU-ready tables the HIP hot path consumes (csrc/hip/). Per-frame work only: headers, TOC,
+// DC global, DC groups (Modular decode of DC + AC metadata), adaptive DC smoothing, EPF sigma, AC global
+// (dequant tables, coefficient orders, entropy-code tables).
+// Follows the frame walk of reference lib/jxl/dec_frame.cc:135-434 and lib/jxl/dec_modular.cc:427-562; this is the
+// "prerequisites computed before the hot path" list of SURVEY.md §1. The AC group sections themselves are only
+// located here (offset/size); their bytes are decoded on the GPU.
+#ifndef JXH_FRAME_H_
+#define JXH_FRAME_H_
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "jxh_bits.h"
+#include "jxh_entropy.h"
+#include "jxh_headers.h"
+#include "jxh_modular.h"
+#include "jxh_vardct.h"
+
+namespace jxh {
+
+// One varblock, in the decode order of its group. Packed for the device.
+struct VarBlock {
+  uint16_t bx, by;        // absolute block coordinates of the top-left 8x8
+  uint8_t strategy;
+  uint8_t quant_dc_ctx;   // DC-derived block context bucket
+  uint16_t qf;            // raw quant field value 1..256
+  uint32_t coef_offset;   // offset of this block's coefficients inside its group's [c][65536] planes
+};
+
+struct PassTables {
+  bool use_prefix = false;
+  bool lz77 = false;
+  int log_alpha = 8;
+  size_t num_clusters = 0;
+  size_t max_num_bits = 0;              // widest value the code can produce (decides int16 vs int32 coefficients)
+  std::vector<uint8_t> ctx_map;         // num_histograms * NumACContexts + 16 slack
+  std::vector<AliasEntry> alias;        // num_clusters << log_alpha
+  std::vector<uint32_t> uint_cfg;       // per cluster: split_exp | msb << 8 | lsb << 16
+  std::vector<uint16_t> orders;         // [13 buckets][3 channels] -> order_offset[]; natural or custom
+  uint32_t order_offset[39];            // start of (bucket, channel) in `orders` (in entries)
+};
+
+struct FramePlan {
+  ImageHeader ih;
+  FrameHeader fh;
+  FrameDim dim;
+  // quantiser / colour correlation scalars
+  uint32_t global_scale = 1, quant_dc = 16;
+  float inv_global_scale = 1.0f, x_dm = 1.0f, b_dm = 1.0f;
+  float color_scale = 1.0f / 84, base_corr_x = 0.0f, base_corr_b = 1.0f;
+  // block-resolution planes (xsize_blocks x ysize_blocks)
+  std::vector<float> dc;            // 3 planes X, Y, B after adaptive smoothing
+  std::vector<uint8_t> acs;         // (strategy << 1) | is_first
+  std::vector<float> inv_sigma;     // EPF 1/sigma per block
+  std::vector<int8_t> ytox, ytob;   // per 64x64 tile
+  // varblocks
+  std::vector<VarBlock> blocks;             // all groups concatenated, decode order inside each group
+  std::vector<uint32_t> group_block_begin;  // num_groups + 1
+  uint32_t used_acs = 0;
+  // block context map
+  BlockCtxMap bctx;
+  std::vector<uint8_t> block_ctx_lut;  // [c(3)][ord(13)][qf_idx][dc_ctx] -> block context (as BlockCtxMap::Context)
+  // dequant tables for the 17 table kinds, concatenated; dequant_offset[kind] in floats (3 channels contiguous)
+  std::vector<float> dequant;
+  uint32_t dequant_offset[17];
+  uint32_t dequant_size[17];  // per-channel entries
+  size_t num_histograms = 1;
+  std::vector<PassTables> passes;
+  // AC sections: for pass p, group g: index p * num_groups + g
+  std::vector<uint64_t> section_offset;  // byte offset inside the codestream buffer handed to ParseFrame
+  std::vector<uint32_t> section_size;
+  // single-section frames: AC data starts mid-byte inside the one section
+  uint32_t first_section_bit_offset = 0;
+  size_t frame_end = 0;  // byte offset just after the frame
+};
+
+// Optional parallel-for hook (the JxlParallelRunner of the public API is adapted onto this).
+typedef std::function<void(size_t /*count*/, const std::function<void(size_t)>&)> ParallelFor;
+static inline void SerialFor(size_t n, const std::function<void(size_t)>& f) {
+  for (size_t i = 0; i < n; i++) f(i);
+}
+
+class FrameParser {
+ public:
+  FrameParser(const uint8_t* data, size_t size) : data_(data), size_(size) {}
+
+  // Parses signature + image header; returns the byte position of the first frame.
+  size_t ParseImageHeader(ImageHeader* ih) {
+    const uint8_t* d = data_;
+    size_t n = size_;
+    codestream_base_ = 0;
+    static const uint8_t kContainer[12] = {0, 0, 0, 0xC, 'J', 'X', 'L', ' ', 0xD, 0xA, 0x87, 0xA};
+    if (n >= 12 && !memcmp(d, kContainer, 12)) {
+      size_t pos = 12;
+      bool found = false;
+      while (pos + 8 <= n) {
+        uint64_t bsize = (uint64_t(d[pos]) << 24) | (d[pos + 1] << 16) | (d[pos + 2] << 8) | d[pos + 3];
+        size_t hdr = 8;
+        if (bsize == 1) {
+          JXH_CHECK(pos + 16 <= n, "truncated box");
+          bsize = 0;
+          for (int i = 0; i < 8; i++) bsize = (bsize << 8) | d[pos + 8 + i];
+          hdr = 16;
+        }
+        if (bsize == 0) bsize = n - pos;
+        JXH_CHECK(bsize >= hdr && pos + bsize <= n, "bad box size");
+        if (!memcmp(d + pos + 4, "jxlc", 4)) {
+          codestream_base_ = pos + hdr;
+          cs_size_ = bsize - hdr;
+          found = true;
+          break;
+        }
+        JXH_CHECK(memcmp(d + pos + 4, "jxlp", 4) != 0, "unsupported: jxlp boxes");
+        pos += bsize;
+      }
+      JXH_CHECK(found, "no codestream box");
+    } else {
+      cs_size_ = n;
+    }
+    const uint8_t* cs = data_ + codestream_base_;
+    JXH_CHECK(cs_size_ >= 2 && cs[0] == 0xFF && cs[1] == 0x0A, "not a JPEG XL codestream");
+    BitReader br(cs, cs_size_);
+    br.Skip(16);
+    ReadImageHeader(br, ih);
+    JXH_CHECK(!br.Overread(), "truncated image header");
+    return codestream_base_ + br.BitPos() / 8;
+  }
+
+  // Parses the frame that starts at byte `pos` of the buffer. Throws jxh::Error for unsupported streams.
+  void ParseFrame(size_t pos, const ImageHeader& ih, FramePlan* plan, const ParallelFor& pfor = SerialFor) {
+    FramePlan& P = *plan;
+    P.ih = ih;
+    BitReader br(data_ + pos, codestream_base_ + cs_size_ - pos);
+    ReadFrameHeader(br, ih, &P.fh);
+    const FrameHeader& fh = P.fh;
+    JXH_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
+    JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
+    JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
+    JXH_CHECK(fh.upsampling == 1, "unsupported: upsampling");
+    JXH_CHECK(!fh.custom_size, "unsupported: cropped frames");
+    JXH_CHECK(fh.is_last, "unsupported: multiple frames");
+    JXH_CHECK(ih.extra.empty(), "unsupported: extra channels");
+    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
+              "unsupported: patches/splines/noise/DC frames");
+    P.dim = MakeFrameDim(fh);
+    const FrameDim& d = P.dim;
+    const size_t np = fh.num_passes;
+    const size_t entries = (d.num_groups == 1 && np == 1) ? 1 : 2 + d.num_dc_groups + d.num_groups * np;
+    Toc toc;
+    ReadToc(br, entries, &toc);
+    JXH_CHECK(!br.Overread(), "truncated frame header");
+    const size_t base = pos + br.BitPos() / 8;
+    JXH_CHECK(base + toc.total <= codestream_base_ + cs_size_, "truncated frame");
+    P.frame_end = base + toc.total;
+    const size_t xb = d.xsize_blocks, yb = d.ysize_blocks;
+    P.dc.assign(3 * xb * yb, 0.0f);
+    P.acs.assign(xb * yb, 0xFF);
+    P.inv_sigma.assign(xb * yb, 0.0f);
+    P.ytox.assign(DivCeil(xb, 8) * DivCeil(yb, 8), 0);
+    P.ytob.assign(P.ytox.size(), 0);
+    quant_.assign(xb * yb, 0);
+    sharp_.assign(xb * yb, 0);
+    quant_dc_ctx_.assign(xb * yb, 0);
+
+    P.section_offset.assign(d.num_groups * np, 0);
+    P.section_size.assign(d.num_groups * np, 0);
+    if (entries == 1) {
+      BitReader r(data_ + base + toc.offset[0], toc.size[0]);
+      DcGlobal(r, &P);
+      DcGroup(r, &P, 0);
+      FinalizeDc(&P);
+      AcGlobal(r, &P);
+      JXH_CHECK(!r.Overread(), "section over-read");
+      // AC data continues in the same section at an arbitrary bit position
+      P.section_offset[0] = base + toc.offset[0] + r.BitPos() / 8;
+      P.first_section_bit_offset = uint32_t(r.BitPos() & 7);
+      P.section_size[0] = uint32_t(toc.size[0] - r.BitPos() / 8);
+    } else {
+      {
+        BitReader r(data_ + base + toc.offset[0], toc.size[0]);
+        DcGlobal(r, &P);
+        JXH_CHECK(!r.Overread(), "DC global over-read");
+      }
+      std::string err;
+      pfor(d.num_dc_groups, [&](size_t g) {
+        try {
+          BitReader r(data_ + base + toc.offset[1 + g], toc.size[1 + g]);
+          DcGroup(r, &P, g);
+          JXH_CHECK(!r.Overread(), "DC group over-read");
+        } catch (const std::exception& e) {
+          err = e.what();
+        }
+      });
+      JXH_CHECK(err.empty(), err);
+      FinalizeDc(&P);
+      {
+        size_t i = 1 + d.num_dc_groups;
+        BitReader r(data_ + base + toc.offset[i], toc.size[i]);
+        AcGlobal(r, &P);
+        JXH_CHECK(!r.Overread(), "AC global over-read");
+      }
+      for (size_t p = 0; p < np; p++)
+        for (size_t g = 0; g < d.num_groups; g++) {
+          size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
+          P.section_offset[p * d.num_groups + g] = base + toc.offset[i];
+          P.section_size[p * d.num_groups + g] = toc.size[i];
+        }
+    }
+    BuildBlockLists(&P);
+  }
+
+ private:
+  void DcGlobal(BitReader& br, FramePlan* P) {
+    if (!br.ReadBool()) {
+      for (int c = 0; c < 3; c++) {
+        dq_.dc_quant[c] = ReadF16(br) * (1.0f / 128.0f);
+        JXH_CHECK(dq_.dc_quant[c] >= 1e-8f, "invalid DC quant");
+      }
+    }
+    P->global_scale = ReadU32(br, BitsOffset(11, 1), BitsOffset(11, 2049), BitsOffset(12, 4097), BitsOffset(16, 8193));
+    P->quant_dc = ReadU32(br, Val(16), BitsOffset(5, 1), BitsOffset(8, 1), BitsOffset(16, 1));
+    ReadBlockCtxMap(br, &P->bctx);
+    uint32_t color_factor = 84;
+    if (!br.ReadBool()) {
+      color_factor = ReadU32(br, Val(84), Val(256), BitsOffset(8, 2), BitsOffset(16, 258));
+      P->base_corr_x = ReadF16(br);
+      P->base_corr_b = ReadF16(br);
+      JXH_CHECK(std::fabs(P->base_corr_x) <= 4.0f && std::fabs(P->base_corr_b) <= 4.0f, "CfL base out of range");
+      ytox_dc_ = int32_t(br.Read(8)) - 128;
+      ytob_dc_ = int32_t(br.Read(8)) - 128;
+    }
+    P->color_scale = 1.0f / float(color_factor);
+    P->inv_global_scale = 65536.0f / float(P->global_scale);
+    P->x_dm = std::pow(1.25f, 2.0f - float(P->fh.x_qm_scale));
+    P->b_dm = std::pow(1.25f, 2.0f - float(P->fh.b_qm_scale));
+    if (br.ReadBool()) {
+      size_t limit = std::min<size_t>(size_t(1) << 22, 1024 + P->dim.xsize * P->dim.ysize / 16);
+      DecodeTree(br, &mglobal_.tree, limit);
+      DecodeHistograms(br, (mglobal_.tree.size() + 1) / 2, &mglobal_.code);
+      mglobal_.have = true;
+    }
+    // VarDCT frame without extra channels: the global Modular image has no channels, nothing more to read.
+  }
+
+  void DcGroup(BitReader& br, FramePlan* P, size_t g) {
+    const FrameDim& d = P->dim;
+    const size_t gx = g % d.xsize_dc_groups, gy = g / d.xsize_dc_groups;
+    const size_t bx0 = gx * d.group_dim, by0 = gy * d.group_dim;
+    const size_t bw = std::min(d.group_dim, d.xsize_blocks - bx0), bh = std::min(d.group_dim, d.ysize_blocks - by0);
+    const size_t ndc = d.num_dc_groups, xb = d.xsize_blocks;
+    {
+      uint32_t extra_precision = uint32_t(br.Read(2));
+      float mul = 1.0f / float(1 << extra_precision);
+      MImage img;
+      for (int c = 0; c < 3; c++) img.ch.emplace_back(bw, bh);
+      ModularDecode(br, &img, int(1 + g), &mglobal_);
+      const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
+      float fac[3];
+      for (int c = 0; c < 3; c++) fac[c] = (inv_quant_dc * dq_.dc_quant[c]) * mul;
+      const float cfl_x = P->base_corr_x + ytox_dc_ * P->color_scale, cfl_b = P->base_corr_b + ytob_dc_ * P->color_scale;
+      const size_t plane = xb * d.ysize_blocks;
+      const BlockCtxMap& bc = P->bctx;
+      for (size_t y = 0; y < bh; y++) {
+        const int32_t *qx = img.ch[1].Row(y), *qy = img.ch[0].Row(y), *qb = img.ch[2].Row(y);
+        for (size_t x = 0; x < bw; x++) {
+          size_t idx = (by0 + y) * xb + bx0 + x;
+          float in_x = float(qx[x]) * fac[0], in_y = float(qy[x]) * fac[1], in_b = float(qb[x]) * fac[2];
+          P->dc[plane + idx] = in_y;
+          P->dc[idx] = in_y * cfl_x + in_x;
+          P->dc[2 * plane + idx] = in_y * cfl_b + in_b;
+          uint8_t bucket = 0;
+          if (bc.num_dc_ctxs > 1) {
+            int kx = 0, ky = 0, kb = 0;
+            for (int t : bc.dc_thresholds[0]) kx += qx[x] > t;
+            for (int t : bc.dc_thresholds[1]) ky += qy[x] > t;
+            for (int t : bc.dc_thresholds[2]) kb += qb[x] > t;
+            int b = kx;
+            b = b * int(bc.dc_thresholds[2].size() + 1) + kb;
+            b = b * int(bc.dc_thresholds[1].size() + 1) + ky;
+            bucket = uint8_t(b);
+          }
+          quant_dc_ctx_[idx] = bucket;
+        }
+      }
+    }
+    {
+      size_t count = size_t(br.Read(CeilLog2(bw * bh))) + 1;
+      MImage img;
+      size_t cw = (bw + 7) >> 3, ch = (bh + 7) >> 3;
+      img.ch.emplace_back(cw, ch, 3, 3);
+      img.ch.emplace_back(cw, ch, 3, 3);
+      img.ch.emplace_back(count, 2, 0, 0);
+      img.ch.emplace_back(bw, bh, 0, 0);
+      ModularDecode(br, &img, int(1 + 2 * ndc + g), &mglobal_);
+      const size_t tiles_x = DivCeil(xb, 8);
+      for (size_t y = 0; y < ch; y++)
+        for (size_t x = 0; x < cw; x++) {
+          size_t idx = (by0 / 8 + y) * tiles_x + bx0 / 8 + x;
+          P->ytox[idx] = int8_t(std::max(-128, std::min(127, img.ch[0].Row(y)[x])));
+          P->ytob[idx] = int8_t(std::max(-128, std::min(127, img.ch[1].Row(y)[x])));
+        }
+      size_t num = 0;
+      const int32_t *r1 = img.ch[2].Row(0), *r2 = img.ch[2].Row(1);
+      uint32_t used = 0;
+      for (size_t iy = 0; iy < bh; iy++) {
+        size_t y = by0 + iy;
+        for (size_t ix = 0; ix < bw; ix++) {
+          size_t x = bx0 + ix;
+          int sh = img.ch[3].Row(iy)[ix];
+          JXH_CHECK(sh >= 0 && sh < 8, "corrupted sharpness field");
+          sharp_[y * xb + x] = uint8_t(sh);
+          if (P->acs[y * xb + x] != 0xFF) continue;
+          JXH_CHECK(num < count, "AC metadata: too few strategies");
+          int raw = r1[num];
+          JXH_CHECK(raw >= 0 && raw < 27, "invalid AC strategy");
+          used |= 1u << raw;
+          size_t cx = kCoveredX[raw], cy = kCoveredY[raw];
+          size_t nx = (x / 32 + 1) * 32, ny = (y / 32 + 1) * 32;
+          JXH_CHECK(x + cx <= nx && x + cx <= std::min(d.xsize_blocks, bx0 + bw), "AC strategy x overflow");
+          JXH_CHECK(y + cy <= ny && y + cy <= std::min(d.ysize_blocks, by0 + bh), "AC strategy y overflow");
+          for (size_t jy = 0; jy < cy; jy++)
+            for (size_t jx = 0; jx < cx; jx++) {
+              uint8_t& a = P->acs[(y + jy) * xb + x + jx];
+              JXH_CHECK(a == 0xFF, "AC strategy overlap");
+              a = uint8_t((raw << 1) | ((jx | jy) == 0 ? 1 : 0));
+            }
+          quant_[y * xb + x] = uint16_t(1 + std::max(0, std::min(255, r2[num])));
+          num++;
+        }
+      }
+      used_mutex_or(P, used);
+    }
+  }
+
+  void used_mutex_or(FramePlan* P, uint32_t used) {
+    // DC groups may run on several threads; a plain OR of a 32-bit mask is safe with the atomic builtin.
+    __atomic_fetch_or(&P->used_acs, used, __ATOMIC_RELAXED);
+  }
+
+  void FinalizeDc(FramePlan* P) {
+    const FrameDim& d = P->dim;
+    const size_t xs = d.xsize_blocks, ys = d.ysize_blocks, plane = xs * ys;
+    const LoopFilter& lf = P->fh.lf;
+    if (lf.epf_iters > 0) {
+      const float kInvSigmaNum = -1.1715728752538099024f;
+      const float quant_scale = float(P->global_scale) * (1.0f / 65536.0f);
+      for (size_t by = 0; by < ys; by++)
+        for (size_t bx = 0; bx < xs; bx++) {
+          uint8_t a = P->acs[by * xs + bx];
+          if (!(a & 1)) continue;
+          int st = a >> 1;
+          float sigma_quant = lf.epf_quant_mul / (quant_scale * float(quant_[by * xs + bx]) * kInvSigmaNum);
+          for (size_t iy = 0; iy < kCoveredY[st]; iy++)
+            for (size_t ix = 0; ix < kCoveredX[st]; ix++) {
+              float sigma = sigma_quant * lf.epf_sharp_lut[sharp_[(by + iy) * xs + bx + ix]];
+              sigma = std::min(-1e-4f, sigma);
+              P->inv_sigma[(by + iy) * xs + bx + ix] = 1.0f / sigma;
+            }
+        }
+    }
+    if (!(P->fh.flags & FrameHeader::kSkipDcSmoothing) && xs > 2 && ys > 2) {
+      const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
+      float dcf[3];
+      for (int c = 0; c < 3; c++) dcf[c] = inv_quant_dc * dq_.dc_quant[c];
+      const float w1 = 0.20345139757231578f, w2 = 0.0334829185968739f, w0 = 1.0f - 4.0f * (w1 + w2);
+      std::vector<float> sm(P->dc);
+      for (size_t y = 1; y + 1 < ys; y++)
+        for (size_t x = 1; x + 1 < xs; x++) {
+          float mc[3], smv[3], gap = 0.5f;
+          for (int c = 0; c < 3; c++) {
+            const float* p = P->dc.data() + plane * c;
+            const float *t = p + (y - 1) * xs, *m = p + y * xs, *b = p + (y + 1) * xs;
+            float corner = (t[x - 1] + t[x + 1]) + (b[x - 1] + b[x + 1]);
+            float side = (m[x - 1] + m[x + 1]) + (t[x] + b[x]);
+            mc[c] = m[x];
+            smv[c] = corner * w2 + (side * w1 + mc[c] * w0);
+            gap = std::max(gap, std::fabs((mc[c] - smv[c]) / dcf[c]));
+          }
+          float factor = std::max(0.0f, -4.0f * gap + 3.0f);
+          for (int c = 0; c < 3; c++) sm[plane * c + y * xs + x] = (smv[c] - mc[c]) * factor + mc[c];
+        }
+      P->dc.swap(sm);
+    }
+  }
+
+  void AcGlobal(BitReader& br, FramePlan* P) {
+    if (!br.ReadBool()) {
+      for (int k = 0; k < 17; k++) {
+        ReadQuantEncoding(br, k, &dq_.enc[k]);
+        dq_.table[k].clear();
+      }
+    }
+    // dequant tables for the kinds in use
+    P->dequant.clear();
+    for (int k = 0; k < 17; k++) {
+      bool used = false;
+      for (int s = 0; s < 27; s++)
+        if ((P->used_acs & (1u << s)) && kStrategyQuantTable[s] == k) used = true;
+      P->dequant_offset[k] = uint32_t(P->dequant.size());
+      P->dequant_size[k] = 0;
+      if (!used) continue;
+      dq_.Compute(k);
+      P->dequant_size[k] = uint32_t(dq_.table[k].size() / 3);
+      P->dequant.insert(P->dequant.end(), dq_.table[k].begin(), dq_.table[k].end());
+    }
+    const FrameDim& d = P->dim;
+    P->num_histograms = 1 + size_t(br.Read(CeilLog2(d.num_groups)));
+    P->passes.resize(P->fh.num_passes);
+    for (uint32_t p = 0; p < P->fh.num_passes; p++) {
+      PassTables& T = P->passes[p];
+      uint32_t used_orders = ReadU32(br, Val(0x5F), Val(0x13), Val(0), Bits(13));
+      std::vector<uint32_t> orders;
+      DecodeCoeffOrders(br, used_orders, P->used_acs, &orders);
+      // compact the used buckets into u16
+      T.orders.clear();
+      for (int ord = 0; ord < 13; ord++) {
+        int s = OrderBucketStrategy(ord);
+        size_t size = size_t(kCoveredX[s]) * kCoveredY[s] * 64;
+        bool used = false;
+        for (int t = 0; t < 27; t++)
+          if ((P->used_acs & (1u << t)) && kStrategyOrder[t] == ord) used = true;
+        for (int c = 0; c < 3; c++) {
+          T.order_offset[3 * ord + c] = uint32_t(T.orders.size());
+          if (!used) continue;
+          const uint32_t* src = &orders[CoeffOrderOffset(ord, c)];
+          for (size_t k = 0; k < size; k++) T.orders.push_back(uint16_t(src[k]));
+        }
+      }
+      EntropyCode code;
+      size_t nctx = P->num_histograms * P->bctx.NumACContexts();
+      DecodeHistograms(br, nctx, &code);
+      T.use_prefix = code.use_prefix;
+      T.lz77 = code.lz77;
+      T.log_alpha = code.log_alpha;
+      T.num_clusters = code.num_clusters;
+      T.max_num_bits = code.max_num_bits;
+      T.ctx_map = code.ctx_map;
+      T.ctx_map.resize(nctx + 16, 0);
+      T.alias = code.alias;
+      T.uint_cfg.resize(code.num_clusters);
+      for (size_t k = 0; k < code.num_clusters; k++)
+        T.uint_cfg[k] = code.cfg[k].split_exp | (code.cfg[k].msb << 8) | (code.cfg[k].lsb << 16);
+      JXH_CHECK(!T.use_prefix, "unsupported on the GPU path: prefix-coded AC coefficients");
+      JXH_CHECK(!T.lz77, "unsupported on the GPU path: LZ77 in AC coefficients");
+    }
+    // block-context LUT: [c][ord][qf_idx][dc_ctx]
+    const BlockCtxMap& bc = P->bctx;
+    size_t nq = bc.qf_thresholds.size() + 1;
+    P->block_ctx_lut.assign(3 * 13 * nq * bc.num_dc_ctxs, 0);
+    for (size_t c = 0; c < 3; c++)
+      for (size_t ord = 0; ord < 13; ord++)
+        for (size_t q = 0; q < nq; q++)
+          for (size_t dcx = 0; dcx < bc.num_dc_ctxs; dcx++) {
+            size_t idx = c < 2 ? c ^ 1 : 2;
+            idx = idx * 13 + ord;
+            idx = idx * nq + q;
+            idx = idx * bc.num_dc_ctxs + dcx;
+            P->block_ctx_lut[((c * 13 + ord) * nq + q) * bc.num_dc_ctxs + dcx] = bc.ctx_map[idx];
+          }
+  }
+
+  void BuildBlockLists(FramePlan* P) {
+    const FrameDim& d = P->dim;
+    const size_t xb = d.xsize_blocks;
+    P->blocks.clear();
+    P->group_block_begin.assign(d.num_groups + 1, 0);
+    for (size_t g = 0; g < d.num_groups; g++) {
+      P->group_block_begin[g] = uint32_t(P->blocks.size());
+      const size_t bx0 = (g % d.xsize_groups) * 32, by0 = (g / d.xsize_groups) * 32;
+      const size_t bw = std::min<size_t>(32, d.xsize_blocks - bx0), bh = std::min<size_t>(32, d.ysize_blocks - by0);
+      uint32_t offset = 0;
+      for (size_t by = 0; by < bh; by++)
+        for (size_t bx = 0; bx < bw; bx++) {
+          uint8_t a = P->acs[(by0 + by) * xb + bx0 + bx];
+          JXH_CHECK(a != 0xFF, "AC strategy map has holes");
+          if (!(a & 1)) continue;
+          VarBlock v;
+          v.bx = uint16_t(bx0 + bx);
+          v.by = uint16_t(by0 + by);
+          v.strategy = uint8_t(a >> 1);
+          v.quant_dc_ctx = quant_dc_ctx_[(by0 + by) * xb + bx0 + bx];
+          v.qf = quant_[(by0 + by) * xb + bx0 + bx];
+          v.coef_offset = offset;
+          offset += uint32_t(64) << kLog2Covered[v.strategy];
+          P->blocks.push_back(v);
+        }
+    }
+    P->group_block_begin[d.num_groups] = uint32_t(P->blocks.size());
+  }
+
+  const uint8_t* data_;
+  size_t size_;
+  size_t codestream_base_ = 0, cs_size_ = 0;
+  DequantTables dq_;
+  MGlobal mglobal_;
+  int32_t ytox_dc_ = 0, ytob_dc_ = 0;
+  std::vector<uint16_t> quant_;
+  std::vector<uint8_t> sharp_, quant_dc_ctx_;
+};
+
+}  // namespace jxh
+#endif  // JXH_FRAME_H_
