@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native JPEG XL VarDCT decode path (BASELINE.json metric: megapixels/sec decode).
+
+A "step" decodes one batch of synthetic frames per GPU: `--batch` copies of a 3840x2160 RGB8 frame encoded at
+distance 1.0 (Gaborish + EPF1, one pass), i.e. BASELINE.json configs[1].  The compressed AC sections and all per-frame
+tables are resident in HBM before the timed region; each frame has its own device buffers and HIP stream, and a step
+runs entropy decode -> dequant/IDCT -> Gaborish/EPF/colour for every frame and leaves RGB8 in HBM.
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run, one rank per GPU): frames are independent, so every rank
+decodes its own batch (weak scaling) with no data-path collective; RCCL is only used for the barrier and the
+max-over-ranks time.  MP/s follows the reference's definition xsize*ysize*1e-6/elapsed (tools/speed_stats.cc:107).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable rate
+
+
+def make_stream(xsize, ysize, distance, seed=177):
+    import libjxl_amd as J
+    cache = "/tmp/libjxl_amd_bench_%dx%d_d%.2f_s%d.jxl" % (xsize, ysize, distance, seed)
+    if os.path.exists(cache):
+        return open(cache, "rb").read()
+    img = J.synth_image(xsize, ysize, seed)
+    data = J.encode_rgb8(img, distance=distance, strategy_mode=1)
+    try:
+        tmp = cache + ".%d" % os.getpid()
+        open(tmp, "wb").write(data)
+        os.replace(tmp, cache)
+    except OSError:
+        pass
+    return data
+
+
+def cpu_baseline(data, xsize, ysize, budget_s=20.0):
+    """Times the oracle (scalar single-thread CPU restatement, kind 'port') on the same stream."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jxlo
+    jxlo.lib()
+    times = []
+    t_start = time.time()
+    while len(times) < 5 and (not times or time.time() - t_start + times[-1] < budget_s):
+        t0 = time.time()
+        d = jxlo.Decoded(data, dumps=False)
+        times.append(time.time() - t0)
+        d.close()
+    best = min(times)
+    return {"value": round(xsize * ysize * 1e-6 / best, 3), "unit": "MP/s", "cores": 1, "kind": "port",
+            "sample": "%d full %dx%d frame decode(s) of the benchmark stream, best of %d" % (len(times), xsize, ysize, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--size", default="3840x2160")
+    ap.add_argument("--distance", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    xsize, ysize = [int(v) for v in args.size.split("x")]
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import libjxl_amd as J
+    from libjxl_amd import sharding
+    J.lib()  # fails loudly if the HIP extension is missing
+
+    data = make_stream(xsize, ysize, args.distance)
+    frame = J.Frame(data, threads=min(8, os.cpu_count() or 1))
+    info = frame.info
+    ctxs = [J.HipContext(local_rank) for _ in range(args.batch)]
+    for c in ctxs:
+        c.upload(frame)
+
+    def step():
+        for c in ctxs:
+            c.run_all()
+        for c in ctxs:
+            c.sync()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    r, flags = ctxs[0].errors()
+    if r:
+        raise SystemExit("entropy kernel reported corrupt sections: %r" % flags)
+    barrier()
+    t0 = time.perf_counter()
+    stage_ms = [0.0, 0.0, 0.0]
+    for _ in range(args.steps):
+        step()
+        for c in ctxs:  # HIP events recorded on each context's own stream
+            for s in range(3):
+                stage_ms[s] += c.stage_ms(s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the stage_ms queries above are host-side reads of already-completed events (negligible, but inside the region)
+    frames_local = args.batch * args.steps
+    total_frames, max_elapsed = sharding.aggregate(frames_local, elapsed, dist)
+    launches = args.batch * args.steps
+    stage_ms = [v / launches for v in stage_ms]
+
+    if rank == 0:
+        px = xsize * ysize
+        mps = total_frames * px * 1e-6 / max_elapsed
+        bpp = len(data) * 8.0 / px
+        # algorithmic bytes per launch (one frame) of each stage, SURVEY.md §8d / DESIGN.md:
+        alg = {
+            "entropy (k_entropy_ans)": info["ac_bytes"] + 6.0 * px,          # bitstream read + int16 coefficients written
+            "transform (k_dct/k_special)": (6.0 + 0.4 + 12.0) * px,          # coefficients + side info read, f32 XYB written
+            "filter+colour (k_gaborish,k_epf,k_color)": (12.0 + 0.06 + 3.0) * px,  # f32 XYB + sigma read, RGB8 written
+        }
+        names = list(alg)
+        dom = max(range(3), key=lambda s: stage_ms[s])
+        achieved = alg[names[dom]] / (stage_ms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "megapixels/sec decode, %dx%d VarDCT d%.1f" % (xsize, ysize, args.distance),
+            "value": round(mps, 2),
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(max_elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
+                xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
+                "frames_per_step_per_gpu": args.batch, "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "note": "entropy decode is serial per 256x256 group (latency-bound, not HBM-bound)" if dom == 0 else ""},
+            "stage_ms_per_frame": {names[s]: round(stage_ms[s], 4) for s in range(3)},
+            "stage_gbs": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9, 2) for s in range(3)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, xsize, ysize)
+        print(json.dumps(out))
+    for c in ctxs:
+        c.close()
+    frame.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -522,7 +522,8 @@ struct Params {
   int32_t max_clusters;    // 0 = default (64)
   int32_t skip_dc_smoothing;
   int32_t random_cmap;     // random chroma-from-luma factors (always on in random mode)
-  int32_t reserved[6];
+  int32_t zero_ac;         // random mode: leave every AC coefficient zero (DC-only stream)
+  int32_t reserved[5];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -1045,11 +1046,22 @@ static void EncodeRandom(size_t xs, size_t ys, const Params& p, std::vector<uint
     for (size_t bx = 0; bx < f.xb; bx++) {
       if (f.acs[by * f.xb + bx] != 0xFF) continue;
       int st = -1;
+      if (allowed.size() <= 8 && bx % 32 == 0 && by % 32 == 0) {
+        // small masks are used to target specific strategies: guarantee the largest one that fits at group origins
+        size_t best_area = 0;
+        for (int cand : allowed) {
+          size_t area = size_t(jxh::kCoveredX[cand]) * jxh::kCoveredY[cand];
+          if (area > best_area && Fits(f, bx, by, cand)) {
+            best_area = area;
+            st = cand;
+          }
+        }
+      }
       for (int tries = 0; tries < 6 && st < 0; tries++) {
         int cand = allowed[rng.Below(uint32_t(allowed.size()))];
         // big transforms are rarer so that small ones get space too
         size_t area = size_t(jxh::kCoveredX[cand]) * jxh::kCoveredY[cand];
-        if (area >= 64 && allowed.size() > 1 && rng.Below(uint32_t(area / 16)) != 0) continue;
+        if (area >= 64 && allowed.size() > 8 && rng.Below(uint32_t(area / 16)) != 0) continue;
         if (Fits(f, bx, by, cand)) st = cand;
       }
       if (st < 0) st = (mask & 1) ? 0 : (Fits(f, bx, by, allowed[0]) ? allowed[0] : 0);
@@ -1090,7 +1102,7 @@ static void EncodeRandom(size_t xs, size_t ys, const Params& p, std::vector<uint
         const int st = a >> 1;
         const size_t cx = jxh::kCoveredX[st], cy = jxh::kCoveredY[st];
         const size_t size = cx * cy * 64, cstride = std::max(cx, cy) * 8, lrows = std::min(cx, cy), lcols = std::max(cx, cy);
-        const float density = 0.02f + 0.25f * rng.Uniform();  // per-block sparsity
+        const float density = p.zero_ac ? 0.0f : 0.02f + 0.25f * rng.Uniform();  // per-block sparsity
         for (int c = 0; c < 3; c++) {
           int32_t* q = co.data() + size_t(c) * 65536 + offset;
           for (size_t k = 0; k < size; k++) {
@@ -1118,8 +1130,8 @@ struct JxlEncParams {
   float distance;
   int32_t epf_iters, gab, strategy_mode;
   uint32_t strategy_mask, seed;
-  int32_t max_clusters, skip_dc_smoothing, random_cmap;
-  int32_t reserved[6];
+  int32_t max_clusters, skip_dc_smoothing, random_cmap, zero_ac;
+  int32_t reserved[5];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

@@ -1,0 +1,183 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle on the same streams.
+Bars: quantised coefficients bit-exact (integer work); float planes within 2e-5 absolute (values are O(1); the
+reference's own fast-vs-slow pipeline tolerance is 2e-4, render_pipeline_test.cc:320-327); RGB8 within 1 level (the
+final rounding may flip on a float difference of 1e-7; the reference itself differs across SIMD targets by more)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _used_mask(o):
+    """Per group/channel: which coefficient slots belong to a varblock (the rest of the 65536-slot plane is unused)."""
+    i = o.info
+    acs = o.buffer("acs").reshape(i["ysize_blocks"], i["xsize_blocks"])
+    xg = (i["xsize"] + 255) // 256
+    used = np.zeros(i["num_groups"], np.int64)
+    for g in range(i["num_groups"]):
+        gy, gx = divmod(g, xg)
+        used[g] = acs[gy * 32:(gy + 1) * 32, gx * 32:(gx + 1) * 32].size * 64
+    return used
+
+
+def _compare(J, jxlo, data, check_rgb=True):
+    f = J.Frame(data, threads=2)
+    o = jxlo.Decoded(data)
+    c = J.HipContext()
+    try:
+        c.upload(f)
+        c.run_entropy()
+        c.sync()
+        r, flags = c.errors()
+        assert r == 0 and not any(flags)
+        co = c.download("coeffs").astype(np.int32)
+        ref = o.planes("coeffs")
+        used = _used_mask(o)
+        for g in range(o.info["num_groups"]):
+            assert np.array_equal(co[g, :, :used[g]], ref[g, :, :used[g]]), "coefficients differ in group %d" % g
+        c.run_transform()
+        c.sync()
+        x = c.download("xyb_idct")
+        assert np.abs(x - o.planes("xyb_idct")).max() < 2e-5
+        c.run_filter_color()
+        c.sync()
+        ys, xs = o.info["ysize"], o.info["xsize"]
+        xf = c.download("xyb_filtered")[:, :ys, :xs]
+        assert np.abs(xf - o.planes("xyb_filtered")[:, :, :xs]).max() < 2e-5
+        rgb = c.rgb8()
+        d = np.abs(rgb.astype(int) - o.rgb8.astype(int))
+        assert d.max() <= 1
+        assert (d > 0).mean() < 1e-3
+        return rgb
+    finally:
+        c.close()
+        f.close()
+        o.close()
+
+
+@pytest.mark.parametrize("size,kw", [
+    ((64, 64), dict()),                                   # single TOC entry: AC data starts mid-byte
+    ((8, 8), dict(strategy_mode=0)),                      # one block
+    ((1, 1), dict(strategy_mode=0)),
+    ((257, 255), dict()),                                 # ragged groups, xsize not a multiple of 8
+    ((520, 300), dict()),
+    ((520, 300), dict(distance=2.0)),                     # EPF1 + EPF2
+    ((520, 300), dict(distance=4.5, gab=0)),              # EPF0 + EPF1 + EPF2, no Gaborish
+    ((520, 300), dict(epf_iters=0, gab=0)),               # no filters
+    ((777, 513), dict(strategy_mode=2, random_cmap=1)),   # random DCT-family tiling up to 256x256, random CfL
+    ((300, 200), dict(skip_dc_smoothing=1)),
+])
+def test_image_streams(built, size, kw):
+    import jxlo
+    J = built
+    _compare(J, jxlo, J.encode_rgb8(J.synth_image(size[0], size[1], seed=size[0]), **kw))
+
+
+@pytest.mark.parametrize("strategy", list(range(27)))
+def test_every_strategy_random_stream(built, strategy):
+    import jxlo
+    J = built
+    _compare(J, jxlo, J.encode_random(512, 512, seed=100 + strategy, strategy_mask=(1 << strategy) | 1))
+
+
+@pytest.mark.parametrize("seed,epf", [(1, 0), (2, 1), (3, 2), (4, 3)])
+def test_all_strategies_mixed(built, seed, epf):
+    import jxlo
+    J = built
+    _compare(J, jxlo, J.encode_random(777, 600, seed=seed, epf_iters=epf))
+
+
+def test_full_size_4k(built):
+    """BASELINE.json config[1]: 3840x2160 d1.0 — direct comparison with the oracle (a few seconds of CPU)."""
+    import jxlo
+    J = built
+    _compare(J, jxlo, J.encode_rgb8(J.synth_image(3840, 2160)))
+
+
+def test_context_reuse_and_idempotence(built):
+    """Re-running the stages on resident inputs gives identical bytes; a context can take a smaller frame after a
+    larger one."""
+    J = built
+    a = J.encode_rgb8(J.synth_image(600, 400))
+    b = J.encode_rgb8(J.synth_image(200, 100, seed=2))
+    c = J.HipContext()
+    fa, fb = J.Frame(a), J.Frame(b)
+    c.upload(fa)
+    c.run_all()
+    r1 = c.rgb8()
+    c.run_all()
+    assert np.array_equal(r1, c.rgb8())
+    c.upload(fb)
+    c.run_all()
+    r2 = c.rgb8()
+    assert r2.shape == (100, 200, 3)
+    assert np.array_equal(r2, J.decode_rgb8(b))
+    c.close()
+
+
+def test_corrupt_sections_are_flagged_not_fatal(built):
+    J = built
+    data = bytearray(J.encode_rgb8(J.synth_image(520, 300)))
+    f = J.Frame(bytes(data))
+    n = len(data)
+    for i in range(n - 3000, n - 2900):  # inside the AC group sections (they are last in the file)
+        data[i] ^= 0xA5
+    f2 = J.Frame(bytes(data))
+    c = J.HipContext()
+    c.upload(f2)
+    c.run_all()
+    r, flags = c.errors()
+    assert r != 0 and any(flags)
+    c.upload(f)
+    c.run_all()
+    r, flags = c.errors()
+    assert r == 0
+    c.close()
+
+
+def test_jxl_decoder_api_full_image(built):
+    """The drop-in boundary: same call sequence as lib/extras/dec/jxl.cc:140-669 with a thread runner."""
+    import jxlo
+    J = built
+    L = J.lib()
+    L.JxlDecoderCreate.restype = ctypes.c_void_p
+    L.JxlDecoderCreate.argtypes = [ctypes.c_void_p]
+    for n in ("JxlDecoderDestroy", "JxlDecoderProcessInput", "JxlDecoderCloseInput"):
+        getattr(L, n).argtypes = [ctypes.c_void_p]
+    L.JxlDecoderSubscribeEvents.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.JxlDecoderSetInput.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.JxlDecoderSetParallelRunner.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+
+    class Fmt(ctypes.Structure):
+        _fields_ = [("num_channels", ctypes.c_uint32), ("data_type", ctypes.c_int), ("endianness", ctypes.c_int), ("align", ctypes.c_size_t)]
+
+    L.JxlDecoderImageOutBufferSize.argtypes = [ctypes.c_void_p, ctypes.POINTER(Fmt), ctypes.POINTER(ctypes.c_size_t)]
+    L.JxlDecoderSetImageOutBuffer.argtypes = [ctypes.c_void_p, ctypes.POINTER(Fmt), ctypes.c_void_p, ctypes.c_size_t]
+    data = J.encode_rgb8(J.synth_image(333, 222))
+    ref = jxlo.Decoded(data, dumps=False).rgb8
+    for nc, align in [(3, 0), (4, 0), (3, 64)]:
+        dec = L.JxlDecoderCreate(None)
+        pool = L.JxlThreadParallelRunnerCreate(None, 2)
+        assert L.JxlDecoderSetParallelRunner(dec, ctypes.cast(L.JxlThreadParallelRunner, ctypes.c_void_p), pool) == 0
+        assert L.JxlDecoderSubscribeEvents(dec, 0x40 | 0x1000) == 0
+        L.JxlDecoderSetInput(dec, data, len(data))
+        L.JxlDecoderCloseInput(dec)
+        assert L.JxlDecoderProcessInput(dec) == 0x40
+        assert L.JxlDecoderProcessInput(dec) == 5  # JXL_DEC_NEED_IMAGE_OUT_BUFFER
+        fmt = Fmt(nc, 2, 0, align)
+        size = ctypes.c_size_t()
+        assert L.JxlDecoderImageOutBufferSize(dec, ctypes.byref(fmt), ctypes.byref(size)) == 0
+        stride = 333 * nc if not align else (333 * nc + align - 1) // align * align
+        assert size.value == stride * 221 + 333 * nc
+        buf = np.zeros(size.value, np.uint8)
+        assert L.JxlDecoderSetImageOutBuffer(dec, ctypes.byref(fmt), buf.ctypes.data, size.value) == 0
+        assert L.JxlDecoderProcessInput(dec) == 0x1000  # JXL_DEC_FULL_IMAGE
+        assert L.JxlDecoderProcessInput(dec) == 0
+        rows = np.stack([buf[y * stride: y * stride + 333 * nc].reshape(333, nc) for y in range(222)])
+        assert np.abs(rows[..., :3].astype(int) - ref.astype(int)).max() <= 1
+        if nc == 4:
+            assert (rows[..., 3] == 255).all()
+        L.JxlDecoderDestroy(dec)
+        L.JxlThreadParallelRunnerDestroy(pool)
