@@ -20,8 +20,9 @@ typedef struct JxlAmdFrame JxlAmdFrame;
  * has been uploaded. runner may be NULL (sequential). Returns 0 or a non-zero code; see jxlamd_last_error(). */
 int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runner, void* runner_opaque, JxlAmdFrame** frame);
 void jxlamd_frame_free(JxlAmdFrame* frame);
-/* info[0..11]: xsize, ysize, xsize_blocks, ysize_blocks, num_groups, num_dc_groups, num_passes, used_acs mask,
- * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes. */
+/* info[0..15]: xsize, ysize, xsize_blocks, ysize_blocks, num_groups, num_dc_groups, num_passes, used_acs mask,
+ * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes, then of pass 0: log2 alphabet size,
+ * number of clustered histograms, context map bytes; [15] reserved (0). */
 void jxlamd_frame_info(const JxlAmdFrame* frame, uint32_t* info);
 int jxlamd_frame_upload(const JxlAmdFrame* frame, JxlHipContext* ctx);
 /* Thread-local description of the last failure of a jxlamd_* call ("" if none). */

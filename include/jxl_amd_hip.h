@@ -122,6 +122,11 @@ int jxlhip_run_transform(JxlHipContext* ctx);
 int jxlhip_run_filter_color(JxlHipContext* ctx);
 /* Convenience: all three, in order. */
 int jxlhip_run_all(JxlHipContext* ctx);
+/* Entropy stage of `n` resident frames (contexts on one device) as ONE kernel launch on ctxs[0]'s stream, so that the
+ * per-section serial decoders of all frames fill the machine together; the other contexts' streams are made to wait
+ * for it. Stage time is then available from ctxs[0] (which == 0). Falls back to n separate launches when the frames
+ * cannot share a launch. */
+int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n);
 
 /* Blocks until the context's stream is idle. */
 int jxlhip_sync(JxlHipContext* ctx);

@@ -45,6 +45,7 @@ def lib():
         L.jxlhip_ctx_destroy.argtypes = [vp]
         for name in ("jxlhip_run_entropy", "jxlhip_run_transform", "jxlhip_run_filter_color", "jxlhip_run_all", "jxlhip_sync"):
             getattr(L, name).argtypes = [vp]
+        L.jxlhip_run_entropy_batch.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
         L.jxlhip_download_rgb8.argtypes = [vp, vp, ctypes.c_size_t]
         L.jxlhip_rgb8_device_ptr.argtypes = [vp]
         L.jxlhip_rgb8_device_ptr.restype = vp
@@ -73,7 +74,7 @@ class Frame:
     """Host-parsed frame (headers, DC, tables); AC sections stay compressed."""
 
     INFO = ("xsize", "ysize", "xsize_blocks", "ysize_blocks", "num_groups", "num_dc_groups", "num_passes", "used_acs",
-            "epf_iters", "gab", "coef_bits", "ac_bytes")
+            "epf_iters", "gab", "coef_bits", "ac_bytes", "log_alpha", "num_clusters", "ctx_map_size")
 
     def __init__(self, data, threads=0):
         L = lib()
@@ -89,7 +90,7 @@ class Frame:
         finally:
             if pool:
                 L.JxlThreadParallelRunnerDestroy(pool)
-        info = (ctypes.c_uint32 * 12)()
+        info = (ctypes.c_uint32 * 16)()
         L.jxlamd_frame_info(self._h, info)
         self.info = dict(zip(self.INFO, list(info)))
 
@@ -173,6 +174,12 @@ class HipContext:
             dt = np.int16 if fi["coef_bits"] == 16 else np.int32
             return buf.view(dt).reshape(fi["num_groups"], 3, 65536)
         return buf.view(np.float32).reshape(3, fi["ysize_blocks"] * 8, fi["xsize_blocks"] * 8)
+
+
+def run_entropy_batch(ctxs):
+    """Entropy stage of several resident frames as one kernel launch (jxlhip_run_entropy_batch)."""
+    arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib().jxlhip_run_entropy_batch(arr, len(ctxs)), "jxlhip_run_entropy_batch")
 
 
 def decode_rgb8(data, device=0, threads=0):

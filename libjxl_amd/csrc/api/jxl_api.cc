@@ -95,6 +95,9 @@ void jxlamd_frame_info(const JxlAmdFrame* f, uint32_t* info) {
   uint64_t total = 0;
   for (uint32_t s : P.section_size) total += s;
   info[11] = uint32_t(total);
+  info[12] = P.passes.empty() ? 0 : uint32_t(P.passes[0].log_alpha);
+  info[13] = P.passes.empty() ? 0 : uint32_t(P.passes[0].num_clusters);
+  info[14] = P.passes.empty() ? 0 : uint32_t(P.passes[0].ctx_map.size());
 }
 
 int jxlamd_frame_upload(const JxlAmdFrame* f, JxlHipContext* ctx) {

@@ -5,13 +5,16 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../../include/jxl_amd_hip.h"
 #include "jxl_hip_kernels.h"
+#include "jxl_hip_entropy_lanes.h"
 
 namespace {
 #include "../host/afv_basis.inc"
@@ -56,6 +59,10 @@ struct PassBufs {
   Buf ctx_map, alias, cfg, orders;
 };
 
+constexpr int kEntropyWPG = 4;  // waves (= AC sections) per workgroup of the scalar-form entropy kernel
+constexpr int kLanesWPG = 4;    // waves per workgroup of the lane-parallel entropy kernel (one frame per workgroup)
+constexpr size_t kLdsBudget = 150 * 1024;
+
 }  // namespace
 
 struct JxlHipContext {
@@ -72,6 +79,17 @@ struct JxlHipContext {
   // buffers
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
   Buf plane[3], rgb, tlist, scratch;
+  Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
+  Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
+  uint32_t batch_passes = 1, batch_wait_shift = 3;
+  int batch_kernel = -1;
+  std::vector<uint32_t> sec_size_host, pass_clusters, pass_log_alpha;
+  std::vector<const JxlHipContext*> batch_ctxs;
+  std::vector<uint64_t> batch_gens;
+  uint32_t batch_wgs = 0;
+  size_t batch_lds = 0;
+  hipEvent_t batch_done = nullptr;
+  uint64_t generation = 0;            // bumped by every jxlhip_frame_upload
   std::vector<PassBufs> pass_bufs;
   uint32_t list_begin[27] = {}, list_count[27] = {};
   jxlhip::EntropyParams ep;
@@ -148,7 +166,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -158,6 +176,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   }
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
+  if (c->batch_done) (void)hipEventDestroy(c->batch_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -224,6 +243,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = Upload(c, c->sections, packed.data(), packed.size()))) return r;
   if ((r = Upload(c, c->sec_word, sec_word.data(), nsec * 4))) return r;
   if ((r = Upload(c, c->sec_size, sec_size.data(), nsec * 4))) return r;
+  c->sec_size_host = sec_size;
+  c->pass_clusters.assign(d->num_passes, 0);
+  c->pass_log_alpha.assign(d->num_passes, 0);
   // the staging vectors die at the end of this call: finish these copies now
   HIP_TRY(hipStreamSynchronize(c->stream));
   if ((r = Upload(c, c->blocks, d->blocks, size_t(d->num_blocks) * sizeof(JxlHipVarBlock)))) return r;
@@ -260,6 +282,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     pd[p].orders = pb.orders.as<uint16_t>();
     memcpy(pd[p].order_offset, s.order_offset, sizeof(s.order_offset));
     pd[p].log_alpha = s.log_alpha;
+    c->pass_clusters[p] = s.num_clusters;
+    c->pass_log_alpha[p] = s.log_alpha;
     pd[p].num_clusters = s.num_clusters;
     pd[p].shift = s.shift;
     pd[p].alias_lds = 0;
@@ -321,10 +345,13 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   ep.errors = c->errors.as<uint32_t>();
   ep.lds_ctx_bytes = (nctx + 16 + 15) & ~15u;
   const size_t lds_budget = 150 * 1024;
-  c->alias_lds = ep.lds_ctx_bytes + alias_bytes_max + 3072 <= lds_budget;
+  c->alias_lds = ep.lds_ctx_bytes + alias_bytes_max + 1024 + 4 * 5120 <= lds_budget;
   ep.lds_alias_bytes = c->alias_lds ? uint32_t((alias_bytes_max + 15) & ~size_t(15)) : 0;
   c->lds_entropy = ep.lds_ctx_bytes + ep.lds_alias_bytes + 3072;
   if (size_t(d->block_ctx_lut_size) < size_t(3) * 13 * ep.nq * ep.ndc) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if ((r = c->ep_dev.Ensure(sizeof(ep)))) return r;
+  HIP_TRY(hipMemcpy(c->ep_dev.p, &ep, sizeof(ep), hipMemcpyHostToDevice));
+  c->generation++;
 
   jxlhip::TransformParams& tp = c->tp;
   memset(&tp, 0, sizeof(tp));
@@ -384,10 +411,43 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
 
 }  // extern "C"
 
+// Which entropy kernel: 2 (default) lane-parallel k_entropy_lanes, 1 wave-per-section scalar k_entropy_uni,
+// 0 the first k_entropy_ans. Environment override JXLHIP_ENTROPY is for A/B measurements only.
+static int EntropyKernelChoice() {
+  static const int v = [] {
+    const char* e = getenv("JXLHIP_ENTROPY");
+    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
+  }();
+  return v;
+}
+static int EnvInt(const char* name, int def) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : def;
+}
+
 template <typename CoefT>
 static int LaunchEntropy(JxlHipContext* c) {
   const dim3 grid(c->ng), block(64);
-  if (c->alias_lds) {
+  const bool use_uni = EntropyKernelChoice() != 0;
+  if (c->alias_lds && use_uni) {
+    // scalar-form kernel: alias tables, context map and uint configs shared in LDS by the waves of a workgroup
+    const size_t shared = size_t(c->ep.lds_ctx_bytes) + c->ep.lds_alias_bytes + 1024;
+    jxlhip::EntropyBatch b{c->ep_dev.as<jxlhip::EntropyParams>(), nullptr};
+    if (c->ep.num_hist == 1) {
+      constexpr int WPG = kEntropyWPG;
+      auto k = jxlhip::k_entropy_uni<CoefT, WPG>;
+      const size_t lds = shared + WPG * 5120;
+      if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+      hipLaunchKernelGGL(k, dim3((c->ng + WPG - 1) / WPG), dim3(64 * WPG), lds, c->stream, b);
+    } else {
+      auto k = jxlhip::k_entropy_uni<CoefT, 1>;
+      const size_t lds = shared + 5120;
+      if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+      hipLaunchKernelGGL(k, grid, block, lds, c->stream, b);
+    }
+  } else if (c->alias_lds) {
     auto k = jxlhip::k_entropy_ans<CoefT, true>;
     if (c->lds_entropy > 48 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c->lds_entropy)));
@@ -400,7 +460,7 @@ static int LaunchEntropy(JxlHipContext* c) {
   return 0;
 }
 
-extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
+static int RunEntropySingle(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   HIP_TRY(hipSetDevice(c->device));
@@ -457,6 +517,181 @@ static int LaunchTransforms(JxlHipContext* c) {
     HIP_TRY(hipGetLastError());
   }
   return 0;
+}
+
+static size_t LanesLdsFor(const JxlHipContext* c) {
+  size_t m = 0;
+  for (uint32_t p = 0; p < c->np; p++) {
+    const jxlhip::LanesLds l = jxlhip::LanesLdsLayout(c->ep.num_hist, c->ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p],
+                                                      39 * c->ep.nq * c->ep.ndc, kLanesWPG);
+    m = l.total > m ? l.total : m;
+  }
+  return m;
+}
+
+template <typename CoefT>
+static int LaunchEntropyLanes(JxlHipContext* c0, uint32_t pass) {
+  auto k = jxlhip::k_entropy_lanes<CoefT, kLanesWPG>;
+  if (c0->batch_lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
+  jxlhip::EntropyLaneBatch b;
+  b.params = c0->batch_params.as<jxlhip::EntropyParams>();
+  b.wg_frame = c0->batch_map.as<uint32_t>();
+  b.lane_group = c0->batch_lanes.as<uint32_t>() + size_t(pass) * c0->batch_wgs * kLanesWPG * 64;
+  b.pass = pass;
+  b.wait_shift = c0->batch_wait_shift;
+  hipLaunchKernelGGL(k, dim3(c0->batch_wgs), dim3(64 * kLanesWPG), c0->batch_lds, c0->stream, b);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <typename CoefT>
+static int LaunchEntropyUniBatch(JxlHipContext* c0) {
+  auto k = jxlhip::k_entropy_uni<CoefT, kEntropyWPG>;
+  if (c0->batch_lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
+  jxlhip::EntropyBatch b{c0->batch_params.as<jxlhip::EntropyParams>(), c0->batch_map.as<uint32_t>()};
+  hipLaunchKernelGGL(k, dim3(c0->batch_wgs), dim3(64 * kEntropyWPG), c0->batch_lds, c0->stream, b);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Builds (or re-uses) the description of a batch: parameter blocks, workgroup -> frame map and, for the lane-parallel
+// kernel, the lane -> section assignment (sections sorted by compressed size inside each frame so that the lanes of a
+// wave finish together; `lanes` populated lanes per wave so that small batches still spread over all SIMDs).
+static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n, int kernel) {
+  bool same = c0->batch_ctxs.size() == n && c0->batch_kernel == kernel;
+  for (size_t i = 0; same && i < n; i++) same = c0->batch_ctxs[i] == ctxs[i] && c0->batch_gens[i] == ctxs[i]->generation;
+  if (same) return 0;
+  std::vector<jxlhip::EntropyParams> params(n);
+  std::vector<uint32_t> map, lanes;
+  size_t lds = 0;
+  uint32_t max_passes = 1;
+  for (size_t i = 0; i < n; i++) {
+    params[i] = ctxs[i]->ep;
+    max_passes = ctxs[i]->np > max_passes ? ctxs[i]->np : max_passes;
+  }
+  if (kernel == 2) {
+    size_t total_sections = 0;
+    for (size_t i = 0; i < n; i++) total_sections += ctxs[i]->ng;
+    // populated lanes per wave: aim at ~2 waves per SIMD (256 CUs x 4 SIMDs) before packing lanes more densely
+    uint32_t lanes_per_wave = 1;
+    const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 2048));
+    while (lanes_per_wave < 64 && (total_sections + lanes_per_wave - 1) / lanes_per_wave > target_waves) lanes_per_wave *= 2;
+    const int forced = EnvInt("JXLHIP_LANES", 0);
+    if (forced >= 1 && forced <= 64) lanes_per_wave = uint32_t(forced);
+    c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 3));
+    const uint32_t per_wg = lanes_per_wave * kLanesWPG;
+    std::vector<uint32_t> frame_wg0(n);
+    for (size_t i = 0; i < n; i++) {
+      frame_wg0[i] = uint32_t(map.size());
+      const uint32_t wgs = (ctxs[i]->ng + per_wg - 1) / per_wg;
+      for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i));
+      const size_t l = LanesLdsFor(ctxs[i]);
+      lds = l > lds ? l : lds;
+    }
+    const size_t per_pass = map.size() * kLanesWPG * 64;
+    lanes.assign(per_pass * max_passes, 0xFFFFFFFFu);
+    std::vector<uint32_t> order;
+    for (size_t i = 0; i < n; i++) {
+      const JxlHipContext* c = ctxs[i];
+      for (uint32_t p = 0; p < c->np; p++) {
+        order.resize(c->ng);
+        for (uint32_t g = 0; g < c->ng; g++) order[g] = g;
+        const uint32_t* sz = c->sec_size_host.data() + size_t(p) * c->ng;
+        std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
+        for (uint32_t j = 0; j < c->ng; j++) {
+          const uint32_t wave = j / lanes_per_wave, lane = j % lanes_per_wave;
+          lanes[per_pass * p + (size_t(frame_wg0[i]) * kLanesWPG + wave) * 64 + lane] = order[j];
+        }
+      }
+    }
+  } else {
+    for (size_t i = 0; i < n; i++) {
+      const uint32_t wgs = (ctxs[i]->ng + kEntropyWPG - 1) / kEntropyWPG;
+      for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i) << 16 | j);
+      const size_t l = size_t(ctxs[i]->ep.lds_ctx_bytes) + ctxs[i]->ep.lds_alias_bytes + 1024 + kEntropyWPG * 5120;
+      lds = l > lds ? l : lds;
+    }
+  }
+  int r;
+  if ((r = c0->batch_params.Ensure(params.size() * sizeof(params[0])))) return r;
+  if ((r = c0->batch_map.Ensure(map.size() * 4))) return r;
+  HIP_TRY(hipMemcpy(c0->batch_params.p, params.data(), params.size() * sizeof(params[0]), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c0->batch_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+  if (!lanes.empty()) {
+    if ((r = c0->batch_lanes.Ensure(lanes.size() * 4))) return r;
+    HIP_TRY(hipMemcpy(c0->batch_lanes.p, lanes.data(), lanes.size() * 4, hipMemcpyHostToDevice));
+  }
+  c0->batch_ctxs.assign(ctxs, ctxs + n);
+  c0->batch_gens.resize(n);
+  for (size_t i = 0; i < n; i++) c0->batch_gens[i] = ctxs[i]->generation;
+  c0->batch_wgs = uint32_t(map.size());
+  c0->batch_lds = lds;
+  c0->batch_passes = max_passes;
+  c0->batch_kernel = kernel;
+  return 0;
+}
+
+extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
+  if (!ctxs || !n || n > 0xFFFF) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JxlHipContext* c0 = ctxs[0];
+  int kernel = EntropyKernelChoice();
+  for (size_t i = 0; i < n; i++) {
+    const JxlHipContext* c = ctxs[i];
+    if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+    if (c->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (kernel == 2 && (c->coef_bits != c0->coef_bits || LanesLdsFor(c) > kLdsBudget)) kernel = 1;
+  }
+  if (kernel == 1)
+    for (size_t i = 0; i < n; i++) {
+      const JxlHipContext* c = ctxs[i];
+      if (!c->alias_lds || c->ep.num_hist != 1 || c->coef_bits != c0->coef_bits || c->ng > 0xFFFF * kEntropyWPG) kernel = 0;
+    }
+  if (kernel == 0) {
+    for (size_t i = 0; i < n; i++) {
+      int r = RunEntropySingle(ctxs[i]);
+      if (r) return r;
+    }
+    return 0;
+  }
+  HIP_TRY(hipSetDevice(c0->device));
+  if (!c0->batch_done) HIP_TRY(hipEventCreateWithFlags(&c0->batch_done, hipEventDisableTiming));
+  int r = PrepareBatch(c0, ctxs, n, kernel);
+  if (r) return r;
+  // the batch kernel runs on the first context's stream, after whatever the other contexts still have in flight
+  for (size_t i = 1; i < n; i++)
+    if (ctxs[i]->ev_valid[2]) HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev[5], 0));
+  HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
+  for (size_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(ctxs[i]->errors.p, 0, size_t(ctxs[i]->ng) * 4, c0->stream));
+  if (kernel == 2) {
+    // the lane kernel only writes non-zero coefficients
+    for (size_t i = 0; i < n; i++)
+      HIP_TRY(hipMemsetAsync(ctxs[i]->coeffs.p, 0, size_t(ctxs[i]->ng) * 3 * 65536 * (ctxs[i]->coef_bits / 8), c0->stream));
+    for (uint32_t p = 0; p < c0->batch_passes; p++) {
+      r = c0->coef_bits == 16 ? LaunchEntropyLanes<int16_t>(c0, p) : LaunchEntropyLanes<int32_t>(c0, p);
+      if (r) return r;
+    }
+  } else {
+    r = c0->coef_bits == 16 ? LaunchEntropyUniBatch<int16_t>(c0) : LaunchEntropyUniBatch<int32_t>(c0);
+    if (r) return r;
+  }
+  HIP_TRY(hipEventRecord(c0->ev[1], c0->stream));
+  c0->ev_valid[0] = true;
+  if (n > 1) {
+    HIP_TRY(hipEventRecord(c0->batch_done, c0->stream));
+    for (size_t i = 1; i < n; i++) {
+      HIP_TRY(hipStreamWaitEvent(ctxs[i]->stream, c0->batch_done, 0));
+      ctxs[i]->ev_valid[0] = false;
+    }
+  }
+  return 0;
+}
+
+extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  return jxlhip_run_entropy_batch(&c, 1);
 }
 
 extern "C" {

@@ -257,6 +257,336 @@ __global__ __launch_bounds__(64) void k_entropy_ans(EntropyParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- entropy, scalar form
+// Same decode as k_entropy_ans, restructured so that the serial chain runs on the scalar unit: every lane of the
+// wave executes the identical (wave-uniform) control flow, all decoder state lives in SGPRs, table reads that have a
+// uniform address go through the scalar cache (constant address space) or LDS + readfirstlane, and only the
+// coefficient stores are vector instructions (lane 0). The context-map / uint-config lookups of the NEXT coefficient
+// are issued speculatively for both outcomes (zero / non-zero) before the current symbol is resolved, which takes
+// them off the dependency chain: per symbol the chain is one LDS alias-table read + ~30 scalar ALU ops.
+typedef const uint32_t __attribute__((address_space(4)))* CU32;
+__device__ __forceinline__ CU32 AsConst(const void* p) { return (CU32)(uintptr_t)p; }
+__device__ __forceinline__ uint32_t Uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+
+__constant__ uint32_t c_strategy_info[27] = {  // covered_x | covered_y << 8 | log2_covered << 16 | order bucket << 24
+    0x00000101, 0x01000101, 0x01000101, 0x01000101, 0x02020202, 0x03040404, 0x04010201, 0x04010102, 0x05020401,
+    0x05020104, 0x06030402, 0x06030204, 0x01000101, 0x01000101, 0x01000101, 0x01000101, 0x01000101, 0x01000101,
+    0x07060808, 0x08050804, 0x08050408, 0x09081010, 0x0A071008, 0x0A070810, 0x0B0A2020, 0x0C092010, 0x0C091020};
+
+struct SBits {
+  CU32 p;
+  uint32_t idx, nwords;  // idx = number of words already moved into buf
+  uint64_t buf;
+  uint32_t bits;
+  uint32_t next;         // word idx, preloaded
+};
+__device__ __forceinline__ void SRefill(SBits& b) {
+  if (b.bits < 32) {
+    b.buf |= uint64_t(b.next) << b.bits;
+    b.bits += 32;
+    b.idx++;
+    const uint32_t j = b.idx < b.nwords ? b.idx : b.nwords;  // word `nwords` is zero padding
+    b.next = b.p[j];
+  }
+}
+__device__ __forceinline__ uint32_t SRead(SBits& b, uint32_t n) {
+  const uint32_t v = uint32_t(b.buf) & ((n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1));
+  b.buf >>= n;
+  b.bits -= n;
+  return v;
+}
+__device__ __forceinline__ uint32_t FreqCtx(uint32_t k) {  // kCoeffFreqContext, arithmetic form (k in 1..63)
+  return k < 16 ? k - 1 : (k < 32 ? 15 + ((k - 16) >> 1) : 23 + ((k - 32) >> 2));
+}
+
+// Decodes one symbol from `cluster` (uniform); `cfg` = packed uint config of that cluster.
+__device__ __forceinline__ uint32_t SReadHybrid(SBits& br, uint32_t& state, uint32_t cluster, uint32_t cfg, const uint2* l_alias,
+                                                uint32_t log_alpha) {
+  const uint32_t log_entry = 12 - log_alpha;
+  const uint32_t res = state & 0xFFFu;
+  const uint32_t i = res >> log_entry;
+  const uint32_t pos = res & ((1u << log_entry) - 1);
+  const uint2 ev = l_alias[(cluster << log_alpha) + i];
+  const uint32_t e0 = Uni(ev.x), e1 = Uni(ev.y);
+  const uint32_t cutoff = e0 & 0xFF;
+  const bool greater = pos >= cutoff;
+  const uint32_t token = greater ? ((e0 >> 8) & 0xFF) : i;
+  const uint32_t off = (greater ? (e1 & 0xFFFF) : 0u) + pos;
+  const uint32_t freq = greater ? (e1 >> 16) : (e0 >> 16);
+  state = freq * (state >> 12) + off;
+  SRefill(br);
+  if (state < (1u << 16)) state = (state << 16) | SRead(br, 16);
+  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+  const uint32_t split_token = 1u << split_exp;
+  if (token < split_token) return token;
+  uint32_t nbits = split_exp - (msb + lsb) + ((token - split_token) >> (msb + lsb));
+  nbits &= 31u;
+  const uint32_t low = token & ((1u << lsb) - 1);
+  const uint32_t hi = token >> lsb;
+  SRefill(br);
+  const uint32_t bits = SRead(br, nbits);
+  return (((((1u << msb) | (hi & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
+}
+
+__device__ __forceinline__ uint32_t NnzCtx(uint32_t n) {  // kCoeffNumNonzeroContext, arithmetic form (n in 1..63)
+  const uint32_t b = (n > 1) + (n > 2) + (n > 4) + (n > 8) + (n > 12) + (n > 20) + (n > 32);
+  return uint32_t((0xCEB4987B5D3E1F00ull >> (8 * b)) & 0xFF);
+}
+
+// WPG waves per workgroup, one 256x256 group (AC section) per wave; the waves of a workgroup share one LDS copy of
+// the context map, alias tables and uint configs. Each wave owns an nzeros map and a small (k, value) list in LDS:
+// the serial scalar loop only appends non-zero coefficients to the list; all 64 lanes then scatter the list through
+// the coefficient-order table into HBM (so neither the order lookup nor the stores sit on the serial chain).
+struct EntropyBatch {
+  const EntropyParams* params;  // one per frame (device memory)
+  const uint32_t* wg_map;       // per workgroup: frame << 16 | workgroup index inside the frame; NULL = single frame
+};
+
+template <typename CoefT, int WPG>
+__global__ __launch_bounds__(64 * WPG) void k_entropy_uni(EntropyBatch B) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  constexpr uint32_t kList = 256;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = Uni(threadIdx.x >> 6);
+  const uint32_t wg = B.wg_map ? AsConst(B.wg_map)[blockIdx.x] : blockIdx.x;
+  // the frame's parameter block is read through the constant address space (scalar loads, never clobbered)
+  const EntropyParams __attribute__((address_space(4)))* Pp =
+      (const EntropyParams __attribute__((address_space(4)))*)(uintptr_t)(B.params + (wg >> 16));
+#define P (*Pp)
+  const uint32_t g = (wg & 0xFFFF) * WPG + wave;
+  const bool have_group = g < P.num_groups;
+  uint8_t* l_ctx = lds_raw;
+  uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + P.lds_ctx_bytes);
+  uint32_t* l_cfg = reinterpret_cast<uint32_t*>(lds_raw + P.lds_ctx_bytes + P.lds_alias_bytes);  // 256
+  uint8_t* l_priv = reinterpret_cast<uint8_t*>(l_cfg + 256) + wave * (3072 + kList * 8);
+  uint8_t* l_nz = l_priv;                                         // 3 * 1024
+  uint2* l_list = reinterpret_cast<uint2*>(l_priv + 3072);        // kList x (k, value)
+  const CU32 gbb = AsConst(P.gbb);
+  const CU32 blk = AsConst(P.blocks);
+  uint32_t b0 = 0, b1 = 0;
+  if (have_group) {
+    b0 = gbb[g];
+    b1 = gbb[g + 1];
+  }
+  CoefT* gco = static_cast<CoefT*>(P.coeffs) + size_t(have_group ? g : 0) * 3 * 65536;
+  uint32_t total = 0;
+  if (b1 > b0) {
+    const uint32_t w1 = blk[(b1 - 1) * 3 + 1], w2 = blk[(b1 - 1) * 3 + 2];
+    total = w2 + (64u << ((c_strategy_info[w1 & 0xFF] >> 16) & 0xFF));
+  }
+  const CU32 lut = AsConst(P.bctx_lut);
+  for (uint32_t pass = 0; pass < P.num_passes; pass++) {
+    const PassDev& T = P.passes[pass];
+    const uint32_t log_alpha = Uni(T.log_alpha), shift = Uni(T.shift), nclusters = Uni(T.num_clusters);
+    __syncthreads();
+    {
+      // shared tables (selector 0 slice; launches with several histogram sets use WPG = 1 and re-stage below)
+      const uint8_t* src = T.ctx_map;
+      for (uint32_t i = threadIdx.x; i < P.nctx + 16; i += 64 * WPG) l_ctx[i] = src[i];
+      const uint32_t n = nclusters << log_alpha;
+      for (uint32_t i = threadIdx.x; i < n; i += 64 * WPG) l_alias[i] = T.alias[i];
+      for (uint32_t i = threadIdx.x; i < nclusters; i += 64 * WPG) l_cfg[i] = T.cfg[i];
+    }
+    if (have_group && pass == 0) {
+      const uint32_t n16 = (total * uint32_t(sizeof(CoefT))) / 16;
+      for (int c = 0; c < 3; c++) {
+        uint4* dst = reinterpret_cast<uint4*>(gco + size_t(c) * 65536);
+        for (uint32_t i = lane; i < n16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+    for (uint32_t i = lane; i < 3 * 1024; i += 64) l_nz[i] = 0;
+    __threadfence_block();
+    __syncthreads();
+    if (!have_group) continue;
+    const uint32_t sec = pass * P.num_groups + g;
+    // bit reader: the stream word for the NEXT refill is fetched with a vector load (tracked by vmcnt, so LDS waits
+    // in the loop never wait for it) and moved to an SGPR only when it is consumed.
+    const uint32_t sec_size = Uni(P.sec_size[sec]);
+    const uint32_t* stream = P.sections + Uni(P.sec_word[sec]);
+    const uint32_t nwords = (sec_size + 3) / 4;
+    uint32_t idx = 0;  // words moved into buf
+    uint64_t buf = 0;
+    uint32_t bits = 0;
+    uint32_t next_v = stream[0];
+#define JXL_REFILL()                                                       \
+  if (bits < 32) {                                                         \
+    buf |= uint64_t(Uni(next_v)) << bits;                                  \
+    bits += 32;                                                            \
+    idx++;                                                                 \
+    next_v = stream[idx < nwords ? idx : nwords]; /* word nwords = 0 pad */ \
+  }
+#define JXL_READ(n, out)                                                            \
+  {                                                                                 \
+    const uint32_t n_ = (n);                                                        \
+    out = uint32_t(buf) & ((n_ >= 32) ? 0xFFFFFFFFu : ((1u << n_) - 1));            \
+    buf >>= n_;                                                                     \
+    bits -= n_;                                                                     \
+  }
+    JXL_REFILL();
+    uint32_t tmp;
+    if (sec == 0 && P.first_bit_offset) JXL_READ(P.first_bit_offset, tmp);
+    uint32_t hb = 0;
+    while ((1u << hb) < P.num_hist) hb++;
+    JXL_REFILL();
+    uint32_t sel = 0;
+    if (hb) JXL_READ(hb, sel);
+    uint32_t err = 0;
+    if (sel >= P.num_hist) {
+      err = kErrSelector;
+      sel = 0;
+    }
+    if (WPG == 1 && sel != 0) {  // re-stage the selected slice of the context map (single-wave workgroup)
+      const uint8_t* src = T.ctx_map + size_t(sel) * P.nctx;
+      for (uint32_t i = lane; i < P.nctx + 16; i += 64) l_ctx[i] = src[i];
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_wave_barrier();
+    }
+    uint32_t state, hi16;
+    JXL_REFILL();
+    JXL_READ(16, state);
+    JXL_REFILL();
+    JXL_READ(16, hi16);
+    state |= hi16 << 16;
+    const uint32_t log_entry = 12 - log_alpha;
+    // One symbol from cluster `cl_` with uint config `cf_` into `out_` (all scalar).
+#define JXL_SYMBOL(cl_, cf_, out_)                                                                         \
+  {                                                                                                        \
+    const uint32_t res_ = state & 0xFFFu;                                                                  \
+    const uint32_t i_ = res_ >> log_entry, pos_ = res_ & ((1u << log_entry) - 1);                          \
+    const uint2 ev_ = l_alias[((cl_) << log_alpha) + i_];                                                  \
+    const uint32_t e0_ = Uni(ev_.x), e1_ = Uni(ev_.y);                                                     \
+    const bool gt_ = pos_ >= (e0_ & 0xFF);                                                                 \
+    uint32_t tok_ = gt_ ? ((e0_ >> 8) & 0xFF) : i_;                                                        \
+    const uint32_t off_ = (gt_ ? (e1_ & 0xFFFF) : 0u) + pos_;                                              \
+    const uint32_t freq_ = gt_ ? (e1_ >> 16) : (e0_ >> 16);                                                \
+    state = freq_ * (state >> 12) + off_;                                                                  \
+    JXL_REFILL();                                                                                          \
+    if (state < (1u << 16)) {                                                                              \
+      uint32_t lo_;                                                                                        \
+      JXL_READ(16, lo_);                                                                                   \
+      state = (state << 16) | lo_;                                                                         \
+    }                                                                                                      \
+    const uint32_t se_ = (cf_) & 0xFF, msb_ = ((cf_) >> 8) & 0xFF, lsb_ = ((cf_) >> 16) & 0xFF;            \
+    const uint32_t st_ = 1u << se_;                                                                        \
+    if (tok_ >= st_) {                                                                                     \
+      const uint32_t nb_ = (se_ - (msb_ + lsb_) + ((tok_ - st_) >> (msb_ + lsb_))) & 31u;                  \
+      const uint32_t low_ = tok_ & ((1u << lsb_) - 1);                                                     \
+      const uint32_t hi_ = tok_ >> lsb_;                                                                   \
+      JXL_REFILL();                                                                                        \
+      uint32_t xb_;                                                                                        \
+      JXL_READ(nb_, xb_);                                                                                  \
+      tok_ = (((((1u << msb_) | (hi_ & ((1u << msb_) - 1))) << nb_) | xb_) << lsb_) | low_;                \
+    }                                                                                                      \
+    out_ = tok_;                                                                                           \
+  }
+    const CU32 ooff = AsConst(&T.order_offset[0]);
+    for (uint32_t bi = b0; bi < b1 && !err; bi++) {
+      const uint32_t w0 = blk[bi * 3], w1 = blk[bi * 3 + 1], coef_offset = blk[bi * 3 + 2];
+      const uint32_t st = w1 & 0xFF, dcctx = (w1 >> 8) & 0xFF, qf = w1 >> 16;
+      const uint32_t info = c_strategy_info[st];
+      const uint32_t cx = info & 0xFF, cy = (info >> 8) & 0xFF, log2c = (info >> 16) & 0xFF, ord = info >> 24;
+      const uint32_t covered = 1u << log2c, size = covered * 64;
+      uint32_t qfi = 0;
+      for (uint32_t t = 0; t + 1 < P.nq; t++) qfi += qf > P.qf_thr[t];
+      const uint32_t lbx = w0 & 31, lby = (w0 >> 16) & 31;
+#pragma unroll 1
+      for (int ci = 0; ci < 3 && !err; ci++) {
+        const uint32_t c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
+        uint8_t* nzc = l_nz + c * 1024;
+        uint32_t pred;
+        if (lbx == 0) pred = lby ? Uni(nzc[(lby - 1) * 32]) : 32;
+        else if (lby == 0) pred = Uni(nzc[lbx - 1]);
+        else pred = (Uni(nzc[(lby - 1) * 32 + lbx]) + Uni(nzc[lby * 32 + lbx - 1]) + 1) >> 1;
+        const uint32_t li = ((c * 13 + ord) * P.nq + qfi) * P.ndc + dcctx;
+        const uint32_t bctx = (lut[li >> 2] >> ((li & 3) * 8)) & 0xFF;
+        uint32_t nzb = pred >= 64 ? 64 : pred;
+        nzb = nzb < 8 ? nzb : 4 + nzb / 2;
+        uint32_t cl = Uni(l_ctx[nzb * P.num_bctx + bctx]);
+        uint32_t cf = Uni(l_cfg[cl]);
+        uint32_t nzeros;
+        JXL_SYMBOL(cl, cf, nzeros);
+        if (nzeros > size - covered) {
+          err = kErrNzeros;
+          break;
+        }
+        {
+          const uint8_t nzv = uint8_t((nzeros + covered - 1) >> log2c);
+          for (uint32_t i = lane; i < cx * cy; i += 64) nzc[(lby + i / cx) * 32 + lbx + i % cx] = nzv;
+        }
+        if (nzeros == 0) continue;
+        const uint32_t hoff = P.num_bctx * 37 + 458 * bctx;
+        const uint16_t* order = T.orders + ooff[ord * 3 + c];
+        CoefT* dst = gco + size_t(c) * 65536 + coef_offset;
+        uint32_t prev = nzeros > size / 16 ? 0 : 1;
+        uint32_t k = covered;
+        uint32_t nnz_cur = NnzCtx(((nzeros + covered - 1) >> log2c) & 63);
+        uint32_t nnz_nxt = NnzCtx(((nzeros - 1 + covered - 1) >> log2c) & 63);
+        cl = Uni(l_ctx[hoff + (nnz_cur + FreqCtx((k >> log2c) & 63)) * 2 + prev]);
+        cf = Uni(l_cfg[cl]);
+        uint32_t count = 0;
+        for (;;) {
+          // speculative lookups for coefficient k+1: A = this one is zero, B = this one is non-zero
+          const uint32_t kn = k + 1;
+          const uint32_t fq = FreqCtx((kn >> log2c) & 63);
+          const uint8_t rawA = l_ctx[hoff + (nnz_cur + fq) * 2];
+          const uint8_t rawB = l_ctx[hoff + (nnz_nxt + fq) * 2 + 1];
+          const uint32_t cfA_v = l_cfg[rawA], cfB_v = l_cfg[rawB];
+          uint32_t u;
+          JXL_SYMBOL(cl, cf, u);
+          if (u) {
+            const uint32_t mag = u >> 1, neg = (~u) & 1;
+            const uint32_t coeff = (mag ^ (neg - 1)) << shift;
+            if (lane == 0) l_list[count] = make_uint2(k, coeff);
+            count++;
+            nzeros--;
+            if (nzeros == 0) break;
+            if (count == kList) {
+              __builtin_amdgcn_s_waitcnt(0xC07F);
+              __builtin_amdgcn_wave_barrier();
+              for (uint32_t i = lane; i < kList; i += 64) {
+                const uint2 e = l_list[i];
+                const uint32_t pos = order[e.x];
+                if (pass == 0) dst[pos] = CoefT(int32_t(e.y));
+                else dst[pos] = CoefT(dst[pos] + int32_t(e.y));
+              }
+              count = 0;
+            }
+            nnz_cur = nnz_nxt;
+            nnz_nxt = NnzCtx(((nzeros - 1 + covered - 1) >> log2c) & 63);
+            cl = Uni(rawB);
+            cf = Uni(cfB_v);
+          } else {
+            cl = Uni(rawA);
+            cf = Uni(cfA_v);
+          }
+          k = kn;
+          if (k >= size) break;
+        }
+        if (nzeros != 0) err = kErrNzeros;
+        // scatter what is left in the list (all lanes)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < count; i += 64) {
+          const uint2 e = l_list[i];
+          const uint32_t pos = order[e.x];
+          if (pass == 0) dst[pos] = CoefT(int32_t(e.y));
+          else dst[pos] = CoefT(dst[pos] + int32_t(e.y));
+        }
+      }
+    }
+#undef JXL_SYMBOL
+#undef JXL_READ
+#undef JXL_REFILL
+    if (!err && state != (0x13u << 16)) err |= kErrFinalState;
+    {
+      const uint64_t consumed = uint64_t(idx) * 32 - uint64_t(bits);
+      if (consumed > uint64_t(sec_size) * 8) err |= kErrOverread;
+    }
+    if (err && lane == 0) atomicOr(&P.errors[g], err);
+  }
+#undef P
+}
+
 // ---------------------------------------------------------------------------------------------- transforms
 struct TransformParams {
   const void* coeffs;

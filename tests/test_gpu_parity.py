@@ -117,6 +117,75 @@ def test_context_reuse_and_idempotence(built):
     c.close()
 
 
+@pytest.mark.parametrize("lanes,wait_shift", [(1, 3), (4, 0), (16, 3), (64, 3), (64, 0), (64, 6)])
+def test_lane_packing_of_sections(built, lanes, wait_shift, monkeypatch):
+    """The lane-parallel entropy kernel must give the same coefficients however many sections share a wave and
+    however block transitions are batched (JXLHIP_LANES / JXLHIP_WAIT_SHIFT only steer the work distribution)."""
+    import jxlo
+    J = built
+    monkeypatch.setenv("JXLHIP_LANES", str(lanes))
+    monkeypatch.setenv("JXLHIP_WAIT_SHIFT", str(wait_shift))
+    for data in (J.encode_random(1100, 900, seed=lanes + 40), J.encode_rgb8(J.synth_image(2100, 1300, seed=lanes), distance=1.5)):
+        f = J.Frame(data, threads=2)
+        o = jxlo.Decoded(data)
+        c = J.HipContext()
+        try:
+            c.upload(f)
+            c.run_entropy()
+            c.sync()
+            r, flags = c.errors()
+            assert r == 0 and not any(flags)
+            co = c.download("coeffs").astype(np.int32)
+            ref = o.planes("coeffs")
+            used = _used_mask(o)
+            for g in range(o.info["num_groups"]):
+                assert np.array_equal(co[g, :, :used[g]], ref[g, :, :used[g]]), "coefficients differ in group %d" % g
+        finally:
+            c.close()
+            f.close()
+            o.close()
+
+
+def test_batched_entropy_launch(built):
+    """jxlhip_run_entropy_batch: frames of different geometry in one launch decode exactly as one by one, the batch
+    description follows a re-upload, and the per-frame stages after it see the batch's coefficients."""
+    import jxlo
+    J = built
+    streams = [J.encode_rgb8(J.synth_image(600, 400)), J.encode_rgb8(J.synth_image(1300, 520, seed=5), distance=2.0),
+               J.encode_random(512, 300, seed=9), J.encode_rgb8(J.synth_image(64, 64, seed=3))]
+    ctxs = [J.HipContext() for _ in streams]
+    frames = [J.Frame(s) for s in streams]
+    try:
+        for rounds in range(2):
+            for c, f in zip(ctxs, frames):
+                c.upload(f)
+            J.run_entropy_batch(ctxs)
+            for c in ctxs:
+                c.run_transform()
+                c.run_filter_color()
+            for c, s in zip(ctxs, streams):
+                c.sync()
+                r, flags = c.errors()
+                assert r == 0 and not any(flags)
+                o = jxlo.Decoded(s)
+                co = c.download("coeffs").astype(np.int32)
+                ref = o.planes("coeffs")
+                used = _used_mask(o)
+                for g in range(o.info["num_groups"]):
+                    assert np.array_equal(co[g, :, :used[g]], ref[g, :, :used[g]])
+                d = np.abs(c.rgb8().astype(int) - o.rgb8.astype(int))
+                assert d.max() <= 1
+                o.close()
+            # second round: every context takes another frame -> the cached batch description must be rebuilt
+            frames = frames[1:] + frames[:1]
+            streams = streams[1:] + streams[:1]
+    finally:
+        for c in ctxs:
+            c.close()
+        for f in frames:
+            f.close()
+
+
 def test_corrupt_sections_are_flagged_not_fatal(built):
     J = built
     data = bytearray(J.encode_rgb8(J.synth_image(520, 300)))
