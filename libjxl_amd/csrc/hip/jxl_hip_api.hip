@@ -81,9 +81,16 @@ struct JxlHipContext {
   Buf plane[3], rgb, tlist, scratch;
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
-  uint32_t batch_passes = 1, batch_wait_shift = 3;
+  uint32_t batch_wait_shift = 2;
   int batch_kernel = -1;
   std::vector<uint32_t> sec_size_host, pass_clusters, pass_log_alpha;
+  // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
+  bool scan_order = false;
+  Buf kend, block_recs;
+  std::vector<JxlHipVarBlock> blocks_host;  // for jxlhip_download("coeffs") of a scan-order frame
+  std::vector<uint32_t> gbb_host;
+  std::vector<uint16_t> orders_host;
+  uint32_t order_offset_host[39] = {};
   std::vector<const JxlHipContext*> batch_ctxs;
   std::vector<uint64_t> batch_gens;
   uint32_t batch_wgs = 0;
@@ -99,6 +106,25 @@ struct JxlHipContext {
   bool alias_lds = false;
   int final_plane = 0;  // which plane set holds the filtered XYB after jxlhip_run_filter_color
 };
+
+// Which entropy kernel: 2 (default) lane-parallel k_entropy_lanes, 1 wave-per-section scalar k_entropy_uni,
+// 0 the first k_entropy_ans. Environment override JXLHIP_ENTROPY is for A/B measurements only.
+static int EntropyKernelChoice() {
+  static const int v = [] {
+    const char* e = getenv("JXLHIP_ENTROPY");
+    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
+  }();
+  return v;
+}
+static int EnvInt(const char* name, int def) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : def;
+}
+
+static size_t LanesLdsFor(const JxlHipContext* c) {
+  return jxlhip::LanesLdsLayout(c->ep.num_hist, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc,
+                                kLanesWPG).total;
+}
 
 extern "C" {
 
@@ -166,7 +192,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->kend, &c->block_recs};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -237,7 +263,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     sec_size[i] = d->section_size[i];
     total += (size_t(d->section_size[i]) + 15 + 4) & ~size_t(15);
   }
-  std::vector<uint8_t> packed(total + 16, 0);
+  std::vector<uint8_t> packed(total + 256, 0);  // the lane kernel prefetches up to 64 bytes past a section
   for (size_t i = 0; i < nsec; i++) memcpy(packed.data() + size_t(sec_word[i]) * 4, d->codestream + d->section_offset[i], d->section_size[i]);
   int r;
   if ((r = Upload(c, c->sections, packed.data(), packed.size()))) return r;
@@ -281,6 +307,10 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     pd[p].cfg = pb.cfg.as<uint32_t>();
     pd[p].orders = pb.orders.as<uint16_t>();
     memcpy(pd[p].order_offset, s.order_offset, sizeof(s.order_offset));
+    for (uint32_t i = 0; i < s.num_clusters; i++) {  // hybrid-uint configs: split_exponent, msb_in_token, lsb_in_token
+      const uint32_t se = s.uint_cfg[i] & 0xFF, msb = (s.uint_cfg[i] >> 8) & 0xFF, lsb = (s.uint_cfg[i] >> 16) & 0xFF;
+      if (se > s.log_alpha || msb > se || lsb > se - msb) return JXLHIP_ERR_INVALID_ARGUMENT;
+    }
     pd[p].log_alpha = s.log_alpha;
     c->pass_clusters[p] = s.num_clusters;
     c->pass_log_alpha[p] = s.log_alpha;
@@ -349,6 +379,28 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   ep.lds_alias_bytes = c->alias_lds ? uint32_t((alias_bytes_max + 15) & ~size_t(15)) : 0;
   c->lds_entropy = ep.lds_ctx_bytes + ep.lds_alias_bytes + 3072;
   if (size_t(d->block_ctx_lut_size) < size_t(3) * 13 * ep.nq * ep.ndc) return JXLHIP_ERR_INVALID_ARGUMENT;
+  // single-pass frames whose tables fit LDS are decoded by the lane-parallel kernel into scan order
+  c->scan_order = d->num_passes == 1 && EntropyKernelChoice() == 2 && LanesLdsFor(c) <= kLdsBudget;
+  if ((r = c->kend.Ensure(size_t(d->num_blocks ? d->num_blocks : 1) * 3 * 4))) return r;
+  ep.kend = c->kend.as<uint32_t>();
+  {
+    std::vector<uint32_t> recs(size_t(d->num_blocks) + 16, 0);
+    for (uint32_t i = 0; i < d->num_blocks; i++) {
+      const JxlHipVarBlock& v = d->blocks[i];
+      uint32_t qfi = 0;
+      for (uint32_t t = 0; t < d->num_qf_thresholds; t++) qfi += v.qf > d->qf_thresholds[t];
+      recs[i] = (v.bx & 31u) | (v.by & 31u) << 5 | uint32_t(v.strategy) << 10 | qfi << 15 | uint32_t(v.quant_dc_ctx) << 19;
+    }
+    if ((r = Upload(c, c->block_recs, recs.data(), recs.size() * 4))) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `recs` is a local
+    ep.block_recs = c->block_recs.as<uint32_t>();
+  }
+  if (c->scan_order) {
+    c->blocks_host.assign(d->blocks, d->blocks + d->num_blocks);
+    c->gbb_host.assign(d->group_block_begin, d->group_block_begin + d->num_groups + 1);
+    c->orders_host.assign(d->passes[0].orders, d->passes[0].orders + d->passes[0].orders_size);
+    memcpy(c->order_offset_host, d->passes[0].order_offset, sizeof(c->order_offset_host));
+  }
   if ((r = c->ep_dev.Ensure(sizeof(ep)))) return r;
   HIP_TRY(hipMemcpy(c->ep_dev.p, &ep, sizeof(ep), hipMemcpyHostToDevice));
   c->generation++;
@@ -383,6 +435,10 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   tp.xb = c->xb; tp.yb = c->yb; tp.xg = c->xg; tp.xp = c->xp; tp.yp = c->yp;
   tp.out = c->plane[0].as<float>();
   tp.scratch = c->scratch.as<float>();
+  tp.scan_order = c->scan_order ? 1 : 0;
+  tp.kend = c->kend.as<uint32_t>();
+  tp.orders = c->pass_bufs[0].orders.as<uint16_t>();
+  memcpy(tp.order_offset, d->passes[0].order_offset, sizeof(tp.order_offset));
 
   jxlhip::FilterParams& fp = c->fp;
   memset(&fp, 0, sizeof(fp));
@@ -410,20 +466,6 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
 }
 
 }  // extern "C"
-
-// Which entropy kernel: 2 (default) lane-parallel k_entropy_lanes, 1 wave-per-section scalar k_entropy_uni,
-// 0 the first k_entropy_ans. Environment override JXLHIP_ENTROPY is for A/B measurements only.
-static int EntropyKernelChoice() {
-  static const int v = [] {
-    const char* e = getenv("JXLHIP_ENTROPY");
-    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 2;
-  }();
-  return v;
-}
-static int EnvInt(const char* name, int def) {
-  const char* e = getenv(name);
-  return e && *e ? atoi(e) : def;
-}
 
 template <typename CoefT>
 static int LaunchEntropy(JxlHipContext* c) {
@@ -480,7 +522,7 @@ static void LaunchDct(JxlHipContext* c, int s) {
   constexpr int BPW = 256 / TPB;
   const uint32_t n = c->list_count[s];
   const dim3 grid((n + BPW - 1) / BPW), block(256);
-  const size_t lds = size_t(BPW) * 2 * SIZE * sizeof(float);
+  const size_t lds = size_t(BPW) * 3 * SIZE * sizeof(float);
   hipLaunchKernelGGL((jxlhip::k_dct<CoefT, CX, CY>), grid, block, lds, c->stream, c->tp, c->tlist.as<uint32_t>() + c->list_begin[s], n,
                      uint32_t(s));
 }
@@ -519,29 +561,42 @@ static int LaunchTransforms(JxlHipContext* c) {
   return 0;
 }
 
-static size_t LanesLdsFor(const JxlHipContext* c) {
-  size_t m = 0;
-  for (uint32_t p = 0; p < c->np; p++) {
-    const jxlhip::LanesLds l = jxlhip::LanesLdsLayout(c->ep.num_hist, c->ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p],
-                                                      39 * c->ep.nq * c->ep.ndc, kLanesWPG);
-    m = l.total > m ? l.total : m;
-  }
-  return m;
-}
-
 template <typename CoefT>
-static int LaunchEntropyLanes(JxlHipContext* c0, uint32_t pass) {
+static int LaunchEntropyLanes(JxlHipContext* c0) {
   auto k = jxlhip::k_entropy_lanes<CoefT, kLanesWPG>;
   if (c0->batch_lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
   jxlhip::EntropyLaneBatch b;
   b.params = c0->batch_params.as<jxlhip::EntropyParams>();
   b.wg_frame = c0->batch_map.as<uint32_t>();
-  b.lane_group = c0->batch_lanes.as<uint32_t>() + size_t(pass) * c0->batch_wgs * kLanesWPG * 64;
-  b.pass = pass;
+  b.lane_group = c0->batch_lanes.as<uint32_t>();
   b.wait_shift = c0->batch_wait_shift;
+  b.prof = nullptr;
+  const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
+  const size_t nwaves = size_t(c0->batch_wgs) * kLanesWPG;
+  if (prof) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.prof), nwaves * 32));
+    HIP_TRY(hipMemsetAsync(b.prof, 0, nwaves * 32, c0->stream));
+  }
   hipLaunchKernelGGL(k, dim3(c0->batch_wgs), dim3(64 * kLanesWPG), c0->batch_lds, c0->stream, b);
   HIP_TRY(hipGetLastError());
+  if (prof) {
+    std::vector<unsigned long long> h(nwaves * 4);
+    HIP_TRY(hipStreamSynchronize(c0->stream));
+    HIP_TRY(hipMemcpy(h.data(), b.prof, nwaves * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(b.prof);
+    unsigned long long mx[4] = {0, 0, 0, 0};
+    double sum[4] = {0, 0, 0, 0};
+    size_t used = 0;
+    for (size_t w = 0; w < nwaves; w++) {
+      if (!h[w * 4 + 3] && !h[w * 4 + 2]) continue;
+      used++;
+      if (h[w * 4] > mx[0]) for (int j = 0; j < 4; j++) mx[j] = h[w * 4 + j];
+      for (int j = 0; j < 4; j++) sum[j] += double(h[w * 4 + j]);
+    }
+    fprintf(stderr, "[lanes prof] waves %zu  longest: cycles %llu service %llu (%llu calls) trips %llu | mean: cycles %.0f service %.0f calls %.0f trips %.0f\n",
+            used, mx[0], mx[1], mx[2], mx[3], sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used);
+  }
   return 0;
 }
 
@@ -558,7 +613,7 @@ static int LaunchEntropyUniBatch(JxlHipContext* c0) {
 
 // Builds (or re-uses) the description of a batch: parameter blocks, workgroup -> frame map and, for the lane-parallel
 // kernel, the lane -> section assignment (sections sorted by compressed size inside each frame so that the lanes of a
-// wave finish together; `lanes` populated lanes per wave so that small batches still spread over all SIMDs).
+// wave finish together; `lanes_per_wave` populated lanes per wave so that small batches still spread over all SIMDs).
 static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n, int kernel) {
   bool same = c0->batch_ctxs.size() == n && c0->batch_kernel == kernel;
   for (size_t i = 0; same && i < n; i++) same = c0->batch_ctxs[i] == ctxs[i] && c0->batch_gens[i] == ctxs[i]->generation;
@@ -566,45 +621,33 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   std::vector<jxlhip::EntropyParams> params(n);
   std::vector<uint32_t> map, lanes;
   size_t lds = 0;
-  uint32_t max_passes = 1;
-  for (size_t i = 0; i < n; i++) {
-    params[i] = ctxs[i]->ep;
-    max_passes = ctxs[i]->np > max_passes ? ctxs[i]->np : max_passes;
-  }
+  for (size_t i = 0; i < n; i++) params[i] = ctxs[i]->ep;
   if (kernel == 2) {
     size_t total_sections = 0;
     for (size_t i = 0; i < n; i++) total_sections += ctxs[i]->ng;
-    // populated lanes per wave: aim at ~2 waves per SIMD (256 CUs x 4 SIMDs) before packing lanes more densely
+    // populated lanes per wave: fill every SIMD (256 CUs x 4) with a wave before packing lanes more densely
     uint32_t lanes_per_wave = 1;
-    const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 2048));
+    const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 1024));
     while (lanes_per_wave < 64 && (total_sections + lanes_per_wave - 1) / lanes_per_wave > target_waves) lanes_per_wave *= 2;
     const int forced = EnvInt("JXLHIP_LANES", 0);
     if (forced >= 1 && forced <= 64) lanes_per_wave = uint32_t(forced);
-    c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 3));
+    c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 2));
     const uint32_t per_wg = lanes_per_wave * kLanesWPG;
-    std::vector<uint32_t> frame_wg0(n);
-    for (size_t i = 0; i < n; i++) {
-      frame_wg0[i] = uint32_t(map.size());
-      const uint32_t wgs = (ctxs[i]->ng + per_wg - 1) / per_wg;
-      for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i));
-      const size_t l = LanesLdsFor(ctxs[i]);
-      lds = l > lds ? l : lds;
-    }
-    const size_t per_pass = map.size() * kLanesWPG * 64;
-    lanes.assign(per_pass * max_passes, 0xFFFFFFFFu);
     std::vector<uint32_t> order;
     for (size_t i = 0; i < n; i++) {
       const JxlHipContext* c = ctxs[i];
-      for (uint32_t p = 0; p < c->np; p++) {
-        order.resize(c->ng);
-        for (uint32_t g = 0; g < c->ng; g++) order[g] = g;
-        const uint32_t* sz = c->sec_size_host.data() + size_t(p) * c->ng;
-        std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
-        for (uint32_t j = 0; j < c->ng; j++) {
-          const uint32_t wave = j / lanes_per_wave, lane = j % lanes_per_wave;
-          lanes[per_pass * p + (size_t(frame_wg0[i]) * kLanesWPG + wave) * 64 + lane] = order[j];
-        }
-      }
+      const size_t wg0 = map.size();
+      const uint32_t wgs = (c->ng + per_wg - 1) / per_wg;
+      for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i));
+      lanes.resize(map.size() * kLanesWPG * 64, 0xFFFFFFFFu);
+      const size_t l = LanesLdsFor(c);
+      lds = l > lds ? l : lds;
+      order.resize(c->ng);
+      for (uint32_t g = 0; g < c->ng; g++) order[g] = g;
+      const uint32_t* sz = c->sec_size_host.data();
+      std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
+      for (uint32_t j = 0; j < c->ng; j++)
+        lanes[(wg0 * kLanesWPG + j / lanes_per_wave) * 64 + j % lanes_per_wave] = order[j];
     }
   } else {
     for (size_t i = 0; i < n; i++) {
@@ -628,7 +671,6 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   for (size_t i = 0; i < n; i++) c0->batch_gens[i] = ctxs[i]->generation;
   c0->batch_wgs = uint32_t(map.size());
   c0->batch_lds = lds;
-  c0->batch_passes = max_passes;
   c0->batch_kernel = kernel;
   return 0;
 }
@@ -636,26 +678,27 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
 extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   if (!ctxs || !n || n > 0xFFFF) return JXLHIP_ERR_INVALID_ARGUMENT;
   JxlHipContext* c0 = ctxs[0];
-  int kernel = EntropyKernelChoice();
+  // One launch needs one kernel: every frame in scan-order layout (lane kernel), or every frame in natural layout with
+  // tables that the scalar-form kernel can share in LDS; anything else is decoded frame by frame.
+  bool all_scan = true, all_uni = true;
   for (size_t i = 0; i < n; i++) {
     const JxlHipContext* c = ctxs[i];
     if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
     if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
     if (c->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
-    if (kernel == 2 && (c->coef_bits != c0->coef_bits || LanesLdsFor(c) > kLdsBudget)) kernel = 1;
+    if (!c->scan_order || c->coef_bits != c0->coef_bits) all_scan = false;
+    if (c->scan_order || !c->alias_lds || c->ep.num_hist != 1 || c->np != 1 || c->coef_bits != c0->coef_bits ||
+        c->ng > 0xFFFF * kEntropyWPG || EntropyKernelChoice() == 0)
+      all_uni = false;
   }
-  if (kernel == 1)
+  if (!all_scan && !all_uni) {
     for (size_t i = 0; i < n; i++) {
-      const JxlHipContext* c = ctxs[i];
-      if (!c->alias_lds || c->ep.num_hist != 1 || c->coef_bits != c0->coef_bits || c->ng > 0xFFFF * kEntropyWPG) kernel = 0;
-    }
-  if (kernel == 0) {
-    for (size_t i = 0; i < n; i++) {
-      int r = RunEntropySingle(ctxs[i]);
+      int r = ctxs[i]->scan_order ? jxlhip_run_entropy_batch(&ctxs[i], 1) : RunEntropySingle(ctxs[i]);
       if (r) return r;
     }
     return 0;
   }
+  const int kernel = all_scan ? 2 : 1;
   HIP_TRY(hipSetDevice(c0->device));
   if (!c0->batch_done) HIP_TRY(hipEventCreateWithFlags(&c0->batch_done, hipEventDisableTiming));
   int r = PrepareBatch(c0, ctxs, n, kernel);
@@ -665,18 +708,9 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
     if (ctxs[i]->ev_valid[2]) HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev[5], 0));
   HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
   for (size_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(ctxs[i]->errors.p, 0, size_t(ctxs[i]->ng) * 4, c0->stream));
-  if (kernel == 2) {
-    // the lane kernel only writes non-zero coefficients
-    for (size_t i = 0; i < n; i++)
-      HIP_TRY(hipMemsetAsync(ctxs[i]->coeffs.p, 0, size_t(ctxs[i]->ng) * 3 * 65536 * (ctxs[i]->coef_bits / 8), c0->stream));
-    for (uint32_t p = 0; p < c0->batch_passes; p++) {
-      r = c0->coef_bits == 16 ? LaunchEntropyLanes<int16_t>(c0, p) : LaunchEntropyLanes<int32_t>(c0, p);
-      if (r) return r;
-    }
-  } else {
-    r = c0->coef_bits == 16 ? LaunchEntropyUniBatch<int16_t>(c0) : LaunchEntropyUniBatch<int32_t>(c0);
-    if (r) return r;
-  }
+  if (kernel == 2) r = c0->coef_bits == 16 ? LaunchEntropyLanes<int16_t>(c0) : LaunchEntropyLanes<int32_t>(c0);
+  else r = c0->coef_bits == 16 ? LaunchEntropyUniBatch<int16_t>(c0) : LaunchEntropyUniBatch<int32_t>(c0);
+  if (r) return r;
   HIP_TRY(hipEventRecord(c0->ev[1], c0->stream));
   c0->ev_valid[0] = true;
   if (n > 1) {
@@ -691,7 +725,8 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
 
 extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
-  return jxlhip_run_entropy_batch(&c, 1);
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  return c->scan_order ? jxlhip_run_entropy_batch(&c, 1) : RunEntropySingle(c);
 }
 
 extern "C" {
@@ -808,6 +843,29 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n == "coeffs" && c->scan_order) {
+    // the device holds scan-order entries [covered, kend) per (block, channel): present them in the natural layout
+    std::vector<uint32_t> kend(c->blocks_host.size() * 3);
+    HIP_TRY(hipMemcpy(kend.data(), c->kend.p, kend.size() * 4, hipMemcpyDeviceToHost));
+    static const uint8_t log2c[27] = {0, 0, 0, 0, 2, 4, 1, 1, 2, 2, 3, 3, 0, 0, 0, 0, 0, 0, 6, 5, 5, 8, 7, 7, 10, 9, 9};
+    static const uint8_t bucket[27] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+    const size_t esz = c->coef_bits / 8;
+    std::vector<uint8_t> tmp(65536 * esz);
+    for (uint32_t g = 0; g < c->ng; g++)
+      for (uint32_t b = c->gbb_host[g]; b < c->gbb_host[g + 1]; b++) {
+        const JxlHipVarBlock& v = c->blocks_host[b];
+        const uint32_t covered = 1u << log2c[v.strategy], size = covered * 64;
+        for (int ch = 0; ch < 3; ch++) {
+          uint8_t* base = static_cast<uint8_t*>(dst) + ((size_t(g) * 3 + ch) * 65536 + v.coef_offset) * esz;
+          const uint16_t* order = c->orders_host.data() + c->order_offset_host[bucket[v.strategy] * 3 + ch];
+          uint32_t ke = kend[size_t(b) * 3 + ch];
+          ke = ke > size ? size : ke;
+          memcpy(tmp.data(), base, size * esz);
+          memset(base, 0, size * esz);
+          for (uint32_t k = covered; k < ke; k++) memcpy(base + size_t(order[k]) * esz, tmp.data() + size_t(k) * esz, esz);
+        }
+      }
+  }
   return 0;
 }
 

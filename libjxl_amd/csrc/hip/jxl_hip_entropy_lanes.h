@@ -3,20 +3,28 @@
 // Replaces (like k_entropy_uni) lib/jxl/dec_group.cc:469-542,594-639 (DecodeACVarBlock / GetBlockFromBitstream),
 // dec_ans.h:170-257 (rANS symbol + hybrid uint), ans_common.h:102-142 (alias lookup), ac_context.h:63-143.
 //
-// One AC section (256x256 group of one pass) is an inherently serial adaptive-context rANS stream, so the only
-// parallelism is ACROSS sections. Here every LANE of a wave decodes its own section: the decoder state (rANS state,
-// 64-bit bit window, block/coefficient cursors) lives in VGPRs, the frame's entropy tables are shared in LDS by the
-// workgroup, and one trip of the main loop decodes one symbol for every runnable lane. A wave-per-section scalar decoder
-// (k_entropy_uni) is bound by the scalar ALU, which the four SIMDs of a CU share; the vector ALUs give 64 decoders per
-// wave for the same issue slots. The host packs sections of similar compressed size into the same wave (longest first)
-// and chooses how many lanes per wave are populated, so that small batches still spread over all SIMDs.
+// One AC section (256x256 group) is an inherently serial adaptive-context rANS stream, so the only parallelism is
+// ACROSS sections. Here every LANE of a wave decodes its own section: the decoder state (rANS state, bit position,
+// block / coefficient cursors) lives in VGPRs, the frame's entropy tables are shared in LDS by the workgroup, and one
+// trip of the hot loop decodes one coefficient token for every runnable lane. A wave-per-section scalar decoder
+// (k_entropy_uni) is bound by the scalar ALU that the four SIMDs of a CU share; the vector ALUs give up to 64 decoders
+// per wave for the same issue slots. The host packs sections of similar compressed size into the same wave (longest
+// first) and chooses how many lanes per wave are populated, so that small batches still spread over all SIMDs.
+//
+// Memory behaviour, all chosen to keep global-memory latency out of the serial chain:
+//   * each lane's compressed stream is staged through a 16-word ring in LDS ([slot][lane] layout: conflict-free);
+//     the hot loop extracts bits with one ds_read2 + v_alignbit at the lane's bit position, the ring is topped up
+//     with 16-byte global loads in the service phase only;
+//   * coefficients are written in SCAN order (position k of the coefficient order, zeros included) with
+//     fire-and-forget stores, plus the number of valid entries per (block, channel) in `kend`; the transform kernels
+//     apply the order permutation when they stage a block into LDS. No zero fill of the coefficient buffer, no
+//     order-table lookup and no dependent load in the decode loop.
 //
 // Control flow is a per-lane state machine kept convergent on the hot part:
-//   mode 2 (COEF)  the pending symbol is a coefficient token        \  one shared symbol-decode sequence per trip
-//   mode 1 (NZ)    the pending symbol is a block's non-zero count    /
-//   mode 0 (NEXT)  the lane finished a (block, channel) and waits for the block-transition code, which runs for all
-//                  waiting lanes at once when enough of them wait (so its cost is amortised over many lanes)
-//   mode 3 (DONE)  section finished, lane idle, or a stream error was flagged
+//   RUN   a coefficient token is pending                       -> the hot trip (one shared code sequence)
+//   WAIT  the lane finished a (block, channel), or its ring runs low -> serviced (block transition incl. the block's
+//         non-zero-count symbol, ring refill) together with the other waiting lanes once enough of them wait
+//   DONE  section finished, lane idle, or a stream error was flagged
 #ifndef JXL_HIP_ENTROPY_LANES_H_
 #define JXL_HIP_ENTROPY_LANES_H_
 
@@ -28,24 +36,62 @@ struct EntropyLaneBatch {
   const EntropyParams* params;  // one per frame of the batch (device memory)
   const uint32_t* wg_frame;     // per workgroup: index into params
   const uint32_t* lane_group;   // per lane of every wave: group (AC section) index in its frame, 0xFFFFFFFF = idle lane
-  uint32_t pass;                // which pass's sections this launch decodes
-  uint32_t wait_shift;          // block transitions run once (waiting lanes << wait_shift) >= runnable lanes
+  uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
+  unsigned long long* prof;     // optional (may be NULL): per wave {cycles total, cycles in service, services, hot trips}
 };
 
-// LDS layout of one workgroup (sizes in bytes, every region 16-byte aligned); must match LanesLdsBytes() on the host.
+// LDS layout of one workgroup (byte offsets, every region 16-byte aligned); the host sizes the launch with it.
 struct LanesLds {
-  uint32_t ctx, alias, lut, ctx2, nz, total;
+  uint32_t alias, ctx, lut, ctx2, sinfo, wave0, per_wave, total;
 };
+constexpr uint32_t kLanesNzBytes = 96 * 64;         // nzeros line buffer [channel * 32 + column][lane], u8
+constexpr uint32_t kLanesRingWords = 16;            // per lane; + 1 mirror row
+constexpr uint32_t kLanesRingBytes = (kLanesRingWords + 1) * 64 * 4;
+constexpr uint32_t kLanesBlockRing = 8;             // packed block records per lane
+constexpr uint32_t kLanesBlockRingBytes = kLanesBlockRing * 64 * 4;
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
                                                    uint32_t lut_bytes, uint32_t waves) {
   LanesLds l;
-  l.ctx = 0;
-  l.alias = ((num_hist * nctx + 16) * 4 + 15) & ~15u;
-  l.lut = l.alias + (num_clusters << log_alpha) * 8;
+  l.alias = 0;
+  l.ctx = (num_clusters << log_alpha) * 8;
+  l.lut = l.ctx + (((num_hist * nctx + 16) * 4 + 15) & ~15u);
   l.ctx2 = l.lut + ((lut_bytes + 15) & ~15u);
-  l.nz = l.ctx2 + 64 * 64 * 2;
-  l.total = l.nz + waves * 96 * 64;
+  l.sinfo = l.ctx2 + (64 * 64 + 64) * 2;
+  l.wave0 = l.sinfo + 32 * 4;
+  l.per_wave = kLanesNzBytes + kLanesRingBytes + kLanesBlockRingBytes;
+  l.total = l.wave0 + waves * l.per_wave;
   return l;
+}
+
+// One rANS symbol + hybrid-uint extra bits for the calling lane. ctxe = split_exp | msb << 4 | lsb << 8 |
+// (byte offset of the cluster's alias table in LDS) << 12. `ring` points at the lane's column of the stream ring.
+__device__ __forceinline__ uint32_t LaneSymbol(uint32_t ctxe, uint32_t& state, uint32_t& bitpos, const uint32_t* ring,
+                                               const uint8_t* lds, uint32_t log_entry) {
+  const uint32_t s0 = (bitpos >> 5) & (kLanesRingWords - 1);
+  const uint32_t w0 = ring[s0 * 64], w1 = ring[s0 * 64 + 64];
+  const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & ((1u << log_entry) - 1);
+  const uint2 e = *reinterpret_cast<const uint2*>(lds + (ctxe >> 12) + slot * 8);
+  const bool gt = pos >= (e.x >> 24);
+  const uint32_t x = gt ? e.y : e.x;
+  uint32_t tok = gt ? (x >> 24) : slot;
+  const uint32_t hi = state >> 12;
+  state = (x & 0xFFFu) * hi + hi + ((x >> 12) & 0xFFFu) + pos;
+  const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31);
+  const bool need = state < (1u << 16);
+  state = need ? ((state << 16) | (win & 0xFFFFu)) : state;
+  bitpos += need ? 16u : 0u;
+  const uint32_t se = ctxe & 15;
+  if (tok >= (1u << se)) {
+    const uint32_t msb = (ctxe >> 4) & 15, lsb = (ctxe >> 8) & 15;
+    const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
+    const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
+    const uint32_t s1 = (bitpos >> 5) & (kLanesRingWords - 1);
+    const uint32_t v0 = ring[s1 * 64], v1 = ring[s1 * 64 + 64];
+    const uint32_t xb = __builtin_amdgcn_alignbit(v1, v0, bitpos & 31) & ((1u << nb) - 1);
+    bitpos += nb;
+    tok = (((((1u << msb) | (top & ((1u << msb) - 1))) << nb) | xb) << lsb) | low;
+  }
+  return tok;
 }
 
 template <typename CoefT, int WPG>
@@ -53,17 +99,19 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   extern __shared__ __align__(16) uint8_t lds_raw[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const EntropyParams& P = B.params[B.wg_frame[blockIdx.x]];
-  const uint32_t pass = B.pass;
-  const PassDev& T = P.passes[pass];
-  const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, shift = T.shift, nclusters = T.num_clusters;
+  const PassDev& T = P.passes[0];
+  const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, nclusters = T.num_clusters;
   const uint32_t nq = P.nq, ndc = P.ndc, num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
   const uint32_t lut_bytes = 39 * nq * ndc;
   const LanesLds L = LanesLdsLayout(num_hist, nctx, nclusters, log_alpha, lut_bytes, WPG);
-  uint32_t* l_ctx = reinterpret_cast<uint32_t*>(lds_raw + L.ctx);     // per context: uint config | cluster << 24
-  uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);        // repacked alias entries, see below
-  uint8_t* l_lut = lds_raw + L.lut;                                    // block context LUT
-  uint16_t* l_ctx2 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);    // [nzeros_left_bucket_input][k bucket input]
-  uint8_t* l_nz = lds_raw + L.nz + wave * (96 * 64);                   // nzeros line buffer [channel * 32 + column][lane]
+  uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
+  uint32_t* l_ctx = reinterpret_cast<uint32_t*>(lds_raw + L.ctx);
+  uint8_t* l_lut = lds_raw + L.lut;
+  uint16_t* l_ctx2 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)][k / covered] -> 2 * (nnz ctx + freq ctx)
+  uint8_t* l_nz = lds_raw + L.wave0 + wave * L.per_wave;             // line buffer of the per-block nzeros prediction
+  uint32_t* ring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzBytes) + lane;
+  uint32_t* bring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzBytes + kLanesRingBytes) + lane;  // block records [slot][lane]
+  const uint32_t* l_sinfo = reinterpret_cast<const uint32_t*>(lds_raw + L.sinfo);
 
   // ---- stage the frame's tables (whole workgroup)
   {
@@ -71,11 +119,12 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
     for (uint32_t i = tid; i < n_ctx; i += 64 * WPG) {
       uint32_t cl = T.ctx_map[i];
       cl = cl < nclusters ? cl : nclusters - 1;
-      l_ctx[i] = (T.cfg[cl] & 0xFFFFFFu) | (cl << 24);
+      const uint32_t cfg = T.cfg[cl];
+      l_ctx[i] = (cfg & 15) | (((cfg >> 8) & 15) << 4) | (((cfg >> 16) & 15) << 8) | ((cl << (log_alpha + 3)) << 12);
     }
     // alias entry {cutoff u8, right u8, freq0 u16 | offsets1 u16, freq1 u16} ->
-    //   x = (freq0 - 1) & 0xFFF | cutoff << 24            (taken when pos <  cutoff: symbol = slot, offset = pos)
-    //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24   (taken when pos >= cutoff)
+    //   x = (freq0 - 1) & 0xFFF | cutoff << 24                    taken when pos <  cutoff: symbol = slot, offset = pos
+    //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24    taken when pos >= cutoff
     const uint32_t n_alias = nclusters << log_alpha;
     for (uint32_t i = tid; i < n_alias; i += 64 * WPG) {
       const uint2 e = T.alias[i];
@@ -83,200 +132,198 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       l_alias[i] = make_uint2(((freq0 - 1) & 0xFFFu) | (cutoff << 24), ((freq1 - 1) & 0xFFFu) | ((offs1 & 0xFFFu) << 12) | (right << 24));
     }
     for (uint32_t i = tid; i < lut_bytes; i += 64 * WPG) l_lut[i] = P.bctx_lut[i];
-    for (uint32_t i = tid; i < 64 * 64; i += 64 * WPG)
-      l_ctx2[i] = uint16_t((uint32_t(c_coeff_nnz_ctx[i >> 6]) + c_coeff_freq_ctx[i & 63]) * 2);
+    for (uint32_t i = tid; i < 64 * 64 + 64; i += 64 * WPG)
+      l_ctx2[i] = uint16_t((uint32_t(c_coeff_nnz_ctx[(i >> 6) & 63]) + c_coeff_freq_ctx[i & 63]) * 2);
+    if (tid < 27) reinterpret_cast<uint32_t*>(lds_raw + L.sinfo)[tid] = c_strategy_info[tid];
     uint32_t* z = reinterpret_cast<uint32_t*>(l_nz);
-    for (uint32_t i = lane; i < 96 * 64 / 4; i += 64) z[i] = 0;
+    for (uint32_t i = lane; i < kLanesNzBytes / 4; i += 64) z[i] = 0;
   }
   __syncthreads();
 
   // ---- per-lane section setup
+  enum : uint32_t { kWait = 0, kRun = 1, kDone = 3 };
   const uint32_t g = B.lane_group[(blockIdx.x * WPG + wave) * 64 + lane];
-  uint32_t mode = g == 0xFFFFFFFFu ? 3u : 0u;
+  uint32_t mode = g == 0xFFFFFFFFu ? uint32_t(kDone) : uint32_t(kWait);
   uint32_t err = 0;
   uint32_t b1 = 0, bi = 0, ci = 2;
-  const uint32_t* stream = P.sections;
-  uint32_t nwords = 0, sec_size = 0, idx = 0, nxt = 0, bits = 0, state = 0, ctx_base = 0;
-  uint64_t buf = 0;
-#define LJ_REFILL()                                   \
-  if (bits <= 32) {                                   \
-    buf |= uint64_t(nxt) << bits;                     \
-    bits += 32;                                       \
-    idx++;                                            \
-    nxt = stream[idx < nwords ? idx : nwords];        \
-  }
-#define LJ_READ(n_, out_)                             \
-  {                                                   \
-    const uint32_t nn_ = (n_);                        \
-    out_ = uint32_t(buf) & ((1u << nn_) - 1);         \
-    buf >>= nn_;                                      \
-    bits -= nn_;                                      \
-  }
-  if (mode == 0) {
+  const uint4* stream4 = reinterpret_cast<const uint4*>(P.sections);
+  const uint4* const rec4 = reinterpret_cast<const uint4*>(P.block_recs);
+  uint32_t* const kend_out = P.kend;
+  uint32_t nwords = 0, sec_size = 0, ring_end = 0, bring_end = 0, bitpos = 0, state = 0, ctx_base = 0;
+  bool started = false, pend_s = false, pend_b = false;
+  uint4 pf_s = make_uint4(0, 0, 0, 0), pf_b = make_uint4(0, 0, 0, 0);
+  if (mode == kWait) {
     bi = P.gbb[g] - 1;  // the first transition advances to the group's first block
     b1 = P.gbb[g + 1];
-    const uint32_t sec = pass * P.num_groups + g;
-    stream = P.sections + P.sec_word[sec];
-    sec_size = P.sec_size[sec];
-    nwords = (sec_size + 3) / 4;  // word `nwords` is zero padding (jxlhip_frame_upload)
-    buf = uint64_t(stream[0]) | (uint64_t(stream[nwords < 1 ? nwords : 1]) << 32);
-    bits = 64;
-    idx = 2;
-    nxt = stream[nwords < 2 ? nwords : 2];
-    uint32_t tmp;
-    if (sec == 0 && P.first_bit_offset) LJ_READ(P.first_bit_offset, tmp);
-    uint32_t hb = 0;
-    while ((1u << hb) < num_hist) hb++;
-    uint32_t sel = 0;
-    LJ_REFILL();
-    if (hb) LJ_READ(hb, sel);
-    if (sel >= num_hist) {
-      err = kErrSelector;
-      sel = 0;
-    }
-    ctx_base = sel * nctx;
-    LJ_REFILL();
-    uint32_t lo16, hi16;
-    LJ_READ(16, lo16);
-    LJ_READ(16, hi16);
-    state = lo16 | (hi16 << 16);
-    LJ_REFILL();
+    bring_end = P.gbb[g] & ~3u;
+    stream4 = reinterpret_cast<const uint4*>(P.sections + P.sec_word[g]);  // 16-byte aligned (jxlhip_frame_upload)
+    sec_size = P.sec_size[g];
+    nwords = (sec_size + 3) / 4;
+    if (g == 0) bitpos = P.first_bit_offset;
   }
   // block / channel cursor
-  uint32_t info = 0, lbx = 0, lby = 0, qfi = 0, dcctx = 0, coef_offset = 0, bctx = 0, c = 0;
+  uint32_t info = 0, lbx = 0, lby = 0, qfi = 0, dcctx = 0, coef_offset = 0, next_offset = 0;
   // coefficient cursor
-  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, hoff = 0, prev = 0, ctxe = 0;
-  const uint16_t* order = T.orders;
-  CoefT* dst = static_cast<CoefT*>(P.coeffs);
-  const uint32_t* blk = reinterpret_cast<const uint32_t*>(P.blocks);
+  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, hoffb = 0, ctxe = 0, dptr = 0, kidx = 0;
+  CoefT* const coeffs = static_cast<CoefT*>(P.coeffs);
+  const uint32_t shift = T.shift;
 
+  unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0;
+  if (B.prof) t_begin = __builtin_readcyclecounter();
   for (;;) {
-    const uint64_t waiting = __ballot(mode == 0), runnable = __ballot(mode == 1 || mode == 2);
+    const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 3;
+    const uint64_t runnable = __ballot(mode == kRun && !low);
+    const uint64_t waiting = __ballot((mode == kWait) || low);
     if (!(waiting | runnable)) break;
-    // ------------------------------------------------------------------ block / channel transition (batched)
     if (waiting && (!runnable || (uint32_t(__popcll(waiting)) << B.wait_shift) >= uint32_t(__popcll(runnable)))) {
-      if (mode == 0) {
-        ci++;
-        if (ci >= 3) {
-          ci = 0;
-          bi++;
-        }
-        if (bi >= b1) {  // section complete
-          if (state != (0x13u << 16)) err |= kErrFinalState;
-          const uint64_t consumed = uint64_t(idx) * 32 - uint64_t(bits);
-          if (consumed > uint64_t(sec_size) * 8) err |= kErrOverread;
-          mode = 3;
-        } else {
-          if (ci == 0) {
-            const uint32_t w0 = blk[bi * 3], w1 = blk[bi * 3 + 1];
-            coef_offset = blk[bi * 3 + 2];
-            const uint32_t qf = w1 >> 16;
-            dcctx = (w1 >> 8) & 0xFF;
-            info = c_strategy_info[w1 & 0xFF];
-            lbx = w0 & 31;
-            lby = (w0 >> 16) & 31;
-            qfi = 0;
-            for (uint32_t t = 0; t + 1 < nq; t++) qfi += qf > P.qf_thr[t];
+      // ================================================================= service phase
+      unsigned long long t0 = 0;
+      if (B.prof) t0 = __builtin_readcyclecounter();
+      // (1) land the prefetches issued by the previous service phase (their latency was hidden behind hot trips)
+      if (pend_s) {
+        pend_s = false;
+        const uint32_t s = ring_end & (kLanesRingWords - 1);
+        ring[(s + 0) * 64] = ring_end + 0 < nwords ? pf_s.x : 0;  // reads past the section are zeros
+        ring[(s + 1) * 64] = ring_end + 1 < nwords ? pf_s.y : 0;
+        ring[(s + 2) * 64] = ring_end + 2 < nwords ? pf_s.z : 0;
+        ring[(s + 3) * 64] = ring_end + 3 < nwords ? pf_s.w : 0;
+        if (s == 0) ring[kLanesRingWords * 64] = ring_end < nwords ? pf_s.x : 0;  // mirror row: a 2-word read at slot 15 needs no wrap
+        ring_end += 4;
+      }
+      if (pend_b) {
+        pend_b = false;
+        const uint32_t s = bring_end & (kLanesBlockRing - 1);
+        bring[(s + 0) * 64] = pf_b.x;
+        bring[(s + 1) * 64] = pf_b.y;
+        bring[(s + 2) * 64] = pf_b.z;
+        bring[(s + 3) * 64] = pf_b.w;
+        bring_end += 4;
+      }
+      // (2) block / channel transitions of the waiting lanes, including the block's non-zero-count symbol
+      const bool next_block = ci == 2 && started;  // the coming transition moves on to block bi + 1
+      if (mode == kWait && (ring_end - (bitpos >> 5)) >= 3 && (!next_block || bi + 1 < bring_end || bi + 1 >= b1)) {
+        if (!started) {  // section header: histogram selector + initial rANS state
+          started = true;
+          uint32_t hb = 0;
+          while ((1u << hb) < num_hist) hb++;
+          const uint32_t w0 = ring[0], w1 = ring[64];
+          const uint64_t win = ((uint64_t(w1) << 32) | w0) >> bitpos;  // bitpos < 8 here
+          uint32_t sel = hb ? uint32_t(win) & ((1u << hb) - 1) : 0;
+          if (sel >= num_hist) {
+            err = kErrSelector;
+            sel = 0;
           }
-          c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
-          const uint32_t ord = info >> 24;
-          const uint8_t* line = l_nz + (c * 32) * 64 + lane;
-          uint32_t pred;
-          if (lbx == 0) pred = lby ? line[0] : 32;
-          else if (lby == 0) pred = line[(lbx - 1) * 64];
-          else pred = (uint32_t(line[lbx * 64]) + line[(lbx - 1) * 64] + 1) >> 1;
-          bctx = l_lut[((c * 13 + ord) * nq + qfi) * ndc + dcctx];
-          uint32_t nzb = pred >= 64 ? 64 : pred;
-          nzb = nzb < 8 ? nzb : 4 + nzb / 2;
-          ctxe = l_ctx[ctx_base + nzb * num_bctx + bctx];
-          mode = 1;
-        }
-      }
-    }
-    // ------------------------------------------------------------------ one symbol for every runnable lane
-    if (mode == 1 || mode == 2) {
-      const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & ((1u << log_entry) - 1);
-      const uint2 e = l_alias[((ctxe >> 24) << log_alpha) + slot];
-      const bool gt = pos >= (e.x >> 24);
-      const uint32_t x = gt ? e.y : e.x;
-      uint32_t tok = gt ? (x >> 24) : slot;
-      const uint32_t hi = state >> 12;
-      state = (x & 0xFFFu) * hi + hi + ((x >> 12) & 0xFFFu) + pos;
-      {
-        const bool need = state < (1u << 16);
-        const uint32_t sh = need ? 16u : 0u;
-        state = need ? ((state << 16) | (uint32_t(buf) & 0xFFFFu)) : state;
-        buf >>= sh;
-        bits -= sh;
-      }
-      LJ_REFILL();
-      const uint32_t se = ctxe & 0xFF;
-      if (tok >= (1u << se)) {  // hybrid uint: extra bits
-        const uint32_t msb = (ctxe >> 8) & 0xFF, lsb = (ctxe >> 16) & 0xFF;
-        const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
-        const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
-        uint32_t xb;
-        LJ_READ(nb, xb);
-        tok = (((((1u << msb) | (top & ((1u << msb) - 1))) << nb) | xb) << lsb) | low;
-        LJ_REFILL();
-      }
-      if (mode == 2) {
-        // ---------------------------------------------------------------- coefficient token
-        if (tok) {
-          const uint32_t mag = tok >> 1, neg = (~tok) & 1;
-          const int32_t coeff = int32_t((mag ^ (neg - 1)) << shift);
-          const uint32_t p = order[k];
-          if (pass == 0) dst[p] = CoefT(coeff);
-          else dst[p] = CoefT(dst[p] + coeff);
-          nzeros--;
-          prev = 1;
+          ctx_base = sel * nctx;
+          state = uint32_t(win >> hb);
+          bitpos += hb + 32;
         } else {
-          prev = 0;
-        }
-        k++;
-        if (nzeros == 0) {
-          mode = 0;
-        } else if (k >= size) {
-          err |= kErrNzeros;
-          mode = 3;
-        } else {
-          const uint32_t covered = 1u << log2c;
-          const uint32_t a = ((nzeros + covered - 1) >> log2c) & 63, b = (k >> log2c) & 63;
-          ctxe = l_ctx[ctx_base + hoff + l_ctx2[a * 64 + b] + prev];
-        }
-      } else {
-        // ---------------------------------------------------------------- non-zero count of (block, channel)
-        const uint32_t cx = info & 0xFF;
-        log2c = (info >> 16) & 0xFF;
-        const uint32_t covered = 1u << log2c;
-        size = covered * 64;
-        nzeros = tok;
-        if (nzeros > size - covered) {
-          err |= kErrNzeros;
-          mode = 3;
-        } else {
-          const uint8_t nzv = uint8_t((nzeros + covered - 1) >> log2c);
-          uint8_t* line = l_nz + (c * 32 + lbx) * 64 + lane;
-          for (uint32_t i = 0; i < cx; i++) line[i * 64] = nzv;
-          if (nzeros == 0) {
-            mode = 0;
+          ci++;
+          if (ci >= 3) {
+            ci = 0;
+            bi++;
+          }
+          if (bi >= b1) {  // section complete
+            if (state != (0x13u << 16)) err |= kErrFinalState;
+            if (bitpos > sec_size * 8) err |= kErrOverread;
+            mode = kDone;
           } else {
-            const uint32_t ord = info >> 24;
-            hoff = num_bctx * 37 + 458 * bctx;
-            order = T.orders + T.order_offset[ord * 3 + c];
-            dst = static_cast<CoefT*>(P.coeffs) + (size_t(g) * 3 + c) * 65536 + coef_offset;
-            prev = nzeros > size / 16 ? 0 : 1;
-            k = covered;
-            const uint32_t a = ((nzeros + covered - 1) >> log2c) & 63, b = (k >> log2c) & 63;
-            ctxe = l_ctx[ctx_base + hoff + l_ctx2[a * 64 + b] + prev];
-            mode = 2;
+            if (ci == 0) {  // packed record: lbx | lby << 5 | strategy << 10 | qf bucket << 15 | dc bucket << 19
+              const uint32_t rec = bring[(bi & (kLanesBlockRing - 1)) * 64];
+              lbx = rec & 31;
+              lby = (rec >> 5) & 31;
+              info = l_sinfo[(rec >> 10) & 31];
+              qfi = (rec >> 15) & 15;
+              dcctx = rec >> 19;
+              coef_offset = next_offset;  // blocks of a group are contiguous in its coefficient planes
+              next_offset += 64u << ((info >> 16) & 0xFF);
+            }
+            const uint32_t c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
+            const uint32_t ord = info >> 24, cx = info & 0xFF;
+            uint8_t* line = l_nz + (c * 32) * 64 + lane;
+            uint32_t pred;
+            if (lbx == 0) pred = lby ? line[0] : 32;
+            else if (lby == 0) pred = line[(lbx - 1) * 64];
+            else pred = (uint32_t(line[lbx * 64]) + line[(lbx - 1) * 64] + 1) >> 1;
+            const uint32_t bctx = l_lut[((c * 13 + ord) * nq + qfi) * ndc + dcctx];
+            uint32_t nzb = pred >= 64 ? 64 : pred;
+            nzb = nzb < 8 ? nzb : 4 + nzb / 2;
+            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, lds_raw, log_entry);
+            log2c = (info >> 16) & 0xFF;
+            const uint32_t covered = 1u << log2c;
+            size = covered * 64;
+            kidx = bi * 3 + c;
+            if (tok > size - covered) {
+              err |= kErrNzeros;
+              mode = kDone;
+            } else {
+              const uint8_t nzv = uint8_t((tok + covered - 1) >> log2c);
+              for (uint32_t i = 0; i < cx; i++) line[(lbx + i) * 64] = nzv;
+              if (tok == 0) {
+                kend_out[kidx] = 0;  // stays waiting: next channel / block
+              } else {
+                nzeros = tok;
+                k = covered;
+                covm1 = covered - 1;
+                hoffb = ctx_base + num_bctx * 37 + 458 * bctx;
+                dptr = (g * 3 + c) * 65536 + coef_offset + covered;
+                const uint32_t prev = nzeros > size / 16 ? 0 : 1;
+                const uint32_t a = (nzeros + covm1) >> log2c;
+                ctxe = l_ctx[hoffb + l_ctx2[(a << 6) + 1] + prev];
+                mode = kRun;
+              }
+            }
           }
         }
+      }
+      // (3) issue the next prefetches; they are consumed by the next service phase
+      if (mode != kDone && (ring_end - (bitpos >> 5)) <= kLanesRingWords - 4) {
+        pf_s = stream4[ring_end >> 2];
+        pend_s = true;
+      }
+      if (mode != kDone && bring_end < b1 && bring_end + 4 - (bi + 1) <= kLanesBlockRing) {
+        pf_b = rec4[bring_end >> 2];
+        pend_b = true;
+      }
+      if (B.prof) {
+        t_service += __builtin_readcyclecounter() - t0;
+        n_service++;
+      }
+      continue;
+    }
+    // =================================================================== hot trip: one coefficient token per lane
+    n_trips++;
+    if (mode == kRun && !low) {
+      // contexts of coefficient k + 1 for both outcomes of this one (off the serial chain)
+      const uint32_t kn = k + 1;
+      const uint32_t b = kn >> log2c;
+      const uint32_t a0 = (nzeros + covm1) >> log2c, a1 = (nzeros - 1 + covm1) >> log2c;
+      const uint32_t cA = l_ctx2[(a0 << 6) + b], cB = l_ctx2[(a1 << 6) + b];
+      const uint32_t eA = l_ctx[hoffb + cA], eB = l_ctx[hoffb + cB + 1];
+      const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, lds_raw, log_entry);
+      const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
+      const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
+      coeffs[dptr] = CoefT(coeff);
+      dptr++;
+      k = kn;
+      const bool nz = tok != 0;
+      nzeros -= nz ? 1u : 0u;
+      ctxe = nz ? eB : eA;
+      if (nzeros == 0) {
+        kend_out[kidx] = k;
+        mode = kWait;
+      } else if (k >= size) {
+        err |= kErrNzeros;
+        mode = kDone;
       }
     }
   }
-#undef LJ_REFILL
-#undef LJ_READ
+  if (B.prof && lane == 0) {
+    unsigned long long* o = B.prof + size_t(blockIdx.x * WPG + wave) * 4;
+    o[0] = __builtin_readcyclecounter() - t_begin;
+    o[1] = t_service;
+    o[2] = n_service;
+    o[3] = n_trips;
+  }
   if (err) atomicOr(&P.errors[g], err);
 }
 

@@ -68,6 +68,9 @@ struct EntropyParams {
   void* coeffs;
   uint32_t* errors;
   uint32_t lds_ctx_bytes, lds_alias_bytes;
+  uint32_t* kend;  // [block * 3 + channel]: number of valid scan-order entries (k_entropy_lanes only)
+  // per block, for k_entropy_lanes: lbx | lby << 5 | strategy << 10 | qf bucket << 15 | dc bucket << 19 (16-byte aligned, padded)
+  const uint32_t* block_recs;
 };
 
 struct BitReader {
@@ -603,6 +606,13 @@ struct TransformParams {
   uint32_t xb, yb, xg, xp, yp;
   float* out;  // 3 planes of xp * yp
   float* scratch;
+  // Coefficient layout. scan_order = 0: natural (coefficient-layout raster) positions, whole block valid.
+  // scan_order = 1: entry k of a (block, channel) is the coefficient at position orders[...][k] and only entries
+  // [covered, kend) were written by the entropy stage (everything else is zero).
+  uint32_t scan_order;
+  const uint32_t* kend;    // [block * 3 + channel]
+  const uint16_t* orders;  // pass 0 coefficient orders
+  uint32_t order_offset[39];
 };
 
 __device__ __forceinline__ float QuantBias(int c, int q, const float* b) {
@@ -613,15 +623,31 @@ __device__ __forceinline__ float QuantBias(int c, int q, const float* b) {
   return qf - b[3] * (1.0f / qf);
 }
 
+// Stages the dequantised coefficients of channel c of one varblock into LDS/scratch `l` at their natural positions
+// (lib/jxl/dec_group.cc:115-181: dequantisation with AdjustQuantBias, then chroma-from-luma for X and B from the
+// already staged dequantised Y in `l_y`). `gq` = the block's coefficients of channel c, `m` = channel c's dequant
+// table, `mul` = inv_global_scale / qf (times the channel's x_dm / b_dm multiplier), `cc` = CfL factor (0 for Y).
 template <typename CoefT>
-__device__ __forceinline__ float DequantOne(const TransformParams& P, const CoefT* gq, uint32_t k, int c, const float* m,
-                                            uint32_t msize, float sc, float x_cc, float b_cc) {
-  // channel c of coefficient k; X and B add the chroma-from-luma term derived from the dequantised Y
-  const int qy = int(gq[65536 + k]);
-  const float dy = QuantBias(1, qy, P.biases) * (m[msize + k] * sc);
-  if (c == 1) return dy;
-  if (c == 0) return x_cc * dy + QuantBias(0, int(gq[k]), P.biases) * (m[k] * (sc * P.x_dm));
-  return b_cc * dy + QuantBias(2, int(gq[2 * 65536 + k]), P.biases) * (m[2 * msize + k] * (sc * P.b_dm));
+__device__ __forceinline__ void StageChannel(const TransformParams& P, const CoefT* gq, uint32_t block_index, int c, uint32_t ord,
+                                             uint32_t size, uint32_t covered, const float* m, float mul, float cc, const float* l_y,
+                                             float* l, uint32_t t, uint32_t nthreads) {
+  if (P.scan_order) {
+    const uint16_t* order = P.orders + P.order_offset[ord * 3 + c];
+    const uint32_t kend = P.kend[block_index * 3 + c];
+    for (uint32_t k = t; k < size; k += nthreads) {
+      const uint32_t pos = order[k];
+      const int q = (k >= covered && k < kend) ? int(gq[k]) : 0;
+      float v = QuantBias(c, q, P.biases) * (m[pos] * mul);
+      if (c != 1) v += cc * l_y[pos];
+      l[pos] = v;
+    }
+  } else {
+    for (uint32_t k = t; k < size; k += nthreads) {
+      float v = QuantBias(c, int(gq[k]), P.biases) * (m[k] * mul);
+      if (c != 1) v += cc * l_y[k];
+      l[k] = v;
+    }
+  }
 }
 
 __device__ __forceinline__ uint32_t BasisOffset(uint32_t n) { return (n * n - 1) / 3; }
@@ -651,17 +677,19 @@ __global__ __launch_bounds__(256) void k_dct(TransformParams P, const uint32_t* 
   constexpr int BPW = 256 / TPB;
   extern __shared__ __align__(16) float lds_f[];
   const int sub = threadIdx.x / TPB, t = threadIdx.x % TPB;
-  float* l_coef = lds_f + sub * 2 * SIZE;
-  float* l_tmp = l_coef + SIZE;
+  float* l_y = lds_f + sub * 3 * SIZE;  // dequantised Y stays resident for the chroma-from-luma of X and B
+  float* l_xb = l_y + SIZE;
+  float* l_tmp = l_xb + SIZE;
   const uint32_t li = blockIdx.x * BPW + sub;
   const bool active = li < n;
   JxlHipVarBlock vb;
   const CoefT* gq = nullptr;
   const float* m = nullptr;
-  uint32_t msize = 0;
+  uint32_t msize = 0, bidx = 0;
   float sc = 0, x_cc = 0, b_cc = 0;
   if (active) {
-    vb = P.blocks[list[li]];
+    bidx = list[li];
+    vb = P.blocks[bidx];
     const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
     gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
     const uint32_t kind = c_strategy_qtable[strategy];
@@ -675,9 +703,13 @@ __global__ __launch_bounds__(256) void k_dct(TransformParams P, const uint32_t* 
   }
   const float* btc = P.basis_t + BasisOffset(C);
   const float* btr = P.basis_t + BasisOffset(R);
-  for (int c = 0; c < 3; c++) {
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    float* l_coef = c == 1 ? l_y : l_xb;
     if (active) {
-      for (int k = t; k < SIZE; k += TPB) l_coef[k] = DequantOne<CoefT>(P, gq, k, c, m, msize, sc, x_cc, b_cc);
+      const float mul = c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm);
+      StageChannel<CoefT>(P, gq + size_t(c) * 65536, bidx, c, c_strategy_order[strategy], SIZE, CX * CY, m + size_t(c) * msize, mul,
+                          c == 0 ? x_cc : b_cc, l_y, l_coef, t, TPB);
     }
     __syncthreads();
     if (active && t < CX * CY) {
@@ -741,7 +773,14 @@ __global__ __launch_bounds__(256) void k_dct_big(TransformParams P, const uint32
   const float b_cc = P.base_b + float(P.ytob[tile]) * P.color_scale;
   float* s_coef = P.scratch + size_t(blockIdx.x) * 2 * 65536;
   float* s_tmp = s_coef + 65536;
-  for (uint32_t k = threadIdx.x; k < SIZE; k += 256) s_coef[k] = DequantOne<CoefT>(P, gq, k, c, m, msize, sc, x_cc, b_cc);
+  const uint32_t ord = c_strategy_order[strategy];
+  if (c != 1) {  // dequantised Y first (into s_tmp, free until the first transform pass) for the chroma-from-luma term
+    StageChannel<CoefT>(P, gq + 65536, list[li], 1, ord, SIZE, CX * CY, m + msize, sc, 0.0f, s_tmp, s_tmp, threadIdx.x, 256);
+    __threadfence_block();
+    __syncthreads();
+  }
+  StageChannel<CoefT>(P, gq + size_t(c) * 65536, list[li], c, ord, SIZE, CX * CY, m + size_t(c) * msize,
+                      c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm), c == 0 ? x_cc : b_cc, s_tmp, s_coef, threadIdx.x, 256);
   __threadfence_block();
   __syncthreads();
   {
@@ -795,19 +834,22 @@ __device__ __forceinline__ float B8(const float* bt8, int n, int k) { return bt8
 // 8x8-coverage special transforms; 64 threads per varblock (one per pixel), 4 varblocks per workgroup.
 template <typename CoefT>
 __global__ __launch_bounds__(256) void k_special(TransformParams P, const uint32_t* list, uint32_t n, uint32_t strategy) {
-  __shared__ float l_all[4][2][64];
+  __shared__ float l_all[4][4][64];
   const int sub = threadIdx.x >> 6, t = threadIdx.x & 63;
-  float* co = l_all[sub][0];
-  float* buf = l_all[sub][1];
+  float* l_y = l_all[sub][0];  // dequantised Y stays resident for the chroma-from-luma of X and B
+  float* l_xb = l_all[sub][1];
+  float* buf = l_all[sub][2];
+  float* buf2 = l_all[sub][3];
   const uint32_t li = blockIdx.x * 4 + sub;
   const bool active = li < n;
   JxlHipVarBlock vb;
   const CoefT* gq = nullptr;
   const float* m = nullptr;
-  uint32_t msize = 0;
+  uint32_t msize = 0, bidx = 0;
   float sc = 0, x_cc = 0, b_cc = 0;
   if (active) {
-    vb = P.blocks[list[li]];
+    bidx = list[li];
+    vb = P.blocks[bidx];
     const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
     gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
     const uint32_t kind = c_strategy_qtable[strategy];
@@ -822,12 +864,15 @@ __global__ __launch_bounds__(256) void k_special(TransformParams P, const uint32
   const float* bt4 = P.basis_t + BasisOffset(4);
   const float* bt8 = P.basis_t + BasisOffset(8);
   const int py = t >> 3, px = t & 7;
-  for (int c = 0; c < 3; c++) {
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    float* co = c == 1 ? l_y : l_xb;
     if (active) {
-      float v = DequantOne<CoefT>(P, gq, t, c, m, msize, sc, x_cc, b_cc);
-      if (t == 0) v = P.dc[size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx];
-      co[t] = v;
+      StageChannel<CoefT>(P, gq + size_t(c) * 65536, bidx, c, 1, 64, 1, m + size_t(c) * msize,
+                          c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm), c == 0 ? x_cc : b_cc, l_y, co, t, 64);
     }
+    __syncthreads();
+    if (active && t == 0) co[0] = P.dc[size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx];
     __syncthreads();
     float result = 0.0f;
     if (strategy == 1) {  // IDENTITY
@@ -864,9 +909,8 @@ __global__ __launch_bounds__(256) void k_special(TransformParams P, const uint32
           dst[t] = v;
         }
         __syncthreads();
-        float* tmp = src;
         src = dst;
-        dst = tmp;
+        dst = dst == buf ? buf2 : buf;  // never back into `co`: l_y must survive
       }
       if (active) result = src[t];
     } else if (strategy == 3) {  // DCT4X4
