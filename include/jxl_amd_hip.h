@@ -144,9 +144,14 @@ int jxlhip_get_errors(JxlHipContext* ctx, uint32_t* flags, size_t n);
 /* Test/debug access to intermediates; synchronous copies to host.
  *   "coeffs"       quantised coefficients, int16 or int32 [num_groups][3][65536]
  *   "xyb_idct"     float [3][ysize_padded][xsize_padded] after the inverse transforms
- *   "xyb_filtered" float [3][ysize_padded][xsize_padded] after Gaborish/EPF (rows < ysize valid)
+ *   "xyb_filtered" float [3][ysize_padded][xsize_padded] after Gaborish/EPF (rows < ysize, columns < xsize valid;
+ *                  only with option "keep_filtered")
  * Returns the number of bytes the buffer needs through *needed when dst is NULL. */
 int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_size, size_t* needed);
+
+/* Options (set before jxlhip_frame_upload): "keep_filtered" = 1 makes jxlhip_run_filter_color also store the filtered
+ * XYB planes for jxlhip_download("xyb_filtered") (test aid; costs one extra plane set and 12 B/pixel of writes). */
+int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
 
 /* Timing of the last run of each stage in milliseconds (HIP events on the context's stream);
  * which: 0 entropy, 1 transform, 2 filter+colour. Synchronous. */

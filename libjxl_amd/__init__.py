@@ -47,6 +47,7 @@ def lib():
             getattr(L, name).argtypes = [vp]
         L.jxlhip_run_entropy_batch.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
         L.jxlhip_download_rgb8.argtypes = [vp, vp, ctypes.c_size_t]
+        L.jxlhip_set_option.argtypes = [vp, cp, ctypes.c_int]
         L.jxlhip_rgb8_device_ptr.argtypes = [vp]
         L.jxlhip_rgb8_device_ptr.restype = vp
         L.jxlhip_get_errors.argtypes = [vp, u32p, ctypes.c_size_t]
@@ -127,6 +128,9 @@ class HipContext:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        _check(lib().jxlhip_set_option(self._h, name.encode(), int(value)), "jxlhip_set_option")
 
     def upload(self, frame):
         _check(lib().jxlamd_frame_upload(frame._h, self._h), "jxlamd_frame_upload")

@@ -15,6 +15,7 @@
 #include "../../../include/jxl_amd_hip.h"
 #include "jxl_hip_kernels.h"
 #include "jxl_hip_entropy_lanes.h"
+#include "jxl_hip_filter_fused.h"
 
 namespace {
 #include "../host/afv_basis.inc"
@@ -81,11 +82,12 @@ struct JxlHipContext {
   Buf plane[3], rgb, tlist, scratch;
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
-  uint32_t batch_wait_shift = 2;
+  uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64;
   int batch_kernel = -1;
   std::vector<uint32_t> sec_size_host, pass_clusters, pass_log_alpha;
   // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
   bool scan_order = false;
+  bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
   Buf kend, block_recs;
   std::vector<JxlHipVarBlock> blocks_host;  // for jxlhip_download("coeffs") of a scan-order frame
   std::vector<uint32_t> gbb_host;
@@ -96,6 +98,10 @@ struct JxlHipContext {
   uint32_t batch_wgs = 0;
   size_t batch_lds = 0;
   hipEvent_t batch_done = nullptr;
+  // Set by jxlhip_run_entropy_batch on the contexts whose coefficients a launch on ANOTHER context's stream produces;
+  // applied (hipStreamWaitEvent on this context's stream) by the next call that touches those results. Enqueuing the
+  // wait only then keeps barrier packets of a long entropy launch out of the hardware queues other streams share.
+  hipEvent_t pending_wait = nullptr;
   uint64_t generation = 0;            // bumped by every jxlhip_frame_upload
   std::vector<PassBufs> pass_bufs;
   uint32_t list_begin[27] = {}, list_count[27] = {};
@@ -121,9 +127,9 @@ static int EnvInt(const char* name, int def) {
   return e && *e ? atoi(e) : def;
 }
 
-static size_t LanesLdsFor(const JxlHipContext* c) {
+static size_t LanesLdsFor(const JxlHipContext* c, uint32_t lanes = 64) {
   return jxlhip::LanesLdsLayout(c->ep.num_hist, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc,
-                                kLanesWPG).total;
+                                kLanesWPG, lanes).total;
 }
 
 extern "C" {
@@ -207,6 +213,14 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   delete c;
 }
 
+static int ApplyPendingWait(JxlHipContext* c) {
+  if (c->pending_wait) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->pending_wait, 0));
+    c->pending_wait = nullptr;
+  }
+  return 0;
+}
+
 static int Upload(JxlHipContext* c, Buf& b, const void* src, size_t bytes) {
   int r = b.Ensure(bytes ? bytes : 16);
   if (r) return r;
@@ -224,6 +238,10 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (d->num_qf_thresholds > 15 || d->num_block_ctxs == 0 || d->num_block_ctxs > 16 || d->num_dc_ctxs == 0)
     return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
   c->have_frame = false;
   c->xs = d->xsize; c->ys = d->ysize; c->xb = d->xsize_blocks; c->yb = d->ysize_blocks;
   c->xg = d->xsize_groups; c->ng = d->num_groups; c->np = d->num_passes;
@@ -325,8 +343,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = c->coeffs.Ensure(coef_bytes))) return r;
   if ((r = c->errors.Ensure(size_t(d->num_groups) * 4))) return r;
   const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
-  for (auto& pl : c->plane)
-    if ((r = pl.Ensure(plane_bytes))) return r;
+  if ((r = c->plane[0].Ensure(plane_bytes))) return r;
+  if (c->keep_filtered && (r = c->plane[1].Ensure(plane_bytes))) return r;
   if ((r = c->rgb.Ensure(size_t(c->xs) * c->ys * 3))) return r;
   // ---- transform work lists (block indices bucketed by strategy)
   {
@@ -506,6 +524,10 @@ static int RunEntropySingle(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
   HIP_TRY(hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(c->ng) * 4, c->stream));
   int r = c->coef_bits == 16 ? LaunchEntropy<int16_t>(c) : LaunchEntropy<int32_t>(c);
@@ -571,6 +593,7 @@ static int LaunchEntropyLanes(JxlHipContext* c0) {
   b.wg_frame = c0->batch_map.as<uint32_t>();
   b.lane_group = c0->batch_lanes.as<uint32_t>();
   b.wait_shift = c0->batch_wait_shift;
+  b.lanes = c0->batch_lanes_per_wave;
   b.prof = nullptr;
   const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
   const size_t nwaves = size_t(c0->batch_wgs) * kLanesWPG;
@@ -630,8 +653,9 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 1024));
     while (lanes_per_wave < 64 && (total_sections + lanes_per_wave - 1) / lanes_per_wave > target_waves) lanes_per_wave *= 2;
     const int forced = EnvInt("JXLHIP_LANES", 0);
-    if (forced >= 1 && forced <= 64) lanes_per_wave = uint32_t(forced);
+    if (forced >= 1 && forced <= 64 && (forced & (forced - 1)) == 0) lanes_per_wave = uint32_t(forced);
     c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 2));
+    c0->batch_lanes_per_wave = lanes_per_wave;
     const uint32_t per_wg = lanes_per_wave * kLanesWPG;
     std::vector<uint32_t> order;
     for (size_t i = 0; i < n; i++) {
@@ -640,7 +664,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
       const uint32_t wgs = (c->ng + per_wg - 1) / per_wg;
       for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i));
       lanes.resize(map.size() * kLanesWPG * 64, 0xFFFFFFFFu);
-      const size_t l = LanesLdsFor(c);
+      const size_t l = LanesLdsFor(c, lanes_per_wave);
       lds = l > lds ? l : lds;
       order.resize(c->ng);
       for (uint32_t g = 0; g < c->ng; g++) order[g] = g;
@@ -706,6 +730,11 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   // the batch kernel runs on the first context's stream, after whatever the other contexts still have in flight
   for (size_t i = 1; i < n; i++)
     if (ctxs[i]->ev_valid[2]) HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev[5], 0));
+  for (size_t i = 0; i < n; i++)
+    if (ctxs[i]->pending_wait) {  // results of an earlier batch launch that nobody consumed: order after that launch
+      HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->pending_wait, 0));
+      ctxs[i]->pending_wait = nullptr;
+    }
   HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
   for (size_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(ctxs[i]->errors.p, 0, size_t(ctxs[i]->ng) * 4, c0->stream));
   if (kernel == 2) r = c0->coef_bits == 16 ? LaunchEntropyLanes<int16_t>(c0) : LaunchEntropyLanes<int32_t>(c0);
@@ -716,7 +745,7 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   if (n > 1) {
     HIP_TRY(hipEventRecord(c0->batch_done, c0->stream));
     for (size_t i = 1; i < n; i++) {
-      HIP_TRY(hipStreamWaitEvent(ctxs[i]->stream, c0->batch_done, 0));
+      ctxs[i]->pending_wait = c0->batch_done;
       ctxs[i]->ev_valid[0] = false;
     }
   }
@@ -729,12 +758,28 @@ extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
   return c->scan_order ? jxlhip_run_entropy_batch(&c, 1) : RunEntropySingle(c);
 }
 
+template <bool GAB, int EPF>
+static int LaunchFused(JxlHipContext* c, const jxlhip::FusedFilterParams& p) {
+  auto k = jxlhip::k_filter_fused<GAB, EPF>;
+  constexpr size_t lds = jxlhip::FusedLdsBytes(GAB, EPF);
+  if (lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+  const dim3 grid((c->xs + jxlhip::kFusedTW - 1) / jxlhip::kFusedTW, (c->ys + jxlhip::kFusedTH - 1) / jxlhip::kFusedTH);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, c->stream, p);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 
 int jxlhip_run_transform(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
   HIP_TRY(hipEventRecord(c->ev[2], c->stream));
   int r = c->coef_bits == 16 ? LaunchTransforms<int16_t>(c) : LaunchTransforms<int32_t>(c);
   if (r) return r;
@@ -748,36 +793,42 @@ int jxlhip_run_filter_color(JxlHipContext* c) {
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-  const dim3 grid((c->xs + 63) / 64, (c->ys + 3) / 4), block(256);
-  int cur = 0;
-  jxlhip::FilterParams fp = c->fp;
-  auto next = [&](int a) { return a == 1 ? 2 : 1; };
-  if (c->gab) {
-    fp.in = c->plane[cur].as<float>();
-    fp.out = c->plane[next(cur)].as<float>();
-    hipLaunchKernelGGL(jxlhip::k_gaborish, grid, block, 0, c->stream, fp);
-    cur = next(cur);
-  }
+  jxlhip::FusedFilterParams p;
+  p.f = c->fp;
+  p.f.in = c->plane[0].as<float>();
+  p.f.out = nullptr;
   for (int stage = 0; stage < 3; stage++) {
-    const bool run = (stage == 0 && c->epf_iters >= 3) || (stage == 1 && c->epf_iters >= 1) || (stage == 2 && c->epf_iters >= 2);
-    if (!run) continue;
     const float scale = stage == 0 ? c->epf_pass0 : stage == 2 ? c->epf_pass2 : 1.0f;
-    fp.sm = stage == 1 ? 1.65f : float(scale * 1.65);
-    fp.bsm = fp.sm * c->epf_border;
-    fp.in = c->plane[cur].as<float>();
-    fp.out = c->plane[next(cur)].as<float>();
-    if (stage == 0) hipLaunchKernelGGL(jxlhip::k_epf<0>, grid, block, 0, c->stream, fp);
-    if (stage == 1) hipLaunchKernelGGL(jxlhip::k_epf<1>, grid, block, 0, c->stream, fp);
-    if (stage == 2) hipLaunchKernelGGL(jxlhip::k_epf<2>, grid, block, 0, c->stream, fp);
-    cur = next(cur);
+    p.sm[stage] = stage == 1 ? 1.65f : float(scale * 1.65);
+    p.bsm[stage] = p.sm[stage] * c->epf_border;
   }
-  c->final_plane = cur;
-  fp.in = c->plane[cur].as<float>();
-  hipLaunchKernelGGL(jxlhip::k_color, grid, block, 0, c->stream, fp);
-  HIP_TRY(hipGetLastError());
+  p.filtered = c->keep_filtered ? c->plane[1].as<float>() : nullptr;
+  c->final_plane = 1;
+  const int epf = c->epf_iters < 0 ? 0 : (c->epf_iters > 3 ? 3 : c->epf_iters);
+  int r = 0;
+  switch ((c->gab ? 4 : 0) + epf) {
+    case 0: r = LaunchFused<false, 0>(c, p); break;
+    case 1: r = LaunchFused<false, 1>(c, p); break;
+    case 2: r = LaunchFused<false, 2>(c, p); break;
+    case 3: r = LaunchFused<false, 3>(c, p); break;
+    case 4: r = LaunchFused<true, 0>(c, p); break;
+    case 5: r = LaunchFused<true, 1>(c, p); break;
+    case 6: r = LaunchFused<true, 2>(c, p); break;
+    default: r = LaunchFused<true, 3>(c, p); break;
+  }
+  if (r) return r;
   HIP_TRY(hipEventRecord(c->ev[5], c->stream));
   c->ev_valid[2] = true;
   return 0;
+}
+
+int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
+  if (!c || !name) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (std::string(name) == "keep_filtered") {
+    c->keep_filtered = value != 0;
+    return 0;
+  }
+  return JXLHIP_ERR_INVALID_ARGUMENT;
 }
 
 int jxlhip_run_all(JxlHipContext* c) {
@@ -790,6 +841,10 @@ int jxlhip_run_all(JxlHipContext* c) {
 int jxlhip_sync(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -799,6 +854,10 @@ int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   if (stride < size_t(c->xs) * 3) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
   HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, size_t(c->xs) * 3, size_t(c->xs) * 3, c->ys, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
@@ -811,6 +870,10 @@ int jxlhip_get_errors(JxlHipContext* c, uint32_t* flags, size_t n) {
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   if (n < c->ng) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
   HIP_TRY(hipMemcpyAsync(flags, c->errors.p, size_t(c->ng) * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (uint32_t g = 0; g < c->ng; g++)
@@ -832,7 +895,8 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
     src = c->plane[0].p;
     bytes = plane_bytes;
   } else if (n == "xyb_filtered") {
-    src = c->plane[c->final_plane].p;
+    if (!c->keep_filtered || !c->plane[1].p) return JXLHIP_ERR_INVALID_ARGUMENT;  // needs jxlhip_set_option("keep_filtered", 1)
+    src = c->plane[1].p;
     bytes = plane_bytes;
   } else {
     return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -841,6 +905,10 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
   if (!dst) return 0;
   if (dst_size < bytes) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (n == "coeffs" && c->scan_order) {

@@ -37,6 +37,7 @@ struct EntropyLaneBatch {
   const uint32_t* wg_frame;     // per workgroup: index into params
   const uint32_t* lane_group;   // per lane of every wave: group (AC section) index in its frame, 0xFFFFFFFF = idle lane
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
+  uint32_t lanes;               // populated lanes per wave (power of two): lanes >= this are idle; strides the per-wave LDS
   unsigned long long* prof;     // optional (may be NULL): per wave {cycles total, cycles in service, services, hot trips}
 };
 
@@ -44,31 +45,33 @@ struct EntropyLaneBatch {
 struct LanesLds {
   uint32_t alias, ctx, lut, ctx2, sinfo, wave0, per_wave, total;
 };
-constexpr uint32_t kLanesNzBytes = 96 * 64;         // nzeros line buffer [channel * 32 + column][lane], u8
-constexpr uint32_t kLanesRingWords = 16;            // per lane; + 1 mirror row
-constexpr uint32_t kLanesRingBytes = (kLanesRingWords + 1) * 64 * 4;
-constexpr uint32_t kLanesBlockRing = 8;             // packed block records per lane
-constexpr uint32_t kLanesBlockRingBytes = kLanesBlockRing * 64 * 4;
+// Per-wave LDS, all [row][lane] with a row stride of `lanes` entries (conflict-free, and a wave that populates few lanes
+// needs little LDS, which keeps room on the CU for the bandwidth-bound kernels running beside this one):
+constexpr uint32_t kLanesNzRows = 96;               // nzeros line buffer [channel * 32 + column], u8
+constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 1 mirror row
+constexpr uint32_t kLanesBlockRing = 8;             // packed block records, u32
+constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 1) * 4 + kLanesBlockRing * 4;
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
-                                                   uint32_t lut_bytes, uint32_t waves) {
+                                                   uint32_t lut_bytes, uint32_t waves, uint32_t lanes) {
   LanesLds l;
   l.alias = 0;
   l.ctx = (num_clusters << log_alpha) * 8;
   l.lut = l.ctx + (((num_hist * nctx + 16) * 4 + 15) & ~15u);
   l.ctx2 = l.lut + ((lut_bytes + 15) & ~15u);
-  l.sinfo = l.ctx2 + (64 * 64 + 64) * 2;
+  l.sinfo = l.ctx2 + 64 * 2;
   l.wave0 = l.sinfo + 32 * 4;
-  l.per_wave = kLanesNzBytes + kLanesRingBytes + kLanesBlockRingBytes;
+  l.per_wave = kLanesPerLaneBytes * lanes;
   l.total = l.wave0 + waves * l.per_wave;
   return l;
 }
 
 // One rANS symbol + hybrid-uint extra bits for the calling lane. ctxe = split_exp | msb << 4 | lsb << 8 |
 // (byte offset of the cluster's alias table in LDS) << 12. `ring` points at the lane's column of the stream ring.
-__device__ __forceinline__ uint32_t LaneSymbol(uint32_t ctxe, uint32_t& state, uint32_t& bitpos, const uint32_t* ring,
+__device__ __forceinline__ uint32_t LaneSymbol(uint32_t ctxe, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
                                                const uint8_t* lds, uint32_t log_entry) {
   const uint32_t s0 = (bitpos >> 5) & (kLanesRingWords - 1);
-  const uint32_t w0 = ring[s0 * 64], w1 = ring[s0 * 64 + 64];
+  uint32_t w0 = ring[s0 * LS], w1 = ring[s0 * LS + LS];
+  asm volatile("" : "+v"(w0), "+v"(w1));  // keep the window read here, next to the alias read (one LDS round trip)
   const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & ((1u << log_entry) - 1);
   const uint2 e = *reinterpret_cast<const uint2*>(lds + (ctxe >> 12) + slot * 8);
   const bool gt = pos >= (e.x >> 24);
@@ -86,7 +89,7 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t ctxe, uint32_t& state, u
     const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
     const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
     const uint32_t s1 = (bitpos >> 5) & (kLanesRingWords - 1);
-    const uint32_t v0 = ring[s1 * 64], v1 = ring[s1 * 64 + 64];
+    const uint32_t v0 = ring[s1 * LS], v1 = ring[s1 * LS + LS];
     const uint32_t xb = __builtin_amdgcn_alignbit(v1, v0, bitpos & 31) & ((1u << nb) - 1);
     bitpos += nb;
     tok = (((((1u << msb) | (top & ((1u << msb) - 1))) << nb) | xb) << lsb) | low;
@@ -103,14 +106,15 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, nclusters = T.num_clusters;
   const uint32_t nq = P.nq, ndc = P.ndc, num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
   const uint32_t lut_bytes = 39 * nq * ndc;
-  const LanesLds L = LanesLdsLayout(num_hist, nctx, nclusters, log_alpha, lut_bytes, WPG);
+  const uint32_t LS = B.lanes;
+  const LanesLds L = LanesLdsLayout(num_hist, nctx, nclusters, log_alpha, lut_bytes, WPG, LS);
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
   uint32_t* l_ctx = reinterpret_cast<uint32_t*>(lds_raw + L.ctx);
   uint8_t* l_lut = lds_raw + L.lut;
-  uint16_t* l_ctx2 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)][k / covered] -> 2 * (nnz ctx + freq ctx)
+  uint16_t* l_nnz8 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)] -> 8 * kCoeffNumNonzeroContext
   uint8_t* l_nz = lds_raw + L.wave0 + wave * L.per_wave;             // line buffer of the per-block nzeros prediction
-  uint32_t* ring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzBytes) + lane;
-  uint32_t* bring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzBytes + kLanesRingBytes) + lane;  // block records [slot][lane]
+  uint32_t* ring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzRows * LS) + lane;                 // stream ring [slot][lane]
+  uint32_t* bring = ring + (kLanesRingWords + 1) * LS;                                           // block records [slot][lane]
   const uint32_t* l_sinfo = reinterpret_cast<const uint32_t*>(lds_raw + L.sinfo);
 
   // ---- stage the frame's tables (whole workgroup)
@@ -132,11 +136,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       l_alias[i] = make_uint2(((freq0 - 1) & 0xFFFu) | (cutoff << 24), ((freq1 - 1) & 0xFFFu) | ((offs1 & 0xFFFu) << 12) | (right << 24));
     }
     for (uint32_t i = tid; i < lut_bytes; i += 64 * WPG) l_lut[i] = P.bctx_lut[i];
-    for (uint32_t i = tid; i < 64 * 64 + 64; i += 64 * WPG)
-      l_ctx2[i] = uint16_t((uint32_t(c_coeff_nnz_ctx[(i >> 6) & 63]) + c_coeff_freq_ctx[i & 63]) * 2);
+    if (tid < 64) l_nnz8[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 8);
     if (tid < 27) reinterpret_cast<uint32_t*>(lds_raw + L.sinfo)[tid] = c_strategy_info[tid];
     uint32_t* z = reinterpret_cast<uint32_t*>(l_nz);
-    for (uint32_t i = lane; i < kLanesNzBytes / 4; i += 64) z[i] = 0;
+    for (uint32_t i = lane; i < kLanesNzRows * LS / 4; i += 64) z[i] = 0;
   }
   __syncthreads();
 
@@ -164,14 +167,16 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   // block / channel cursor
   uint32_t info = 0, lbx = 0, lby = 0, qfi = 0, dcctx = 0, coef_offset = 0, next_offset = 0;
   // coefficient cursor
-  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, hoffb = 0, ctxe = 0, dptr = 0, kidx = 0;
+  // addr_a / addr_b: LDS byte address of the context entry of the NEXT coefficient at frequency context 0, if the
+  // current token turns out zero (same non-zero count, prev = 0) / non-zero (one fewer to come, prev = 1)
+  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, addr_b = 0, ctxe = 0, dptr = 0, kidx = 0;
   CoefT* const coeffs = static_cast<CoefT*>(P.coeffs);
   const uint32_t shift = T.shift;
 
   unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0;
   if (B.prof) t_begin = __builtin_readcyclecounter();
   for (;;) {
-    const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 3;
+    const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 5;  // two hot trips consume at most 4 ring words
     const uint64_t runnable = __ballot(mode == kRun && !low);
     const uint64_t waiting = __ballot((mode == kWait) || low);
     if (!(waiting | runnable)) break;
@@ -183,20 +188,20 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       if (pend_s) {
         pend_s = false;
         const uint32_t s = ring_end & (kLanesRingWords - 1);
-        ring[(s + 0) * 64] = ring_end + 0 < nwords ? pf_s.x : 0;  // reads past the section are zeros
-        ring[(s + 1) * 64] = ring_end + 1 < nwords ? pf_s.y : 0;
-        ring[(s + 2) * 64] = ring_end + 2 < nwords ? pf_s.z : 0;
-        ring[(s + 3) * 64] = ring_end + 3 < nwords ? pf_s.w : 0;
-        if (s == 0) ring[kLanesRingWords * 64] = ring_end < nwords ? pf_s.x : 0;  // mirror row: a 2-word read at slot 15 needs no wrap
+        ring[(s + 0) * LS] = ring_end + 0 < nwords ? pf_s.x : 0;  // reads past the section are zeros
+        ring[(s + 1) * LS] = ring_end + 1 < nwords ? pf_s.y : 0;
+        ring[(s + 2) * LS] = ring_end + 2 < nwords ? pf_s.z : 0;
+        ring[(s + 3) * LS] = ring_end + 3 < nwords ? pf_s.w : 0;
+        if (s == 0) ring[kLanesRingWords * LS] = ring_end < nwords ? pf_s.x : 0;  // mirror row: a 2-word read at slot 15 needs no wrap
         ring_end += 4;
       }
       if (pend_b) {
         pend_b = false;
         const uint32_t s = bring_end & (kLanesBlockRing - 1);
-        bring[(s + 0) * 64] = pf_b.x;
-        bring[(s + 1) * 64] = pf_b.y;
-        bring[(s + 2) * 64] = pf_b.z;
-        bring[(s + 3) * 64] = pf_b.w;
+        bring[(s + 0) * LS] = pf_b.x;
+        bring[(s + 1) * LS] = pf_b.y;
+        bring[(s + 2) * LS] = pf_b.z;
+        bring[(s + 3) * LS] = pf_b.w;
         bring_end += 4;
       }
       // (2) block / channel transitions of the waiting lanes, including the block's non-zero-count symbol
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
           started = true;
           uint32_t hb = 0;
           while ((1u << hb) < num_hist) hb++;
-          const uint32_t w0 = ring[0], w1 = ring[64];
+          const uint32_t w0 = ring[0], w1 = ring[LS];
           const uint64_t win = ((uint64_t(w1) << 32) | w0) >> bitpos;  // bitpos < 8 here
           uint32_t sel = hb ? uint32_t(win) & ((1u << hb) - 1) : 0;
           if (sel >= num_hist) {
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
             mode = kDone;
           } else {
             if (ci == 0) {  // packed record: lbx | lby << 5 | strategy << 10 | qf bucket << 15 | dc bucket << 19
-              const uint32_t rec = bring[(bi & (kLanesBlockRing - 1)) * 64];
+              const uint32_t rec = bring[(bi & (kLanesBlockRing - 1)) * LS];
               lbx = rec & 31;
               lby = (rec >> 5) & 31;
               info = l_sinfo[(rec >> 10) & 31];
@@ -239,15 +244,15 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
             }
             const uint32_t c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
             const uint32_t ord = info >> 24, cx = info & 0xFF;
-            uint8_t* line = l_nz + (c * 32) * 64 + lane;
+            uint8_t* line = l_nz + (c * 32) * LS + lane;
             uint32_t pred;
             if (lbx == 0) pred = lby ? line[0] : 32;
-            else if (lby == 0) pred = line[(lbx - 1) * 64];
-            else pred = (uint32_t(line[lbx * 64]) + line[(lbx - 1) * 64] + 1) >> 1;
+            else if (lby == 0) pred = line[(lbx - 1) * LS];
+            else pred = (uint32_t(line[lbx * LS]) + line[(lbx - 1) * LS] + 1) >> 1;
             const uint32_t bctx = l_lut[((c * 13 + ord) * nq + qfi) * ndc + dcctx];
             uint32_t nzb = pred >= 64 ? 64 : pred;
             nzb = nzb < 8 ? nzb : 4 + nzb / 2;
-            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, lds_raw, log_entry);
+            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, lds_raw, log_entry);
             log2c = (info >> 16) & 0xFF;
             const uint32_t covered = 1u << log2c;
             size = covered * 64;
@@ -257,18 +262,19 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
               mode = kDone;
             } else {
               const uint8_t nzv = uint8_t((tok + covered - 1) >> log2c);
-              for (uint32_t i = 0; i < cx; i++) line[(lbx + i) * 64] = nzv;
+              for (uint32_t i = 0; i < cx; i++) line[(lbx + i) * LS] = nzv;
               if (tok == 0) {
                 kend_out[kidx] = 0;  // stays waiting: next channel / block
               } else {
                 nzeros = tok;
                 k = covered;
                 covm1 = covered - 1;
-                hoffb = ctx_base + num_bctx * 37 + 458 * bctx;
+                cbase = L.ctx + (ctx_base + num_bctx * 37 + 458 * bctx) * 4;
                 dptr = (g * 3 + c) * 65536 + coef_offset + covered;
                 const uint32_t prev = nzeros > size / 16 ? 0 : 1;
-                const uint32_t a = (nzeros + covm1) >> log2c;
-                ctxe = l_ctx[hoffb + l_ctx2[(a << 6) + 1] + prev];
+                addr_a = cbase + l_nnz8[((nzeros + covm1) >> log2c) & 63];
+                addr_b = cbase + l_nnz8[((nzeros - 1 + covm1) >> log2c) & 63] + 4;
+                ctxe = *reinterpret_cast<const uint32_t*>(lds_raw + addr_a + prev * 4);  // frequency context of k = covered is 0
                 mode = kRun;
               }
             }
@@ -290,30 +296,36 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       }
       continue;
     }
-    // =================================================================== hot trip: one coefficient token per lane
-    n_trips++;
-    if (mode == kRun && !low) {
-      // contexts of coefficient k + 1 for both outcomes of this one (off the serial chain)
-      const uint32_t kn = k + 1;
-      const uint32_t b = kn >> log2c;
-      const uint32_t a0 = (nzeros + covm1) >> log2c, a1 = (nzeros - 1 + covm1) >> log2c;
-      const uint32_t cA = l_ctx2[(a0 << 6) + b], cB = l_ctx2[(a1 << 6) + b];
-      const uint32_t eA = l_ctx[hoffb + cA], eB = l_ctx[hoffb + cB + 1];
-      const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, lds_raw, log_entry);
-      const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
-      const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
-      coeffs[dptr] = CoefT(coeff);
-      dptr++;
-      k = kn;
-      const bool nz = tok != 0;
-      nzeros -= nz ? 1u : 0u;
-      ctxe = nz ? eB : eA;
-      if (nzeros == 0) {
-        kend_out[kidx] = k;
-        mode = kWait;
-      } else if (k >= size) {
-        err |= kErrNzeros;
-        mode = kDone;
+    // =================================================================== hot trips: one coefficient token per lane each
+    n_trips += 2;
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+      if (mode == kRun && !low) {
+        // context entries of coefficient k + 1 for both outcomes of this one (off the serial chain);
+        // kCoeffFreqContext(b) for b = (k + 1) / covered in 1..63 is min(b - 1, 7 + b / 2, 15 + b / 4)
+        const uint32_t kn = k + 1;
+        const uint32_t b = kn >> log2c;
+        const uint32_t f8 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 3;
+        const uint32_t e_zero = *reinterpret_cast<const uint32_t*>(lds_raw + addr_a + f8);
+        const uint32_t e_nonzero = *reinterpret_cast<const uint32_t*>(lds_raw + addr_b + f8);
+        const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, LS, lds_raw, log_entry);
+        const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
+        const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
+        coeffs[dptr] = CoefT(coeff);
+        dptr++;
+        k = kn;
+        const bool nz = tok != 0;
+        nzeros -= nz ? 1u : 0u;
+        ctxe = nz ? e_nonzero : e_zero;
+        addr_a = nz ? addr_b - 4 : addr_a;
+        addr_b = cbase + l_nnz8[((nzeros - 1 + covm1) >> log2c) & 63] + 4;
+        if (nzeros == 0) {
+          kend_out[kidx] = k;
+          mode = kWait;
+        } else if (k >= size) {
+          err |= kErrNzeros;
+          mode = kDone;
+        }
       }
     }
   }

@@ -1,0 +1,203 @@
+// libjxl_amd — fused loop filters + colour for gfx950 (MI355X): Gaborish -> EPF0/1/2 -> XYB->RGB -> sRGB -> RGB8 in one
+// pass over an LDS-resident tile. Replaces the reference's render-pipeline stage list for VarDCT frames
+// (lib/jxl/render_pipeline/stage_gaborish.cc:56-100, stage_epf.cc:82-494, stage_xyb.cc:80-92 + dec_xyb-inl.h:38-86,
+// stage_from_linear.cc:114-144 + cms/transfer_functions-inl.h:245-268, stage_write.cc:266-286,548-590) and the edge
+// mirroring of low_memory_render_pipeline.cc:475-517.
+//
+// One workgroup owns a 64x32 output tile. The inverse-transform output (3 f32 planes) is read ONCE from HBM for the
+// tile plus a halo of H pixels (H = sum of the enabled stages' radii, coordinates mirrored about the frame size), every
+// stage then runs LDS -> LDS on a region that shrinks by its radius, and the last region (the tile itself) is colour
+// converted and written as packed RGB8. HBM traffic per pixel: 12 B * halo overhead in, 3 B out, versus one full
+// read + write of the 3 planes per stage in the unfused kernels.
+//
+// Computing a stage at a halo position that lies outside the frame from mirrored inputs gives exactly the mirrored
+// output of that stage (Gaborish and EPF are reflection-symmetric once sigma and the block-border flag are also taken
+// at the mirrored position), which is what the reference's row pipeline feeds the next stage.
+#ifndef JXL_HIP_FILTER_FUSED_H_
+#define JXL_HIP_FILTER_FUSED_H_
+
+#include "jxl_hip_kernels.h"
+
+namespace jxlhip {
+
+struct FusedFilterParams {
+  FilterParams f;          // geometry, sigma, Gaborish weights, channel scales, colour constants, rgb; f.in = IDCT output
+  float sm[3], bsm[3];     // per EPF stage (0, 1, 2): sigma multipliers for block-interior / block-border pixels
+  float* filtered;         // optional (may be NULL): filtered XYB planes for tests (same geometry as f.in)
+};
+
+constexpr int kFusedTW = 64, kFusedTH = 32;
+__host__ __device__ constexpr int FusedHalo(bool gab, int epf) {
+  return (gab ? 1 : 0) + (epf >= 3 ? 3 : 0) + (epf >= 1 ? 2 : 0) + (epf >= 2 ? 1 : 0);
+}
+__host__ __device__ constexpr size_t FusedLdsBytes(bool gab, int epf) {
+  return size_t(2) * 3 * (kFusedTW + 2 * FusedHalo(gab, epf)) * (kFusedTH + 2 * FusedHalo(gab, epf)) * sizeof(float);
+}
+
+// One EPF stage (STAGE 0: 12 neighbours within distance 2, plus-shaped 5-point SADs; STAGE 1: 4 neighbours, plus-shaped
+// SADs; STAGE 2: 4 neighbours, single-point SADs) for the pixel at LDS offset `o`; S = row stride, PL = plane stride.
+template <int STAGE, int S, int PL>
+__device__ __forceinline__ void EpfPixel(const FusedFilterParams& P, const float* src, int o, float inv_sigma_raw, bool border,
+                                         float* out0, float* out1, float* out2) {
+  const float c0 = src[o], c1 = src[PL + o], c2 = src[2 * PL + o];
+  if (inv_sigma_raw < -3.90524291751269967465540850526868f) {  // sigma too small: pixel unchanged (stage_epf.cc kMinSigma)
+    *out0 = c0;
+    *out1 = c1;
+    *out2 = c2;
+    return;
+  }
+  const float inv_sig = inv_sigma_raw * (border ? P.bsm[STAGE] : P.sm[STAGE]);
+  constexpr int NOFF = STAGE == 0 ? 12 : 4;
+  constexpr int off0[12][2] = {{-2, 0}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 1}, {0, 2}, {1, -1}, {1, 0}, {1, 1}, {2, 0}};
+  constexpr int off1[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+  constexpr int plus[5][2] = {{0, 0}, {-1, 0}, {0, -1}, {1, 0}, {0, 1}};
+  float w = 1.0f, a0 = c0, a1 = c1, a2 = c2;
+#pragma unroll
+  for (int i = 0; i < NOFF; i++) {
+    const int dy = STAGE == 0 ? off0[i][0] : off1[i][0], dx = STAGE == 0 ? off0[i][1] : off1[i][1];
+    const int n = o + dy * S + dx;
+    float sad = 0.0f;
+    if (STAGE == 2) {
+      sad = fabsf(src[n] - c0) * P.f.ch_scale[0];
+      sad = fabsf(src[PL + n] - c1) * P.f.ch_scale[1] + sad;
+      sad = fabsf(src[2 * PL + n] - c2) * P.f.ch_scale[2] + sad;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float* p = src + c * PL;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          const int d = plus[k][0] * S + plus[k][1];
+          s += fabsf(p[o + d] - p[n + d]);
+        }
+        sad = s * P.f.ch_scale[c] + sad;
+      }
+    }
+    float weight = sad * inv_sig + 1.0f;
+    weight = weight < 0.0f ? 0.0f : weight;
+    w += weight;
+    a0 = weight * src[n] + a0;
+    a1 = weight * src[PL + n] + a1;
+    a2 = weight * src[2 * PL + n] + a2;
+  }
+  const float inv_w = 1.0f / w;
+  *out0 = a0 * inv_w;
+  *out1 = a1 * inv_w;
+  *out2 = a2 * inv_w;
+}
+
+template <bool GAB, int EPF>
+__global__ __launch_bounds__(256) void k_filter_fused(FusedFilterParams P) {
+  constexpr int H = FusedHalo(GAB, EPF);
+  constexpr int TW = kFusedTW, TH = kFusedTH, S = TW + 2 * H, SH = TH + 2 * H, PL = S * SH;
+  extern __shared__ __align__(16) float lds_ff[];
+  float* src = lds_ff;
+  float* dst = lds_ff + 3 * PL;
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int xs = int(P.f.xs), ys = int(P.f.ys);
+  const size_t gplane = size_t(P.f.xp) * P.f.yp;
+  // ---- tile + halo from HBM, mirrored about the frame size
+  for (int i = tid; i < PL; i += 256) {
+    const int ly = i / S, lx = i - ly * S;
+    const size_t g = size_t(MirrorI(y0 + ly - H, ys)) * P.f.xp + MirrorI(x0 + lx - H, xs);
+    src[i] = P.f.in[g];
+    src[PL + i] = P.f.in[gplane + g];
+    src[2 * PL + i] = P.f.in[2 * gplane + g];
+  }
+  __syncthreads();
+  int h = H;  // halo still valid around the tile in `src`
+  if (GAB) {
+    h -= 1;
+    const int w = TW + 2 * h, n = w * (TH + 2 * h);
+    for (int i = tid; i < n; i += 256) {
+      const int ry = i / w, rx = i - ry * w;
+      const int o = (ry + H - h) * S + rx + H - h;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float* p = src + c * PL;
+        const float m = p[o];
+        const float s1 = (p[o - 1] + p[o + 1]) + (p[o - S] + p[o + S]);
+        const float s2 = (p[o - S - 1] + p[o - S + 1]) + (p[o + S - 1] + p[o + S + 1]);
+        dst[c * PL + o] = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
+      }
+    }
+    __syncthreads();
+    float* t = src;
+    src = dst;
+    dst = t;
+  }
+#define JXL_EPF_STAGE(STAGE_, RADIUS_)                                                                       \
+  {                                                                                                          \
+    h -= RADIUS_;                                                                                            \
+    const int w = TW + 2 * h, n = w * (TH + 2 * h);                                                          \
+    for (int i = tid; i < n; i += 256) {                                                                     \
+      const int ry = i / w, rx = i - ry * w;                                                                 \
+      const int o = (ry + H - h) * S + rx + H - h;                                                           \
+      const int mx = MirrorI(x0 + rx - h, xs), my = MirrorI(y0 + ry - h, ys);                                \
+      const float is = P.f.inv_sigma[size_t(my >> 3) * P.f.xb + (mx >> 3)];                                  \
+      const bool border = ((mx & 7) == 0) || ((mx & 7) == 7) || ((my & 7) == 0) || ((my & 7) == 7);          \
+      EpfPixel<STAGE_, S, PL>(P, src, o, is, border, &dst[o], &dst[PL + o], &dst[2 * PL + o]);               \
+    }                                                                                                        \
+    __syncthreads();                                                                                         \
+    float* t = src;                                                                                          \
+    src = dst;                                                                                               \
+    dst = t;                                                                                                 \
+  }
+  if (EPF >= 3) JXL_EPF_STAGE(0, 3)
+  if (EPF >= 1) JXL_EPF_STAGE(1, 2)
+  if (EPF >= 2) JXL_EPF_STAGE(2, 1)
+#undef JXL_EPF_STAGE
+  // ---- colour: XYB -> linear RGB -> sRGB -> dithered 8 bit, staged as bytes in LDS for wide stores
+  uint8_t* bytes = reinterpret_cast<uint8_t*>(dst);
+  for (int i = tid; i < TW * TH; i += 256) {
+    const int ry = i / TW, rx = i - ry * TW;
+    const int o = (ry + H) * S + rx + H;
+    const int x = x0 + rx, y = y0 + ry;
+    const float X = src[o], Y = src[PL + o], Bc = src[2 * PL + o];
+    if (P.filtered && x < xs && y < ys) {
+      const size_t g = size_t(y) * P.f.xp + x;
+      P.filtered[g] = X;
+      P.filtered[gplane + g] = Y;
+      P.filtered[2 * gplane + g] = Bc;
+    }
+    const float gr = (Y + X) - P.f.opsin_bias_cbrt[0], gg = (Y - X) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
+    const float mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
+    float r = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);
+    float g = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
+    float b = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
+    if (!P.f.linear_output) {
+      r = LinearToSrgb(r);
+      g = LinearToSrgb(g);
+      b = LinearToSrgb(b);
+    }
+    bytes[i * 3] = ToU8(r, x, y, 0);
+    bytes[i * 3 + 1] = ToU8(g, x, y, 1);
+    bytes[i * 3 + 2] = ToU8(b, x, y, 2);
+  }
+  __syncthreads();
+  const int cols = xs - x0 < TW ? xs - x0 : TW;  // valid pixels per tile row
+  const int rows = ys - y0 < TH ? ys - y0 : TH;
+  const int row_bytes = cols * 3;
+  if (((size_t(xs) * 3) & 3) == 0) {  // every tile row starts 4-byte aligned (x0 * 3 is a multiple of 192)
+    const int dw = row_bytes >> 2;
+    const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bytes);
+    for (int i = tid; i < rows * (TW * 3 / 4); i += 256) {
+      const int ry = i / (TW * 3 / 4), j = i - ry * (TW * 3 / 4);
+      if (j < dw) reinterpret_cast<uint32_t*>(P.f.rgb + (size_t(y0 + ry) * xs + x0) * 3)[j] = b32[i];
+    }
+    for (int i = tid; i < rows * 4; i += 256) {  // up to 3 tail bytes per row
+      const int ry = i >> 2, j = (dw << 2) + (i & 3);
+      if (j < row_bytes) P.f.rgb[(size_t(y0 + ry) * xs + x0) * 3 + j] = bytes[ry * TW * 3 + j];
+    }
+  } else {
+    for (int i = tid; i < rows * TW * 3; i += 256) {
+      const int ry = i / (TW * 3), j = i - ry * (TW * 3);
+      if (j < row_bytes) P.f.rgb[(size_t(y0 + ry) * xs + x0) * 3 + j] = bytes[i];
+    }
+  }
+}
+
+}  // namespace jxlhip
+#endif  // JXL_HIP_FILTER_FUSED_H_

@@ -27,6 +27,7 @@ def _compare(J, jxlo, data, check_rgb=True):
     o = jxlo.Decoded(data)
     c = J.HipContext()
     try:
+        c.set_option("keep_filtered", 1)
         c.upload(f)
         c.run_entropy()
         c.sync()
