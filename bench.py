@@ -112,9 +112,8 @@ def main():
         ent = sets[k % nsets]
         down = sets[(k + 1) % nsets]
         J.run_entropy_batch(ent)  # one launch: the per-section decoders of all frames of the set share the GPU
-        for c in down:
-            c.run_transform()
-            c.run_filter_color()
+        J.run_transform_batch(down)      # one launch per transform kernel for the whole set
+        J.run_filter_color_batch(down)   # one fused filter + colour launch
         for cs in sets:
             for c in cs:
                 c.sync()
@@ -141,17 +140,17 @@ def main():
     elapsed = time.perf_counter() - t0
     frames_local = args.batch * args.steps
     total_frames, max_elapsed = sharding.aggregate(frames_local, elapsed, dist)
-    # transform and filter+colour: isolated launches on one resident frame after the timed region (inside the region
-    # their events interleave with the concurrently running entropy kernel and with each other)
+    # transform and filter+colour: the same batched launches over one set, run alone after the timed region (inside the
+    # region their kernels share the GPU with the concurrently running entropy kernel); per frame = launch time / frames
     iso = [0.0, 0.0]
     c = sets[0][0]
-    for which, fn in ((1, c.run_transform), (2, c.run_filter_color)):
+    for which, fn in ((1, J.run_transform_batch), (2, J.run_filter_color_batch)):
         best = 1e9
-        for _ in range(4):
-            fn()
+        for _ in range(3):
+            fn(sets[0])
             c.sync()
             best = min(best, c.stage_ms(which))
-        iso[which - 1] = best
+        iso[which - 1] = best / args.batch
     stage_ms = [entropy_ms / args.steps / args.batch, iso[0], iso[1]]
 
     if rank == 0:

@@ -127,6 +127,11 @@ int jxlhip_run_all(JxlHipContext* ctx);
  * for it. Stage time is then available from ctxs[0] (which == 0). Falls back to n separate launches when the frames
  * cannot share a launch. */
 int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n);
+/* Transform stage / filter+colour stage of `n` resident frames with one launch per kernel for the whole set (on
+ * ctxs[0]'s stream; stage times from ctxs[0]). The frames must share the device and the coefficient storage type.
+ * jxlhip_run_transform(ctx) and jxlhip_run_filter_color(ctx) are the n = 1 case. */
+int jxlhip_run_transform_batch(JxlHipContext* const* ctxs, size_t n);
+int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n);
 
 /* Blocks until the context's stream is idle. */
 int jxlhip_sync(JxlHipContext* ctx);

@@ -45,7 +45,8 @@ def lib():
         L.jxlhip_ctx_destroy.argtypes = [vp]
         for name in ("jxlhip_run_entropy", "jxlhip_run_transform", "jxlhip_run_filter_color", "jxlhip_run_all", "jxlhip_sync"):
             getattr(L, name).argtypes = [vp]
-        L.jxlhip_run_entropy_batch.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
+        for name in ("jxlhip_run_entropy_batch", "jxlhip_run_transform_batch", "jxlhip_run_filter_color_batch"):
+            getattr(L, name).argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
         L.jxlhip_download_rgb8.argtypes = [vp, vp, ctypes.c_size_t]
         L.jxlhip_set_option.argtypes = [vp, cp, ctypes.c_int]
         L.jxlhip_rgb8_device_ptr.argtypes = [vp]
@@ -184,6 +185,16 @@ def run_entropy_batch(ctxs):
     """Entropy stage of several resident frames as one kernel launch (jxlhip_run_entropy_batch)."""
     arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
     _check(lib().jxlhip_run_entropy_batch(arr, len(ctxs)), "jxlhip_run_entropy_batch")
+
+
+def run_transform_batch(ctxs):
+    arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib().jxlhip_run_transform_batch(arr, len(ctxs)), "jxlhip_run_transform_batch")
+
+
+def run_filter_color_batch(ctxs):
+    arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib().jxlhip_run_filter_color_batch(arr, len(ctxs)), "jxlhip_run_filter_color_batch")
 
 
 def decode_rgb8(data, device=0, threads=0):

@@ -102,6 +102,17 @@ struct JxlHipContext {
   // applied (hipStreamWaitEvent on this context's stream) by the next call that touches those results. Enqueuing the
   // wait only then keeps barrier packets of a long entropy launch out of the hardware queues other streams share.
   hipEvent_t pending_wait = nullptr;
+  // jxlhip_run_transform_batch / jxlhip_run_filter_color_batch: description of the frame set launched from this context
+  struct FilterGroup {
+    int key;  // gaborish * 4 + epf iterations
+    uint32_t first, count, tiles_x, tiles_y;
+  };
+  Buf tb_params, tb_desc, fb_params;
+  std::vector<const JxlHipContext*> db_ctxs;
+  std::vector<uint64_t> db_gens;
+  uint32_t desc_begin[27] = {}, desc_count[27] = {};
+  std::vector<FilterGroup> fgroups;
+  hipEvent_t down_done = nullptr;
   uint64_t generation = 0;            // bumped by every jxlhip_frame_upload
   std::vector<PassBufs> pass_bufs;
   uint32_t list_begin[27] = {}, list_count[27] = {};
@@ -162,12 +173,18 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
     }
   }
   // static tables
-  std::vector<float> bt(87381);
+  constexpr size_t kBasisFloats = 87381;
+  std::vector<float> bt(2 * kBasisFloats + 4);  // [k][n] matrices, then (16-byte aligned) the transposed [n][k] ones
   for (int l = 0; l <= 8; l++) {
     const int N = 1 << l;
     float* dst = bt.data() + (size_t(N) * N - 1) / 3;
+    float* dst_t = dst + kBasisFloats + 3;
     for (int k = 0; k < N; k++)
-      for (int n = 0; n < N; n++) dst[size_t(k) * N + n] = float((k ? std::sqrt(2.0) : 1.0) * std::cos((n + 0.5) * k * M_PI / N));
+      for (int n = 0; n < N; n++) {
+        const float v = float((k ? std::sqrt(2.0) : 1.0) * std::cos((n + 0.5) * k * M_PI / N));
+        dst[size_t(k) * N + n] = v;
+        dst_t[size_t(n) * N + k] = v;
+      }
   }
   int r = c->basis.Ensure(bt.size() * sizeof(float));
   if (r) {
@@ -198,7 +215,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->kend, &c->block_recs};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->kend, &c->block_recs, &c->tb_params, &c->tb_desc, &c->fb_params};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -209,6 +226,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->batch_done) (void)hipEventDestroy(c->batch_done);
+  if (c->down_done) (void)hipEventDestroy(c->down_done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -443,6 +461,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   tp.ytox = c->ytox.as<int8_t>();
   tp.ytob = c->ytob.as<int8_t>();
   tp.basis_t = c->basis.as<float>();
+  tp.basis_n = c->basis.as<float>() + 87381 + 3;
   tp.inv_global_scale = d->inv_global_scale;
   tp.x_dm = d->x_dm;
   tp.b_dm = d->b_dm;
@@ -453,6 +472,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   tp.xb = c->xb; tp.yb = c->yb; tp.xg = c->xg; tp.xp = c->xp; tp.yp = c->yp;
   tp.out = c->plane[0].as<float>();
   tp.scratch = c->scratch.as<float>();
+  tp.tlist = c->tlist.as<uint32_t>();
+  memcpy(tp.list_begin, c->list_begin, sizeof(tp.list_begin));
+  memcpy(tp.list_count, c->list_count, sizeof(tp.list_count));
   tp.scan_order = c->scan_order ? 1 : 0;
   tp.kend = c->kend.as<uint32_t>();
   tp.orders = c->pass_bufs[0].orders.as<uint16_t>();
@@ -537,48 +559,178 @@ static int RunEntropySingle(JxlHipContext* c) {
   return 0;
 }
 
+// ---- transform + filter launches, batched over the frames of a set ---------------------------------------------------
+// Varblocks a workgroup of the strategy's kernel handles.
+static uint32_t BlocksPerWG(int s) {
+  static const uint8_t cx[27] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
+  if (s == 0 || (s >= 4 && s <= 11)) return 256 / (cx[s] * 8);  // k_idct_cols: 8 * covered_x threads per varblock
+  if (s >= 18 && s <= 20) return 1;                               // k_dct 64-class
+  return 4;                                                       // k_special
+}
+
 template <typename CoefT, int CX, int CY>
-static void LaunchDct(JxlHipContext* c, int s) {
+static int LaunchIdctCols(JxlHipContext* c0, int s) {
+  constexpr int C = CX * 8, SIZE = CX * CY * 64, GROUPS = 256 / C;
+  constexpr size_t lds = size_t(GROUPS) * (2 * SIZE + 4) * sizeof(float);
+  auto k = jxlhip::k_idct_cols<CoefT, CX, CY>;
+  if (lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+  hipLaunchKernelGGL(k, dim3(c0->desc_count[s]), dim3(256), lds, c0->stream, c0->tb_params.as<jxlhip::TransformParams>(),
+                     c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));
+  return 0;
+}
+
+template <typename CoefT, int CX, int CY>
+static int LaunchDct(JxlHipContext* c0, int s) {
   constexpr int SIZE = CX * CY * 64;
-  constexpr int TPB = SIZE >= 256 ? 256 : SIZE;
-  constexpr int BPW = 256 / TPB;
-  const uint32_t n = c->list_count[s];
-  const dim3 grid((n + BPW - 1) / BPW), block(256);
-  const size_t lds = size_t(BPW) * 3 * SIZE * sizeof(float);
-  hipLaunchKernelGGL((jxlhip::k_dct<CoefT, CX, CY>), grid, block, lds, c->stream, c->tp, c->tlist.as<uint32_t>() + c->list_begin[s], n,
-                     uint32_t(s));
+  constexpr size_t lds = size_t(3) * SIZE * sizeof(float);
+  auto k = jxlhip::k_dct<CoefT, CX, CY>;
+  if (lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+  hipLaunchKernelGGL(k, dim3(c0->desc_count[s]), dim3(256), lds, c0->stream, c0->tb_params.as<jxlhip::TransformParams>(),
+                     c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));
+  return 0;
 }
 
 template <typename CoefT>
-static int LaunchTransforms(JxlHipContext* c) {
-  for (int s = 0; s < 27; s++) {
-    const uint32_t n = c->list_count[s];
-    if (!n) continue;
-    const uint32_t* list = c->tlist.as<uint32_t>() + c->list_begin[s];
+static int LaunchTransforms(JxlHipContext* c0) {
+  for (int s = 0; s < 21; s++) {
+    if (!c0->desc_count[s]) continue;
+    int e = 0;
     switch (s) {
-      case 0: LaunchDct<CoefT, 1, 1>(c, s); break;
-      case 4: LaunchDct<CoefT, 2, 2>(c, s); break;
-      case 5: LaunchDct<CoefT, 4, 4>(c, s); break;
-      case 6: LaunchDct<CoefT, 1, 2>(c, s); break;
-      case 7: LaunchDct<CoefT, 2, 1>(c, s); break;
-      case 8: LaunchDct<CoefT, 1, 4>(c, s); break;
-      case 9: LaunchDct<CoefT, 4, 1>(c, s); break;
-      case 10: LaunchDct<CoefT, 2, 4>(c, s); break;
-      case 11: LaunchDct<CoefT, 4, 2>(c, s); break;
-      case 18: LaunchDct<CoefT, 8, 8>(c, s); break;
-      case 19: LaunchDct<CoefT, 4, 8>(c, s); break;
-      case 20: LaunchDct<CoefT, 8, 4>(c, s); break;
-      case 21: case 22: case 23: case 24: case 25: case 26: {
-        for (uint32_t i = 0; i < n; i += 32) {
-          const uint32_t m = n - i < 32 ? n - i : 32;
-          hipLaunchKernelGGL((jxlhip::k_dct_big<CoefT>), dim3(m * 3), dim3(256), 0, c->stream, c->tp, list + i, m, uint32_t(s));
-        }
-        break;
-      }
+      case 0: e = LaunchIdctCols<CoefT, 1, 1>(c0, s); break;
+      case 4: e = LaunchIdctCols<CoefT, 2, 2>(c0, s); break;
+      case 5: e = LaunchIdctCols<CoefT, 4, 4>(c0, s); break;
+      case 6: e = LaunchIdctCols<CoefT, 1, 2>(c0, s); break;
+      case 7: e = LaunchIdctCols<CoefT, 2, 1>(c0, s); break;
+      case 8: e = LaunchIdctCols<CoefT, 1, 4>(c0, s); break;
+      case 9: e = LaunchIdctCols<CoefT, 4, 1>(c0, s); break;
+      case 10: e = LaunchIdctCols<CoefT, 2, 4>(c0, s); break;
+      case 11: e = LaunchIdctCols<CoefT, 4, 2>(c0, s); break;
+      case 18: e = LaunchDct<CoefT, 8, 8>(c0, s); break;
+      case 19: e = LaunchDct<CoefT, 4, 8>(c0, s); break;
+      case 20: e = LaunchDct<CoefT, 8, 4>(c0, s); break;
       default:
-        hipLaunchKernelGGL((jxlhip::k_special<CoefT>), dim3((n + 3) / 4), dim3(256), 0, c->stream, c->tp, list, n, uint32_t(s));
+        hipLaunchKernelGGL((jxlhip::k_special<CoefT>), dim3(c0->desc_count[s]), dim3(256), 0, c0->stream,
+                           c0->tb_params.as<jxlhip::TransformParams>(), c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));
     }
+    if (e) return e;
     HIP_TRY(hipGetLastError());
+  }
+  // 128/256-class transforms go through per-frame global scratch: one frame at a time (rare)
+  for (const JxlHipContext* c : c0->db_ctxs)
+    for (int s = 21; s < 27; s++) {
+      const uint32_t n = c->list_count[s];
+      if (!n) continue;
+      const uint32_t* list = c->tlist.as<uint32_t>() + c->list_begin[s];
+      for (uint32_t i = 0; i < n; i += 32) {
+        const uint32_t m = n - i < 32 ? n - i : 32;
+        hipLaunchKernelGGL((jxlhip::k_dct_big<CoefT>), dim3(m * 3), dim3(256), 0, c0->stream, c->tp, list + i, m, uint32_t(s));
+      }
+      HIP_TRY(hipGetLastError());
+    }
+  return 0;
+}
+
+static void FillFusedParams(const JxlHipContext* c, jxlhip::FusedFilterParams* p) {
+  p->f = c->fp;
+  p->f.in = c->plane[0].as<float>();
+  p->f.out = nullptr;
+  for (int stage = 0; stage < 3; stage++) {
+    const float scale = stage == 0 ? c->epf_pass0 : stage == 2 ? c->epf_pass2 : 1.0f;
+    p->sm[stage] = stage == 1 ? 1.65f : float(scale * 1.65);
+    p->bsm[stage] = p->sm[stage] * c->epf_border;
+  }
+  p->filtered = c->keep_filtered ? c->plane[1].as<float>() : nullptr;
+}
+static int FilterKey(const JxlHipContext* c) {
+  const int epf = c->epf_iters < 0 ? 0 : (c->epf_iters > 3 ? 3 : c->epf_iters);
+  return (c->gab ? 4 : 0) + epf;
+}
+
+// Builds (or re-uses) the description of a set of frames for the batched transform and filter launches.
+static int PrepareDownstream(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n) {
+  bool same = c0->db_ctxs.size() == n;
+  for (size_t i = 0; same && i < n; i++) same = c0->db_ctxs[i] == ctxs[i] && c0->db_gens[i] == ctxs[i]->generation;
+  if (same) return 0;
+  std::vector<jxlhip::TransformParams> tparams(n);
+  for (size_t i = 0; i < n; i++) tparams[i] = ctxs[i]->tp;
+  std::vector<uint2> desc;
+  for (int s = 0; s < 21; s++) {
+    c0->desc_begin[s] = uint32_t(desc.size());
+    const uint32_t bpw = BlocksPerWG(s);
+    for (size_t i = 0; i < n; i++)
+      for (uint32_t j = 0; j < ctxs[i]->list_count[s]; j += bpw) desc.push_back(make_uint2(uint32_t(i), j));
+    c0->desc_count[s] = uint32_t(desc.size()) - c0->desc_begin[s];
+  }
+  // filter launches: frames grouped by (gaborish, epf iterations), one grid z slice per frame
+  std::vector<size_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return FilterKey(ctxs[a]) < FilterKey(ctxs[b]); });
+  std::vector<jxlhip::FusedFilterParams> fparams(n);
+  c0->fgroups.clear();
+  for (size_t j = 0; j < n; j++) {
+    const JxlHipContext* c = ctxs[order[j]];
+    FillFusedParams(c, &fparams[j]);
+    const int key = FilterKey(c);
+    const uint32_t tx = (c->xs + jxlhip::kFusedTW - 1) / jxlhip::kFusedTW, ty = (c->ys + jxlhip::kFusedTH - 1) / jxlhip::kFusedTH;
+    if (c0->fgroups.empty() || c0->fgroups.back().key != key) c0->fgroups.push_back({key, uint32_t(j), 0, 0, 0});
+    JxlHipContext::FilterGroup& g = c0->fgroups.back();
+    g.count++;
+    g.tiles_x = tx > g.tiles_x ? tx : g.tiles_x;
+    g.tiles_y = ty > g.tiles_y ? ty : g.tiles_y;
+  }
+  int r;
+  if ((r = c0->tb_params.Ensure(n * sizeof(tparams[0])))) return r;
+  if ((r = c0->tb_desc.Ensure((desc.size() + 1) * sizeof(uint2)))) return r;
+  if ((r = c0->fb_params.Ensure(n * sizeof(fparams[0])))) return r;
+  HIP_TRY(hipMemcpy(c0->tb_params.p, tparams.data(), n * sizeof(tparams[0]), hipMemcpyHostToDevice));
+  if (!desc.empty()) HIP_TRY(hipMemcpy(c0->tb_desc.p, desc.data(), desc.size() * sizeof(uint2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c0->fb_params.p, fparams.data(), n * sizeof(fparams[0]), hipMemcpyHostToDevice));
+  c0->db_ctxs.assign(ctxs, ctxs + n);
+  c0->db_gens.resize(n);
+  for (size_t i = 0; i < n; i++) c0->db_gens[i] = ctxs[i]->generation;
+  return 0;
+}
+
+template <bool GAB, int EPF>
+static int LaunchFused(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
+  auto k = jxlhip::k_filter_fused<GAB, EPF>;
+  constexpr size_t lds = jxlhip::FusedLdsBytes(GAB, EPF);
+  if (lds > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+  for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
+    const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
+    hipLaunchKernelGGL(k, dim3(g.tiles_x, g.tiles_y, zn), dim3(256), lds, c0->stream,
+                       c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Validates a set for a batched downstream call and orders the launch stream after everything its frames wait for.
+static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
+  if (!ctxs || !n) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JxlHipContext* c0 = ctxs[0];
+  for (size_t i = 0; i < n; i++) {
+    if (!ctxs[i]) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (!ctxs[i]->have_frame) return JXLHIP_ERR_NO_FRAME;
+    if (ctxs[i]->device != c0->device || ctxs[i]->coef_bits != c0->coef_bits) return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(c0->device));
+  for (size_t i = 0; i < n; i++)
+    if (ctxs[i]->pending_wait) {
+      HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->pending_wait, 0));
+      ctxs[i]->pending_wait = nullptr;
+    }
+  return PrepareDownstream(c0, ctxs, n);
+}
+static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
+  JxlHipContext* c0 = ctxs[0];
+  if (n > 1) {
+    if (!c0->down_done) HIP_TRY(hipEventCreateWithFlags(&c0->down_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c0->down_done, c0->stream));
+    for (size_t i = 1; i < n; i++) ctxs[i]->pending_wait = c0->down_done;
   }
   return 0;
 }
@@ -758,69 +910,48 @@ extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
   return c->scan_order ? jxlhip_run_entropy_batch(&c, 1) : RunEntropySingle(c);
 }
 
-template <bool GAB, int EPF>
-static int LaunchFused(JxlHipContext* c, const jxlhip::FusedFilterParams& p) {
-  auto k = jxlhip::k_filter_fused<GAB, EPF>;
-  constexpr size_t lds = jxlhip::FusedLdsBytes(GAB, EPF);
-  if (lds > 48 * 1024)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-  const dim3 grid((c->xs + jxlhip::kFusedTW - 1) / jxlhip::kFusedTW, (c->ys + jxlhip::kFusedTH - 1) / jxlhip::kFusedTH);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, c->stream, p);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 extern "C" {
 
-int jxlhip_run_transform(JxlHipContext* c) {
-  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  HIP_TRY(hipSetDevice(c->device));
-  {
-    int pw = ApplyPendingWait(c);
-    if (pw) return pw;
-  }
-  HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-  int r = c->coef_bits == 16 ? LaunchTransforms<int16_t>(c) : LaunchTransforms<int32_t>(c);
+int jxlhip_run_transform_batch(JxlHipContext* const* ctxs, size_t n) {
+  int r = BeginDownstreamBatch(ctxs, n);
   if (r) return r;
-  HIP_TRY(hipEventRecord(c->ev[3], c->stream));
-  c->ev_valid[1] = true;
-  return 0;
+  JxlHipContext* c0 = ctxs[0];
+  HIP_TRY(hipEventRecord(c0->ev[2], c0->stream));
+  r = c0->coef_bits == 16 ? LaunchTransforms<int16_t>(c0) : LaunchTransforms<int32_t>(c0);
+  if (r) return r;
+  HIP_TRY(hipEventRecord(c0->ev[3], c0->stream));
+  c0->ev_valid[1] = true;
+  for (size_t i = 1; i < n; i++) ctxs[i]->ev_valid[1] = false;
+  return EndDownstreamBatch(ctxs, n);
 }
 
-int jxlhip_run_filter_color(JxlHipContext* c) {
-  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipEventRecord(c->ev[4], c->stream));
-  jxlhip::FusedFilterParams p;
-  p.f = c->fp;
-  p.f.in = c->plane[0].as<float>();
-  p.f.out = nullptr;
-  for (int stage = 0; stage < 3; stage++) {
-    const float scale = stage == 0 ? c->epf_pass0 : stage == 2 ? c->epf_pass2 : 1.0f;
-    p.sm[stage] = stage == 1 ? 1.65f : float(scale * 1.65);
-    p.bsm[stage] = p.sm[stage] * c->epf_border;
-  }
-  p.filtered = c->keep_filtered ? c->plane[1].as<float>() : nullptr;
-  c->final_plane = 1;
-  const int epf = c->epf_iters < 0 ? 0 : (c->epf_iters > 3 ? 3 : c->epf_iters);
-  int r = 0;
-  switch ((c->gab ? 4 : 0) + epf) {
-    case 0: r = LaunchFused<false, 0>(c, p); break;
-    case 1: r = LaunchFused<false, 1>(c, p); break;
-    case 2: r = LaunchFused<false, 2>(c, p); break;
-    case 3: r = LaunchFused<false, 3>(c, p); break;
-    case 4: r = LaunchFused<true, 0>(c, p); break;
-    case 5: r = LaunchFused<true, 1>(c, p); break;
-    case 6: r = LaunchFused<true, 2>(c, p); break;
-    default: r = LaunchFused<true, 3>(c, p); break;
-  }
+int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
+  int r = BeginDownstreamBatch(ctxs, n);
   if (r) return r;
-  HIP_TRY(hipEventRecord(c->ev[5], c->stream));
-  c->ev_valid[2] = true;
-  return 0;
+  JxlHipContext* c0 = ctxs[0];
+  HIP_TRY(hipEventRecord(c0->ev[4], c0->stream));
+  for (const JxlHipContext::FilterGroup& g : c0->fgroups) {
+    switch (g.key) {
+      case 0: r = LaunchFused<false, 0>(c0, g); break;
+      case 1: r = LaunchFused<false, 1>(c0, g); break;
+      case 2: r = LaunchFused<false, 2>(c0, g); break;
+      case 3: r = LaunchFused<false, 3>(c0, g); break;
+      case 4: r = LaunchFused<true, 0>(c0, g); break;
+      case 5: r = LaunchFused<true, 1>(c0, g); break;
+      case 6: r = LaunchFused<true, 2>(c0, g); break;
+      default: r = LaunchFused<true, 3>(c0, g); break;
+    }
+    if (r) return r;
+  }
+  HIP_TRY(hipEventRecord(c0->ev[5], c0->stream));
+  c0->ev_valid[2] = true;
+  for (size_t i = 0; i < n; i++) ctxs[i]->final_plane = 1;
+  for (size_t i = 1; i < n; i++) ctxs[i]->ev_valid[2] = false;
+  return EndDownstreamBatch(ctxs, n);
 }
+
+int jxlhip_run_transform(JxlHipContext* c) { return jxlhip_run_transform_batch(&c, 1); }
+int jxlhip_run_filter_color(JxlHipContext* c) { return jxlhip_run_filter_color_batch(&c, 1); }
 
 int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
   if (!c || !name) return JXLHIP_ERR_INVALID_ARGUMENT;

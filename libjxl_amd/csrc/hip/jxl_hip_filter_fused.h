@@ -88,7 +88,8 @@ __device__ __forceinline__ void EpfPixel(const FusedFilterParams& P, const float
 }
 
 template <bool GAB, int EPF>
-__global__ __launch_bounds__(256) void k_filter_fused(FusedFilterParams P) {
+__global__ __launch_bounds__(256) void k_filter_fused(const FusedFilterParams* params) {
+  const FusedFilterParams& P = params[blockIdx.z];  // one frame per grid z slice
   constexpr int H = FusedHalo(GAB, EPF);
   constexpr int TW = kFusedTW, TH = kFusedTH, S = TW + 2 * H, SH = TH + 2 * H, PL = S * SH;
   extern __shared__ __align__(16) float lds_ff[];
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void k_filter_fused(FusedFilterParams P) {
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int xs = int(P.f.xs), ys = int(P.f.ys);
+  if (x0 >= xs || y0 >= ys) return;  // the grid covers the largest frame of the launch
   const size_t gplane = size_t(P.f.xp) * P.f.yp;
   // ---- tile + halo from HBM, mirrored about the frame size
   for (int i = tid; i < PL; i += 256) {

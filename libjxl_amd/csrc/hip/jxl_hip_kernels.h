@@ -601,6 +601,7 @@ struct TransformParams {
   const int8_t* ytox;
   const int8_t* ytob;
   const float* basis_t;  // BT_N[k * N + n], N = 1..256, offset (N*N-1)/3
+  const float* basis_n;  // the same matrices transposed: [n * N + k]
   float inv_global_scale, x_dm, b_dm, color_scale, base_x, base_b;
   float biases[4];
   uint32_t xb, yb, xg, xp, yp;
@@ -613,7 +614,18 @@ struct TransformParams {
   const uint32_t* kend;    // [block * 3 + channel]
   const uint16_t* orders;  // pass 0 coefficient orders
   uint32_t order_offset[39];
+  // transform work lists: block indices bucketed by strategy (tlist[list_begin[s] .. + list_count[s]))
+  const uint32_t* tlist;
+  uint32_t list_begin[27], list_count[27];
 };
+
+// Batched launches: one workgroup descriptor per workgroup = {frame index into the parameter array, index of the
+// workgroup's first varblock in that frame's list of the launched strategy}.
+#define JXL_TRANSFORM_PREAMBLE()                                   \
+  const uint2 wgd = desc[blockIdx.x];                              \
+  const TransformParams& P = params[wgd.x];                        \
+  const uint32_t n = P.list_count[strategy];                       \
+  const uint32_t* list = P.tlist + P.list_begin[strategy];
 
 __device__ __forceinline__ float QuantBias(int c, int q, const float* b) {
   if (q == 0) return 0.0f;
@@ -671,7 +683,8 @@ __device__ __forceinline__ float LlfFromDc(const TransformParams& P, const float
 // DCT-family strategies up to 64x64: per channel, dequantised coefficients are staged in LDS and the separable
 // inverse transform is evaluated as two matrix passes (LDS-resident tile, coalesced plane writes).
 template <typename CoefT, int CX, int CY>
-__global__ __launch_bounds__(256) void k_dct(TransformParams P, const uint32_t* list, uint32_t n, uint32_t strategy) {
+__global__ __launch_bounds__(256) void k_dct(const TransformParams* params, const uint2* desc, uint32_t strategy) {
+  JXL_TRANSFORM_PREAMBLE();
   constexpr int R = CY * 8, C = CX * 8, SIZE = R * C;
   constexpr int TPB = SIZE >= 256 ? 256 : SIZE;
   constexpr int BPW = 256 / TPB;
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(256) void k_dct(TransformParams P, const uint32_t* 
   float* l_y = lds_f + sub * 3 * SIZE;  // dequantised Y stays resident for the chroma-from-luma of X and B
   float* l_xb = l_y + SIZE;
   float* l_tmp = l_xb + SIZE;
-  const uint32_t li = blockIdx.x * BPW + sub;
+  const uint32_t li = wgd.y + sub;
   const bool active = li < n;
   JxlHipVarBlock vb;
   const CoefT* gq = nullptr;
@@ -746,6 +759,123 @@ __global__ __launch_bounds__(256) void k_dct(TransformParams P, const uint32_t* 
 #pragma unroll 8
         for (int ky = 0; ky < R; ky++) s += l_tmp[ky * C + x] * btr[ky * R + y];
         out[size_t(y) * P.xp + x] = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// DCT-family strategies up to 32x32, column-thread form. C = CX * 8 threads own one varblock, thread x owns column x:
+//   * dequantised coefficients are staged in LDS as [ky][kx] (zero / chroma-from-luma fill, then only the entropy
+//     stage's valid scan-order prefix is scattered through the coefficient order);
+//   * row pass:    tmp[ky] = sum_kx coef[ky][kx] * B_C[kx][x]   -- the thread keeps its basis column B_C[:][x] in
+//     registers and reads coefficient rows as LDS broadcasts (one ds_read_b128 per 4 FMAs, same address for the group);
+//   * column pass: out[y][x] = sum_ky tmp[ky] * B_R[ky][y]      -- tmp[] never leaves registers and the basis is
+//     wave-uniform, so it comes from the scalar cache (SGPR operands), no LDS and no second barrier;
+//   * row y of the block is written by the C threads of the group as one contiguous segment.
+typedef const float __attribute__((address_space(4)))* CF32;
+
+template <typename CoefT, int CX, int CY>
+__global__ __launch_bounds__(256) void k_idct_cols(const TransformParams* params, const uint2* desc, uint32_t strategy) {
+  JXL_TRANSFORM_PREAMBLE();
+  constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, GSTRIDE = 2 * SIZE + 4;
+  extern __shared__ __align__(16) float lds_f[];
+  const int grp = threadIdx.x / C, x = threadIdx.x % C;
+  float* l_y = lds_f + grp * GSTRIDE;  // dequantised Y stays resident for the chroma-from-luma of X and B
+  float* l_xb = l_y + SIZE;
+  const uint32_t li = wgd.y + grp;
+  const bool active = li < n;
+  JxlHipVarBlock vb;
+  const CoefT* gq = nullptr;
+  const float* m = nullptr;
+  uint32_t msize = 0, bidx = 0;
+  float sc = 0, x_cc = 0, b_cc = 0;
+  if (active) {
+    bidx = list[li];
+    vb = P.blocks[bidx];
+    const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
+    gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
+    const uint32_t kind = c_strategy_qtable[strategy];
+    m = P.dequant + P.dq_offset[kind];
+    msize = P.dq_size[kind];
+    sc = P.inv_global_scale / float(vb.qf);
+    const uint32_t tiles_x = (P.xb + 7) / 8;
+    const uint32_t tile = (vb.by / 8) * tiles_x + vb.bx / 8;
+    x_cc = P.base_x + float(P.ytox[tile]) * P.color_scale;
+    b_cc = P.base_b + float(P.ytob[tile]) * P.color_scale;
+  }
+  float breg[C];
+  {
+    const float* bt = P.basis_t + BasisOffset(C);
+#pragma unroll
+    for (int kx = 0; kx < C; kx++) breg[kx] = bt[kx * C + x];
+  }
+  const CF32 bn = (CF32)(uintptr_t)(P.basis_n + BasisOffset(R));  // [y * R + ky]
+  const uint32_t ord = c_strategy_order[strategy];
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    float* l = c == 1 ? l_y : l_xb;
+    if (active) {
+      if (c == 1) {
+        for (int i = x * 4; i < SIZE; i += C * 4) *reinterpret_cast<float4*>(l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const float cc = c == 0 ? x_cc : b_cc;
+        for (int i = x * 4; i < SIZE; i += C * 4) {
+          const float4 y4 = *reinterpret_cast<const float4*>(l_y + i);
+          *reinterpret_cast<float4*>(l + i) = make_float4(cc * y4.x, cc * y4.y, cc * y4.z, cc * y4.w);
+        }
+      }
+    }
+    __syncthreads();
+    if (active) {
+      const float mul = c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm);
+      const CoefT* gqc = gq + size_t(c) * 65536;
+      const float* mc = m + size_t(c) * msize;
+      uint32_t k0 = x, k1 = SIZE;
+      const uint16_t* order = nullptr;
+      if (P.scan_order) {
+        order = P.orders + P.order_offset[ord * 3 + c];
+        const uint32_t ke = P.kend[bidx * 3 + c];
+        k0 = CX * CY + x;
+        k1 = ke < uint32_t(SIZE) ? ke : uint32_t(SIZE);
+      }
+      for (uint32_t k = k0; k < k1; k += C) {
+        const int q = int(gqc[k]);
+        if (q) {
+          const uint32_t pos = order ? order[k] : k;
+          const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
+          l[idx] += QuantBias(c, q, P.biases) * (mc[pos] * mul);
+        }
+      }
+      if (x < CX * CY) {  // lowest frequencies from the DC image
+        const float* dc = P.dc + size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
+        const int ky = x / CX, kx = x % CX;
+        l[ky * C + kx] = LlfFromDc<CX, CY>(P, dc, ky, kx);
+      }
+    }
+    __syncthreads();
+    if (active) {
+      float tmp[R];
+#pragma unroll
+      for (int ky = 0; ky < R; ky++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k4 = 0; k4 < C; k4 += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(l + ky * C + k4);
+          acc += v.x * breg[k4];
+          acc += v.y * breg[k4 + 1];
+          acc += v.z * breg[k4 + 2];
+          acc += v.w * breg[k4 + 3];
+        }
+        tmp[ky] = acc;
+      }
+      float* out = P.out + size_t(c) * P.xp * P.yp + size_t(vb.by) * 8 * P.xp + size_t(vb.bx) * 8 + x;
+#pragma unroll
+      for (int y = 0; y < R; y++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < R; ky++) acc += tmp[ky] * bn[y * R + ky];
+        out[size_t(y) * P.xp] = acc;
       }
     }
     __syncthreads();
@@ -833,14 +963,15 @@ __device__ __forceinline__ float B8(const float* bt8, int n, int k) { return bt8
 
 // 8x8-coverage special transforms; 64 threads per varblock (one per pixel), 4 varblocks per workgroup.
 template <typename CoefT>
-__global__ __launch_bounds__(256) void k_special(TransformParams P, const uint32_t* list, uint32_t n, uint32_t strategy) {
+__global__ __launch_bounds__(256) void k_special(const TransformParams* params, const uint2* desc, uint32_t strategy) {
+  JXL_TRANSFORM_PREAMBLE();
   __shared__ float l_all[4][4][64];
   const int sub = threadIdx.x >> 6, t = threadIdx.x & 63;
   float* l_y = l_all[sub][0];  // dequantised Y stays resident for the chroma-from-luma of X and B
   float* l_xb = l_all[sub][1];
   float* buf = l_all[sub][2];
   float* buf2 = l_all[sub][3];
-  const uint32_t li = blockIdx.x * 4 + sub;
+  const uint32_t li = wgd.y + sub;
   const bool active = li < n;
   JxlHipVarBlock vb;
   const CoefT* gq = nullptr;

@@ -161,9 +161,13 @@ def test_batched_entropy_launch(built):
             for c, f in zip(ctxs, frames):
                 c.upload(f)
             J.run_entropy_batch(ctxs)
-            for c in ctxs:
-                c.run_transform()
-                c.run_filter_color()
+            if rounds == 0:  # per-frame downstream launches
+                for c in ctxs:
+                    c.run_transform()
+                    c.run_filter_color()
+            else:            # one launch per kernel for the whole set (mixed geometry and filter settings)
+                J.run_transform_batch(ctxs)
+                J.run_filter_color_batch(ctxs)
             for c, s in zip(ctxs, streams):
                 c.sync()
                 r, flags = c.errors()
