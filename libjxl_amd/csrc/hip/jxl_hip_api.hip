@@ -701,7 +701,7 @@ static int LaunchFused(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
   for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
     const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
-    hipLaunchKernelGGL(k, dim3(g.tiles_x, g.tiles_y, zn), dim3(256), lds, c0->stream,
+    hipLaunchKernelGGL(k, dim3(g.tiles_x, g.tiles_y, zn), dim3(jxlhip::kFusedThreads), lds, c0->stream,
                        c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
   }
   HIP_TRY(hipGetLastError());
@@ -800,13 +800,15 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   if (kernel == 2) {
     size_t total_sections = 0;
     for (size_t i = 0; i < n; i++) total_sections += ctxs[i]->ng;
-    // populated lanes per wave: fill every SIMD (256 CUs x 4) with a wave before packing lanes more densely
+    // populated lanes per wave: spread the sections over ~640 waves before packing lanes more densely (measured optimum
+    // on MI355X for 64..256 4K frames: the launch lasts as long as its longest section, and a wave costs the same
+    // issue slots however many of its lanes are populated)
     uint32_t lanes_per_wave = 1;
-    const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 1024));
+    const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 640));
     while (lanes_per_wave < 64 && (total_sections + lanes_per_wave - 1) / lanes_per_wave > target_waves) lanes_per_wave *= 2;
     const int forced = EnvInt("JXLHIP_LANES", 0);
     if (forced >= 1 && forced <= 64 && (forced & (forced - 1)) == 0) lanes_per_wave = uint32_t(forced);
-    c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 2));
+    c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 1));
     c0->batch_lanes_per_wave = lanes_per_wave;
     const uint32_t per_wg = lanes_per_wave * kLanesWPG;
     std::vector<uint32_t> order;

@@ -27,11 +27,14 @@ struct FusedFilterParams {
 };
 
 constexpr int kFusedTW = 64, kFusedTH = 32;
+constexpr int kFusedThreads = 512;  // 8 waves per tile: two resident tiles give every SIMD four waves to hide LDS latency
+constexpr int kFusedSigW = kFusedTW / 8 + 3, kFusedSigH = kFusedTH / 8 + 3;  // sigma blocks around a tile
 __host__ __device__ constexpr int FusedHalo(bool gab, int epf) {
   return (gab ? 1 : 0) + (epf >= 3 ? 3 : 0) + (epf >= 1 ? 2 : 0) + (epf >= 2 ? 1 : 0);
 }
 __host__ __device__ constexpr size_t FusedLdsBytes(bool gab, int epf) {
-  return size_t(2) * 3 * (kFusedTW + 2 * FusedHalo(gab, epf)) * (kFusedTH + 2 * FusedHalo(gab, epf)) * sizeof(float);
+  return (size_t(2) * 3 * (kFusedTW + 2 * FusedHalo(gab, epf)) * (kFusedTH + 2 * FusedHalo(gab, epf)) + kFusedSigW * kFusedSigH) *
+         sizeof(float);
 }
 
 // One EPF stage (STAGE 0: 12 neighbours within distance 2, plus-shaped 5-point SADs; STAGE 1: 4 neighbours, plus-shaped
@@ -87,35 +90,157 @@ __device__ __forceinline__ void EpfPixel(const FusedFilterParams& P, const float
   *out2 = a2 * inv_w;
 }
 
+// EPF stage 1 over the region that extends HO pixels around the tile, with shared absolute differences: the plus-shaped
+// SAD between the neighbourhoods of a pixel and of its right / lower neighbour is a 5-point sum of the per-position maps
+//   D_h(q) = sum_c scale_c * |p_c(q) - p_c(q + (0,1))|,   D_v(q) = sum_c scale_c * |p_c(q) - p_c(q + (1,0))|
+// (left / upper neighbour: the same maps one column / row earlier), so every absolute difference is computed once per
+// workgroup instead of up to ten times. The maps live in the two lower planes of `dst`; the stage's outputs are kept in
+// registers until every thread is done reading the maps, then stored over them.
+template <int S, int PL, int HO, int H>
+__device__ __forceinline__ void Epf1Stage(const FusedFilterParams& P, const float* src, float* dst, const float* l_sig, int x0,
+                                          int y0, int xs, int ys, int tid) {
+  const int sbx = (x0 >> 3) - 1, sby = (y0 >> 3) - 1;
+  constexpr int TW = kFusedTW, TH = kFusedTH;
+  {
+    constexpr int w = TW + 2 * HO + 3, n = w * (TH + 2 * HO + 3), NITD = (n + kFusedThreads - 1) / kFusedThreads;
+#pragma unroll 4
+    for (int it = 0; it < NITD; it++) {
+      const int i = tid + it * kFusedThreads;
+      if (i >= n) break;
+      const int ry = i / w, rx = i - ry * w;
+      const int q = (ry + H - HO - 2) * S + rx + H - HO - 2;
+      float dh = 0.0f, dv = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float v = src[c * PL + q];
+        dh = fabsf(v - src[c * PL + q + 1]) * P.f.ch_scale[c] + dh;
+        dv = fabsf(v - src[c * PL + q + S]) * P.f.ch_scale[c] + dv;
+      }
+      dst[q] = dh;
+      dst[PL + q] = dv;
+    }
+  }
+  __syncthreads();
+  constexpr int w = TW + 2 * HO, n = w * (TH + 2 * HO), NIT = (n + kFusedThreads - 1) / kFusedThreads;
+  float out[NIT][3];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int i = tid + it * kFusedThreads;
+    if (i < n) {
+      const int ry = i / w, rx = i - ry * w;
+      const int o = (ry + H - HO) * S + rx + H - HO;
+      const int mx = MirrorI(x0 + rx - HO, xs), my = MirrorI(y0 + ry - HO, ys);
+      const float is = l_sig[((my >> 3) - sby) * kFusedSigW + (mx >> 3) - sbx];
+      const float c0 = src[o], c1 = src[PL + o], c2 = src[2 * PL + o];
+      if (is < -3.90524291751269967465540850526868f) {
+        out[it][0] = c0;
+        out[it][1] = c1;
+        out[it][2] = c2;
+      } else {
+        const bool border = ((mx & 7) == 0) || ((mx & 7) == 7) || ((my & 7) == 0) || ((my & 7) == 7);
+        const float inv_sig = is * (border ? P.bsm[1] : P.sm[1]);
+        const float* dh = dst;
+        const float* dv = dst + PL;
+        // neighbours in the reference's order: up, left, right, down
+        const int nb[4] = {o - S, o - 1, o + 1, o + S};
+        const float sad[4] = {
+            (dv[o - S] + dv[o - 2 * S]) + (dv[o - S - 1] + dv[o]) + dv[o - S + 1],
+            (dh[o - 1] + dh[o - S - 1]) + (dh[o - 2] + dh[o + S - 1]) + dh[o],
+            (dh[o] + dh[o - S]) + (dh[o - 1] + dh[o + S]) + dh[o + 1],
+            (dv[o] + dv[o - S]) + (dv[o - 1] + dv[o + S]) + dv[o + 1]};
+        float wsum = 1.0f, a0 = c0, a1 = c1, a2 = c2;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float weight = sad[j] * inv_sig + 1.0f;
+          weight = weight < 0.0f ? 0.0f : weight;
+          wsum += weight;
+          a0 = weight * src[nb[j]] + a0;
+          a1 = weight * src[PL + nb[j]] + a1;
+          a2 = weight * src[2 * PL + nb[j]] + a2;
+        }
+        const float inv_w = 1.0f / wsum;
+        out[it][0] = a0 * inv_w;
+        out[it][1] = a1 * inv_w;
+        out[it][2] = a2 * inv_w;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    const int i = tid + it * kFusedThreads;
+    if (i < n) {
+      const int ry = i / w, rx = i - ry * w;
+      const int o = (ry + H - HO) * S + rx + H - HO;
+      dst[o] = out[it][0];
+      dst[PL + o] = out[it][1];
+      dst[2 * PL + o] = out[it][2];
+    }
+  }
+  __syncthreads();
+}
+
 template <bool GAB, int EPF>
-__global__ __launch_bounds__(256) void k_filter_fused(const FusedFilterParams* params) {
-  const FusedFilterParams& P = params[blockIdx.z];  // one frame per grid z slice
+__global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilterParams* params) {
+  // one frame per grid z slice; its parameter block is read through the constant address space (scalar loads that the
+  // compiler may hoist out of the pixel loops: a plain global reference is re-read after every store)
+  FusedFilterParams P;
+  LoadParams(P, params + blockIdx.z);
   constexpr int H = FusedHalo(GAB, EPF);
   constexpr int TW = kFusedTW, TH = kFusedTH, S = TW + 2 * H, SH = TH + 2 * H, PL = S * SH;
   extern __shared__ __align__(16) float lds_ff[];
   float* src = lds_ff;
   float* dst = lds_ff + 3 * PL;
+  float* l_sig = lds_ff + 6 * PL;  // 1 / sigma of the 8x8 blocks around the tile (block columns bx0 - 1 .., rows by0 - 1 ..)
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int xs = int(P.f.xs), ys = int(P.f.ys);
   if (x0 >= xs || y0 >= ys) return;  // the grid covers the largest frame of the launch
   const size_t gplane = size_t(P.f.xp) * P.f.yp;
+  const int sbx = (x0 >> 3) - 1, sby = (y0 >> 3) - 1;
+  if (EPF > 0 && tid < kFusedSigW * kFusedSigH) {
+    int bx = sbx + tid % kFusedSigW, by = sby + tid / kFusedSigW;
+    bx = bx < 0 ? 0 : (bx >= int(P.f.xb) ? int(P.f.xb) - 1 : bx);
+    by = by < 0 ? 0 : (by >= int((P.f.ys + 7) / 8) ? int((P.f.ys + 7) / 8) - 1 : by);
+    l_sig[tid] = P.f.inv_sigma[size_t(by) * P.f.xb + bx];
+  }
   // ---- tile + halo from HBM, mirrored about the frame size
-  for (int i = tid; i < PL; i += 256) {
-    const int ly = i / S, lx = i - ly * S;
-    const size_t g = size_t(MirrorI(y0 + ly - H, ys)) * P.f.xp + MirrorI(x0 + lx - H, xs);
-    src[i] = P.f.in[g];
-    src[PL + i] = P.f.in[gplane + g];
-    src[2 * PL + i] = P.f.in[2 * gplane + g];
+  {
+    // all loads of the thread are issued before the first LDS store (the HBM latency is paid once, not per element)
+    constexpr int NLD = (PL + kFusedThreads - 1) / kFusedThreads;
+    float v[NLD][3];
+#pragma unroll
+    for (int it = 0; it < NLD; it++) {
+      const int i = tid + it * kFusedThreads;
+      if (i < PL) {
+        const int ly = i / S, lx = i - ly * S;
+        const size_t g = size_t(MirrorI(y0 + ly - H, ys)) * P.f.xp + MirrorI(x0 + lx - H, xs);
+        v[it][0] = P.f.in[g];
+        v[it][1] = P.f.in[gplane + g];
+        v[it][2] = P.f.in[2 * gplane + g];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; it++) {
+      const int i = tid + it * kFusedThreads;
+      if (i < PL) {
+        src[i] = v[it][0];
+        src[PL + i] = v[it][1];
+        src[2 * PL + i] = v[it][2];
+      }
+    }
   }
   __syncthreads();
   int h = H;  // halo still valid around the tile in `src`
   if (GAB) {
     h -= 1;
-    const int w = TW + 2 * h, n = w * (TH + 2 * h);
-    for (int i = tid; i < n; i += 256) {
+    constexpr int HG = H - 1, w = TW + 2 * HG, n = w * (TH + 2 * HG), NIT = (n + kFusedThreads - 1) / kFusedThreads;
+#pragma unroll 4
+    for (int it = 0; it < NIT; it++) {
+      const int i = tid + it * kFusedThreads;
+      if (i >= n) break;
       const int ry = i / w, rx = i - ry * w;
-      const int o = (ry + H - h) * S + rx + H - h;
+      const int o = (ry + H - HG) * S + rx + H - HG;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         const float* p = src + c * PL;
@@ -134,11 +259,11 @@ __global__ __launch_bounds__(256) void k_filter_fused(const FusedFilterParams* p
   {                                                                                                          \
     h -= RADIUS_;                                                                                            \
     const int w = TW + 2 * h, n = w * (TH + 2 * h);                                                          \
-    for (int i = tid; i < n; i += 256) {                                                                     \
+    for (int i = tid; i < n; i += kFusedThreads) {                                                                     \
       const int ry = i / w, rx = i - ry * w;                                                                 \
       const int o = (ry + H - h) * S + rx + H - h;                                                           \
       const int mx = MirrorI(x0 + rx - h, xs), my = MirrorI(y0 + ry - h, ys);                                \
-      const float is = P.f.inv_sigma[size_t(my >> 3) * P.f.xb + (mx >> 3)];                                  \
+      const float is = l_sig[((my >> 3) - sby) * kFusedSigW + (mx >> 3) - sbx];                              \
       const bool border = ((mx & 7) == 0) || ((mx & 7) == 7) || ((my & 7) == 0) || ((my & 7) == 7);          \
       EpfPixel<STAGE_, S, PL>(P, src, o, is, border, &dst[o], &dst[PL + o], &dst[2 * PL + o]);               \
     }                                                                                                        \
@@ -148,12 +273,20 @@ __global__ __launch_bounds__(256) void k_filter_fused(const FusedFilterParams* p
     dst = t;                                                                                                 \
   }
   if (EPF >= 3) JXL_EPF_STAGE(0, 3)
-  if (EPF >= 1) JXL_EPF_STAGE(1, 2)
+  if (EPF >= 1) {
+    constexpr int HO = H - (GAB ? 1 : 0) - (EPF >= 3 ? 3 : 0) - 2;
+    Epf1Stage<S, PL, HO, H>(P, src, dst, l_sig, x0, y0, xs, ys, tid);
+    h = HO;
+    float* t = src;
+    src = dst;
+    dst = t;
+  }
   if (EPF >= 2) JXL_EPF_STAGE(2, 1)
 #undef JXL_EPF_STAGE
   // ---- colour: XYB -> linear RGB -> sRGB -> dithered 8 bit, staged as bytes in LDS for wide stores
   uint8_t* bytes = reinterpret_cast<uint8_t*>(dst);
-  for (int i = tid; i < TW * TH; i += 256) {
+#pragma unroll 2
+  for (int i = tid; i < TW * TH; i += kFusedThreads) {
     const int ry = i / TW, rx = i - ry * TW;
     const int o = (ry + H) * S + rx + H;
     const int x = x0 + rx, y = y0 + ry;
@@ -185,16 +318,16 @@ __global__ __launch_bounds__(256) void k_filter_fused(const FusedFilterParams* p
   if (((size_t(xs) * 3) & 3) == 0) {  // every tile row starts 4-byte aligned (x0 * 3 is a multiple of 192)
     const int dw = row_bytes >> 2;
     const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bytes);
-    for (int i = tid; i < rows * (TW * 3 / 4); i += 256) {
+    for (int i = tid; i < rows * (TW * 3 / 4); i += kFusedThreads) {
       const int ry = i / (TW * 3 / 4), j = i - ry * (TW * 3 / 4);
       if (j < dw) reinterpret_cast<uint32_t*>(P.f.rgb + (size_t(y0 + ry) * xs + x0) * 3)[j] = b32[i];
     }
-    for (int i = tid; i < rows * 4; i += 256) {  // up to 3 tail bytes per row
+    for (int i = tid; i < rows * 4; i += kFusedThreads) {  // up to 3 tail bytes per row
       const int ry = i >> 2, j = (dw << 2) + (i & 3);
       if (j < row_bytes) P.f.rgb[(size_t(y0 + ry) * xs + x0) * 3 + j] = bytes[ry * TW * 3 + j];
     }
   } else {
-    for (int i = tid; i < rows * TW * 3; i += 256) {
+    for (int i = tid; i < rows * TW * 3; i += kFusedThreads) {
       const int ry = i / (TW * 3), j = i - ry * (TW * 3);
       if (j < row_bytes) P.f.rgb[(size_t(y0 + ry) * xs + x0) * 3 + j] = bytes[i];
     }

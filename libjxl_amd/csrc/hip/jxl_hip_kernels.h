@@ -41,6 +41,18 @@ __constant__ float c_dither[32 * 32];
 // Resample scales mapping coefficient i of an n-point DCT to an 8n-point DCT; entry [n - 1 + i], n in {1,2,4,8,16,32}.
 __constant__ float c_resample[63];
 
+// Copies a per-frame parameter block into a local object with loads through the constant address space: they become
+// scalar loads that the compiler may hoist and re-materialise freely (a plain global reference has to be re-read after
+// every store the compiler cannot prove distinct).
+template <typename T>
+__device__ __forceinline__ void LoadParams(T& dst, const T* src) {
+  static_assert(sizeof(T) % 4 == 0, "parameter blocks are dword multiples");
+  const uint32_t __attribute__((address_space(4)))* s = (const uint32_t __attribute__((address_space(4)))*)(uintptr_t)src;
+  uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(T) / 4; i++) d[i] = s[i];
+}
+
 static const uint32_t kErrNzeros = 1, kErrFinalState = 2, kErrOverread = 4, kErrSelector = 8;
 
 struct PassDev {
@@ -623,11 +635,14 @@ struct TransformParams {
 // workgroup's first varblock in that frame's list of the launched strategy}.
 #define JXL_TRANSFORM_PREAMBLE()                                   \
   const uint2 wgd = desc[blockIdx.x];                              \
-  const TransformParams& P = params[wgd.x];                        \
+  /* the frame's parameter block through the constant address space: scalar loads the compiler may hoist */ \
+  const TransformParams __attribute__((address_space(4)))& P =                                                \
+      *(const TransformParams __attribute__((address_space(4)))*)(uintptr_t)(params + wgd.x);                 \
   const uint32_t n = P.list_count[strategy];                       \
   const uint32_t* list = P.tlist + P.list_begin[strategy];
 
-__device__ __forceinline__ float QuantBias(int c, int q, const float* b) {
+template <typename BiasPtr>
+__device__ __forceinline__ float QuantBias(int c, int q, BiasPtr b) {
   if (q == 0) return 0.0f;
   if (q == 1) return b[c];
   if (q == -1) return -b[c];
@@ -639,8 +654,8 @@ __device__ __forceinline__ float QuantBias(int c, int q, const float* b) {
 // (lib/jxl/dec_group.cc:115-181: dequantisation with AdjustQuantBias, then chroma-from-luma for X and B from the
 // already staged dequantised Y in `l_y`). `gq` = the block's coefficients of channel c, `m` = channel c's dequant
 // table, `mul` = inv_global_scale / qf (times the channel's x_dm / b_dm multiplier), `cc` = CfL factor (0 for Y).
-template <typename CoefT>
-__device__ __forceinline__ void StageChannel(const TransformParams& P, const CoefT* gq, uint32_t block_index, int c, uint32_t ord,
+template <typename CoefT, typename PT>
+__device__ __forceinline__ void StageChannel(const PT& P, const CoefT* gq, uint32_t block_index, int c, uint32_t ord,
                                              uint32_t size, uint32_t covered, const float* m, float mul, float cc, const float* l_y,
                                              float* l, uint32_t t, uint32_t nthreads) {
   if (P.scan_order) {
@@ -666,8 +681,8 @@ __device__ __forceinline__ uint32_t BasisOffset(uint32_t n) { return (n * n - 1)
 
 // Lowest-frequency coefficient (ky, kx) of a CY x CX varblock from the DC image (scaled forward DCT of the
 // covered DC samples times the resample scales).
-template <int CX, int CY>
-__device__ __forceinline__ float LlfFromDc(const TransformParams& P, const float* dc, int ky, int kx) {
+template <int CX, int CY, typename PT>
+__device__ __forceinline__ float LlfFromDc(const PT& P, const float* dc, int ky, int kx) {
   const float* bty = P.basis_t + BasisOffset(CY);
   const float* btx = P.basis_t + BasisOffset(CX);
   float s = 0.0f;
