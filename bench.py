@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--distance", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,6 +167,17 @@ def main():
         dom = max(range(3), key=lambda s: stage_ms[s])
         achieved = alg[names[dom]] / (stage_ms[dom] * 1e-3) / 1e9
         frames_per_launch = args.batch if dom == 0 else 1
+        # HBM traffic of the dominant kernel: PMC counters from separate rocprofv3 passes of this command (committed
+        # summary; FETCH_SIZE + WRITE_SIZE per dispatch), only quoted when taken at the same frames per launch
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = ["k_entropy_lanes", "k_idct_cols<short, 4, 4>", "k_filter_fused"][dom]
+            for name, v in pmc.items():
+                if key in name and pmc.get("_frames_per_launch") == args.batch:
+                    traffic = int((v["fetch_kib_per_dispatch"] + v["write_kib_per_dispatch"]) * 1024)
+        except (OSError, ValueError, KeyError, TypeError):
+            pass
         out = {
             "metric": "megapixels/sec decode, %dx%d VarDCT d%.1f" % (xsize, ysize, args.distance),
             "value": round(mps, 2),
@@ -184,7 +195,7 @@ def main():
                 xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
                 "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else "none", "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "frames_per_launch": frames_per_launch, "launch_ms": round(stage_ms[dom] * frames_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(alg[names[dom]] * frames_per_launch),
                          "note": "entropy decode is serial per 256x256 group (latency-bound, not HBM-bound); amortised over the frames of one launch" if dom == 0 else ""},

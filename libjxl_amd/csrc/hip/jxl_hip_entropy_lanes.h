@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
     o[2] = n_service;
     o[3] = n_trips;
   }
-  if (err) atomicOr(&P.errors[g], err);
+  if (g != 0xFFFFFFFFu) P.errors[g] = err;  // every section's flag word is written: the host does not clear the array
 }
 
 }  // namespace jxlhip

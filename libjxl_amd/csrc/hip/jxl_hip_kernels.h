@@ -2,15 +2,17 @@
 // launches it is in jxl_hip_api.hip. No CPU implementation of these stages exists in the product.
 //
 // Kernels and the reference code they replace:
-//   k_entropy_ans   lib/jxl/dec_group.cc:469-542,594-639 + dec_ans.h:170-257 + ans_common.h:102-142
-//   k_dct<CX,CY>    lib/jxl/dec_group.cc:115-181 (dequant, CfL), dec_transforms-inl.h:691-818 (LLF from DC),
+//   k_entropy_lanes (jxl_hip_entropy_lanes.h), k_entropy_uni, k_entropy_ans
+//                   lib/jxl/dec_group.cc:469-542,594-639 + dec_ans.h:170-257 + ans_common.h:102-142
+//   k_idct_cols<CX,CY>, k_dct<CX,CY>
+//                   lib/jxl/dec_group.cc:115-181 (dequant, CfL), dec_transforms-inl.h:691-818 (LLF from DC),
 //                   dct-inl.h:376-397 (scaled IDCT, evaluated here in its separable matrix form)
 //   k_special       dec_transforms-inl.h:66-93,95-454,463-568 (IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4, AFV0-3)
 //   k_dct_big       same as k_dct for 128/256-class transforms (global scratch instead of LDS)
-//   k_gaborish      render_pipeline/stage_gaborish.cc:56-100
-//   k_epf<STAGE>    render_pipeline/stage_epf.cc:82-494
-//   k_color         stage_xyb.cc:80-92, dec_xyb-inl.h:38-86, stage_from_linear.cc:114-144,
-//                   cms/transfer_functions-inl.h:245-268, stage_write.cc:266-286,548-590
+//   k_filter_fused (jxl_hip_filter_fused.h)
+//                   render_pipeline/stage_gaborish.cc:56-100, stage_epf.cc:82-494, stage_xyb.cc:80-92,
+//                   dec_xyb-inl.h:38-86, stage_from_linear.cc:114-144, cms/transfer_functions-inl.h:245-268,
+//                   stage_write.cc:266-286,548-590
 #ifndef JXL_HIP_KERNELS_H_
 #define JXL_HIP_KERNELS_H_
 
@@ -1149,7 +1151,6 @@ struct FilterParams {
   const float* inv_sigma;
   float gab_w[9];  // normalised {w0,w1,w2} per channel
   float ch_scale[3];
-  float sm, bsm;   // sigma multipliers (centre / border) of the current EPF stage
   // colour
   float opsin_inv[9], opsin_bias[3], opsin_bias_cbrt[3];
   int32_t linear_output;
@@ -1160,74 +1161,6 @@ __device__ __forceinline__ int MirrorI(int x, int n) {
   while (x < 0 || x >= n) x = x < 0 ? -x - 1 : 2 * n - 1 - x;
   return x;
 }
-__device__ __forceinline__ float At(const float* plane, const FilterParams& P, int x, int y) {
-  return plane[size_t(MirrorI(y, int(P.ys))) * P.xp + MirrorI(x, int(P.xs))];
-}
-
-__global__ __launch_bounds__(256) void k_gaborish(FilterParams P) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= int(P.xs) || y >= int(P.ys)) return;
-  for (int c = 0; c < 3; c++) {
-    const float* p = P.in + size_t(c) * P.xp * P.yp;
-    const float m = At(p, P, x, y);
-    const float s1 = (At(p, P, x - 1, y) + At(p, P, x + 1, y)) + (At(p, P, x, y - 1) + At(p, P, x, y + 1));
-    const float s2 = (At(p, P, x - 1, y - 1) + At(p, P, x + 1, y - 1)) + (At(p, P, x - 1, y + 1) + At(p, P, x + 1, y + 1));
-    P.out[size_t(c) * P.xp * P.yp + size_t(y) * P.xp + x] = s2 * P.gab_w[c * 3 + 2] + (s1 * P.gab_w[c * 3 + 1] + m * P.gab_w[c * 3]);
-  }
-}
-
-template <int STAGE>
-__global__ __launch_bounds__(256) void k_epf(FilterParams P) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= int(P.xs) || y >= int(P.ys)) return;
-  const size_t plane = size_t(P.xp) * P.yp, o = size_t(y) * P.xp + x;
-  const float is = P.inv_sigma[size_t(y >> 3) * P.xb + (x >> 3)];
-  const float c0 = P.in[o], c1 = P.in[plane + o], c2 = P.in[2 * plane + o];
-  if (is < -3.90524291751269967465540850526868f) {
-    P.out[o] = c0;
-    P.out[plane + o] = c1;
-    P.out[2 * plane + o] = c2;
-    return;
-  }
-  const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
-  const float inv_sig = is * (border ? P.bsm : P.sm);
-  constexpr int NOFF = STAGE == 0 ? 12 : 4;
-  const int off0[12][2] = {{-2, 0}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 1}, {0, 2}, {1, -1}, {1, 0}, {1, 1}, {2, 0}};
-  const int off1[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
-  const int plus[5][2] = {{0, 0}, {-1, 0}, {0, -1}, {1, 0}, {0, 1}};
-  float w = 1.0f, a0 = c0, a1 = c1, a2 = c2;
-#pragma unroll
-  for (int i = 0; i < NOFF; i++) {
-    const int dy = STAGE == 0 ? off0[i][0] : off1[i][0], dx = STAGE == 0 ? off0[i][1] : off1[i][1];
-    float sad = 0.0f;
-    if (STAGE == 2) {
-      sad = fabsf(At(P.in, P, x + dx, y + dy) - c0) * P.ch_scale[0];
-      sad = fabsf(At(P.in + plane, P, x + dx, y + dy) - c1) * P.ch_scale[1] + sad;
-      sad = fabsf(At(P.in + 2 * plane, P, x + dx, y + dy) - c2) * P.ch_scale[2] + sad;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        const float* p = P.in + size_t(c) * plane;
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-          s += fabsf(At(p, P, x + plus[k][1], y + plus[k][0]) - At(p, P, x + dx + plus[k][1], y + dy + plus[k][0]));
-        sad = s * P.ch_scale[c] + sad;
-      }
-    }
-    float weight = sad * inv_sig + 1.0f;
-    weight = weight < 0.0f ? 0.0f : weight;
-    w += weight;
-    a0 = weight * At(P.in, P, x + dx, y + dy) + a0;
-    a1 = weight * At(P.in + plane, P, x + dx, y + dy) + a1;
-    a2 = weight * At(P.in + 2 * plane, P, x + dx, y + dy) + a2;
-  }
-  const float inv_w = 1.0f / w;
-  P.out[o] = a0 * inv_w;
-  P.out[plane + o] = a1 * inv_w;
-  P.out[2 * plane + o] = a2 * inv_w;
-}
-
 __device__ __forceinline__ float LinearToSrgb(float v) {
   const float a = fabsf(v);
   float r;
@@ -1252,27 +1185,6 @@ __device__ __forceinline__ uint8_t ToU8(float v, int x, int y, int c) {
   v = v >= 0.0f ? v : 0.0f;
   v = v > 255.0f ? 255.0f : v;
   return uint8_t(__float2int_rn(v));
-}
-
-__global__ __launch_bounds__(256) void k_color(FilterParams P) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= int(P.xs) || y >= int(P.ys)) return;
-  const size_t plane = size_t(P.xp) * P.yp, o = size_t(y) * P.xp + x;
-  const float X = P.in[o], Y = P.in[plane + o], B = P.in[2 * plane + o];
-  const float gr = (Y + X) - P.opsin_bias_cbrt[0], gg = (Y - X) - P.opsin_bias_cbrt[1], gb = B - P.opsin_bias_cbrt[2];
-  const float mr = (gr * gr) * gr + P.opsin_bias[0], mg = (gg * gg) * gg + P.opsin_bias[1], mb = (gb * gb) * gb + P.opsin_bias[2];
-  float r = P.opsin_inv[2] * mb + (P.opsin_inv[1] * mg + P.opsin_inv[0] * mr);
-  float g = P.opsin_inv[5] * mb + (P.opsin_inv[4] * mg + P.opsin_inv[3] * mr);
-  float b = P.opsin_inv[8] * mb + (P.opsin_inv[7] * mg + P.opsin_inv[6] * mr);
-  if (!P.linear_output) {
-    r = LinearToSrgb(r);
-    g = LinearToSrgb(g);
-    b = LinearToSrgb(b);
-  }
-  uint8_t* dst = P.rgb + (size_t(y) * P.xs + x) * 3;
-  dst[0] = ToU8(r, x, y, 0);
-  dst[1] = ToU8(g, x, y, 1);
-  dst[2] = ToU8(b, x, y, 2);
 }
 
 }  // namespace jxlhip

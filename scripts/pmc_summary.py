@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs into a per-kernel JSON summary.
+usage: pmc_summary.py FETCH.csv WRITE.csv OUT.json FRAMES_PER_LAUNCH   (counter values are KiB per dispatch, see MI355X_MICROARCH.md HBM)"""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"]
+        agg[k][0] += 1
+        agg[k][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main():
+    fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    out = {"_frames_per_launch": int(sys.argv[4]), "_unit": "KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes)"}
+    for k in sorted(set(fetch) | set(write)):
+        if "jxlhip" not in k:
+            continue
+        out[k] = {"dispatches": fetch.get(k, write.get(k))[0],
+                  "fetch_kib_per_dispatch": round(fetch[k][1] / fetch[k][0], 1) if k in fetch else None,
+                  "write_kib_per_dispatch": round(write[k][1] / write[k][0], 1) if k in write else None}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
