@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--distance", type=float, default=1.0)
+    ap.add_argument("--shard", choices=("frames", "bands"), default="frames",
+                    help="multi-GPU split: whole frames per rank (weak scaling) or, for very large frames, one band of rows "
+                         "of 256x256 groups of every frame per rank (strong scaling, no exchange between ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one frame set: entropy, then transform+filter, in sequence")
     args = ap.parse_args()
@@ -96,9 +99,17 @@ def main():
     # stage once over `batch` frames, so a step completes `batch` frames; a frame's latency is two steps.
     nsets = 1 if args.no_pipeline else 2
     sets = [[J.HipContext(local_rank) for _ in range(args.batch)] for _ in range(nsets)]
+    band = None
+    share = 1.0  # fraction of every frame's pixels this rank produces
+    if args.shard == "bands":
+        group_rows = (ysize + 255) // 256
+        band = sharding.band_of(group_rows, rank, world)
+        if band[0] == band[1]:
+            raise SystemExit("more ranks than rows of groups: use --shard frames")
+        share = (min(band[1] * 256, ysize) - band[0] * 256) / float(ysize)
     for cs in sets:
         for c in cs:
-            c.upload(frame)
+            c.upload(frame, band=band)
     for cs in sets:  # prime: every set holds decoded coefficients before the first (warmup) step
         J.run_entropy_batch(cs)
     for cs in sets:
@@ -138,7 +149,7 @@ def main():
         entropy_ms += ent[0].stage_ms(0)  # HIP events on the stream the batch kernel was launched on (host-side read)
     barrier()
     elapsed = time.perf_counter() - t0
-    frames_local = args.batch * args.steps
+    frames_local = args.batch * args.steps * share
     total_frames, max_elapsed = sharding.aggregate(frames_local, elapsed, dist)
     # transform and filter+colour: the same batched launches over one set, run alone after the timed region (inside the
     # region their kernels share the GPU with the concurrently running entropy kernel); per frame = launch time / frames
@@ -187,13 +198,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if args.shard == "frames" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
                 xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
-                "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else "none", "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
+                "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else "none", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
+                ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "frames_per_launch": frames_per_launch, "launch_ms": round(stage_ms[dom] * frames_per_launch, 4),

@@ -25,6 +25,8 @@ void jxlamd_frame_free(JxlAmdFrame* frame);
  * number of clustered histograms, context map bytes; [15] reserved (0). */
 void jxlamd_frame_info(const JxlAmdFrame* frame, uint32_t* info);
 int jxlamd_frame_upload(const JxlAmdFrame* frame, JxlHipContext* ctx);
+/* Same, for a band of rows of 256x256 groups [group_row_begin, group_row_end) (see JxlHipFrameDesc); 0, 0 = whole frame. */
+int jxlamd_frame_upload_band(const JxlAmdFrame* frame, JxlHipContext* ctx, uint32_t group_row_begin, uint32_t group_row_end);
 /* Thread-local description of the last failure of a jxlamd_* call ("" if none). */
 const char* jxlamd_last_error(void);
 #ifdef __cplusplus

@@ -106,6 +106,11 @@ typedef struct JxlHipFrameDesc {
   float opsin_inv[9]; /* inverse opsin matrix, already scaled by 255 / intensity_target */
   float opsin_bias[3];
   int32_t linear_output; /* 0 = sRGB transfer function, 1 = linear */
+  /* Band decode (one frame split over several GPUs by rows of 256x256 groups): produce only the pixel
+   * rows of group rows [band_group_row_begin, band_group_row_end). The context then also decodes and transforms the
+   * one group row above and below the band (the loop filters need up to 7 rows of their output), so no exchange
+   * between devices is needed. 0, 0 = the whole frame. */
+  uint32_t band_group_row_begin, band_group_row_end;
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);
@@ -138,6 +143,8 @@ int jxlhip_sync(JxlHipContext* ctx);
 
 /* Copies the interleaved RGB8 result (row stride in bytes) to host memory; synchronous. */
 int jxlhip_download_rgb8(JxlHipContext* ctx, uint8_t* dst, size_t stride);
+/* Same for pixel rows [y_begin, y_end) only (dst receives y_end - y_begin rows): the rows a band context produced. */
+int jxlhip_download_rgb8_rows(JxlHipContext* ctx, uint8_t* dst, size_t stride, uint32_t y_begin, uint32_t y_end);
 /* Device pointer of the RGB8 result (xsize * 3 bytes per row, tightly packed). */
 const uint8_t* jxlhip_rgb8_device_ptr(JxlHipContext* ctx);
 

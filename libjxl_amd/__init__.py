@@ -49,6 +49,8 @@ def lib():
             getattr(L, name).argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
         L.jxlhip_download_rgb8.argtypes = [vp, vp, ctypes.c_size_t]
         L.jxlhip_set_option.argtypes = [vp, cp, ctypes.c_int]
+        L.jxlhip_download_rgb8_rows.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]
+        L.jxlamd_frame_upload_band.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32]
         L.jxlhip_rgb8_device_ptr.argtypes = [vp]
         L.jxlhip_rgb8_device_ptr.restype = vp
         L.jxlhip_get_errors.argtypes = [vp, u32p, ctypes.c_size_t]
@@ -133,9 +135,17 @@ class HipContext:
     def set_option(self, name, value):
         _check(lib().jxlhip_set_option(self._h, name.encode(), int(value)), "jxlhip_set_option")
 
-    def upload(self, frame):
-        _check(lib().jxlamd_frame_upload(frame._h, self._h), "jxlamd_frame_upload")
+    def upload(self, frame, band=None):
+        """band = (group_row_begin, group_row_end): produce only those rows of 256x256 groups (multi-GPU split)."""
+        b0, b1 = band if band else (0, 0)
+        _check(lib().jxlamd_frame_upload_band(frame._h, self._h, b0, b1), "jxlamd_frame_upload_band")
         self.frame_info = dict(frame.info)
+
+    def rgb8_rows(self, y0, y1):
+        fi = self.frame_info
+        out = np.empty((y1 - y0, fi["xsize"], 3), np.uint8)
+        _check(lib().jxlhip_download_rgb8_rows(self._h, out.ctypes.data, fi["xsize"] * 3, y0, y1), "jxlhip_download_rgb8_rows")
+        return out
 
     def run_entropy(self):
         _check(lib().jxlhip_run_entropy(self._h), "jxlhip_run_entropy")

@@ -100,7 +100,9 @@ void jxlamd_frame_info(const JxlAmdFrame* f, uint32_t* info) {
   info[14] = P.passes.empty() ? 0 : uint32_t(P.passes[0].ctx_map.size());
 }
 
-int jxlamd_frame_upload(const JxlAmdFrame* f, JxlHipContext* ctx) {
+int jxlamd_frame_upload(const JxlAmdFrame* f, JxlHipContext* ctx) { return jxlamd_frame_upload_band(f, ctx, 0, 0); }
+
+int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t group_row_begin, uint32_t group_row_end) {
   g_last_error.clear();
   if (!f || !ctx) {
     g_last_error = "invalid argument";
@@ -177,6 +179,8 @@ int jxlamd_frame_upload(const JxlAmdFrame* f, JxlHipContext* ctx) {
   d.epf_border_sad_mul = lf.epf_border_sad_mul;
   for (int i = 0; i < 9; i++) d.opsin_inv[i] = P.ih.inv_opsin[i] * (255.0f / P.ih.intensity_target);
   d.linear_output = P.ih.linear_tf;
+  d.band_group_row_begin = group_row_begin;
+  d.band_group_row_end = group_row_end;
   int r = jxlhip_frame_upload(ctx, &d);
   if (r == 0) r = jxlhip_sync(ctx);  // `pd` and the staging copies are locals
   if (r) g_last_error = "jxlhip_frame_upload failed (" + std::to_string(r) + ")";

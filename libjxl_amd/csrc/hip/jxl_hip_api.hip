@@ -86,6 +86,9 @@ struct JxlHipContext {
   int batch_kernel = -1;
   std::vector<uint32_t> sec_size_host, pass_clusters, pass_log_alpha;
   // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
+  // band decode: groups this context decodes (band + one group row either side), pixel rows it produces
+  std::vector<uint32_t> group_list;
+  uint32_t band_y0 = 0, band_y1 = 0;
   bool scan_order = false;
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
   Buf kend, block_recs;
@@ -264,6 +267,19 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->xs = d->xsize; c->ys = d->ysize; c->xb = d->xsize_blocks; c->yb = d->ysize_blocks;
   c->xg = d->xsize_groups; c->ng = d->num_groups; c->np = d->num_passes;
   c->xp = c->xb * 8; c->yp = c->yb * 8;
+  uint32_t ext_row0 = 0, ext_row1 = d->num_groups / d->xsize_groups;  // group rows to entropy-decode and transform
+  {
+    const uint32_t yg = d->num_groups / d->xsize_groups;
+    uint32_t rb = d->band_group_row_begin, re = d->band_group_row_end;
+    if (rb == 0 && re == 0) re = yg;
+    if (rb >= re || re > yg) return JXLHIP_ERR_INVALID_ARGUMENT;
+    ext_row0 = rb ? rb - 1 : 0;
+    ext_row1 = re < yg ? re + 1 : yg;
+    c->band_y0 = rb * 256;
+    c->band_y1 = re * 256 < d->ysize ? re * 256 : d->ysize;
+    c->group_list.clear();
+    for (uint32_t g = ext_row0 * d->xsize_groups; g < ext_row1 * d->xsize_groups; g++) c->group_list.push_back(g);
+  }
   c->coef_bits = d->coef_bits;
   c->gab = d->gab; c->epf_iters = d->epf_iters;
   // ---- validate varblocks against the geometry (the kernels index with these)
@@ -360,6 +376,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   const size_t coef_bytes = size_t(d->num_groups) * 3 * 65536 * (d->coef_bits / 8);
   if ((r = c->coeffs.Ensure(coef_bytes))) return r;
   if ((r = c->errors.Ensure(size_t(d->num_groups) * 4))) return r;
+  HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(d->num_groups) * 4, c->stream));  // groups outside a band stay clean
   const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
   if ((r = c->plane[0].Ensure(plane_bytes))) return r;
   if (c->keep_filtered && (r = c->plane[1].Ensure(plane_bytes))) return r;
@@ -367,7 +384,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   // ---- transform work lists (block indices bucketed by strategy)
   {
     std::vector<uint32_t> count(27, 0);
-    for (uint32_t i = 0; i < d->num_blocks; i++) count[d->blocks[i].strategy]++;
+    auto in_band = [&](uint32_t i) { return uint32_t(d->blocks[i].by >> 5) >= ext_row0 && uint32_t(d->blocks[i].by >> 5) < ext_row1; };
+    for (uint32_t i = 0; i < d->num_blocks; i++)
+      if (in_band(i)) count[d->blocks[i].strategy]++;
     uint32_t acc = 0;
     for (int s = 0; s < 27; s++) {
       c->list_begin[s] = acc;
@@ -376,6 +395,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     }
     std::vector<uint32_t> list(d->num_blocks ? d->num_blocks : 1), fill(27, 0);
     for (uint32_t i = 0; i < d->num_blocks; i++) {
+      if (!in_band(i)) continue;
       const int s = d->blocks[i].strategy;
       list[c->list_begin[s] + fill[s]++] = i;
     }
@@ -483,6 +503,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   jxlhip::FilterParams& fp = c->fp;
   memset(&fp, 0, sizeof(fp));
   fp.xs = c->xs; fp.ys = c->ys; fp.xp = c->xp; fp.yp = c->yp; fp.xb = c->xb;
+  fp.y_begin = c->band_y0; fp.y_end = c->band_y1;
   fp.inv_sigma = c->inv_sigma.as<float>();
   for (int ch = 0; ch < 3; ch++) {
     const float w1 = d->gab_w[ch * 2], w2 = d->gab_w[ch * 2 + 1];
@@ -673,7 +694,8 @@ static int PrepareDownstream(JxlHipContext* c0, JxlHipContext* const* ctxs, size
     const JxlHipContext* c = ctxs[order[j]];
     FillFusedParams(c, &fparams[j]);
     const int key = FilterKey(c);
-    const uint32_t tx = (c->xs + jxlhip::kFusedTW - 1) / jxlhip::kFusedTW, ty = (c->ys + jxlhip::kFusedTH - 1) / jxlhip::kFusedTH;
+    const uint32_t tx = (c->xs + jxlhip::kFusedTW - 1) / jxlhip::kFusedTW;
+    const uint32_t ty = (c->band_y1 - c->band_y0 + jxlhip::kFusedTH - 1) / jxlhip::kFusedTH;
     if (c0->fgroups.empty() || c0->fgroups.back().key != key) c0->fgroups.push_back({key, uint32_t(j), 0, 0, 0});
     JxlHipContext::FilterGroup& g = c0->fgroups.back();
     g.count++;
@@ -799,7 +821,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   for (size_t i = 0; i < n; i++) params[i] = ctxs[i]->ep;
   if (kernel == 2) {
     size_t total_sections = 0;
-    for (size_t i = 0; i < n; i++) total_sections += ctxs[i]->ng;
+    for (size_t i = 0; i < n; i++) total_sections += ctxs[i]->group_list.size();
     // populated lanes per wave: spread the sections over ~640 waves before packing lanes more densely (measured optimum
     // on MI355X for 64..256 4K frames: the launch lasts as long as its longest section, and a wave costs the same
     // issue slots however many of its lanes are populated)
@@ -823,41 +845,41 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     for (size_t i = 0; i < n; i++) {
       const JxlHipContext* c = ctxs[i];
       frame_wg0[i] = uint32_t(map.size());
-      const uint32_t wgs = (c->ng + per_wg - 1) / per_wg;
+      const uint32_t ng = uint32_t(c->group_list.size());
+      const uint32_t wgs = (ng + per_wg - 1) / per_wg;
       for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i));
-      order.resize(c->ng);
-      for (uint32_t g = 0; g < c->ng; g++) order[g] = g;
+      order = c->group_list;
       const uint32_t* sz = c->sec_size_host.data();
       std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
       const uint32_t waves = wgs * kLanesWPG;
       count.assign(waves, 0);
       bool done = false;
-      if (graded && c->ng > waves) {
+      if (graded && ng > waves) {
         // smallest finish time T such that filling the waves in order with floor((T / longest - a) / b) sections fits
         double lo = 0.0, hi = double(sz[order[0]] + 1) * (cost_a + cost_b * 64.0);
         for (int it = 0; it < 40; it++) {
           const double T = 0.5 * (lo + hi);
           uint32_t j = 0;
-          for (uint32_t w = 0; w < waves && j < c->ng; w++) {
+          for (uint32_t w = 0; w < waves && j < ng; w++) {
             const double room = (T / double(sz[order[j]] + 1) - cost_a) / cost_b;
             const uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
             j += take;
           }
-          if (j >= c->ng) hi = T; else lo = T;
+          if (j >= ng) hi = T; else lo = T;
         }
         uint32_t j = 0;
-        for (uint32_t w = 0; w < waves && j < c->ng; w++) {
+        for (uint32_t w = 0; w < waves && j < ng; w++) {
           const double room = (hi / double(sz[order[j]] + 1) - cost_a) / cost_b;
           uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
-          take = take > c->ng - j ? c->ng - j : take;
+          take = take > ng - j ? ng - j : take;
           count[w] = take;
           j += take;
         }
-        done = j >= c->ng;
+        done = j >= ng;
       }
       if (!done) {
         count.assign(waves, 0);
-        for (uint32_t j = 0; j < c->ng; j++) count[j / lanes_per_wave]++;
+        for (uint32_t j = 0; j < ng; j++) count[j / lanes_per_wave]++;
       }
       for (uint32_t w = 0; w < waves; w++) max_lanes = count[w] > max_lanes ? count[w] : max_lanes;
       frame_order[i] = order;
@@ -1040,6 +1062,21 @@ int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
     if (pw) return pw;
   }
   HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, size_t(c->xs) * 3, size_t(c->xs) * 3, c->ys, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int jxlhip_download_rgb8_rows(JxlHipContext* c, uint8_t* dst, size_t stride, uint32_t y_begin, uint32_t y_end) {
+  if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  if (stride < size_t(c->xs) * 3 || y_begin >= y_end || y_end > c->ys) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.as<uint8_t>() + size_t(y_begin) * c->xs * 3, size_t(c->xs) * 3, size_t(c->xs) * 3,
+                           y_end - y_begin, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -193,9 +193,9 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
   float* dst = lds_ff + 3 * PL;
   float* l_sig = lds_ff + 6 * PL;  // 1 / sigma of the 8x8 blocks around the tile (block columns bx0 - 1 .., rows by0 - 1 ..)
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int x0 = blockIdx.x * TW, y0 = int(P.f.y_begin) + blockIdx.y * TH;
   const int xs = int(P.f.xs), ys = int(P.f.ys);
-  if (x0 >= xs || y0 >= ys) return;  // the grid covers the largest frame of the launch
+  if (x0 >= xs || y0 >= int(P.f.y_end)) return;  // the grid covers the largest frame (band) of the launch
   const size_t gplane = size_t(P.f.xp) * P.f.yp;
   const int sbx = (x0 >> 3) - 1, sby = (y0 >> 3) - 1;
   if (EPF > 0 && tid < kFusedSigW * kFusedSigH) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
   }
   __syncthreads();
   const int cols = xs - x0 < TW ? xs - x0 : TW;  // valid pixels per tile row
-  const int rows = ys - y0 < TH ? ys - y0 : TH;
+  const int rows = int(P.f.y_end) - y0 < TH ? int(P.f.y_end) - y0 : TH;
   const int row_bytes = cols * 3;
   if (((size_t(xs) * 3) & 3) == 0) {  // every tile row starts 4-byte aligned (x0 * 3 is a multiple of 192)
     const int dw = row_bytes >> 2;

@@ -1148,6 +1148,7 @@ struct FilterParams {
   const float* in;   // 3 planes, stride xp, plane size xp * yp
   float* out;
   uint32_t xs, ys, xp, yp, xb;
+  uint32_t y_begin, y_end;  // pixel rows to produce (band decode; whole frame: 0, ys); y_begin is a multiple of 256
   const float* inv_sigma;
   float gab_w[9];  // normalised {w0,w1,w2} per channel
   float ch_scale[3];

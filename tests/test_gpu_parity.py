@@ -191,6 +191,40 @@ def test_batched_entropy_launch(built):
             f.close()
 
 
+@pytest.mark.parametrize("kind", ["image", "random_epf3"])
+def test_band_decode_matches_whole_frame(built, kind):
+    """One frame split into bands of group rows (the multi-GPU split of a large frame, here on one device): every band
+    context produces exactly the rows of the whole-frame decode, with no data exchanged between the contexts."""
+    from libjxl_amd import sharding
+    J = built
+    if kind == "image":
+        data = J.encode_rgb8(J.synth_image(1000, 1300, seed=11), distance=2.0)  # gab + EPF1 + EPF2: 4 rows of halo
+    else:
+        data = J.encode_random(700, 1100, seed=12, epf_iters=3)                 # all strategies, 7 rows of halo
+    f = J.Frame(data, threads=2)
+    ys = f.info["ysize"]
+    rows = (ys + 255) // 256
+    whole = J.decode_rgb8(data)
+    for world in (2, 3, rows):
+        stitched = np.zeros_like(whole)
+        for rank in range(world):
+            b0, b1 = sharding.band_of(rows, rank, world)
+            if b0 == b1:
+                continue
+            c = J.HipContext()
+            try:
+                c.upload(f, band=(b0, b1))
+                c.run_all()
+                r, flags = c.errors()
+                assert r == 0
+                y0, y1 = b0 * 256, min(b1 * 256, ys)
+                stitched[y0:y1] = c.rgb8_rows(y0, y1)
+            finally:
+                c.close()
+        assert np.array_equal(stitched, whole), "band split over %d ranks differs from the whole-frame decode" % world
+    f.close()
+
+
 def test_corrupt_sections_are_flagged_not_fatal(built):
     J = built
     data = bytearray(J.encode_rgb8(J.synth_image(520, 300)))

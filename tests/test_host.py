@@ -166,4 +166,19 @@ def test_sharding_two_ranks_gloo(built, tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs)
     line = [l for l in outs[0].splitlines() if l.startswith("RESULT")][0]
-    assert line == "RESULT [0, 2, 4, 6, 8] 10 2.0"
+    assert line == "RESULT [0, 2, 4, 6, 8] 10.0 2.0"
+
+
+def test_band_partition_of_group_rows():
+    """sharding.band_of: contiguous, disjoint, complete; sizes within one row; 16K = 64 rows -> 8 bands of 8."""
+    from libjxl_amd import sharding
+    assert [sharding.band_of(64, r, 8) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+    for rows in (1, 5, 9, 64, 67):
+        for world in (1, 2, 3, 8):
+            bands = [sharding.band_of(rows, r, world) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == rows
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in bands]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.band_of(4, 2, 2)
