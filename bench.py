@@ -125,9 +125,9 @@ def main():
         J.run_entropy_batch(ent)  # one launch: the per-section decoders of all frames of the set share the GPU
         J.run_transform_batch(down)      # one launch per transform kernel for the whole set
         J.run_filter_color_batch(down)   # one fused filter + colour launch
-        for cs in sets:
-            for c in cs:
-                c.sync()
+        # No host synchronisation inside a step: all work of a set is ordered on that set's first stream (entropy ->
+        # transform -> filter -> next entropy ...), the two sets' streams overlap on the device, and the host only
+        # enqueues. The timed region is closed by the barrier's device synchronisation.
         return ent
 
     def barrier():
@@ -138,17 +138,20 @@ def main():
     for _ in range(args.warmup):
         step()
     for cs in sets:
+        cs[0].sync()
+    for cs in sets:
         r, flags = cs[0].errors()
         if r:
             raise SystemExit("entropy kernel reported corrupt sections: %r" % flags)
     barrier()
     t0 = time.perf_counter()
-    entropy_ms = 0.0
     for _ in range(args.steps):
-        ent = step()
-        entropy_ms += ent[0].stage_ms(0)  # HIP events on the stream the batch kernel was launched on (host-side read)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # duration of the entropy launches: HIP events on the stream each batch kernel was launched on; the events of the
+    # last launch of every set are still in place after the region
+    entropy_ms = sum(cs[0].stage_ms(0) for cs in sets) / float(nsets) * args.steps
     frames_local = args.batch * args.steps * share
     total_frames, max_elapsed = sharding.aggregate(frames_local, elapsed, dist)
     # transform and filter+colour: the same batched launches over one set, run alone after the timed region (inside the

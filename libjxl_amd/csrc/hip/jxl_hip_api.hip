@@ -91,7 +91,7 @@ struct JxlHipContext {
   uint32_t band_y0 = 0, band_y1 = 0;
   bool scan_order = false;
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
-  Buf kend, block_recs;
+  Buf kend, block_recs, dequant_scan;
   std::vector<JxlHipVarBlock> blocks_host;  // for jxlhip_download("coeffs") of a scan-order frame
   std::vector<uint32_t> gbb_host;
   std::vector<uint16_t> orders_host;
@@ -218,7 +218,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->kend, &c->block_recs, &c->tb_params, &c->tb_desc, &c->fb_params};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -498,6 +498,31 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   tp.scan_order = c->scan_order ? 1 : 0;
   tp.kend = c->kend.as<uint32_t>();
   tp.orders = c->pass_bufs[0].orders.as<uint16_t>();
+  tp.dequant_scan = nullptr;
+  if (c->scan_order) {
+    // dequant tables in scan order for the kinds in use
+    static const uint8_t kind_of[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+    static const uint8_t bucket_of[27] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+    std::vector<float> scan(d->dequant_floats, 0.0f);
+    for (int st = 0; st < 27; st++) {
+      if (!c->list_count[st]) continue;
+      const uint32_t kind = kind_of[st], size = d->dequant_size[kind];
+      for (int ch = 0; ch < 3; ch++) {
+        const uint32_t oo = d->passes[0].order_offset[bucket_of[st] * 3 + ch];
+        if (size_t(oo) + size > d->passes[0].orders_size) return JXLHIP_ERR_INVALID_ARGUMENT;
+        const uint16_t* order = d->passes[0].orders + oo;
+        const float* m = d->dequant + d->dequant_offset[kind] + size_t(ch) * size;
+        float* o = scan.data() + d->dequant_offset[kind] + size_t(ch) * size;
+        for (uint32_t k = 0; k < size; k++) {
+          if (order[k] >= size) return JXLHIP_ERR_INVALID_ARGUMENT;
+          o[k] = m[order[k]];
+        }
+      }
+    }
+    if ((r = Upload(c, c->dequant_scan, scan.data(), scan.size() * 4))) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `scan` is a local
+    tp.dequant_scan = c->dequant_scan.as<float>();
+  }
   memcpy(tp.order_offset, d->passes[0].order_offset, sizeof(tp.order_offset));
 
   jxlhip::FilterParams& fp = c->fp;
@@ -591,8 +616,8 @@ static uint32_t BlocksPerWG(int s) {
 
 template <typename CoefT, int CX, int CY>
 static int LaunchIdctCols(JxlHipContext* c0, int s) {
-  constexpr int C = CX * 8, SIZE = CX * CY * 64, GROUPS = 256 / C;
-  constexpr size_t lds = size_t(GROUPS) * (2 * SIZE + 4) * sizeof(float);
+  constexpr int C = CX * 8, R = CY * 8, SIZE = CX * CY * 64, GROUPS = 256 / C;
+  constexpr size_t lds = (size_t(GROUPS) * (2 * SIZE + 4) + R * R) * sizeof(float);
   auto k = jxlhip::k_idct_cols<CoefT, CX, CY>;
   if (lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
@@ -772,27 +797,27 @@ static int LaunchEntropyLanes(JxlHipContext* c0) {
   const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
   const size_t nwaves = size_t(c0->batch_wgs) * kLanesWPG;
   if (prof) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.prof), nwaves * 32));
-    HIP_TRY(hipMemsetAsync(b.prof, 0, nwaves * 32, c0->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.prof), nwaves * 64));
+    HIP_TRY(hipMemsetAsync(b.prof, 0, nwaves * 64, c0->stream));
   }
   hipLaunchKernelGGL(k, dim3(c0->batch_wgs), dim3(64 * kLanesWPG), c0->batch_lds, c0->stream, b);
   HIP_TRY(hipGetLastError());
   if (prof) {
-    std::vector<unsigned long long> h(nwaves * 4);
+    std::vector<unsigned long long> h(nwaves * 8);
     HIP_TRY(hipStreamSynchronize(c0->stream));
-    HIP_TRY(hipMemcpy(h.data(), b.prof, nwaves * 32, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), b.prof, nwaves * 64, hipMemcpyDeviceToHost));
     (void)hipFree(b.prof);
-    unsigned long long mx[4] = {0, 0, 0, 0};
-    double sum[4] = {0, 0, 0, 0};
+    unsigned long long mx[6] = {0, 0, 0, 0, 0, 0};
+    double sum[6] = {0, 0, 0, 0, 0, 0};
     size_t used = 0;
     for (size_t w = 0; w < nwaves; w++) {
-      if (!h[w * 4 + 3] && !h[w * 4 + 2]) continue;
+      if (!h[w * 8 + 3] && !h[w * 8 + 2]) continue;
       used++;
-      if (h[w * 4] > mx[0]) for (int j = 0; j < 4; j++) mx[j] = h[w * 4 + j];
-      for (int j = 0; j < 4; j++) sum[j] += double(h[w * 4 + j]);
+      if (h[w * 8] > mx[0]) for (int j = 0; j < 6; j++) mx[j] = h[w * 8 + j];
+      for (int j = 0; j < 6; j++) sum[j] += double(h[w * 8 + j]);
     }
-    fprintf(stderr, "[lanes prof] waves %zu  longest: cycles %llu service %llu (%llu calls) trips %llu | mean: cycles %.0f service %.0f calls %.0f trips %.0f\n",
-            used, mx[0], mx[1], mx[2], mx[3], sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used);
+    fprintf(stderr, "[lanes prof] waves %zu  longest: cycles %llu service %llu (%llu calls) trips %llu hot0 %llu hot1 %llu | mean: cycles %.0f service %.0f calls %.0f trips %.0f hot0 %.0f hot1 %.0f\n",
+            used, mx[0], mx[1], mx[2], mx[3], mx[4], mx[5], sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used, sum[4] / used, sum[5] / used);
   }
   return 0;
 }
@@ -837,7 +862,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     // measured ~900 + 20 * lanes cycles). The longest sections therefore go to sparsely populated waves and the short
     // ones are packed densely, with lane counts chosen so that all waves of a frame finish together.
     const bool graded = EnvInt("JXLHIP_GRADED", 1) != 0 && lanes_per_wave > 1;
-    const double cost_a = 900.0, cost_b = 20.0;
+    const double cost_a = double(EnvInt("JXLHIP_COST_A", 900)), cost_b = 20.0;
     uint32_t max_lanes = lanes_per_wave;
     std::vector<uint32_t> order, count;
     std::vector<std::vector<uint32_t>> frame_order(n), frame_count(n);

@@ -43,7 +43,7 @@ struct EntropyLaneBatch {
 
 // LDS layout of one workgroup (byte offsets, every region 16-byte aligned); the host sizes the launch with it.
 struct LanesLds {
-  uint32_t alias, ctx, lut, ctx2, sinfo, wave0, per_wave, total;
+  uint32_t alias, ctx, lut, ctx2, cfg, sinfo, wave0, per_wave, total;
 };
 // Per-wave LDS, all [row][lane] with a row stride of `lanes` entries (conflict-free, and a wave that populates few lanes
 // needs little LDS, which keeps room on the CU for the bandwidth-bound kernels running beside this one):
@@ -56,24 +56,27 @@ __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t n
   LanesLds l;
   l.alias = 0;
   l.ctx = (num_clusters << log_alpha) * 8;
-  l.lut = l.ctx + (((num_hist * nctx + 16) * 4 + 15) & ~15u);
+  l.lut = l.ctx + ((num_hist * nctx + 16 + 15) & ~15u);
   l.ctx2 = l.lut + ((lut_bytes + 15) & ~15u);
-  l.sinfo = l.ctx2 + 64 * 2;
+  l.cfg = l.ctx2 + 64 * 2;
+  l.sinfo = l.cfg + 256 * 2;
   l.wave0 = l.sinfo + 32 * 4;
   l.per_wave = kLanesPerLaneBytes * lanes;
   l.total = l.wave0 + waves * l.per_wave;
   return l;
 }
 
-// One rANS symbol + hybrid-uint extra bits for the calling lane. ctxe = split_exp | msb << 4 | lsb << 8 |
-// (byte offset of the cluster's alias table in LDS) << 12. `ring` points at the lane's column of the stream ring.
-__device__ __forceinline__ uint32_t LaneSymbol(uint32_t ctxe, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
-                                               const uint8_t* lds, uint32_t log_entry) {
+// One rANS symbol + hybrid-uint extra bits for the calling lane from histogram `cluster` (alias tables start at LDS
+// offset 0, 8 << log_alpha bytes per cluster; l_cfg[cluster] = split_exp | msb << 4 | lsb << 8). `ring` points at the
+// lane's column of the stream ring.
+__device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
+                                               const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry) {
+  const uint32_t ctxe = l_cfg[cluster];
   const uint32_t s0 = (bitpos >> 5) & (kLanesRingWords - 1);
   uint32_t w0 = ring[s0 * LS], w1 = ring[s0 * LS + LS];
   asm volatile("" : "+v"(w0), "+v"(w1));  // keep the window read here, next to the alias read (one LDS round trip)
   const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & ((1u << log_entry) - 1);
-  const uint2 e = *reinterpret_cast<const uint2*>(lds + (ctxe >> 12) + slot * 8);
+  const uint2 e = *reinterpret_cast<const uint2*>(lds + (cluster << (15 - log_entry)) + slot * 8);  // 8 << log_alpha per cluster
   const bool gt = pos >= (e.x >> 24);
   const uint32_t x = gt ? e.y : e.x;
   uint32_t tok = gt ? (x >> 24) : slot;
@@ -109,9 +112,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   const uint32_t LS = B.lanes;
   const LanesLds L = LanesLdsLayout(num_hist, nctx, nclusters, log_alpha, lut_bytes, WPG, LS);
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
-  uint32_t* l_ctx = reinterpret_cast<uint32_t*>(lds_raw + L.ctx);
+  uint8_t* l_ctx = lds_raw + L.ctx;                                      // context -> histogram (cluster)
+  uint16_t* l_cfg = reinterpret_cast<uint16_t*>(lds_raw + L.cfg);        // per cluster: split_exp | msb << 4 | lsb << 8
   uint8_t* l_lut = lds_raw + L.lut;
-  uint16_t* l_nnz8 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)] -> 8 * kCoeffNumNonzeroContext
+  uint16_t* l_nnz2 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)] -> 2 * kCoeffNumNonzeroContext
   uint8_t* l_nz = lds_raw + L.wave0 + wave * L.per_wave;             // line buffer of the per-block nzeros prediction
   uint32_t* ring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzRows * LS) + lane;                 // stream ring [slot][lane]
   uint32_t* bring = ring + (kLanesRingWords + 1) * LS;                                           // block records [slot][lane]
@@ -121,10 +125,12 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   {
     const uint32_t n_ctx = num_hist * nctx + 16;
     for (uint32_t i = tid; i < n_ctx; i += 64 * WPG) {
-      uint32_t cl = T.ctx_map[i];
-      cl = cl < nclusters ? cl : nclusters - 1;
-      const uint32_t cfg = T.cfg[cl];
-      l_ctx[i] = (cfg & 15) | (((cfg >> 8) & 15) << 4) | (((cfg >> 16) & 15) << 8) | ((cl << (log_alpha + 3)) << 12);
+      const uint32_t cl = T.ctx_map[i];
+      l_ctx[i] = uint8_t(cl < nclusters ? cl : nclusters - 1);
+    }
+    for (uint32_t i = tid; i < nclusters; i += 64 * WPG) {
+      const uint32_t cfg = T.cfg[i];
+      l_cfg[i] = uint16_t((cfg & 15) | (((cfg >> 8) & 15) << 4) | (((cfg >> 16) & 15) << 8));
     }
     // alias entry {cutoff u8, right u8, freq0 u16 | offsets1 u16, freq1 u16} ->
     //   x = (freq0 - 1) & 0xFFF | cutoff << 24                    taken when pos <  cutoff: symbol = slot, offset = pos
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       l_alias[i] = make_uint2(((freq0 - 1) & 0xFFFu) | (cutoff << 24), ((freq1 - 1) & 0xFFFu) | ((offs1 & 0xFFFu) << 12) | (right << 24));
     }
     for (uint32_t i = tid; i < lut_bytes; i += 64 * WPG) l_lut[i] = P.bctx_lut[i];
-    if (tid < 64) l_nnz8[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 8);
+    if (tid < 64) l_nnz2[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 2);
     if (tid < 27) reinterpret_cast<uint32_t*>(lds_raw + L.sinfo)[tid] = c_strategy_info[tid];
     uint32_t* z = reinterpret_cast<uint32_t*>(l_nz);
     for (uint32_t i = lane; i < kLanesNzRows * LS / 4; i += 64) z[i] = 0;
@@ -153,8 +159,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   const uint4* const rec4 = reinterpret_cast<const uint4*>(P.block_recs);
   uint32_t* const kend_out = P.kend;
   uint32_t nwords = 0, sec_size = 0, ring_end = 0, bring_end = 0, bitpos = 0, state = 0, ctx_base = 0;
-  bool started = false, pend_s = false, pend_b = false;
-  uint4 pf_s = make_uint4(0, 0, 0, 0), pf_b = make_uint4(0, 0, 0, 0);
+  bool started = false;
   if (mode == kWait) {
     bi = P.gbb[g] - 1;  // the first transition advances to the group's first block
     b1 = P.gbb[g + 1];
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   CoefT* const coeffs = static_cast<CoefT*>(P.coeffs);
   const uint32_t shift = T.shift;
 
-  unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0;
+  unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, t_hot0 = 0, t_hot1 = 0;
   if (B.prof) t_begin = __builtin_readcyclecounter();
   for (;;) {
     const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 5;  // two hot trips consume at most 4 ring words
@@ -184,26 +189,14 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       // ================================================================= service phase
       unsigned long long t0 = 0;
       if (B.prof) t0 = __builtin_readcyclecounter();
-      // (1) land the prefetches issued by the previous service phase (their latency was hidden behind hot trips)
-      if (pend_s) {
-        pend_s = false;
-        const uint32_t s = ring_end & (kLanesRingWords - 1);
-        ring[(s + 0) * LS] = ring_end + 0 < nwords ? pf_s.x : 0;  // reads past the section are zeros
-        ring[(s + 1) * LS] = ring_end + 1 < nwords ? pf_s.y : 0;
-        ring[(s + 2) * LS] = ring_end + 2 < nwords ? pf_s.z : 0;
-        ring[(s + 3) * LS] = ring_end + 3 < nwords ? pf_s.w : 0;
-        if (s == 0) ring[kLanesRingWords * LS] = ring_end < nwords ? pf_s.x : 0;  // mirror row: a 2-word read at slot 15 needs no wrap
-        ring_end += 4;
-      }
-      if (pend_b) {
-        pend_b = false;
-        const uint32_t s = bring_end & (kLanesBlockRing - 1);
-        bring[(s + 0) * LS] = pf_b.x;
-        bring[(s + 1) * LS] = pf_b.y;
-        bring[(s + 2) * LS] = pf_b.z;
-        bring[(s + 3) * LS] = pf_b.w;
-        bring_end += 4;
-      }
+      // (1) issue this phase's ring refills first: their HBM latency overlaps the transition work below, and no load
+      // is left in flight when the hot loop resumes (a pending load would make the compiler drain vmcnt, i.e. wait for
+      // the previous iteration's coefficient stores, at the top of every hot-loop iteration)
+      const bool want_s = mode != kDone && (ring_end - (bitpos >> 5)) <= kLanesRingWords - 4;
+      const bool want_b = mode != kDone && bring_end < b1 && bring_end + 4 - (bi + 1) <= kLanesBlockRing;
+      uint4 pf_s = make_uint4(0, 0, 0, 0), pf_b = make_uint4(0, 0, 0, 0);
+      if (want_s) pf_s = stream4[ring_end >> 2];
+      if (want_b) pf_b = rec4[bring_end >> 2];
       // (2) block / channel transitions of the waiting lanes, including the block's non-zero-count symbol
       const bool next_block = ci == 2 && started;  // the coming transition moves on to block bi + 1
       if (mode == kWait && (ring_end - (bitpos >> 5)) >= 3 && (!next_block || bi + 1 < bring_end || bi + 1 >= b1)) {
@@ -252,7 +245,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
             const uint32_t bctx = l_lut[((c * 13 + ord) * nq + qfi) * ndc + dcctx];
             uint32_t nzb = pred >= 64 ? 64 : pred;
             nzb = nzb < 8 ? nzb : 4 + nzb / 2;
-            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, lds_raw, log_entry);
+            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, lds_raw, l_cfg, log_entry);
             log2c = (info >> 16) & 0xFF;
             const uint32_t covered = 1u << log2c;
             size = covered * 64;
@@ -269,26 +262,35 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
                 nzeros = tok;
                 k = covered;
                 covm1 = covered - 1;
-                cbase = L.ctx + (ctx_base + num_bctx * 37 + 458 * bctx) * 4;
+                cbase = L.ctx + ctx_base + num_bctx * 37 + 458 * bctx;
                 dptr = (g * 3 + c) * 65536 + coef_offset + covered;
                 const uint32_t prev = nzeros > size / 16 ? 0 : 1;
-                addr_a = cbase + l_nnz8[((nzeros + covm1) >> log2c) & 63];
-                addr_b = cbase + l_nnz8[((nzeros - 1 + covm1) >> log2c) & 63] + 4;
-                ctxe = *reinterpret_cast<const uint32_t*>(lds_raw + addr_a + prev * 4);  // frequency context of k = covered is 0
+                addr_a = cbase + l_nnz2[((nzeros + covm1) >> log2c) & 63];
+                addr_b = cbase + l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63] + 1;
+                ctxe = lds_raw[addr_a + prev];  // frequency context of k = covered is 0
                 mode = kRun;
               }
             }
           }
         }
       }
-      // (3) issue the next prefetches; they are consumed by the next service phase
-      if (mode != kDone && (ring_end - (bitpos >> 5)) <= kLanesRingWords - 4) {
-        pf_s = stream4[ring_end >> 2];
-        pend_s = true;
+      // (3) land the refills in the LDS rings
+      if (want_s) {
+        const uint32_t s = ring_end & (kLanesRingWords - 1);
+        ring[(s + 0) * LS] = ring_end + 0 < nwords ? pf_s.x : 0;  // reads past the section are zeros
+        ring[(s + 1) * LS] = ring_end + 1 < nwords ? pf_s.y : 0;
+        ring[(s + 2) * LS] = ring_end + 2 < nwords ? pf_s.z : 0;
+        ring[(s + 3) * LS] = ring_end + 3 < nwords ? pf_s.w : 0;
+        if (s == 0) ring[kLanesRingWords * LS] = ring_end < nwords ? pf_s.x : 0;  // mirror row: a 2-word read at slot 15 needs no wrap
+        ring_end += 4;
       }
-      if (mode != kDone && bring_end < b1 && bring_end + 4 - (bi + 1) <= kLanesBlockRing) {
-        pf_b = rec4[bring_end >> 2];
-        pend_b = true;
+      if (want_b) {
+        const uint32_t s = bring_end & (kLanesBlockRing - 1);
+        bring[(s + 0) * LS] = pf_b.x;
+        bring[(s + 1) * LS] = pf_b.y;
+        bring[(s + 2) * LS] = pf_b.z;
+        bring[(s + 3) * LS] = pf_b.w;
+        bring_end += 4;
       }
       if (B.prof) {
         t_service += __builtin_readcyclecounter() - t0;
@@ -298,17 +300,24 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
     }
     // =================================================================== hot trips: one coefficient token per lane each
     n_trips += 2;
+    unsigned long long th = 0;
+    if (B.prof) th = __builtin_readcyclecounter();
 #pragma unroll
     for (int rep = 0; rep < 2; rep++) {
+      if (B.prof && rep == 1) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        t_hot0 += now - th;
+        th = now;
+      }
       if (mode == kRun && !low) {
         // context entries of coefficient k + 1 for both outcomes of this one (off the serial chain);
         // kCoeffFreqContext(b) for b = (k + 1) / covered in 1..63 is min(b - 1, 7 + b / 2, 15 + b / 4)
         const uint32_t kn = k + 1;
         const uint32_t b = kn >> log2c;
-        const uint32_t f8 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 3;
-        const uint32_t e_zero = *reinterpret_cast<const uint32_t*>(lds_raw + addr_a + f8);
-        const uint32_t e_nonzero = *reinterpret_cast<const uint32_t*>(lds_raw + addr_b + f8);
-        const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, LS, lds_raw, log_entry);
+        const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
+        const uint32_t e_zero = lds_raw[addr_a + f2];
+        const uint32_t e_nonzero = lds_raw[addr_b + f2];
+        const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, LS, lds_raw, l_cfg, log_entry);
         const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
         const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
         coeffs[dptr] = CoefT(coeff);
@@ -317,8 +326,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
         const bool nz = tok != 0;
         nzeros -= nz ? 1u : 0u;
         ctxe = nz ? e_nonzero : e_zero;
-        addr_a = nz ? addr_b - 4 : addr_a;
-        addr_b = cbase + l_nnz8[((nzeros - 1 + covm1) >> log2c) & 63] + 4;
+        addr_a = nz ? addr_b - 1 : addr_a;
+        addr_b = cbase + l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63] + 1;
         if (nzeros == 0) {
           kend_out[kidx] = k;
           mode = kWait;
@@ -328,9 +337,12 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
         }
       }
     }
+    if (B.prof) t_hot1 += __builtin_readcyclecounter() - th;
   }
   if (B.prof && lane == 0) {
-    unsigned long long* o = B.prof + size_t(blockIdx.x * WPG + wave) * 4;
+    unsigned long long* o = B.prof + size_t(blockIdx.x * WPG + wave) * 8;
+    o[4] = t_hot0;
+    o[5] = t_hot1;
     o[0] = __builtin_readcyclecounter() - t_begin;
     o[1] = t_service;
     o[2] = n_service;

@@ -628,6 +628,8 @@ struct TransformParams {
   const uint32_t* kend;    // [block * 3 + channel]
   const uint16_t* orders;  // pass 0 coefficient orders
   uint32_t order_offset[39];
+  const float* dequant_scan;  // the dequant tables permuted into scan order: [dq_offset[kind] + c * dq_size[kind] + k] =
+                              // dequant[... + orders[k]] (scan_order frames; lets the staging loop run without a dependent gather)
   // transform work lists: block indices bucketed by strategy (tlist[list_begin[s] .. + list_count[s]))
   const uint32_t* tlist;
   uint32_t list_begin[27], list_count[27];
@@ -787,8 +789,8 @@ __global__ __launch_bounds__(256) void k_dct(const TransformParams* params, cons
 //     stage's valid scan-order prefix is scattered through the coefficient order);
 //   * row pass:    tmp[ky] = sum_kx coef[ky][kx] * B_C[kx][x]   -- the thread keeps its basis column B_C[:][x] in
 //     registers and reads coefficient rows as LDS broadcasts (one ds_read_b128 per 4 FMAs, same address for the group);
-//   * column pass: out[y][x] = sum_ky tmp[ky] * B_R[ky][y]      -- tmp[] never leaves registers and the basis is
-//     wave-uniform, so it comes from the scalar cache (SGPR operands), no LDS and no second barrier;
+//   * column pass: out[y][x] = sum_ky tmp[ky] * B_R[ky][y]      -- tmp[] never leaves registers, the basis rows are LDS
+//     broadcasts as well (scalar-cache loads were measured to serialise on their latency), no second barrier;
 //   * row y of the block is written by the C threads of the group as one contiguous segment.
 typedef const float __attribute__((address_space(4)))* CF32;
 
@@ -798,7 +800,8 @@ __global__ __launch_bounds__(256) void k_idct_cols(const TransformParams* params
   constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, GSTRIDE = 2 * SIZE + 4;
   extern __shared__ __align__(16) float lds_f[];
   const int grp = threadIdx.x / C, x = threadIdx.x % C;
-  float* l_y = lds_f + grp * GSTRIDE;  // dequantised Y stays resident for the chroma-from-luma of X and B
+  float* l_bn = lds_f;                          // column-pass basis [y][ky], read as broadcasts
+  float* l_y = lds_f + R * R + grp * GSTRIDE;  // dequantised Y stays resident for the chroma-from-luma of X and B
   float* l_xb = l_y + SIZE;
   const uint32_t li = wgd.y + grp;
   const bool active = li < n;
@@ -827,7 +830,10 @@ __global__ __launch_bounds__(256) void k_idct_cols(const TransformParams* params
 #pragma unroll
     for (int kx = 0; kx < C; kx++) breg[kx] = bt[kx * C + x];
   }
-  const CF32 bn = (CF32)(uintptr_t)(P.basis_n + BasisOffset(R));  // [y * R + ky]
+  {
+    const float* bn = P.basis_n + BasisOffset(R);  // [y * R + ky]
+    for (int i = threadIdx.x; i < R * R; i += 256) l_bn[i] = bn[i];
+  }
   const uint32_t ord = c_strategy_order[strategy];
   for (int ci = 0; ci < 3; ci++) {
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
@@ -848,20 +854,29 @@ __global__ __launch_bounds__(256) void k_idct_cols(const TransformParams* params
       const float mul = c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm);
       const CoefT* gqc = gq + size_t(c) * 65536;
       const float* mc = m + size_t(c) * msize;
-      uint32_t k0 = x, k1 = SIZE;
-      const uint16_t* order = nullptr;
       if (P.scan_order) {
-        order = P.orders + P.order_offset[ord * 3 + c];
+        // entry k: coefficient, its position and its dequant weight are three independent coalesced loads
+        const uint16_t* order = P.orders + P.order_offset[ord * 3 + c];
+        const float* ms = P.dequant_scan + (mc - P.dequant);
         const uint32_t ke = P.kend[bidx * 3 + c];
-        k0 = CX * CY + x;
-        k1 = ke < uint32_t(SIZE) ? ke : uint32_t(SIZE);
-      }
-      for (uint32_t k = k0; k < k1; k += C) {
-        const int q = int(gqc[k]);
-        if (q) {
-          const uint32_t pos = order ? order[k] : k;
-          const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
-          l[idx] += QuantBias(c, q, P.biases) * (mc[pos] * mul);
+        const uint32_t k1 = ke < uint32_t(SIZE) ? ke : uint32_t(SIZE);
+#pragma unroll 4
+        for (uint32_t k = CX * CY + x; k < k1; k += C) {
+          const int q = int(gqc[k]);
+          const uint32_t pos = order[k];
+          const float w = ms[k];
+          if (q) {
+            const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
+            l[idx] += QuantBias(c, q, P.biases) * (w * mul);
+          }
+        }
+      } else {
+        for (uint32_t k = x; k < uint32_t(SIZE); k += C) {
+          const int q = int(gqc[k]);
+          if (q) {
+            const uint32_t idx = R < C ? k : (k % R) * C + k / R;
+            l[idx] += QuantBias(c, q, P.biases) * (mc[k] * mul);
+          }
         }
       }
       if (x < CX * CY) {  // lowest frequencies from the DC image
@@ -891,7 +906,13 @@ __global__ __launch_bounds__(256) void k_idct_cols(const TransformParams* params
       for (int y = 0; y < R; y++) {
         float acc = 0.0f;
 #pragma unroll
-        for (int ky = 0; ky < R; ky++) acc += tmp[ky] * bn[y * R + ky];
+        for (int k4 = 0; k4 < R; k4 += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(l_bn + y * R + k4);
+          acc += tmp[k4] * v.x;
+          acc += tmp[k4 + 1] * v.y;
+          acc += tmp[k4 + 2] * v.z;
+          acc += tmp[k4 + 3] * v.w;
+        }
         out[size_t(y) * P.xp] = acc;
       }
     }
