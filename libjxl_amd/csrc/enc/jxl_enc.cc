@@ -523,7 +523,8 @@ struct Params {
   int32_t skip_dc_smoothing;
   int32_t random_cmap;     // random chroma-from-luma factors (always on in random mode)
   int32_t zero_ac;         // random mode: leave every AC coefficient zero (DC-only stream)
-  int32_t reserved[5];
+  int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
+  int32_t reserved[4];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -607,6 +608,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   // ---- tokenise AC groups
   jxh::BlockCtxMap bctx;
   const size_t nctx = bctx.NumACContexts();
+  const size_t num_hist = (p.num_histograms > 1 && num_groups > 1) ? std::min<size_t>(size_t(p.num_histograms), num_groups) : 1;
   std::vector<std::vector<Token>> ac_tokens(num_groups);
   std::vector<std::vector<uint32_t>> natural(13);
   for (int s = 0; s < 27; s++)
@@ -639,13 +641,14 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
           size_t nz = 0;
           for (size_t k = covered; k < size; k++) nz += q[order[k]] != 0;
           size_t bc = bctx.Context(0, qf, ord, c);
-          out_t.push_back({uint32_t(bctx.NonZeroContext(uint32_t(pred), bc)), uint32_t(nz)});
+          const size_t hist_off = (g % num_hist) * nctx;  // this group's histogram set
+          out_t.push_back({uint32_t(hist_off + bctx.NonZeroContext(uint32_t(pred), bc)), uint32_t(nz)});
           for (size_t y = 0; y < cy; y++)
             for (size_t x = 0; x < cx; x++) cur[bx + x + y * 32] = int32_t((nz + covered - 1) >> log2c);
           const size_t hoff = bctx.ZeroDensityOffset(bc);
           size_t prev = nz > size / 16 ? 0 : 1, left = nz;
           for (size_t k = covered; k < size && left != 0; k++) {
-            size_t ctx = hoff + jxh::ZeroDensityContext(left, k, covered, log2c, prev);
+            size_t ctx = hist_off + hoff + jxh::ZeroDensityContext(left, k, covered, log2c, prev);
             int32_t v = q[order[k]];
             out_t.push_back({uint32_t(ctx), PackSigned(v)});
             prev = v != 0;
@@ -659,7 +662,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   {
     std::vector<const std::vector<Token>*> all;
     for (auto& t : ac_tokens) all.push_back(&t);
-    BuildCode(all, nctx, p.max_clusters > 0 ? size_t(p.max_clusters) : 64, cfg420, &ac_code);
+    BuildCode(all, nctx * num_hist, p.max_clusters > 0 ? size_t(p.max_clusters) : 64, cfg420, &ac_code);
   }
   // ---- sections
   auto write_dc_global = [&](BitWriter& bw) {
@@ -696,11 +699,14 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   };
   auto write_ac_global = [&](BitWriter& bw) {
     bw.Write(1, 1);                            // default dequant tables
-    bw.Write(CeilLog2(num_groups), 0);         // one histogram set
+    bw.Write(CeilLog2(num_groups), uint32_t(num_hist - 1));  // number of histogram sets - 1
     bw.Write(2, 2);                            // used_orders = 0
     WriteCodeHeader(bw, ac_code);
   };
-  auto write_ac_group = [&](BitWriter& bw, size_t g) { WriteTokens(bw, ac_tokens[g].data(), ac_tokens[g].size(), ac_code); };
+  auto write_ac_group = [&](BitWriter& bw, size_t g) {
+    bw.Write(CeilLog2(num_hist), uint32_t(g % num_hist));  // histogram selector (dec_group.cc:594-610)
+    WriteTokens(bw, ac_tokens[g].data(), ac_tokens[g].size(), ac_code);
+  };
 
   std::vector<std::vector<uint8_t>> sections;
   if (num_groups == 1) {
@@ -1131,7 +1137,8 @@ struct JxlEncParams {
   int32_t epf_iters, gab, strategy_mode;
   uint32_t strategy_mask, seed;
   int32_t max_clusters, skip_dc_smoothing, random_cmap, zero_ac;
-  int32_t reserved[5];
+  int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
+  int32_t reserved[4];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

@@ -84,7 +84,7 @@ struct JxlHipContext {
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
   uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64;
   int batch_kernel = -1;
-  std::vector<uint32_t> sec_size_host, pass_clusters, pass_log_alpha;
+  std::vector<uint32_t> sec_size_host, sec_sel_host, pass_clusters, pass_log_alpha;
   // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
   // band decode: groups this context decodes (band + one group row either side), pixel rows it produces
   std::vector<uint32_t> group_list;
@@ -142,7 +142,7 @@ static int EnvInt(const char* name, int def) {
 }
 
 static size_t LanesLdsFor(const JxlHipContext* c, uint32_t lanes = 64) {
-  return jxlhip::LanesLdsLayout(c->ep.num_hist, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc,
+  return jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc,
                                 kLanesWPG, lanes).total;
 }
 
@@ -322,6 +322,19 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = Upload(c, c->sec_word, sec_word.data(), nsec * 4))) return r;
   if ((r = Upload(c, c->sec_size, sec_size.data(), nsec * 4))) return r;
   c->sec_size_host = sec_size;
+  {
+    // histogram selector of every first-pass section: its first ceil(log2(num_histograms)) bits (dec_group.cc:594-610)
+    uint32_t hb = 0;
+    while ((1u << hb) < d->num_histograms) hb++;
+    c->sec_sel_host.assign(d->num_groups, 0);
+    for (uint32_t g = 0; hb && g < d->num_groups; g++) {
+      const uint8_t* p = d->codestream + d->section_offset[g];
+      const uint32_t bit0 = g == 0 ? d->first_section_bit_offset : 0;
+      uint64_t v = 0;
+      for (uint32_t b = 0; b < 8 && b < d->section_size[g]; b++) v |= uint64_t(p[b]) << (8 * b);
+      c->sec_sel_host[g] = uint32_t((v >> bit0) & ((1u << hb) - 1));
+    }
+  }
   c->pass_clusters.assign(d->num_passes, 0);
   c->pass_log_alpha.assign(d->num_passes, 0);
   // the staging vectors die at the end of this call: finish these copies now
@@ -864,51 +877,64 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     const bool graded = EnvInt("JXLHIP_GRADED", 1) != 0 && lanes_per_wave > 1;
     const double cost_a = double(EnvInt("JXLHIP_COST_A", 900)), cost_b = 20.0;
     uint32_t max_lanes = lanes_per_wave;
-    std::vector<uint32_t> order, count;
-    std::vector<std::vector<uint32_t>> frame_order(n), frame_count(n);
-    std::vector<uint32_t> frame_wg0(n);
+    // A workgroup stages ONE histogram set's slice of the context map: its sections must share the frame and the
+    // histogram selector (read from the first bits of every section at upload). unit = (frame, selector).
+    struct Unit {
+      uint32_t frame, sel, wg0;
+      std::vector<uint32_t> order, count;
+    };
+    std::vector<Unit> units;
+    std::vector<uint32_t> count;
     for (size_t i = 0; i < n; i++) {
       const JxlHipContext* c = ctxs[i];
-      frame_wg0[i] = uint32_t(map.size());
-      const uint32_t ng = uint32_t(c->group_list.size());
-      const uint32_t wgs = (ng + per_wg - 1) / per_wg;
-      for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i));
-      order = c->group_list;
       const uint32_t* sz = c->sec_size_host.data();
-      std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
-      const uint32_t waves = wgs * kLanesWPG;
-      count.assign(waves, 0);
-      bool done = false;
-      if (graded && ng > waves) {
-        // smallest finish time T such that filling the waves in order with floor((T / longest - a) / b) sections fits
-        double lo = 0.0, hi = double(sz[order[0]] + 1) * (cost_a + cost_b * 64.0);
-        for (int it = 0; it < 40; it++) {
-          const double T = 0.5 * (lo + hi);
+      for (uint32_t sel = 0; sel < c->ep.num_hist; sel++) {
+        Unit u;
+        u.frame = uint32_t(i);
+        u.sel = sel;
+        for (uint32_t g : c->group_list)
+          if (c->sec_sel_host[g] == sel || (sel == 0 && c->sec_sel_host[g] >= c->ep.num_hist)) u.order.push_back(g);
+        if (u.order.empty()) continue;
+        u.wg0 = uint32_t(map.size());
+        const uint32_t ng = uint32_t(u.order.size());
+        const uint32_t wgs = (ng + per_wg - 1) / per_wg;
+        for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i) | sel << 16);
+        std::vector<uint32_t>& order = u.order;
+        std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
+        const uint32_t waves = wgs * kLanesWPG;
+        count.assign(waves, 0);
+        bool done = false;
+        if (graded && ng > waves) {
+          // smallest finish time T such that filling the waves in order with floor((T / longest - a) / b) sections fits
+          double lo = 0.0, hi = double(sz[order[0]] + 1) * (cost_a + cost_b * 64.0);
+          for (int it = 0; it < 40; it++) {
+            const double T = 0.5 * (lo + hi);
+            uint32_t j = 0;
+            for (uint32_t w = 0; w < waves && j < ng; w++) {
+              const double room = (T / double(sz[order[j]] + 1) - cost_a) / cost_b;
+              const uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
+              j += take;
+            }
+            if (j >= ng) hi = T; else lo = T;
+          }
           uint32_t j = 0;
           for (uint32_t w = 0; w < waves && j < ng; w++) {
-            const double room = (T / double(sz[order[j]] + 1) - cost_a) / cost_b;
-            const uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
+            const double room = (hi / double(sz[order[j]] + 1) - cost_a) / cost_b;
+            uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
+            take = take > ng - j ? ng - j : take;
+            count[w] = take;
             j += take;
           }
-          if (j >= ng) hi = T; else lo = T;
+          done = j >= ng;
         }
-        uint32_t j = 0;
-        for (uint32_t w = 0; w < waves && j < ng; w++) {
-          const double room = (hi / double(sz[order[j]] + 1) - cost_a) / cost_b;
-          uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
-          take = take > ng - j ? ng - j : take;
-          count[w] = take;
-          j += take;
+        if (!done) {
+          count.assign(waves, 0);
+          for (uint32_t j = 0; j < ng; j++) count[j / lanes_per_wave]++;
         }
-        done = j >= ng;
+        for (uint32_t w = 0; w < waves; w++) max_lanes = count[w] > max_lanes ? count[w] : max_lanes;
+        u.count = count;
+        units.push_back(std::move(u));
       }
-      if (!done) {
-        count.assign(waves, 0);
-        for (uint32_t j = 0; j < ng; j++) count[j / lanes_per_wave]++;
-      }
-      for (uint32_t w = 0; w < waves; w++) max_lanes = count[w] > max_lanes ? count[w] : max_lanes;
-      frame_order[i] = order;
-      frame_count[i] = count;
     }
     uint32_t stride = 1;  // row stride of the per-wave LDS regions
     while (stride < max_lanes) stride *= 2;
@@ -917,9 +943,11 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     for (size_t i = 0; i < n; i++) {
       const size_t l = LanesLdsFor(ctxs[i], stride);
       lds = l > lds ? l : lds;
+    }
+    for (const Unit& u : units) {
       uint32_t j = 0;
-      for (size_t w = 0; w < frame_count[i].size(); w++)
-        for (uint32_t k = 0; k < frame_count[i][w]; k++) lanes[(size_t(frame_wg0[i]) * kLanesWPG + w) * 64 + k] = frame_order[i][j++];
+      for (size_t w = 0; w < u.count.size(); w++)
+        for (uint32_t k = 0; k < u.count[w]; k++) lanes[(size_t(u.wg0) * kLanesWPG + w) * 64 + k] = u.order[j++];
     }
   } else {
     for (size_t i = 0; i < n; i++) {

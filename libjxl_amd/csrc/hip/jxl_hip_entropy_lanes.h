@@ -34,7 +34,7 @@ namespace jxlhip {
 
 struct EntropyLaneBatch {
   const EntropyParams* params;  // one per frame of the batch (device memory)
-  const uint32_t* wg_frame;     // per workgroup: index into params
+  const uint32_t* wg_frame;     // per workgroup: index into params | histogram selector of its sections << 16
   const uint32_t* lane_group;   // per lane of every wave: group (AC section) index in its frame, 0xFFFFFFFF = idle lane
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
   uint32_t lanes;               // populated lanes per wave (power of two): lanes >= this are idle; strides the per-wave LDS
@@ -104,13 +104,15 @@ template <typename CoefT, int WPG>
 __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const EntropyParams& P = B.params[B.wg_frame[blockIdx.x]];
+  const uint32_t wg_desc = B.wg_frame[blockIdx.x];
+  const uint32_t wg_sel = wg_desc >> 16;  // the histogram set this workgroup's sections use
+  const EntropyParams& P = B.params[wg_desc & 0xFFFF];
   const PassDev& T = P.passes[0];
   const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, nclusters = T.num_clusters;
   const uint32_t nq = P.nq, ndc = P.ndc, num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
   const uint32_t lut_bytes = 39 * nq * ndc;
   const uint32_t LS = B.lanes;
-  const LanesLds L = LanesLdsLayout(num_hist, nctx, nclusters, log_alpha, lut_bytes, WPG, LS);
+  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, lut_bytes, WPG, LS);
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
   uint8_t* l_ctx = lds_raw + L.ctx;                                      // context -> histogram (cluster)
   uint16_t* l_cfg = reinterpret_cast<uint16_t*>(lds_raw + L.cfg);        // per cluster: split_exp | msb << 4 | lsb << 8
@@ -123,9 +125,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
 
   // ---- stage the frame's tables (whole workgroup)
   {
-    const uint32_t n_ctx = num_hist * nctx + 16;
+    const uint32_t n_ctx = nctx + 16;  // the selected set's slice of the context map
+    const uint8_t* ctx_slice = T.ctx_map + size_t(wg_sel) * nctx;
     for (uint32_t i = tid; i < n_ctx; i += 64 * WPG) {
-      const uint32_t cl = T.ctx_map[i];
+      const uint32_t cl = ctx_slice[i];
       l_ctx[i] = uint8_t(cl < nclusters ? cl : nclusters - 1);
     }
     for (uint32_t i = tid; i < nclusters; i += 64 * WPG) {
@@ -207,11 +210,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
           const uint32_t w0 = ring[0], w1 = ring[LS];
           const uint64_t win = ((uint64_t(w1) << 32) | w0) >> bitpos;  // bitpos < 8 here
           uint32_t sel = hb ? uint32_t(win) & ((1u << hb) - 1) : 0;
-          if (sel >= num_hist) {
-            err = kErrSelector;
-            sel = 0;
-          }
-          ctx_base = sel * nctx;
+          if (sel != wg_sel) err = kErrSelector;  // (the host packed the section by the selector it read: cannot differ)
+          ctx_base = 0;
           state = uint32_t(win >> hb);
           bitpos += hb + 32;
         } else {

@@ -69,6 +69,8 @@ def _compare(J, jxlo, data, check_rgb=True):
     ((520, 300), dict(epf_iters=0, gab=0)),               # no filters
     ((777, 513), dict(strategy_mode=2, random_cmap=1)),   # random DCT-family tiling up to 256x256, random CfL
     ((300, 200), dict(skip_dc_smoothing=1)),
+    ((1000, 700), dict(num_histograms=3)),                # several AC histogram sets (libjxl's streaming encoder)
+    ((1300, 1100), dict(num_histograms=30, strategy_mode=2, distance=2.0)),  # one set per group
 ])
 def test_image_streams(built, size, kw):
     import jxlo
