@@ -524,7 +524,8 @@ struct Params {
   int32_t random_cmap;     // random chroma-from-luma factors (always on in random mode)
   int32_t zero_ac;         // random mode: leave every AC coefficient zero (DC-only stream)
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
-  int32_t reserved[4];
+  int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
+  int32_t reserved[3];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -1118,6 +1119,7 @@ static void EncodeRandom(size_t xs, size_t ys, const Params& p, std::vector<uint
             if (rng.Uniform() < density * std::exp(-2.5f * freq)) {
               int mag = 1 + int(rng.Below(3) == 0 ? rng.Below(6) : 0);
               if (rng.Below(64) == 0) mag += int(rng.Below(40));
+              if (p.big_coeffs && rng.Below(256) == 0) mag = 40000 + int(rng.Below(200000));
               q[k] = rng.Below(2) ? mag : -mag;
             }
           }
@@ -1138,7 +1140,8 @@ struct JxlEncParams {
   uint32_t strategy_mask, seed;
   int32_t max_clusters, skip_dc_smoothing, random_cmap, zero_ac;
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
-  int32_t reserved[4];
+  int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
+  int32_t reserved[3];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

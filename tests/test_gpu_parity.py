@@ -149,6 +149,49 @@ def test_lane_packing_of_sections(built, lanes, wait_shift, monkeypatch):
             o.close()
 
 
+def test_randomized_parity_sweep(built):
+    """A short run of scripts/fuzz_parity.py: random sizes, distances, filter settings, strategy sets, histogram counts."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "12", "3"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_int32_coefficient_storage(built):
+    """Streams whose histograms allow magnitudes beyond 15 bits make the decoder store int32 coefficients
+    (dec_frame.cc:412-429); the entropy stage must stay bit-exact and the later stages must take the same layout."""
+    import jxlo
+    J = built
+    data = J.encode_random(700, 520, seed=8, big_coeffs=1)
+    f = J.Frame(data, threads=2)
+    assert f.info["coef_bits"] == 32
+    o = jxlo.Decoded(data)
+    c = J.HipContext()
+    try:
+        c.set_option("keep_filtered", 1)
+        c.upload(f)
+        c.run_all()
+        c.sync()
+        r, flags = c.errors()
+        assert r == 0 and not any(flags)
+        co = c.download("coeffs")
+        assert co.dtype == np.int32 and np.abs(co).max() > 40000
+        ref = o.planes("coeffs")
+        used = _used_mask(o)
+        for g in range(o.info["num_groups"]):
+            assert np.array_equal(co[g, :, :used[g]], ref[g, :, :used[g]]), "coefficients differ in group %d" % g
+        # pixel values are huge here: compare the transform output relative to the block's own dynamic range
+        x, xr = c.download("xyb_idct"), o.planes("xyb_idct")
+        assert np.abs(x - xr).max() <= 1e-5 * max(1.0, float(np.abs(xr).max()))
+    finally:
+        c.close()
+        f.close()
+        o.close()
+
+
 def test_batched_entropy_launch(built):
     """jxlhip_run_entropy_batch: frames of different geometry in one launch decode exactly as one by one, the batch
     description follows a re-upload, and the per-frame stages after it see the batch's coefficients."""
