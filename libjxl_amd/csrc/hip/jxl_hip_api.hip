@@ -622,20 +622,20 @@ static int RunEntropySingle(JxlHipContext* c) {
 // Varblocks a workgroup of the strategy's kernel handles.
 static uint32_t BlocksPerWG(int s) {
   static const uint8_t cx[27] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
-  if (s == 0 || (s >= 4 && s <= 11)) return 256 / (cx[s] * 8);  // k_idct_cols: 8 * covered_x threads per varblock
+  if (s == 0 || (s >= 4 && s <= 11)) return jxlhip::kIdctColsThreads / (cx[s] * 8);  // k_idct_cols: 8 * covered_x threads per varblock
   if (s >= 18 && s <= 20) return 1;                               // k_dct 64-class
   return 4;                                                       // k_special
 }
 
 template <typename CoefT, int CX, int CY>
 static int LaunchIdctCols(JxlHipContext* c0, int s) {
-  constexpr int C = CX * 8, R = CY * 8, SIZE = CX * CY * 64, GROUPS = 256 / C;
+  constexpr int C = CX * 8, R = CY * 8, SIZE = CX * CY * 64, GROUPS = jxlhip::kIdctColsThreads / C;
   constexpr size_t lds = (size_t(GROUPS) * (2 * SIZE + 4) + R * R) * sizeof(float);
   auto k = jxlhip::k_idct_cols<CoefT, CX, CY>;
   if (lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-  hipLaunchKernelGGL(k, dim3(c0->desc_count[s]), dim3(256), lds, c0->stream, c0->tb_params.as<jxlhip::TransformParams>(),
-                     c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));
+  hipLaunchKernelGGL(k, dim3(c0->desc_count[s]), dim3(jxlhip::kIdctColsThreads), lds, c0->stream,
+                     c0->tb_params.as<jxlhip::TransformParams>(), c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));
   return 0;
 }
 
@@ -806,6 +806,7 @@ static int LaunchEntropyLanes(JxlHipContext* c0) {
   b.lane_group = c0->batch_lanes.as<uint32_t>();
   b.wait_shift = c0->batch_wait_shift;
   b.lanes = c0->batch_lanes_per_wave;
+  b.debug = uint32_t(EnvInt("JXLHIP_LANES_DEBUG", 0));
   b.prof = nullptr;
   const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
   const size_t nwaves = size_t(c0->batch_wgs) * kLanesWPG;

@@ -38,6 +38,7 @@ struct EntropyLaneBatch {
   const uint32_t* lane_group;   // per lane of every wave: group (AC section) index in its frame, 0xFFFFFFFF = idle lane
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
   uint32_t lanes;               // populated lanes per wave (power of two): lanes >= this are idle; strides the per-wave LDS
+  uint32_t debug;               // measurement aid: bit 0 = skip the coefficient stores (results are then invalid)
   unsigned long long* prof;     // optional (may be NULL): per wave {cycles total, cycles in service, services, hot trips}
 };
 
@@ -70,11 +71,14 @@ __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t n
 // offset 0, 8 << log_alpha bytes per cluster; l_cfg[cluster] = split_exp | msb << 4 | lsb << 8). `ring` points at the
 // lane's column of the stream ring.
 __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
-                                               const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry) {
+                                               uint32_t log_ls, const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry) {
   const uint32_t ctxe = l_cfg[cluster];
-  const uint32_t s0 = (bitpos >> 5) & (kLanesRingWords - 1);
-  uint32_t w0 = ring[s0 * LS], w1 = ring[s0 * LS + LS];
-  asm volatile("" : "+v"(w0), "+v"(w1));  // keep the window read here, next to the alias read (one LDS round trip)
+  // the bit window is read unconditionally and up front (volatile: not sunk into the renormalisation branch), so that it
+  // shares one LDS round trip with the alias entry; LS is a power of two
+  const uint32_t s0 = ((bitpos >> 5) & (kLanesRingWords - 1)) << log_ls;
+  typedef const volatile __attribute__((address_space(3))) uint32_t* LdsVolatile;
+  const uint32_t w0 = *(LdsVolatile)(ring + s0);
+  const uint32_t w1 = *(LdsVolatile)(ring + s0 + LS);
   const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & ((1u << log_entry) - 1);
   const uint2 e = *reinterpret_cast<const uint2*>(lds + (cluster << (15 - log_entry)) + slot * 8);  // 8 << log_alpha per cluster
   const bool gt = pos >= (e.x >> 24);
@@ -91,8 +95,8 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
     const uint32_t msb = (ctxe >> 4) & 15, lsb = (ctxe >> 8) & 15;
     const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
     const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
-    const uint32_t s1 = (bitpos >> 5) & (kLanesRingWords - 1);
-    const uint32_t v0 = ring[s1 * LS], v1 = ring[s1 * LS + LS];
+    const uint32_t s1 = ((bitpos >> 5) & (kLanesRingWords - 1)) << log_ls;
+    const uint32_t v0 = ring[s1], v1 = ring[s1 + LS];
     const uint32_t xb = __builtin_amdgcn_alignbit(v1, v0, bitpos & 31) & ((1u << nb) - 1);
     bitpos += nb;
     tok = (((((1u << msb) | (top & ((1u << msb) - 1))) << nb) | xb) << lsb) | low;
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   const uint32_t nq = P.nq, ndc = P.ndc, num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
   const uint32_t lut_bytes = 39 * nq * ndc;
   const uint32_t LS = B.lanes;
+  const uint32_t log_ls = 31 - __clz(int(LS));
   const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, lut_bytes, WPG, LS);
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
   uint8_t* l_ctx = lds_raw + L.ctx;                                      // context -> histogram (cluster)
@@ -177,7 +182,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   // coefficient cursor
   // addr_a / addr_b: LDS byte address of the context entry of the NEXT coefficient at frequency context 0, if the
   // current token turns out zero (same non-zero count, prev = 0) / non-zero (one fewer to come, prev = 1)
-  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, addr_b = 0, ctxe = 0, dptr = 0, kidx = 0;
+  // (addr_b is kept as cbase + 1 + nnz_b with nnz_b the raw table value: the add happens where addr_b is used, so the
+  // table read issued at the end of a trip is only waited for after the next trip has issued its other LDS reads)
+  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, nnz_b = 0, ctxe = 0, dptr = 0, kidx = 0;
   CoefT* const coeffs = static_cast<CoefT*>(P.coeffs);
   const uint32_t shift = T.shift;
 
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
             const uint32_t bctx = l_lut[((c * 13 + ord) * nq + qfi) * ndc + dcctx];
             uint32_t nzb = pred >= 64 ? 64 : pred;
             nzb = nzb < 8 ? nzb : 4 + nzb / 2;
-            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, lds_raw, l_cfg, log_entry);
+            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
             log2c = (info >> 16) & 0xFF;
             const uint32_t covered = 1u << log2c;
             size = covered * 64;
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
                 dptr = (g * 3 + c) * 65536 + coef_offset + covered;
                 const uint32_t prev = nzeros > size / 16 ? 0 : 1;
                 addr_a = cbase + l_nnz2[((nzeros + covm1) >> log2c) & 63];
-                addr_b = cbase + l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63] + 1;
+                nnz_b = l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63];
                 ctxe = lds_raw[addr_a + prev];  // frequency context of k = covered is 0
                 mode = kRun;
               }
@@ -316,18 +323,19 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
         const uint32_t b = kn >> log2c;
         const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
         const uint32_t e_zero = lds_raw[addr_a + f2];
+        const uint32_t addr_b = cbase + 1 + nnz_b;
         const uint32_t e_nonzero = lds_raw[addr_b + f2];
-        const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, LS, lds_raw, l_cfg, log_entry);
+        const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
         const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
         const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
-        coeffs[dptr] = CoefT(coeff);
+        if (!(B.debug & 1)) coeffs[dptr] = CoefT(coeff);
         dptr++;
         k = kn;
         const bool nz = tok != 0;
         nzeros -= nz ? 1u : 0u;
         ctxe = nz ? e_nonzero : e_zero;
         addr_a = nz ? addr_b - 1 : addr_a;
-        addr_b = cbase + l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63] + 1;
+        nnz_b = l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63];
         if (nzeros == 0) {
           kend_out[kidx] = k;
           mode = kWait;

@@ -4,7 +4,7 @@
 // stage_from_linear.cc:114-144 + cms/transfer_functions-inl.h:245-268, stage_write.cc:266-286,548-590) and the edge
 // mirroring of low_memory_render_pipeline.cc:475-517.
 //
-// One workgroup owns a 64x32 output tile. The inverse-transform output (3 f32 planes) is read ONCE from HBM for the
+// One workgroup owns a 64x16 output tile. The inverse-transform output (3 f32 planes) is read ONCE from HBM for the
 // tile plus a halo of H pixels (H = sum of the enabled stages' radii, coordinates mirrored about the frame size), every
 // stage then runs LDS -> LDS on a region that shrinks by its radius, and the last region (the tile itself) is colour
 // converted and written as packed RGB8. HBM traffic per pixel: 12 B * halo overhead in, 3 B out, versus one full
@@ -26,7 +26,7 @@ struct FusedFilterParams {
   float* filtered;         // optional (may be NULL): filtered XYB planes for tests (same geometry as f.in)
 };
 
-constexpr int kFusedTW = 64, kFusedTH = 32;
+constexpr int kFusedTW = 64, kFusedTH = 16;  // 37 KB of LDS with a 3-pixel halo: two tiles fit beside an entropy workgroup
 constexpr int kFusedThreads = 512;  // 8 waves per tile: two resident tiles give every SIMD four waves to hide LDS latency
 constexpr int kFusedSigW = kFusedTW / 8 + 3, kFusedSigH = kFusedTH / 8 + 3;  // sigma blocks around a tile
 __host__ __device__ constexpr int FusedHalo(bool gab, int epf) {

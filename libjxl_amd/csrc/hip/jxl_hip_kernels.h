@@ -794,8 +794,10 @@ __global__ __launch_bounds__(256) void k_dct(const TransformParams* params, cons
 //   * row y of the block is written by the C threads of the group as one contiguous segment.
 typedef const float __attribute__((address_space(4)))* CF32;
 
+constexpr int kIdctColsThreads = 128;  // small workgroups: their LDS has to fit beside the resident entropy workgroups
+
 template <typename CoefT, int CX, int CY>
-__global__ __launch_bounds__(256) void k_idct_cols(const TransformParams* params, const uint2* desc, uint32_t strategy) {
+__global__ __launch_bounds__(kIdctColsThreads) void k_idct_cols(const TransformParams* params, const uint2* desc, uint32_t strategy) {
   JXL_TRANSFORM_PREAMBLE();
   constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, GSTRIDE = 2 * SIZE + 4;
   extern __shared__ __align__(16) float lds_f[];
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(256) void k_idct_cols(const TransformParams* params
   }
   {
     const float* bn = P.basis_n + BasisOffset(R);  // [y * R + ky]
-    for (int i = threadIdx.x; i < R * R; i += 256) l_bn[i] = bn[i];
+    for (int i = threadIdx.x; i < R * R; i += kIdctColsThreads) l_bn[i] = bn[i];
   }
   const uint32_t ord = c_strategy_order[strategy];
   for (int ci = 0; ci < 3; ci++) {
