@@ -81,6 +81,7 @@ struct JxlHipContext {
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
   Buf plane[3], rgb, tlist, scratch;
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
+  Buf batch_wave_ls;
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
   uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64;
   int batch_kernel = -1;
@@ -218,7 +219,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -805,7 +806,7 @@ static int LaunchEntropyLanes(JxlHipContext* c0) {
   b.wg_frame = c0->batch_map.as<uint32_t>();
   b.lane_group = c0->batch_lanes.as<uint32_t>();
   b.wait_shift = c0->batch_wait_shift;
-  b.lanes = c0->batch_lanes_per_wave;
+  b.wave_log_ls = c0->batch_wave_ls.as<uint8_t>();
   b.debug = uint32_t(EnvInt("JXLHIP_LANES_DEBUG", 0));
   b.prof = nullptr;
   const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
@@ -856,6 +857,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   if (same) return 0;
   std::vector<jxlhip::EntropyParams> params(n);
   std::vector<uint32_t> map, lanes;
+  std::vector<uint8_t> wave_ls;
   size_t lds = 0;
   for (size_t i = 0; i < n; i++) params[i] = ctxs[i]->ep;
   if (kernel == 2) {
@@ -937,18 +939,23 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
         units.push_back(std::move(u));
       }
     }
-    uint32_t stride = 1;  // row stride of the per-wave LDS regions
-    while (stride < max_lanes) stride *= 2;
-    c0->batch_lanes_per_wave = stride;
+    (void)max_lanes;
     lanes.assign(map.size() * kLanesWPG * 64, 0xFFFFFFFFu);
-    for (size_t i = 0; i < n; i++) {
-      const size_t l = LanesLdsFor(ctxs[i], stride);
-      lds = l > lds ? l : lds;
-    }
+    wave_ls.assign(map.size() * kLanesWPG, 0);
     for (const Unit& u : units) {
       uint32_t j = 0;
-      for (size_t w = 0; w < u.count.size(); w++)
+      for (size_t w = 0; w < u.count.size(); w++) {
+        uint32_t l2 = 0;
+        while ((1u << l2) < u.count[w]) l2++;
+        wave_ls[size_t(u.wg0) * kLanesWPG + w] = uint8_t(l2);
         for (uint32_t k = 0; k < u.count[w]; k++) lanes[(size_t(u.wg0) * kLanesWPG + w) * 64 + k] = u.order[j++];
+      }
+    }
+    for (size_t wg = 0; wg < map.size(); wg++) {  // LDS of the launch = the largest workgroup
+      const JxlHipContext* c = ctxs[map[wg] & 0xFFFF];
+      size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc, 0, 0).wave0;
+      for (int w = 0; w < kLanesWPG; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * kLanesWPG + w];
+      lds = l > lds ? l : lds;
     }
   } else {
     for (size_t i = 0; i < n; i++) {
@@ -963,6 +970,10 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   if ((r = c0->batch_map.Ensure(map.size() * 4))) return r;
   HIP_TRY(hipMemcpy(c0->batch_params.p, params.data(), params.size() * sizeof(params[0]), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c0->batch_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+  if (!wave_ls.empty()) {
+    if ((r = c0->batch_wave_ls.Ensure(wave_ls.size()))) return r;
+    HIP_TRY(hipMemcpy(c0->batch_wave_ls.p, wave_ls.data(), wave_ls.size(), hipMemcpyHostToDevice));
+  }
   if (!lanes.empty()) {
     if ((r = c0->batch_lanes.Ensure(lanes.size() * 4))) return r;
     HIP_TRY(hipMemcpy(c0->batch_lanes.p, lanes.data(), lanes.size() * 4, hipMemcpyHostToDevice));

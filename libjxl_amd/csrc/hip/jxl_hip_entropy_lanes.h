@@ -37,7 +37,8 @@ struct EntropyLaneBatch {
   const uint32_t* wg_frame;     // per workgroup: index into params | histogram selector of its sections << 16
   const uint32_t* lane_group;   // per lane of every wave: group (AC section) index in its frame, 0xFFFFFFFF = idle lane
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
-  uint32_t lanes;               // populated lanes per wave (power of two): lanes >= this are idle; strides the per-wave LDS
+  const uint8_t* wave_log_ls;   // per wave: log2 of its populated-lane capacity (lanes beyond it are idle); the wave's LDS
+                                // rows are strided by that many entries, so sparse waves take little LDS
   uint32_t debug;               // measurement aid: bit 0 = skip the coefficient stores (results are then invalid)
   unsigned long long* prof;     // optional (may be NULL): per wave {cycles total, cycles in service, services, hot trips}
 };
@@ -115,15 +116,18 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, nclusters = T.num_clusters;
   const uint32_t nq = P.nq, ndc = P.ndc, num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
   const uint32_t lut_bytes = 39 * nq * ndc;
-  const uint32_t LS = B.lanes;
-  const uint32_t log_ls = 31 - __clz(int(LS));
-  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, lut_bytes, WPG, LS);
+  const uint8_t* wls = B.wave_log_ls + blockIdx.x * WPG;
+  const uint32_t log_ls = wls[wave];
+  const uint32_t LS = 1u << log_ls;
+  uint32_t wave_off = 0;  // the per-wave regions are packed one after the other
+  for (uint32_t w = 0; w < wave; w++) wave_off += kLanesPerLaneBytes << wls[w];
+  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, lut_bytes, 0, 0);
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
   uint8_t* l_ctx = lds_raw + L.ctx;                                      // context -> histogram (cluster)
   uint16_t* l_cfg = reinterpret_cast<uint16_t*>(lds_raw + L.cfg);        // per cluster: split_exp | msb << 4 | lsb << 8
   uint8_t* l_lut = lds_raw + L.lut;
   uint16_t* l_nnz2 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)] -> 2 * kCoeffNumNonzeroContext
-  uint8_t* l_nz = lds_raw + L.wave0 + wave * L.per_wave;             // line buffer of the per-block nzeros prediction
+  uint8_t* l_nz = lds_raw + L.wave0 + wave_off;                       // line buffer of the per-block nzeros prediction
   uint32_t* ring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzRows * LS) + lane;                 // stream ring [slot][lane]
   uint32_t* bring = ring + (kLanesRingWords + 1) * LS;                                           // block records [slot][lane]
   const uint32_t* l_sinfo = reinterpret_cast<const uint32_t*>(lds_raw + L.sinfo);
