@@ -158,7 +158,7 @@ __device__ __forceinline__ void Epf1Stage(const FusedFilterParams& P, const floa
           a1 = weight * src[PL + nb[j]] + a1;
           a2 = weight * src[2 * PL + nb[j]] + a2;
         }
-        const float inv_w = 1.0f / wsum;
+        const float inv_w = __builtin_amdgcn_rcpf(wsum);  // 1 ulp; wsum >= 1
         out[it][0] = a0 * inv_w;
         out[it][1] = a1 * inv_w;
         out[it][2] = a2 * inv_w;
@@ -209,12 +209,14 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
     // all loads of the thread are issued before the first LDS store (the HBM latency is paid once, not per element)
     constexpr int NLD = (PL + kFusedThreads - 1) / kFusedThreads;
     float v[NLD][3];
+    const bool interior = x0 >= H && y0 >= H && x0 + TW + H <= xs && y0 + TH + H <= ys;  // no mirroring needed (uniform)
 #pragma unroll
     for (int it = 0; it < NLD; it++) {
       const int i = tid + it * kFusedThreads;
       if (i < PL) {
         const int ly = i / S, lx = i - ly * S;
-        const size_t g = size_t(MirrorI(y0 + ly - H, ys)) * P.f.xp + MirrorI(x0 + lx - H, xs);
+        const size_t g = interior ? size_t(y0 + ly - H) * P.f.xp + (x0 + lx - H)
+                                  : size_t(MirrorI(y0 + ly - H, ys)) * P.f.xp + MirrorI(x0 + lx - H, xs);
         v[it][0] = P.f.in[g];
         v[it][1] = P.f.in[gplane + g];
         v[it][2] = P.f.in[2 * gplane + g];

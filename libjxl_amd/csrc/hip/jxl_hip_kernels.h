@@ -1189,7 +1189,7 @@ __device__ __forceinline__ float LinearToSrgb(float v) {
   const float a = fabsf(v);
   float r;
   if (a > 0.0031308f) {
-    const float s = sqrtf(a);
+    const float s = __builtin_amdgcn_sqrtf(a);  // 1 ulp hardware square root (a > 0.0031308: no denormals)
     float yp = 7.352629620e-01f * s + 1.474205315e+00f;
     yp = yp * s + 3.903842876e-01f;
     yp = yp * s + 5.287254571e-03f;
@@ -1198,7 +1198,7 @@ __device__ __forceinline__ float LinearToSrgb(float v) {
     yq = yq * s + 1.340816930e+00f;
     yq = yq * s + 3.036675394e-01f;
     yq = yq * s + 1.004519624e-02f;
-    r = yp / yq;
+    r = yp * __builtin_amdgcn_rcpf(yq);  // yq in [0.01, 3.6]: 1 ulp hardware reciprocal
   } else {
     r = a * 12.92f;
   }
