@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Isolated stage timings of one resident 4K frame (no other stream active): transform and filter+colour (GPU box only)."""
+"""Isolated timings of the batched transform and filter+colour launches over a resident frame set (no other kernel
+running): min and median of 12 launches. usage: stage_times.py [FRAMES]   (GPU box only)"""
 import os
+import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,19 +10,21 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import libjxl_amd as J  # noqa: E402
 
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 data = bench.make_stream(3840, 2160, 1.0)
 frame = J.Frame(data, threads=8)
-c = J.HipContext(0)
-c.upload(frame)
-c.run_entropy()
-c.sync()
+ctxs = [J.HipContext(0) for _ in range(n)]
+for c in ctxs:
+    c.upload(frame)
+J.run_entropy_batch(ctxs)
+ctxs[0].sync()
 px = 3840 * 2160
-for name, fn, which, alg in (("transform", c.run_transform, 1, 18.4 * px), ("filter+colour", c.run_filter_color, 2, 15.06 * px)):
+for name, fn, which, alg in (("transform", J.run_transform_batch, 1, 18.4 * px), ("filter+colour", J.run_filter_color_batch, 2, 15.06 * px)):
     ms = []
-    for _ in range(6):
-        fn()
-        c.sync()
-        ms.append(c.stage_ms(which))
-    best = min(ms[1:])
-    print("%s: %.3f ms  (%.1f GB/s algorithmic)" % (name, best, alg / best / 1e6), flush=True)
-c.close()
+    for _ in range(12):
+        fn(ctxs)
+        ctxs[0].sync()
+        ms.append(ctxs[0].stage_ms(which) / n)
+    print("%s: min %.4f median %.4f ms/frame  (%.0f GB/s algorithmic at min)" % (name, min(ms), statistics.median(ms), alg / min(ms) / 1e6), flush=True)
+for c in ctxs:
+    c.close()
