@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=384, help="frames per step per GPU")
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--distance", type=float, default=1.0)
     ap.add_argument("--shard", choices=("frames", "bands"), default="frames",
