@@ -149,6 +149,35 @@ def test_lane_packing_of_sections(built, lanes, wait_shift, monkeypatch):
             o.close()
 
 
+@pytest.mark.parametrize("choice", ["1", "0"])
+def test_fallback_entropy_kernels_natural_layout(built, choice):
+    """JXLHIP_ENTROPY=1 / 0 select the wave-per-section kernels (k_entropy_uni / k_entropy_ans) that multi-pass frames
+    and frames with oversized tables fall back to; they write the natural, zero-filled coefficient layout, which the
+    transform kernels must take as well. The choice is latched per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, libjxl_amd as J, jxlo\n"
+        "for data in (J.encode_rgb8(J.synth_image(700, 520, seed=4), distance=2.0), J.encode_random(520, 300, seed=6),\n"
+        "             J.encode_rgb8(J.synth_image(600, 400, seed=9), num_histograms=3)):\n"
+        "    o = jxlo.Decoded(data)\n"
+        "    f = J.Frame(data); c = J.HipContext(); c.upload(f); c.run_entropy(); c.sync()\n"
+        "    r, flags = c.errors(); assert r == 0\n"
+        "    co = c.download('coeffs').astype(np.int32); ref = o.planes('coeffs')\n"
+        "    acs = o.buffer('acs'); n = o.info['num_groups']\n"
+        "    c.run_transform(); c.run_filter_color()\n"
+        "    d = np.abs(c.rgb8().astype(int) - o.rgb8.astype(int)); assert d.max() <= 1, d.max()\n"
+        "    x = c.download('xyb_idct'); assert np.abs(x - o.planes('xyb_idct')).max() < 2e-5\n"
+        "    c.close(); f.close(); o.close()\n"
+        "print('ok')\n") % (root, os.path.join(root, "oracle"))
+    env = dict(os.environ, JXLHIP_ENTROPY=choice)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_randomized_parity_sweep(built):
     """A short run of scripts/fuzz_parity.py: random sizes, distances, filter settings, strategy sets, histogram counts."""
     import os
