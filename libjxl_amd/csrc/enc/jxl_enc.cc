@@ -525,7 +525,8 @@ struct Params {
   int32_t zero_ac;         // random mode: leave every AC coefficient zero (DC-only stream)
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
-  int32_t reserved[3];
+  int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
+  int32_t reserved[2];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -610,16 +611,20 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   jxh::BlockCtxMap bctx;
   const size_t nctx = bctx.NumACContexts();
   const size_t num_hist = (p.num_histograms > 1 && num_groups > 1) ? std::min<size_t>(size_t(p.num_histograms), num_groups) : 1;
-  std::vector<std::vector<Token>> ac_tokens(num_groups);
+  const size_t num_passes = p.num_passes == 2 ? 2 : 1;
+  std::vector<std::vector<Token>> ac_tokens(num_groups * num_passes);  // [pass * num_groups + group]
   std::vector<std::vector<uint32_t>> natural(13);
   for (int s = 0; s < 27; s++)
     if (natural[jxh::kStrategyOrder[s]].empty()) jxh::NaturalOrder(s, &natural[jxh::kStrategyOrder[s]]);
 #pragma omp parallel for schedule(dynamic)
-  for (size_t g = 0; g < num_groups; g++) {
+  for (size_t pg = 0; pg < num_groups * num_passes; pg++) {
+    const size_t g = pg % num_groups, pass = pg / num_groups;
+    // the part of a coefficient this pass carries (the decoder adds value << shift over the passes, dec_group.cc:335-338)
+    auto part = [&](int32_t v) -> int32_t { return num_passes == 1 ? v : (pass == 0 ? (v >> 1) : v - ((v >> 1) << 1)); };
     const size_t bx0 = (g % xg) * 32, by0 = (g / xg) * 32;
     const size_t gw = std::min<size_t>(32, f.xb - bx0), gh = std::min<size_t>(32, f.yb - by0);
     std::vector<int32_t> nzmap(3 * 1024, 0);
-    std::vector<Token>& out_t = ac_tokens[g];
+    std::vector<Token>& out_t = ac_tokens[pg];
     size_t offset = 0;
     for (size_t by = 0; by < gh; by++)
       for (size_t bx = 0; bx < gw; bx++) {
@@ -640,7 +645,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
           int32_t pred = bx == 0 ? (top ? top[0] : 32) : (!top ? cur[bx - 1] : (top[bx] + cur[bx - 1] + 1) / 2);
           const uint32_t* order = natural[ord].data();
           size_t nz = 0;
-          for (size_t k = covered; k < size; k++) nz += q[order[k]] != 0;
+          for (size_t k = covered; k < size; k++) nz += part(q[order[k]]) != 0;
           size_t bc = bctx.Context(0, qf, ord, c);
           const size_t hist_off = (g % num_hist) * nctx;  // this group's histogram set
           out_t.push_back({uint32_t(hist_off + bctx.NonZeroContext(uint32_t(pred), bc)), uint32_t(nz)});
@@ -650,7 +655,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
           size_t prev = nz > size / 16 ? 0 : 1, left = nz;
           for (size_t k = covered; k < size && left != 0; k++) {
             size_t ctx = hist_off + hoff + jxh::ZeroDensityContext(left, k, covered, log2c, prev);
-            int32_t v = q[order[k]];
+            int32_t v = part(q[order[k]]);
             out_t.push_back({uint32_t(ctx), PackSigned(v)});
             prev = v != 0;
             left -= prev;
@@ -659,11 +664,11 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
         offset += size;
       }
   }
-  EncCode ac_code;
-  {
+  std::vector<EncCode> ac_codes(num_passes);
+  for (size_t pass = 0; pass < num_passes; pass++) {
     std::vector<const std::vector<Token>*> all;
-    for (auto& t : ac_tokens) all.push_back(&t);
-    BuildCode(all, nctx * num_hist, p.max_clusters > 0 ? size_t(p.max_clusters) : 64, cfg420, &ac_code);
+    for (size_t g = 0; g < num_groups; g++) all.push_back(&ac_tokens[pass * num_groups + g]);
+    BuildCode(all, nctx * num_hist, p.max_clusters > 0 ? size_t(p.max_clusters) : 64, cfg420, &ac_codes[pass]);
   }
   // ---- sections
   auto write_dc_global = [&](BitWriter& bw) {
@@ -701,16 +706,19 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   auto write_ac_global = [&](BitWriter& bw) {
     bw.Write(1, 1);                            // default dequant tables
     bw.Write(CeilLog2(num_groups), uint32_t(num_hist - 1));  // number of histogram sets - 1
-    bw.Write(2, 2);                            // used_orders = 0
-    WriteCodeHeader(bw, ac_code);
+    for (size_t pass = 0; pass < num_passes; pass++) {
+      bw.Write(2, 2);                          // used_orders = 0
+      WriteCodeHeader(bw, ac_codes[pass]);
+    }
   };
-  auto write_ac_group = [&](BitWriter& bw, size_t g) {
+  auto write_ac_group = [&](BitWriter& bw, size_t pg) {
+    const size_t g = pg % num_groups;
     bw.Write(CeilLog2(num_hist), uint32_t(g % num_hist));  // histogram selector (dec_group.cc:594-610)
-    WriteTokens(bw, ac_tokens[g].data(), ac_tokens[g].size(), ac_code);
+    WriteTokens(bw, ac_tokens[pg].data(), ac_tokens[pg].size(), ac_codes[pg / num_groups]);
   };
 
   std::vector<std::vector<uint8_t>> sections;
-  if (num_groups == 1) {
+  if (num_groups == 1 && num_passes == 1) {
     BitWriter bw;
     write_dc_global(bw);
     write_dc_group(bw, 0);
@@ -719,7 +727,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.ZeroPad();
     sections.push_back(bw.bytes());
   } else {
-    sections.resize(2 + ndc + num_groups);
+    sections.resize(2 + ndc + num_groups * num_passes);
     {
       BitWriter bw;
       write_dc_global(bw);
@@ -739,11 +747,11 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
       sections[1 + ndc] = bw.bytes();
     }
 #pragma omp parallel for schedule(dynamic)
-    for (size_t g = 0; g < num_groups; g++) {
+    for (size_t pg = 0; pg < num_groups * num_passes; pg++) {  // TOC order: pass-major (toc.h: AcGroupIndex)
       BitWriter bw;
-      write_ac_group(bw, g);
+      write_ac_group(bw, pg);
       bw.ZeroPad();
-      sections[2 + ndc + g] = bw.bytes();
+      sections[2 + ndc + pg] = bw.bytes();
     }
   }
   // ---- headers
@@ -769,7 +777,13 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(2, 0);  // upsampling 1
   bw.Write(3, 3);  // x_qm_scale
   bw.Write(3, 2);  // b_qm_scale
-  bw.Write(2, 0);  // one pass
+  if (num_passes == 1) {
+    bw.Write(2, 0);  // one pass
+  } else {
+    bw.Write(2, 1);  // two passes
+    bw.Write(2, 0);  // no downsampling brackets
+    bw.Write(2, 1);  // shift of pass 0 = 1 (the last pass always has shift 0)
+  }
   bw.Write(1, 0);  // no custom size/origin
   bw.Write(2, 0);  // blend mode: replace
   bw.Write(1, 1);  // is_last
@@ -1141,7 +1155,8 @@ struct JxlEncParams {
   int32_t max_clusters, skip_dc_smoothing, random_cmap, zero_ac;
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
-  int32_t reserved[3];
+  int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
+  int32_t reserved[2];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

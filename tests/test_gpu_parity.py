@@ -71,6 +71,9 @@ def _compare(J, jxlo, data, check_rgb=True):
     ((300, 200), dict(skip_dc_smoothing=1)),
     ((1000, 700), dict(num_histograms=3)),                # several AC histogram sets (libjxl's streaming encoder)
     ((1300, 1100), dict(num_histograms=30, strategy_mode=2, distance=2.0)),  # one set per group
+    ((700, 520), dict(num_passes=2)),                     # progressive: two passes, pass 0 shifted by one bit
+    ((200, 100), dict(num_passes=2)),                     # ... with a single group
+    ((1000, 700), dict(num_passes=2, num_histograms=3, distance=2.0)),
 ])
 def test_image_streams(built, size, kw):
     import jxlo
