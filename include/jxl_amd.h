@@ -24,6 +24,8 @@ void jxlamd_frame_free(JxlAmdFrame* frame);
  * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes, then of pass 0: log2 alphabet size,
  * number of clustered histograms, context map bytes; [15] reserved (0). */
 void jxlamd_frame_info(const JxlAmdFrame* frame, uint32_t* info);
+/* Size of the decoded image: the frame size, times the upsampling factor of an upsampled frame (cropped to the image). */
+void jxlamd_frame_out_size(const JxlAmdFrame* frame, uint32_t* width_height);
 int jxlamd_frame_upload(const JxlAmdFrame* frame, JxlHipContext* ctx);
 /* Same, for a band of rows of 256x256 groups [group_row_begin, group_row_end) (see JxlHipFrameDesc); 0, 0 = whole frame. */
 int jxlamd_frame_upload_band(const JxlAmdFrame* frame, JxlHipContext* ctx, uint32_t group_row_begin, uint32_t group_row_end);

@@ -111,6 +111,11 @@ typedef struct JxlHipFrameDesc {
    * one group row above and below the band (the loop filters need up to 7 rows of their output), so no exchange
    * between devices is needed. 0, 0 = the whole frame. */
   uint32_t band_group_row_begin, band_group_row_end;
+  /* Upsampling of the decoded frame by 2, 4 or 8 before the colour conversion (stage_upsampling.cc:49-282; 0 or 1 = none):
+   * xsize / ysize above are the coded frame, out_xsize / out_ysize the image (in (factor * (frame - 1), factor * frame]),
+   * upsampling_kernel the factor * factor 5x5 kernels, [factor * oy + ox][5 * (iy + 2) + ix + 2]. */
+  uint32_t upsampling, out_xsize, out_ysize;
+  const float* upsampling_kernel;
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);
@@ -141,7 +146,8 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n);
 /* Blocks until the context's stream is idle. */
 int jxlhip_sync(JxlHipContext* ctx);
 
-/* Copies the interleaved RGB8 result (row stride in bytes) to host memory; synchronous. */
+/* Copies the interleaved RGB8 result (row stride in bytes) to host memory; synchronous. The result has the frame's
+ * size, or out_xsize x out_ysize for an upsampled frame. */
 int jxlhip_download_rgb8(JxlHipContext* ctx, uint8_t* dst, size_t stride);
 /* Same for pixel rows [y_begin, y_end) only (dst receives y_end - y_begin rows): the rows a band context produced. */
 int jxlhip_download_rgb8_rows(JxlHipContext* ctx, uint8_t* dst, size_t stride, uint32_t y_begin, uint32_t y_end);

@@ -59,6 +59,7 @@ def lib():
         L.jxlamd_frame_parse.argtypes = [cp, ctypes.c_size_t, vp, vp, ctypes.POINTER(vp)]
         L.jxlamd_frame_free.argtypes = [vp]
         L.jxlamd_frame_info.argtypes = [vp, u32p]
+        L.jxlamd_frame_out_size.argtypes = [vp, u32p]
         L.jxlamd_frame_upload.argtypes = [vp, vp]
         L.jxlamd_last_error.restype = cp
         L.JxlThreadParallelRunnerCreate.restype = vp
@@ -97,6 +98,9 @@ class Frame:
         info = (ctypes.c_uint32 * 16)()
         L.jxlamd_frame_info(self._h, info)
         self.info = dict(zip(self.INFO, list(info)))
+        wh = (ctypes.c_uint32 * 2)()
+        L.jxlamd_frame_out_size(self._h, wh)
+        self.info["out_xsize"], self.info["out_ysize"] = int(wh[0]), int(wh[1])  # the image (upsampled frames: > frame size)
 
     def close(self):
         if self._h:
@@ -143,8 +147,8 @@ class HipContext:
 
     def rgb8_rows(self, y0, y1):
         fi = self.frame_info
-        out = np.empty((y1 - y0, fi["xsize"], 3), np.uint8)
-        _check(lib().jxlhip_download_rgb8_rows(self._h, out.ctypes.data, fi["xsize"] * 3, y0, y1), "jxlhip_download_rgb8_rows")
+        out = np.empty((y1 - y0, fi["out_xsize"], 3), np.uint8)
+        _check(lib().jxlhip_download_rgb8_rows(self._h, out.ctypes.data, fi["out_xsize"] * 3, y0, y1), "jxlhip_download_rgb8_rows")
         return out
 
     def run_entropy(self):
@@ -175,8 +179,8 @@ class HipContext:
 
     def rgb8(self):
         fi = self.frame_info
-        out = np.empty((fi["ysize"], fi["xsize"], 3), np.uint8)
-        _check(lib().jxlhip_download_rgb8(self._h, out.ctypes.data, fi["xsize"] * 3), "jxlhip_download_rgb8")
+        out = np.empty((fi["out_ysize"], fi["out_xsize"], 3), np.uint8)
+        _check(lib().jxlhip_download_rgb8(self._h, out.ctypes.data, fi["out_xsize"] * 3), "jxlhip_download_rgb8")
         return out
 
     def download(self, name):
@@ -228,7 +232,7 @@ class EncParams(ctypes.Structure):
     _fields_ = [("distance", ctypes.c_float), ("epf_iters", ctypes.c_int32), ("gab", ctypes.c_int32),
                 ("strategy_mode", ctypes.c_int32), ("strategy_mask", ctypes.c_uint32), ("seed", ctypes.c_uint32),
                 ("max_clusters", ctypes.c_int32), ("skip_dc_smoothing", ctypes.c_int32), ("random_cmap", ctypes.c_int32),
-                ("zero_ac", ctypes.c_int32), ("num_histograms", ctypes.c_int32), ("big_coeffs", ctypes.c_int32), ("num_passes", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+                ("zero_ac", ctypes.c_int32), ("num_histograms", ctypes.c_int32), ("big_coeffs", ctypes.c_int32), ("num_passes", ctypes.c_int32), ("upsampling", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
 
 
 def _enc_lib():

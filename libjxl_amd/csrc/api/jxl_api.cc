@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../../include/jxl_amd.h"
@@ -100,6 +101,35 @@ void jxlamd_frame_info(const JxlAmdFrame* f, uint32_t* info) {
   info[14] = P.passes.empty() ? 0 : uint32_t(P.passes[0].ctx_map.size());
 }
 
+void jxlamd_frame_out_size(const JxlAmdFrame* f, uint32_t* wh) {
+  const jxh::FramePlan& P = f->plan;
+  wh[0] = uint32_t(P.fh.upsampling == 1 ? P.dim.xsize : P.ih.xsize);
+  wh[1] = uint32_t(P.fh.upsampling == 1 ? P.dim.ysize : P.ih.ysize);
+}
+
+// The N*N 5x5 upsampling kernels from the upper triangle of the symmetric default weight matrix
+// (stage_upsampling.cc:59-84; weights image_metadata.cc:98-214).
+#include "../host/upsampling_weights.inc"
+static void UpsamplingKernels(uint32_t N, std::vector<float>* kernel) {
+  const float* weights = N == 2 ? kUpsamplingWeights2 : (N == 4 ? kUpsamplingWeights4 : kUpsamplingWeights8);
+  kernel->assign(size_t(N) * N * 25, 0.0f);
+  const size_t H = N / 2;
+  for (size_t ky = 0; ky < H; ++ky)
+    for (size_t kx = 0; kx < H; ++kx) {
+      const size_t o0 = (ky * N + kx) * 25, o1 = (ky * N + (N - 1 - kx)) * 25, o2 = ((N - 1 - ky) * N + kx) * 25,
+                   o3 = ((N - 1 - ky) * N + (N - 1 - kx)) * 25;
+      for (size_t py = 0; py < 5; ++py)
+        for (size_t px = 0; px < 5; ++px) {
+          const size_t j = 5 * ky + py, i = 5 * kx + px, my = std::min(i, j), mx = std::max(i, j);
+          const float w = weights[5 * H * my - my * (my - 1) / 2 + mx - my];
+          (*kernel)[o0 + py * 5 + px] = w;
+          (*kernel)[o1 + py * 5 + (4 - px)] = w;
+          (*kernel)[o2 + (4 - py) * 5 + px] = w;
+          (*kernel)[o3 + (4 - py) * 5 + (4 - px)] = w;
+        }
+    }
+}
+
 int jxlamd_frame_upload(const JxlAmdFrame* f, JxlHipContext* ctx) { return jxlamd_frame_upload_band(f, ctx, 0, 0); }
 
 int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t group_row_begin, uint32_t group_row_end) {
@@ -181,6 +211,14 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.linear_output = P.ih.linear_tf;
   d.band_group_row_begin = group_row_begin;
   d.band_group_row_end = group_row_end;
+  std::vector<float> ups_kernel;
+  if (P.fh.upsampling != 1) {
+    UpsamplingKernels(P.fh.upsampling, &ups_kernel);
+    d.upsampling = P.fh.upsampling;
+    d.out_xsize = uint32_t(P.ih.xsize);
+    d.out_ysize = uint32_t(P.ih.ysize);
+    d.upsampling_kernel = ups_kernel.data();
+  }
   int r = jxlhip_frame_upload(ctx, &d);
   if (r == 0) r = jxlhip_sync(ctx);  // `pd` and the staging copies are locals
   if (r) g_last_error = "jxlhip_frame_upload failed (" + std::to_string(r) + ")";
@@ -377,7 +415,9 @@ JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
     std::vector<uint32_t> flags(d->frame->plan.dim.num_groups);
     if (!r) r = jxlhip_get_errors(d->ctx, flags.data(), flags.size());
     if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
-    const size_t xs = d->frame->plan.dim.xsize, ys = d->frame->plan.dim.ysize;
+    uint32_t out_wh[2];
+    jxlamd_frame_out_size(d->frame, out_wh);
+    const size_t xs = out_wh[0], ys = out_wh[1];
     const uint32_t nc = d->fmt.num_channels;
     std::vector<uint8_t> rgb;
     uint8_t* dst = static_cast<uint8_t*>(d->out_buf);

@@ -510,6 +510,7 @@ struct FrameModel {
   uint32_t global_scale, quant_dc;
   int epf_iters, gab;
   uint64_t flags;
+  size_t img_xs = 0, img_ys = 0;  // image size when the frame is coded downsampled (upsampling > 1)
 };
 
 struct Params {
@@ -526,7 +527,8 @@ struct Params {
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
   int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
-  int32_t reserved[2];
+  int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
+  int32_t reserved[1];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -758,9 +760,12 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   BitWriter bw;
   bw.Write(16, 0x0AFF);
   bw.Write(1, 0);  // not "small"
-  WriteSizeDim(bw, uint32_t(f.ys));
+  const uint32_t ups = (p.upsampling == 2 || p.upsampling == 4 || p.upsampling == 8) ? uint32_t(p.upsampling) : 1;
+  // the image is the frame times the upsampling factor (the frame is ceil(image / factor): any image size in
+  // (factor * (frame - 1), factor * frame] is valid; img_xs / img_ys pick one)
+  WriteSizeDim(bw, uint32_t(ups == 1 ? f.ys : f.img_ys));
   bw.Write(3, 0);  // no aspect-ratio shortcut
-  WriteSizeDim(bw, uint32_t(f.xs));
+  WriteSizeDim(bw, uint32_t(ups == 1 ? f.xs : f.img_xs));
   bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
   bw.Write(1, 1);  // CustomTransformData all_default
   bw.ZeroPad();
@@ -774,7 +779,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(2, 2);
     bw.Write(8, f.flags - 17);
   }
-  bw.Write(2, 0);  // upsampling 1
+  bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
   bw.Write(3, 3);  // x_qm_scale
   bw.Write(3, 2);  // b_qm_scale
   if (num_passes == 1) {
@@ -829,9 +834,12 @@ static void QuantParams(float distance, FrameModel* f, float* quant_ac) {
   *quant_ac = qac;
 }
 
-static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out) {
+static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out, size_t img_xs = 0,
+                        size_t img_ys = 0) {
   FrameModel f;
   f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
+  f.img_xs = img_xs ? img_xs : xs;
+  f.img_ys = img_ys ? img_ys : ys;
   const size_t xp = f.xb * 8, yp = f.yb * 8;
   std::vector<float> xyb[3];
   RgbToXyb(rgb, xs, ys, xp, yp, xyb);
@@ -1040,8 +1048,12 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
 }
 
 // ---------------------------------------------------------------- random mode
-static void EncodeRandom(size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out) {
+static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vector<uint8_t>* out) {
   FrameModel f;
+  const size_t ups = (p.upsampling == 2 || p.upsampling == 4 || p.upsampling == 8) ? size_t(p.upsampling) : 1;
+  const size_t xs = DivCeil(img_xs, ups), ys = DivCeil(img_ys, ups);  // the coded frame
+  f.img_xs = img_xs;
+  f.img_ys = img_ys;
   f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
   Rng rng(p.seed);
   f.global_scale = 3000 + rng.Below(9000);
@@ -1156,7 +1168,8 @@ struct JxlEncParams {
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
   int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
-  int32_t reserved[2];
+  int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
+  int32_t reserved[1];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
@@ -1174,6 +1187,23 @@ int jxlenc_encode_rgb8(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEn
   memcpy(&q, p, sizeof(q));
   std::vector<uint8_t> v;
   try {
+    if (q.upsampling == 2 || q.upsampling == 4 || q.upsampling == 8) {
+      // code a box-downsampled frame; the decoder upsamples it back to xs x ys
+      const uint32_t N = uint32_t(q.upsampling), sx = (xs + N - 1) / N, sy = (ys + N - 1) / N;
+      std::vector<uint8_t> small(size_t(sx) * sy * 3);
+      for (uint32_t y = 0; y < sy; y++)
+        for (uint32_t x = 0; x < sx; x++)
+          for (int c = 0; c < 3; c++) {
+            uint32_t sum = 0, cnt = 0;
+            for (uint32_t dy = 0; dy < N && y * N + dy < ys; dy++)
+              for (uint32_t dx = 0; dx < N && x * N + dx < xs; dx++) {
+                sum += rgb[(size_t(y * N + dy) * xs + x * N + dx) * 3 + c];
+                cnt++;
+              }
+            small[(size_t(y) * sx + x) * 3 + c] = uint8_t((sum + cnt / 2) / cnt);
+          }
+      jxe::EncodeImage(small.data(), sx, sy, q, &v, xs, ys);
+    } else
     jxe::EncodeImage(rgb, xs, ys, q, &v);
   } catch (...) {
     return -2;

@@ -90,6 +90,9 @@ struct JxlHipContext {
   // band decode: groups this context decodes (band + one group row either side), pixel rows it produces
   std::vector<uint32_t> group_list;
   uint32_t band_y0 = 0, band_y1 = 0;
+  // upsampled frames: factor (1 = none), image size, kernels
+  uint32_t ups = 1, oxs = 0, oys = 0;
+  Buf ups_kernel;
   bool scan_order = false;
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
   Buf kend, block_recs, dequant_scan;
@@ -219,7 +222,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -268,6 +271,14 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->xs = d->xsize; c->ys = d->ysize; c->xb = d->xsize_blocks; c->yb = d->ysize_blocks;
   c->xg = d->xsize_groups; c->ng = d->num_groups; c->np = d->num_passes;
   c->xp = c->xb * 8; c->yp = c->yb * 8;
+  c->ups = d->upsampling > 1 ? d->upsampling : 1;
+  c->oxs = c->ups == 1 ? d->xsize : d->out_xsize;
+  c->oys = c->ups == 1 ? d->ysize : d->out_ysize;
+  if (c->ups != 1) {
+    if ((c->ups != 2 && c->ups != 4 && c->ups != 8) || !d->upsampling_kernel || (d->band_group_row_begin | d->band_group_row_end) ||
+        (c->oxs + c->ups - 1) / c->ups != d->xsize || (c->oys + c->ups - 1) / c->ups != d->ysize)
+      return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
   uint32_t ext_row0 = 0, ext_row1 = d->num_groups / d->xsize_groups;  // group rows to entropy-decode and transform
   {
     const uint32_t yg = d->num_groups / d->xsize_groups;
@@ -393,8 +404,12 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(d->num_groups) * 4, c->stream));  // groups outside a band stay clean
   const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
   if ((r = c->plane[0].Ensure(plane_bytes))) return r;
-  if (c->keep_filtered && (r = c->plane[1].Ensure(plane_bytes))) return r;
-  if ((r = c->rgb.Ensure(size_t(c->xs) * c->ys * 3))) return r;
+  if ((c->keep_filtered || c->ups != 1) && (r = c->plane[1].Ensure(plane_bytes))) return r;
+  if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * 3))) return r;
+  if (c->ups != 1) {
+    if ((r = Upload(c, c->ups_kernel, d->upsampling_kernel, size_t(c->ups) * c->ups * 25 * 4))) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's table may be a temporary
+  }
   // ---- transform work lists (block indices bucketed by strategy)
   {
     std::vector<uint32_t> count(27, 0);
@@ -701,7 +716,8 @@ static void FillFusedParams(const JxlHipContext* c, jxlhip::FusedFilterParams* p
     p->sm[stage] = stage == 1 ? 1.65f : float(scale * 1.65);
     p->bsm[stage] = p->sm[stage] * c->epf_border;
   }
-  p->filtered = c->keep_filtered ? c->plane[1].as<float>() : nullptr;
+  p->filtered = (c->keep_filtered || c->ups != 1) ? c->plane[1].as<float>() : nullptr;
+  if (c->ups != 1) p->f.rgb = nullptr;  // the upsampling kernel produces the pixels
 }
 static int FilterKey(const JxlHipContext* c) {
   const int epf = c->epf_iters < 0 ? 0 : (c->epf_iters > 3 ? 3 : c->epf_iters);
@@ -1080,6 +1096,19 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
     }
     if (r) return r;
   }
+  for (size_t i = 0; i < n; i++) {
+    const JxlHipContext* c = ctxs[i];
+    if (c->ups == 1) continue;
+    jxlhip::UpsampleParams up;
+    up.f = c->fp;
+    up.f.in = c->plane[1].as<float>();
+    up.kernel = c->ups_kernel.as<float>();
+    up.n = c->ups;
+    up.oxs = c->oxs;
+    up.oys = c->oys;
+    hipLaunchKernelGGL(jxlhip::k_upsample_color, dim3((c->xs + 63) / 64, (c->ys + 3) / 4), dim3(256), 0, c0->stream, up);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(c0->ev[5], c0->stream));
   c0->ev_valid[2] = true;
   for (size_t i = 0; i < n; i++) ctxs[i]->final_plane = 1;
@@ -1120,13 +1149,13 @@ int jxlhip_sync(JxlHipContext* c) {
 int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
   if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  if (stride < size_t(c->xs) * 3) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (stride < size_t(c->oxs) * 3) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   {
     int pw = ApplyPendingWait(c);
     if (pw) return pw;
   }
-  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, size_t(c->xs) * 3, size_t(c->xs) * 3, c->ys, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, size_t(c->oxs) * 3, size_t(c->oxs) * 3, c->oys, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1134,13 +1163,13 @@ int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
 int jxlhip_download_rgb8_rows(JxlHipContext* c, uint8_t* dst, size_t stride, uint32_t y_begin, uint32_t y_end) {
   if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  if (stride < size_t(c->xs) * 3 || y_begin >= y_end || y_end > c->ys) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (stride < size_t(c->oxs) * 3 || y_begin >= y_end || y_end > c->oys) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   {
     int pw = ApplyPendingWait(c);
     if (pw) return pw;
   }
-  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.as<uint8_t>() + size_t(y_begin) * c->xs * 3, size_t(c->xs) * 3, size_t(c->xs) * 3,
+  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.as<uint8_t>() + size_t(y_begin) * c->oxs * 3, size_t(c->oxs) * 3, size_t(c->oxs) * 3,
                            y_end - y_begin, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;

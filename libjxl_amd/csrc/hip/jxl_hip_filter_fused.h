@@ -180,6 +180,77 @@ __device__ __forceinline__ void Epf1Stage(const FusedFilterParams& P, const floa
   __syncthreads();
 }
 
+// Upsampling by N = 2, 4, 8 + colour (stage_upsampling.cc:49-282, then the same XYB -> RGB8 conversion as the fused kernel):
+// one thread per pixel of the coded frame produces its N x N image pixels. Every image pixel is a 5x5 weighted sum of the
+// filtered XYB frame around the source pixel (kernel N * oy + ox, mirrored edges), clamped to the window's min / max.
+struct UpsampleParams {
+  FilterParams f;       // f.in = filtered XYB planes of the frame, f.rgb = image-sized output
+  const float* kernel;  // [N * N][25]
+  uint32_t n, oxs, oys;
+};
+__global__ __launch_bounds__(256) void k_upsample_color(UpsampleParams P) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int xs = int(P.f.xs), ys = int(P.f.ys);
+  if (x >= xs || y >= ys) return;
+  const size_t plane = size_t(P.f.xp) * P.f.yp;
+  float v[3][25], mn[3], mx[3];
+#pragma unroll
+  for (int iy = 0; iy < 5; iy++) {
+    const size_t row = size_t(MirrorI(y + iy - 2, ys)) * P.f.xp;
+#pragma unroll
+    for (int ix = 0; ix < 5; ix++) {
+      const size_t g = row + MirrorI(x + ix - 2, xs);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const float t = P.f.in[c * plane + g];
+        v[c][iy * 5 + ix] = t;
+        mn[c] = (iy | ix) == 0 ? t : fminf(mn[c], t);
+        mx[c] = (iy | ix) == 0 ? t : fmaxf(mx[c], t);
+      }
+    }
+  }
+  const int N = int(P.n);
+  for (int oy = 0; oy < N; oy++) {
+    const int Y = y * N + oy;
+    if (Y >= int(P.oys)) break;
+    for (int ox = 0; ox < N; ox++) {
+      const int X = x * N + ox;
+      if (X >= int(P.oxs)) break;
+      const float* k = P.kernel + (N * oy + ox) * 25;
+      float ch[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        // three accumulation chains in the reference's order: taps 0,3,..,24 / 1,4,..,22 / 2,5,..,23
+        float a0 = v[c][0] * k[0], a1 = v[c][1] * k[1], a2 = v[c][2] * k[2];
+#pragma unroll
+        for (int i = 3; i < 24; i += 3) {
+          a0 = fmaf(v[c][i], k[i], a0);
+          a1 = fmaf(v[c][i + 1], k[i + 1], a1);
+          a2 = fmaf(v[c][i + 2], k[i + 2], a2);
+        }
+        a0 = fmaf(v[c][24], k[24], a0);
+        const float r = (a1 + a2) + a0;
+        ch[c] = r < mn[c] ? mn[c] : (r > mx[c] ? mx[c] : r);
+      }
+      const float Xc = ch[0], Yc = ch[1], Bc = ch[2];
+      const float gr = (Yc + Xc) - P.f.opsin_bias_cbrt[0], gg = (Yc - Xc) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
+      const float mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
+      float r = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);
+      float g = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
+      float b = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
+      if (!P.f.linear_output) {
+        r = LinearToSrgb(r);
+        g = LinearToSrgb(g);
+        b = LinearToSrgb(b);
+      }
+      uint8_t* dst = P.f.rgb + (size_t(Y) * P.oxs + X) * 3;
+      dst[0] = ToU8(r, X, Y, 0);
+      dst[1] = ToU8(g, X, Y, 1);
+      dst[2] = ToU8(b, X, Y, 2);
+    }
+  }
+}
+
 template <bool GAB, int EPF>
 __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilterParams* params) {
   // one frame per grid z slice; its parameter block is read through the constant address space (scalar loads that the
@@ -314,6 +385,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
     bytes[i * 3 + 2] = ToU8(b, x, y, 2);
   }
   __syncthreads();
+  if (!P.f.rgb) return;  // upsampled frames: only the filtered planes are produced here (k_upsample_color follows)
   const int cols = xs - x0 < TW ? xs - x0 : TW;  // valid pixels per tile row
   const int rows = int(P.f.y_end) - y0 < TH ? int(P.f.y_end) - y0 : TH;
   const int row_bytes = cols * 3;

@@ -138,7 +138,7 @@ class FrameParser {
     JXH_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
     JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
-    JXH_CHECK(fh.upsampling == 1, "unsupported: upsampling");
+    JXH_CHECK(fh.upsampling == 1 || !ih.custom_upsampling, "unsupported: custom upsampling weights");
     JXH_CHECK(!fh.custom_size, "unsupported: cropped frames");
     JXH_CHECK(fh.is_last, "unsupported: multiple frames");
     JXH_CHECK(ih.extra.empty(), "unsupported: extra channels");

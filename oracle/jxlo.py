@@ -32,6 +32,7 @@ def lib():
         L.jxlo_buffer.restype = ctypes.c_void_p
         L.jxlo_buffer.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
         L.jxlo_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        L.jxlo_out_size.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.jxlo_free.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib
@@ -58,6 +59,9 @@ class Decoded:
         info = (ctypes.c_uint32 * 16)()
         L.jxlo_info(self._h, info)
         self.info = dict(zip(INFO, list(info)))
+        wh = (ctypes.c_uint32 * 2)()
+        L.jxlo_out_size(self._h, wh)
+        self.out_size = (int(wh[0]), int(wh[1]))  # the image: frame size ("xsize", "ysize") times its upsampling factor
 
     def buffer(self, name):
         n = ctypes.c_size_t()
@@ -69,7 +73,7 @@ class Decoded:
     @property
     def rgb8(self):
         i = self.info
-        return self.buffer("rgb8").reshape(i["ysize"], i["xsize"], i["channels"])
+        return self.buffer("rgb8").reshape(self.out_size[1], self.out_size[0], i["channels"])
 
     def planes(self, name):
         i = self.info
@@ -79,7 +83,7 @@ class Decoded:
         if name == "xyb_filtered":
             return a.reshape(3, i["ysize"], i["xsize_padded"])
         if name == "rgbf":
-            return a.reshape(3, i["ysize"], i["xsize"])
+            return a.reshape(3, self.out_size[1], self.out_size[0])
         if name == "coeffs":
             return a.reshape(i["num_groups"], 3, 65536)
         raise KeyError(name)

@@ -30,7 +30,8 @@ struct Decoded {
   FrameHeader fh;
   FrameDim dim;
   int out_channels = 3;
-  std::vector<uint8_t> rgb8;   // interleaved, xsize*ysize*out_channels
+  size_t out_xsize = 0, out_ysize = 0;  // the image (= frame size times the frame's upsampling factor, cropped)
+  std::vector<uint8_t> rgb8;   // interleaved, out_xsize*out_ysize*out_channels
   std::vector<float> rgbf;     // planar 3 x ysize x xsize (after transfer function, before uint8)
   // VarDCT intermediates
   std::vector<int32_t> coeffs;     // [group][c][65536], block-contiguous per varblock
@@ -444,7 +445,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   ReadFrameHeader(br, ih, &s->fh);
   const FrameHeader& fh = s->fh;
   JXLO_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
-  JXLO_CHECK(fh.upsampling == 1, "unsupported: upsampling");
+  JXLO_CHECK(fh.upsampling == 1 || (!fh.modular && !ih.custom_upsampling), "unsupported: upsampled Modular frames / custom weights");
   JXLO_CHECK(!fh.custom_size, "unsupported: cropped frames");
   JXLO_CHECK(fh.is_last, "unsupported: multiple frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
@@ -528,8 +529,10 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   for (size_t i = s->full.transforms.size(); i-- > 0;) InverseTransform(&s->full, s->full.transforms[i]);
   s->full.transforms.clear();
 
-  // ---- render
-  const size_t xs = d.xsize, ys = d.ysize;
+  // ---- render (xs, ys: the image; the frame is ceil(image / upsampling))
+  const size_t xs = fh.upsampling == 1 ? d.xsize : ih.xsize, ys = fh.upsampling == 1 ? d.ysize : ih.ysize;
+  out->out_xsize = xs;
+  out->out_ysize = ys;
   const bool has_alpha = !ih.extra.empty() && ih.extra[0].type == 0;
   out->out_channels = has_alpha ? 4 : 3;
   out->rgbf.assign(3 * xs * ys, 0.0f);
@@ -556,9 +559,17 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     if (fh.lf.epf_iters >= 1) run_epf(1);
     if (fh.lf.epf_iters >= 2) run_epf(2);
     if (want_dumps) {
-      out->xyb_filtered.resize(3 * d.xsize_padded * ys);
+      out->xyb_filtered.resize(3 * d.xsize_padded * d.ysize);
       for (int c = 0; c < 3; c++)
-        memcpy(out->xyb_filtered.data() + c * d.xsize_padded * ys, cur->p[c].data(), d.xsize_padded * ys * sizeof(float));
+        memcpy(out->xyb_filtered.data() + c * d.xsize_padded * d.ysize, cur->p[c].data(), d.xsize_padded * d.ysize * sizeof(float));
+    }
+    Planes3 up;
+    if (fh.upsampling != 1) {
+      Planes3 crop;  // the filters work on the padded stride; the upsampler mirrors about the frame size
+      crop.xs = d.xsize; crop.ys = d.ysize; crop.stride = cur->stride;
+      for (int c = 0; c < 3; c++) crop.p[c] = cur->p[c];
+      Upsample(crop, fh.upsampling, xs, ys, &up);
+      cur = &up;
     }
     OpsinParams op = MakeOpsinParams(ih);
     for (size_t y = 0; y < ys; y++)
@@ -664,6 +675,10 @@ const char* jxlo_error(JxloHandle* h) { return h->error.empty() ? nullptr : h->e
 void jxlo_free(JxloHandle* h) { delete h; }
 // info[0..15]: xsize, ysize, out_channels, is_modular, xsize_blocks, ysize_blocks, xsize_padded, ysize_padded,
 // num_groups, num_dc_groups, epf_iters, gab, num_passes, used_acs, bits, ac_symbols(low 32)
+void jxlo_out_size(JxloHandle* h, uint32_t* wh) {
+  wh[0] = uint32_t(h->d.out_xsize);
+  wh[1] = uint32_t(h->d.out_ysize);
+}
 void jxlo_info(JxloHandle* h, uint32_t* info) {
   const jxlo::Decoded& d = h->d;
   info[0] = uint32_t(d.dim.xsize);

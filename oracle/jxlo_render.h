@@ -122,6 +122,65 @@ static inline OpsinParams MakeOpsinParams(const ImageHeader& h) {
   }
   return o;
 }
+// ---- upsampling by N = 2, 4, 8 (lib/jxl/render_pipeline/stage_upsampling.cc:49-282): every output pixel
+// (N x + ox, N y + oy) is a 5x5 weighted sum of the input around (x, y) with kernel k = N oy + ox, clamped to the
+// minimum / maximum of that 5x5 window. The N*N kernels come from the upper triangle of a symmetric weight matrix
+// (default weights: image_metadata.cc:98-214) by the four mirror symmetries.
+#include "upsampling_weights.inc"
+static inline void UpsamplingKernels(uint32_t N, float* kernel /* N*N*25 */) {
+  const float* weights = N == 2 ? kUpsamplingWeights2 : (N == 4 ? kUpsamplingWeights4 : kUpsamplingWeights8);
+  const size_t H = N / 2;
+  for (size_t ky = 0; ky < H; ++ky)
+    for (size_t kx = 0; kx < H; ++kx) {
+      const size_t o0 = (ky * N + kx) * 25, o1 = (ky * N + (N - 1 - kx)) * 25, o2 = ((N - 1 - ky) * N + kx) * 25,
+                   o3 = ((N - 1 - ky) * N + (N - 1 - kx)) * 25;
+      for (size_t py = 0; py < 5; ++py)
+        for (size_t px = 0; px < 5; ++px) {
+          const size_t j = 5 * ky + py, i = 5 * kx + px, my = std::min(i, j), mx = std::max(i, j);
+          const float w = weights[5 * H * my - my * (my - 1) / 2 + mx - my];
+          kernel[o0 + py * 5 + px] = w;
+          kernel[o1 + py * 5 + (4 - px)] = w;
+          kernel[o2 + (4 - py) * 5 + px] = w;
+          kernel[o3 + (4 - py) * 5 + (4 - px)] = w;
+        }
+    }
+}
+static inline void Upsample(const Planes3& in, uint32_t N, size_t out_xs, size_t out_ys, Planes3* out) {
+  std::vector<float> kernel(size_t(N) * N * 25);
+  UpsamplingKernels(N, kernel.data());
+  out->Alloc(out_xs, out_ys, out_xs);
+  for (int c = 0; c < 3; c++)
+    for (size_t y = 0; y < in.ys; y++)
+      for (size_t x = 0; x < in.xs; x++) {
+        float v[25], mn = 0, mx = 0;
+        for (int iy = -2; iy <= 2; iy++)
+          for (int ix = -2; ix <= 2; ix++) {
+            const float t = in.At(c, int64_t(x) + ix, int64_t(y) + iy);
+            v[5 * (iy + 2) + ix + 2] = t;
+            if (iy == -2 && ix == -2) mn = mx = t;
+            mn = std::min(mn, t);
+            mx = std::max(mx, t);
+          }
+        for (uint32_t oy = 0; oy < N; oy++)
+          for (uint32_t ox = 0; ox < N; ox++) {
+            const size_t X = x * N + ox, Y = y * N + oy;
+            if (X >= out_xs || Y >= out_ys) continue;
+            const float* k = kernel.data() + size_t(N * oy + ox) * 25;
+            // three accumulation chains, as the reference: acc0 takes taps 0,3,..,24, acc1 1,4,..,22, acc2 2,5,..,23
+            float a0 = v[0] * k[0], a1 = v[1] * k[1], a2 = v[2] * k[2];
+            for (int i = 3; i < 24; i += 3) {
+              a0 = std::fma(v[i], k[i], a0);
+              a1 = std::fma(v[i + 1], k[i + 1], a1);
+              a2 = std::fma(v[i + 2], k[i + 2], a2);
+            }
+            a0 = std::fma(v[24], k[24], a0);
+            float r = (a1 + a2) + a0;
+            r = r < mn ? mn : (r > mx ? mx : r);
+            out->p[c][Y * out_xs + X] = r;
+          }
+      }
+}
+
 static inline void XybToRgb(const OpsinParams& op, float X, float Y, float B, float* r, float* g, float* b) {
   float gr = (Y + X) - op.bias_cbrt[0];
   float gg = (Y - X) - op.bias_cbrt[1];

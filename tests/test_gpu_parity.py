@@ -181,6 +181,26 @@ def test_fallback_entropy_kernels_natural_layout(built, choice):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.parametrize("factor", [2, 4, 8])
+def test_upsampled_frames(built, factor):
+    """Frames coded at 1/2, 1/4, 1/8 size with the upsampling flag (stage_upsampling.cc): the GPU produces the full-size
+    image like the oracle, for ragged image sizes, and through the JxlDecoder-level helper as well."""
+    import jxlo
+    J = built
+    for data in (J.encode_rgb8(J.synth_image(701, 523, seed=factor), upsampling=factor),
+                 J.encode_random(300, 203, seed=20 + factor, upsampling=factor, epf_iters=2)):
+        o = jxlo.Decoded(data, dumps=False)
+        f = J.Frame(data)
+        assert (f.info["out_xsize"], f.info["out_ysize"]) == o.out_size
+        assert f.info["xsize"] == (o.out_size[0] + factor - 1) // factor
+        f.close()
+        rgb = J.decode_rgb8(data)
+        assert rgb.shape == o.rgb8.shape
+        d = np.abs(rgb.astype(int) - o.rgb8.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3
+        o.close()
+
+
 def test_randomized_parity_sweep(built):
     """A short run of scripts/fuzz_parity.py: random sizes, distances, filter settings, strategy sets, histogram counts."""
     import os
