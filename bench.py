@@ -62,6 +62,56 @@ def cpu_baseline(data, xsize, ysize, budget_s=20.0):
             "sample": "%d full %dx%d frame decode(s) of the benchmark stream, best of %d" % (len(times), xsize, ysize, len(times))}
 
 
+def system_libjxl_baseline(data, xsize, ysize, threads):
+    """If the box has a libjxl of its own (probe, never assume), times it on the same stream through the
+    same JxlDecoder C API with its thread pool and returns a cpu_baseline dict (kind "reference"), else None."""
+    import ctypes
+    import ctypes.util
+    name, tname = ctypes.util.find_library("jxl"), ctypes.util.find_library("jxl_threads")
+    if not name or not tname:
+        return None
+    try:
+        L, T = ctypes.CDLL(name), ctypes.CDLL(tname)
+        vp = ctypes.c_void_p
+        L.JxlDecoderCreate.restype = vp
+        L.JxlDecoderCreate.argtypes = [vp]
+        T.JxlThreadParallelRunnerCreate.restype = vp
+        T.JxlThreadParallelRunnerCreate.argtypes = [vp, ctypes.c_size_t]
+        for fn, args in (("JxlDecoderDestroy", [vp]), ("JxlDecoderSubscribeEvents", [vp, ctypes.c_int]),
+                         ("JxlDecoderSetInput", [vp, ctypes.c_char_p, ctypes.c_size_t]), ("JxlDecoderCloseInput", [vp]),
+                         ("JxlDecoderProcessInput", [vp]), ("JxlDecoderSetParallelRunner", [vp, vp, vp]),
+                         ("JxlDecoderSetImageOutBuffer", [vp, vp, vp, ctypes.c_size_t])):
+            getattr(L, fn).argtypes = args
+
+        class Fmt(ctypes.Structure):
+            _fields_ = [("num_channels", ctypes.c_uint32), ("data_type", ctypes.c_int), ("endianness", ctypes.c_int),
+                        ("align", ctypes.c_size_t)]
+        fmt = Fmt(3, 2, 0, 0)  # RGB, JXL_TYPE_UINT8, native endian
+        out = ctypes.create_string_buffer(xsize * ysize * 3)
+        pool = T.JxlThreadParallelRunnerCreate(None, threads)
+        runner = ctypes.cast(T.JxlThreadParallelRunner, vp)
+        times = []
+        for _ in range(4):
+            t0 = time.time()
+            dec = L.JxlDecoderCreate(None)
+            L.JxlDecoderSetParallelRunner(dec, runner, pool)
+            L.JxlDecoderSubscribeEvents(dec, 0x1000)  # JXL_DEC_FULL_IMAGE
+            L.JxlDecoderSetInput(dec, data, len(data))
+            L.JxlDecoderCloseInput(dec)
+            status = L.JxlDecoderProcessInput(dec)
+            if status == 5:  # JXL_DEC_NEED_IMAGE_OUT_BUFFER
+                L.JxlDecoderSetImageOutBuffer(dec, ctypes.byref(fmt), out, len(out))
+                status = L.JxlDecoderProcessInput(dec)
+            L.JxlDecoderDestroy(dec)
+            if status != 0x1000:
+                return None
+            times.append(time.time() - t0)
+        return {"value": round(xsize * ysize * 1e-6 / min(times), 3), "unit": "MP/s", "cores": threads, "kind": "reference",
+                "sample": "system %s, %d full %dx%d frame decodes of the benchmark stream, best of %d" % (name, len(times), xsize, ysize, len(times))}
+    except (OSError, AttributeError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,7 +268,8 @@ def main():
             "stage_gbs": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9, 2) for s in range(3)},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(data, xsize, ysize)
+            ref = system_libjxl_baseline(data, xsize, ysize, os.cpu_count() or 1)
+            out["cpu_baseline"] = ref if ref else cpu_baseline(data, xsize, ysize)
         print(json.dumps(out))
     for cs in sets:
         for c in cs:
