@@ -26,10 +26,15 @@ struct MChannel {
   const int32_t* Row(size_t y) const { return d.data() + y * w; }
 };
 
+struct SqueezeStep {  // modular/transform/squeeze_params.cc:14-24
+  bool horizontal = false, in_place = false;
+  uint32_t begin_c = 0, num_c = 2;
+};
 struct MTransform {
   uint32_t id = 0;  // 0 RCT, 1 Palette, 2 Squeeze
   uint32_t begin_c = 0, rct_type = 6;
   uint32_t num_c = 3, nb_colors = 256, nb_deltas = 0, predictor = 0;
+  std::vector<SqueezeStep> squeezes;  // empty = default parameters (derived from the image in MetaSqueeze)
 };
 
 struct WpHeader {
@@ -305,7 +310,175 @@ static inline void ReadTransform(BitReader& br, MTransform* t) {
     t->predictor = uint32_t(br.Read(4));
     JXLO_CHECK(t->predictor < 14, "invalid palette predictor");
   }
-  if (t->id == 2) throw Error("unsupported: Squeeze transform");
+  if (t->id == 2) {  // transform.cc:77-87
+    const uint32_t n = ReadU32(br, Val(0), BitsOffset(4, 1), BitsOffset(6, 9), BitsOffset(8, 41));
+    t->squeezes.resize(n);
+    for (auto& q : t->squeezes) {
+      q.horizontal = br.ReadBool();
+      q.in_place = br.ReadBool();
+      q.begin_c = ReadU32(br, Bits(3), BitsOffset(6, 8), BitsOffset(10, 72), BitsOffset(13, 1096));
+      q.num_c = ReadU32(br, Val(1), Val(2), Val(3), BitsOffset(4, 4));
+    }
+  }
+}
+
+// ---- Squeeze (modular/transform/squeeze.cc; squeeze.h:54-77). Forward: a channel is replaced by the averages of
+// pixel pairs (rounded towards the first pixel) plus a residual channel of (difference - predicted tendency).
+static inline int64_t SmoothTendency(int64_t B, int64_t a, int64_t n) {
+  int64_t diff = 0;
+  if (B >= a && a >= n) {
+    diff = (4 * B - 3 * n - a + 6) / 12;
+    if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+    if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+  } else if (B <= a && a <= n) {
+    diff = (4 * B - 3 * n - a - 6) / 12;
+    if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+    if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+  }
+  return diff;
+}
+static inline void DefaultSqueezeSteps(const MImage& img, std::vector<SqueezeStep>* out) {  // squeeze.cc:387-444
+  const size_t nb_channels = img.ch.size() - img.nb_meta;
+  out->clear();
+  size_t w = img.ch[img.nb_meta].w, h = img.ch[img.nb_meta].h;
+  const bool wide = w > h;
+  if (nb_channels > 2 && img.ch[img.nb_meta + 1].w == w && img.ch[img.nb_meta + 1].h == h) {
+    SqueezeStep q;
+    q.horizontal = true;
+    q.in_place = false;
+    q.begin_c = uint32_t(img.nb_meta + 1);
+    q.num_c = 2;
+    out->push_back(q);
+    q.horizontal = false;
+    out->push_back(q);
+  }
+  SqueezeStep q;
+  q.begin_c = uint32_t(img.nb_meta);
+  q.num_c = uint32_t(nb_channels);
+  q.in_place = true;
+  if (!wide && h > 8) {
+    q.horizontal = false;
+    out->push_back(q);
+    h = (h + 1) / 2;
+  }
+  while (w > 8 || h > 8) {
+    if (w > 8) {
+      q.horizontal = true;
+      out->push_back(q);
+      w = (w + 1) / 2;
+    }
+    if (h > 8) {
+      q.horizontal = false;
+      out->push_back(q);
+      h = (h + 1) / 2;
+    }
+  }
+}
+static inline void MetaSqueeze(MImage* img, MTransform* t) {  // squeeze.cc:456-517
+  if (t->squeezes.empty()) DefaultSqueezeSteps(*img, &t->squeezes);
+  for (const SqueezeStep& q : t->squeezes) {
+    const size_t nc = img->ch.size();
+    JXLO_CHECK(q.num_c >= 1 && q.begin_c < nc && q.begin_c + q.num_c - 1 < nc, "squeeze: invalid channel range");
+    const uint32_t beginc = q.begin_c, endc = q.begin_c + q.num_c - 1;
+    if (beginc < img->nb_meta) {
+      JXLO_CHECK(endc < img->nb_meta, "squeeze: mix of meta and non-meta channels");
+      JXLO_CHECK(q.in_place, "squeeze: meta channels require in-place residuals");
+      img->nb_meta += q.num_c;
+    }
+    const size_t offset = q.in_place ? endc + 1 : img->ch.size();
+    for (uint32_t c = beginc; c <= endc; c++) {
+      MChannel& ch = img->ch[c];
+      JXLO_CHECK(ch.hshift <= 30 && ch.vshift <= 30, "squeeze: too many squeezes");
+      size_t w = ch.w, h = ch.h;
+      JXLO_CHECK(w && h, "squeeze of an empty channel");
+      if (q.horizontal) {
+        ch.w = (w + 1) / 2;
+        if (ch.hshift >= 0) ch.hshift++;
+        w = w - (w + 1) / 2;
+      } else {
+        ch.h = (h + 1) / 2;
+        if (ch.vshift >= 0) ch.vshift++;
+        h = h - (h + 1) / 2;
+      }
+      ch.d.assign(ch.w * ch.h, 0);
+      MChannel residual(w, h, ch.hshift, ch.vshift);
+      img->ch.insert(img->ch.begin() + offset + (c - beginc), residual);
+    }
+  }
+}
+static inline void InvHSqueeze(MImage* img, uint32_t c, uint32_t rc) {  // squeeze.cc:128-239
+  MChannel& chin = img->ch[c];
+  const MChannel& res = img->ch[rc];
+  JXLO_CHECK(chin.w == (chin.w + res.w + 1) / 2 && chin.h == res.h, "squeeze: channel sizes do not match");
+  if (res.w == 0) {
+    chin.hshift--;
+    return;
+  }
+  MChannel out(chin.w + res.w, chin.h, chin.hshift - 1, chin.vshift);
+  for (size_t y = 0; y < chin.h && res.h; y++) {
+    const int32_t* p_res = res.Row(y);
+    const int32_t* p_avg = chin.Row(y);
+    int32_t* p_out = out.Row(y);
+    for (size_t x = 0; x < res.w; x++) {
+      const int64_t avg = p_avg[x], next_avg = x + 1 < chin.w ? p_avg[x + 1] : avg, left = x ? p_out[(x << 1) - 1] : avg;
+      const int64_t diff = int64_t(p_res[x]) + SmoothTendency(left, avg, next_avg);
+      const int64_t A = avg + diff / 2;
+      p_out[x << 1] = int32_t(A);
+      p_out[(x << 1) + 1] = int32_t(A - diff);
+    }
+    if (out.w & 1) p_out[out.w - 1] = p_avg[chin.w - 1];
+  }
+  img->ch[c] = out;
+}
+static inline void InvVSqueeze(MImage* img, uint32_t c, uint32_t rc) {  // squeeze.cc:241-329
+  MChannel& chin = img->ch[c];
+  const MChannel& res = img->ch[rc];
+  JXLO_CHECK(chin.h == (chin.h + res.h + 1) / 2 && chin.w == res.w, "squeeze: channel sizes do not match");
+  if (res.h == 0) {
+    chin.vshift--;
+    return;
+  }
+  MChannel out(chin.w, chin.h + res.h, chin.hshift, chin.vshift - 1);
+  for (size_t y = 0; y < res.h && res.w; y++) {
+    const int32_t* p_res = res.Row(y);
+    const int32_t* p_avg = chin.Row(y);
+    const int32_t* p_navg = chin.Row(y + 1 < chin.h ? y + 1 : y);
+    int32_t* p_out = out.Row(y << 1);
+    int32_t* p_nout = out.Row((y << 1) + 1);
+    const int32_t* p_pout = y > 0 ? out.Row((y << 1) - 1) : p_avg;
+    for (size_t x = 0; x < chin.w; x++) {
+      const int64_t avg = p_avg[x], next_avg = p_navg[x], top = p_pout[x];
+      const int64_t diff = int64_t(p_res[x]) + SmoothTendency(top, avg, next_avg);
+      const int64_t o = avg + diff / 2;
+      p_out[x] = int32_t(o);
+      p_nout[x] = int32_t(o - diff);
+    }
+  }
+  if ((out.h & 1) && res.w) {
+    const size_t y = chin.h - 1;
+    memcpy(out.Row(y << 1), chin.Row(y), chin.w * sizeof(int32_t));
+  }
+  img->ch[c] = out;
+}
+static inline void InvSqueeze(MImage* img, const MTransform& t) {  // squeeze.cc:331-378
+  for (size_t i = t.squeezes.size(); i-- > 0;) {
+    const SqueezeStep& q = t.squeezes[i];
+    const size_t nc = img->ch.size();
+    JXLO_CHECK(q.num_c >= 1 && q.begin_c < nc && q.begin_c + q.num_c - 1 < nc, "squeeze: invalid channel range");
+    const uint32_t beginc = q.begin_c, endc = q.begin_c + q.num_c - 1;
+    const uint32_t offset = q.in_place ? endc + 1 : uint32_t(nc + beginc - endc - 1);
+    if (beginc < img->nb_meta) {
+      JXLO_CHECK(img->nb_meta > q.num_c, "squeeze: invalid meta channel count");
+      img->nb_meta -= q.num_c;
+    }
+    for (uint32_t c = beginc; c <= endc; c++) {
+      const uint32_t rc = offset + c - beginc;
+      JXLO_CHECK(rc < img->ch.size(), "squeeze: residual channel out of range");
+      if (q.horizontal) InvHSqueeze(img, c, rc);
+      else InvVSqueeze(img, c, rc);
+    }
+    img->ch.erase(img->ch.begin() + offset, img->ch.begin() + offset + (endc - beginc + 1));
+  }
 }
 
 static inline void InvRct(MImage* img, const MTransform& t) {
@@ -458,13 +631,15 @@ static inline void InvPalette(MImage* img, const MTransform& t) {
   img->ch.erase(img->ch.begin());
 }
 
-static inline void MetaApply(MImage* img, const MTransform& t) {
+static inline void MetaApply(MImage* img, MTransform& t) {
   if (t.id == 0) CheckEqualChannels(*img, t.begin_c, t.begin_c + 2);
   else if (t.id == 1) MetaPalette(img, t);
+  else if (t.id == 2) MetaSqueeze(img, &t);
 }
 static inline void InverseTransform(MImage* img, const MTransform& t) {
   if (t.id == 0) InvRct(img, t);
   else if (t.id == 1) InvPalette(img, t);
+  else if (t.id == 2) InvSqueeze(img, t);
 }
 
 // Decodes one Modular stream into `img` (whose channels are pre-sized) and undoes its transforms.

@@ -62,14 +62,20 @@ def test_fjxl_live_when_reference_encoder_present(built, tmp_path):
 
 
 def test_reference_decode_test_1x1_stream(built):
-    """The only codestream embedded in the reference's tests (lib/jxl/decode_test.cc:2512-2517, a 1x1 image):
-    signature, SizeHeader, ImageMetadata, FrameHeader, TOC and the entropy-coded Modular global section parse
-    cleanly; the stream uses the Squeeze transform, which the oracle does not implement yet and must say so."""
+    """The only codestream embedded in the reference's tests (lib/jxl/decode_test.cc:2512-2517): a 1x1 image that
+    libjxl itself encoded as a VarDCT frame with an alpha channel (Modular, default Squeeze transform). The oracle decodes
+    it completely: signature, SizeHeader, ImageMetadata with an extra channel, FrameHeader, single-section TOC, DC global
+    (quantiser, block context map, colour correlation, global MA tree), DC group, AC global (dequant tables, coefficient
+    orders, ANS histograms), the AC group and the Squeeze-coded alpha, with the ANS final-state and section-size checks of
+    every stream satisfied. The reference only asserts decoder statuses for it, so the pixel itself is not a golden value."""
     import jxlo
     data = open(os.path.join(GOLDEN, "ref_decode_test_1x1.jxl"), "rb").read()
     assert len(data) == 68
-    with pytest.raises(RuntimeError, match="Squeeze"):
-        jxlo.Decoded(data)
+    o = jxlo.Decoded(data)
+    assert o.out_size == (1, 1) and o.info["modular"] == 0 and o.info["channels"] == 4
+    assert o.rgb8.shape == (1, 1, 4)
+    assert o.rgb8[0, 0, 3] == 255  # opaque
+    o.close()
 
 
 @pytest.mark.parametrize("seed", [1, 2])
