@@ -9,6 +9,7 @@
 #define JXH_FRAME_H_
 
 #include <functional>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -178,11 +179,18 @@ class FrameParser {
       P.first_section_bit_offset = uint32_t(r.BitPos() & 7);
       P.section_size[0] = uint32_t(toc.size[0] - r.BitPos() / 8);
     } else {
+      const bool timing = getenv("JXLAMD_TIMING") != nullptr;  // debugging aid: stage times of the host front-end
+      auto now = [] { return std::chrono::steady_clock::now(); };
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+      };
+      const auto t0 = now();
       {
         BitReader r(data_ + base + toc.offset[0], toc.size[0]);
         DcGlobal(r, &P);
         JXH_CHECK(!r.Overread(), "DC global over-read");
       }
+      const auto t1 = now();
       std::string err;
       pfor(d.num_dc_groups, [&](size_t g) {
         try {
@@ -194,13 +202,18 @@ class FrameParser {
         }
       });
       JXH_CHECK(err.empty(), err);
+      const auto t2 = now();
       FinalizeDc(&P);
+      const auto t3 = now();
       {
         size_t i = 1 + d.num_dc_groups;
         BitReader r(data_ + base + toc.offset[i], toc.size[i]);
         AcGlobal(r, &P);
         JXH_CHECK(!r.Overread(), "AC global over-read");
       }
+      if (timing)
+        fprintf(stderr, "[host parse] DC global %.2f ms, DC groups %.2f ms, DC smoothing + sigma %.2f ms, AC global %.2f ms\n", ms(t0, t1),
+                ms(t1, t2), ms(t2, t3), ms(t3, now()));
       for (size_t p = 0; p < np; p++)
         for (size_t g = 0; g < d.num_groups; g++) {
           size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;

@@ -112,6 +112,30 @@ def test_jxl_decoder_api_events_without_pixels(built):
     L.JxlDecoderDestroy(dec)
 
 
+def test_reference_dc_not_gettable_sequence(built):
+    """DecodeTest.DCNotGettableTest (lib/jxl/decode_test.cc:2509-2536) on the reference's own 68-byte stream: subscribed to
+    BASIC_INFO only, JxlDecoderProcessInput returns JXL_DEC_BASIC_INFO and then JXL_DEC_SUCCESS."""
+    J = built
+    L = J.lib()
+    L.JxlDecoderCreate.restype = ctypes.c_void_p
+    L.JxlDecoderCreate.argtypes = [ctypes.c_void_p]
+    for n in ("JxlDecoderDestroy", "JxlDecoderProcessInput"):
+        getattr(L, n).argtypes = [ctypes.c_void_p]
+    L.JxlDecoderSubscribeEvents.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.JxlDecoderSetInput.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.JxlDecoderGetBasicInfo.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    data = open(os.path.join(ROOT, "tests", "golden", "ref_decode_test_1x1.jxl"), "rb").read()
+    dec = L.JxlDecoderCreate(None)
+    assert L.JxlDecoderSubscribeEvents(dec, 0x40) == 0
+    assert L.JxlDecoderSetInput(dec, data, len(data)) == 0
+    assert L.JxlDecoderProcessInput(dec) == 0x40  # JXL_DEC_BASIC_INFO
+    info = (ctypes.c_uint32 * 64)()
+    assert L.JxlDecoderGetBasicInfo(dec, info) == 0
+    assert (info[1], info[2], info[3]) == (1, 1, 8)
+    assert L.JxlDecoderProcessInput(dec) == 0    # JXL_DEC_SUCCESS
+    L.JxlDecoderDestroy(dec)
+
+
 def test_thread_parallel_runner(built):
     L = built.lib()
     L.JxlThreadParallelRunnerCreate.restype = ctypes.c_void_p
