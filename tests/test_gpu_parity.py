@@ -386,3 +386,20 @@ def test_jxl_decoder_api_full_image(built):
             assert (rows[..., 3] == 255).all()
         L.JxlDecoderDestroy(dec)
         L.JxlThreadParallelRunnerDestroy(pool)
+    # an upsampled frame: the caller sees the image size, not the coded frame's
+    data = J.encode_rgb8(J.synth_image(333, 222), upsampling=2)
+    ref = jxlo.Decoded(data, dumps=False).rgb8
+    dec = L.JxlDecoderCreate(None)
+    assert L.JxlDecoderSubscribeEvents(dec, 0x1000) == 0
+    L.JxlDecoderSetInput(dec, data, len(data))
+    L.JxlDecoderCloseInput(dec)
+    assert L.JxlDecoderProcessInput(dec) == 5
+    fmt = Fmt(3, 2, 0, 0)
+    size = ctypes.c_size_t()
+    assert L.JxlDecoderImageOutBufferSize(dec, ctypes.byref(fmt), ctypes.byref(size)) == 0
+    assert size.value == 333 * 222 * 3
+    buf = np.zeros(size.value, np.uint8)
+    assert L.JxlDecoderSetImageOutBuffer(dec, ctypes.byref(fmt), buf.ctypes.data, size.value) == 0
+    assert L.JxlDecoderProcessInput(dec) == 0x1000
+    assert np.abs(buf.reshape(222, 333, 3).astype(int) - ref.astype(int)).max() <= 1
+    L.JxlDecoderDestroy(dec)
