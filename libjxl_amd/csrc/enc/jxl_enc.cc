@@ -528,7 +528,7 @@ struct Params {
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
   int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
-  int32_t reserved[1];
+  int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -618,6 +618,53 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   std::vector<std::vector<uint32_t>> natural(13);
   for (int s = 0; s < 27; s++)
     if (natural[jxh::kStrategyOrder[s]].empty()) jxh::NaturalOrder(s, &natural[jxh::kStrategyOrder[s]]);
+  // coefficient orders actually used: the natural ones, or (custom_orders) natural[perm[k]] with a coded permutation
+  // (coeff_order.cc:37-62,102-156: Lehmer code of the permutation, entries below the LLF count fixed)
+  bool used_bucket[13] = {};
+  for (uint8_t a : f.acs)
+    if (a != 0xFF && (a & 1)) used_bucket[jxh::kStrategyOrder[a >> 1]] = true;
+  uint32_t used_orders = 0;
+  std::vector<std::vector<uint32_t>> scan(num_passes * 13 * 3);  // [(pass * 13 + ord) * 3 + c]
+  std::vector<std::vector<Token>> perm_tokens(num_passes);
+  auto order_ctx = [](uint32_t v) { return v == 0 ? 0u : std::min<uint32_t>(1u + uint32_t(jxh::FloorLog2(v)), 7u); };
+  for (size_t pass = 0; pass < num_passes; pass++) {
+    Rng prng(p.seed * 7919u + uint32_t(pass) + 17u);
+    bool done[13] = {};
+    for (int o = 0; o < 27; o++) {  // the decoder's bucket order: first strategy of each bucket
+      const int ord = jxh::kStrategyOrder[o];
+      if (done[ord]) continue;
+      done[ord] = true;
+      if (!used_bucket[ord]) continue;
+      const size_t llf = size_t(jxh::kCoveredX[o]) * jxh::kCoveredY[o], size = 64 * llf;
+      for (int c = 0; c < 3; c++) {
+        std::vector<uint32_t>& sc = scan[(pass * 13 + ord) * 3 + c];
+        sc = natural[ord];
+        if (!p.custom_orders) continue;
+        used_orders |= 1u << ord;
+        const size_t win = std::min<size_t>(size - llf, 48);
+        std::vector<uint32_t> perm(size);
+        for (size_t k = 0; k < size; k++) perm[k] = uint32_t(k);
+        for (size_t k = win; k > 1; k--) std::swap(perm[llf + k - 1], perm[llf + prng.Below(uint32_t(k))]);
+        for (size_t k = 0; k < size; k++) sc[k] = natural[ord][perm[k]];
+        // Lehmer code: how many later entries are smaller (all entries beyond the shuffled window are larger)
+        std::vector<uint32_t> lehmer(llf + win, 0);
+        size_t end = llf;
+        for (size_t i = llf; i < llf + win; i++) {
+          for (size_t j = i + 1; j < llf + win; j++) lehmer[i] += perm[j] < perm[i];
+          if (lehmer[i]) end = i + 1;
+        }
+        perm_tokens[pass].push_back({order_ctx(uint32_t(size)), uint32_t(end - llf)});
+        uint32_t last = 0;
+        for (size_t i = llf; i < end; i++) {
+          perm_tokens[pass].push_back({order_ctx(last), lehmer[i]});
+          last = lehmer[i];
+        }
+      }
+    }
+  }
+  std::vector<EncCode> perm_codes(num_passes);
+  if (used_orders)
+    for (size_t pass = 0; pass < num_passes; pass++) BuildCode({&perm_tokens[pass]}, 8, 8, cfg420, &perm_codes[pass]);
 #pragma omp parallel for schedule(dynamic)
   for (size_t pg = 0; pg < num_groups * num_passes; pg++) {
     const size_t g = pg % num_groups, pass = pg / num_groups;
@@ -645,7 +692,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
           const int32_t* top = by ? nzc + (by - 1) * 32 : nullptr;
           int32_t* cur = nzc + by * 32;
           int32_t pred = bx == 0 ? (top ? top[0] : 32) : (!top ? cur[bx - 1] : (top[bx] + cur[bx - 1] + 1) / 2);
-          const uint32_t* order = natural[ord].data();
+          const uint32_t* order = scan[(pass * 13 + ord) * 3 + c].data();
           size_t nz = 0;
           for (size_t k = covered; k < size; k++) nz += part(q[order[k]]) != 0;
           size_t bc = bctx.Context(0, qf, ord, c);
@@ -709,7 +756,14 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(1, 1);                            // default dequant tables
     bw.Write(CeilLog2(num_groups), uint32_t(num_hist - 1));  // number of histogram sets - 1
     for (size_t pass = 0; pass < num_passes; pass++) {
-      bw.Write(2, 2);                          // used_orders = 0
+      if (!used_orders) {
+        bw.Write(2, 2);                        // used_orders = 0
+      } else {
+        bw.Write(2, 3);                        // used_orders: 13-bit mask of the order buckets with a coded permutation
+        bw.Write(13, used_orders);
+        WriteCodeHeader(bw, perm_codes[pass]);
+        WriteTokens(bw, perm_tokens[pass].data(), perm_tokens[pass].size(), perm_codes[pass]);
+      }
       WriteCodeHeader(bw, ac_codes[pass]);
     }
   };
@@ -1169,7 +1223,7 @@ struct JxlEncParams {
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
   int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
-  int32_t reserved[1];
+  int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

@@ -71,6 +71,9 @@ def _compare(J, jxlo, data, check_rgb=True):
     ((300, 200), dict(skip_dc_smoothing=1)),
     ((1000, 700), dict(num_histograms=3)),                # several AC histogram sets (libjxl's streaming encoder)
     ((1300, 1100), dict(num_histograms=30, strategy_mode=2, distance=2.0)),  # one set per group
+    ((700, 520), dict(custom_orders=1)),                  # coded (Lehmer) coefficient orders, different per channel
+    ((777, 600), dict(custom_orders=1, strategy_mode=2, num_histograms=2, distance=2.0)),
+    ((520, 300), dict(custom_orders=1, num_passes=2)),    # ... and different per pass
     ((700, 520), dict(num_passes=2)),                     # progressive: two passes, pass 0 shifted by one bit
     ((200, 100), dict(num_passes=2)),                     # ... with a single group
     ((1000, 700), dict(num_passes=2, num_histograms=3, distance=2.0)),
@@ -92,7 +95,7 @@ def test_every_strategy_random_stream(built, strategy):
 def test_all_strategies_mixed(built, seed, epf):
     import jxlo
     J = built
-    _compare(J, jxlo, J.encode_random(777, 600, seed=seed, epf_iters=epf))
+    _compare(J, jxlo, J.encode_random(777, 600, seed=seed, epf_iters=epf, custom_orders=seed & 1))
 
 
 def test_full_size_4k(built):
