@@ -529,6 +529,8 @@ struct Params {
   int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
   int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
+  int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)
+  int32_t reserved[4];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -611,6 +613,48 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   // ---- tokenise AC groups
   jxh::BlockCtxMap bctx;
+  if (p.custom_bctx) {
+    // thresholds at quantiles of what the frame actually holds, so that every bucket is exercised
+    auto quantile = [](std::vector<int32_t> v, double q) {
+      std::sort(v.begin(), v.end());
+      return v.empty() ? 0 : v[std::min(v.size() - 1, size_t(q * double(v.size())))];
+    };
+    std::vector<int32_t> qfs;
+    for (size_t i = 0; i < f.acs.size(); i++)
+      if (f.acs[i] != 0xFF && (f.acs[i] & 1)) qfs.push_back(f.qf[i]);
+    const int32_t q1 = quantile(qfs, 0.33), q2 = quantile(qfs, 0.66);
+    bctx.qf_thresholds.clear();
+    if (q1 >= 1) bctx.qf_thresholds.push_back(uint32_t(q1));
+    if (q2 > q1) bctx.qf_thresholds.push_back(uint32_t(q2));
+    bctx.dc_thresholds[0].clear();
+    bctx.dc_thresholds[1] = {quantile(f.dc[1], 0.5)};
+    bctx.dc_thresholds[2] = {quantile(f.dc[2], 0.3), quantile(f.dc[2], 0.7)};
+    if (bctx.dc_thresholds[2][1] <= bctx.dc_thresholds[2][0]) bctx.dc_thresholds[2].pop_back();
+    bctx.num_dc_ctxs = (bctx.dc_thresholds[1].size() + 1) * (bctx.dc_thresholds[2].size() + 1);
+    const size_t nq = bctx.qf_thresholds.size() + 1;
+    bctx.ctx_map.assign(3 * jxh::kNumOrders * nq * bctx.num_dc_ctxs, 0);
+    size_t mx = 0;
+    for (size_t i = 0; i < bctx.ctx_map.size(); i++) {
+      const size_t dc = i % bctx.num_dc_ctxs, qf = (i / bctx.num_dc_ctxs) % nq, ord = (i / (bctx.num_dc_ctxs * nq)) % jxh::kNumOrders,
+                   c = i / (bctx.num_dc_ctxs * nq * jxh::kNumOrders);
+      const size_t v = c * 5 + (std::min<size_t>(ord, 2) + qf + dc) % 5;  // 15 contexts, every input matters
+      bctx.ctx_map[i] = uint8_t(v);
+      mx = std::max(mx, v);
+    }
+    bctx.num_ctxs = mx + 1;
+  }
+  // DC bucket of a block: from the quantised DC at its top-left corner (dec_modular.cc / compressed_dc.cc)
+  auto dc_bucket = [&](size_t i) -> int {
+    if (bctx.num_dc_ctxs <= 1) return 0;
+    int kx = 0, ky = 0, kb = 0;
+    for (int t : bctx.dc_thresholds[0]) kx += f.dc[0][i] > t;
+    for (int t : bctx.dc_thresholds[1]) ky += f.dc[1][i] > t;
+    for (int t : bctx.dc_thresholds[2]) kb += f.dc[2][i] > t;
+    int b = kx;
+    b = b * int(bctx.dc_thresholds[2].size() + 1) + kb;
+    b = b * int(bctx.dc_thresholds[1].size() + 1) + ky;
+    return b;
+  };
   const size_t nctx = bctx.NumACContexts();
   const size_t num_hist = (p.num_histograms > 1 && num_groups > 1) ? std::min<size_t>(size_t(p.num_histograms), num_groups) : 1;
   const size_t num_passes = p.num_passes == 2 ? 2 : 1;
@@ -695,7 +739,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
           const uint32_t* order = scan[(pass * 13 + ord) * 3 + c].data();
           size_t nz = 0;
           for (size_t k = covered; k < size; k++) nz += part(q[order[k]]) != 0;
-          size_t bc = bctx.Context(0, qf, ord, c);
+          size_t bc = bctx.Context(dc_bucket((by0 + by) * f.xb + bx0 + bx), qf, ord, c);
           const size_t hist_off = (g % num_hist) * nctx;  // this group's histogram set
           out_t.push_back({uint32_t(hist_off + bctx.NonZeroContext(uint32_t(pred), bc)), uint32_t(nz)});
           for (size_t y = 0; y < cy; y++)
@@ -730,7 +774,23 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
       static const uint32_t bits[4] = {0, 5, 8, 16}, offs[4] = {16, 1, 1, 1};
       WriteU32Sel(bw, f.quant_dc, bits, offs);
     }
-    bw.Write(1, 1);  // default block context map
+    if (!p.custom_bctx) {
+      bw.Write(1, 1);  // default block context map
+    } else {
+      bw.Write(1, 0);
+      static const uint32_t tb[4] = {4, 8, 16, 32}, to[4] = {0, 16, 272, 65808};
+      for (int j = 0; j < 3; j++) {
+        bw.Write(4, bctx.dc_thresholds[j].size());
+        for (int32_t t : bctx.dc_thresholds[j]) WriteU32Sel(bw, PackSigned(t), tb, to);
+      }
+      bw.Write(4, bctx.qf_thresholds.size());
+      static const uint32_t qb[4] = {2, 3, 5, 8}, qo[4] = {0, 4, 12, 44};
+      for (uint32_t t : bctx.qf_thresholds) WriteU32Sel(bw, t - 1, qb, qo);
+      EncCode cm;
+      cm.ctx_map = bctx.ctx_map;
+      cm.num_clusters = bctx.num_ctxs;
+      WriteContextMap(bw, cm);
+    }
     bw.Write(1, 1);  // default colour correlation
     bw.Write(1, 1);  // has global tree
     WriteCodeHeader(bw, tree_code);
@@ -1224,6 +1284,8 @@ struct JxlEncParams {
   int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
   int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
+  int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)
+  int32_t reserved[4];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
