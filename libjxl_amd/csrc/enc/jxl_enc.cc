@@ -530,7 +530,9 @@ struct Params {
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
   int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
   int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)
-  int32_t reserved[4];
+  int32_t custom_cmap;     // 1 = non-default colour-correlation header (factor 100, bases 0.25 / 0.75, DC factors 3 / -5) and
+                           //     x/b quant-matrix scales 2 / 4: valid streams, but image mode does not compensate for them
+  int32_t reserved[3];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -791,7 +793,17 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
       cm.num_clusters = bctx.num_ctxs;
       WriteContextMap(bw, cm);
     }
-    bw.Write(1, 1);  // default colour correlation
+    if (!p.custom_cmap) {
+      bw.Write(1, 1);  // default colour correlation
+    } else {           // chroma_from_luma.h:112-140
+      bw.Write(1, 0);
+      bw.Write(2, 2);      // color_factor = 2 + 8 bits
+      bw.Write(8, 98);     //   = 100
+      bw.Write(16, 0x3400);  // base_correlation_x = 0.25 (F16)
+      bw.Write(16, 0x3A00);  // base_correlation_b = 0.75
+      bw.Write(8, 128 + 3);  // ytox_dc
+      bw.Write(8, 128 - 5);  // ytob_dc
+    }
     bw.Write(1, 1);  // has global tree
     WriteCodeHeader(bw, tree_code);
     WriteTokens(bw, tree_tokens.data(), tree_tokens.size(), tree_code);
@@ -894,8 +906,8 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(8, f.flags - 17);
   }
   bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
-  bw.Write(3, 3);  // x_qm_scale
-  bw.Write(3, 2);  // b_qm_scale
+  bw.Write(3, p.custom_cmap ? 2 : 3);  // x_qm_scale
+  bw.Write(3, p.custom_cmap ? 4 : 2);  // b_qm_scale
   if (num_passes == 1) {
     bw.Write(2, 0);  // one pass
   } else {
@@ -1285,7 +1297,9 @@ struct JxlEncParams {
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
   int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
   int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)
-  int32_t reserved[4];
+  int32_t custom_cmap;     // 1 = non-default colour-correlation header (factor 100, bases 0.25 / 0.75, DC factors 3 / -5) and
+                           //     x/b quant-matrix scales 2 / 4: valid streams, but image mode does not compensate for them
+  int32_t reserved[3];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

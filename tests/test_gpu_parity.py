@@ -71,6 +71,7 @@ def _compare(J, jxlo, data, check_rgb=True):
     ((300, 200), dict(skip_dc_smoothing=1)),
     ((1000, 700), dict(num_histograms=3)),                # several AC histogram sets (libjxl's streaming encoder)
     ((1300, 1100), dict(num_histograms=30, strategy_mode=2, distance=2.0)),  # one set per group
+    ((600, 400), dict(custom_cmap=1, random_cmap=1)),     # coded colour correlation (factor, bases, DC factors), qm scales
     ((700, 520), dict(custom_bctx=1)),                    # coded block context map: quant-field and DC thresholds
     ((1000, 700), dict(custom_bctx=1, custom_orders=1, num_histograms=3, strategy_mode=2)),
     ((520, 300), dict(custom_bctx=1, num_passes=2)),
@@ -98,7 +99,7 @@ def test_every_strategy_random_stream(built, strategy):
 def test_all_strategies_mixed(built, seed, epf):
     import jxlo
     J = built
-    _compare(J, jxlo, J.encode_random(777, 600, seed=seed, epf_iters=epf, custom_orders=seed & 1, custom_bctx=(seed >> 1) & 1))
+    _compare(J, jxlo, J.encode_random(777, 600, seed=seed, epf_iters=epf, custom_orders=seed & 1, custom_bctx=(seed >> 1) & 1, custom_cmap=int(seed == 4)))
 
 
 def test_full_size_4k(built):
