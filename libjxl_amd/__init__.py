@@ -233,7 +233,7 @@ class EncParams(ctypes.Structure):
                 ("strategy_mode", ctypes.c_int32), ("strategy_mask", ctypes.c_uint32), ("seed", ctypes.c_uint32),
                 ("max_clusters", ctypes.c_int32), ("skip_dc_smoothing", ctypes.c_int32), ("random_cmap", ctypes.c_int32),
                 ("zero_ac", ctypes.c_int32), ("num_histograms", ctypes.c_int32), ("big_coeffs", ctypes.c_int32), ("num_passes", ctypes.c_int32), ("upsampling", ctypes.c_int32), ("custom_orders", ctypes.c_int32), ("custom_bctx", ctypes.c_int32),
-                ("custom_cmap", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("custom_cmap", ctypes.c_int32), ("custom_lf", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
 
 
 def _enc_lib():

@@ -341,6 +341,20 @@ static void WriteCodeHeader(BitWriter& bw, const EncCode& code) {
   for (size_t k = 0; k < code.num_clusters; k++) WriteHistogram(bw, code.norm[k]);
 }
 
+// IEEE half (fields.cc:550-575): the value must be a normal half-precision number or zero.
+static void WriteF16(BitWriter& bw, float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  const uint32_t sign = u >> 31, e32 = (u >> 23) & 0xFF, m32 = u & 0x7FFFFF;
+  uint32_t h = 0;
+  if (e32 != 0) {
+    const int e = int(e32) - 127 + 15;
+    if (e <= 0 || e >= 31 || (m32 & 0x1FFF)) abort();  // only exactly representable normal values are used here
+    h = (sign << 15) | (uint32_t(e) << 10) | (m32 >> 13);
+  }
+  bw.Write(16, h);
+}
+
 static void WriteU32Sel(BitWriter& bw, uint32_t v, const uint32_t bits[4], const uint32_t offs[4]) {
   for (int s = 0; s < 4; s++) {
     if (bits[s] == 0) {
@@ -532,7 +546,9 @@ struct Params {
   int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)
   int32_t custom_cmap;     // 1 = non-default colour-correlation header (factor 100, bases 0.25 / 0.75, DC factors 3 / -5) and
                            //     x/b quant-matrix scales 2 / 4: valid streams, but image mode does not compensate for them
-  int32_t reserved[3];
+  int32_t custom_lf;       // 1 = non-default loop filter header: Gaborish weights, EPF sharpness LUT, channel scales and
+                           //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
+  int32_t reserved[2];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -767,7 +783,14 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   // ---- sections
   auto write_dc_global = [&](BitWriter& bw) {
-    bw.Write(1, 1);  // DC dequant all_default
+    if (!p.custom_lf) {
+      bw.Write(1, 1);  // DC dequant all_default
+    } else {
+      bw.Write(1, 0);
+      WriteF16(bw, 0.03125f);   // X: step = value / 128 (default 1/4096)
+      WriteF16(bw, 0.3125f);    // Y (default 1/512)
+      WriteF16(bw, 0.4375f);    // B (default 1/256)
+    }
     {
       static const uint32_t bits[4] = {11, 11, 12, 16}, offs[4] = {1, 2049, 4097, 8193};
       WriteU32Sel(bw, f.global_scale, bits, offs);
@@ -921,12 +944,37 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(2, 0);  // no name
   bw.Write(1, 0);  // loop filter not all_default
   bw.Write(1, f.gab ? 1 : 0);
-  if (f.gab) bw.Write(1, 0);  // default gaborish weights
+  if (f.gab) {
+    if (!p.custom_lf) {
+      bw.Write(1, 0);  // default gaborish weights
+    } else {
+      bw.Write(1, 1);
+      static const float w[6] = {0.125f, 0.046875f, 0.09375f, 0.0625f, 0.109375f, 0.03125f};
+      for (float v : w) WriteF16(bw, v);
+    }
+  }
   bw.Write(2, f.epf_iters);
   if (f.epf_iters > 0) {
-    bw.Write(1, 0);  // default sharpness LUT
-    bw.Write(1, 0);  // default channel weights
-    bw.Write(1, 0);  // default sigma parameters
+    if (!p.custom_lf) {
+      bw.Write(1, 0);  // default sharpness LUT
+      bw.Write(1, 0);  // default channel weights
+      bw.Write(1, 0);  // default sigma parameters
+    } else {
+      bw.Write(1, 1);
+      static const float lut[8] = {0.0f, 0.25f, 0.375f, 0.5f, 0.625f, 0.75f, 0.875f, 1.0f};
+      for (float v : lut) WriteF16(bw, v);
+      bw.Write(1, 1);
+      WriteF16(bw, 32.0f);   // channel scales
+      WriteF16(bw, 6.0f);
+      WriteF16(bw, 2.5f);
+      WriteF16(bw, 0.5f);    // pass1 / pass2 zero-flush (parsed, unused by the decoder)
+      WriteF16(bw, 0.25f);
+      bw.Write(1, 1);
+      WriteF16(bw, 0.5f);    // quant_mul
+      WriteF16(bw, 0.75f);   // pass0 sigma scale
+      WriteF16(bw, 5.0f);    // pass2 sigma scale
+      WriteF16(bw, 0.5f);    // border SAD multiplier
+    }
   }
   bw.Write(2, 0);  // no loop-filter extensions
   bw.Write(2, 0);  // no frame-header extensions
@@ -1299,7 +1347,9 @@ struct JxlEncParams {
   int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)
   int32_t custom_cmap;     // 1 = non-default colour-correlation header (factor 100, bases 0.25 / 0.75, DC factors 3 / -5) and
                            //     x/b quant-matrix scales 2 / 4: valid streams, but image mode does not compensate for them
-  int32_t reserved[3];
+  int32_t custom_lf;       // 1 = non-default loop filter header: Gaborish weights, EPF sharpness LUT, channel scales and
+                           //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
+  int32_t reserved[2];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

@@ -21,7 +21,7 @@ for it in range(n):
     kw = dict(seed=rnd.randint(1, 10 ** 6), epf_iters=rnd.choice([-1, 0, 1, 2, 3]), gab=rnd.choice([-1, 0, 1]),
               num_histograms=rnd.choice([0, 1, 2, 7]), max_clusters=rnd.choice([0, 1, 4, 100]),
               upsampling=rnd.choice([0, 0, 0, 2, 4, 8]), num_passes=rnd.choice([1, 1, 1, 2]),
-              custom_orders=rnd.choice([0, 1]), custom_bctx=rnd.choice([0, 1]), custom_cmap=rnd.choice([0, 0, 1]))
+              custom_orders=rnd.choice([0, 1]), custom_bctx=rnd.choice([0, 1]), custom_cmap=rnd.choice([0, 0, 1]), custom_lf=rnd.choice([0, 0, 1]))
     if rnd.random() < 0.5:
         kind = "random"
         data = J.encode_random(xs, ys, strategy_mask=rnd.choice([0, 0, rnd.getrandbits(27) | 1]), **kw)

@@ -102,6 +102,15 @@ def test_all_strategies_mixed(built, seed, epf):
     _compare(J, jxlo, J.encode_random(777, 600, seed=seed, epf_iters=epf, custom_orders=seed & 1, custom_bctx=(seed >> 1) & 1, custom_cmap=int(seed == 4)))
 
 
+@pytest.mark.parametrize("epf", [0, 1, 2, 3])
+def test_custom_loop_filter_and_dc_dequant_headers(built, epf):
+    """Coded (non-default) Gaborish weights, EPF sharpness LUT / channel scales / sigma parameters and DC dequantisation
+    steps (loop_filter.cc:20-100, quantizer.h): the GPU must take them from the stream like the oracle."""
+    import jxlo
+    J = built
+    _compare(J, jxlo, J.encode_random(700, 520, seed=30 + epf, epf_iters=epf, custom_lf=1, custom_cmap=epf & 1))
+
+
 def test_full_size_4k(built):
     """BASELINE.json config[1]: 3840x2160 d1.0 — direct comparison with the oracle (a few seconds of CPU)."""
     import jxlo
