@@ -34,6 +34,8 @@ def lib():
         L.jxlo_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.jxlo_out_size.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.jxlo_free.argtypes = [ctypes.c_void_p]
+        L.jxlo_set_threads.argtypes = [ctypes.c_int]
+        L.jxlo_set_threads.restype = ctypes.c_int
         _lib = L
     return _lib
 

@@ -10,6 +10,8 @@
 // Follows the frame walk of reference lib/jxl/dec_frame.cc:135-733 (InitFrame, ProcessDCGlobal, ProcessDCGroup,
 // FinalizeDC, ProcessACGlobal, ProcessACGroup), lib/jxl/dec_modular.cc:209-562, lib/jxl/dec_group.cc:183-460,
 // lib/jxl/dec_cache.cc:117-371 (stage order), lib/jxl/decode.cc:115-150 (signature).
+#include <omp.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -343,6 +345,7 @@ static void DecodeAcGroupPass(BitReader& br, FrameState* s, size_t g, uint32_t p
   JXLO_CHECK(sel < s->num_histograms, "invalid histogram selector");
   const size_t ctx_offset = sel * s->bctx.NumACContexts();
   const EntropyCode& code = s->ac_codes[pass];
+  uint64_t symbols = 0;  // added to the frame total once per group (groups may run on OpenMP threads)
   SymbolReader rd(&code, &br);
   const std::vector<uint32_t>& orders = s->orders[pass];
   const uint32_t shift = s->fh.pass_shift[pass];
@@ -377,7 +380,7 @@ static void DecodeAcGroupPass(BitReader& br, FrameState* s, size_t g, uint32_t p
         for (size_t k = covered; k < size && nzeros != 0; ++k) {
           size_t ctx = histo_offset + ZeroDensityContext(nzeros, k, covered, log2c, prev);
           uint32_t u = rd.Read(ctx);
-          o->ac_symbols++;
+          symbols++;
           uint32_t mag = u >> 1, neg = (~u) & 1;
           int32_t coeff = int32_t((mag ^ (neg - 1)) << shift);
           block[order[k]] += coeff;
@@ -390,6 +393,8 @@ static void DecodeAcGroupPass(BitReader& br, FrameState* s, size_t g, uint32_t p
     }
   }
   JXLO_CHECK(rd.FinalStateOk(), "AC group: bad ANS final state");
+#pragma omp atomic
+  o->ac_symbols += symbols;
 }
 
 // Dequantise + CfL + LLF + inverse transform for all varblocks of a group (dec_group.cc:115-181, 433-450).
@@ -511,17 +516,28 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       // Downsampling bracket (frame_header.h:268-284) for streams without progressive-downsampling info:
       // the last pass carries shifts 0..2, earlier passes carry no Modular data.
       const int min_shift = 0, max_shift = 2;
+      // Groups are independent (OpenMP threads when the caller sets OMP_NUM_THREADS > 1: bench.py's cpu_baseline; the
+      // tests run it serially or not, the results are identical). Frames with Modular channels keep the serial order.
+      std::string group_error;
+      const bool parallel = !fh.modular && s->full.ch.empty();
+#pragma omp parallel for schedule(dynamic) if (parallel)
       for (size_t g = 0; g < d.num_groups; g++) {
-        size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
-        BitReader r(data + base + toc.offset[i], toc.size[i]);
-        if (!fh.modular)
-          DecodeAcGroupPass(r, s, g, uint32_t(p), out->coeffs.data() + g * 3 * 65536, out->nzeros.data() + g * 3 * 1024);
-        size_t gx = g % d.xsize_groups, gy = g / d.xsize_groups;
-        if (np == 1 || p + 1 == np)
-          DecodeModularGroup(r, s, gx * d.group_dim, gy * d.group_dim, d.group_dim, d.group_dim, min_shift, max_shift,
-                             int(1 + 3 * d.num_dc_groups + 17 + d.num_groups * p + g));
-        check_section(r, "AC group");
+        try {
+          size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
+          BitReader r(data + base + toc.offset[i], toc.size[i]);
+          if (!fh.modular)
+            DecodeAcGroupPass(r, s, g, uint32_t(p), out->coeffs.data() + g * 3 * 65536, out->nzeros.data() + g * 3 * 1024);
+          size_t gx = g % d.xsize_groups, gy = g / d.xsize_groups;
+          if (np == 1 || p + 1 == np)
+            DecodeModularGroup(r, s, gx * d.group_dim, gy * d.group_dim, d.group_dim, d.group_dim, min_shift, max_shift,
+                               int(1 + 3 * d.num_dc_groups + 17 + d.num_groups * p + g));
+          check_section(r, "AC group");
+        } catch (const std::exception& e) {
+#pragma omp critical
+          group_error = e.what();
+        }
       }
+      if (!group_error.empty()) throw Error(group_error);
     }
   }
   br.Skip(base * 8 + toc.total * 8 - br.BitPos());
@@ -537,7 +553,25 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   out->out_channels = has_alpha ? 4 : 3;
   out->rgbf.assign(3 * xs * ys, 0.0f);
   if (!fh.modular) {
-    for (size_t g = 0; g < d.num_groups; g++) ReconstructGroup(s, g, out->coeffs.data() + g * 3 * 65536);
+    // The dequant matrices are built on first use: build them all before the groups run in parallel.
+    // (An invalid table is only an error when a block uses it: dequant_matrices.h EnsureComputed(acs_mask).)
+    for (int st = 0; st < 27; st++) {
+      try {
+        s->dq.Matrix(st, 0);
+      } catch (const std::exception&) {
+      }
+    }
+    std::string group_error;
+#pragma omp parallel for schedule(dynamic)
+    for (size_t g = 0; g < d.num_groups; g++) {
+      try {
+        ReconstructGroup(s, g, out->coeffs.data() + g * 3 * 65536);
+      } catch (const std::exception& e) {
+#pragma omp critical
+        group_error = e.what();
+      }
+    }
+    if (!group_error.empty()) throw Error(group_error);
     if (want_dumps) {
       out->xyb_idct.resize(3 * d.xsize_padded * d.ysize_padded);
       for (int c = 0; c < 3; c++)
@@ -572,6 +606,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       cur = &up;
     }
     OpsinParams op = MakeOpsinParams(ih);
+#pragma omp parallel for schedule(static)
     for (size_t y = 0; y < ys; y++)
       for (size_t x = 0; x < xs; x++) {
         size_t i = y * cur->stride + x;
@@ -608,6 +643,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     alpha.resize(xs * ys);
     for (size_t i = 0; i < xs * ys; i++) alpha[i] = float(ch.d[i]) * af;
   }
+#pragma omp parallel for schedule(static)
   for (size_t y = 0; y < ys; y++)
     for (size_t x = 0; x < xs; x++) {
       for (int c = 0; c < 3; c++) out->rgb8[(y * xs + x) * oc + c] = ToU8(out->rgbf[c * xs * ys + y * xs + x], x, y, c);
@@ -675,6 +711,11 @@ const char* jxlo_error(JxloHandle* h) { return h->error.empty() ? nullptr : h->e
 void jxlo_free(JxloHandle* h) { delete h; }
 // info[0..15]: xsize, ysize, out_channels, is_modular, xsize_blocks, ysize_blocks, xsize_padded, ysize_padded,
 // num_groups, num_dc_groups, epf_iters, gab, num_passes, used_acs, bits, ac_symbols(low 32)
+// Threads for the group / row loops (bench.py's cpu_baseline reports this as "cores"); returns the count in effect.
+int jxlo_set_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
 void jxlo_out_size(JxloHandle* h, uint32_t* wh) {
   wh[0] = uint32_t(h->d.out_xsize);
   wh[1] = uint32_t(h->d.out_ysize);

@@ -44,6 +44,7 @@ static inline void Gaborish(const Planes3& in, const LoopFilter& lf, Planes3* ou
     float w0 = 1.0f, w1 = lf.gab_w[c][0], w2 = lf.gab_w[c][1];
     const float mul = 1.0f / (w0 + 4 * (w1 + w2));
     w0 *= mul; w1 *= mul; w2 *= mul;
+#pragma omp parallel for schedule(static)
     for (int64_t y = 0; y < int64_t(in.ys); y++)
       for (int64_t x = 0; x < int64_t(in.xs); x++) {
         float m = in.At(c, x, y);
@@ -70,6 +71,7 @@ static inline void EpfPass(int stage, const Planes3& in, const LoopFilter& lf, c
   static const int kPlus[5][2] = {{0, 0}, {-1, 0}, {0, -1}, {1, 0}, {0, 1}};
   const int noff = stage == 0 ? 12 : 4;
   const int(*offs)[2] = stage == 0 ? kOff0 : kOff1;
+#pragma omp parallel for schedule(static)
   for (int64_t y = 0; y < int64_t(in.ys); y++)
     for (int64_t x = 0; x < int64_t(in.xs); x++) {
       const size_t o = size_t(y) * in.stride + size_t(x);

@@ -401,11 +401,11 @@ struct DequantTables {
       default:
         throw Error("unsupported quant table mode");
     }
-    table[kind].resize(3 * num);
     for (size_t i = 0; i < 3 * num; i++) {
       JXLO_CHECK(w[i] < 1.0f / 1e-8f && w[i] >= 1e-8f, "invalid quantization table");
-      table[kind][i] = 1.0f / w[i];
+      w[i] = 1.0f / w[i];
     }
+    table[kind] = std::move(w);
   }
   // Dequant matrix (multipliers) for a strategy and channel.
   const float* Matrix(int strategy, int c) {
