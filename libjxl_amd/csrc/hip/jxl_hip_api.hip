@@ -82,8 +82,9 @@ struct JxlHipContext {
   Buf plane[3], rgb, tlist, scratch;
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
   Buf batch_wave_ls;
+  size_t batch_off_units = 0, batch_off_queue = 0, batch_off_wave_lanes = 0, batch_units = 0;  // layout of batch_lanes
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
-  uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64;
+  uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64, batch_wpg = 4;
   int batch_kernel = -1;
   std::vector<uint32_t> sec_size_host, sec_sel_host, pass_clusters, pass_log_alpha;
   // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
@@ -708,6 +709,7 @@ static int LaunchTransforms(JxlHipContext* c0) {
 }
 
 static void FillFusedParams(const JxlHipContext* c, jxlhip::FusedFilterParams* p) {
+  p->debug = uint32_t(EnvInt("JXLHIP_FILTER_DEBUG", 0));
   p->f = c->fp;
   p->f.in = c->plane[0].as<float>();
   p->f.out = nullptr;
@@ -812,26 +814,38 @@ static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
   return 0;
 }
 
+template <typename CoefT, int WPG>
+static int LaunchEntropyLanesW(JxlHipContext* c0);
 template <typename CoefT>
 static int LaunchEntropyLanes(JxlHipContext* c0) {
-  auto k = jxlhip::k_entropy_lanes<CoefT, kLanesWPG>;
+  return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1>(c0)
+                            : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2>(c0) : LaunchEntropyLanesW<CoefT, 4>(c0));
+}
+template <typename CoefT, int WPG>
+static int LaunchEntropyLanesW(JxlHipContext* c0) {
+  auto k = jxlhip::k_entropy_lanes<CoefT, WPG>;
   if (c0->batch_lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
   jxlhip::EntropyLaneBatch b;
   b.params = c0->batch_params.as<jxlhip::EntropyParams>();
-  b.wg_frame = c0->batch_map.as<uint32_t>();
-  b.lane_group = c0->batch_lanes.as<uint32_t>();
+  uint8_t* blob = c0->batch_lanes.as<uint8_t>();
+  b.wg_unit = c0->batch_map.as<uint32_t>();
+  b.list = reinterpret_cast<const uint32_t*>(blob);
+  b.units = reinterpret_cast<const uint4*>(blob + c0->batch_off_units);
+  b.queue = reinterpret_cast<uint32_t*>(blob + c0->batch_off_queue);
+  b.wave_lanes = blob + c0->batch_off_wave_lanes;
+  HIP_TRY(hipMemsetAsync(b.queue, 0, c0->batch_units * 4, c0->stream));
   b.wait_shift = c0->batch_wait_shift;
   b.wave_log_ls = c0->batch_wave_ls.as<uint8_t>();
   b.debug = uint32_t(EnvInt("JXLHIP_LANES_DEBUG", 0));
   b.prof = nullptr;
   const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
-  const size_t nwaves = size_t(c0->batch_wgs) * kLanesWPG;
+  const size_t nwaves = size_t(c0->batch_wgs) * WPG;
   if (prof) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b.prof), nwaves * 64));
     HIP_TRY(hipMemsetAsync(b.prof, 0, nwaves * 64, c0->stream));
   }
-  hipLaunchKernelGGL(k, dim3(c0->batch_wgs), dim3(64 * kLanesWPG), c0->batch_lds, c0->stream, b);
+  hipLaunchKernelGGL(k, dim3(c0->batch_wgs), dim3(64 * WPG), c0->batch_lds, c0->stream, b);
   HIP_TRY(hipGetLastError());
   if (prof) {
     std::vector<unsigned long long> h(nwaves * 8);
@@ -872,107 +886,105 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   for (size_t i = 0; same && i < n; i++) same = c0->batch_ctxs[i] == ctxs[i] && c0->batch_gens[i] == ctxs[i]->generation;
   if (same) return 0;
   std::vector<jxlhip::EntropyParams> params(n);
-  std::vector<uint32_t> map, lanes;
+  std::vector<uint32_t> map, list, unit_desc;
+  std::vector<uint8_t> wave_lanes;
   std::vector<uint8_t> wave_ls;
   size_t lds = 0;
   for (size_t i = 0; i < n; i++) params[i] = ctxs[i]->ep;
   if (kernel == 2) {
-    size_t total_sections = 0;
-    for (size_t i = 0; i < n; i++) total_sections += ctxs[i]->group_list.size();
-    // populated lanes per wave: spread the sections over ~640 waves before packing lanes more densely (measured optimum
-    // on MI355X for 64..256 4K frames: the launch lasts as long as its longest section, and a wave costs the same
-    // issue slots however many of its lanes are populated)
-    uint32_t lanes_per_wave = 1;
-    const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 640));
-    while (lanes_per_wave < 64 && (total_sections + lanes_per_wave - 1) / lanes_per_wave > target_waves) lanes_per_wave *= 2;
-    const int forced = EnvInt("JXLHIP_LANES", 0);
-    if (forced >= 1 && forced <= 64 && (forced & (forced - 1)) == 0) lanes_per_wave = uint32_t(forced);
+    // unit = the sections of one frame that share a histogram set (a workgroup stages ONE set's slice of the context
+    // map; the selector is read from the first bits of every section at upload). The lanes of a unit take its sections
+    // from a queue, largest first, so the split by lanes below only fixes HOW MANY lanes serve a unit:
+    //   * a launch lasts as long as its busiest lane, which cannot beat the unit's longest section, so a unit gets
+    //     about (its total cost) / (cost of its longest section) lanes: more would idle (typical 4K d1.0 frame: 135
+    //     sections of 12k-100k tokens, 60 lanes). The cost of a section is estimated as bytes + kSectionBytes (token
+    //     counts are unknown before decoding; a constant term dominates in sparse sections);
+    //   * small batches that leave SIMDs empty spread over up to one lane per section;
+    //   * the lanes of a unit are split evenly over the waves of its workgroups, and a wave's LDS rows are strided by
+    //     its lane count rounded up to a power of two.
+    const uint32_t kSectionBytes = uint32_t(EnvInt("JXLHIP_SECTION_BYTES", 4000));
+    const size_t target_waves = size_t(EnvInt("JXLHIP_TARGET_WAVES", 1024));
+    const int forced = EnvInt("JXLHIP_LANES", 0);  // measurement aid: lanes per wave
+    const int spread = EnvInt("JXLHIP_SPREAD", 100);  // percent of the minimum lane count (>= 100)
     c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 1));
-    const uint32_t per_wg = lanes_per_wave * kLanesWPG;
-    // Graded packing: a launch lasts as long as its slowest wave, a wave lasts (longest section in it) x (cost of a
-    // trip), and a trip costs more the more lanes are populated (divergence, LDS conflicts, shared service phases;
-    // measured ~900 + 20 * lanes cycles). The longest sections therefore go to sparsely populated waves and the short
-    // ones are packed densely, with lane counts chosen so that all waves of a frame finish together.
-    const bool graded = EnvInt("JXLHIP_GRADED", 1) != 0 && lanes_per_wave > 1;
-    const double cost_a = double(EnvInt("JXLHIP_COST_A", 900)), cost_b = 20.0;
-    uint32_t max_lanes = lanes_per_wave;
-    // A workgroup stages ONE histogram set's slice of the context map: its sections must share the frame and the
-    // histogram selector (read from the first bits of every section at upload). unit = (frame, selector).
+    uint32_t wpg = uint32_t(EnvInt("JXLHIP_WPG", kLanesWPG));  // waves per workgroup
+    if (wpg != 1 && wpg != 2) wpg = 4;
+    c0->batch_wpg = wpg;
     struct Unit {
-      uint32_t frame, sel, wg0;
-      std::vector<uint32_t> order, count;
+      uint32_t frame, sel, begin, count, min_lanes, lanes;
     };
     std::vector<Unit> units;
-    std::vector<uint32_t> count;
+    std::vector<uint32_t> order;
+    size_t min_total = 0, total_sections = 0;
     for (size_t i = 0; i < n; i++) {
       const JxlHipContext* c = ctxs[i];
       const uint32_t* sz = c->sec_size_host.data();
       for (uint32_t sel = 0; sel < c->ep.num_hist; sel++) {
+        order.clear();
+        for (uint32_t g : c->group_list)
+          if (c->sec_sel_host[g] == sel || (sel == 0 && c->sec_sel_host[g] >= c->ep.num_hist)) order.push_back(g);
+        if (order.empty()) continue;
+        std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
+        uint64_t total = 0;
+        for (uint32_t g : order) total += uint64_t(sz[g]) + kSectionBytes;
+        const uint64_t longest = uint64_t(sz[order[0]]) + kSectionBytes;
         Unit u;
         u.frame = uint32_t(i);
         u.sel = sel;
-        for (uint32_t g : c->group_list)
-          if (c->sec_sel_host[g] == sel || (sel == 0 && c->sec_sel_host[g] >= c->ep.num_hist)) u.order.push_back(g);
-        if (u.order.empty()) continue;
-        u.wg0 = uint32_t(map.size());
-        const uint32_t ng = uint32_t(u.order.size());
-        const uint32_t wgs = (ng + per_wg - 1) / per_wg;
-        for (uint32_t j = 0; j < wgs; j++) map.push_back(uint32_t(i) | sel << 16);
-        std::vector<uint32_t>& order = u.order;
-        std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
-        const uint32_t waves = wgs * kLanesWPG;
-        count.assign(waves, 0);
-        bool done = false;
-        if (graded && ng > waves) {
-          // smallest finish time T such that filling the waves in order with floor((T / longest - a) / b) sections fits
-          double lo = 0.0, hi = double(sz[order[0]] + 1) * (cost_a + cost_b * 64.0);
-          for (int it = 0; it < 40; it++) {
-            const double T = 0.5 * (lo + hi);
-            uint32_t j = 0;
-            for (uint32_t w = 0; w < waves && j < ng; w++) {
-              const double room = (T / double(sz[order[j]] + 1) - cost_a) / cost_b;
-              const uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
-              j += take;
-            }
-            if (j >= ng) hi = T; else lo = T;
-          }
-          uint32_t j = 0;
-          for (uint32_t w = 0; w < waves && j < ng; w++) {
-            const double room = (hi / double(sz[order[j]] + 1) - cost_a) / cost_b;
-            uint32_t take = room < 1.0 ? 1u : (room > 64.0 ? 64u : uint32_t(room));
-            take = take > ng - j ? ng - j : take;
-            count[w] = take;
-            j += take;
-          }
-          done = j >= ng;
-        }
-        if (!done) {
-          count.assign(waves, 0);
-          for (uint32_t j = 0; j < ng; j++) count[j / lanes_per_wave]++;
-        }
-        for (uint32_t w = 0; w < waves; w++) max_lanes = count[w] > max_lanes ? count[w] : max_lanes;
-        u.count = count;
-        units.push_back(std::move(u));
+        u.begin = uint32_t(list.size());
+        u.count = uint32_t(order.size());
+        u.min_lanes = uint32_t((total * uint64_t(spread < 100 ? 100 : spread) / 100 + longest - 1) / longest);
+        u.min_lanes = u.min_lanes > u.count ? u.count : (u.min_lanes ? u.min_lanes : 1);
+        u.lanes = u.min_lanes;
+        list.insert(list.end(), order.begin(), order.end());
+        min_total += u.min_lanes;
+        total_sections += u.count;
+        units.push_back(u);
       }
     }
-    (void)max_lanes;
-    lanes.assign(map.size() * kLanesWPG * 64, 0xFFFFFFFFu);
-    wave_ls.assign(map.size() * kLanesWPG, 0);
+    // lanes per wave: the fewest that fit all lanes into `target_waves` waves (a trip costs ~900 + 20 * lanes cycles)
+    uint32_t lanes_per_wave = 1;
+    while (lanes_per_wave < 64 && (min_total + lanes_per_wave - 1) / lanes_per_wave > target_waves) lanes_per_wave *= 2;
+    if (forced >= 1 && forced <= 64 && (forced & (forced - 1)) == 0) lanes_per_wave = uint32_t(forced);
+    if (!EnvInt("JXLHIP_WPG", 0) && lanes_per_wave >= 32) {  // dense regime: one wave per workgroup, all of a unit's lanes
+      wpg = 1;                                                // in it (a trip costs about the same for 14 or 55 lanes)
+      lanes_per_wave = 64;
+    }
+    c0->batch_wpg = wpg;
+    if (lanes_per_wave == 1 && min_total < target_waves) {  // room to spare: more lanes per unit, up to one per section
+      const double grow = double(target_waves) / double(min_total);
+      for (Unit& u : units) {
+        const uint32_t want = uint32_t(double(u.min_lanes) * grow);
+        u.lanes = want > u.count ? u.count : (want < u.min_lanes ? u.min_lanes : want);
+      }
+    }
     for (const Unit& u : units) {
-      uint32_t j = 0;
-      for (size_t w = 0; w < u.count.size(); w++) {
+      const uint32_t per_wg = lanes_per_wave * wpg;
+      const uint32_t wgs = (u.lanes + per_wg - 1) / per_wg;
+      const uint32_t waves = wgs * wpg;
+      const uint32_t unit_index = uint32_t(unit_desc.size() / 4);
+      unit_desc.push_back(u.frame | u.sel << 16);
+      unit_desc.push_back(u.begin);
+      unit_desc.push_back(u.count);
+      unit_desc.push_back(0);
+      for (uint32_t j = 0; j < wgs; j++) map.push_back(unit_index);
+      for (uint32_t w = 0; w < waves; w++) {  // even split of the unit's lanes over its waves
+        const uint32_t cnt = u.lanes / waves + (w < u.lanes % waves ? 1u : 0u);
         uint32_t l2 = 0;
-        while ((1u << l2) < u.count[w]) l2++;
-        wave_ls[size_t(u.wg0) * kLanesWPG + w] = uint8_t(l2);
-        for (uint32_t k = 0; k < u.count[w]; k++) lanes[(size_t(u.wg0) * kLanesWPG + w) * 64 + k] = u.order[j++];
+        while ((1u << l2) < cnt) l2++;
+        wave_ls.push_back(uint8_t(l2));
+        wave_lanes.push_back(uint8_t(cnt));
       }
     }
     for (size_t wg = 0; wg < map.size(); wg++) {  // LDS of the launch = the largest workgroup
-      const JxlHipContext* c = ctxs[map[wg] & 0xFFFF];
+      const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg]) * 4] & 0xFFFF];
       size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc, 0, 0).wave0;
-      for (int w = 0; w < kLanesWPG; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * kLanesWPG + w];
+      for (uint32_t w = 0; w < wpg; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * wpg + w];
       lds = l > lds ? l : lds;
     }
+    if (EnvInt("JXLHIP_PACK_DEBUG", 0))
+      fprintf(stderr, "[pack] units %zu sections %zu lanes(min) %zu lanes/wave %u waves/wg %u workgroups %zu lds %zu\n", units.size(),
+              total_sections, min_total, lanes_per_wave, wpg, map.size(), lds);
   } else {
     for (size_t i = 0; i < n; i++) {
       const uint32_t wgs = (ctxs[i]->ng + kEntropyWPG - 1) / kEntropyWPG;
@@ -990,9 +1002,20 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     if ((r = c0->batch_wave_ls.Ensure(wave_ls.size()))) return r;
     HIP_TRY(hipMemcpy(c0->batch_wave_ls.p, wave_ls.data(), wave_ls.size(), hipMemcpyHostToDevice));
   }
-  if (!lanes.empty()) {
-    if ((r = c0->batch_lanes.Ensure(lanes.size() * 4))) return r;
-    HIP_TRY(hipMemcpy(c0->batch_lanes.p, lanes.data(), lanes.size() * 4, hipMemcpyHostToDevice));
+  if (!list.empty()) {
+    // one buffer: section list | unit descriptors (16-byte aligned) | queue counters | populated lanes per wave
+    const size_t o_units = (list.size() * 4 + 15) & ~size_t(15), o_queue = o_units + unit_desc.size() * 4;
+    const size_t o_wl = o_queue + unit_desc.size(), total = o_wl + wave_lanes.size();
+    std::vector<uint8_t> blob(total, 0);
+    memcpy(blob.data(), list.data(), list.size() * 4);
+    memcpy(blob.data() + o_units, unit_desc.data(), unit_desc.size() * 4);
+    memcpy(blob.data() + o_wl, wave_lanes.data(), wave_lanes.size());
+    if ((r = c0->batch_lanes.Ensure(total))) return r;
+    HIP_TRY(hipMemcpy(c0->batch_lanes.p, blob.data(), total, hipMemcpyHostToDevice));
+    c0->batch_off_units = o_units;
+    c0->batch_off_queue = o_queue;
+    c0->batch_off_wave_lanes = o_wl;
+    c0->batch_units = unit_desc.size() / 4;
   }
   c0->batch_ctxs.assign(ctxs, ctxs + n);
   c0->batch_gens.resize(n);

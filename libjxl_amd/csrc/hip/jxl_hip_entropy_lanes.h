@@ -34,12 +34,20 @@ namespace jxlhip {
 
 struct EntropyLaneBatch {
   const EntropyParams* params;  // one per frame of the batch (device memory)
-  const uint32_t* wg_frame;     // per workgroup: index into params | histogram selector of its sections << 16
-  const uint32_t* lane_group;   // per lane of every wave: group (AC section) index in its frame, 0xFFFFFFFF = idle lane
+  const uint32_t* wg_unit;      // per workgroup: its unit = the sections of one frame that use one histogram set
+  const uint4* units;           // per unit: {index into params | histogram selector << 16, first entry in `list`, entries, 0}
+  const uint32_t* list;         // group (AC section) indices of every unit, largest compressed size first
+  uint32_t* queue;              // per unit: next entry of its list to hand out (zeroed before the launch). A lane takes a
+                                // section, decodes it and comes back for the next one, so the lanes of a unit share its
+                                // sections by actual decode time (a launch lasts as long as its busiest lane; sections
+                                // differ 8x in token count, which their byte size predicts poorly)
+  const uint8_t* wave_lanes;    // per wave: populated lanes (the others idle)
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
   const uint8_t* wave_log_ls;   // per wave: log2 of its populated-lane capacity (lanes beyond it are idle); the wave's LDS
                                 // rows are strided by that many entries, so sparse waves take little LDS
-  uint32_t debug;               // measurement aid: bit 0 = skip the coefficient stores (results are then invalid)
+  uint32_t debug;               // measurement aid: bit 0 = skip the coefficient stores (results are then invalid),
+                                // bit 1 = report every section's coefficient-token count in its error word,
+                                // bit 2 = run at the default wave priority
   unsigned long long* prof;     // optional (may be NULL): per wave {cycles total, cycles in service, services, hot trips}
 };
 
@@ -50,9 +58,9 @@ struct LanesLds {
 // Per-wave LDS, all [row][lane] with a row stride of `lanes` entries (conflict-free, and a wave that populates few lanes
 // needs little LDS, which keeps room on the CU for the bandwidth-bound kernels running beside this one):
 constexpr uint32_t kLanesNzRows = 96;               // nzeros line buffer [channel * 32 + column], u8
-constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 1 mirror row
+constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 2 mirror rows (a 3-word read at slot 15 needs no wrap)
 constexpr uint32_t kLanesBlockRing = 8;             // packed block records, u32
-constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 1) * 4 + kLanesBlockRing * 4;
+constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 2) * 4 + kLanesBlockRing * 4;
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
                                                    uint32_t lut_bytes, uint32_t waves, uint32_t lanes) {
   LanesLds l;
@@ -74,12 +82,15 @@ __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t n
 __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
                                                uint32_t log_ls, const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry) {
   const uint32_t ctxe = l_cfg[cluster];
-  // the bit window is read unconditionally and up front (volatile: not sunk into the renormalisation branch), so that it
-  // shares one LDS round trip with the alias entry; LS is a power of two
+  // the bit window (96 bits: 16 renormalisation bits + up to 31 extra bits from any bit offset) is read unconditionally
+  // and up front (volatile: not sunk into the branches), so that it shares one LDS round trip with the alias entry;
+  // LS is a power of two
   const uint32_t s0 = ((bitpos >> 5) & (kLanesRingWords - 1)) << log_ls;
   typedef const volatile __attribute__((address_space(3))) uint32_t* LdsVolatile;
   const uint32_t w0 = *(LdsVolatile)(ring + s0);
   const uint32_t w1 = *(LdsVolatile)(ring + s0 + LS);
+  const uint32_t w2 = *(LdsVolatile)(ring + s0 + 2 * LS);
+  const uint32_t boff = bitpos & 31;
   const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & ((1u << log_entry) - 1);
   const uint2 e = *reinterpret_cast<const uint2*>(lds + (cluster << (15 - log_entry)) + slot * 8);  // 8 << log_alpha per cluster
   const bool gt = pos >= (e.x >> 24);
@@ -87,18 +98,18 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
   uint32_t tok = gt ? (x >> 24) : slot;
   const uint32_t hi = state >> 12;
   state = (x & 0xFFFu) * hi + hi + ((x >> 12) & 0xFFFu) + pos;
-  const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos & 31);
+  const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, boff);
   const bool need = state < (1u << 16);
   state = need ? ((state << 16) | (win & 0xFFFFu)) : state;
+  const uint32_t boff2 = boff + (need ? 16u : 0u);  // < 48
   bitpos += need ? 16u : 0u;
   const uint32_t se = ctxe & 15;
   if (tok >= (1u << se)) {
     const uint32_t msb = (ctxe >> 4) & 15, lsb = (ctxe >> 8) & 15;
     const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
     const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
-    const uint32_t s1 = ((bitpos >> 5) & (kLanesRingWords - 1)) << log_ls;
-    const uint32_t v0 = ring[s1], v1 = ring[s1 + LS];
-    const uint32_t xb = __builtin_amdgcn_alignbit(v1, v0, bitpos & 31) & ((1u << nb) - 1);
+    const bool up = boff2 >= 32;
+    const uint32_t xb = __builtin_amdgcn_alignbit(up ? w2 : w1, up ? w1 : w0, boff2 & 31) & ((1u << nb) - 1);
     bitpos += nb;
     tok = (((((1u << msb) | (top & ((1u << msb) - 1))) << nb) | xb) << lsb) | low;
   }
@@ -108,8 +119,13 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
 template <typename CoefT, int WPG>
 __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
+  // This wave is a serial dependency chain that leaves most issue slots empty: it takes precedence over the
+  // bandwidth-bound kernels that share its SIMD (they fill the gaps) whatever their age.
+  if (B.debug & 4) __builtin_amdgcn_s_setprio(3);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t wg_desc = B.wg_frame[blockIdx.x];
+  const uint32_t unit = B.wg_unit[blockIdx.x];
+  const uint4 unit_desc = B.units[unit];
+  const uint32_t wg_desc = unit_desc.x;
   const uint32_t wg_sel = wg_desc >> 16;  // the histogram set this workgroup's sections use
   const EntropyParams& P = B.params[wg_desc & 0xFFFF];
   const PassDev& T = P.passes[0];
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   uint16_t* l_nnz2 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)] -> 2 * kCoeffNumNonzeroContext
   uint8_t* l_nz = lds_raw + L.wave0 + wave_off;                       // line buffer of the per-block nzeros prediction
   uint32_t* ring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzRows * LS) + lane;                 // stream ring [slot][lane]
-  uint32_t* bring = ring + (kLanesRingWords + 1) * LS;                                           // block records [slot][lane]
+  uint32_t* bring = ring + (kLanesRingWords + 2) * LS;                                           // block records [slot][lane]
   const uint32_t* l_sinfo = reinterpret_cast<const uint32_t*>(lds_raw + L.sinfo);
 
   // ---- stage the frame's tables (whole workgroup)
@@ -163,26 +179,37 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
 
   // ---- per-lane section setup
   enum : uint32_t { kWait = 0, kRun = 1, kDone = 3 };
-  const uint32_t g = B.lane_group[(blockIdx.x * WPG + wave) * 64 + lane];
+  auto take_section = [&]() -> uint32_t {
+    const uint32_t idx = atomicAdd(B.queue + unit, 1u);
+    return idx < unit_desc.z ? B.list[unit_desc.y + idx] : 0xFFFFFFFFu;
+  };
+  uint32_t g = lane < B.wave_lanes[blockIdx.x * WPG + wave] ? take_section() : 0xFFFFFFFFu;
   uint32_t mode = g == 0xFFFFFFFFu ? uint32_t(kDone) : uint32_t(kWait);
-  uint32_t err = 0;
+  uint32_t err = 0, ntok = 0;  // ntok: measurement aid (debug bit 1: the flag word reports the section's token count)
   uint32_t b1 = 0, bi = 0, ci = 2;
   const uint4* stream4 = reinterpret_cast<const uint4*>(P.sections);
   const uint4* const rec4 = reinterpret_cast<const uint4*>(P.block_recs);
   uint32_t* const kend_out = P.kend;
   uint32_t nwords = 0, sec_size = 0, ring_end = 0, bring_end = 0, bitpos = 0, state = 0, ctx_base = 0;
   bool started = false;
-  if (mode == kWait) {
-    bi = P.gbb[g] - 1;  // the first transition advances to the group's first block
+  // block / channel cursor
+  uint32_t info = 0, lbx = 0, lby = 0, qfi = 0, dcctx = 0, coef_offset = 0, next_offset = 0;
+  auto open_section = [&]() {  // cursors of section g (the nzeros line buffer needs no reset: every entry a section
+                               // reads was written by an earlier block of the same section)
+    bi = P.gbb[g] - 1;         // the first transition advances to the group's first block
     b1 = P.gbb[g + 1];
     bring_end = P.gbb[g] & ~3u;
     stream4 = reinterpret_cast<const uint4*>(P.sections + P.sec_word[g]);  // 16-byte aligned (jxlhip_frame_upload)
     sec_size = P.sec_size[g];
     nwords = (sec_size + 3) / 4;
-    if (g == 0) bitpos = P.first_bit_offset;
-  }
-  // block / channel cursor
-  uint32_t info = 0, lbx = 0, lby = 0, qfi = 0, dcctx = 0, coef_offset = 0, next_offset = 0;
+    bitpos = g == 0 ? P.first_bit_offset : 0;
+    ring_end = 0;
+    next_offset = 0;
+    ci = 2;
+    err = 0;
+    started = false;
+  };
+  if (mode == kWait) open_section();
   // coefficient cursor
   // addr_a / addr_b: LDS byte address of the context entry of the NEXT coefficient at frequency context 0, if the
   // current token turns out zero (same non-zero count, prev = 0) / non-zero (one fewer to come, prev = 1)
@@ -195,7 +222,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, t_hot0 = 0, t_hot1 = 0;
   if (B.prof) t_begin = __builtin_readcyclecounter();
   for (;;) {
-    const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 5;  // two hot trips consume at most 4 ring words
+    // two hot trips consume at most 2 * 47 bits, i.e. bits of at most 4 ring words (words read beyond ring_end are
+    // stale but never consumed)
+    const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 5;
     const uint64_t runnable = __ballot(mode == kRun && !low);
     const uint64_t waiting = __ballot((mode == kWait) || low);
     if (!(waiting | runnable)) break;
@@ -206,10 +235,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       // (1) issue this phase's ring refills first: their HBM latency overlaps the transition work below, and no load
       // is left in flight when the hot loop resumes (a pending load would make the compiler drain vmcnt, i.e. wait for
       // the previous iteration's coefficient stores, at the top of every hot-loop iteration)
-      const bool want_s = mode != kDone && (ring_end - (bitpos >> 5)) <= kLanesRingWords - 4;
-      const bool want_b = mode != kDone && bring_end < b1 && bring_end + 4 - (bi + 1) <= kLanesBlockRing;
+      bool want_s = mode != kDone && (ring_end - (bitpos >> 5)) <= kLanesRingWords - 4;
+      bool want_b = mode != kDone && bring_end < b1 && bring_end + 4 - (bi + 1) <= kLanesBlockRing;
       uint4 pf_s = make_uint4(0, 0, 0, 0), pf_b = make_uint4(0, 0, 0, 0);
-      if (want_s) pf_s = stream4[ring_end >> 2];
+      if (want_s && ring_end < nwords) pf_s = stream4[ring_end >> 2];  // (past the section the ring is fed zeros)
       if (want_b) pf_b = rec4[bring_end >> 2];
       // (2) block / channel transitions of the waiting lanes, including the block's non-zero-count symbol
       const bool next_block = ci == 2 && started;  // the coming transition moves on to block bi + 1
@@ -231,10 +260,18 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
             ci = 0;
             bi++;
           }
-          if (bi >= b1) {  // section complete
+          if (bi >= b1) {  // section complete (or abandoned after an error): on to the next one of the unit
             if (state != (0x13u << 16)) err |= kErrFinalState;
             if (bitpos > sec_size * 8) err |= kErrOverread;
-            mode = kDone;
+            P.errors[g] = (B.debug & 2) ? ntok : err;  // every section's flag word is written: the host does not clear the array
+            ntok = 0;
+            g = take_section();
+            if (g == 0xFFFFFFFFu) {
+              mode = kDone;
+            } else {
+              open_section();
+              want_s = want_b = false;  // the loads issued above belong to the finished section
+            }
           } else {
             if (ci == 0) {  // packed record: lbx | lby << 5 | strategy << 10 | qf bucket << 15 | dc bucket << 19
               const uint32_t rec = bring[(bi & (kLanesBlockRing - 1)) * LS];
@@ -262,8 +299,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
             size = covered * 64;
             kidx = bi * 3 + c;
             if (tok > size - covered) {
-              err |= kErrNzeros;
-              mode = kDone;
+              err |= kErrNzeros;  // abandon the section: the next transition takes the "section complete" path
+              bi = b1;
+              ci = 2;
             } else {
               const uint8_t nzv = uint8_t((tok + covered - 1) >> log2c);
               for (uint32_t i = 0; i < cx; i++) line[(lbx + i) * LS] = nzv;
@@ -292,7 +330,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
         ring[(s + 1) * LS] = ring_end + 1 < nwords ? pf_s.y : 0;
         ring[(s + 2) * LS] = ring_end + 2 < nwords ? pf_s.z : 0;
         ring[(s + 3) * LS] = ring_end + 3 < nwords ? pf_s.w : 0;
-        if (s == 0) ring[kLanesRingWords * LS] = ring_end < nwords ? pf_s.x : 0;  // mirror row: a 2-word read at slot 15 needs no wrap
+        if (s == 0) {  // mirror rows
+          ring[kLanesRingWords * LS] = ring_end < nwords ? pf_s.x : 0;
+          ring[(kLanesRingWords + 1) * LS] = ring_end + 1 < nwords ? pf_s.y : 0;
+        }
         ring_end += 4;
       }
       if (want_b) {
@@ -329,23 +370,29 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
         const uint32_t e_zero = lds_raw[addr_a + f2];
         const uint32_t addr_b = cbase + 1 + nnz_b;
         const uint32_t e_nonzero = lds_raw[addr_b + f2];
+        // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays): read here, with
+        // everything else, so that no LDS read is waited for at the end of the trip
+        const uint32_t nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
         const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
         const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
         const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
         if (!(B.debug & 1)) coeffs[dptr] = CoefT(coeff);
         dptr++;
+        if (B.debug & 2) ntok++;
         k = kn;
         const bool nz = tok != 0;
         nzeros -= nz ? 1u : 0u;
         ctxe = nz ? e_nonzero : e_zero;
         addr_a = nz ? addr_b - 1 : addr_a;
-        nnz_b = l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63];
+        nnz_b = nz ? nnz_c : nnz_b;
         if (nzeros == 0) {
           kend_out[kidx] = k;
           mode = kWait;
         } else if (k >= size) {
-          err |= kErrNzeros;
-          mode = kDone;
+          err |= kErrNzeros;  // abandon the section
+          bi = b1;
+          ci = 2;
+          mode = kWait;
         }
       }
     }
@@ -360,7 +407,6 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
     o[2] = n_service;
     o[3] = n_trips;
   }
-  if (g != 0xFFFFFFFFu) P.errors[g] = err;  // every section's flag word is written: the host does not clear the array
 }
 
 }  // namespace jxlhip

@@ -24,6 +24,7 @@ struct FusedFilterParams {
   FilterParams f;          // geometry, sigma, Gaborish weights, channel scales, colour constants, rgb; f.in = IDCT output
   float sm[3], bsm[3];     // per EPF stage (0, 1, 2): sigma multipliers for block-interior / block-border pixels
   float* filtered;         // optional (may be NULL): filtered XYB planes for tests (same geometry as f.in)
+  uint32_t debug;          // measurement aid (results invalid when set): bit 0 skip Gaborish, 1 skip EPF, 2 skip colour maths
 };
 
 constexpr int kFusedTW = 64, kFusedTH = 16;  // 37 KB of LDS with a 3-pixel halo: two tiles fit beside an entropy workgroup
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
   }
   __syncthreads();
   int h = H;  // halo still valid around the tile in `src`
-  if (GAB) {
+  if (GAB && !(P.debug & 1)) {
     h -= 1;
     constexpr int HG = H - 1, w = TW + 2 * HG, n = w * (TH + 2 * HG), NIT = (n + kFusedThreads - 1) / kFusedThreads;
 #pragma unroll 4
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
     dst = t;                                                                                                 \
   }
   if (EPF >= 3) JXL_EPF_STAGE(0, 3)
-  if (EPF >= 1) {
+  if (EPF >= 1 && !(P.debug & 2)) {
     constexpr int HO = H - (GAB ? 1 : 0) - (EPF >= 3 ? 3 : 0) - 2;
     Epf1Stage<S, PL, HO, H>(P, src, dst, l_sig, x0, y0, xs, ys, tid);
     h = HO;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
     float r = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);
     float g = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
     float b = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
-    if (!P.f.linear_output) {
+    if (!P.f.linear_output && !(P.debug & 4)) {
       r = LinearToSrgb(r);
       g = LinearToSrgb(g);
       b = LinearToSrgb(b);
