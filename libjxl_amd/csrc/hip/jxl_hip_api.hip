@@ -787,6 +787,20 @@ static int LaunchFused(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
   return 0;
 }
 
+// Gaborish + EPF1 (the d1.0 configuration): the row-streaming kernel, no LDS.
+static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
+  const uint32_t cols = g.tiles_x * jxlhip::kFusedTW, rows = g.tiles_y * jxlhip::kFusedTH;  // upper bounds of the group
+  const uint32_t gx = ((cols + jxlhip::kRowsLanes - 1) / jxlhip::kRowsLanes + jxlhip::kRowsWaves - 1) / jxlhip::kRowsWaves;
+  const uint32_t gy = (rows + jxlhip::kRowsStrip - 1) / jxlhip::kRowsStrip;
+  for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
+    const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
+    hipLaunchKernelGGL(jxlhip::k_filter_rows, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0, c0->stream,
+                       c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // Validates a set for a batched downstream call and orders the launch stream after everything its frames wait for.
 static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
   if (!ctxs || !n) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -1113,7 +1127,7 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
       case 2: r = LaunchFused<false, 2>(c0, g); break;
       case 3: r = LaunchFused<false, 3>(c0, g); break;
       case 4: r = LaunchFused<true, 0>(c0, g); break;
-      case 5: r = LaunchFused<true, 1>(c0, g); break;
+      case 5: r = EnvInt("JXLHIP_FILTER_TILES", 0) ? LaunchFused<true, 1>(c0, g) : LaunchFilterRows(c0, g); break;
       case 6: r = LaunchFused<true, 2>(c0, g); break;
       default: r = LaunchFused<true, 3>(c0, g); break;
     }

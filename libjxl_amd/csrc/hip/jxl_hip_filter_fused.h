@@ -252,6 +252,195 @@ __global__ __launch_bounds__(256) void k_upsample_color(UpsampleParams P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-streaming form of Gaborish -> EPF1 -> colour (the d1.0 configuration): no LDS at all, so it runs beside the
+// LDS-hungry entropy workgroups instead of queueing for their LDS.
+//
+// A wave owns 64 adjacent columns (lane l <-> column x0 - 3 + l, the middle 58 produce output) and walks down a strip of
+// rows. Everything vertical lives in the lane's registers as short sliding windows (3 input rows, 5 Gaborish rows, 3 rows
+// of each absolute-difference map); everything horizontal comes from the neighbouring lanes through DPP wave shifts.
+// The arithmetic is that of k_filter_fused<true, 1> expression for expression (same association), including the shared
+// plus-shaped sums: with
+//   D_h(q) = sum_c scale_c * |p_c(q) - p_c(q + (0,1))|,   D_v(q) = sum_c scale_c * |p_c(q) - p_c(q + (1,0))|,
+//   P_h(q) = (D_h(q) + D_h(q - (1,0))) + (D_h(q - (0,1)) + D_h(q + (1,0))) + D_h(q + (0,1))   (P_v alike from D_v)
+// the four SADs of stage_epf.cc:225-367 for pixel o are P_v(o - (1,0)), P_h(o - (0,1)), P_h(o), P_v(o): every P is
+// used by two pixels and computed once.
+constexpr int kRowsHalo = 3;                          // Gaborish 1 + EPF1 2
+constexpr int kRowsLanes = 64 - 2 * kRowsHalo;        // output columns per wave
+constexpr int kRowsStrip = 64;                        // output rows per wave
+constexpr int kRowsWaves = 4;                         // waves (adjacent column groups) per workgroup
+
+__device__ __forceinline__ float FromLeft(float v) {  // the value held by the lane of column x - 1 (wave_shr:1)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float FromRight(float v) {  // the value held by the lane of column x + 1 (wave_shl:1)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+__global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows(const FusedFilterParams* params) {
+  FusedFilterParams P;
+  LoadParams(P, params + blockIdx.z);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xs = int(P.f.xs), ys = int(P.f.ys);
+  const int xw0 = (int(blockIdx.x) * kRowsWaves + wave) * kRowsLanes;  // first output column of the wave
+  const int y0 = int(P.f.y_begin) + int(blockIdx.y) * kRowsStrip;
+  const int y1 = y0 + kRowsStrip < int(P.f.y_end) ? y0 + kRowsStrip : int(P.f.y_end);
+  if (xw0 >= xs || y0 >= y1) return;  // the grid covers the largest frame (band) of the launch
+  const int x = xw0 - kRowsHalo + lane;
+  const int mx = MirrorI(x, xs);
+  const bool emit = lane >= kRowsHalo && lane < 64 - kRowsHalo && x < xs;
+  const bool xborder = ((mx & 7) == 0) || ((mx & 7) == 7);
+  const size_t gplane = size_t(P.f.xp) * P.f.yp;
+  typedef const float __attribute__((address_space(1)))* GF32;  // global (not generic) accesses: no LDS-counter coupling
+  typedef float __attribute__((address_space(1)))* GF32W;
+  typedef uint8_t __attribute__((address_space(1)))* GU8W;
+  const GF32 in = (GF32)(uintptr_t)P.f.in + mx;
+  const GF32 sig = (GF32)(uintptr_t)P.f.inv_sigma + (mx >> 3);
+  const GF32 dither = (GF32)(uintptr_t)c_dither;
+  const GF32W filtered = (GF32W)(uintptr_t)P.filtered;
+  const GU8W rgb = (GU8W)(uintptr_t)P.f.rgb;
+  const int dcol[3] = {x & 31, (x + 23) & 31, (x + 46) & 31};
+  // sliding windows; index 0 = oldest row
+  float p[3][3], h1[3][3];  // input rows and their horizontal pair sums p(x - 1) + p(x + 1)
+  float g[3][5];            // Gaborish rows yg - 4 .. yg
+  float dh[3], dv[3];       // D_h rows yg - 3 .. yg - 1 (the newest, yg, enters at the next step), D_v rows yg - 3 .. yg - 1
+  float pv_prev = 0.0f;     // P_v of the previous output row
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[c][k] = h1[c][k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 5; k++) g[c][k] = 0.0f;
+  }
+  dh[0] = dh[1] = dh[2] = dv[0] = dv[1] = dv[2] = 0.0f;
+  float dh_new = 0.0f;
+  const int steps = y1 - y0 + 2 * kRowsHalo;
+  // Everything a step reads from memory (its input row, the sigma and the dither values of its output row) is loaded
+  // one step ahead, so the only wait for memory is at the top of a step, for loads a whole step old.
+  float nx[3], nis = 0.0f, ndi[3] = {0.0f, 0.0f, 0.0f};
+  {
+    const size_t row = size_t(MirrorI(y0 - kRowsHalo, ys)) * P.f.xp;
+    nx[0] = in[row];
+    nx[1] = in[gplane + row];
+    nx[2] = in[2 * gplane + row];
+  }
+  for (int j = 0; j < steps; j++) {
+    const int yi = y0 - kRowsHalo + j;  // input row of this step
+    const float cur[3] = {nx[0], nx[1], nx[2]};
+    const float is = nis;
+    const float di[3] = {ndi[0], ndi[1], ndi[2]};
+    const int r = yi - kRowsHalo;  // output row of this step (= yg - 2 = y0 - 6 + j), valid from step 6
+    const int my = MirrorI(r, ys);
+    if (j + 1 < steps) {
+      const size_t row = size_t(MirrorI(yi + 1, ys)) * P.f.xp;
+      nx[0] = in[row];
+      nx[1] = in[gplane + row];
+      nx[2] = in[2 * gplane + row];
+      if (j + 1 >= 2 * kRowsHalo) {  // r + 1 is an output row (inside the frame)
+        nis = sig[size_t((r + 1) >> 3) * P.f.xb];
+        ndi[0] = dither[((r + 1) & 31) * 32 + dcol[0]];
+        ndi[1] = dither[((r + 1 + 13) & 31) * 32 + dcol[1]];
+        ndi[2] = dither[((r + 1 + 26) & 31) * 32 + dcol[2]];
+      }
+    }
+    // ---- input window
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      p[c][0] = p[c][1];
+      p[c][1] = p[c][2];
+      p[c][2] = cur[c];
+      h1[c][0] = h1[c][1];
+      h1[c][1] = h1[c][2];
+      h1[c][2] = FromLeft(cur[c]) + FromRight(cur[c]);
+    }
+    // ---- Gaborish row yg = yi - 1 (stage_gaborish.cc:56-100)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float m = p[c][1];
+      const float s1 = h1[c][1] + (p[c][0] + p[c][2]);
+      const float s2 = h1[c][0] + h1[c][2];
+      const float v = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) g[c][k] = g[c][k + 1];
+      g[c][4] = v;
+    }
+    // ---- difference maps: D_h(yg - 1) enters the window (computed last step as dh_new), D_v(yg - 1) = |G(yg - 1) - G(yg)|
+    dh[0] = dh[1];
+    dh[1] = dh[2];
+    dh[2] = dh_new;
+    dv[0] = dv[1];
+    dv[1] = dv[2];
+    {
+      float a = 0.0f, b = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        a = fabsf(g[c][4] - FromRight(g[c][4])) * P.f.ch_scale[c] + a;
+        b = fabsf(g[c][3] - g[c][4]) * P.f.ch_scale[c] + b;
+      }
+      dh_new = a;  // D_h(yg)
+      dv[2] = b;   // D_v(yg - 1)
+    }
+    // ---- plus-shaped sums of output row r = yg - 2: window index 1 is row r for dh / dv, index 2 for g
+    const float pv = (dv[1] + dv[0]) + (FromLeft(dv[1]) + dv[2]) + FromRight(dv[1]);
+    const float ph = (dh[1] + dh[0]) + (FromLeft(dh[1]) + dh[2]) + FromRight(dh[1]);
+    const float ph_left = FromLeft(ph);
+    if (j >= 2 * kRowsHalo) {
+      float o0 = g[0][2], o1 = g[1][2], o2 = g[2][2];
+      float l0 = FromLeft(o0), l1 = FromLeft(o1), l2 = FromLeft(o2);
+      float r0 = FromRight(o0), r1 = FromRight(o1), r2 = FromRight(o2);
+      if (!(is < -3.90524291751269967465540850526868f)) {  // else sigma too small: pixel unchanged (stage_epf.cc kMinSigma)
+        const bool border = xborder || ((my & 7) == 0) || ((my & 7) == 7);
+        const float inv_sig = is * (border ? P.bsm[1] : P.sm[1]);
+        // neighbours in the reference's order: up, left, right, down
+        const float sad[4] = {pv_prev, ph_left, ph, pv};
+        const float n0[4] = {g[0][1], l0, r0, g[0][3]};
+        const float n1[4] = {g[1][1], l1, r1, g[1][3]};
+        const float n2[4] = {g[2][1], l2, r2, g[2][3]};
+        float wsum = 1.0f, a0 = o0, a1 = o1, a2 = o2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float weight = sad[k] * inv_sig + 1.0f;
+          weight = weight < 0.0f ? 0.0f : weight;
+          wsum += weight;
+          a0 = weight * n0[k] + a0;
+          a1 = weight * n1[k] + a1;
+          a2 = weight * n2[k] + a2;
+        }
+        const float inv_w = __builtin_amdgcn_rcpf(wsum);  // 1 ulp; wsum >= 1
+        o0 = a0 * inv_w;
+        o1 = a1 * inv_w;
+        o2 = a2 * inv_w;
+      }
+      if (emit) {
+        if (filtered) {
+          const size_t gi = size_t(r) * P.f.xp + x;
+          filtered[gi] = o0;
+          filtered[gplane + gi] = o1;
+          filtered[2 * gplane + gi] = o2;
+        }
+        if (rgb) {
+          const float X = o0, Y = o1, Bc = o2;
+          const float gr = (Y + X) - P.f.opsin_bias_cbrt[0], gg = (Y - X) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
+          const float mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
+          float cr = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);
+          float cg = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
+          float cb = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
+          if (!P.f.linear_output) {
+            cr = LinearToSrgb(cr);
+            cg = LinearToSrgb(cg);
+            cb = LinearToSrgb(cb);
+          }
+          const GU8W dst = rgb + (size_t(r) * xs + x) * 3;
+          dst[0] = ToU8D(cr, di[0]);
+          dst[1] = ToU8D(cg, di[1]);
+          dst[2] = ToU8D(cb, di[2]);
+        }
+      }
+    }
+    pv_prev = pv;
+  }
+}
+
 template <bool GAB, int EPF>
 __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilterParams* params) {
   // one frame per grid z slice; its parameter block is read through the constant address space (scalar loads that the

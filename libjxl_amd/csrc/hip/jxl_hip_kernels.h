@@ -1204,11 +1204,14 @@ __device__ __forceinline__ float LinearToSrgb(float v) {
   }
   return copysignf(r, v);
 }
-__device__ __forceinline__ uint8_t ToU8(float v, int x, int y, int c) {
-  v = v * 255.0f + c_dither[((y + c * 13) & 31) * 32 + ((x + c * 23) & 31)];
+__device__ __forceinline__ uint8_t ToU8D(float v, float dither) {  // dither = c_dither[(y + c * 13) & 31][(x + c * 23) & 31]
+  v = v * 255.0f + dither;
   v = v >= 0.0f ? v : 0.0f;
   v = v > 255.0f ? 255.0f : v;
   return uint8_t(__float2int_rn(v));
+}
+__device__ __forceinline__ uint8_t ToU8(float v, int x, int y, int c) {
+  return ToU8D(v, c_dither[((y + c * 13) & 31) * 32 + ((x + c * 23) & 31)]);
 }
 
 }  // namespace jxlhip
