@@ -922,6 +922,180 @@ __global__ __launch_bounds__(kIdctColsThreads) void k_idct_cols(const TransformP
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// DCT-family strategies up to 32x32, fast form: the separable inverse DCT as two passes of the recursive even / odd
+// decomposition (the algorithm of lib/jxl/dct-inl.h:191-232, IDCT1DImpl<N>: N/2-point IDCT of the even coefficients;
+// N/2-point IDCT of the odd ones after d[j] = c[2j+1] + c[2j-1], d[0] = sqrt(2) c[1]; odd half scaled by
+// WcMultipliers<N>[n] = 1 / (2 cos((n + 1/2) pi / N)), dct_scales.h:234-236; out[n], out[N-1-n] = even +- odd), each
+// 1-D transform entirely in the registers of one thread: ~9 flops per sample and pass instead of N FMAs, and two plain
+// LDS accesses per sample and pass instead of N/4 broadcast reads.
+//   * max(R, C) threads own one varblock; its dequantised coefficients are staged in ONE LDS tile [ky][kx] (row stride
+//     C + 1: both the per-row and the per-column accesses are conflict-free);
+//   * pass 1: thread ky transforms row ky in place; pass 2: thread x transforms column x and writes it to the plane,
+//     row segments contiguous across the threads;
+//   * chroma from luma is applied to the PIXELS (the transform is linear): the thread keeps its column of Y output and
+//     adds cc * Y to the X / B column. The reference adds cc * Y to the coefficients except the lowest-frequency corner
+//     (which comes from the DC image, dec_group.cc:115-181); that corner is therefore staged as LLF_c - cc * LLF_Y. This
+//     is what lets one tile per varblock do: the dequantised Y coefficients need not stay resident.
+template <int N>
+struct WcTable;
+template <>
+struct WcTable<2> {
+  static constexpr float v[1] = {7.071067812e-01f};
+};
+template <>
+struct WcTable<4> {
+  static constexpr float v[2] = {5.411961001e-01f, 1.306562965e+00f};
+};
+template <>
+struct WcTable<8> {
+  static constexpr float v[4] = {5.097955791e-01f, 6.013448869e-01f, 8.999762231e-01f, 2.562915448e+00f};
+};
+template <>
+struct WcTable<16> {
+  static constexpr float v[8] = {5.024192862e-01f, 5.224986149e-01f, 5.669440348e-01f, 6.468217834e-01f, 7.881546235e-01f, 1.060677686e+00f, 1.722447098e+00f, 5.101148619e+00f};
+};
+template <>
+struct WcTable<32> {
+  static constexpr float v[16] = {5.006029982e-01f, 5.054709599e-01f, 5.154473099e-01f, 5.310425911e-01f, 5.531038960e-01f, 5.829349682e-01f, 6.225041230e-01f, 6.748083415e-01f, 7.445362710e-01f, 8.393496454e-01f, 9.725682379e-01f, 1.169439933e+00f, 1.484164616e+00f, 2.057781010e+00f, 3.407608418e+00f, 1.019000812e+01f};
+};
+
+template <int N>
+__device__ __forceinline__ void FastIdct(float (&v)[N]) {
+  if constexpr (N == 2) {
+    const float a = v[0] + v[1], b = v[0] - v[1];
+    v[0] = a;
+    v[1] = b;
+  } else if constexpr (N > 2) {
+    float e[N / 2], o[N / 2];
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) {
+      e[j] = v[2 * j];
+      o[j] = v[2 * j + 1];
+    }
+#pragma unroll
+    for (int j = N / 2 - 1; j > 0; j--) o[j] += o[j - 1];
+    o[0] *= 1.41421356237309504880f;
+    FastIdct<N / 2>(e);
+    FastIdct<N / 2>(o);
+#pragma unroll
+    for (int n = 0; n < N / 2; n++) {
+      const float t = o[n] * WcTable<N>::v[n];
+      v[n] = e[n] + t;
+      v[N - 1 - n] = e[n] - t;
+    }
+  }
+}
+
+constexpr int kIdctFastThreads = 128;
+
+template <typename CoefT, int CX, int CY>
+__global__ __launch_bounds__(kIdctFastThreads) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
+  JXL_TRANSFORM_PREAMBLE();
+  constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, TB = R > C ? R : C, S = C + 1, TILE = R * S;
+  constexpr int LOGC = CX == 1 ? 3 : (CX == 2 ? 4 : 5);
+  extern __shared__ __align__(16) float lds_f[];
+  const int grp = threadIdx.x / TB, t = threadIdx.x % TB;
+  float* l = lds_f + grp * TILE;
+  const uint32_t li = wgd.y + grp;
+  const bool active = li < n;
+  JxlHipVarBlock vb;
+  const CoefT* gq = nullptr;
+  const float* m = nullptr;
+  uint32_t msize = 0, bidx = 0;
+  float sc = 0, x_cc = 0, b_cc = 0;
+  if (active) {
+    bidx = list[li];
+    vb = P.blocks[bidx];
+    const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
+    gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
+    const uint32_t kind = c_strategy_qtable[strategy];
+    m = P.dequant + P.dq_offset[kind];
+    msize = P.dq_size[kind];
+    sc = P.inv_global_scale / float(vb.qf);
+    const uint32_t tiles_x = (P.xb + 7) / 8;
+    const uint32_t tile = (vb.by / 8) * tiles_x + vb.bx / 8;
+    x_cc = P.base_x + float(P.ytox[tile]) * P.color_scale;
+    b_cc = P.base_b + float(P.ytob[tile]) * P.color_scale;
+  }
+  const uint32_t ord = c_strategy_order[strategy];
+  float yout[R];  // this thread's column of the Y output (threads t < C)
+#pragma unroll
+  for (int y = 0; y < R; y++) yout[y] = 0.0f;
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    const float cc = c == 1 ? 0.0f : (c == 0 ? x_cc : b_cc);
+    if (active)
+      for (int i = t * 4; i < TILE; i += TB * 4) *reinterpret_cast<float4*>(l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (active) {
+      const float mul = c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm);
+      const CoefT* gqc = gq + size_t(c) * 65536;
+      const float* mc = m + size_t(c) * msize;
+      if (P.scan_order) {
+        // entry k: coefficient, its position and its dequant weight are three independent coalesced loads
+        const uint16_t* order = P.orders + P.order_offset[ord * 3 + c];
+        const float* ms = P.dequant_scan + (mc - P.dequant);
+        const uint32_t ke = P.kend[bidx * 3 + c];
+        const uint32_t k1 = ke < uint32_t(SIZE) ? ke : uint32_t(SIZE);
+#pragma unroll 4
+        for (uint32_t k = CX * CY + t; k < k1; k += TB) {
+          const int q = int(gqc[k]);
+          const uint32_t pos = order[k];
+          const float w = ms[k];
+          if (q) {
+            const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
+            l[(idx >> LOGC) * S + (idx & (C - 1))] += QuantBias(c, q, P.biases) * (w * mul);
+          }
+        }
+      } else {
+        for (uint32_t k = t; k < uint32_t(SIZE); k += TB) {
+          const int q = int(gqc[k]);
+          if (q) {
+            const uint32_t idx = R < C ? k : (k % R) * C + k / R;
+            l[(idx >> LOGC) * S + (idx & (C - 1))] += QuantBias(c, q, P.biases) * (mc[k] * mul);
+          }
+        }
+      }
+      if (t < CX * CY) {  // lowest frequencies from the DC image (minus the part the pixel-domain chroma from luma adds back)
+        const float* dc = P.dc + size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
+        const int ky = t / CX, kx = t % CX;
+        float v = LlfFromDc<CX, CY>(P, dc, ky, kx);
+        if (c != 1) {
+          const float* dcy = P.dc + size_t(1) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
+          v -= cc * LlfFromDc<CX, CY>(P, dcy, ky, kx);
+        }
+        l[ky * S + kx] = v;
+      }
+    }
+    __syncthreads();
+    if (active && t < R) {  // pass 1: row ky = t
+      float v[C];
+#pragma unroll
+      for (int kx = 0; kx < C; kx++) v[kx] = l[t * S + kx];
+      FastIdct<C>(v);
+#pragma unroll
+      for (int x = 0; x < C; x++) l[t * S + x] = v[x];
+    }
+    __syncthreads();
+    if (active && t < C) {  // pass 2: column x = t
+      float v[R];
+#pragma unroll
+      for (int ky = 0; ky < R; ky++) v[ky] = l[ky * S + t];
+      FastIdct<R>(v);
+      float* out = P.out + size_t(c) * P.xp * P.yp + size_t(vb.by) * 8 * P.xp + size_t(vb.bx) * 8 + t;
+#pragma unroll
+      for (int y = 0; y < R; y++) {
+        float r = v[y];
+        if (c == 1) yout[y] = r;
+        else r += cc * yout[y];
+        out[size_t(y) * P.xp] = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // 128/256-class transforms: one workgroup per (varblock, channel), intermediates in global scratch.
 template <typename CoefT>
 __global__ __launch_bounds__(256) void k_dct_big(TransformParams P, const uint32_t* list, uint32_t n, uint32_t strategy) {
