@@ -171,6 +171,15 @@ int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_
  * XYB planes for jxlhip_download("xyb_filtered") (test aid; costs one extra plane set and 12 B/pixel of writes). */
 int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
 
+/* Memory sharing for pipelined frame sets (call before jxlhip_frame_upload): `ctx` keeps its inverse-transform output (the
+ * 3 f32 XYB planes, 12 B/pixel: the largest buffer of a context) in `lender`'s plane buffer instead of allocating its
+ * own; lender = NULL undoes it. The planes only live between a frame's transform and its filter + colour stage, so
+ * frames whose downstream stages never run at the same time (e.g. the two frame sets of a software pipeline: one set is
+ * in the entropy stage while the other is transformed and filtered) can share them. The library orders the launches: a
+ * transform that overwrites shared planes waits for the filter launch that last read them, also across streams. The
+ * lender must have uploaded a frame at least as large and must outlive the borrower's use. */
+int jxlhip_share_planes(JxlHipContext* ctx, JxlHipContext* lender);
+
 /* Timing of the last run of each stage in milliseconds (HIP events on the context's stream);
  * which: 0 entropy, 1 transform, 2 filter+colour. Synchronous. */
 int jxlhip_last_stage_ms(JxlHipContext* ctx, int which, float* ms);

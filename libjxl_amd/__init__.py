@@ -49,6 +49,7 @@ def lib():
             getattr(L, name).argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
         L.jxlhip_download_rgb8.argtypes = [vp, vp, ctypes.c_size_t]
         L.jxlhip_set_option.argtypes = [vp, cp, ctypes.c_int]
+        L.jxlhip_share_planes.argtypes = [vp, vp]
         L.jxlhip_download_rgb8_rows.argtypes = [vp, vp, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]
         L.jxlamd_frame_upload_band.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint32]
         L.jxlhip_rgb8_device_ptr.argtypes = [vp]
@@ -138,6 +139,11 @@ class HipContext:
 
     def set_option(self, name, value):
         _check(lib().jxlhip_set_option(self._h, name.encode(), int(value)), "jxlhip_set_option")
+
+    def share_planes(self, lender):
+        """Keep this context's XYB planes in `lender`'s buffer (None: its own again); call before upload()."""
+        _check(lib().jxlhip_share_planes(self._h, lender._h if lender is not None else None), "jxlhip_share_planes")
+        self._lender = lender  # keeps the lender alive
 
     def upload(self, frame, band=None):
         """band = (group_row_begin, group_row_end): produce only those rows of 256x256 groups (multi-GPU split)."""

@@ -80,6 +80,7 @@ struct JxlHipContext {
   // buffers
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
   Buf plane[3], rgb, tlist, scratch;
+  size_t plane_bytes = 0;  // bytes of plane[0] the current frame needs
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
   Buf batch_wave_ls;
   size_t batch_off_units = 0, batch_off_queue = 0, batch_off_wave_lanes = 0, batch_units = 0;  // layout of batch_lanes
@@ -110,6 +111,12 @@ struct JxlHipContext {
   // applied (hipStreamWaitEvent on this context's stream) by the next call that touches those results. Enqueuing the
   // wait only then keeps barrier packets of a long entropy launch out of the hardware queues other streams share.
   hipEvent_t pending_wait = nullptr;
+  // jxlhip_share_planes: this context's inverse-transform output lives in `plane_lender`'s plane buffer (NULL: its own).
+  // planes_event (on the context that owns the buffer): end of the last filter launch that read the buffer, recorded on
+  // planes_stream; a transform launch from another stream waits for it before overwriting the planes.
+  JxlHipContext* plane_lender = nullptr;
+  hipEvent_t planes_event = nullptr;
+  hipStream_t planes_stream = nullptr;
   // jxlhip_run_transform_batch / jxlhip_run_filter_color_batch: description of the frame set launched from this context
   struct FilterGroup {
     int key;  // gaborish * 4 + epf iterations
@@ -141,6 +148,9 @@ static int EntropyKernelChoice() {
   }();
   return v;
 }
+static JxlHipContext* PlaneHolder(JxlHipContext* c) { return c->plane_lender ? c->plane_lender : c; }
+static const JxlHipContext* PlaneHolder(const JxlHipContext* c) { return c->plane_lender ? c->plane_lender : c; }
+
 static int EnvInt(const char* name, int def) {
   const char* e = getenv(name);
   return e && *e ? atoi(e) : def;
@@ -404,7 +414,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = c->errors.Ensure(size_t(d->num_groups) * 4))) return r;
   HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(d->num_groups) * 4, c->stream));  // groups outside a band stay clean
   const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
-  if ((r = c->plane[0].Ensure(plane_bytes))) return r;
+  c->plane_bytes = plane_bytes;
+  if (!c->plane_lender && (r = c->plane[0].Ensure(plane_bytes))) return r;
   if ((c->keep_filtered || c->ups != 1) && (r = c->plane[1].Ensure(plane_bytes))) return r;
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * 3))) return r;
   if (c->ups != 1) {
@@ -520,7 +531,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   tp.base_b = d->base_corr_b;
   memcpy(tp.biases, d->quant_biases, sizeof(tp.biases));
   tp.xb = c->xb; tp.yb = c->yb; tp.xg = c->xg; tp.xp = c->xp; tp.yp = c->yp;
-  tp.out = c->plane[0].as<float>();
+  tp.out = PlaneHolder(c)->plane[0].as<float>();  // (a lender's buffer is checked again at launch: PrepareDownstream)
   tp.scratch = c->scratch.as<float>();
   tp.tlist = c->tlist.as<uint32_t>();
   memcpy(tp.list_begin, c->list_begin, sizeof(tp.list_begin));
@@ -727,7 +738,7 @@ static int LaunchTransforms(JxlHipContext* c0) {
 static void FillFusedParams(const JxlHipContext* c, jxlhip::FusedFilterParams* p) {
   p->debug = uint32_t(EnvInt("JXLHIP_FILTER_DEBUG", 0));
   p->f = c->fp;
-  p->f.in = c->plane[0].as<float>();
+  p->f.in = PlaneHolder(c)->plane[0].as<float>();
   p->f.out = nullptr;
   for (int stage = 0; stage < 3; stage++) {
     const float scale = stage == 0 ? c->epf_pass0 : stage == 2 ? c->epf_pass2 : 1.0f;
@@ -748,7 +759,12 @@ static int PrepareDownstream(JxlHipContext* c0, JxlHipContext* const* ctxs, size
   for (size_t i = 0; same && i < n; i++) same = c0->db_ctxs[i] == ctxs[i] && c0->db_gens[i] == ctxs[i]->generation;
   if (same) return 0;
   std::vector<jxlhip::TransformParams> tparams(n);
-  for (size_t i = 0; i < n; i++) tparams[i] = ctxs[i]->tp;
+  for (size_t i = 0; i < n; i++) {
+    tparams[i] = ctxs[i]->tp;
+    const JxlHipContext* h = PlaneHolder(ctxs[i]);
+    if (!h->plane[0].p || h->plane[0].cap < ctxs[i]->plane_bytes) return JXLHIP_ERR_INVALID_ARGUMENT;  // lender too small
+    tparams[i].out = h->plane[0].as<float>();
+  }
   std::vector<uint2> desc;
   for (int s = 0; s < 21; s++) {
     c0->desc_begin[s] = uint32_t(desc.size());
@@ -832,15 +848,32 @@ static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
       HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->pending_wait, 0));
       ctxs[i]->pending_wait = nullptr;
     }
+  // plane buffers last read by a filter launch on another stream (shared planes): wait for that launch, once per event
+  hipEvent_t waited = nullptr;
+  for (size_t i = 0; i < n; i++) {
+    JxlHipContext* h = PlaneHolder(ctxs[i]);
+    if (h->planes_event && h->planes_stream != c0->stream && h->planes_event != waited) {
+      HIP_TRY(hipStreamWaitEvent(c0->stream, h->planes_event, 0));
+      waited = h->planes_event;
+    }
+  }
   return PrepareDownstream(c0, ctxs, n);
 }
 static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
   JxlHipContext* c0 = ctxs[0];
-  if (n > 1) {
+  bool shared = false;
+  for (size_t i = 0; i < n && !shared; i++) shared = ctxs[i]->plane_lender != nullptr || ctxs[i]->planes_event != nullptr;
+  if (n > 1 || shared) {
     if (!c0->down_done) HIP_TRY(hipEventCreateWithFlags(&c0->down_done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c0->down_done, c0->stream));
     for (size_t i = 1; i < n; i++) ctxs[i]->pending_wait = c0->down_done;
   }
+  if (shared)
+    for (size_t i = 0; i < n; i++) {
+      JxlHipContext* h = PlaneHolder(ctxs[i]);
+      h->planes_event = c0->down_done;
+      h->planes_stream = c0->stream;
+    }
   return 0;
 }
 
@@ -1172,6 +1205,20 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
 int jxlhip_run_transform(JxlHipContext* c) { return jxlhip_run_transform_batch(&c, 1); }
 int jxlhip_run_filter_color(JxlHipContext* c) { return jxlhip_run_filter_color_batch(&c, 1); }
 
+int jxlhip_share_planes(JxlHipContext* c, JxlHipContext* lender) {
+  if (!c || c == lender || (lender && (lender->plane_lender || lender->device != c->device))) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->plane_lender = lender;
+  if (lender && !lender->planes_event) {  // marks the lender as shared from now on (its launches record the event)
+    HIP_TRY(hipSetDevice(lender->device));
+    if (!lender->down_done) HIP_TRY(hipEventCreateWithFlags(&lender->down_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(lender->down_done, lender->stream));
+    lender->planes_event = lender->down_done;
+    lender->planes_stream = lender->stream;
+  }
+  c->generation++;  // cached batch descriptions hold plane pointers
+  return 0;
+}
+
 int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
   if (!c || !name) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (std::string(name) == "keep_filtered") {
@@ -1257,7 +1304,7 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
     src = c->coeffs.p;
     bytes = size_t(c->ng) * 3 * 65536 * (c->coef_bits / 8);
   } else if (n == "xyb_idct") {
-    src = c->plane[0].p;
+    src = PlaneHolder(c)->plane[0].p;
     bytes = plane_bytes;
   } else if (n == "xyb_filtered") {
     if (!c->keep_filtered || !c->plane[1].p) return JXLHIP_ERR_INVALID_ARGUMENT;  // needs jxlhip_set_option("keep_filtered", 1)

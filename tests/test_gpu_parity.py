@@ -260,6 +260,48 @@ def test_int32_coefficient_storage(built):
         o.close()
 
 
+def test_shared_planes_between_frame_sets(built):
+    """jxlhip_share_planes: the contexts of a second frame set keep their XYB planes in the first set's buffers. The
+    two sets' transform -> filter sequences run from different streams; every launch that overwrites shared planes has to
+    wait for the filter launch that last read them, so repeated alternating decodes stay identical to unshared ones."""
+    J = built
+    a_data = J.encode_rgb8(J.synth_image(900, 600))
+    b_data = J.encode_rgb8(J.synth_image(880, 590, seed=7), distance=2.0)  # smaller frame, other filter settings
+    ref_a, ref_b = J.decode_rgb8(a_data), J.decode_rgb8(b_data)
+    fa, fb = J.Frame(a_data), J.Frame(b_data)
+    A = [J.HipContext() for _ in range(3)]
+    B = [J.HipContext() for _ in range(3)]
+    try:
+        for a, b in zip(A, B):
+            b.share_planes(a)
+        for c in A:
+            c.upload(fa)
+        for c in B:
+            c.upload(fb)
+        J.run_entropy_batch(A)
+        J.run_entropy_batch(B)
+        for _ in range(4):
+            J.run_transform_batch(A)
+            J.run_filter_color_batch(A)
+            J.run_transform_batch(B)
+            J.run_filter_color_batch(B)
+        for c in A:
+            assert np.array_equal(c.rgb8(), ref_a)
+        for c in B:
+            assert np.array_equal(c.rgb8(), ref_b)
+        # a lender that is too small for the borrower's frame is refused at launch
+        B[0].share_planes(None)
+        A[0].share_planes(B[0])
+        A[0].upload(fa)
+        B[0].upload(fb)
+        J.run_entropy_batch([A[0]])
+        with pytest.raises(Exception):
+            J.run_transform_batch([A[0]])
+    finally:
+        for c in A + B:
+            c.close()
+
+
 def test_batched_entropy_launch(built):
     """jxlhip_run_entropy_batch: frames of different geometry in one launch decode exactly as one by one, the batch
     description follows a re-upload, and the per-frame stages after it see the batch's coefficients."""
