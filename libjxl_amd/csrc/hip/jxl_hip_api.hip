@@ -157,8 +157,7 @@ static int EnvInt(const char* name, int def) {
 }
 
 static size_t LanesLdsFor(const JxlHipContext* c, uint32_t lanes = 64) {
-  return jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc,
-                                kLanesWPG, lanes).total;
+  return jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], kLanesWPG, lanes).total;
 }
 
 extern "C" {
@@ -477,16 +476,29 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->lds_entropy = ep.lds_ctx_bytes + ep.lds_alias_bytes + 3072;
   if (size_t(d->block_ctx_lut_size) < size_t(3) * 13 * ep.nq * ep.ndc) return JXLHIP_ERR_INVALID_ARGUMENT;
   // single-pass frames whose tables fit LDS are decoded by the lane-parallel kernel into scan order
-  c->scan_order = d->num_passes == 1 && EntropyKernelChoice() == 2 && LanesLdsFor(c) <= kLdsBudget;
+  // (its packed block records hold the block contexts in 4 bits each: the codestream allows at most 16)
+  c->scan_order = d->num_passes == 1 && EntropyKernelChoice() == 2 && LanesLdsFor(c) <= kLdsBudget && ep.num_bctx <= 16;
   if ((r = c->kend.Ensure(size_t(d->num_blocks ? d->num_blocks : 1) * 3 * 4))) return r;
   ep.kend = c->kend.as<uint32_t>();
   {
+    // Per varblock, everything the lane kernel's block transition needs in one word, so that it does no dependent
+    // table lookups: column in the group (5 bits) | not in the group's first row (1) | log2 covered_x (3) |
+    // log2 covered_y (3) | block context of X, Y, B (4 bits each: ac_context.h:101-143 BlockCtxMap::Context, from the
+    // strategy's order bucket, the quant-field bucket and the DC bucket).
+    static const uint8_t kOrderBucket[27] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+    static const uint8_t kLog2Cx[27] = {0, 0, 0, 0, 1, 2, 0, 1, 0, 2, 1, 2, 0, 0, 0, 0, 0, 0, 3, 2, 3, 4, 3, 4, 5, 4, 5};
+    static const uint8_t kLog2Cy[27] = {0, 0, 0, 0, 1, 2, 1, 0, 2, 0, 2, 1, 0, 0, 0, 0, 0, 0, 3, 3, 2, 4, 4, 3, 5, 5, 4};
     std::vector<uint32_t> recs(size_t(d->num_blocks) + 16, 0);
     for (uint32_t i = 0; i < d->num_blocks; i++) {
       const JxlHipVarBlock& v = d->blocks[i];
       uint32_t qfi = 0;
       for (uint32_t t = 0; t < d->num_qf_thresholds; t++) qfi += v.qf > d->qf_thresholds[t];
-      recs[i] = (v.bx & 31u) | (v.by & 31u) << 5 | uint32_t(v.strategy) << 10 | qfi << 15 | uint32_t(v.quant_dc_ctx) << 19;
+      uint32_t rec = (v.bx & 31u) | ((v.by & 31u) ? 32u : 0u) | uint32_t(kLog2Cx[v.strategy]) << 6 | uint32_t(kLog2Cy[v.strategy]) << 9;
+      for (uint32_t ch = 0; ch < 3; ch++) {
+        const uint32_t bctx = d->block_ctx_lut[((ch * 13 + kOrderBucket[v.strategy]) * ep.nq + qfi) * ep.ndc + v.quant_dc_ctx];
+        rec |= (bctx & 15u) << (12 + 4 * ch);
+      }
+      recs[i] = rec;
     }
     if ((r = Upload(c, c->block_recs, recs.data(), recs.size() * 4))) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));  // `recs` is a local
@@ -915,17 +927,17 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
     HIP_TRY(hipStreamSynchronize(c0->stream));
     HIP_TRY(hipMemcpy(h.data(), b.prof, nwaves * 64, hipMemcpyDeviceToHost));
     (void)hipFree(b.prof);
-    unsigned long long mx[6] = {0, 0, 0, 0, 0, 0};
-    double sum[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long mx[7] = {0, 0, 0, 0, 0, 0, 0};
+    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
     size_t used = 0;
     for (size_t w = 0; w < nwaves; w++) {
       if (!h[w * 8 + 3] && !h[w * 8 + 2]) continue;
       used++;
-      if (h[w * 8] > mx[0]) for (int j = 0; j < 6; j++) mx[j] = h[w * 8 + j];
-      for (int j = 0; j < 6; j++) sum[j] += double(h[w * 8 + j]);
+      if (h[w * 8] > mx[0]) for (int j = 0; j < 7; j++) mx[j] = h[w * 8 + j];
+      for (int j = 0; j < 7; j++) sum[j] += double(h[w * 8 + j]);
     }
-    fprintf(stderr, "[lanes prof] waves %zu  longest: cycles %llu service %llu (%llu calls) trips %llu hot0 %llu hot1 %llu | mean: cycles %.0f service %.0f calls %.0f trips %.0f hot0 %.0f hot1 %.0f\n",
-            used, mx[0], mx[1], mx[2], mx[3], mx[4], mx[5], sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used, sum[4] / used, sum[5] / used);
+    fprintf(stderr, "[lanes prof] waves %zu  longest: cycles %llu service %llu (%llu calls) trips %llu hot0 %llu hot1 %llu | mean: cycles %.0f service %.0f calls %.0f trips %.0f hot0 %.0f hot1 %.0f landing %.0f\n",
+            used, mx[0], mx[1], mx[2], mx[3], mx[4], mx[5], sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used, sum[4] / used, sum[5] / used, sum[6] / used);
   }
   return 0;
 }
@@ -1041,7 +1053,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     }
     for (size_t wg = 0; wg < map.size(); wg++) {  // LDS of the launch = the largest workgroup
       const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg]) * 4] & 0xFFFF];
-      size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 39 * c->ep.nq * c->ep.ndc, 0, 0).wave0;
+      size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 0, 0).wave0;
       for (uint32_t w = 0; w < wpg; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * wpg + w];
       lds = l > lds ? l : lds;
     }

@@ -53,7 +53,7 @@ struct EntropyLaneBatch {
 
 // LDS layout of one workgroup (byte offsets, every region 16-byte aligned); the host sizes the launch with it.
 struct LanesLds {
-  uint32_t alias, ctx, lut, ctx2, cfg, sinfo, wave0, per_wave, total;
+  uint32_t alias, ctx, ctx2, cfg, wave0, per_wave, total;
 };
 // Per-wave LDS, all [row][lane] with a row stride of `lanes` entries (conflict-free, and a wave that populates few lanes
 // needs little LDS, which keeps room on the CU for the bandwidth-bound kernels running beside this one):
@@ -62,15 +62,13 @@ constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 2 mir
 constexpr uint32_t kLanesBlockRing = 8;             // packed block records, u32
 constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 2) * 4 + kLanesBlockRing * 4;
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
-                                                   uint32_t lut_bytes, uint32_t waves, uint32_t lanes) {
+                                                   uint32_t waves, uint32_t lanes) {
   LanesLds l;
   l.alias = 0;
   l.ctx = (num_clusters << log_alpha) * 8;
-  l.lut = l.ctx + ((num_hist * nctx + 16 + 15) & ~15u);
-  l.ctx2 = l.lut + ((lut_bytes + 15) & ~15u);
+  l.ctx2 = l.ctx + ((num_hist * nctx + 16 + 15) & ~15u);
   l.cfg = l.ctx2 + 64 * 2;
-  l.sinfo = l.cfg + 256 * 2;
-  l.wave0 = l.sinfo + 32 * 4;
+  l.wave0 = l.cfg + 256 * 2;
   l.per_wave = kLanesPerLaneBytes * lanes;
   l.total = l.wave0 + waves * l.per_wave;
   return l;
@@ -130,23 +128,20 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   const EntropyParams& P = B.params[wg_desc & 0xFFFF];
   const PassDev& T = P.passes[0];
   const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, nclusters = T.num_clusters;
-  const uint32_t nq = P.nq, ndc = P.ndc, num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
-  const uint32_t lut_bytes = 39 * nq * ndc;
+  const uint32_t num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
   const uint8_t* wls = B.wave_log_ls + blockIdx.x * WPG;
   const uint32_t log_ls = wls[wave];
   const uint32_t LS = 1u << log_ls;
   uint32_t wave_off = 0;  // the per-wave regions are packed one after the other
   for (uint32_t w = 0; w < wave; w++) wave_off += kLanesPerLaneBytes << wls[w];
-  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, lut_bytes, 0, 0);
+  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, 0, 0);
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
   uint8_t* l_ctx = lds_raw + L.ctx;                                      // context -> histogram (cluster)
   uint16_t* l_cfg = reinterpret_cast<uint16_t*>(lds_raw + L.cfg);        // per cluster: split_exp | msb << 4 | lsb << 8
-  uint8_t* l_lut = lds_raw + L.lut;
   uint16_t* l_nnz2 = reinterpret_cast<uint16_t*>(lds_raw + L.ctx2);  // [ceil(nzeros left / covered)] -> 2 * kCoeffNumNonzeroContext
   uint8_t* l_nz = lds_raw + L.wave0 + wave_off;                       // line buffer of the per-block nzeros prediction
   uint32_t* ring = reinterpret_cast<uint32_t*>(l_nz + kLanesNzRows * LS) + lane;                 // stream ring [slot][lane]
   uint32_t* bring = ring + (kLanesRingWords + 2) * LS;                                           // block records [slot][lane]
-  const uint32_t* l_sinfo = reinterpret_cast<const uint32_t*>(lds_raw + L.sinfo);
 
   // ---- stage the frame's tables (whole workgroup)
   {
@@ -169,9 +164,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       const uint32_t cutoff = e.x & 0xFF, right = (e.x >> 8) & 0xFF, freq0 = e.x >> 16, offs1 = e.y & 0xFFFF, freq1 = e.y >> 16;
       l_alias[i] = make_uint2(((freq0 - 1) & 0xFFFu) | (cutoff << 24), ((freq1 - 1) & 0xFFFu) | ((offs1 & 0xFFFu) << 12) | (right << 24));
     }
-    for (uint32_t i = tid; i < lut_bytes; i += 64 * WPG) l_lut[i] = P.bctx_lut[i];
     if (tid < 64) l_nnz2[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 2);
-    if (tid < 27) reinterpret_cast<uint32_t*>(lds_raw + L.sinfo)[tid] = c_strategy_info[tid];
     uint32_t* z = reinterpret_cast<uint32_t*>(l_nz);
     for (uint32_t i = lane; i < kLanesNzRows * LS / 4; i += 64) z[i] = 0;
   }
@@ -193,7 +186,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   uint32_t nwords = 0, sec_size = 0, ring_end = 0, bring_end = 0, bitpos = 0, state = 0, ctx_base = 0;
   bool started = false;
   // block / channel cursor
-  uint32_t info = 0, lbx = 0, lby = 0, qfi = 0, dcctx = 0, coef_offset = 0, next_offset = 0;
+  uint32_t info = 0, lbx = 0, lby = 0, coef_offset = 0, next_offset = 0;
   auto open_section = [&]() {  // cursors of section g (the nzeros line buffer needs no reset: every entry a section
                                // reads was written by an earlier block of the same section)
     bi = P.gbb[g] - 1;         // the first transition advances to the group's first block
@@ -219,7 +212,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   CoefT* const coeffs = static_cast<CoefT*>(P.coeffs);
   const uint32_t shift = T.shift;
 
-  unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, t_hot0 = 0, t_hot1 = 0;
+  unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, t_hot0 = 0, t_hot1 = 0, t_land = 0;
   if (B.prof) t_begin = __builtin_readcyclecounter();
   for (;;) {
     // two hot trips consume at most 2 * 47 bits, i.e. bits of at most 4 ring words (words read beyond ring_end are
@@ -240,9 +233,14 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
       uint4 pf_s = make_uint4(0, 0, 0, 0), pf_b = make_uint4(0, 0, 0, 0);
       if (want_s && ring_end < nwords) pf_s = stream4[ring_end >> 2];  // (past the section the ring is fed zeros)
       if (want_b) pf_b = rec4[bring_end >> 2];
-      // (2) block / channel transitions of the waiting lanes, including the block's non-zero-count symbol
+      // (2) block / channel transitions of the waiting lanes, including the block's non-zero-count symbol. A lane whose
+      // channel turns out empty (non-zero count 0: common for the chroma channels) is still waiting afterwards, so up to
+      // three transitions (a whole block) are made per phase.
+      for (int pass = 0; pass < 3; pass++) {
       const bool next_block = ci == 2 && started;  // the coming transition moves on to block bi + 1
-      if (mode == kWait && (ring_end - (bitpos >> 5)) >= 3 && (!next_block || bi + 1 < bring_end || bi + 1 >= b1)) {
+      const bool go = mode == kWait && (ring_end - (bitpos >> 5)) >= 3 && (!next_block || bi + 1 < bring_end || bi + 1 >= b1);
+      if (pass && !__ballot(go)) break;
+      if (go) {
         if (!started) {  // section header: histogram selector + initial rANS state
           started = true;
           uint32_t hb = 0;
@@ -273,28 +271,26 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
               want_s = want_b = false;  // the loads issued above belong to the finished section
             }
           } else {
-            if (ci == 0) {  // packed record: lbx | lby << 5 | strategy << 10 | qf bucket << 15 | dc bucket << 19
-              const uint32_t rec = bring[(bi & (kLanesBlockRing - 1)) * LS];
-              lbx = rec & 31;
-              lby = (rec >> 5) & 31;
-              info = l_sinfo[(rec >> 10) & 31];
-              qfi = (rec >> 15) & 15;
-              dcctx = rec >> 19;
+            if (ci == 0) {  // packed record (jxlhip_frame_upload): column | not first row << 5 | log2 covered_x << 6 |
+                            // log2 covered_y << 9 | block context of X, Y, B << 12, 16, 20
+              info = bring[(bi & (kLanesBlockRing - 1)) * LS];
+              lbx = info & 31;
+              lby = (info >> 5) & 1;
+              log2c = ((info >> 6) & 7) + ((info >> 9) & 7);
               coef_offset = next_offset;  // blocks of a group are contiguous in its coefficient planes
-              next_offset += 64u << ((info >> 16) & 0xFF);
+              next_offset += 64u << log2c;
             }
             const uint32_t c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
-            const uint32_t ord = info >> 24, cx = info & 0xFF;
+            const uint32_t cx = 1u << ((info >> 6) & 7);
+            const uint32_t bctx = (info >> (12 + 4 * c)) & 15;
             uint8_t* line = l_nz + (c * 32) * LS + lane;
             uint32_t pred;
             if (lbx == 0) pred = lby ? line[0] : 32;
             else if (lby == 0) pred = line[(lbx - 1) * LS];
             else pred = (uint32_t(line[lbx * LS]) + line[(lbx - 1) * LS] + 1) >> 1;
-            const uint32_t bctx = l_lut[((c * 13 + ord) * nq + qfi) * ndc + dcctx];
             uint32_t nzb = pred >= 64 ? 64 : pred;
             nzb = nzb < 8 ? nzb : 4 + nzb / 2;
             const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
-            log2c = (info >> 16) & 0xFF;
             const uint32_t covered = 1u << log2c;
             size = covered * 64;
             kidx = bi * 3 + c;
@@ -323,7 +319,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
           }
         }
       }
+      }
       // (3) land the refills in the LDS rings
+      unsigned long long t3 = 0;
+      if (B.prof) t3 = __builtin_readcyclecounter();
       if (want_s) {
         const uint32_t s = ring_end & (kLanesRingWords - 1);
         ring[(s + 0) * LS] = ring_end + 0 < nwords ? pf_s.x : 0;  // reads past the section are zeros
@@ -345,7 +344,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
         bring_end += 4;
       }
       if (B.prof) {
-        t_service += __builtin_readcyclecounter() - t0;
+        const unsigned long long now = __builtin_readcyclecounter();
+        t_service += now - t0;
+        t_land += now - t3;
         n_service++;
       }
       continue;
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
   }
   if (B.prof && lane == 0) {
     unsigned long long* o = B.prof + size_t(blockIdx.x * WPG + wave) * 8;
+    o[6] = t_land;
     o[4] = t_hot0;
     o[5] = t_hot1;
     o[0] = __builtin_readcyclecounter() - t_begin;
