@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=384, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=640, help="frames per step per GPU")
     ap.add_argument("--size", default="3840x2160")
     ap.add_argument("--distance", type=float, default=1.0)
     ap.add_argument("--shard", choices=("frames", "bands"), default="frames",
@@ -235,8 +235,8 @@ def main():
         # algorithmic bytes per launch (one frame) of each stage, SURVEY.md §8d / DESIGN.md:
         alg = {
             "entropy (k_entropy_lanes)": info["ac_bytes"] + 6.0 * px,          # bitstream read + int16 coefficients written
-            "transform (k_dct/k_special)": (6.0 + 0.4 + 12.0) * px,          # coefficients + side info read, f32 XYB written
-            "filter+colour (k_filter_fused)": (12.0 + 0.06 + 3.0) * px,  # f32 XYB + sigma read, RGB8 written
+            "transform (k_idct_fast/k_dct/k_special)": (6.0 + 0.4 + 12.0) * px,  # coefficients + side info read, f32 XYB written
+            "filter+colour (k_filter_rows)": (12.0 + 0.06 + 3.0) * px,           # f32 XYB + sigma read, RGB8 written
         }
         names = list(alg)
         dom = max(range(3), key=lambda s: stage_ms[s])
@@ -247,7 +247,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = ["k_entropy_lanes", "k_idct_cols<short, 4, 4>", "k_filter_fused"][dom]
+            key = ["k_entropy_lanes", "k_idct_fast<short, 4, 4>", "k_filter_rows"][dom]
             for name, v in pmc.items():
                 if key in name and pmc.get("_frames_per_launch") == args.batch:
                     traffic = int((v["fetch_kib_per_dispatch"] + v["write_kib_per_dispatch"]) * 1024)
@@ -268,7 +268,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
                 xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
-                "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else "none", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
+                "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else "none",
+                "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
                 ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -277,6 +278,7 @@ def main():
                          "note": "entropy decode is serial per 256x256 group (latency-bound, not HBM-bound); amortised over the frames of one launch" if dom == 0 else ""},
             "stage_ms_per_frame": {names[s]: round(stage_ms[s], 4) for s in range(3)},  # entropy: live, launch / frames; others: isolated
             "stage_gbs": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9, 2) for s in range(3)},
+            "stage_hbm_frac": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for s in range(3)},
         }
         if not args.no_cpu_baseline:
             ref = system_libjxl_baseline(data, xsize, ysize, os.cpu_count() or 1)

@@ -1024,6 +1024,8 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     if (!EnvInt("JXLHIP_WPG", 0) && lanes_per_wave >= 32) {  // dense regime: one wave per workgroup, all of a unit's lanes
       wpg = 1;                                                // in it (a trip costs about the same for 14 or 55 lanes)
       lanes_per_wave = 64;
+      for (Unit& u : units)  // the wave's spare lanes are free: shorter lists per lane
+        if (u.lanes < 64) u.lanes = u.count < 64 ? u.count : 64;
     }
     c0->batch_wpg = wpg;
     if (lanes_per_wave == 1 && min_total < target_waves) {  // room to spare: more lanes per unit, up to one per section
