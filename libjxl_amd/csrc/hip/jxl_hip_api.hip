@@ -889,16 +889,19 @@ static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
   return 0;
 }
 
-template <typename CoefT, int WPG>
+template <typename CoefT, int WPG, bool AIDS>
 static int LaunchEntropyLanesW(JxlHipContext* c0);
 template <typename CoefT>
 static int LaunchEntropyLanes(JxlHipContext* c0) {
-  return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1>(c0)
-                            : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2>(c0) : LaunchEntropyLanesW<CoefT, 4>(c0));
+  if (EnvInt("JXLHIP_LANES_DEBUG", 0) || EnvInt("JXLHIP_LANES_PROF", 0))  // measurement aids: instrumented build of the kernel
+    return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, true>(c0)
+                              : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, true>(c0) : LaunchEntropyLanesW<CoefT, 4, true>(c0));
+  return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, false>(c0)
+                            : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, false>(c0) : LaunchEntropyLanesW<CoefT, 4, false>(c0));
 }
-template <typename CoefT, int WPG>
+template <typename CoefT, int WPG, bool AIDS>
 static int LaunchEntropyLanesW(JxlHipContext* c0) {
-  auto k = jxlhip::k_entropy_lanes<CoefT, WPG>;
+  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS>;
   if (c0->batch_lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
   jxlhip::EntropyLaneBatch b;
@@ -911,6 +914,7 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
   b.wave_lanes = blob + c0->batch_off_wave_lanes;
   HIP_TRY(hipMemsetAsync(b.queue, 0, c0->batch_units * 4, c0->stream));
   b.wait_shift = c0->batch_wait_shift;
+  b.prio = uint32_t(EnvInt("JXLHIP_LANES_PRIO", 0));
   b.wave_log_ls = c0->batch_wave_ls.as<uint8_t>();
   b.debug = uint32_t(EnvInt("JXLHIP_LANES_DEBUG", 0));
   b.prof = nullptr;

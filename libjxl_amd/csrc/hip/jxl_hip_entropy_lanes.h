@@ -42,12 +42,12 @@ struct EntropyLaneBatch {
                                 // sections by actual decode time (a launch lasts as long as its busiest lane; sections
                                 // differ 8x in token count, which their byte size predicts poorly)
   const uint8_t* wave_lanes;    // per wave: populated lanes (the others idle)
+  uint32_t prio;                // non-zero: the waves raise their issue priority (s_setprio 3)
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
   const uint8_t* wave_log_ls;   // per wave: log2 of its populated-lane capacity (lanes beyond it are idle); the wave's LDS
                                 // rows are strided by that many entries, so sparse waves take little LDS
   uint32_t debug;               // measurement aid: bit 0 = skip the coefficient stores (results are then invalid),
-                                // bit 1 = report every section's coefficient-token count in its error word,
-                                // bit 2 = run at the default wave priority
+                                // bit 1 = report every section's coefficient-token count in its error word
   unsigned long long* prof;     // optional (may be NULL): per wave {cycles total, cycles in service, services, hot trips}
 };
 
@@ -77,6 +77,9 @@ __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t n
 // One rANS symbol + hybrid-uint extra bits for the calling lane from histogram `cluster` (alias tables start at LDS
 // offset 0, 8 << log_alpha bytes per cluster; l_cfg[cluster] = split_exp | msb << 4 | lsb << 8). `ring` points at the
 // lane's column of the stream ring.
+// FLAT = true: no branches (the renormalisation and the extra bits are computed for every lane and selected), so that a
+// hot trip is one basic block whose independent instructions the scheduler can interleave with the serial chain.
+template <bool FLAT = false>
 __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
                                                uint32_t log_ls, const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry) {
   const uint32_t ctxe = l_cfg[cluster];
@@ -98,6 +101,22 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
   state = (x & 0xFFFu) * hi + hi + ((x >> 12) & 0xFFFu) + pos;
   const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, boff);
   const bool need = state < (1u << 16);
+  if (FLAT) {
+    const uint32_t sh = need ? 16u : 0u;
+    state = (state << sh) | (need ? (win & 0xFFFFu) : 0u);
+    const uint32_t boff2 = boff + sh;  // < 48
+    bitpos += sh;
+    const uint32_t se = ctxe & 15;
+    const bool take = tok >= (1u << se);
+    const uint32_t msb = (ctxe >> 4) & 15, lsb = (ctxe >> 8) & 15;
+    const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
+    const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
+    const bool up = boff2 >= 32;
+    const uint32_t xb = __builtin_amdgcn_alignbit(up ? w2 : w1, up ? w1 : w0, boff2 & 31) & ((1u << nb) - 1);
+    const uint32_t big = (((((1u << msb) | (top & ((1u << msb) - 1))) << nb) | xb) << lsb) | low;
+    bitpos += take ? nb : 0u;
+    return take ? big : tok;
+  }
   state = need ? ((state << 16) | (win & 0xFFFFu)) : state;
   const uint32_t boff2 = boff + (need ? 16u : 0u);  // < 48
   bitpos += need ? 16u : 0u;
@@ -114,12 +133,18 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
   return tok;
 }
 
-template <typename CoefT, int WPG>
-__global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) {
+// AIDS = false compiles the measurement aids (B.prof, B.debug) out.
+template <typename CoefT, int WPG, bool AIDS>
+__global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_) {
+  EntropyLaneBatch B = B_;
+  if (!AIDS) {
+    B.prof = nullptr;
+    B.debug = 0;
+  }
   extern __shared__ __align__(16) uint8_t lds_raw[];
   // This wave is a serial dependency chain that leaves most issue slots empty: it takes precedence over the
   // bandwidth-bound kernels that share its SIMD (they fill the gaps) whatever their age.
-  if (B.debug & 4) __builtin_amdgcn_s_setprio(3);
+  if (B_.prio) __builtin_amdgcn_s_setprio(3);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t unit = B.wg_unit[blockIdx.x];
   const uint4 unit_desc = B.units[unit];
@@ -374,7 +399,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B) 
         // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays): read here, with
         // everything else, so that no LDS read is waited for at the end of the trip
         const uint32_t nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
-        const uint32_t tok = LaneSymbol(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
+        const uint32_t tok = LaneSymbol<true>(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
         const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
         const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
         if (!(B.debug & 1)) coeffs[dptr] = CoefT(coeff);
