@@ -1379,9 +1379,7 @@ __device__ __forceinline__ float LinearToSrgb(float v) {
   return copysignf(r, v);
 }
 __device__ __forceinline__ uint8_t ToU8D(float v, float dither) {  // dither = c_dither[(y + c * 13) & 31][(x + c * 23) & 31]
-  v = v * 255.0f + dither;
-  v = v >= 0.0f ? v : 0.0f;
-  v = v > 255.0f ? 255.0f : v;
+  v = __builtin_amdgcn_fmed3f(v * 255.0f + dither, 0.0f, 255.0f);  // clamp (a NaN becomes 0 as before)
   return uint8_t(__float2int_rn(v));
 }
 __device__ __forceinline__ uint8_t ToU8(float v, int x, int y, int c) {
