@@ -130,6 +130,9 @@ def main():
                          "of 256x256 groups of every frame per rank (strong scaling, no exchange between ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one frame set: entropy, then transform+filter, in sequence")
+    ap.add_argument("--chain", action="store_true",
+                    help="one frame set, filter + colour of step k on a second stream under the entropy launch of step k + 1 "
+                         "(option filter_async), instead of the default software pipeline over two frame sets")
     ap.add_argument("--no-share-planes", action="store_true", help="every context of both pipelined sets keeps its own XYB planes")
     args = ap.parse_args()
     xsize, ysize = [int(v) for v in args.size.split("x")]
@@ -153,7 +156,8 @@ def main():
     # Two sets of `batch` frames: while one set is in the (latency-bound, serial per section) entropy stage, the other
     # set's coefficients go through the (bandwidth-bound) transform + filter + colour stages. Every step runs every
     # stage once over `batch` frames, so a step completes `batch` frames; a frame's latency is two steps.
-    nsets = 1 if args.no_pipeline else 2
+    nsets = 1 if (args.no_pipeline or args.chain) else 2
+    chain = args.chain and not args.no_pipeline
     sets = [[J.HipContext(local_rank) for _ in range(args.batch)] for _ in range(nsets)]
     band = None
     share = 1.0  # fraction of every frame's pixels this rank produces
@@ -168,6 +172,8 @@ def main():
         # those stages at the same time: set 1 keeps its planes in set 0's buffers (100 MB less per pair of 4K frames)
         for a, b in zip(sets[0], sets[1]):
             b.share_planes(a)
+    if chain:
+        sets[0][0].set_option("filter_async", 1)
     for cs in sets:
         for c in cs:
             c.upload(frame, band=band)
@@ -268,7 +274,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
                 xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
-                "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else "none",
+                "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else
+                ("1 frame set: entropy and transform back to back, filter+colour of step k on a second stream under the entropy launch of step k+1" if chain else "none"),
                 "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
                 ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -168,7 +168,13 @@ int jxlhip_get_errors(JxlHipContext* ctx, uint32_t* flags, size_t n);
 int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_size, size_t* needed);
 
 /* Options (set before jxlhip_frame_upload): "keep_filtered" = 1 makes jxlhip_run_filter_color also store the filtered
- * XYB planes for jxlhip_download("xyb_filtered") (test aid; costs one extra plane set and 12 B/pixel of writes). */
+ * XYB planes for jxlhip_download("xyb_filtered") (test aid; costs one extra plane set and 12 B/pixel of writes).
+ * "filter_async" = 1 (on the FIRST context of a set; may be changed at any time): jxlhip_run_filter_color_batch launches
+ * on that context's second stream, ordered after the work its first stream holds. The call sequence entropy_batch,
+ * transform_batch, filter_color_batch, entropy_batch, ... on one frame set then overlaps every filter + colour launch
+ * with the next entropy launch (which touches neither planes nor pixels): the LDS-hungry entropy and transform kernels
+ * never share the GPU, the LDS-free filter fills the gaps of the latency-bound entropy kernel. The library keeps the
+ * order: the next transform, upload, download or sync of any frame of the set waits for the filter launch. */
 int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
 
 /* Memory sharing for pipelined frame sets (call before jxlhip_frame_upload): `ctx` keeps its inverse-transform output (the

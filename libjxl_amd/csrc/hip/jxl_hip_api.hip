@@ -114,6 +114,15 @@ struct JxlHipContext {
   // jxlhip_share_planes: this context's inverse-transform output lives in `plane_lender`'s plane buffer (NULL: its own).
   // planes_event (on the context that owns the buffer): end of the last filter launch that read the buffer, recorded on
   // planes_stream; a transform launch from another stream waits for it before overwriting the planes.
+  // Option "filter_async": batched filter + colour launches from this context go to its SECOND stream, ordered after
+  // what the first stream holds at that moment; the first stream is then free for the next entropy launch (which touches
+  // neither the planes nor the pixels) while the filter still runs. filter_wait (on every context of such a launch):
+  // the launch's end event; waited for by whatever touches the planes or the pixels next (transform, download, sync,
+  // upload), never by an entropy launch.
+  bool filter_async = false;
+  hipStream_t stream2 = nullptr;
+  hipStream_t fstream = nullptr;  // stream of the filter launch in progress (set by BeginDownstreamBatch)
+  hipEvent_t fork_event = nullptr, filter_done = nullptr, filter_wait = nullptr;
   JxlHipContext* plane_lender = nullptr;
   hipEvent_t planes_event = nullptr;
   hipStream_t planes_stream = nullptr;
@@ -230,6 +239,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params};
@@ -244,6 +254,9 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
     if (ev) (void)hipEventDestroy(ev);
   if (c->batch_done) (void)hipEventDestroy(c->batch_done);
   if (c->down_done) (void)hipEventDestroy(c->down_done);
+  if (c->fork_event) (void)hipEventDestroy(c->fork_event);
+  if (c->filter_done) (void)hipEventDestroy(c->filter_done);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -252,6 +265,10 @@ static int ApplyPendingWait(JxlHipContext* c) {
   if (c->pending_wait) {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->pending_wait, 0));
     c->pending_wait = nullptr;
+  }
+  if (c->filter_wait) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->filter_wait, 0));
+    c->filter_wait = nullptr;
   }
   return 0;
 }
@@ -824,7 +841,7 @@ static int LaunchFused(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
   for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
     const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
-    hipLaunchKernelGGL(k, dim3(g.tiles_x, g.tiles_y, zn), dim3(jxlhip::kFusedThreads), lds, c0->stream,
+    hipLaunchKernelGGL(k, dim3(g.tiles_x, g.tiles_y, zn), dim3(jxlhip::kFusedThreads), lds, c0->fstream,
                        c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
   }
   HIP_TRY(hipGetLastError());
@@ -838,7 +855,7 @@ static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup&
   const uint32_t gy = (rows + jxlhip::kRowsStrip - 1) / jxlhip::kRowsStrip;
   for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
     const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
-    hipLaunchKernelGGL(jxlhip::k_filter_rows, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0, c0->stream,
+    hipLaunchKernelGGL(jxlhip::k_filter_rows, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0, c0->fstream,
                        c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
   }
   HIP_TRY(hipGetLastError());
@@ -846,7 +863,7 @@ static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup&
 }
 
 // Validates a set for a batched downstream call and orders the launch stream after everything its frames wait for.
-static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
+static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_stage = false) {
   if (!ctxs || !n) return JXLHIP_ERR_INVALID_ARGUMENT;
   JxlHipContext* c0 = ctxs[0];
   for (size_t i = 0; i < n; i++) {
@@ -855,36 +872,64 @@ static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
     if (ctxs[i]->device != c0->device || ctxs[i]->coef_bits != c0->coef_bits) return JXLHIP_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(hipSetDevice(c0->device));
+  hipStream_t ls = c0->stream;  // launch stream
+  if (filter_stage && c0->filter_async) {
+    if (!c0->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&c0->stream2, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c0->fork_event, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c0->filter_done, hipEventDisableTiming));
+    }
+    ls = c0->stream2;
+    HIP_TRY(hipEventRecord(c0->fork_event, c0->stream));  // after everything the first stream holds (the transform)
+    HIP_TRY(hipStreamWaitEvent(ls, c0->fork_event, 0));
+  }
+  c0->fstream = ls;
+  hipEvent_t waited = nullptr;
   for (size_t i = 0; i < n; i++)
     if (ctxs[i]->pending_wait) {
-      HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->pending_wait, 0));
+      if (ctxs[i]->pending_wait != waited) HIP_TRY(hipStreamWaitEvent(ls, ctxs[i]->pending_wait, 0));
+      waited = ctxs[i]->pending_wait;
       ctxs[i]->pending_wait = nullptr;
     }
+  // planes / pixels still in use by an asynchronous filter launch: wait for it, once per event
+  waited = nullptr;
+  for (size_t i = 0; i < n; i++)
+    if (ctxs[i]->filter_wait) {
+      if (ctxs[i]->filter_wait != waited) HIP_TRY(hipStreamWaitEvent(ls, ctxs[i]->filter_wait, 0));
+      waited = ctxs[i]->filter_wait;
+      ctxs[i]->filter_wait = nullptr;
+    }
   // plane buffers last read by a filter launch on another stream (shared planes): wait for that launch, once per event
-  hipEvent_t waited = nullptr;
+  waited = nullptr;
   for (size_t i = 0; i < n; i++) {
     JxlHipContext* h = PlaneHolder(ctxs[i]);
-    if (h->planes_event && h->planes_stream != c0->stream && h->planes_event != waited) {
-      HIP_TRY(hipStreamWaitEvent(c0->stream, h->planes_event, 0));
+    if (h->planes_event && h->planes_stream != ls && h->planes_event != waited) {
+      HIP_TRY(hipStreamWaitEvent(ls, h->planes_event, 0));
       waited = h->planes_event;
     }
   }
   return PrepareDownstream(c0, ctxs, n);
 }
-static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n) {
+static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_stage = false) {
   JxlHipContext* c0 = ctxs[0];
   bool shared = false;
   for (size_t i = 0; i < n && !shared; i++) shared = ctxs[i]->plane_lender != nullptr || ctxs[i]->planes_event != nullptr;
-  if (n > 1 || shared) {
+  hipEvent_t done = nullptr;
+  if (filter_stage && c0->fstream != c0->stream) {  // asynchronous filter launch: every context of it remembers its end
+    HIP_TRY(hipEventRecord(c0->filter_done, c0->fstream));
+    done = c0->filter_done;
+    for (size_t i = 0; i < n; i++) ctxs[i]->filter_wait = done;
+  } else if (n > 1 || shared) {
     if (!c0->down_done) HIP_TRY(hipEventCreateWithFlags(&c0->down_done, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c0->down_done, c0->stream));
-    for (size_t i = 1; i < n; i++) ctxs[i]->pending_wait = c0->down_done;
+    done = c0->down_done;
+    for (size_t i = 1; i < n; i++) ctxs[i]->pending_wait = done;
   }
-  if (shared)
+  if (shared && filter_stage)
     for (size_t i = 0; i < n; i++) {
       JxlHipContext* h = PlaneHolder(ctxs[i]);
-      h->planes_event = c0->down_done;
-      h->planes_stream = c0->stream;
+      h->planes_event = done;
+      h->planes_stream = c0->fstream;
     }
   return 0;
 }
@@ -1183,10 +1228,11 @@ int jxlhip_run_transform_batch(JxlHipContext* const* ctxs, size_t n) {
 }
 
 int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
-  int r = BeginDownstreamBatch(ctxs, n);
+  int r = BeginDownstreamBatch(ctxs, n, true);
   if (r) return r;
   JxlHipContext* c0 = ctxs[0];
-  HIP_TRY(hipEventRecord(c0->ev[4], c0->stream));
+  const hipStream_t ls = c0->fstream;
+  HIP_TRY(hipEventRecord(c0->ev[4], ls));
   for (const JxlHipContext::FilterGroup& g : c0->fgroups) {
     switch (g.key) {
       case 0: r = LaunchFused<false, 0>(c0, g); break;
@@ -1210,14 +1256,14 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
     up.n = c->ups;
     up.oxs = c->oxs;
     up.oys = c->oys;
-    hipLaunchKernelGGL(jxlhip::k_upsample_color, dim3((c->xs + 63) / 64, (c->ys + 3) / 4), dim3(256), 0, c0->stream, up);
+    hipLaunchKernelGGL(jxlhip::k_upsample_color, dim3((c->xs + 63) / 64, (c->ys + 3) / 4), dim3(256), 0, ls, up);
     HIP_TRY(hipGetLastError());
   }
-  HIP_TRY(hipEventRecord(c0->ev[5], c0->stream));
+  HIP_TRY(hipEventRecord(c0->ev[5], ls));
   c0->ev_valid[2] = true;
   for (size_t i = 0; i < n; i++) ctxs[i]->final_plane = 1;
   for (size_t i = 1; i < n; i++) ctxs[i]->ev_valid[2] = false;
-  return EndDownstreamBatch(ctxs, n);
+  return EndDownstreamBatch(ctxs, n, true);
 }
 
 int jxlhip_run_transform(JxlHipContext* c) { return jxlhip_run_transform_batch(&c, 1); }
@@ -1241,6 +1287,10 @@ int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
   if (!c || !name) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (std::string(name) == "keep_filtered") {
     c->keep_filtered = value != 0;
+    return 0;
+  }
+  if (std::string(name) == "filter_async") {
+    c->filter_async = value != 0;
     return 0;
   }
   return JXLHIP_ERR_INVALID_ARGUMENT;

@@ -302,6 +302,31 @@ def test_shared_planes_between_frame_sets(built):
             c.close()
 
 
+def test_async_filter_overlaps_next_entropy(built):
+    """Option "filter_async": the filter launch of a frame set runs on a second stream while the next entropy launch of
+    the same set is already queued; transforms, re-uploads and downloads still wait for it."""
+    J = built
+    datas = [J.encode_rgb8(J.synth_image(700, 500, seed=s), distance=d) for s, d in ((1, 1.0), (2, 2.0), (3, 1.0))]
+    refs = [J.decode_rgb8(d) for d in datas]
+    frames = [J.Frame(d) for d in datas]
+    ctxs = [J.HipContext() for _ in range(3)]
+    try:
+        ctxs[0].set_option("filter_async", 1)
+        for rot in range(3):  # every round decodes a different assignment of frames to contexts
+            for i, c in enumerate(ctxs):
+                c.upload(frames[(i + rot) % 3])
+            for _ in range(3):
+                J.run_entropy_batch(ctxs)
+                J.run_transform_batch(ctxs)
+                J.run_filter_color_batch(ctxs)
+            J.run_entropy_batch(ctxs)  # queued behind nothing the filter needs
+            for i, c in enumerate(ctxs):
+                assert np.array_equal(c.rgb8(), refs[(i + rot) % 3])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_batched_entropy_launch(built):
     """jxlhip_run_entropy_batch: frames of different geometry in one launch decode exactly as one by one, the batch
     description follows a re-upload, and the per-frame stages after it see the batch's coefficients."""
