@@ -876,7 +876,7 @@ static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filte
   if (filter_stage && c0->filter_async) {
     if (!c0->stream2) {
       HIP_TRY(hipStreamCreateWithFlags(&c0->stream2, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&c0->fork_event, hipEventDisableTiming));
+      if (!c0->fork_event) HIP_TRY(hipEventCreateWithFlags(&c0->fork_event, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&c0->filter_done, hipEventDisableTiming));
     }
     ls = c0->stream2;
@@ -1183,9 +1183,11 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   // the batch kernel runs on the first context's stream, after whatever the other contexts still have in flight
   for (size_t i = 1; i < n; i++)
     if (ctxs[i]->ev_valid[2]) HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev[5], 0));
+  hipEvent_t waited = nullptr;
   for (size_t i = 0; i < n; i++)
     if (ctxs[i]->pending_wait) {  // results of an earlier batch launch that nobody consumed: order after that launch
-      HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->pending_wait, 0));
+      if (ctxs[i]->pending_wait != waited) HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->pending_wait, 0));
+      waited = ctxs[i]->pending_wait;
       ctxs[i]->pending_wait = nullptr;
     }
   HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
