@@ -283,6 +283,10 @@ def main():
                          "frames_per_launch": frames_per_launch, "launch_ms": round(stage_ms[dom] * frames_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(alg[names[dom]] * frames_per_launch),
                          "note": "entropy decode is serial per 256x256 group (latency-bound, not HBM-bound); amortised over the frames of one launch" if dom == 0 else ""},
+            # the whole path against HBM: B_alg = 39.4 + bpp / 8 bytes per pixel for the three-pass formulation
+            "path_roofline": {"algorithmic_bytes_per_px": round(39.4 + bpp / 8.0, 3),
+                              "achieved_gbs_per_gpu": round((39.4 + bpp / 8.0) * mps * 1e6 / world / 1e9, 1),
+                              "frac_of_hbm_peak": round((39.4 + bpp / 8.0) * mps * 1e6 / world / 1e9 / HBM_PEAK_GBS, 4)},
             "stage_ms_per_frame": {names[s]: round(stage_ms[s], 4) for s in range(3)},  # entropy: live, launch / frames; others: isolated
             "stage_gbs": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9, 2) for s in range(3)},
             "stage_hbm_frac": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for s in range(3)},
