@@ -684,7 +684,7 @@ static uint32_t BlocksPerWG(int s) {
   static const uint8_t cy[27] = {1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1, 1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16};
   if (s == 0 || (s >= 4 && s <= 11)) {
     if (IdctMatrixForm()) return jxlhip::kIdctColsThreads / (cx[s] * 8);  // k_idct_cols: 8 * covered_x threads per varblock
-    return jxlhip::kIdctFastThreads / ((cx[s] > cy[s] ? cx[s] : cy[s]) * 8);  // k_idct_fast: max(rows, columns) threads
+    return jxlhip::IdctFastThreads(cx[s], cy[s]) / ((cx[s] > cy[s] ? cx[s] : cy[s]) * 8);  // k_idct_fast: max(rows, columns) threads
   }
   if (s >= 18 && s <= 20) return 1;                               // k_dct 64-class
   return 4;                                                       // k_special
@@ -692,9 +692,9 @@ static uint32_t BlocksPerWG(int s) {
 
 template <typename CoefT, int CX, int CY>
 static int LaunchIdctFast(JxlHipContext* c0, int s) {
-  constexpr int C = CX * 8, R = CY * 8, TB = R > C ? R : C, GROUPS = jxlhip::kIdctFastThreads / TB;
+  constexpr int C = CX * 8, R = CY * 8, TB = R > C ? R : C, GROUPS = jxlhip::IdctFastThreads(CX, CY) / TB;
   constexpr size_t lds = size_t(GROUPS) * R * (C + 1) * sizeof(float);
-  hipLaunchKernelGGL((jxlhip::k_idct_fast<CoefT, CX, CY>), dim3(c0->desc_count[s]), dim3(jxlhip::kIdctFastThreads), lds, c0->stream,
+  hipLaunchKernelGGL((jxlhip::k_idct_fast<CoefT, CX, CY>), dim3(c0->desc_count[s]), dim3(jxlhip::IdctFastThreads(CX, CY)), lds, c0->stream,
                      c0->tb_params.as<jxlhip::TransformParams>(), c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));
   return 0;
 }

@@ -987,10 +987,12 @@ __device__ __forceinline__ void FastIdct(float (&v)[N]) {
   }
 }
 
-constexpr int kIdctFastThreads = 128;
+// threads per workgroup: one wave (two varblocks, 8.4 KB of LDS) for the 32-row / 32-column class so that a workgroup fits
+// into the LDS the resident entropy workgroups leave free, two waves otherwise
+__host__ __device__ constexpr int IdctFastThreads(int cx, int cy) { return (cx >= 4 || cy >= 4) ? 64 : 128; }
 
 template <typename CoefT, int CX, int CY>
-__global__ __launch_bounds__(kIdctFastThreads) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
+__global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
   JXL_TRANSFORM_PREAMBLE();
   constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, TB = R > C ? R : C, S = C + 1, TILE = R * S;
   constexpr int LOGC = CX == 1 ? 3 : (CX == 2 ? 4 : 5);
