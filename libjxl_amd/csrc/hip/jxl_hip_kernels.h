@@ -987,9 +987,9 @@ __device__ __forceinline__ void FastIdct(float (&v)[N]) {
   }
 }
 
-// threads per workgroup: one wave (two varblocks, 8.4 KB of LDS) for the 32-row / 32-column class so that a workgroup fits
-// into the LDS the resident entropy workgroups leave free, two waves otherwise
-__host__ __device__ constexpr int IdctFastThreads(int cx, int cy) { return (cx >= 4 || cy >= 4) ? 64 : 128; }
+// threads per workgroup: one wave (e.g. two 32x32 varblocks, 8.4 KB of LDS; eight 8x8 ones), so that a workgroup fits into
+// the LDS the resident entropy workgroups leave free and a barrier stalls one wave only
+__host__ __device__ constexpr int IdctFastThreads(int cx, int cy) { return (void(cx), void(cy), 64); }
 
 template <typename CoefT, int CX, int CY>
 __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
