@@ -960,6 +960,8 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
   HIP_TRY(hipMemsetAsync(b.queue, 0, c0->batch_units * 4, c0->stream));
   b.wait_shift = c0->batch_wait_shift;
   b.prio = uint32_t(EnvInt("JXLHIP_LANES_PRIO", 0));
+  b.extra_pass_min = uint32_t(EnvInt("JXLHIP_EXTRA_PASS_MIN", 8));
+  if (b.extra_pass_min < 1) b.extra_pass_min = 1;
   b.wave_log_ls = c0->batch_wave_ls.as<uint8_t>();
   b.debug = uint32_t(EnvInt("JXLHIP_LANES_DEBUG", 0));
   b.prof = nullptr;

@@ -43,6 +43,7 @@ struct EntropyLaneBatch {
                                 // differ 8x in token count, which their byte size predicts poorly)
   const uint8_t* wave_lanes;    // per wave: populated lanes (the others idle)
   uint32_t prio;                // non-zero: the waves raise their issue priority (s_setprio 3)
+  uint32_t extra_pass_min;      // a service phase makes a further round of transitions only for at least this many lanes (>= 1)
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
   const uint8_t* wave_log_ls;   // per wave: log2 of its populated-lane capacity (lanes beyond it are idle); the wave's LDS
                                 // rows are strided by that many entries, so sparse waves take little LDS
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       for (int pass = 0; pass < 3; pass++) {
       const bool next_block = ci == 2 && started;  // the coming transition moves on to block bi + 1
       const bool go = mode == kWait && (ring_end - (bitpos >> 5)) >= 3 && (!next_block || bi + 1 < bring_end || bi + 1 >= b1);
-      if (pass && !__ballot(go)) break;
+      if (pass && uint32_t(__popcll(__ballot(go))) < B.extra_pass_min) break;
       if (go) {
         if (!started) {  // section header: histogram selector + initial rANS state
           started = true;
