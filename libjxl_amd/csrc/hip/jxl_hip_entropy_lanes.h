@@ -61,6 +61,7 @@ struct LanesLds {
 constexpr uint32_t kLanesNzRows = 96;               // nzeros line buffer [channel * 32 + column], u8
 constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 2 mirror rows (a 3-word read at slot 15 needs no wrap)
 constexpr uint32_t kLanesBlockRing = 8;             // packed block records, u32
+constexpr int kLanesTrips = 4;                      // hot trips per control check
 constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 2) * 4 + kLanesBlockRing * 4;
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
                                                    uint32_t waves, uint32_t lanes) {
@@ -241,9 +242,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, t_hot0 = 0, t_hot1 = 0, t_land = 0;
   if (B.prof) t_begin = __builtin_readcyclecounter();
   for (;;) {
-    // two hot trips consume at most 2 * 47 bits, i.e. bits of at most 4 ring words (words read beyond ring_end are
-    // stale but never consumed)
-    const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 5;
+    // a group of kLanesTrips hot trips consumes at most kLanesTrips * 47 bits (16 renormalisation + 31 extra bits each),
+    // i.e. bits of at most 2 * kLanesTrips ring words (words read beyond ring_end are stale but never consumed)
+    const bool low = mode != kDone && (ring_end - (bitpos >> 5)) < 2 * kLanesTrips + 1;
     const uint64_t runnable = __ballot(mode == kRun && !low);
     const uint64_t waiting = __ballot((mode == kWait) || low);
     if (!(waiting | runnable)) break;
@@ -378,11 +379,11 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       continue;
     }
     // =================================================================== hot trips: one coefficient token per lane each
-    n_trips += 2;
+    n_trips += kLanesTrips;
     unsigned long long th = 0;
     if (B.prof) th = __builtin_readcyclecounter();
 #pragma unroll
-    for (int rep = 0; rep < 2; rep++) {
+    for (int rep = 0; rep < kLanesTrips; rep++) {
       if (B.prof && rep == 1) {
         const unsigned long long now = __builtin_readcyclecounter();
         t_hot0 += now - th;
