@@ -851,12 +851,14 @@ static int LaunchFused(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
 // Gaborish + EPF1 (the d1.0 configuration): the row-streaming kernel, no LDS.
 static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
   const uint32_t cols = g.tiles_x * jxlhip::kFusedTW, rows = g.tiles_y * jxlhip::kFusedTH;  // upper bounds of the group
-  const uint32_t gx = ((cols + jxlhip::kRowsLanes - 1) / jxlhip::kRowsLanes + jxlhip::kRowsWaves - 1) / jxlhip::kRowsWaves;
+  const bool one_px = EnvInt("JXLHIP_FILTER_ROWS1", 0) != 0;  // measurement aid: the one-column-per-lane form
+  const uint32_t per_wave = one_px ? jxlhip::kRowsLanes : jxlhip::kRows2Cols;
+  const uint32_t gx = ((cols + per_wave - 1) / per_wave + jxlhip::kRowsWaves - 1) / jxlhip::kRowsWaves;
   const uint32_t gy = (rows + jxlhip::kRowsStrip - 1) / jxlhip::kRowsStrip;
   for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
     const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
-    hipLaunchKernelGGL(jxlhip::k_filter_rows, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0, c0->fstream,
-                       c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
+    hipLaunchKernelGGL(one_px ? jxlhip::k_filter_rows : jxlhip::k_filter_rows2, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0,
+                       c0->fstream, c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
   }
   HIP_TRY(hipGetLastError());
   return 0;
