@@ -450,6 +450,22 @@ constexpr int kRows2Cols = 120;  // output columns per wave: 128 - 2 * 4 (left h
 __device__ __forceinline__ f2 LeftOf(f2 v) { return f2{FromLeft(v.y), v.x}; }     // the columns x - 1 of the pair's columns
 __device__ __forceinline__ f2 RightOf(f2 v) { return f2{v.y, FromRight(v.x)}; }   // the columns x + 1
 __device__ __forceinline__ f2 Abs2(f2 v) { return __builtin_elementwise_abs(v); }
+// LinearToSrgb for two values: the same operations per element, the polynomials as packed FMAs
+__device__ __forceinline__ f2 LinearToSrgb2(f2 v) {
+  const f2 a = Abs2(v);
+  const f2 s = f2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)};
+  f2 yp = 7.352629620e-01f * s + 1.474205315e+00f;
+  yp = yp * s + 3.903842876e-01f;
+  yp = yp * s + 5.287254571e-03f;
+  yp = yp * s + -5.135152395e-04f;
+  f2 yq = 2.424867759e-02f * s + 9.258482155e-01f;
+  yq = yq * s + 1.340816930e+00f;
+  yq = yq * s + 3.036675394e-01f;
+  yq = yq * s + 1.004519624e-02f;
+  const f2 hi = yp * f2{__builtin_amdgcn_rcpf(yq.x), __builtin_amdgcn_rcpf(yq.y)};
+  const f2 lo = a * 12.92f;
+  return f2{copysignf(a.x > 0.0031308f ? hi.x : lo.x, v.x), copysignf(a.y > 0.0031308f ? hi.y : lo.y, v.y)};
+}
 
 __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFilterParams* params) {
   FusedFilterParams P;
@@ -485,14 +501,14 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
 #pragma unroll
     for (int c = 0; c < 3; c++) dcol[e][c] = (x + e + 23 * c) & 31;
   const f2 zero2 = f2{0.0f, 0.0f};
-  f2 p[3][3], h1[3][3], g[3][5], dh[3], dv[3];
+  f2 p[3][3], h1[3][3], g[3][4], dh[3], dv[3];  // g: Gaborish rows yg - 3 .. yg
   f2 pv_prev = zero2, dh_new = zero2;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
 #pragma unroll
     for (int k = 0; k < 3; k++) p[c][k] = h1[c][k] = zero2;
 #pragma unroll
-    for (int k = 0; k < 5; k++) g[c][k] = zero2;
+    for (int k = 0; k < 4; k++) g[c][k] = zero2;
   }
   dh[0] = dh[1] = dh[2] = dv[0] = dv[1] = dv[2] = zero2;
   const int steps = y1 - y0 + 2 * kRowsHalo;
@@ -544,8 +560,8 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
       const f2 s2 = h1[c][0] + h1[c][2];
       const f2 v = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
 #pragma unroll
-      for (int k = 0; k < 4; k++) g[c][k] = g[c][k + 1];
-      g[c][4] = v;
+      for (int k = 0; k < 3; k++) g[c][k] = g[c][k + 1];
+      g[c][3] = v;
     }
     dh[0] = dh[1];
     dh[1] = dh[2];
@@ -556,8 +572,8 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
       f2 a = zero2, b = zero2;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        a = Abs2(g[c][4] - RightOf(g[c][4])) * P.f.ch_scale[c] + a;
-        b = Abs2(g[c][3] - g[c][4]) * P.f.ch_scale[c] + b;
+        a = Abs2(g[c][3] - RightOf(g[c][3])) * P.f.ch_scale[c] + a;
+        b = Abs2(g[c][2] - g[c][3]) * P.f.ch_scale[c] + b;
       }
       dh_new = a;
       dv[2] = b;
@@ -566,7 +582,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
     const f2 ph = (dh[1] + dh[0]) + (LeftOf(dh[1]) + dh[2]) + RightOf(dh[1]);
     const f2 ph_left = LeftOf(ph);
     if (j >= 2 * kRowsHalo) {
-      f2 o[3] = {g[0][2], g[1][2], g[2][2]};
+      f2 o[3] = {g[0][1], g[1][1], g[2][1]};
       f2 nl[3], nr[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -583,9 +599,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
           f2 weight = sad[k] * inv_sig + 1.0f;
           weight = __builtin_elementwise_max(weight, zero2);
           wsum += weight;
-          const f2 n0 = k == 0 ? g[0][1] : (k == 1 ? nl[0] : (k == 2 ? nr[0] : g[0][3]));
-          const f2 n1 = k == 0 ? g[1][1] : (k == 1 ? nl[1] : (k == 2 ? nr[1] : g[1][3]));
-          const f2 n2 = k == 0 ? g[2][1] : (k == 1 ? nl[2] : (k == 2 ? nr[2] : g[2][3]));
+          const f2 n0 = k == 0 ? g[0][0] : (k == 1 ? nl[0] : (k == 2 ? nr[0] : g[0][2]));
+          const f2 n1 = k == 0 ? g[1][0] : (k == 1 ? nl[1] : (k == 2 ? nr[1] : g[1][2]));
+          const f2 n2 = k == 0 ? g[2][0] : (k == 1 ? nl[2] : (k == 2 ? nr[2] : g[2][2]));
           a0 = weight * n0 + a0;
           a1 = weight * n1 + a1;
           a2 = weight * n2 + a2;
@@ -612,9 +628,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
           f2 cg = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
           f2 cb = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
           if (!P.f.linear_output) {
-            cr = f2{LinearToSrgb(cr.x), LinearToSrgb(cr.y)};
-            cg = f2{LinearToSrgb(cg.x), LinearToSrgb(cg.y)};
-            cb = f2{LinearToSrgb(cb.x), LinearToSrgb(cb.y)};
+            cr = LinearToSrgb2(cr);
+            cg = LinearToSrgb2(cg);
+            cb = LinearToSrgb2(cb);
           }
           const uint32_t b0 = ToU8D(cr.x, di[0].x), b1 = ToU8D(cg.x, di[1].x), b2 = ToU8D(cb.x, di[2].x);
           const uint32_t b3 = ToU8D(cr.y, di[0].y), b4 = ToU8D(cg.y, di[1].y), b5 = ToU8D(cb.y, di[2].y);
