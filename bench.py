@@ -242,7 +242,7 @@ def main():
         alg = {
             "entropy (k_entropy_lanes)": info["ac_bytes"] + 6.0 * px,          # bitstream read + int16 coefficients written
             "transform (k_idct_fast/k_dct/k_special)": (6.0 + 0.4 + 12.0) * px,  # coefficients + side info read, f32 XYB written
-            "filter+colour (k_filter_rows)": (12.0 + 0.06 + 3.0) * px,           # f32 XYB + sigma read, RGB8 written
+            "filter+colour (k_filter_rows2)": (12.0 + 0.06 + 3.0) * px,           # f32 XYB + sigma read, RGB8 written
         }
         names = list(alg)
         dom = max(range(3), key=lambda s: stage_ms[s])
@@ -253,7 +253,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = ["k_entropy_lanes", "k_idct_fast<short, 4, 4>", "k_filter_rows"][dom]
+            key = ["k_entropy_lanes", "k_idct_fast<short, 4, 4>", "k_filter_rows2"][dom]
             for name, v in pmc.items():
                 if key in name and pmc.get("_frames_per_launch") == args.batch:
                     traffic = int((v["fetch_kib_per_dispatch"] + v["write_kib_per_dispatch"]) * 1024)
