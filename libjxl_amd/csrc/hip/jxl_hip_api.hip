@@ -96,6 +96,11 @@ struct JxlHipContext {
   uint32_t ups = 1, oxs = 0, oys = 0;
   Buf ups_kernel;
   bool scan_order = false;
+  // lanes: the frame's entropy stage runs on k_entropy_lanes. Single-pass frames hand the scan-order layout to the
+  // transforms (scan_order); progressive frames (lane_multi) decode every pass into its own scan-order buffer and
+  // k_merge_passes sums them into the natural layout.
+  bool lanes = false, lane_multi = false;
+  uint32_t nblocks = 0;
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
   Buf kend, block_recs, dequant_scan;
   std::vector<JxlHipVarBlock> blocks_host;  // for jxlhip_download("coeffs") of a scan-order frame
@@ -297,6 +302,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->have_frame = false;
   c->xs = d->xsize; c->ys = d->ysize; c->xb = d->xsize_blocks; c->yb = d->ysize_blocks;
   c->xg = d->xsize_groups; c->ng = d->num_groups; c->np = d->num_passes;
+  c->nblocks = d->num_blocks;
   c->xp = c->xb * 8; c->yp = c->yb * 8;
   c->ups = d->upsampling > 1 ? d->upsampling : 1;
   c->oxs = c->ups == 1 ? d->xsize : d->out_xsize;
@@ -365,8 +371,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     // histogram selector of every first-pass section: its first ceil(log2(num_histograms)) bits (dec_group.cc:594-610)
     uint32_t hb = 0;
     while ((1u << hb) < d->num_histograms) hb++;
-    c->sec_sel_host.assign(d->num_groups, 0);
-    for (uint32_t g = 0; hb && g < d->num_groups; g++) {
+    c->sec_sel_host.assign(nsec, 0);
+    for (size_t g = 0; hb && g < nsec; g++) {  // [pass * num_groups + group]
       const uint8_t* p = d->codestream + d->section_offset[g];
       const uint32_t bit0 = g == 0 ? d->first_section_bit_offset : 0;
       uint64_t v = 0;
@@ -425,8 +431,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = Upload(c, c->passes_dev, pd.data(), pd.size() * sizeof(jxlhip::PassDev)))) return r;
   HIP_TRY(hipStreamSynchronize(c->stream));  // `pd` is a local
   // ---- work buffers
+  // (progressive frames: the natural-layout buffer + one scan-order buffer per pass for the lane kernel)
   const size_t coef_bytes = size_t(d->num_groups) * 3 * 65536 * (d->coef_bits / 8);
-  if ((r = c->coeffs.Ensure(coef_bytes))) return r;
+  if ((r = c->coeffs.Ensure(coef_bytes * (d->num_passes > 1 ? d->num_passes + 1 : 1)))) return r;
   if ((r = c->errors.Ensure(size_t(d->num_groups) * 4))) return r;
   HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(d->num_groups) * 4, c->stream));  // groups outside a band stay clean
   const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
@@ -494,9 +501,32 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (size_t(d->block_ctx_lut_size) < size_t(3) * 13 * ep.nq * ep.ndc) return JXLHIP_ERR_INVALID_ARGUMENT;
   // single-pass frames whose tables fit LDS are decoded by the lane-parallel kernel into scan order
   // (its packed block records hold the block contexts in 4 bits each: the codestream allows at most 16)
-  c->scan_order = d->num_passes == 1 && EntropyKernelChoice() == 2 && LanesLdsFor(c) <= kLdsBudget && ep.num_bctx <= 16;
-  if ((r = c->kend.Ensure(size_t(d->num_blocks ? d->num_blocks : 1) * 3 * 4))) return r;
+  c->lanes = EntropyKernelChoice() == 2 && ep.num_bctx <= 16 && d->num_passes <= 8;
+  for (uint32_t p = 0; c->lanes && p < d->num_passes; p++)
+    c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64).total <= kLdsBudget;
+  c->scan_order = c->lanes && d->num_passes == 1;
+  c->lane_multi = c->lanes && d->num_passes > 1;
+  const size_t kend_per_pass = size_t(d->num_blocks ? d->num_blocks : 1) * 3;
+  if ((r = c->kend.Ensure(kend_per_pass * 4 * d->num_passes))) return r;
   ep.kend = c->kend.as<uint32_t>();
+  ep.coef_pass_base = c->lane_multi ? uint64_t(d->num_groups) * 3 * 65536 : 0;
+  ep.coef_pass_stride = uint64_t(d->num_groups) * 3 * 65536;
+  ep.kend_pass_stride = uint32_t(kend_per_pass);
+  if (c->lane_multi) {  // k_merge_passes scatters through every pass's orders: validate them here
+    static const uint8_t kind_of[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+    static const uint8_t bucket_of[27] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+    for (uint32_t p = 0; p < d->num_passes; p++)
+      for (int st = 0; st < 27; st++) {
+        if (!c->list_count[st]) continue;
+        const uint32_t size = d->dequant_size[kind_of[st]];
+        for (int ch = 0; ch < 3; ch++) {
+          const uint32_t oo = d->passes[p].order_offset[bucket_of[st] * 3 + ch];
+          if (size_t(oo) + size > d->passes[p].orders_size) return JXLHIP_ERR_INVALID_ARGUMENT;
+          for (uint32_t k = 0; k < size; k++)
+            if (d->passes[p].orders[oo + k] >= size) return JXLHIP_ERR_INVALID_ARGUMENT;
+        }
+      }
+  }
   {
     // Per varblock, everything the lane kernel's block transition needs in one word, so that it does no dependent
     // table lookups: column in the group (5 bits) | not in the group's first row (1) | log2 covered_x (3) |
@@ -1039,18 +1069,20 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     if (wpg != 1 && wpg != 2) wpg = 4;
     c0->batch_wpg = wpg;
     struct Unit {
-      uint32_t frame, sel, begin, count, min_lanes, lanes;
+      uint32_t frame, sel, pass, begin, count, min_lanes, lanes;
     };
     std::vector<Unit> units;
     std::vector<uint32_t> order;
     size_t min_total = 0, total_sections = 0;
     for (size_t i = 0; i < n; i++) {
       const JxlHipContext* c = ctxs[i];
-      const uint32_t* sz = c->sec_size_host.data();
+      for (uint32_t pass = 0; pass < c->np; pass++)
       for (uint32_t sel = 0; sel < c->ep.num_hist; sel++) {
+        const uint32_t* sz = c->sec_size_host.data() + size_t(pass) * c->ng;    // [pass * num_groups + group]
+        const uint32_t* ssel = c->sec_sel_host.data() + size_t(pass) * c->ng;
         order.clear();
         for (uint32_t g : c->group_list)
-          if (c->sec_sel_host[g] == sel || (sel == 0 && c->sec_sel_host[g] >= c->ep.num_hist)) order.push_back(g);
+          if (ssel[g] == sel || (sel == 0 && ssel[g] >= c->ep.num_hist)) order.push_back(g);
         if (order.empty()) continue;
         std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
         uint64_t total = 0;
@@ -1059,6 +1091,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
         Unit u;
         u.frame = uint32_t(i);
         u.sel = sel;
+        u.pass = pass;
         u.begin = uint32_t(list.size());
         u.count = uint32_t(order.size());
         u.min_lanes = uint32_t((total * uint64_t(spread < 100 ? 100 : spread) / 100 + longest - 1) / longest);
@@ -1096,7 +1129,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
       unit_desc.push_back(u.frame | u.sel << 16);
       unit_desc.push_back(u.begin);
       unit_desc.push_back(u.count);
-      unit_desc.push_back(0);
+      unit_desc.push_back(u.pass);
       for (uint32_t j = 0; j < wgs; j++) map.push_back(unit_index);
       for (uint32_t w = 0; w < waves; w++) {  // even split of the unit's lanes over its waves
         const uint32_t cnt = u.lanes / waves + (w < u.lanes % waves ? 1u : 0u);
@@ -1108,7 +1141,8 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     }
     for (size_t wg = 0; wg < map.size(); wg++) {  // LDS of the launch = the largest workgroup
       const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg]) * 4] & 0xFFFF];
-      size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[0], c->pass_log_alpha[0], 0, 0).wave0;
+      const uint32_t up = unit_desc[size_t(map[wg]) * 4 + 3];  // the unit's pass
+      size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[up], c->pass_log_alpha[up], 0, 0).wave0;
       for (uint32_t w = 0; w < wpg; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * wpg + w];
       lds = l > lds ? l : lds;
     }
@@ -1167,14 +1201,14 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
     if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
     if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
     if (c->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
-    if (!c->scan_order || c->coef_bits != c0->coef_bits) all_scan = false;
-    if (c->scan_order || !c->alias_lds || c->ep.num_hist != 1 || c->np != 1 || c->coef_bits != c0->coef_bits ||
+    if (!c->lanes || c->coef_bits != c0->coef_bits) all_scan = false;
+    if (c->lanes || !c->alias_lds || c->ep.num_hist != 1 || c->np != 1 || c->coef_bits != c0->coef_bits ||
         c->ng > 0xFFFF * kEntropyWPG || EntropyKernelChoice() == 0)
       all_uni = false;
   }
   if (!all_scan && !all_uni) {
     for (size_t i = 0; i < n; i++) {
-      int r = ctxs[i]->scan_order ? jxlhip_run_entropy_batch(&ctxs[i], 1) : RunEntropySingle(ctxs[i]);
+      int r = ctxs[i]->lanes ? jxlhip_run_entropy_batch(&ctxs[i], 1) : RunEntropySingle(ctxs[i]);
       if (r) return r;
     }
     return 0;
@@ -1195,11 +1229,30 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
       ctxs[i]->pending_wait = nullptr;
     }
   HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
-  if (kernel != 2)  // (the lane kernel writes every section's flag word itself)
-    for (size_t i = 0; i < n; i++) HIP_TRY(hipMemsetAsync(ctxs[i]->errors.p, 0, size_t(ctxs[i]->ng) * 4, c0->stream));
+  for (size_t i = 0; i < n; i++)  // (the lane kernel writes every section's flag word itself, unless passes share it)
+    if (kernel != 2 || ctxs[i]->np > 1) HIP_TRY(hipMemsetAsync(ctxs[i]->errors.p, 0, size_t(ctxs[i]->ng) * 4, c0->stream));
   if (kernel == 2) r = c0->coef_bits == 16 ? LaunchEntropyLanes<int16_t>(c0) : LaunchEntropyLanes<int32_t>(c0);
   else r = c0->coef_bits == 16 ? LaunchEntropyUniBatch<int16_t>(c0) : LaunchEntropyUniBatch<int32_t>(c0);
   if (r) return r;
+  if (kernel == 2)
+    for (size_t i = 0; i < n; i++) {  // progressive frames: sum the passes into the natural layout
+      const JxlHipContext* c = ctxs[i];
+      if (!c->lane_multi) continue;
+      jxlhip::MergeParams m;
+      m.coeffs = c->coeffs.p;
+      m.blocks = c->blocks.as<JxlHipVarBlock>();
+      m.passes = c->passes_dev.as<jxlhip::PassDev>();
+      m.kend = c->kend.as<uint32_t>();
+      m.pass_stride = c->ep.coef_pass_stride;
+      m.num_blocks = c->nblocks;
+      m.num_passes = c->np;
+      m.xg = c->xg;
+      m.kend_stride = c->ep.kend_pass_stride;
+      if (!m.num_blocks) continue;
+      if (c->coef_bits == 16) hipLaunchKernelGGL(jxlhip::k_merge_passes<int16_t>, dim3(m.num_blocks), dim3(64), 0, c0->stream, m);
+      else hipLaunchKernelGGL(jxlhip::k_merge_passes<int32_t>, dim3(m.num_blocks), dim3(64), 0, c0->stream, m);
+      HIP_TRY(hipGetLastError());
+    }
   HIP_TRY(hipEventRecord(c0->ev[1], c0->stream));
   c0->ev_valid[0] = true;
   if (n > 1) {
@@ -1215,7 +1268,7 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
 extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  return c->scan_order ? jxlhip_run_entropy_batch(&c, 1) : RunEntropySingle(c);
+  return c->lanes ? jxlhip_run_entropy_batch(&c, 1) : RunEntropySingle(c);
 }
 
 extern "C" {

@@ -35,7 +35,7 @@ namespace jxlhip {
 struct EntropyLaneBatch {
   const EntropyParams* params;  // one per frame of the batch (device memory)
   const uint32_t* wg_unit;      // per workgroup: its unit = the sections of one frame that use one histogram set
-  const uint4* units;           // per unit: {index into params | histogram selector << 16, first entry in `list`, entries, 0}
+  const uint4* units;           // per unit: {index into params | histogram selector << 16, first entry in `list`, entries, pass}
   const uint32_t* list;         // group (AC section) indices of every unit, largest compressed size first
   uint32_t* queue;              // per unit: next entry of its list to hand out (zeroed before the launch). A lane takes a
                                 // section, decodes it and comes back for the next one, so the lanes of a unit share its
@@ -153,7 +153,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   const uint32_t wg_desc = unit_desc.x;
   const uint32_t wg_sel = wg_desc >> 16;  // the histogram set this workgroup's sections use
   const EntropyParams& P = B.params[wg_desc & 0xFFFF];
-  const PassDev& T = P.passes[0];
+  const uint32_t pass = unit_desc.w;  // the unit's sections belong to this pass (0 unless the frame is progressive)
+  const PassDev& T = P.passes[pass];
   const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, nclusters = T.num_clusters;
   const uint32_t num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
   const uint8_t* wls = B.wave_log_ls + blockIdx.x * WPG;
@@ -209,20 +210,21 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   uint32_t b1 = 0, bi = 0, ci = 2;
   const uint4* stream4 = reinterpret_cast<const uint4*>(P.sections);
   const uint4* const rec4 = reinterpret_cast<const uint4*>(P.block_recs);
-  uint32_t* const kend_out = P.kend;
+  uint32_t* const kend_out = P.kend + size_t(pass) * P.kend_pass_stride;
   uint32_t nwords = 0, sec_size = 0, ring_end = 0, bring_end = 0, bitpos = 0, state = 0, ctx_base = 0;
   bool started = false;
   // block / channel cursor
   uint32_t info = 0, lbx = 0, lby = 0, coef_offset = 0, next_offset = 0;
+  const uint32_t sec0 = pass * P.num_groups;  // the pass's first entry in the section tables
   auto open_section = [&]() {  // cursors of section g (the nzeros line buffer needs no reset: every entry a section
                                // reads was written by an earlier block of the same section)
     bi = P.gbb[g] - 1;         // the first transition advances to the group's first block
     b1 = P.gbb[g + 1];
     bring_end = P.gbb[g] & ~3u;
-    stream4 = reinterpret_cast<const uint4*>(P.sections + P.sec_word[g]);  // 16-byte aligned (jxlhip_frame_upload)
-    sec_size = P.sec_size[g];
+    stream4 = reinterpret_cast<const uint4*>(P.sections + P.sec_word[sec0 + g]);  // 16-byte aligned (jxlhip_frame_upload)
+    sec_size = P.sec_size[sec0 + g];
     nwords = (sec_size + 3) / 4;
-    bitpos = g == 0 ? P.first_bit_offset : 0;
+    bitpos = sec0 + g == 0 ? P.first_bit_offset : 0;
     ring_end = 0;
     next_offset = 0;
     ci = 2;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   // (addr_b is kept as cbase + 1 + nnz_b with nnz_b the raw table value: the add happens where addr_b is used, so the
   // table read issued at the end of a trip is only waited for after the next trip has issued its other LDS reads)
   uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, nnz_b = 0, ctxe = 0, dptr = 0, kidx = 0;
-  CoefT* const coeffs = static_cast<CoefT*>(P.coeffs);
+  CoefT* const coeffs = static_cast<CoefT*>(P.coeffs) + P.coef_pass_base + size_t(pass) * P.coef_pass_stride;
   const uint32_t shift = T.shift;
 
   unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, t_hot0 = 0, t_hot1 = 0, t_land = 0;
@@ -288,7 +290,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           if (bi >= b1) {  // section complete (or abandoned after an error): on to the next one of the unit
             if (state != (0x13u << 16)) err |= kErrFinalState;
             if (bitpos > sec_size * 8) err |= kErrOverread;
-            P.errors[g] = (B.debug & 2) ? ntok : err;  // every section's flag word is written: the host does not clear the array
+            // every section's flag word is written (the host does not clear the array); the passes of a progressive frame
+            // share a group's word, which the host clears before the launch
+            if (P.num_passes > 1) atomicOr(P.errors + g, err);
+            else P.errors[g] = (B.debug & 2) ? ntok : err;
             ntok = 0;
             g = take_section();
             if (g == 0xFFFFFFFFu) {

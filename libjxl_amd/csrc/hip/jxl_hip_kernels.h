@@ -82,7 +82,12 @@ struct EntropyParams {
   void* coeffs;
   uint32_t* errors;
   uint32_t lds_ctx_bytes, lds_alias_bytes;
-  uint32_t* kend;  // [block * 3 + channel]: number of valid scan-order entries (k_entropy_lanes only)
+  uint32_t* kend;  // [pass][block * 3 + channel]: number of valid scan-order entries (k_entropy_lanes only)
+  // k_entropy_lanes, multi-pass frames: pass p writes its scan-order coefficients at element offset coef_pass_base +
+  // p * coef_pass_stride of `coeffs` and its kend at p * kend_pass_stride (single pass: all three are 0 / unused);
+  // k_merge_passes then sums the passes into the natural-layout buffer at offset 0
+  uint64_t coef_pass_base, coef_pass_stride;
+  uint32_t kend_pass_stride;
   // per block, for k_entropy_lanes: lbx | lby << 5 | strategy << 10 | qf bucket << 15 | dc bucket << 19 (16-byte aligned, padded)
   const uint32_t* block_recs;
 };
@@ -602,6 +607,46 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_uni(EntropyBatch B) {
     if (err && lane == 0) atomicOr(&P.errors[g], err);
   }
 #undef P
+}
+
+// ---------------------------------------------------------------------------------------------- multi-pass merge
+// Progressive frames on the lane kernel: every pass was decoded into its own scan-order buffer (its own coefficient
+// order, dec_group.cc:335-338 adds the passes' coefficients); this kernel zero-fills the natural-layout buffer the
+// transform kernels read (TransformParams::scan_order = 0) and adds each pass's valid scan prefix at its positions.
+// One 64-thread workgroup per varblock; passes are separated by barriers (positions are unique within a pass only).
+struct MergeParams {
+  void* coeffs;  // natural-layout result at element offset 0, pass p's scan-order buffer at (1 + p) * pass_stride
+  const JxlHipVarBlock* blocks;
+  const PassDev* passes;
+  const uint32_t* kend;  // [pass][block * 3 + channel]
+  uint64_t pass_stride;
+  uint32_t num_blocks, num_passes, xg, kend_stride;
+};
+template <typename CoefT>
+__global__ __launch_bounds__(64) void k_merge_passes(MergeParams M) {
+  const uint32_t b = blockIdx.x, t = threadIdx.x;
+  if (b >= M.num_blocks) return;
+  const JxlHipVarBlock vb = M.blocks[b];
+  const uint32_t st = vb.strategy, covered = 1u << c_log2_covered[st], size = covered * 64, ord = c_strategy_order[st];
+  const uint32_t g = (vb.by >> 5) * M.xg + (vb.bx >> 5);
+  CoefT* const base = static_cast<CoefT*>(M.coeffs);
+  for (uint32_t c = 0; c < 3; c++) {
+    const size_t off = (size_t(g) * 3 + c) * 65536 + vb.coef_offset;
+    CoefT* out = base + off;
+    for (uint32_t i = t; i < size; i += 64) out[i] = CoefT(0);
+    __syncthreads();
+    for (uint32_t p = 0; p < M.num_passes; p++) {
+      const CoefT* src = base + (1 + p) * M.pass_stride + off;
+      const uint16_t* order = M.passes[p].orders + M.passes[p].order_offset[ord * 3 + c];
+      const uint32_t ke0 = M.kend[size_t(p) * M.kend_stride + b * 3 + c];
+      const uint32_t ke = ke0 < size ? ke0 : size;
+      for (uint32_t k = covered + t; k < ke; k += 64) {
+        const CoefT q = src[k];
+        if (q) out[order[k]] = CoefT(out[order[k]] + q);
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- transforms
