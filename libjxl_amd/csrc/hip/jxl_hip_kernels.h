@@ -1066,6 +1066,7 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
     b_cc = P.base_b + float(P.ytob[tile]) * P.color_scale;
   }
   const uint32_t ord = c_strategy_order[strategy];
+  float llf_y = 0.0f;  // this thread's lowest-frequency coefficient of Y (threads t < CX * CY)
   float yout[R];  // this thread's column of the Y output (threads t < C)
 #pragma unroll
   for (int y = 0; y < R; y++) yout[y] = 0.0f;
@@ -1108,10 +1109,8 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
         const float* dc = P.dc + size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
         const int ky = t / CX, kx = t % CX;
         float v = LlfFromDc<CX, CY>(P, dc, ky, kx);
-        if (c != 1) {
-          const float* dcy = P.dc + size_t(1) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
-          v -= cc * LlfFromDc<CX, CY>(P, dcy, ky, kx);
-        }
+        if (c == 1) llf_y = v;  // (Y comes first)
+        else v -= cc * llf_y;
         l[ky * S + kx] = v;
       }
     }
