@@ -130,6 +130,9 @@ def main():
                          "of 256x256 groups of every frame per rank (strong scaling, no exchange between ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one frame set: entropy, then transform+filter, in sequence")
+    ap.add_argument("--three-stage", action="store_true",
+                    help="two frame sets, three concurrent launches per step: entropy(A) | transform(B) | filter+colour(A, planes of "
+                         "the previous step; option filter_async), instead of entropy(A) | transform(B) -> filter(B)")
     ap.add_argument("--chain", action="store_true",
                     help="one frame set, filter + colour of step k on a second stream under the entropy launch of step k + 1 "
                          "(option filter_async), instead of the default software pipeline over two frame sets")
@@ -167,7 +170,11 @@ def main():
         if band[0] == band[1]:
             raise SystemExit("more ranks than rows of groups: use --shard frames")
         share = (min(band[1] * 256, ysize) - band[0] * 256) / float(ysize)
-    if nsets == 2 and not args.no_share_planes:
+    three = args.three_stage and nsets == 2
+    if three:
+        for cs in sets:
+            cs[0].set_option("filter_async", 1)
+    if nsets == 2 and not args.no_share_planes and not three:  # (three-stage: both sets' planes are live at once)
         # the XYB planes of a frame only live between its transform and its filter stage, and the two sets are never in
         # those stages at the same time: set 1 keeps its planes in set 0's buffers (100 MB less per pair of 4K frames)
         for a, b in zip(sets[0], sets[1]):
@@ -189,6 +196,13 @@ def main():
         step_no[0] += 1
         ent = sets[k % nsets]
         down = sets[(k + 1) % nsets]
+        if three:
+            # three independent launches: the planes `ent` got from its transform in the previous step are filtered (on its
+            # second stream) while its next coefficients are decoded and the other set is transformed
+            J.run_filter_color_batch(ent)
+            J.run_entropy_batch(ent)
+            J.run_transform_batch(down)
+            return ent
         J.run_entropy_batch(ent)  # one launch: the per-section decoders of all frames of the set share the GPU
         J.run_transform_batch(down)      # one launch per transform kernel for the whole set
         J.run_filter_color_batch(down)   # one fused filter + colour launch
@@ -274,9 +288,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
                 xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
-                "frames_per_step_per_gpu": args.batch, "pipeline": "2 frame sets: entropy(set A) overlaps transform+filter(set B)" if nsets == 2 else
+                "frames_per_step_per_gpu": args.batch, "pipeline": ("2 frame sets, 3 concurrent launches: entropy(A) | transform(B) | filter+colour(A, previous step)" if three else
+                             "2 frame sets: entropy(set A) overlaps transform+filter(set B)") if nsets == 2 else
                 ("1 frame set: entropy and transform back to back, filter+colour of step k on a second stream under the entropy launch of step k+1" if chain else "none"),
-                "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
+                "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes and not three else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
                 ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
