@@ -333,7 +333,8 @@ def test_batched_entropy_launch(built):
     import jxlo
     J = built
     streams = [J.encode_rgb8(J.synth_image(600, 400)), J.encode_rgb8(J.synth_image(1300, 520, seed=5), distance=2.0),
-               J.encode_random(512, 300, seed=9), J.encode_rgb8(J.synth_image(64, 64, seed=3))]
+               J.encode_random(512, 300, seed=9), J.encode_rgb8(J.synth_image(64, 64, seed=3)),
+               J.encode_rgb8(J.synth_image(900, 420, seed=8), num_passes=2, num_histograms=2)]  # progressive: lanes + pass merge
     ctxs = [J.HipContext() for _ in streams]
     frames = [J.Frame(s) for s in streams]
     try:
