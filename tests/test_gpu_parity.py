@@ -197,6 +197,33 @@ def test_fallback_entropy_kernels_natural_layout(built, choice):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.parametrize("env", [{"JXLHIP_FILTER_ROWS1": "1"}, {"JXLHIP_FILTER_TILES": "1"}, {"JXLHIP_IDCT_MATRIX": "1"}])
+def test_alternate_kernel_forms_agree_with_the_oracle(built, env):
+    """The kernels the default path replaced stay selectable (one-column row filter, LDS-tile filter, matrix-form IDCT):
+    each of them has to meet the same parity bars, so they cross-check the default forms (different tilings, different
+    summation structure). The environment is read per launch; a subprocess keeps it out of the other tests."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, libjxl_amd as J, jxlo\n"
+        "for data in (J.encode_rgb8(J.synth_image(1111, 777, seed=4)), J.encode_random(520, 300, seed=6),\n"
+        "             J.encode_rgb8(J.synth_image(64, 40, seed=9), distance=2.0)):\n"
+        "    o = jxlo.Decoded(data)\n"
+        "    f = J.Frame(data); c = J.HipContext(); c.set_option('keep_filtered', 1); c.upload(f); c.run_all(); c.sync()\n"
+        "    r, flags = c.errors(); assert r == 0\n"
+        "    x = c.download('xyb_idct'); assert np.abs(x - o.planes('xyb_idct')).max() < 2e-5\n"
+        "    xs, ys = o.info['xsize'], o.info['ysize']\n"
+        "    xf = c.download('xyb_filtered')[:, :ys, :xs]; assert np.abs(xf - o.planes('xyb_filtered')[:, :, :xs]).max() < 2e-5\n"
+        "    d = np.abs(c.rgb8().astype(int) - o.rgb8.astype(int)); assert d.max() <= 1, d.max()\n"
+        "    c.close(); f.close(); o.close()\n"
+        "print('ok')\n") % (root, os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize("factor", [2, 4, 8])
 def test_upsampled_frames(built, factor):
     """Frames coded at 1/2, 1/4, 1/8 size with the upsampling flag (stage_upsampling.cc): the GPU produces the full-size
