@@ -16,6 +16,8 @@
 #ifndef JXL_HIP_FILTER_FUSED_H_
 #define JXL_HIP_FILTER_FUSED_H_
 
+#include <type_traits>
+
 #include "jxl_hip_kernels.h"
 
 namespace jxlhip {
@@ -501,17 +503,18 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
 #pragma unroll
     for (int c = 0; c < 3; c++) dcol[e][c] = (x + e + 23 * c) & 31;
   const f2 zero2 = f2{0.0f, 0.0f};
-  f2 p[3][3], h1[3][3], g[3][4], dh[3], dv[3];  // g: Gaborish rows yg - 3 .. yg
+  // sliding windows as rings of 4 rows indexed with the step's phase (the row loop is unrolled by 4): a window shift is a
+  // renaming, not register moves
+  f2 p[3][4], h1[3][4], g[3][4], dh[4], dv[4];
   f2 pv_prev = zero2, dh_new = zero2;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) p[c][k] = h1[c][k] = zero2;
-#pragma unroll
-    for (int k = 0; k < 4; k++) g[c][k] = zero2;
+    for (int k = 0; k < 4; k++) p[c][k] = h1[c][k] = g[c][k] = zero2;
   }
-  dh[0] = dh[1] = dh[2] = dv[0] = dv[1] = dv[2] = zero2;
-  const int steps = y1 - y0 + 2 * kRowsHalo;
+#pragma unroll
+  for (int k = 0; k < 4; k++) dh[k] = dv[k] = zero2;
+  const int steps = (y1 - y0 + 2 * kRowsHalo + 3) / 4 * 4;  // whole groups of 4 steps (the extra steps emit nothing)
   auto load_row = [&](int y, f2 (&dst)[3]) {
     const size_t row = size_t(MirrorI(y, ys)) * P.f.xp;
     if (paired) {
@@ -526,7 +529,10 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
   f2 nx[3], ndi[3] = {zero2, zero2, zero2};
   float nis = 0.0f;
   load_row(y0 - kRowsHalo, nx);
-  for (int j = 0; j < steps; j++) {
+  auto step = [&](auto phase, int j) {
+    constexpr int PH = decltype(phase)::value;
+    // ring slots: N = newest (written in this step), M1 / M2 / M3 = one / two / three rows older
+    constexpr int N = PH % 4, M1 = (PH + 3) % 4, M2 = (PH + 2) % 4, M3 = (PH + 1) % 4;
     const int yi = y0 - kRowsHalo + j;
     const f2 cur[3] = {nx[0], nx[1], nx[2]};
     const float is = nis;
@@ -546,43 +552,32 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      p[c][0] = p[c][1];
-      p[c][1] = p[c][2];
-      p[c][2] = cur[c];
-      h1[c][0] = h1[c][1];
-      h1[c][1] = h1[c][2];
-      h1[c][2] = LeftOf(cur[c]) + RightOf(cur[c]);
+      p[c][N] = cur[c];
+      h1[c][N] = LeftOf(cur[c]) + RightOf(cur[c]);
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const f2 m = p[c][1];
-      const f2 s1 = h1[c][1] + (p[c][0] + p[c][2]);
-      const f2 s2 = h1[c][0] + h1[c][2];
-      const f2 v = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
-#pragma unroll
-      for (int k = 0; k < 3; k++) g[c][k] = g[c][k + 1];
-      g[c][3] = v;
+      const f2 m = p[c][M1];
+      const f2 s1 = h1[c][M1] + (p[c][M2] + p[c][N]);
+      const f2 s2 = h1[c][M2] + h1[c][N];
+      g[c][N] = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
     }
-    dh[0] = dh[1];
-    dh[1] = dh[2];
-    dh[2] = dh_new;
-    dv[0] = dv[1];
-    dv[1] = dv[2];
+    dh[N] = dh_new;
     {
       f2 a = zero2, b = zero2;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        a = Abs2(g[c][3] - RightOf(g[c][3])) * P.f.ch_scale[c] + a;
-        b = Abs2(g[c][2] - g[c][3]) * P.f.ch_scale[c] + b;
+        a = Abs2(g[c][N] - RightOf(g[c][N])) * P.f.ch_scale[c] + a;
+        b = Abs2(g[c][M1] - g[c][N]) * P.f.ch_scale[c] + b;
       }
       dh_new = a;
-      dv[2] = b;
+      dv[N] = b;
     }
-    const f2 pv = (dv[1] + dv[0]) + (LeftOf(dv[1]) + dv[2]) + RightOf(dv[1]);
-    const f2 ph = (dh[1] + dh[0]) + (LeftOf(dh[1]) + dh[2]) + RightOf(dh[1]);
+    const f2 pv = (dv[M1] + dv[M2]) + (LeftOf(dv[M1]) + dv[N]) + RightOf(dv[M1]);
+    const f2 ph = (dh[M1] + dh[M2]) + (LeftOf(dh[M1]) + dh[N]) + RightOf(dh[M1]);
     const f2 ph_left = LeftOf(ph);
-    if (j >= 2 * kRowsHalo) {
-      f2 o[3] = {g[0][1], g[1][1], g[2][1]};
+    if (j >= 2 * kRowsHalo && r < y1) {
+      f2 o[3] = {g[0][M2], g[1][M2], g[2][M2]};
       f2 nl[3], nr[3];
 #pragma unroll
       for (int c = 0; c < 3; c++) {
@@ -599,9 +594,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
           f2 weight = sad[k] * inv_sig + 1.0f;
           weight = __builtin_elementwise_max(weight, zero2);
           wsum += weight;
-          const f2 n0 = k == 0 ? g[0][0] : (k == 1 ? nl[0] : (k == 2 ? nr[0] : g[0][2]));
-          const f2 n1 = k == 0 ? g[1][0] : (k == 1 ? nl[1] : (k == 2 ? nr[1] : g[1][2]));
-          const f2 n2 = k == 0 ? g[2][0] : (k == 1 ? nl[2] : (k == 2 ? nr[2] : g[2][2]));
+          const f2 n0 = k == 0 ? g[0][M3] : (k == 1 ? nl[0] : (k == 2 ? nr[0] : g[0][M1]));
+          const f2 n1 = k == 0 ? g[1][M3] : (k == 1 ? nl[1] : (k == 2 ? nr[1] : g[1][M1]));
+          const f2 n2 = k == 0 ? g[2][M3] : (k == 1 ? nl[2] : (k == 2 ? nr[2] : g[2][M1]));
           a0 = weight * n0 + a0;
           a1 = weight * n1 + a1;
           a2 = weight * n2 + a2;
@@ -655,6 +650,12 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
       }
     }
     pv_prev = pv;
+  };
+  for (int j = 0; j < steps; j += 4) {
+    step(std::integral_constant<int, 0>{}, j);
+    step(std::integral_constant<int, 1>{}, j + 1);
+    step(std::integral_constant<int, 2>{}, j + 2);
+    step(std::integral_constant<int, 3>{}, j + 3);
   }
 }
 
