@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
     const int my = MirrorI(r, ys);
     if (j + 1 < steps) {
       load_row(yi + 1, nx);
-      if (j + 1 >= 2 * kRowsHalo) {
+      if (j + 1 >= 2 * kRowsHalo && r + 1 < y1) {  // r + 1 is an output row (the padding steps of the last group of 4 are not)
         nis = sig[size_t((r + 1) >> 3) * P.f.xb];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
