@@ -4,6 +4,7 @@
  * the MI355X through include/jxl_amd_hip.h; there is no CPU pixel path behind this API. */
 #ifndef JXL_DECODE_H_
 #define JXL_DECODE_H_
+#include <jxl/cms_interface.h>
 #include <jxl/codestream_header.h>
 #include <jxl/color_encoding.h>
 #include <jxl/memory_manager.h>
@@ -24,6 +25,11 @@ typedef enum { JXL_COLOR_PROFILE_TARGET_ORIGINAL = 0, JXL_COLOR_PROFILE_TARGET_D
 typedef enum { kFrames = 0, kDC = 1, kLastPasses = 2, kPasses = 3, kDCProgressive = 4, kDCGroups = 5, kGroups = 6 } JxlProgressiveDetail;
 typedef struct JxlDecoderStruct JxlDecoder;
 typedef void (*JxlImageOutCallback)(void* opaque, size_t x, size_t y, size_t num_pixels, const void* pixels);
+/* Multi-threaded form (decode.h:1055-1085): init returns a run_opaque, run delivers pixel runs, destroy ends it. */
+typedef void* (*JxlImageOutInitCallback)(void* init_opaque, size_t num_threads, size_t num_pixels_per_thread);
+typedef void (*JxlImageOutRunCallback)(void* run_opaque, size_t thread_id, size_t x, size_t y, size_t num_pixels,
+                                       const void* pixels);
+typedef void (*JxlImageOutDestroyCallback)(void* run_opaque);
 
 JXL_EXPORT uint32_t JxlDecoderVersion(void);                                            /* decode.cc:151 */
 JXL_EXPORT JxlSignature JxlSignatureCheck(const uint8_t* buf, size_t len);              /* decode.cc:115-159 */
@@ -76,6 +82,24 @@ JXL_EXPORT JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* dec, JxlP
 JXL_EXPORT size_t JxlDecoderGetIntendedDownsamplingRatio(JxlDecoder* dec);
 JXL_EXPORT JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* dec);
 JXL_EXPORT JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* dec, const JxlBitDepth* bit_depth); /* :2994 */
+JXL_EXPORT JxlDecoderStatus JxlDecoderSetMultithreadedImageOutCallback(JxlDecoder* dec, const JxlPixelFormat* format,
+                                                                       JxlImageOutInitCallback init_callback,
+                                                                       JxlImageOutRunCallback run_callback,
+                                                                       JxlImageOutDestroyCallback destroy_callback,
+                                                                       void* init_opaque); /* decode.cc:2664-2703 */
+/* Colour management (decode.cc:2480): accepted and kept, never called (sRGB / linear sRGB output only). */
+JXL_EXPORT JxlDecoderStatus JxlDecoderSetCms(JxlDecoder* dec, JxlCmsInterface cms);
+JXL_EXPORT JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* dec, size_t index, JxlBlendInfo* blend_info);
+/* Container boxes (decode.cc:2852-2990). Box contents are handed out as stored: Brotli ("brob") boxes are not
+ * decompressed (no Brotli in this build: a decompressed view of such a box is empty). */
+JXL_EXPORT JxlDecoderStatus JxlDecoderSetBoxBuffer(JxlDecoder* dec, uint8_t* data, size_t size);
+JXL_EXPORT size_t JxlDecoderReleaseBoxBuffer(JxlDecoder* dec);
+JXL_EXPORT JxlDecoderStatus JxlDecoderGetBoxType(JxlDecoder* dec, JxlBoxType type, JXL_BOOL decompressed);
+JXL_EXPORT JxlDecoderStatus JxlDecoderGetBoxSizeRaw(const JxlDecoder* dec, uint64_t* size);
+JXL_EXPORT JxlDecoderStatus JxlDecoderGetBoxSizeContents(const JxlDecoder* dec, uint64_t* size);
+/* JPEG reconstruction (decode.cc:2821-2850) is outside this path: the buffer calls fail, the event never occurs. */
+JXL_EXPORT JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder* dec, uint8_t* data, size_t size);
+JXL_EXPORT size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder* dec);
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,15 @@ void jxlamd_frame_out_size(const JxlAmdFrame* frame, uint32_t* width_height);
 int jxlamd_frame_upload(const JxlAmdFrame* frame, JxlHipContext* ctx);
 /* Same, for a band of rows of 256x256 groups [group_row_begin, group_row_end) (see JxlHipFrameDesc); 0, 0 = whole frame. */
 int jxlamd_frame_upload_band(const JxlAmdFrame* frame, JxlHipContext* ctx, uint32_t group_row_begin, uint32_t group_row_end);
+/* Output transfer function of the frame's pixels: 0 = sRGB, 1 = linear (JxlDecoderSetOutputColorProfile); before upload. */
+void jxlamd_frame_set_linear_output(JxlAmdFrame* frame, int linear);
+/* Extra channels (alpha, ...) of the frame. jxlamd_frame_extra_pending() != 0: their data continues behind the
+ * coefficients of the AC group sections; run the entropy stage, then jxlamd_frame_finish_extra() (which reads the section
+ * end positions from the context). jxlamd_frame_extra_plane() returns channel `index` as xsize * ysize int32 samples
+ * (the frame's size), or NULL while pending / when there is no such channel. */
+int jxlamd_frame_extra_pending(const JxlAmdFrame* frame);
+int jxlamd_frame_finish_extra(JxlAmdFrame* frame, JxlHipContext* ctx);
+const int32_t* jxlamd_frame_extra_plane(const JxlAmdFrame* frame, uint32_t index);
 /* Thread-local description of the last failure of a jxlamd_* call ("" if none). */
 const char* jxlamd_last_error(void);
 #ifdef __cplusplus

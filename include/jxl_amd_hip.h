@@ -59,6 +59,16 @@ typedef struct JxlHipPassDesc {
   uint32_t orders_size;
   uint32_t order_offset[39];  /* [bucket * 3 + channel] -> first entry in `orders` */
   uint32_t shift;             /* left shift applied to this pass's coefficients */
+  /* Prefix-coded streams (dec_huffman.h:28-41; libjxl's fastest efforts) instead of rANS: per cluster
+   * prefix_offset[cluster] = first entry of its lookup table | max code length << 24 (0 = one symbol, no bits),
+   * prefix_table[first + (next max_len bits)] = code length | symbol << 8. alias / log_alpha are unused then. */
+  uint32_t use_prefix;
+  const uint32_t* prefix_table;
+  uint32_t prefix_table_size;
+  const uint32_t* prefix_offset;
+  /* LZ77 (dec_ans.h:288-353): tokens >= lz_min_symbol start a copy of lz_min_length + hybrid(lz_len_cfg) earlier values at
+   * a distance read with cluster lz_dist_ctx. lz_len_cfg is packed like uint_cfg. */
+  uint32_t lz77, lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_ctx;
 } JxlHipPassDesc;
 
 typedef struct JxlHipFrameDesc {
@@ -149,6 +159,17 @@ int jxlhip_sync(JxlHipContext* ctx);
 /* Copies the interleaved RGB8 result (row stride in bytes) to host memory; synchronous. The result has the frame's
  * size, or out_xsize x out_ysize for an upsampled frame. */
 int jxlhip_download_rgb8(JxlHipContext* ctx, uint8_t* dst, size_t stride);
+/* Output pixel format of the filter + colour stage (reference render_pipeline/stage_write.cc:266-286,334-370,548-590;
+ * call before jxlhip_frame_upload; default RGB8). data_type uses the JxlDataType values (0 = f32, 2 = u8, 3 = u16,
+ * 5 = f16), num_channels 1..4 (2 and 4 carry alpha: jxlhip_set_alpha, else opaque), bits_per_sample the depth of the
+ * unsigned types (0 = full width), big_endian swaps the bytes of multi-byte samples. RGB8 is written by every filter
+ * kernel and RGB f32 by the row-streaming one (the d1.0 configuration); other formats cost one more pass over the planes. */
+int jxlhip_set_output_format(JxlHipContext* ctx, uint32_t data_type, uint32_t num_channels, uint32_t bits_per_sample, int big_endian);
+/* Alpha plane of the image (f32 in [0, 1], xsize * ysize, host memory; copied synchronously) for 2- and 4-channel output;
+ * NULL = opaque again. */
+int jxlhip_set_alpha(JxlHipContext* ctx, const float* alpha, uint32_t xsize, uint32_t ysize);
+/* Copies the interleaved result in the format of jxlhip_set_output_format (row stride in bytes); synchronous. */
+int jxlhip_download_pixels(JxlHipContext* ctx, void* dst, size_t stride);
 /* Same for pixel rows [y_begin, y_end) only (dst receives y_end - y_begin rows): the rows a band context produced. */
 int jxlhip_download_rgb8_rows(JxlHipContext* ctx, uint8_t* dst, size_t stride, uint32_t y_begin, uint32_t y_end);
 /* Device pointer of the RGB8 result (xsize * 3 bytes per row, tightly packed). */
@@ -158,6 +179,11 @@ const uint8_t* jxlhip_rgb8_device_ptr(JxlHipContext* ctx);
  * bit2 section over-read, bit3 invalid histogram selector. Synchronous. `flags` has num_groups entries.
  * Returns JXLHIP_ERR_STREAM if any flag is set. */
 int jxlhip_get_errors(JxlHipContext* ctx, uint32_t* flags, size_t n);
+
+/* Where every AC section's coefficient stream ended: bits[pass * num_groups + group] = bit position from the section's
+ * first byte (after the entropy stage; synchronous). Sections of frames with extra channels carry Modular data behind
+ * the coefficients (reference dec_frame.cc:511-542), which the host front-end decodes from there. */
+int jxlhip_get_section_end_bits(JxlHipContext* ctx, uint32_t* bits, size_t n);
 
 /* Test/debug access to intermediates; synchronous copies to host.
  *   "coeffs"       quantised coefficients, int16 or int32 [num_groups][3][65536]

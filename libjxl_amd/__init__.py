@@ -239,7 +239,8 @@ class EncParams(ctypes.Structure):
                 ("strategy_mode", ctypes.c_int32), ("strategy_mask", ctypes.c_uint32), ("seed", ctypes.c_uint32),
                 ("max_clusters", ctypes.c_int32), ("skip_dc_smoothing", ctypes.c_int32), ("random_cmap", ctypes.c_int32),
                 ("zero_ac", ctypes.c_int32), ("num_histograms", ctypes.c_int32), ("big_coeffs", ctypes.c_int32), ("num_passes", ctypes.c_int32), ("upsampling", ctypes.c_int32), ("custom_orders", ctypes.c_int32), ("custom_bctx", ctypes.c_int32),
-                ("custom_cmap", ctypes.c_int32), ("custom_lf", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+                ("custom_cmap", ctypes.c_int32), ("custom_lf", ctypes.c_int32), ("ac_code_mode", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 1)]
 
 
 def _enc_lib():
@@ -251,6 +252,7 @@ def _enc_lib():
         pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8))
         E.jxlenc_encode_rgb8.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), pp,
                                          ctypes.POINTER(ctypes.c_size_t)]
+        E.jxlenc_encode_rgba8.argtypes = E.jxlenc_encode_rgb8.argtypes
         E.jxlenc_encode_random.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), pp,
                                            ctypes.POINTER(ctypes.c_size_t)]
         E.jxlenc_synth_image.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
@@ -291,6 +293,18 @@ def encode_rgb8(img, **kw):
     n = ctypes.c_size_t()
     r = E.jxlenc_encode_rgb8(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), ctypes.byref(out), ctypes.byref(n))
     return _finish(E, r, out, n, "jxlenc_encode_rgb8")
+
+
+def encode_rgba8(img, **kw):
+    """RGBA8 image -> VarDCT codestream with alpha as a (lossless) Modular-coded extra channel."""
+    E = _enc_lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 4
+    p = _params(**kw)
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    r = E.jxlenc_encode_rgba8(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), ctypes.byref(out), ctypes.byref(n))
+    return _finish(E, r, out, n, "jxlenc_encode_rgba8")
 
 
 def encode_random(xsize, ysize, **kw):

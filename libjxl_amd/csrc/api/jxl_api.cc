@@ -167,6 +167,15 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
     pd[p].orders_size = uint32_t(T.orders.size());
     memcpy(pd[p].order_offset, T.order_offset, sizeof(T.order_offset));
     pd[p].shift = P.fh.pass_shift[p];
+    pd[p].use_prefix = T.use_prefix ? 1 : 0;
+    pd[p].prefix_table = T.prefix_table.data();
+    pd[p].prefix_table_size = uint32_t(T.prefix_table.size());
+    pd[p].prefix_offset = T.prefix_offset.data();
+    pd[p].lz77 = T.lz77 ? 1 : 0;
+    pd[p].lz_min_symbol = T.lz_min_symbol;
+    pd[p].lz_min_length = T.lz_min_length;
+    pd[p].lz_len_cfg = T.lz_len_cfg;
+    pd[p].lz_dist_ctx = T.lz_dist_ctx;
   }
   d.passes = pd.data();
   static_assert(sizeof(jxh::VarBlock) == sizeof(JxlHipVarBlock), "varblock layout");
@@ -226,51 +235,538 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ JxlDecoder
+void jxlamd_frame_set_linear_output(JxlAmdFrame* f, int linear) {
+  if (f) f->plan.ih.linear_tf = linear != 0;
+}
+int jxlamd_frame_extra_pending(const JxlAmdFrame* f) { return f && f->plan.extra_pending ? 1 : 0; }
+int jxlamd_frame_finish_extra(JxlAmdFrame* f, JxlHipContext* ctx) {
+  g_last_error.clear();
+  if (!f || !ctx) return 1;
+  if (!f->plan.extra_pending) return 0;
+  std::vector<uint32_t> bits(f->plan.section_size.size());
+  int r = jxlhip_get_section_end_bits(ctx, bits.data(), bits.size());
+  if (r) return r;
+  try {
+    jxh::FrameParser::FinishExtraChannels(f->data, &f->plan, bits.data());
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return 2;
+  }
+  return 0;
+}
+const int32_t* jxlamd_frame_extra_plane(const JxlAmdFrame* f, uint32_t index) {
+  if (!f || f->plan.extra_pending || index >= f->plan.extra.ch.size()) return nullptr;
+  const jxh::MChannel& c = f->plan.extra.ch[index];
+  if (c.w != f->plan.dim.xsize || c.h != f->plan.dim.ysize) return nullptr;
+  return c.d.data();
+}
 }  // extern "C"
+
+namespace {
+// Growable byte buffer on the caller's JxlMemoryManager (memory_manager.h:51-65): the assembled codestream lives here.
+struct MmBytes {
+  JxlMemoryManager mm{};
+  uint8_t* p = nullptr;
+  size_t size = 0, cap = 0;
+  bool Append(const uint8_t* src, size_t n) {
+    if (size + n > cap) {
+      size_t want = cap ? cap * 2 : 4096;
+      while (want < size + n) want *= 2;
+      uint8_t* q = static_cast<uint8_t*>(mm.alloc(mm.opaque, want));
+      if (!q) return false;
+      if (size) memcpy(q, p, size);
+      if (p) mm.free(mm.opaque, p);
+      p = q;
+      cap = want;
+    }
+    if (n) memcpy(p + size, src, n);
+    size += n;
+    return true;
+  }
+  void Clear() {
+    if (p) mm.free(mm.opaque, p);
+    p = nullptr;
+    size = cap = 0;
+  }
+};
+void* DefaultAlloc(void*, size_t n) { return malloc(n); }
+void DefaultFree(void*, void* p) { free(p); }
+}  // namespace
 
 struct JxlDecoderStruct {
   JxlMemoryManager mm{};
   JxlParallelRunner runner = nullptr;
   void* runner_opaque = nullptr;
   int events = 0;
-  const uint8_t* data = nullptr;
-  size_t size = 0;
+  // ---- input (decode.cc:1574-1595): the caller's current buffer; file_pos = file offset of in[0]
+  const uint8_t* in = nullptr;
+  size_t in_size = 0, in_pos = 0;
+  uint64_t file_pos = 0;
   bool input_closed = false;
-  int stage = 0;  // 0 start, 1 after basic info, 2 after colour, 3 after frame header, 4 need buffer, 5 done image, 6 end
+  // ---- container walk (decode.cc:1639-2157)
+  int container = -1;  // -1 unknown, 0 bare codestream, 1 boxes
+  enum BoxStage { kHeader, kFtyp, kJxlpIndex, kCodestream, kSkip };
+  BoxStage box_stage = kHeader;
+  bool box_unbounded = false;
+  uint64_t box_remaining = 0, box_size_raw = 0, box_contents_size = 0;
+  char box_type[4] = {0, 0, 0, 0}, box_decoded_type[4] = {0, 0, 0, 0};
+  size_t box_count = 0;
+  bool last_codestream_seen = false, have_box = false;
+  uint32_t next_jxlp_index = 0;
+  bool decompress_boxes = false;
+  uint8_t* box_out = nullptr;
+  size_t box_out_size = 0, box_out_pos = 0;
+  bool box_out_set = false;
+  // ---- codestream
+  MmBytes cs;
+  bool cs_complete = false;  // no more codestream bytes will come
+  int stage = 0;  // 0 start, 1 after basic info, 2 after colour, 3 after frame header, 4 need buffer, 5 image done, 6 end
   bool error = false;
   jxh::ImageHeader ih;
   bool have_ih = false;
-  size_t frame_pos = 0;
   JxlAmdFrame* frame = nullptr;
   JxlHipContext* ctx = nullptr;
+  // ---- settings
+  bool keep_orientation = false, unpremul = false;
+  int want_linear = -1;  // JxlDecoderSetOutputColorProfile: -1 = as coded
+  JxlCmsInterface cms{};
+  bool have_cms = false;
+  JxlBitDepth bit_depth{JXL_BIT_DEPTH_FROM_PIXEL_FORMAT, 0, 0};
+  // ---- output
   JxlPixelFormat fmt{};
   void* out_buf = nullptr;
   size_t out_size = 0;
   JxlImageOutCallback callback = nullptr;
   void* callback_opaque = nullptr;
+  JxlImageOutInitCallback mt_init = nullptr;
+  JxlImageOutRunCallback mt_run = nullptr;
+  JxlImageOutDestroyCallback mt_destroy = nullptr;
+  void* mt_init_opaque = nullptr;
   bool have_out = false;
+  struct ExtraOut {
+    JxlPixelFormat fmt;
+    void* buf;
+    size_t size;
+  };
+  std::vector<std::pair<uint32_t, ExtraOut>> extra_out;
 };
 
 namespace {
+uint16_t F32ToF16(float f) {  // round to nearest even; overflow to infinity, denormals kept
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7FFFFFFFu;
+  if (u >= 0x7F800000u) return uint16_t(sign | 0x7C00u | (u > 0x7F800000u ? 0x200u : 0));
+  if (u >= 0x477FF000u) return uint16_t(sign | 0x7C00u);
+  if (u < 0x38800000u) {  // denormal half
+    if (u < 0x33000000u) return uint16_t(sign);
+    const uint32_t shift = 126 - (u >> 23), m = (u & 0x7FFFFFu) | 0x800000u;
+    const uint32_t r = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    return uint16_t(sign | (r + ((rem > half || (rem == half && (r & 1))) ? 1 : 0)));
+  }
+  const uint32_t v = u - 0x38000000u, r = v >> 13, rem = v & 0x1FFFu;
+  return uint16_t(sign | (r + ((rem > 0x1000u || (rem == 0x1000u && (r & 1))) ? 1 : 0)));
+}
+size_t SampleBytes(JxlDataType t) { return t == JXL_TYPE_UINT8 ? 1 : (t == JXL_TYPE_FLOAT ? 4 : 2); }
+bool KnownType(JxlDataType t) { return t == JXL_TYPE_UINT8 || t == JXL_TYPE_UINT16 || t == JXL_TYPE_FLOAT16 || t == JXL_TYPE_FLOAT; }
 size_t RowStride(const JxlPixelFormat& f, size_t xsize) {
-  size_t bytes = f.data_type == JXL_TYPE_UINT8 ? 1 : f.data_type == JXL_TYPE_UINT16 || f.data_type == JXL_TYPE_FLOAT16 ? 2 : 4;
-  size_t stride = xsize * f.num_channels * bytes;
+  size_t stride = xsize * f.num_channels * SampleBytes(f.data_type);
   if (f.align > 1) stride = (stride + f.align - 1) / f.align * f.align;
   return stride;
 }
+bool IsBigEndian(const JxlPixelFormat& f) { return f.endianness == JXL_BIG_ENDIAN; }  // (the hosts of this library are little endian)
 void ResetState(JxlDecoder* d) {
   if (d->frame) jxlamd_frame_free(d->frame);
   d->frame = nullptr;
   d->events = 0;
-  d->data = nullptr;
-  d->size = 0;
+  d->in = nullptr;
+  d->in_size = d->in_pos = 0;
+  d->file_pos = 0;
   d->input_closed = false;
+  d->container = -1;
+  d->box_stage = JxlDecoder::kHeader;
+  d->box_unbounded = false;
+  d->box_remaining = 0;
+  d->box_count = 0;
+  d->last_codestream_seen = d->have_box = false;
+  d->next_jxlp_index = 0;
+  d->box_out = nullptr;
+  d->box_out_set = false;
+  d->cs.size = 0;
+  d->cs_complete = false;
   d->stage = 0;
   d->error = false;
   d->have_ih = false;
   d->have_out = false;
   d->out_buf = nullptr;
   d->callback = nullptr;
+  d->mt_run = nullptr;
+  d->extra_out.clear();
+  d->want_linear = -1;
+  d->bit_depth = JxlBitDepth{JXL_BIT_DEPTH_FROM_PIXEL_FORMAT, 0, 0};
+}
+JxlDecoderStatus Fail(JxlDecoder* d, const std::string& why) {
+  g_last_error = why;
+  d->error = true;
+  return JXL_DEC_ERROR;
+}
+uint32_t Be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+
+// Input step (container walk). Returns: 0 = consumed something (or changed state), 1 = nothing more can be done with the
+// bytes at hand, 2 = event in *ev, 3 = error (sticky).
+int StepInput(JxlDecoder* d, JxlDecoderStatus* ev) {
+  const uint8_t* in = d->in ? d->in + d->in_pos : nullptr;
+  size_t avail = d->in ? d->in_size - d->in_pos : 0;
+  auto advance = [&](size_t n) {
+    d->in_pos += n;
+    in += n;
+    avail -= n;
+  };
+  if (d->container < 0) {
+    if (!d->in) return 1;
+    const JxlSignature sig = JxlSignatureCheck(in, avail);
+    if (sig == JXL_SIG_INVALID) {
+      *ev = Fail(d, "invalid signature");
+      return 3;
+    }
+    if (sig == JXL_SIG_NOT_ENOUGH_BYTES) return 1;
+    d->container = sig == JXL_SIG_CONTAINER ? 1 : 0;
+    return 0;
+  }
+  if (d->container == 0) {  // bare codestream: every byte belongs to it
+    if (d->cs_complete || !avail) return 1;
+    if (!d->cs.Append(in, avail)) {
+      *ev = Fail(d, "out of memory");
+      return 3;
+    }
+    advance(avail);
+    return 0;
+  }
+  switch (d->box_stage) {
+    case JxlDecoder::kHeader: {
+      if (avail < 8) return 1;
+      uint64_t bsize = Be32(in);
+      size_t hdr = 8;
+      if (bsize == 1) {
+        if (avail < 16) return 1;
+        bsize = (uint64_t(Be32(in + 8)) << 32) | Be32(in + 12);
+        hdr = 16;
+      }
+      if (bsize != 0 && bsize < hdr) {
+        *ev = Fail(d, "invalid box size");
+        return 3;
+      }
+      const bool brob = !memcmp(in + 4, "brob", 4);
+      if (brob && avail < hdr + 4) return 1;
+      memcpy(d->box_type, in + 4, 4);
+      memcpy(d->box_decoded_type, brob ? in + hdr : in + 4, 4);
+      d->box_count++;
+      if (d->box_count == 1 && memcmp(d->box_type, "JXL ", 4)) {
+        *ev = Fail(d, "the first box must be the signature box");
+        return 3;
+      }
+      if ((d->box_count == 2) != !memcmp(d->box_type, "ftyp", 4)) {
+        *ev = Fail(d, "the ftyp box must come second");
+        return 3;
+      }
+      d->box_unbounded = bsize == 0;
+      d->box_size_raw = bsize;
+      d->box_contents_size = bsize ? bsize - hdr : 0;
+      d->box_remaining = d->box_contents_size;
+      d->have_box = true;
+      d->box_out_set = false;
+      d->box_out = nullptr;
+      advance(hdr);
+      if (!memcmp(d->box_type, "ftyp", 4)) d->box_stage = JxlDecoder::kFtyp;
+      else if (!memcmp(d->box_type, "jxlc", 4)) {
+        if (d->last_codestream_seen) {
+          *ev = Fail(d, "there can only be one jxlc box");
+          return 3;
+        }
+        d->last_codestream_seen = true;
+        d->box_stage = JxlDecoder::kCodestream;
+      } else if (!memcmp(d->box_type, "jxlp", 4)) {
+        if (d->last_codestream_seen) {
+          *ev = Fail(d, "cannot have a jxlp box after the last one");
+          return 3;
+        }
+        d->box_stage = JxlDecoder::kJxlpIndex;
+      } else {
+        d->box_stage = JxlDecoder::kSkip;
+      }
+      if (d->events & JXL_DEC_BOX) {
+        *ev = JXL_DEC_BOX;
+        return 2;
+      }
+      return 0;
+    }
+    case JxlDecoder::kFtyp: {
+      if (d->box_contents_size < 12 && !d->box_unbounded) {
+        *ev = Fail(d, "file type box too small");
+        return 3;
+      }
+      if (avail < 8) return 1;
+      if (memcmp(in, "jxl ", 4) || Be32(in + 4) > 1) {
+        *ev = Fail(d, "unknown file type brand / version");
+        return 3;
+      }
+      d->box_stage = JxlDecoder::kSkip;  // (the 8 bytes stay part of the contents a box buffer receives)
+      return 0;
+    }
+    case JxlDecoder::kJxlpIndex: {
+      if (!d->box_unbounded && d->box_contents_size < 4) {
+        *ev = Fail(d, "jxlp box too small to contain its index");
+        return 3;
+      }
+      if (avail < 4) return 1;
+      const uint32_t index = Be32(in);
+      if ((index & 0x7FFFFFFFu) != d->next_jxlp_index) {
+        *ev = Fail(d, "unsupported: jxlp boxes out of order");
+        return 3;
+      }
+      d->next_jxlp_index++;
+      if (index & 0x80000000u) d->last_codestream_seen = true;
+      advance(4);
+      if (!d->box_unbounded) d->box_remaining -= 4;
+      d->box_stage = JxlDecoder::kCodestream;
+      return 0;
+    }
+    case JxlDecoder::kCodestream:
+    case JxlDecoder::kSkip: {
+      const bool to_cs = d->box_stage == JxlDecoder::kCodestream;
+      if (!d->box_unbounded && d->box_remaining == 0) {
+        if (to_cs && d->last_codestream_seen) d->cs_complete = true;
+        d->box_stage = JxlDecoder::kHeader;
+        d->have_box = false;
+        return 0;
+      }
+      if (!avail) {
+        if (d->box_unbounded && d->input_closed) {  // an unbounded box ends with the file
+          if (to_cs && d->last_codestream_seen) d->cs_complete = true;
+          d->box_unbounded = false;
+          d->box_remaining = 0;
+          return 0;
+        }
+        return 1;
+      }
+      size_t n = d->box_unbounded ? avail : size_t(std::min<uint64_t>(avail, d->box_remaining));
+      if (to_cs) {
+        if (!d->cs.Append(in, n)) {
+          *ev = Fail(d, "out of memory");
+          return 3;
+        }
+      } else if (d->box_out_set) {
+        // contents as stored; a Brotli box asked for decompressed has no contents here (decode.h:262-300, no Brotli)
+        const bool hidden = d->decompress_boxes && !memcmp(d->box_type, "brob", 4);
+        if (!hidden) {
+          const size_t room = d->box_out_size - d->box_out_pos;
+          if (room == 0) {
+            *ev = JXL_DEC_BOX_NEED_MORE_OUTPUT;
+            return 2;
+          }
+          n = std::min(n, room);
+          memcpy(d->box_out + d->box_out_pos, in, n);
+          d->box_out_pos += n;
+        }
+      }
+      advance(n);
+      if (!d->box_unbounded) d->box_remaining -= n;
+      return 0;
+    }
+  }
+  return 1;
+}
+
+// How the requested pixel format maps on the device writer.
+struct OutFormat {
+  uint32_t type, nc, bits;
+  int big_endian;
+};
+OutFormat MapFormat(const JxlDecoder* d, const JxlPixelFormat& f) {
+  OutFormat o;
+  o.type = uint32_t(f.data_type);
+  o.nc = f.num_channels;
+  o.bits = f.data_type == JXL_TYPE_UINT8 ? 8 : 16;
+  if (f.data_type == JXL_TYPE_UINT8 || f.data_type == JXL_TYPE_UINT16) {
+    if (d->bit_depth.type == JXL_BIT_DEPTH_FROM_CODESTREAM) o.bits = std::min<uint32_t>(d->ih.bits, o.bits);
+    else if (d->bit_depth.type == JXL_BIT_DEPTH_CUSTOM) o.bits = d->bit_depth.bits_per_sample;
+  }
+  o.big_endian = IsBigEndian(f) ? 1 : 0;
+  return o;
+}
+
+// Host-side conversion of one Modular-coded extra channel (integer samples) to the caller's sample type
+// (dec_frame.cc:511-542 hands these channels to the same stage_write.cc conversions; they never touch the GPU stages).
+void StoreExtraRow(const int32_t* src, size_t xs, uint32_t ch_bits, const JxlPixelFormat& f, uint32_t out_bits, uint8_t* dst) {
+  const float inv = 1.0f / float((uint64_t(1) << ch_bits) - 1);
+  for (size_t x = 0; x < xs; x++) {
+    const float v = float(src[x]) * inv;
+    if (f.data_type == JXL_TYPE_FLOAT) {
+      uint32_t u;
+      memcpy(&u, &v, 4);
+      if (IsBigEndian(f)) u = __builtin_bswap32(u);
+      memcpy(dst + x * 4, &u, 4);
+    } else if (f.data_type == JXL_TYPE_FLOAT16) {
+      uint16_t h = F32ToF16(v);
+      if (IsBigEndian(f)) h = uint16_t((h << 8) | (h >> 8));
+      memcpy(dst + x * 2, &h, 2);
+    } else {
+      const float mul = float((1u << out_bits) - 1u);
+      const float t = std::min(std::max(v * mul, 0.0f), mul);
+      const uint32_t u = uint32_t(std::nearbyint(t));
+      if (f.data_type == JXL_TYPE_UINT8) dst[x] = uint8_t(u);
+      else {
+        uint16_t h = uint16_t(u);
+        if (IsBigEndian(f)) h = uint16_t((h << 8) | (h >> 8));
+        memcpy(dst + x * 2, &h, 2);
+      }
+    }
+  }
+}
+
+JxlDecoderStatus DecodePixels(JxlDecoder* d) {
+  if (!d->ctx) {
+    if (jxlhip_device_count() <= 0) return Fail(d, "no HIP device: libjxl_amd has no CPU decode path");
+    const char* dev = getenv("JXLHIP_DEVICE");
+    int r = jxlhip_ctx_create(dev ? atoi(dev) : 0, &d->ctx);
+    if (r) return Fail(d, "jxlhip_ctx_create failed (" + std::to_string(r) + ")");
+  }
+  const jxh::FramePlan& P = d->frame->plan;
+  if (!d->keep_orientation && d->ih.orientation != 1) return Fail(d, "unsupported: undoing a non-identity orientation");
+  const OutFormat of = MapFormat(d, d->fmt);
+  int alpha_ec = -1;
+  for (size_t e = 0; e < d->ih.extra.size(); e++)
+    if (d->ih.extra[e].type == 0) {
+      alpha_ec = int(e);
+      break;
+    }
+  const bool want_alpha = (of.nc == 2 || of.nc == 4) && alpha_ec >= 0;
+  if (want_alpha && d->unpremul && d->ih.extra[alpha_ec].alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
+  jxlamd_frame_set_linear_output(d->frame, d->want_linear >= 0 ? d->want_linear : (P.ih.linear_tf ? 1 : 0));
+  int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
+  if (!r) r = jxlhip_set_alpha(d->ctx, nullptr, 0, 0);
+  if (!r) r = jxlamd_frame_upload(d->frame, d->ctx);
+  if (!r) r = jxlhip_run_entropy(d->ctx);
+  std::vector<uint32_t> flags(P.dim.num_groups);
+  if (!r) r = jxlhip_get_errors(d->ctx, flags.data(), flags.size());
+  if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
+  const bool need_extra = want_alpha || !d->extra_out.empty();
+  if (need_extra && jxlamd_frame_extra_pending(d->frame)) {
+    r = jxlamd_frame_finish_extra(d->frame, d->ctx);
+    if (r) return Fail(d, "extra channels: " + g_last_error);
+  }
+  uint32_t out_wh[2];
+  jxlamd_frame_out_size(d->frame, out_wh);
+  const size_t xs = out_wh[0], ys = out_wh[1];
+  if (want_alpha) {
+    const int32_t* a = jxlamd_frame_extra_plane(d->frame, uint32_t(alpha_ec));
+    if (!a) return Fail(d, "alpha channel unavailable");
+    std::vector<float> af(xs * ys);
+    const float inv = 1.0f / float((uint64_t(1) << d->ih.extra[alpha_ec].bits) - 1);
+    for (size_t i = 0; i < xs * ys; i++) af[i] = float(a[i]) * inv;
+    r = jxlhip_set_alpha(d->ctx, af.data(), uint32_t(xs), uint32_t(ys));
+    if (r) return Fail(d, "jxlhip_set_alpha failed");
+  }
+  r = jxlhip_run_transform(d->ctx);
+  if (!r) r = jxlhip_run_filter_color(d->ctx);
+  if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
+  const size_t bpp = of.nc * SampleBytes(d->fmt.data_type);
+  if (d->out_buf) {
+    r = jxlhip_download_pixels(d->ctx, d->out_buf, RowStride(d->fmt, xs));
+    if (r) return Fail(d, "download failed");
+  } else {
+    std::vector<uint8_t> px(xs * ys * bpp);
+    r = jxlhip_download_pixels(d->ctx, px.data(), xs * bpp);
+    if (r) return Fail(d, "download failed");
+    void* run_opaque = nullptr;
+    if (d->mt_run) {
+      run_opaque = d->mt_init(d->mt_init_opaque, 1, xs);
+      if (!run_opaque) return Fail(d, "image out init callback failed");
+    }
+    for (size_t y = 0; y < ys; y++) {
+      if (d->mt_run) d->mt_run(run_opaque, 0, 0, y, xs, px.data() + y * xs * bpp);
+      else d->callback(d->callback_opaque, 0, y, xs, px.data() + y * xs * bpp);
+    }
+    if (d->mt_run && d->mt_destroy) d->mt_destroy(run_opaque);
+  }
+  for (const auto& eo : d->extra_out) {
+    const int32_t* p = jxlamd_frame_extra_plane(d->frame, eo.first);
+    if (!p) return Fail(d, "extra channel unavailable");
+    const JxlPixelFormat& f = eo.second.fmt;
+    const size_t stride = RowStride(f, xs);
+    uint32_t bits = f.data_type == JXL_TYPE_UINT8 ? 8 : 16;
+    if (d->bit_depth.type == JXL_BIT_DEPTH_FROM_CODESTREAM) bits = std::min(bits, d->ih.extra[eo.first].bits);
+    else if (d->bit_depth.type == JXL_BIT_DEPTH_CUSTOM) bits = d->bit_depth.bits_per_sample;
+    for (size_t y = 0; y < ys; y++)
+      StoreExtraRow(p + y * xs, xs, d->ih.extra[eo.first].bits, f, bits, static_cast<uint8_t*>(eo.second.buf) + y * stride);
+  }
+  return JXL_DEC_FULL_IMAGE;
+}
+
+// Codestream step. Returns 0 = needs more codestream bytes, 1 = finished, 2 = event / status in *ev.
+int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
+  if (d->stage == 0) {
+    if (d->cs.size < 2) return 0;
+    try {
+      jxh::FrameParser parser(d->cs.p, d->cs.size);
+      parser.ParseImageHeader(&d->ih);
+      d->have_ih = true;
+    } catch (const std::exception& e) {
+      const std::string w = e.what();
+      if (!d->cs_complete && w.find("truncated") != std::string::npos) return 0;
+      *ev = Fail(d, w);
+      return 2;
+    }
+    d->stage = 1;
+    if (d->events & JXL_DEC_BASIC_INFO) {
+      *ev = JXL_DEC_BASIC_INFO;
+      return 2;
+    }
+  }
+  if (d->stage == 1) {
+    d->stage = 2;
+    if (d->events & JXL_DEC_COLOR_ENCODING) {
+      *ev = JXL_DEC_COLOR_ENCODING;
+      return 2;
+    }
+  }
+  if (d->stage == 2) {
+    if (!(d->events & (JXL_DEC_FRAME | JXL_DEC_FULL_IMAGE))) {
+      d->stage = 6;
+      return 1;
+    }
+    int r = jxlamd_frame_parse(d->cs.p, d->cs.size, d->runner, d->runner_opaque, &d->frame);
+    if (r) {
+      const std::string w = g_last_error;
+      if (!d->cs_complete && w.find("truncated") != std::string::npos) return 0;
+      *ev = Fail(d, w);
+      return 2;
+    }
+    d->stage = 3;
+    if (d->events & JXL_DEC_FRAME) {
+      *ev = JXL_DEC_FRAME;
+      return 2;
+    }
+  }
+  if (d->stage == 3) {
+    if (!(d->events & JXL_DEC_FULL_IMAGE)) {
+      d->stage = 6;
+      return 1;
+    }
+    d->stage = 4;
+  }
+  if (d->stage == 4) {
+    if (!d->have_out) {
+      *ev = JXL_DEC_NEED_IMAGE_OUT_BUFFER;
+      return 2;
+    }
+    *ev = DecodePixels(d);
+    if (*ev == JXL_DEC_FULL_IMAGE) d->stage = 5;
+    return 2;
+  }
+  d->stage = 6;
+  return 1;
 }
 }  // namespace
 
@@ -290,11 +786,18 @@ JxlSignature JxlSignatureCheck(const uint8_t* buf, size_t len) {
   return len < 12 ? JXL_SIG_NOT_ENOUGH_BYTES : JXL_SIG_CONTAINER;
 }
 
+// decode.cc:844-868: the decoder object and its byte buffers come from the caller's memory manager.
 JxlDecoder* JxlDecoderCreate(const JxlMemoryManager* memory_manager) {
-  if (memory_manager && (!memory_manager->alloc != !memory_manager->free)) return nullptr;
-  JxlDecoder* d = new (std::nothrow) JxlDecoder;
-  if (!d) return nullptr;
-  if (memory_manager) d->mm = *memory_manager;
+  JxlMemoryManager mm{nullptr, DefaultAlloc, DefaultFree};
+  if (memory_manager) {
+    if (!memory_manager->alloc != !memory_manager->free) return nullptr;
+    if (memory_manager->alloc) mm = *memory_manager;
+  }
+  void* mem = mm.alloc(mm.opaque, sizeof(JxlDecoder));
+  if (!mem) return nullptr;
+  JxlDecoder* d = new (mem) JxlDecoder;
+  d->mm = mm;
+  d->cs.mm = mm;
   return d;
 }
 void JxlDecoderReset(JxlDecoder* d) { ResetState(d); }
@@ -302,16 +805,23 @@ void JxlDecoderDestroy(JxlDecoder* d) {
   if (!d) return;
   ResetState(d);
   if (d->ctx) jxlhip_ctx_destroy(d->ctx);
-  delete d;
+  d->cs.Clear();
+  const JxlMemoryManager mm = d->mm;
+  d->~JxlDecoderStruct();
+  mm.free(mm.opaque, d);
 }
 void JxlDecoderRewind(JxlDecoder* d) {
-  int ev = d->events;
-  JxlParallelRunner r = d->runner;
+  const int ev = d->events;
+  const JxlParallelRunner r = d->runner;
   void* ro = d->runner_opaque;
+  const bool ko = d->keep_orientation, up = d->unpremul, db = d->decompress_boxes;
   ResetState(d);
   d->events = ev;
   d->runner = r;
   d->runner_opaque = ro;
+  d->keep_orientation = ko;
+  d->unpremul = up;
+  d->decompress_boxes = db;
 }
 void JxlDecoderSkipFrames(JxlDecoder*, size_t) {}
 JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* d) { return d->stage >= 3 && d->stage < 5 ? (d->stage = 6, JXL_DEC_SUCCESS) : JXL_DEC_ERROR; }
@@ -329,154 +839,131 @@ JxlDecoderStatus JxlDecoderSubscribeEvents(JxlDecoder* d, int events) {
   d->events = events;
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderSetKeepOrientation(JxlDecoder* d, JXL_BOOL) { return d->stage == 0 ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* d, JXL_BOOL) { return d->stage == 0 ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
+JxlDecoderStatus JxlDecoderSetKeepOrientation(JxlDecoder* d, JXL_BOOL keep) {
+  if (d->stage != 0) return JXL_DEC_ERROR;
+  d->keep_orientation = keep != 0;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* d, JXL_BOOL unpremul) {
+  if (d->stage != 0) return JXL_DEC_ERROR;
+  d->unpremul = unpremul != 0;
+  return JXL_DEC_SUCCESS;
+}
 JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* d, JXL_BOOL) { return d->stage == 0 ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
 JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL) { return d->stage == 0 ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
 
 JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t size) {
-  if (d->data) return JXL_DEC_ERROR;
-  d->data = data;
-  d->size = size;
+  if (d->in) return JXL_DEC_ERROR;
+  d->in = data;
+  d->in_size = size;
+  d->in_pos = 0;
   return JXL_DEC_SUCCESS;
 }
+// decode.cc:1586: the unprocessed tail of the buffer (the caller re-supplies it with the next input).
 size_t JxlDecoderReleaseInput(JxlDecoder* d) {
-  size_t remaining = 0;
-  if (d->data && d->stage < 6) {
-    size_t used = d->frame ? d->frame->plan.frame_end : 0;
-    remaining = d->stage >= 5 ? d->size - std::min(d->size, used) : d->size;
+  if (!d->in) return 0;
+  size_t remaining = d->in_size - d->in_pos;
+  if (d->container == 0 && d->frame && d->stage >= 5) {
+    // bare codestream: bytes behind the last frame were copied along but are not part of it
+    const uint64_t cs_end = d->frame->plan.frame_end;
+    const uint64_t given = d->file_pos + d->in_pos;
+    if (given > cs_end) remaining = size_t(std::min<uint64_t>(d->in_size, given - cs_end));
   }
-  d->data = nullptr;
-  d->size = 0;
+  d->file_pos += d->in_size - remaining;
+  d->in = nullptr;
+  d->in_size = d->in_pos = 0;
   return remaining;
 }
 void JxlDecoderCloseInput(JxlDecoder* d) { d->input_closed = true; }
 
-static JxlDecoderStatus Fail(JxlDecoder* d, const std::string& why) {
-  g_last_error = why;
-  d->error = true;
-  return JXL_DEC_ERROR;
-}
-
+// decode.cc:2159: events in stream order; input is consumed box by box, the codestream it carries is assembled and
+// decoded as soon as a unit (headers, whole frame) is complete.
 JxlDecoderStatus JxlDecoderProcessInput(JxlDecoder* d) {
   if (d->error) return JXL_DEC_ERROR;
-  if (!d->data) return d->stage == 6 ? JXL_DEC_SUCCESS : JXL_DEC_NEED_MORE_INPUT;
-  if (d->stage == 0) {
-    JxlSignature sig = JxlSignatureCheck(d->data, d->size);
-    if (sig == JXL_SIG_INVALID) return Fail(d, "invalid signature");
-    if (sig == JXL_SIG_NOT_ENOUGH_BYTES) return d->input_closed ? Fail(d, "truncated") : JXL_DEC_NEED_MORE_INPUT;
-    try {
-      jxh::FrameParser parser(d->data, d->size);
-      d->frame_pos = parser.ParseImageHeader(&d->ih);
-      d->have_ih = true;
-    } catch (const std::exception& e) {
-      std::string w = e.what();
-      if (!d->input_closed && w.find("truncated") != std::string::npos) return JXL_DEC_NEED_MORE_INPUT;
-      return Fail(d, w);
+  for (;;) {
+    JxlDecoderStatus ev = JXL_DEC_SUCCESS;
+    bool cs_done = d->stage == 6;
+    if (!cs_done && d->cs.size) {
+      const int c = StepCodestream(d, &ev);
+      if (c == 2) return ev;
+      cs_done = c == 1;
     }
-    d->stage = 1;
-    if (d->events & JXL_DEC_BASIC_INFO) return JXL_DEC_BASIC_INFO;
+    if (cs_done && (d->container == 0 || !(d->events & JXL_DEC_BOX))) return JXL_DEC_SUCCESS;
+    const int r = StepInput(d, &ev);
+    if (r == 2 || r == 3) return ev;
+    if (r == 0) continue;
+    // nothing more to do with the bytes at hand
+    if (d->container == 0 && d->input_closed && !d->cs_complete && d->cs.size) {
+      d->cs_complete = true;  // a bare codestream ends with the input
+      continue;
+    }
+    if (cs_done) {
+      // (decode.cc:1770-1790) at a box boundary: success once the caller closed the input, else more boxes may follow
+      if (d->input_closed || d->box_stage != JxlDecoder::kHeader) return d->input_closed ? JXL_DEC_SUCCESS : JXL_DEC_NEED_MORE_INPUT;
+      return JXL_DEC_NEED_MORE_INPUT;
+    }
+    if (d->input_closed && (!d->in || d->in_pos == d->in_size)) {
+      if (d->cs_complete || d->container < 0 || !d->cs.size) return Fail(d, "truncated input");
+      d->cs_complete = true;  // let the codestream step report what is missing
+      continue;
+    }
+    return JXL_DEC_NEED_MORE_INPUT;
   }
-  if (d->stage == 1) {
-    d->stage = 2;
-    if (d->events & JXL_DEC_COLOR_ENCODING) return JXL_DEC_COLOR_ENCODING;
-  }
-  if (d->stage == 2) {
-    if (!(d->events & (JXL_DEC_FRAME | JXL_DEC_FULL_IMAGE))) {
-      d->stage = 6;
-      return JXL_DEC_SUCCESS;
-    }
-    int r = jxlamd_frame_parse(d->data, d->size, d->runner, d->runner_opaque, &d->frame);
-    if (r) {
-      std::string w = g_last_error;
-      if (!d->input_closed && w.find("truncated") != std::string::npos) return JXL_DEC_NEED_MORE_INPUT;
-      return Fail(d, w);
-    }
-    d->stage = 3;
-    if (d->events & JXL_DEC_FRAME) return JXL_DEC_FRAME;
-  }
-  if (d->stage == 3) {
-    if (!(d->events & JXL_DEC_FULL_IMAGE)) {
-      d->stage = 6;
-      return JXL_DEC_SUCCESS;
-    }
-    d->stage = 4;
-  }
-  if (d->stage == 4) {
-    if (!d->have_out) return JXL_DEC_NEED_IMAGE_OUT_BUFFER;
-    if (!d->ctx) {
-      if (jxlhip_device_count() <= 0) return Fail(d, "no HIP device: libjxl_amd has no CPU decode path");
-      const char* dev = getenv("JXLHIP_DEVICE");
-      int r = jxlhip_ctx_create(dev ? atoi(dev) : 0, &d->ctx);
-      if (r) return Fail(d, "jxlhip_ctx_create failed (" + std::to_string(r) + ")");
-    }
-    int r = jxlamd_frame_upload(d->frame, d->ctx);
-    if (!r) r = jxlhip_run_all(d->ctx);
-    std::vector<uint32_t> flags(d->frame->plan.dim.num_groups);
-    if (!r) r = jxlhip_get_errors(d->ctx, flags.data(), flags.size());
-    if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
-    uint32_t out_wh[2];
-    jxlamd_frame_out_size(d->frame, out_wh);
-    const size_t xs = out_wh[0], ys = out_wh[1];
-    const uint32_t nc = d->fmt.num_channels;
-    std::vector<uint8_t> rgb;
-    uint8_t* dst = static_cast<uint8_t*>(d->out_buf);
-    const size_t stride = RowStride(d->fmt, xs);
-    if (nc == 3 && !d->callback) {
-      r = jxlhip_download_rgb8(d->ctx, dst, stride);
-      if (r) return Fail(d, "download failed");
-    } else {
-      rgb.resize(xs * ys * 3);
-      r = jxlhip_download_rgb8(d->ctx, rgb.data(), xs * 3);
-      if (r) return Fail(d, "download failed");
-      std::vector<uint8_t> row(xs * nc);
-      for (size_t y = 0; y < ys; y++) {
-        uint8_t* o = d->callback ? row.data() : dst + y * stride;
-        const uint8_t* s = rgb.data() + y * xs * 3;
-        for (size_t x = 0; x < xs; x++) {
-          if (nc >= 3) {
-            o[x * nc] = s[x * 3];
-            o[x * nc + 1] = s[x * 3 + 1];
-            o[x * nc + 2] = s[x * 3 + 2];
-            if (nc == 4) o[x * nc + 3] = 255;
-          } else {  // grey output of a colour image: not meaningful; keep the first channel
-            o[x * nc] = s[x * 3 + 1];
-            if (nc == 2) o[x * nc + 1] = 255;
-          }
-        }
-        if (d->callback) d->callback(d->callback_opaque, 0, y, xs, row.data());
-      }
-    }
-    d->stage = 5;
-    return JXL_DEC_FULL_IMAGE;
-  }
-  d->stage = 6;
-  return JXL_DEC_SUCCESS;
 }
 
 JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* d, JxlBasicInfo* info) {
   if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
   if (info) {
     memset(info, 0, sizeof(*info));
-    static const uint8_t kContainer[4] = {0, 0, 0, 0xC};
-    info->have_container = d->data && d->size >= 4 && !memcmp(d->data, kContainer, 4);
+    info->have_container = d->container == 1;
     info->xsize = d->ih.xsize;
     info->ysize = d->ih.ysize;
     info->bits_per_sample = d->ih.bits;
     info->exponent_bits_per_sample = d->ih.exp_bits;
     info->intensity_target = d->ih.intensity_target;
     info->uses_original_profile = !d->ih.xyb_encoded;
-    info->orientation = JxlOrientation(d->ih.orientation);
+    info->orientation = d->keep_orientation ? JxlOrientation(d->ih.orientation) : JXL_ORIENT_IDENTITY;
     info->num_color_channels = d->ih.gray ? 1 : 3;
     info->num_extra_channels = uint32_t(d->ih.extra.size());
+    for (const auto& e : d->ih.extra)
+      if (e.type == 0) {
+        info->alpha_bits = e.bits;
+        info->alpha_exponent_bits = e.exp_bits;
+        info->alpha_premultiplied = e.alpha_associated;
+        break;
+      }
     info->intrinsic_xsize = d->ih.xsize;
     info->intrinsic_ysize = d->ih.ysize;
   }
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderGetExtraChannelInfo(const JxlDecoder*, size_t, JxlExtraChannelInfo*) { return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderGetExtraChannelName(const JxlDecoder*, size_t, char*, size_t) { return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* d, JxlColorProfileTarget, JxlColorEncoding* ce) {
+JxlDecoderStatus JxlDecoderGetExtraChannelInfo(const JxlDecoder* d, size_t index, JxlExtraChannelInfo* info) {
+  if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
+  if (index >= d->ih.extra.size()) return JXL_DEC_ERROR;
+  if (info) {
+    memset(info, 0, sizeof(*info));
+    const jxh::ExtraChannel& e = d->ih.extra[index];
+    info->type = JxlExtraChannelType(e.type);
+    info->bits_per_sample = e.bits;
+    info->exponent_bits_per_sample = e.floating ? e.exp_bits : 0;
+    info->dim_shift = e.dim_shift;
+    info->name_length = 0;
+    info->alpha_premultiplied = e.alpha_associated;
+  }
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetExtraChannelName(const JxlDecoder* d, size_t index, char* name, size_t size) {
+  if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
+  if (index >= d->ih.extra.size() || !name || !size) return JXL_DEC_ERROR;
+  name[0] = 0;  // (names are parsed over, not kept)
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* d, size_t index, JxlBlendInfo* info) {
+  if (!d->frame || index >= d->ih.extra.size()) return JXL_DEC_ERROR;
+  if (info) memset(info, 0, sizeof(*info));
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* d, JxlColorProfileTarget target, JxlColorEncoding* ce) {
   if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
   if (ce) {
     memset(ce, 0, sizeof(*ce));
@@ -488,24 +975,38 @@ JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* d, JxlColo
     ce->primaries_red_xy[0] = 0.639998686; ce->primaries_red_xy[1] = 0.330010138;
     ce->primaries_green_xy[0] = 0.300003784; ce->primaries_green_xy[1] = 0.600003357;
     ce->primaries_blue_xy[0] = 0.150002046; ce->primaries_blue_xy[1] = 0.059997204;
-    ce->transfer_function = d->ih.linear_tf ? JXL_TRANSFER_FUNCTION_LINEAR : JXL_TRANSFER_FUNCTION_SRGB;
+    // the pixels (target DATA) follow JxlDecoderSetOutputColorProfile; the original profile is what the stream says
+    const bool linear = target == JXL_COLOR_PROFILE_TARGET_DATA && d->want_linear >= 0 ? d->want_linear != 0 : d->ih.linear_tf;
+    ce->transfer_function = linear ? JXL_TRANSFER_FUNCTION_LINEAR : JXL_TRANSFER_FUNCTION_SRGB;
     ce->rendering_intent = JXL_RENDERING_INTENT_RELATIVE;
   }
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder*, JxlColorProfileTarget, size_t* size) {
-  if (size) *size = 0;
-  return JXL_DEC_ERROR;  // no ICC synthesis: callers fall back to the encoded profile
+JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* d, JxlColorProfileTarget, size_t* size) {
+  if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
+  if (size) *size = 0;  // no ICC synthesis: the encoded profile is the primary representation (size 0 = none)
+  return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder*, JxlColorProfileTarget, uint8_t*, size_t) { return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderSetPreferredColorProfile(JxlDecoder*, const JxlColorEncoding*) { return JXL_DEC_SUCCESS; }
+JxlDecoderStatus JxlDecoderSetPreferredColorProfile(JxlDecoder* d, const JxlColorEncoding* ce) {
+  return JxlDecoderSetOutputColorProfile(d, ce, nullptr, 0);
+}
 JxlDecoderStatus JxlDecoderSetDesiredIntensityTarget(JxlDecoder*, float) { return JXL_DEC_SUCCESS; }
-JxlDecoderStatus JxlDecoderSetOutputColorProfile(JxlDecoder* d, const JxlColorEncoding* ce, const uint8_t*, size_t) {
-  // only (linear or non-linear) sRGB output is implemented; anything else is refused so that the caller notices
-  if (!ce) return JXL_DEC_ERROR;
-  if (ce->primaries != JXL_PRIMARIES_SRGB || ce->white_point != JXL_WHITE_POINT_D65) return JXL_DEC_ERROR;
-  if (ce->transfer_function == JXL_TRANSFER_FUNCTION_LINEAR) d->ih.linear_tf = true;
-  else if (ce->transfer_function == JXL_TRANSFER_FUNCTION_SRGB) d->ih.linear_tf = false;
+JxlDecoderStatus JxlDecoderSetCms(JxlDecoder* d, JxlCmsInterface cms) {
+  d->cms = cms;
+  d->have_cms = true;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetOutputColorProfile(JxlDecoder* d, const JxlColorEncoding* ce, const uint8_t* icc, size_t icc_size) {
+  // decode.cc:2810: after the colour-encoding event, before the pixels. Only (linear or non-linear) sRGB output exists
+  // here; anything else is refused so that the caller notices.
+  if (!d->have_ih || d->stage > 4) return JXL_DEC_ERROR;
+  if (!ce || icc || icc_size) return JXL_DEC_ERROR;
+  if (ce->color_space != (d->ih.gray ? JXL_COLOR_SPACE_GRAY : JXL_COLOR_SPACE_RGB)) return JXL_DEC_ERROR;
+  if (ce->white_point != JXL_WHITE_POINT_D65) return JXL_DEC_ERROR;
+  if (ce->color_space == JXL_COLOR_SPACE_RGB && ce->primaries != JXL_PRIMARIES_SRGB) return JXL_DEC_ERROR;
+  if (ce->transfer_function == JXL_TRANSFER_FUNCTION_LINEAR) d->want_linear = 1;
+  else if (ce->transfer_function == JXL_TRANSFER_FUNCTION_SRGB) d->want_linear = 0;
   else return JXL_DEC_ERROR;
   return JXL_DEC_SUCCESS;
 }
@@ -516,21 +1017,29 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
     h->is_last = JXL_TRUE;
     h->layer_info.xsize = d->ih.xsize;
     h->layer_info.ysize = d->ih.ysize;
+    h->layer_info.blend_info.blendmode = JXL_BLEND_REPLACE;
   }
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder*, char* name, size_t size) {
-  if (name && size) name[0] = 0;
+JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* d, char* name, size_t size) {
+  if (!d->frame || !name || !size) return JXL_DEC_ERROR;
+  name[0] = 0;
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderPreviewOutBufferSize(const JxlDecoder*, const JxlPixelFormat*, size_t*) { return JXL_DEC_ERROR; }
 JxlDecoderStatus JxlDecoderSetPreviewOutBuffer(JxlDecoder*, const JxlPixelFormat*, void*, size_t) { return JXL_DEC_ERROR; }
+
+static JxlDecoderStatus CheckFormat(const JxlDecoder* d, const JxlPixelFormat* f) {
+  if (!d->have_ih || !f) return JXL_DEC_ERROR;
+  if (f->num_channels < 1 || f->num_channels > 4 || !KnownType(f->data_type)) return JXL_DEC_ERROR;
+  if (f->num_channels < 3 && !d->ih.gray) return JXL_DEC_ERROR;  // decode.cc:2512-2520: grayscale output of a colour image
+  if (d->ih.gray) return JXL_DEC_ERROR;                          // (grey VarDCT images are not on this path)
+  return JXL_DEC_SUCCESS;
+}
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* f, size_t* size) {
-  if (!d->have_ih || !f || !size) return JXL_DEC_ERROR;
-  if (f->num_channels < 1 || f->num_channels > 4) return JXL_DEC_ERROR;
-  if (f->data_type != JXL_TYPE_UINT8) return JXL_DEC_ERROR;  // only 8-bit output is implemented on the GPU path
-  size_t stride = RowStride(*f, d->ih.xsize);
-  *size = stride * (d->ih.ysize - 1) + size_t(d->ih.xsize) * f->num_channels;
+  if (CheckFormat(d, f) != JXL_DEC_SUCCESS || !size) return JXL_DEC_ERROR;
+  const size_t stride = RowStride(*f, d->ih.xsize);
+  *size = stride * (d->ih.ysize - 1) + size_t(d->ih.xsize) * f->num_channels * SampleBytes(f->data_type);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat* f, void* buffer, size_t size) {
@@ -541,30 +1050,110 @@ JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat
   d->out_buf = buffer;
   d->out_size = size;
   d->callback = nullptr;
+  d->mt_run = nullptr;
   d->have_out = true;
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetImageOutCallback(JxlDecoder* d, const JxlPixelFormat* f, JxlImageOutCallback cb, void* opaque) {
-  size_t need = 0;
-  if (!cb || JxlDecoderImageOutBufferSize(d, f, &need) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  if (!cb || CheckFormat(d, f) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
   d->fmt = *f;
   d->callback = cb;
   d->callback_opaque = opaque;
+  d->mt_run = nullptr;
   d->out_buf = nullptr;
   d->have_out = true;
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderExtraChannelBufferSize(const JxlDecoder*, const JxlPixelFormat*, size_t*, uint32_t) { return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder*, const JxlPixelFormat*, void*, size_t, uint32_t) { return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderSetDecompressBoxes(JxlDecoder*, JXL_BOOL) { return JXL_DEC_SUCCESS; }
-JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder*, JxlProgressiveDetail) { return JXL_DEC_SUCCESS; }
-size_t JxlDecoderGetIntendedDownsamplingRatio(JxlDecoder*) { return 1; }
-JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder*) { return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder*, const JxlBitDepth* bd) {
-  if (!bd) return JXL_DEC_ERROR;
-  if (bd->type == JXL_BIT_DEPTH_CUSTOM && bd->bits_per_sample != 8) return JXL_DEC_ERROR;
+JxlDecoderStatus JxlDecoderSetMultithreadedImageOutCallback(JxlDecoder* d, const JxlPixelFormat* f, JxlImageOutInitCallback init_cb,
+                                                            JxlImageOutRunCallback run_cb, JxlImageOutDestroyCallback destroy_cb,
+                                                            void* init_opaque) {
+  if (!init_cb || !run_cb || CheckFormat(d, f) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  d->fmt = *f;
+  d->mt_init = init_cb;
+  d->mt_run = run_cb;
+  d->mt_destroy = destroy_cb;
+  d->mt_init_opaque = init_opaque;
+  d->callback = nullptr;
+  d->out_buf = nullptr;
+  d->have_out = true;
   return JXL_DEC_SUCCESS;
 }
+JxlDecoderStatus JxlDecoderExtraChannelBufferSize(const JxlDecoder* d, const JxlPixelFormat* f, size_t* size, uint32_t index) {
+  if (!d->have_ih || !f || !size || index >= d->ih.extra.size() || !KnownType(f->data_type)) return JXL_DEC_ERROR;
+  JxlPixelFormat one = *f;
+  one.num_channels = 1;  // decode.cc:2608-2625: the channel count of the format is ignored
+  *size = RowStride(one, d->ih.xsize) * (d->ih.ysize - 1) + size_t(d->ih.xsize) * SampleBytes(f->data_type);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* d, const JxlPixelFormat* f, void* buffer, size_t size, uint32_t index) {
+  size_t need = 0;
+  if (JxlDecoderExtraChannelBufferSize(d, f, &need, index) != JXL_DEC_SUCCESS || !buffer || size < need) return JXL_DEC_ERROR;
+  JxlPixelFormat one = *f;
+  one.num_channels = 1;
+  for (auto& eo : d->extra_out)
+    if (eo.first == index) {
+      eo.second = JxlDecoder::ExtraOut{one, buffer, size};
+      return JXL_DEC_SUCCESS;
+    }
+  d->extra_out.push_back({index, JxlDecoder::ExtraOut{one, buffer, size}});
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetDecompressBoxes(JxlDecoder* d, JXL_BOOL decompress) {
+  d->decompress_boxes = decompress != 0;  // (no Brotli here: see JxlDecoderSetBoxBuffer)
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder*, JxlProgressiveDetail) { return JXL_DEC_SUCCESS; }
+size_t JxlDecoderGetIntendedDownsamplingRatio(JxlDecoder*) { return 1; }
+JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder*) { return JXL_DEC_ERROR; }  // nothing is rendered before a frame is complete
+JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* d, const JxlBitDepth* bd) {
+  if (!bd || !d->have_out) return JXL_DEC_ERROR;
+  const uint32_t max_bits = d->fmt.data_type == JXL_TYPE_UINT8 ? 8 : 16;
+  if (bd->type == JXL_BIT_DEPTH_CUSTOM) {
+    if (d->fmt.data_type != JXL_TYPE_UINT8 && d->fmt.data_type != JXL_TYPE_UINT16) return JXL_DEC_ERROR;
+    if (bd->bits_per_sample == 0 || bd->bits_per_sample > max_bits) return JXL_DEC_ERROR;
+  } else if (bd->type == JXL_BIT_DEPTH_FROM_CODESTREAM) {
+    if ((d->fmt.data_type == JXL_TYPE_UINT8 || d->fmt.data_type == JXL_TYPE_UINT16) && d->ih.bits > max_bits) return JXL_DEC_ERROR;
+  } else if (bd->type != JXL_BIT_DEPTH_FROM_PIXEL_FORMAT) {
+    return JXL_DEC_ERROR;
+  }
+  d->bit_depth = *bd;
+  return JXL_DEC_SUCCESS;
+}
+
+// ---- boxes (decode.cc:2852-2990)
+JxlDecoderStatus JxlDecoderSetBoxBuffer(JxlDecoder* d, uint8_t* data, size_t size) {
+  if (d->box_out_set) return JXL_DEC_ERROR;  // release the previous buffer first
+  if (!d->have_box || !(d->events & JXL_DEC_BOX)) return JXL_DEC_ERROR;
+  d->box_out = data;
+  d->box_out_size = size;
+  d->box_out_pos = 0;
+  d->box_out_set = true;
+  return JXL_DEC_SUCCESS;
+}
+size_t JxlDecoderReleaseBoxBuffer(JxlDecoder* d) {
+  if (!d->box_out_set) return 0;
+  const size_t unused = d->box_out_size - d->box_out_pos;
+  d->box_out_set = false;
+  d->box_out = nullptr;
+  return unused;
+}
+JxlDecoderStatus JxlDecoderGetBoxType(JxlDecoder* d, JxlBoxType type, JXL_BOOL decompressed) {
+  if (!d->have_box) return JXL_DEC_ERROR;
+  memcpy(type, decompressed ? d->box_decoded_type : d->box_type, 4);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetBoxSizeRaw(const JxlDecoder* d, uint64_t* size) {
+  if (!d->have_box) return JXL_DEC_ERROR;
+  if (size) *size = d->box_size_raw;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderGetBoxSizeContents(const JxlDecoder* d, uint64_t* size) {
+  if (!d->have_box) return JXL_DEC_ERROR;
+  if (size) *size = d->box_contents_size;
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetJPEGBuffer(JxlDecoder*, uint8_t*, size_t) { return JXL_DEC_ERROR; }
+size_t JxlDecoderReleaseJPEGBuffer(JxlDecoder*) { return 0; }
 
 // ------------------------------------------------------------------------------------------------ thread runners
 }  // extern "C"

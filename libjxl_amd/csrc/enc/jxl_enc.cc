@@ -69,6 +69,16 @@ static inline void HybridEncode(const jxh::HybridCfg& c, uint32_t value, uint32_
   *bits = (value >> c.lsb) & ((1u << *nbits) - 1);
 }
 
+static inline void Symbolize(const jxh::HybridCfg& cfg, const jxh::HybridCfg& len_cfg, uint32_t value, uint32_t* token, uint32_t* nbits,
+                             uint32_t* bits) {
+  if (value & 0x80000000u) {  // LZ77 length token (kLzLenFlag)
+    HybridEncode(len_cfg, value & 0x7FFFFFFFu, token, nbits, bits);
+    *token += 224;  // kLzMinSymbol
+    return;
+  }
+  HybridEncode(cfg, value, token, nbits, bits);
+}
+
 static void WriteVarLenU8(BitWriter& bw, uint32_t n) {
   if (n == 0) {
     bw.Write(1, 0);
@@ -165,12 +175,22 @@ static std::vector<int32_t> Normalize(const std::vector<uint32_t>& h) {
   return n;
 }
 
+// Special tokens of an LZ77-enabled stream (dec_ans.h:288-353): a copy is a length token in the context of the value it
+// replaces (value = kLzLenFlag | (length - min_length)) followed by a distance token in the extra last context
+// (value = distance - 1; no special distances: AC streams have no distance multiplier).
+static const uint32_t kLzLenFlag = 0x80000000u;
+static const uint32_t kLzMinSymbol = 224, kLzMinLength = 3;
+
 struct EncCode {
-  size_t num_ctx = 0;
+  size_t num_ctx = 0;  // (including the distance context of an LZ77 stream)
   std::vector<uint8_t> ctx_map;
   size_t num_clusters = 1;
   jxh::HybridCfg cfg;
   int log_alpha = 5;
+  bool use_prefix = false, lz77 = false;
+  jxh::HybridCfg lz_len_cfg;
+  std::vector<std::vector<uint8_t>> plen;          // prefix codes: [cluster][symbol] code length (0 = unused)
+  std::vector<std::vector<uint16_t>> pbits;        // [cluster][symbol] code, bit-reversed for LSB-first writing
   std::vector<std::vector<int32_t>> norm;          // [cluster][symbol]
   std::vector<std::vector<uint32_t>> rev_start;    // [cluster][symbol] -> start in rev
   std::vector<std::vector<uint16_t>> rev;          // [cluster] slot of (symbol, offset)
@@ -206,23 +226,31 @@ static void BuildReverseMaps(EncCode* code) {
 }
 
 // Builds clustered, normalised histograms for a token set over `num_ctx` contexts.
+static void BuildPrefixCodes(EncCode* code, const std::vector<std::vector<double>>& csum);
+
+// mode: bit 0 = prefix codes instead of ANS, bit 1 = the streams carry LZ77 tokens (num_ctx then includes the distance context)
 static void BuildCode(const std::vector<const std::vector<Token>*>& streams, size_t num_ctx, size_t max_clusters,
-                      jxh::HybridCfg cfg, EncCode* code) {
+                      jxh::HybridCfg cfg, EncCode* code, int mode = 0) {
   code->num_ctx = num_ctx;
   code->cfg = cfg;
+  code->use_prefix = (mode & 1) != 0;
+  code->lz77 = (mode & 2) != 0;
+  code->lz_len_cfg.split_exp = 4;
+  code->lz_len_cfg.split_token = 16;
+  code->lz_len_cfg.msb = code->lz_len_cfg.lsb = 0;
   uint32_t max_tok = 0;
   std::vector<std::vector<uint32_t>> hist(num_ctx);
   for (const auto* st : streams)
     for (const Token& t : *st) {
       uint32_t tok, nb, bits;
-      HybridEncode(cfg, t.value, &tok, &nb, &bits);
+      Symbolize(cfg, code->lz_len_cfg, t.value, &tok, &nb, &bits);
       max_tok = std::max(max_tok, tok);
       auto& h = hist[t.ctx];
       if (h.size() <= tok) h.resize(tok + 1, 0);
       h[tok]++;
     }
-  code->log_alpha = std::max(5, CeilLog2(max_tok + 1));
-  if (code->log_alpha > 8) abort();
+  code->log_alpha = code->use_prefix ? 15 : std::max(5, CeilLog2(max_tok + 1));
+  if (!code->use_prefix && code->log_alpha > 8) abort();
   const size_t A = max_tok + 1;
   // greedy clustering, largest contexts first
   std::vector<size_t> order;
@@ -270,6 +298,10 @@ static void BuildCode(const std::vector<const std::vector<Token>*>& streams, siz
     ctot.push_back(0);
   }
   code->num_clusters = csum.size();
+  if (code->use_prefix) {
+    BuildPrefixCodes(code, csum);
+    return;
+  }
   code->norm.resize(code->num_clusters);
   for (size_t k = 0; k < code->num_clusters; k++) {
     std::vector<uint32_t> h(A);
@@ -280,11 +312,131 @@ static void BuildCode(const std::vector<const std::vector<Token>*>& streams, siz
 }
 
 // rANS-encodes tokens (all contexts via code->ctx_map); writes the 32-bit initial state first.
+// Length-limited Huffman code lengths (limit 15: dec_huffman.cc), then canonical codes (huffman_table.cc:27-161).
+static void HuffmanLengths(std::vector<double> counts, int limit, std::vector<uint8_t>* lens) {
+  const size_t n = counts.size();
+  for (;;) {
+    lens->assign(n, 0);
+    struct Node { double w; int l, r; };
+    std::vector<Node> nodes;
+    std::vector<int> live;
+    for (size_t i = 0; i < n; i++)
+      if (counts[i] > 0) {
+        nodes.push_back({counts[i], -1, int(i)});
+        live.push_back(int(nodes.size()) - 1);
+      }
+    if (live.size() <= 1) {
+      if (live.size() == 1) (*lens)[size_t(nodes[0].r)] = 1;  // a single symbol: zero-bit code (any non-zero length marks it)
+      return;
+    }
+    while (live.size() > 1) {
+      std::sort(live.begin(), live.end(), [&](int a, int b) { return nodes[a].w != nodes[b].w ? nodes[a].w > nodes[b].w : a < b; });
+      const int a = live.back();
+      live.pop_back();
+      const int b = live.back();
+      live.pop_back();
+      nodes.push_back({nodes[a].w + nodes[b].w, a, b});
+      live.push_back(int(nodes.size()) - 1);
+    }
+    int max_len = 0;
+    std::vector<std::pair<int, int>> stack{{live[0], 0}};
+    while (!stack.empty()) {
+      const auto [id, depth] = stack.back();
+      stack.pop_back();
+      if (nodes[id].l < 0) {
+        (*lens)[size_t(nodes[id].r)] = uint8_t(depth);
+        max_len = std::max(max_len, depth);
+      } else {
+        stack.push_back({nodes[id].l, depth + 1});
+        stack.push_back({nodes[id].r, depth + 1});
+      }
+    }
+    if (max_len <= limit) return;
+    for (double& c : counts)  // flatten and retry
+      if (c > 0) c = std::floor(c / 2) + 1;
+  }
+}
+static void CanonicalCodes(const std::vector<uint8_t>& lens, std::vector<uint16_t>* rev_bits) {
+  rev_bits->assign(lens.size(), 0);
+  uint32_t code = 0;
+  for (int l = 1; l <= 15; l++) {
+    for (size_t s = 0; s < lens.size(); s++) {
+      if (lens[s] != l) continue;
+      uint32_t rev = 0;
+      for (int b = 0; b < l; b++) rev |= ((code >> b) & 1) << (l - 1 - b);
+      (*rev_bits)[s] = uint16_t(rev);
+      code++;
+    }
+    code <<= 1;
+  }
+}
+static void BuildPrefixCodes(EncCode* code, const std::vector<std::vector<double>>& csum) {
+  code->plen.resize(code->num_clusters);
+  code->pbits.resize(code->num_clusters);
+  for (size_t k = 0; k < code->num_clusters; k++) {
+    std::vector<double> c = csum[k];
+    while (!c.empty() && c.back() == 0) c.pop_back();
+    if (c.empty()) c.push_back(1);
+    HuffmanLengths(c, 15, &code->plen[k]);
+    CanonicalCodes(code->plen[k], &code->pbits[k]);
+  }
+}
+// One prefix code as HuffmanDecodingData::ReadFromBitStream expects it (dec_huffman.cc:179-245; the "complex" form with
+// a code-length code, or the 1-symbol simple form).
+static void WritePrefixCode(BitWriter& bw, const std::vector<uint8_t>& lens) {
+  const size_t alphabet = lens.size();
+  std::vector<size_t> used;
+  for (size_t i = 0; i < alphabet; i++)
+    if (lens[i]) used.push_back(i);
+  if (used.size() == 1) {
+    bw.Write(2, 1);  // simple code
+    bw.Write(2, 0);  // one symbol
+    bw.Write(alphabet > 1 ? FloorLog2(uint32_t(alphabet - 1)) + 1 : 0, uint32_t(used[0]));
+    return;
+  }
+  bw.Write(2, 0);  // complex code, no skipped code-length-code entries
+  const size_t last = used.back();
+  std::vector<double> clh(18, 0.0);
+  for (size_t i = 0; i <= last; i++) clh[lens[i]] += 1;
+  std::vector<uint8_t> cl_lens;
+  HuffmanLengths(clh, 5, &cl_lens);
+  std::vector<uint16_t> cl_bits;
+  CanonicalCodes(cl_lens, &cl_bits);
+  static const uint8_t kOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+  // fixed code of the code-length-code lengths: value -> (bit pattern LSB first, length)
+  static const uint8_t kPat[6][2] = {{0, 2}, {7, 4}, {3, 3}, {2, 2}, {1, 2}, {15, 4}};
+  int space = 32, num_codes = 0;
+  for (size_t i = 0; i < 18 && space > 0; i++) {
+    const int v = cl_lens[kOrder[i]];
+    bw.Write(kPat[v][1], kPat[v][0]);
+    if (v) {
+      space -= 32 >> v;
+      num_codes++;
+    }
+  }
+  if (!(num_codes == 1 || space == 0)) abort();
+  for (size_t i = 0; i <= last; i++)
+    if (num_codes > 1) bw.Write(cl_lens[lens[i]], cl_bits[lens[i]]);
+}
+
 static void WriteTokens(BitWriter& bw, const Token* tk, size_t n, const EncCode& code) {
+  if (code.use_prefix) {  // forward order, no coder state (dec_ans.h:170-197 ReadSymbolHuffWithoutRefill)
+    for (size_t i = 0; i < n; i++) {
+      uint32_t tok, nbits, bits;
+      Symbolize(code.cfg, code.lz_len_cfg, tk[i].value, &tok, &nbits, &bits);
+      const size_t k = code.ctx_map[tk[i].ctx];
+      if (tok >= code.plen[k].size() || code.plen[k][tok] == 0) abort();
+      size_t used = 0;
+      for (uint8_t l : code.plen[k]) used += l != 0;
+      if (used > 1) bw.Write(code.plen[k][tok], code.pbits[k][tok]);
+      bw.Write(nbits, bits);
+    }
+    return;
+  }
   struct Out { uint32_t tok, nbits, bits; uint16_t chunk; bool has_chunk; uint8_t cluster; };
   std::vector<Out> o(n);
   for (size_t i = 0; i < n; i++) {
-    HybridEncode(code.cfg, tk[i].value, &o[i].tok, &o[i].nbits, &o[i].bits);
+    Symbolize(code.cfg, code.lz_len_cfg, tk[i].value, &o[i].tok, &o[i].nbits, &o[i].bits);
     o[i].cluster = code.ctx_map[tk[i].ctx];
     o[i].has_chunk = false;
   }
@@ -332,13 +484,65 @@ static void WriteContextMap(BitWriter& bw, const EncCode& code) {
 }
 
 // Everything DecodeHistograms() reads (dec_ans.cc:341-376).
+static void WriteVarLenU16(BitWriter& bw, uint32_t n) {
+  if (n == 0) {
+    bw.Write(1, 0);
+    return;
+  }
+  bw.Write(1, 1);
+  uint32_t nb = uint32_t(FloorLog2(n));
+  bw.Write(4, nb);
+  bw.Write(nb, n - (1u << nb));
+}
 static void WriteCodeHeader(BitWriter& bw, const EncCode& code) {
-  bw.Write(1, 0);  // lz77 disabled
+  if (!code.lz77) {
+    bw.Write(1, 0);  // lz77 disabled
+  } else {
+    bw.Write(1, 1);
+    bw.Write(2, 0);  // min_symbol 224
+    bw.Write(2, 0);  // min_length 3
+    WriteHybridCfg(bw, code.lz_len_cfg, 8);
+  }
   if (code.num_ctx > 1) WriteContextMap(bw, code);
+  if (code.use_prefix) {
+    bw.Write(1, 1);
+    for (size_t k = 0; k < code.num_clusters; k++) WriteHybridCfg(bw, code.cfg, 15);
+    for (size_t k = 0; k < code.num_clusters; k++) WriteVarLenU16(bw, uint32_t(code.plen[k].size() - 1));
+    for (size_t k = 0; k < code.num_clusters; k++)
+      if (code.plen[k].size() > 1) WritePrefixCode(bw, code.plen[k]);
+    return;
+  }
   bw.Write(1, 0);  // ANS, not prefix codes
   bw.Write(2, code.log_alpha - 5);
   for (size_t k = 0; k < code.num_clusters; k++) WriteHybridCfg(bw, code.cfg, code.log_alpha);
   for (size_t k = 0; k < code.num_clusters; k++) WriteHistogram(bw, code.norm[k]);
+}
+
+// Replaces runs that repeat the values `distance` tokens back (distance 1, 2 or 3: zero runs and short periodic
+// patterns) by LZ77 copies. The copy's length token takes the context of the first value it replaces.
+static void Lz77Pass(std::vector<Token>* tokens, uint32_t dist_ctx) {
+  const std::vector<Token>& in = *tokens;
+  std::vector<Token> out;
+  out.reserve(in.size());
+  for (size_t i = 0; i < in.size();) {
+    size_t best_len = 0, best_d = 0;
+    for (size_t d = 1; d <= 3 && d <= i; d++) {
+      size_t l = 0;
+      while (i + l < in.size() && in[i + l].value == in[i + l - d].value) l++;
+      if (l > best_len) {
+        best_len = l;
+        best_d = d;
+      }
+    }
+    if (best_len >= 6) {
+      out.push_back({in[i].ctx, kLzLenFlag | uint32_t(best_len - kLzMinLength)});
+      out.push_back({dist_ctx, uint32_t(best_d - 1)});
+      i += best_len;
+    } else {
+      out.push_back(in[i++]);
+    }
+  }
+  tokens->swap(out);
 }
 
 // IEEE half (fields.cc:550-575): the value must be a normal half-precision number or zero.
@@ -525,6 +729,7 @@ struct FrameModel {
   int epf_iters, gab;
   uint64_t flags;
   size_t img_xs = 0, img_ys = 0;  // image size when the frame is coded downsampled (upsampling > 1)
+  std::vector<uint8_t> alpha;     // optional 8-bit alpha plane (xs * ys): one Modular-coded extra channel (dec_frame.cc:511-542)
 };
 
 struct Params {
@@ -548,7 +753,8 @@ struct Params {
                            //     x/b quant-matrix scales 2 / 4: valid streams, but image mode does not compensate for them
   int32_t custom_lf;       // 1 = non-default loop filter header: Gaborish weights, EPF sharpness LUT, channel scales and
                            //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
-  int32_t reserved[2];
+  int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS (libjxl's fastest efforts), bit 1 = LZ77
+  int32_t reserved[1];
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -620,6 +826,24 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   jxh::HybridCfg cfg420;
   cfg420.split_exp = 4; cfg420.split_token = 16; cfg420.msb = 2; cfg420.lsb = 0;
   EncCode tree_code, mod_code;
+  // alpha: channel 0 of the frame's global Modular image. Up to a group in size it is coded whole in stream 0 (DC global),
+  // else one rectangle per AC group section, behind the coefficients (stream ids: dec_modular.h:44-67).
+  const bool have_alpha = !f.alpha.empty();
+  const bool alpha_global = have_alpha && f.xs <= 256 && f.ys <= 256;
+  std::vector<Token> alpha_global_tokens;
+  std::vector<std::vector<Token>> alpha_group_tokens(have_alpha && !alpha_global ? num_groups : 0);
+  if (alpha_global) {
+    std::vector<int32_t> px(f.alpha.begin(), f.alpha.end());
+    ModularTokens(tree, px.data(), f.xs, f.ys, 0, 0, &alpha_global_tokens);
+  }
+  for (size_t g = 0; g < alpha_group_tokens.size(); g++) {
+    const size_t x0 = (g % xg) * 256, y0 = (g / xg) * 256, w = std::min<size_t>(256, f.xs - x0), h = std::min<size_t>(256, f.ys - y0);
+    std::vector<int32_t> px(w * h);
+    for (size_t y = 0; y < h; y++)
+      for (size_t x = 0; x < w; x++) px[y * w + x] = f.alpha[(y0 + y) * f.xs + x0 + x];
+    const size_t last_pass = (p.num_passes == 2 ? 2 : 1) - 1;
+    ModularTokens(tree, px.data(), w, h, 0, int(1 + 3 * ndc + 17 + num_groups * last_pass + g), &alpha_group_tokens[g]);
+  }
   BuildCode({&tree_tokens}, 6, 6, cfg420, &tree_code);
   {
     std::vector<const std::vector<Token>*> all;
@@ -627,6 +851,8 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     for (auto& t : meta_tokens) all.push_back(&t);
     size_t nleaf = 0;
     for (int c : tree.leaf_ctx) nleaf += c >= 0;
+    if (alpha_global) all.push_back(&alpha_global_tokens);
+    for (const auto& t : alpha_group_tokens) all.push_back(&t);
     BuildCode(all, nleaf, 8, cfg420, &mod_code);
   }
   // ---- tokenise AC groups
@@ -779,7 +1005,10 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   for (size_t pass = 0; pass < num_passes; pass++) {
     std::vector<const std::vector<Token>*> all;
     for (size_t g = 0; g < num_groups; g++) all.push_back(&ac_tokens[pass * num_groups + g]);
-    BuildCode(all, nctx * num_hist, p.max_clusters > 0 ? size_t(p.max_clusters) : 64, cfg420, &ac_codes[pass]);
+    const int mode = p.ac_code_mode & 3;  // bit 0: prefix codes, bit 1: LZ77
+    if (mode & 2)
+      for (size_t g = 0; g < num_groups; g++) Lz77Pass(&ac_tokens[pass * num_groups + g], uint32_t(nctx * num_hist));
+    BuildCode(all, nctx * num_hist + ((mode & 2) ? 1 : 0), p.max_clusters > 0 ? size_t(p.max_clusters) : 64, cfg420, &ac_codes[pass], mode);
   }
   // ---- sections
   auto write_dc_global = [&](BitWriter& bw) {
@@ -831,6 +1060,12 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     WriteCodeHeader(bw, tree_code);
     WriteTokens(bw, tree_tokens.data(), tree_tokens.size(), tree_code);
     WriteCodeHeader(bw, mod_code);
+    if (have_alpha) {  // stream 0 of the global Modular image: its group header, and the channel if it fits a group
+      bw.Write(1, 1);  // use global tree
+      bw.Write(1, 1);  // default weighted-predictor header
+      bw.Write(2, 0);  // no transforms
+      if (alpha_global) WriteTokens(bw, alpha_global_tokens.data(), alpha_global_tokens.size(), mod_code);
+    }
   };
   auto write_group_header = [&](BitWriter& bw) {
     bw.Write(1, 1);  // use global tree
@@ -866,6 +1101,10 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     const size_t g = pg % num_groups;
     bw.Write(CeilLog2(num_hist), uint32_t(g % num_hist));  // histogram selector (dec_group.cc:594-610)
     WriteTokens(bw, ac_tokens[pg].data(), ac_tokens[pg].size(), ac_codes[pg / num_groups]);
+    if (!alpha_group_tokens.empty() && pg / num_groups == num_passes - 1) {  // Modular data of the group, behind the coefficients
+      write_group_header(bw);
+      WriteTokens(bw, alpha_group_tokens[g].data(), alpha_group_tokens[g].size(), mod_code);
+    }
   };
 
   std::vector<std::vector<uint8_t>> sections;
@@ -915,7 +1154,20 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   WriteSizeDim(bw, uint32_t(ups == 1 ? f.ys : f.img_ys));
   bw.Write(3, 0);  // no aspect-ratio shortcut
   WriteSizeDim(bw, uint32_t(ups == 1 ? f.xs : f.img_xs));
-  bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
+  if (!have_alpha) {
+    bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
+  } else {           // image_metadata.cc:283-356
+    bw.Write(1, 0);  // not all_default
+    bw.Write(1, 0);  // no extra_fields
+    bw.Write(1, 0);  // integer samples
+    bw.Write(2, 0);  //   8 bits
+    bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
+    bw.Write(2, 1);  // one extra channel
+    bw.Write(1, 1);  //   ExtraChannelInfo all_default: 8-bit alpha
+    bw.Write(1, 1);  // xyb_encoded
+    bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
+    bw.Write(2, 0);  // no extensions
+  }
   bw.Write(1, 1);  // CustomTransformData all_default
   bw.ZeroPad();
   // FrameHeader
@@ -929,6 +1181,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(8, f.flags - 17);
   }
   bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
+  if (have_alpha) bw.Write(2, 0);  // extra channel upsampling 1
   bw.Write(3, p.custom_cmap ? 2 : 3);  // x_qm_scale
   bw.Write(3, p.custom_cmap ? 4 : 2);  // b_qm_scale
   if (num_passes == 1) {
@@ -940,6 +1193,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   bw.Write(1, 0);  // no custom size/origin
   bw.Write(2, 0);  // blend mode: replace
+  if (have_alpha) bw.Write(2, 0);  // the extra channel's blend mode: replace
   bw.Write(1, 1);  // is_last
   bw.Write(2, 0);  // no name
   bw.Write(1, 0);  // loop filter not all_default
@@ -1009,8 +1263,9 @@ static void QuantParams(float distance, FrameModel* f, float* quant_ac) {
 }
 
 static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out, size_t img_xs = 0,
-                        size_t img_ys = 0) {
+                        size_t img_ys = 0, const std::vector<uint8_t>* alpha = nullptr) {
   FrameModel f;
+  if (alpha) f.alpha = *alpha;
   f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
   f.img_xs = img_xs ? img_xs : xs;
   f.img_ys = img_ys ? img_ys : ys;
@@ -1349,7 +1604,8 @@ struct JxlEncParams {
                            //     x/b quant-matrix scales 2 / 4: valid streams, but image mode does not compensate for them
   int32_t custom_lf;       // 1 = non-default loop filter header: Gaborish weights, EPF sharpness LUT, channel scales and
                            //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
-  int32_t reserved[2];
+  int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS, bit 1 = LZ77
+  int32_t reserved[1];
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
@@ -1385,6 +1641,28 @@ int jxlenc_encode_rgb8(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEn
       jxe::EncodeImage(small.data(), sx, sy, q, &v, xs, ys);
     } else
     jxe::EncodeImage(rgb, xs, ys, q, &v);
+  } catch (...) {
+    return -2;
+  }
+  return Finish(v, out, n);
+}
+
+// RGBA8 image: the colour as jxlenc_encode_rgb8, alpha (channel 3) losslessly as a Modular-coded extra channel.
+int jxlenc_encode_rgba8(const uint8_t* rgba, uint32_t xs, uint32_t ys, const JxlEncParams* p, uint8_t** out, size_t* n) {
+  if (!rgba || !xs || !ys || !p || p->distance <= 0) return -1;
+  jxe::Params q;
+  memcpy(&q, p, sizeof(q));
+  if (q.upsampling > 1) return -1;
+  std::vector<uint8_t> rgb(size_t(xs) * ys * 3), alpha(size_t(xs) * ys);
+  for (size_t i = 0; i < size_t(xs) * ys; i++) {
+    rgb[i * 3] = rgba[i * 4];
+    rgb[i * 3 + 1] = rgba[i * 4 + 1];
+    rgb[i * 3 + 2] = rgba[i * 4 + 2];
+    alpha[i] = rgba[i * 4 + 3];
+  }
+  std::vector<uint8_t> v;
+  try {
+    jxe::EncodeImage(rgb.data(), xs, ys, q, &v, 0, 0, &alpha);
   } catch (...) {
     return -2;
   }

@@ -57,7 +57,7 @@ struct Buf {
 };
 
 struct PassBufs {
-  Buf ctx_map, alias, cfg, orders;
+  Buf ctx_map, alias, cfg, orders, ptable, poffset;
 };
 
 constexpr int kEntropyWPG = 4;  // waves (= AC sections) per workgroup of the scalar-form entropy kernel
@@ -79,7 +79,8 @@ struct JxlHipContext {
   float epf_pass0 = 0.9f, epf_pass2 = 6.5f, epf_border = 2.0f / 3;
   // buffers
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
-  Buf plane[3], rgb, tlist, scratch;
+  Buf plane[3], rgb, tlist, scratch, sec_end, lz_window;
+  bool generic_codec = false;  // a pass is prefix-coded or uses LZ77: k_entropy_generic decodes the frame
   size_t plane_bytes = 0;  // bytes of plane[0] the current frame needs
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
   Buf batch_wave_ls;
@@ -102,6 +103,11 @@ struct JxlHipContext {
   bool lanes = false, lane_multi = false;
   uint32_t nblocks = 0;
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
+  // output pixel format (jxlhip_set_output_format; JxlDataType numbering): RGB8 by default
+  uint32_t out_type = 2, out_nc = 3, out_bits = 8, out_swap = 0;
+  Buf alpha;                // f32 plane of the image size (jxlhip_set_alpha), used by 2- and 4-channel output
+  bool have_alpha = false;
+  bool color_out = false;   // the pixels come from k_color_out / k_upsample_color's generic writer (set at upload)
   Buf kend, block_recs, dequant_scan;
   std::vector<JxlHipVarBlock> blocks_host;  // for jxlhip_download("coeffs") of a scan-order frame
   std::vector<uint32_t> gbb_host;
@@ -164,6 +170,11 @@ static int EntropyKernelChoice() {
 }
 static JxlHipContext* PlaneHolder(JxlHipContext* c) { return c->plane_lender ? c->plane_lender : c; }
 static const JxlHipContext* PlaneHolder(const JxlHipContext* c) { return c->plane_lender ? c->plane_lender : c; }
+
+static size_t OutSampleBytes(const JxlHipContext* c) { return c->out_type == 2 ? 1 : (c->out_type == 0 ? 4 : 2); }
+static size_t OutPixelBytes(const JxlHipContext* c) { return OutSampleBytes(c) * c->out_nc; }
+static bool OutIsRgb8(const JxlHipContext* c) { return c->out_type == 2 && c->out_nc == 3 && c->out_bits == 8; }
+static bool OutIsRgbF32(const JxlHipContext* c) { return c->out_type == 0 && c->out_nc == 3 && !c->out_swap; }
 
 static int EnvInt(const char* name, int def) {
   const char* e = getenv(name);
@@ -247,13 +258,15 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
     pb.alias.Free();
     pb.cfg.Free();
     pb.orders.Free();
+    pb.ptable.Free();
+    pb.poffset.Free();
   }
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -399,14 +412,27 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   std::vector<jxlhip::PassDev> pd(d->num_passes);
   const uint32_t nctx = d->num_block_ctxs * 495;
   size_t alias_bytes_max = 0;
+  bool generic = false, any_lz77 = false;
   for (uint32_t p = 0; p < d->num_passes; p++) {
     const JxlHipPassDesc& s = d->passes[p];
-    if (s.log_alpha < 5 || s.log_alpha > 8 || s.num_clusters == 0 || s.num_clusters > 256) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (s.num_clusters == 0 || s.num_clusters > 256) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (!s.use_prefix && (s.log_alpha < 5 || s.log_alpha > 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (s.use_prefix) {  // every table index the kernel can form must be inside the table
+      if (!s.prefix_offset || !s.prefix_table) return JXLHIP_ERR_INVALID_ARGUMENT;
+      for (uint32_t i = 0; i < s.num_clusters; i++) {
+        const uint32_t first = s.prefix_offset[i] & 0xFFFFFFu, max_len = s.prefix_offset[i] >> 24;
+        if (max_len > 15 || size_t(first) + (size_t(1) << max_len) > s.prefix_table_size) return JXLHIP_ERR_INVALID_ARGUMENT;
+        for (size_t j = 0; j < (size_t(1) << max_len); j++)
+          if ((s.prefix_table[first + j] & 0xFF) > max_len) return JXLHIP_ERR_INVALID_ARGUMENT;
+      }
+    }
+    if (s.lz77 && (s.lz_dist_ctx >= s.num_clusters || s.lz_min_length == 0)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    generic = generic || s.use_prefix || s.lz77;
     if (s.ctx_map_size < size_t(d->num_histograms) * nctx + 16) return JXLHIP_ERR_INVALID_ARGUMENT;
     for (uint32_t i = 0; i < s.ctx_map_size; i++)
       if (s.ctx_map[i] >= s.num_clusters) return JXLHIP_ERR_INVALID_ARGUMENT;
     PassBufs& pb = c->pass_bufs[p];
-    const size_t alias_bytes = (size_t(s.num_clusters) << s.log_alpha) * 8;
+    const size_t alias_bytes = s.use_prefix ? 0 : (size_t(s.num_clusters) << s.log_alpha) * 8;
     alias_bytes_max = alias_bytes > alias_bytes_max ? alias_bytes : alias_bytes_max;
     if ((r = Upload(c, pb.ctx_map, s.ctx_map, s.ctx_map_size))) return r;
     if ((r = Upload(c, pb.alias, s.alias, alias_bytes))) return r;
@@ -419,8 +445,19 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     memcpy(pd[p].order_offset, s.order_offset, sizeof(s.order_offset));
     for (uint32_t i = 0; i < s.num_clusters; i++) {  // hybrid-uint configs: split_exponent, msb_in_token, lsb_in_token
       const uint32_t se = s.uint_cfg[i] & 0xFF, msb = (s.uint_cfg[i] >> 8) & 0xFF, lsb = (s.uint_cfg[i] >> 16) & 0xFF;
-      if (se > s.log_alpha || msb > se || lsb > se - msb) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (se > (s.use_prefix ? 15u : s.log_alpha) || msb > se || lsb > se - msb) return JXLHIP_ERR_INVALID_ARGUMENT;
     }
+    if ((r = Upload(c, pb.ptable, s.prefix_table, s.use_prefix ? size_t(s.prefix_table_size) * 4 : 0))) return r;
+    if ((r = Upload(c, pb.poffset, s.prefix_offset, s.use_prefix ? size_t(s.num_clusters) * 4 : 0))) return r;
+    pd[p].use_prefix = s.use_prefix ? 1 : 0;
+    pd[p].lz77 = s.lz77 ? 1 : 0;
+    pd[p].lz_min_symbol = s.lz_min_symbol;
+    pd[p].lz_min_length = s.lz_min_length;
+    pd[p].lz_len_cfg = s.lz_len_cfg;
+    pd[p].lz_dist_ctx = s.lz_dist_ctx;
+    pd[p].prefix_table = pb.ptable.as<uint32_t>();
+    pd[p].prefix_offset = pb.poffset.as<uint32_t>();
+    if (s.lz77) any_lz77 = true;
     pd[p].log_alpha = s.log_alpha;
     c->pass_clusters[p] = s.num_clusters;
     c->pass_log_alpha[p] = s.log_alpha;
@@ -439,8 +476,13 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
   c->plane_bytes = plane_bytes;
   if (!c->plane_lender && (r = c->plane[0].Ensure(plane_bytes))) return r;
-  if ((c->keep_filtered || c->ups != 1) && (r = c->plane[1].Ensure(plane_bytes))) return r;
-  if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * 3))) return r;
+  // pixels: RGB8 from every filter kernel, RGB f32 from the row-streaming one; any other format from the generic writer
+  // (k_color_out on the filtered planes, or k_upsample_color)
+  c->color_out = !OutIsRgb8(c) && !(OutIsRgbF32(c) && c->ups == 1 && (c->gab && c->epf_iters == 1) &&
+                                    !EnvInt("JXLHIP_FILTER_TILES", 0) && !EnvInt("JXLHIP_FILTER_ROWS1", 0));
+  if (c->have_alpha && c->alpha.cap < size_t(c->oxs) * c->oys * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if ((c->keep_filtered || c->ups != 1 || c->color_out) && (r = c->plane[1].Ensure(plane_bytes))) return r;
+  if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
   if (c->ups != 1) {
     if ((r = Upload(c, c->ups_kernel, d->upsampling_kernel, size_t(c->ups) * c->ups * 25 * 4))) return r;
     HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's table may be a temporary
@@ -493,6 +535,15 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   ep.num_groups = d->num_groups;
   ep.coeffs = c->coeffs.p;
   ep.errors = c->errors.as<uint32_t>();
+  c->generic_codec = generic;
+  ep.lz_window = nullptr;
+  if (any_lz77) {
+    if ((r = c->lz_window.Ensure(size_t(d->num_groups) * jxlhip::kLzWindow * 4))) return r;
+    ep.lz_window = c->lz_window.as<uint32_t>();
+  }
+  if ((r = c->sec_end.Ensure(nsec * 4))) return r;
+  HIP_TRY(hipMemsetAsync(c->sec_end.p, 0, nsec * 4, c->stream));
+  ep.sec_end_bits = c->sec_end.as<uint32_t>();
   ep.lds_ctx_bytes = (nctx + 16 + 15) & ~15u;
   const size_t lds_budget = 150 * 1024;
   c->alias_lds = ep.lds_ctx_bytes + alias_bytes_max + 1024 + 4 * 5120 <= lds_budget;
@@ -501,7 +552,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (size_t(d->block_ctx_lut_size) < size_t(3) * 13 * ep.nq * ep.ndc) return JXLHIP_ERR_INVALID_ARGUMENT;
   // single-pass frames whose tables fit LDS are decoded by the lane-parallel kernel into scan order
   // (its packed block records hold the block contexts in 4 bits each: the codestream allows at most 16)
-  c->lanes = EntropyKernelChoice() == 2 && ep.num_bctx <= 16 && d->num_passes <= 8;
+  c->lanes = EntropyKernelChoice() == 2 && ep.num_bctx <= 16 && d->num_passes <= 8 && !generic;
   for (uint32_t p = 0; c->lanes && p < d->num_passes; p++)
     c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64).total <= kLdsBudget;
   c->scan_order = c->lanes && d->num_passes == 1;
@@ -642,7 +693,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   }
   memcpy(fp.opsin_inv, d->opsin_inv, sizeof(fp.opsin_inv));
   fp.linear_output = d->linear_output;
-  fp.rgb = c->rgb.as<uint8_t>();
+  fp.rgb = OutIsRgb8(c) ? c->rgb.as<uint8_t>() : nullptr;
+  fp.rgbf = !OutIsRgb8(c) && !c->color_out ? c->rgb.as<float>() : nullptr;
   c->epf_pass0 = d->epf_pass0_sigma_scale;
   c->epf_pass2 = d->epf_pass2_sigma_scale;
   c->epf_border = d->epf_border_sad_mul;
@@ -657,7 +709,9 @@ template <typename CoefT>
 static int LaunchEntropy(JxlHipContext* c) {
   const dim3 grid(c->ng), block(64);
   const bool use_uni = EntropyKernelChoice() != 0;
-  if (c->alias_lds && use_uni) {
+  if (c->generic_codec) {
+    hipLaunchKernelGGL(jxlhip::k_entropy_generic<CoefT>, grid, block, 3072, c->stream, c->ep);
+  } else if (c->alias_lds && use_uni) {
     // scalar-form kernel: alias tables, context map and uint configs shared in LDS by the waves of a workgroup
     const size_t shared = size_t(c->ep.lds_ctx_bytes) + c->ep.lds_alias_bytes + 1024;
     jxlhip::EntropyBatch b{c->ep_dev.as<jxlhip::EntropyParams>(), nullptr};
@@ -804,12 +858,19 @@ static void FillFusedParams(const JxlHipContext* c, jxlhip::FusedFilterParams* p
     p->sm[stage] = stage == 1 ? 1.65f : float(scale * 1.65);
     p->bsm[stage] = p->sm[stage] * c->epf_border;
   }
-  p->filtered = (c->keep_filtered || c->ups != 1) ? c->plane[1].as<float>() : nullptr;
-  if (c->ups != 1) p->f.rgb = nullptr;  // the upsampling kernel produces the pixels
+  p->filtered = (c->keep_filtered || c->ups != 1 || c->color_out) ? c->plane[1].as<float>() : nullptr;
+  if (c->ups != 1 || c->color_out) {
+    p->f.rgb = nullptr;
+    p->f.rgbf = nullptr;
+  }  // the upsampling / colour kernel produces the pixels
 }
 static int FilterKey(const JxlHipContext* c) {
   const int epf = c->epf_iters < 0 ? 0 : (c->epf_iters > 3 ? 3 : c->epf_iters);
   return (c->gab ? 4 : 0) + epf;
+}
+// The frame's filter stage runs on k_filter_rows2 (Gaborish + EPF1, the d1.0 configuration), which writes RGB f32 itself.
+static bool UsesRows2(const JxlHipContext* c) {
+  return FilterKey(c) == 5 && !EnvInt("JXLHIP_FILTER_TILES", 0) && !EnvInt("JXLHIP_FILTER_ROWS1", 0);
 }
 
 // Builds (or re-uses) the description of a set of frames for the batched transform and filter launches.
@@ -1202,7 +1263,7 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
     if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
     if (c->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
     if (!c->lanes || c->coef_bits != c0->coef_bits) all_scan = false;
-    if (c->lanes || !c->alias_lds || c->ep.num_hist != 1 || c->np != 1 || c->coef_bits != c0->coef_bits ||
+    if (c->lanes || c->generic_codec || !c->alias_lds || c->ep.num_hist != 1 || c->np != 1 || c->coef_bits != c0->coef_bits ||
         c->ng > 0xFFFF * kEntropyWPG || EntropyKernelChoice() == 0)
       all_uni = false;
   }
@@ -1307,14 +1368,36 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
   }
   for (size_t i = 0; i < n; i++) {
     const JxlHipContext* c = ctxs[i];
-    if (c->ups == 1) continue;
+    if (c->ups == 1 && !c->color_out) continue;
+    jxlhip::PixelOut po;
+    memset(&po, 0, sizeof(po));
+    if (c->color_out) {
+      po.dst = c->rgb.p;
+      po.alpha = c->have_alpha ? c->alpha.as<float>() : nullptr;
+      po.xsize = c->oxs;
+      po.type = c->out_type;
+      po.nc = c->out_nc;
+      po.bits = c->out_bits;
+      po.swap = c->out_swap;
+    }
+    if (c->ups == 1) {
+      jxlhip::ColorOutParams cp;
+      cp.f = c->fp;
+      cp.f.in = c->plane[1].as<float>();
+      cp.po = po;
+      hipLaunchKernelGGL(jxlhip::k_color_out, dim3((c->xs + 63) / 64, (c->band_y1 - c->band_y0 + 3) / 4), dim3(256), 0, ls, cp);
+      HIP_TRY(hipGetLastError());
+      continue;
+    }
     jxlhip::UpsampleParams up;
     up.f = c->fp;
     up.f.in = c->plane[1].as<float>();
+    up.f.rgb = c->rgb.as<uint8_t>();
     up.kernel = c->ups_kernel.as<float>();
     up.n = c->ups;
     up.oxs = c->oxs;
     up.oys = c->oys;
+    up.po = po;
     hipLaunchKernelGGL(jxlhip::k_upsample_color, dim3((c->xs + 63) / 64, (c->ys + 3) / 4), dim3(256), 0, ls, up);
     HIP_TRY(hipGetLastError());
   }
@@ -1355,6 +1438,50 @@ int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
   return JXLHIP_ERR_INVALID_ARGUMENT;
 }
 
+int jxlhip_set_output_format(JxlHipContext* c, uint32_t data_type, uint32_t num_channels, uint32_t bits_per_sample, int big_endian) {
+  if (!c || num_channels < 1 || num_channels > 4) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (data_type != 0 && data_type != 2 && data_type != 3 && data_type != 5) return JXLHIP_ERR_INVALID_ARGUMENT;
+  const uint32_t max_bits = data_type == 2 ? 8 : 16;
+  if (bits_per_sample == 0) bits_per_sample = max_bits;
+  if ((data_type == 2 || data_type == 3) && bits_per_sample > max_bits) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->out_type = data_type;
+  c->out_nc = num_channels;
+  c->out_bits = bits_per_sample;
+  c->out_swap = big_endian && data_type != 2 ? 1 : 0;
+  c->generation++;  // cached batch descriptions hold the pixel pointers
+  return 0;
+}
+
+int jxlhip_set_alpha(JxlHipContext* c, const float* alpha, uint32_t xsize, uint32_t ysize) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!alpha) {
+    c->have_alpha = false;
+    return 0;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = size_t(xsize) * ysize * 4;
+  int r = c->alpha.Ensure(bytes);
+  if (r) return r;
+  HIP_TRY(hipMemcpy(c->alpha.p, alpha, bytes, hipMemcpyHostToDevice));
+  c->have_alpha = true;
+  return 0;
+}
+
+int jxlhip_download_pixels(JxlHipContext* c, void* dst, size_t stride) {
+  if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  const size_t row = size_t(c->oxs) * OutPixelBytes(c);
+  if (stride < row) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, row, row, c->oys, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int jxlhip_run_all(JxlHipContext* c) {
   int r = jxlhip_run_entropy(c);
   if (!r) r = jxlhip_run_transform(c);
@@ -1376,7 +1503,7 @@ int jxlhip_sync(JxlHipContext* c) {
 int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
   if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  if (stride < size_t(c->oxs) * 3) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (stride < size_t(c->oxs) * 3 || !OutIsRgb8(c)) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   {
     int pw = ApplyPendingWait(c);
@@ -1390,7 +1517,7 @@ int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
 int jxlhip_download_rgb8_rows(JxlHipContext* c, uint8_t* dst, size_t stride, uint32_t y_begin, uint32_t y_end) {
   if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  if (stride < size_t(c->oxs) * 3 || y_begin >= y_end || y_end > c->oys) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (stride < size_t(c->oxs) * 3 || y_begin >= y_end || y_end > c->oys || !OutIsRgb8(c)) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   {
     int pw = ApplyPendingWait(c);
@@ -1417,6 +1544,20 @@ int jxlhip_get_errors(JxlHipContext* c, uint32_t* flags, size_t n) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   for (uint32_t g = 0; g < c->ng; g++)
     if (flags[g]) return JXLHIP_ERR_STREAM;
+  return 0;
+}
+
+int jxlhip_get_section_end_bits(JxlHipContext* c, uint32_t* bits, size_t n) {
+  if (!c || !bits) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  if (n < size_t(c->ng) * c->np) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  HIP_TRY(hipMemcpyAsync(bits, c->sec_end.p, size_t(c->ng) * c->np * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 

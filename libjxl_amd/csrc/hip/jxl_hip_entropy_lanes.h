@@ -16,9 +16,11 @@
 //     the hot loop extracts bits with one ds_read2 + v_alignbit at the lane's bit position, the ring is topped up
 //     with 16-byte global loads in the service phase only;
 //   * coefficients are written in SCAN order (position k of the coefficient order, zeros included) with
-//     fire-and-forget stores, plus the number of valid entries per (block, channel) in `kend`; the transform kernels
-//     apply the order permutation when they stage a block into LDS. No zero fill of the coefficient buffer, no
-//     order-table lookup and no dependent load in the decode loop.
+//     fire-and-forget stores of aligned 8-byte chunks (four int16 at a time, collected in a register pair: a lane's
+//     stores are uncoalesced by nature, and the memory pipeline serialises such a wave-instruction per lane), plus the
+//     number of valid entries per (block, channel) in `kend`; the transform kernels apply the order permutation when
+//     they stage a block into LDS. No zero fill of the coefficient buffer, no order-table lookup and no dependent load
+//     in the decode loop.
 //
 // Control flow is a per-lane state machine kept convergent on the hot part:
 //   RUN   a coefficient token is pending                       -> the hot trip (one shared code sequence)
@@ -110,6 +112,10 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
     bitpos += sh;
     const uint32_t se = ctxe & 15;
     const bool take = tok >= (1u << se);
+    // Tokens with extra bits are rare (|coefficient| >= 8 at the usual split of 16): the wave is bound by instruction
+    // issue (one instruction per four cycles for a lone wave: rocprofv3 SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU), so the
+    // ~25 instructions of the extra-bits path are skipped when no lane needs them (a wave-uniform branch).
+    if (!__builtin_amdgcn_ballot_w64(take)) return tok;
     const uint32_t msb = (ctxe >> 4) & 15, lsb = (ctxe >> 8) & 15;
     const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
     const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
@@ -210,7 +216,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   uint32_t b1 = 0, bi = 0, ci = 2;
   const uint4* stream4 = reinterpret_cast<const uint4*>(P.sections);
   const uint4* const rec4 = reinterpret_cast<const uint4*>(P.block_recs);
-  uint32_t* const kend_out = P.kend + size_t(pass) * P.kend_pass_stride;
+  typedef uint32_t __attribute__((address_space(1)))* GU32W;  // (global, not generic: a flat store also ticks the LDS counter)
+  const GU32W kend_out = (GU32W)(uintptr_t)(P.kend + size_t(pass) * P.kend_pass_stride);
   uint32_t nwords = 0, sec_size = 0, ring_end = 0, bring_end = 0, bitpos = 0, state = 0, ctx_base = 0;
   bool started = false;
   // block / channel cursor
@@ -237,8 +244,12 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   // current token turns out zero (same non-zero count, prev = 0) / non-zero (one fewer to come, prev = 1)
   // (addr_b is kept as cbase + 1 + nnz_b with nnz_b the raw table value: the add happens where addr_b is used, so the
   // table read issued at the end of a trip is only waited for after the next trip has issued its other LDS reads)
-  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, nnz_b = 0, ctxe = 0, dptr = 0, kidx = 0;
-  CoefT* const coeffs = static_cast<CoefT*>(P.coeffs) + P.coef_pass_base + size_t(pass) * P.coef_pass_stride;
+  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, nnz_b = 0, ctxe = 0, dbase = 0, kidx = 0;
+  uint32_t acc_lo = 0, acc_hi = 0;  // the coefficient chunk in progress
+  typedef CoefT __attribute__((address_space(1)))* GCoef;
+  typedef uint32_t U32x2 __attribute__((ext_vector_type(2)));
+  typedef U32x2 __attribute__((address_space(1)))* G64W;
+  const GCoef coeffs = (GCoef)(uintptr_t)(static_cast<CoefT*>(P.coeffs) + P.coef_pass_base + size_t(pass) * P.coef_pass_stride);
   const uint32_t shift = T.shift;
 
   unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, t_hot0 = 0, t_hot1 = 0, t_land = 0;
@@ -290,6 +301,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           if (bi >= b1) {  // section complete (or abandoned after an error): on to the next one of the unit
             if (state != (0x13u << 16)) err |= kErrFinalState;
             if (bitpos > sec_size * 8) err |= kErrOverread;
+            P.sec_end_bits[sec0 + g] = bitpos;
             // every section's flag word is written (the host does not clear the array); the passes of a progressive frame
             // share a group's word, which the host clears before the launch
             if (P.num_passes > 1) atomicOr(P.errors + g, err);
@@ -340,7 +352,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
                 k = covered;
                 covm1 = covered - 1;
                 cbase = L.ctx + ctx_base + num_bctx * 37 + 458 * bctx;
-                dptr = (g * 3 + c) * 65536 + coef_offset + covered;
+                dbase = (g * 3 + c) * 65536 + coef_offset;  // (a multiple of 64 entries: chunks are 8-byte aligned)
+                acc_lo = acc_hi = 0;
                 const uint32_t prev = nzeros > size / 16 ? 0 : 1;
                 addr_a = cbase + l_nnz2[((nzeros + covm1) >> log2c) & 63];
                 nnz_b = l_nnz2[((nzeros - 1 + covm1) >> log2c) & 63];
@@ -409,8 +422,18 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         const uint32_t tok = LaneSymbol<true>(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
         const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
         const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
-        if (!(B.debug & 1)) coeffs[dptr] = CoefT(coeff);
-        dptr++;
+        // Coefficients leave in aligned 8-byte chunks (4 x int16 / 2 x int32), shifted into a register pair from the top:
+        // a lane's stores go to 64 different cache lines, and the memory pipeline takes such a wave-instruction one lane
+        // at a time (~8 cycles each: scripts/ubench_trip.hip), so one 2-byte store per token caps the whole chip at
+        // ~67 G tokens/s. The chunk of scan positions [4j, 4j + 4) is stored when position 4j + 3 has been decoded or the
+        // (block, channel) ends; entries outside [covered, kend) of a chunk are unspecified (the transforms never read them).
+        if (sizeof(CoefT) == 2) {
+          acc_lo = __builtin_amdgcn_alignbit(acc_hi, acc_lo, 16);
+          acc_hi = (acc_hi >> 16) | (uint32_t(coeff) << 16);
+        } else {
+          acc_lo = acc_hi;
+          acc_hi = uint32_t(coeff);
+        }
         if (B.debug & 2) ntok++;
         k = kn;
         const bool nz = tok != 0;
@@ -418,6 +441,17 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         ctxe = nz ? e_nonzero : e_zero;
         addr_a = nz ? addr_b - 1 : addr_a;
         nnz_b = nz ? nnz_c : nnz_b;
+        constexpr uint32_t kPerChunk = 8 / sizeof(CoefT);
+        const uint32_t part = k & (kPerChunk - 1);  // entries of the chunk in progress
+        if (part == 0 || nzeros == 0) {
+          uint32_t lo = acc_lo, hi = acc_hi;
+          if (part) {  // a partial last chunk: its entries sit at the top of the pair
+            const uint64_t v = ((uint64_t(hi) << 32) | lo) >> ((kPerChunk - part) * (64 / kPerChunk));
+            lo = uint32_t(v);
+            hi = uint32_t(v >> 32);
+          }
+          if (!(B.debug & 1)) *(G64W)(coeffs + (dbase + ((k - 1) & ~(kPerChunk - 1)))) = U32x2{lo, hi};
+        }
         if (nzeros == 0) {
           kend_out[kidx] = k;
           mode = kWait;

@@ -190,7 +190,38 @@ struct UpsampleParams {
   FilterParams f;       // f.in = filtered XYB planes of the frame, f.rgb = image-sized output
   const float* kernel;  // [N * N][25]
   uint32_t n, oxs, oys;
+  PixelOut po;          // po.dst != NULL: the image in this format instead of RGB8 in f.rgb
 };
+
+// XYB -> linear RGB -> (sRGB) for one pixel (stage_xyb.cc:80-92 + dec_xyb-inl.h:38-86, stage_from_linear.cc:114-144).
+__device__ __forceinline__ void XybToRgb(const FilterParams& f, float X, float Y, float Bc, float* r, float* g, float* b) {
+  const float gr = (Y + X) - f.opsin_bias_cbrt[0], gg = (Y - X) - f.opsin_bias_cbrt[1], gb = Bc - f.opsin_bias_cbrt[2];
+  const float mr = (gr * gr) * gr + f.opsin_bias[0], mg = (gg * gg) * gg + f.opsin_bias[1], mb = (gb * gb) * gb + f.opsin_bias[2];
+  *r = f.opsin_inv[2] * mb + (f.opsin_inv[1] * mg + f.opsin_inv[0] * mr);
+  *g = f.opsin_inv[5] * mb + (f.opsin_inv[4] * mg + f.opsin_inv[3] * mr);
+  *b = f.opsin_inv[8] * mb + (f.opsin_inv[7] * mg + f.opsin_inv[6] * mr);
+  if (!f.linear_output) {
+    *r = LinearToSrgb(*r);
+    *g = LinearToSrgb(*g);
+    *b = LinearToSrgb(*b);
+  }
+}
+
+// Colour conversion + write for the output formats the filter kernels do not produce themselves (anything but RGB8,
+// and RGB f32 on the row-streaming kernel): the filter kernel leaves the filtered XYB planes, this kernel makes the pixels.
+struct ColorOutParams {
+  FilterParams f;  // f.in = filtered XYB planes; y_begin / y_end = rows to produce
+  PixelOut po;
+};
+__global__ __launch_bounds__(256) void k_color_out(ColorOutParams P) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = int(P.f.y_begin) + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= int(P.f.xs) || y >= int(P.f.y_end)) return;
+  const size_t plane = size_t(P.f.xp) * P.f.yp, gi = size_t(y) * P.f.xp + x;
+  float r, g, b;
+  XybToRgb(P.f, P.f.in[gi], P.f.in[plane + gi], P.f.in[2 * plane + gi], &r, &g, &b);
+  StorePixel(P.po, x, y, r, g, b);
+}
+
 __global__ __launch_bounds__(256) void k_upsample_color(UpsampleParams P) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int xs = int(P.f.xs), ys = int(P.f.ys);
@@ -245,6 +276,10 @@ __global__ __launch_bounds__(256) void k_upsample_color(UpsampleParams P) {
         r = LinearToSrgb(r);
         g = LinearToSrgb(g);
         b = LinearToSrgb(b);
+      }
+      if (P.po.dst) {
+        StorePixel(P.po, X, Y, r, g, b);
+        continue;
       }
       uint8_t* dst = P.f.rgb + (size_t(Y) * P.oxs + X) * 3;
       dst[0] = ToU8(r, X, Y, 0);
@@ -497,6 +532,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
   const GF32 dither = (GF32)(uintptr_t)c_dither;
   const GF32W filtered = (GF32W)(uintptr_t)P.filtered;
   const GU8W rgb = (GU8W)(uintptr_t)P.f.rgb;
+  const GF32W rgbf = (GF32W)(uintptr_t)P.f.rgbf;
   int dcol[2][3];
 #pragma unroll
   for (int e = 0; e < 2; e++)
@@ -615,7 +651,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
             if (emit1) filtered[c * gplane + gi + 1] = o[c].y;
           }
         }
-        if (rgb) {
+        if (rgb || rgbf) {
           const f2 X = o[0], Y = o[1], Bc = o[2];
           const f2 gr = (Y + X) - P.f.opsin_bias_cbrt[0], gg = (Y - X) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
           const f2 mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
@@ -627,9 +663,27 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
             cg = LinearToSrgb2(cg);
             cb = LinearToSrgb2(cb);
           }
+          const size_t off = (size_t(r) * xs + x) * 3;
+          if (rgbf) {  // float output (stage_write.cc:334-370): the samples as they are
+            const GF32W d = rgbf + off;
+            if (emit1 && (off & 1) == 0) {  // six floats from an 8-byte aligned offset
+              typedef f2 __attribute__((address_space(1)))* GF32x2W;
+              *(GF32x2W)(d) = f2{cr.x, cg.x};
+              *(GF32x2W)(d + 2) = f2{cb.x, cr.y};
+              *(GF32x2W)(d + 4) = f2{cg.y, cb.y};
+            } else {
+              d[0] = cr.x;
+              d[1] = cg.x;
+              d[2] = cb.x;
+              if (emit1) {
+                d[3] = cr.y;
+                d[4] = cg.y;
+                d[5] = cb.y;
+              }
+            }
+          } else {
           const uint32_t b0 = ToU8D(cr.x, di[0].x), b1 = ToU8D(cg.x, di[1].x), b2 = ToU8D(cb.x, di[2].x);
           const uint32_t b3 = ToU8D(cr.y, di[0].y), b4 = ToU8D(cg.y, di[1].y), b5 = ToU8D(cb.y, di[2].y);
-          const size_t off = (size_t(r) * xs + x) * 3;
           const GU8W dst = rgb + off;
           if (emit1 && (off & 1) == 0) {  // six bytes from an even offset: three 16-bit stores
             const GU16W d16 = (GU16W)dst;
@@ -645,6 +699,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
               dst[4] = uint8_t(b4);
               dst[5] = uint8_t(b5);
             }
+          }
           }
         }
       }

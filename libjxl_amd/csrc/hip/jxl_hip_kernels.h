@@ -17,6 +17,7 @@
 #define JXL_HIP_KERNELS_H_
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #include "../../../include/jxl_amd_hip.h"
@@ -64,6 +65,10 @@ struct PassDev {
   const uint16_t* orders;
   uint32_t order_offset[39];
   uint32_t log_alpha, num_clusters, shift, alias_lds;
+  // prefix-coded and / or LZ77 streams (k_entropy_generic): see JxlHipPassDesc
+  uint32_t use_prefix, lz77, lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_ctx;
+  const uint32_t* prefix_table;
+  const uint32_t* prefix_offset;
 };
 
 struct EntropyParams {
@@ -90,7 +95,13 @@ struct EntropyParams {
   uint32_t kend_pass_stride;
   // per block, for k_entropy_lanes: lbx | lby << 5 | strategy << 10 | qf bucket << 15 | dc bucket << 19 (16-byte aligned, padded)
   const uint32_t* block_recs;
+  // [pass * num_groups + group]: bit position (from the section's first byte) where the coefficient stream ended. The
+  // host needs it for sections that carry Modular data of extra channels behind the coefficients (dec_frame.cc:511-542).
+  uint32_t* sec_end_bits;
+  // LZ77 streams (k_entropy_generic): window of the values decoded so far, kLzWindow entries per section of one pass
+  uint32_t* lz_window;
 };
+constexpr uint32_t kLzWindow = 1u << 18;  // a section decodes fewer than 3 * (65536 + 1024) values: never wraps
 
 struct BitReader {
   const uint32_t* p;
@@ -274,6 +285,193 @@ __global__ __launch_bounds__(64) void k_entropy_ans(EntropyParams P) {
     {
       const uint64_t consumed = uint64_t(br.idx) * 32 - uint64_t(br.bits);
       if (consumed > uint64_t(P.sec_size[sec]) * 8) err |= kErrOverread;
+      P.sec_end_bits[sec] = uint32_t(consumed);
+    }
+    if (err) atomicOr(&P.errors[g], err);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- entropy, every code
+// The streams libjxl's fastest and slowest efforts write: prefix codes instead of rANS (dec_huffman.h:28-41, dec_ans.h:
+// 170-197) and / or LZ77 copies of earlier values (dec_ans.h:288-353). Same walk as k_entropy_ans, tables in global
+// memory, one lane per section: the correctness path for these streams, not a tuned one.
+struct GenericReader {
+  BitReader br;
+  uint32_t state;
+  const PassDev* T;
+  uint32_t* window;
+  uint32_t num_decoded, num_to_copy, copy_pos;
+  uint32_t err;
+};
+__device__ __forceinline__ uint32_t GenericSymbol(GenericReader& r, uint32_t cluster) {
+  const PassDev& T = *r.T;
+  BrRefill(r.br);
+  if (T.use_prefix) {
+    const uint32_t po = T.prefix_offset[cluster], max_len = po >> 24;
+    if (max_len == 0) return T.prefix_table[po & 0xFFFFFFu] >> 8;
+    const uint32_t e = T.prefix_table[(po & 0xFFFFFFu) + uint32_t(r.br.buf & ((1u << max_len) - 1))];
+    BrRead(r.br, e & 0xFF);
+    return e >> 8;
+  }
+  const uint32_t log_entry = 12 - T.log_alpha;
+  const uint32_t res = r.state & 0xFFFu, i = res >> log_entry, pos = res & ((1u << log_entry) - 1);
+  const uint2 e = T.alias[(cluster << T.log_alpha) + i];
+  const uint32_t cutoff = e.x & 0xFF, right = (e.x >> 8) & 0xFF, freq0 = e.x >> 16, offsets1 = e.y & 0xFFFF, freq1 = e.y >> 16;
+  const bool greater = pos >= cutoff;
+  r.state = (greater ? freq1 : freq0) * (r.state >> 12) + (greater ? offsets1 : 0u) + pos;
+  if (r.state < (1u << 16)) r.state = (r.state << 16) | BrRead(r.br, 16);
+  return greater ? right : i;
+}
+__device__ __forceinline__ uint32_t GenericUint(GenericReader& r, uint32_t cfg, uint32_t token) {
+  const uint32_t split_exp = cfg & 0xFF, msb = (cfg >> 8) & 0xFF, lsb = (cfg >> 16) & 0xFF;
+  if (token < (1u << split_exp)) return token;
+  const uint32_t nbits = (split_exp - (msb + lsb) + ((token - (1u << split_exp)) >> (msb + lsb))) & 31u;
+  const uint32_t low = token & ((1u << lsb) - 1), hi = token >> lsb;
+  BrRefill(r.br);
+  const uint32_t bits = BrRead(r.br, nbits);
+  return (((((1u << msb) | (hi & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
+}
+__device__ __forceinline__ uint32_t GenericRead(GenericReader& r, uint32_t cluster) {
+  const PassDev& T = *r.T;
+  if (T.lz77 && r.num_to_copy > 0) {
+    const uint32_t v = r.window[(r.copy_pos++) & (kLzWindow - 1)];
+    r.num_to_copy--;
+    r.window[(r.num_decoded++) & (kLzWindow - 1)] = v;
+    return v;
+  }
+  const uint32_t token = GenericSymbol(r, cluster);
+  if (T.lz77 && token >= T.lz_min_symbol) {
+    r.num_to_copy = GenericUint(r, T.lz_len_cfg, token - T.lz_min_symbol) + T.lz_min_length;
+    const uint32_t dtok = GenericSymbol(r, T.lz_dist_ctx);
+    uint32_t distance = GenericUint(r, T.cfg[T.lz_dist_ctx], dtok) + 1;  // (no special distances without a multiplier)
+    if (distance > r.num_decoded) distance = r.num_decoded;
+    if (distance > kLzWindow) distance = kLzWindow;
+    r.copy_pos = r.num_decoded - distance;
+    if (r.num_to_copy < T.lz_min_length || r.num_decoded + r.num_to_copy > kLzWindow) {  // length overflow / more than a section holds
+      r.err |= kErrNzeros;
+      r.num_to_copy = 0;
+      return 0;
+    }
+    const uint32_t v = distance == 0 ? 0u : r.window[(r.copy_pos++) & (kLzWindow - 1)];
+    r.num_to_copy--;
+    r.window[(r.num_decoded++) & (kLzWindow - 1)] = v;
+    return v;
+  }
+  const uint32_t v = GenericUint(r, T.cfg[cluster], token);
+  if (T.lz77) r.window[(r.num_decoded++) & (kLzWindow - 1)] = v;
+  return v;
+}
+
+template <typename CoefT>
+__global__ __launch_bounds__(64) void k_entropy_generic(EntropyParams P) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
+  uint8_t* l_nz = lds_raw;  // 3 * 1024
+  const uint32_t b0 = P.gbb[g], b1 = P.gbb[g + 1];
+  CoefT* gco = static_cast<CoefT*>(P.coeffs) + size_t(g) * 3 * 65536;
+  uint32_t total = 0;
+  if (b1 > b0) {
+    const JxlHipVarBlock last = P.blocks[b1 - 1];
+    total = last.coef_offset + (64u << c_log2_covered[last.strategy]);
+  }
+  {
+    const uint32_t n16 = (total * uint32_t(sizeof(CoefT))) / 16;
+    for (int c = 0; c < 3; c++) {
+      uint4* dst = reinterpret_cast<uint4*>(gco + size_t(c) * 65536);
+      for (uint32_t i = lane; i < n16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  for (uint32_t pass = 0; pass < P.num_passes; pass++) {
+    const PassDev& T = P.passes[pass];
+    const uint32_t sec = pass * P.num_groups + g;
+    __syncthreads();
+    for (uint32_t i = lane; i < 3 * 1024; i += 64) l_nz[i] = 0;
+    __threadfence_block();
+    __syncthreads();
+    if (lane != 0) continue;
+    GenericReader r;
+    r.T = &T;
+    r.window = P.lz_window ? P.lz_window + size_t(g) * kLzWindow : nullptr;  // (passes run one after the other)
+    r.num_decoded = r.num_to_copy = r.copy_pos = 0;
+    r.err = 0;
+    r.br.p = P.sections + P.sec_word[sec];
+    r.br.nwords = (P.sec_size[sec] + 3) / 4;
+    r.br.idx = 0;
+    r.br.buf = 0;
+    r.br.bits = 0;
+    BrRefill(r.br);
+    if (sec == 0 && P.first_bit_offset) BrRead(r.br, P.first_bit_offset);
+    uint32_t hb = 0;
+    while ((1u << hb) < P.num_hist) hb++;
+    BrRefill(r.br);
+    uint32_t sel = hb ? BrRead(r.br, hb) : 0;
+    if (sel >= P.num_hist) {
+      r.err |= kErrSelector;
+      sel = 0;
+    }
+    r.state = 0x13u << 16;
+    if (!T.use_prefix) {  // dec_ans.cc:402: only an ANS stream starts with its state
+      BrRefill(r.br);
+      r.state = BrRead(r.br, 16);
+      BrRefill(r.br);
+      r.state |= BrRead(r.br, 16) << 16;
+    }
+    const uint8_t* ctx_map = T.ctx_map + size_t(sel) * P.nctx;
+    const uint32_t shift = T.shift;
+    for (uint32_t bi = b0; bi < b1 && !r.err; bi++) {
+      const JxlHipVarBlock vb = P.blocks[bi];
+      const uint32_t st = vb.strategy;
+      const uint32_t cx = c_covered_x[st], cy = c_covered_y[st], log2c = c_log2_covered[st];
+      const uint32_t covered = 1u << log2c, size = covered * 64;
+      const uint32_t ord = c_strategy_order[st];
+      uint32_t qfi = 0;
+      for (uint32_t t = 0; t + 1 < P.nq; t++) qfi += vb.qf > P.qf_thr[t];
+      const uint32_t lbx = vb.bx & 31, lby = vb.by & 31;
+#pragma unroll 1
+      for (int ci = 0; ci < 3 && !r.err; ci++) {
+        const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+        uint8_t* nzc = l_nz + c * 1024;
+        uint32_t pred;
+        if (lbx == 0) pred = lby ? nzc[(lby - 1) * 32] : 32;
+        else if (lby == 0) pred = nzc[lbx - 1];
+        else pred = (uint32_t(nzc[(lby - 1) * 32 + lbx]) + nzc[lby * 32 + lbx - 1] + 1) >> 1;
+        const uint32_t bctx = P.bctx_lut[((c * 13 + ord) * P.nq + qfi) * P.ndc + vb.quant_dc_ctx];
+        uint32_t nzb = pred >= 64 ? 64 : pred;
+        nzb = nzb < 8 ? nzb : 4 + nzb / 2;
+        uint32_t nzeros = GenericRead(r, ctx_map[nzb * P.num_bctx + bctx]);
+        if (nzeros > size - covered) {
+          r.err |= kErrNzeros;
+          break;
+        }
+        const uint8_t nzv = uint8_t((nzeros + covered - 1) >> log2c);
+        for (uint32_t y = 0; y < cy; y++)
+          for (uint32_t x = 0; x < cx; x++) nzc[(lby + y) * 32 + lbx + x] = nzv;
+        const uint32_t hoff = P.num_bctx * 37 + 458 * bctx;
+        const uint16_t* order = T.orders + T.order_offset[ord * 3 + c];
+        CoefT* dst = gco + size_t(c) * 65536 + vb.coef_offset;
+        uint32_t prev = nzeros > size / 16 ? 0 : 1;
+        for (uint32_t k = covered; k < size && nzeros != 0 && !r.err; ++k) {
+          const uint32_t nzl = (nzeros + covered - 1) >> log2c;
+          const uint32_t ctx = hoff + (uint32_t(c_coeff_nnz_ctx[nzl & 63]) + c_coeff_freq_ctx[(k >> log2c) & 63]) * 2 + prev;
+          const uint32_t u = GenericRead(r, ctx_map[ctx]);
+          const uint32_t mag = u >> 1, neg = (~u) & 1;
+          const int32_t coeff = int32_t((mag ^ (neg - 1)) << shift);
+          if (u) {
+            const uint32_t pos = order[k];
+            dst[pos] = CoefT(dst[pos] + coeff);
+          }
+          prev = u != 0;
+          nzeros -= prev;
+        }
+        if (nzeros != 0) r.err |= kErrNzeros;
+      }
+    }
+    uint32_t err = r.err;
+    if (!err && r.state != (0x13u << 16)) err |= kErrFinalState;
+    {
+      const uint64_t consumed = uint64_t(r.br.idx) * 32 - uint64_t(r.br.bits);
+      if (consumed > uint64_t(P.sec_size[sec]) * 8) err |= kErrOverread;
+      P.sec_end_bits[sec] = uint32_t(consumed);
     }
     if (err) atomicOr(&P.errors[g], err);
   }
@@ -603,6 +801,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_uni(EntropyBatch B) {
     {
       const uint64_t consumed = uint64_t(idx) * 32 - uint64_t(bits);
       if (consumed > uint64_t(sec_size) * 8) err |= kErrOverread;
+      if (lane == 0) P.sec_end_bits[sec] = uint32_t(consumed);
     }
     if (err && lane == 0) atomicOr(&P.errors[g], err);
   }
@@ -1398,7 +1597,16 @@ struct FilterParams {
   // colour
   float opsin_inv[9], opsin_bias[3], opsin_bias_cbrt[3];
   int32_t linear_output;
-  uint8_t* rgb;
+  uint8_t* rgb;  // interleaved RGB8 (xs * 3 bytes per row), or NULL
+  float* rgbf;   // interleaved RGB f32 (stage_write.cc:334-370 StoreFloatRow), or NULL; honoured by k_filter_rows2 only
+};
+
+// Every output format of the boundary (JxlPixelFormat; stage_write.cc:266-286,334-370,548-590): written by k_color_out
+// and k_upsample_color. `type` uses the JxlDataType values (0 f32, 2 u8, 3 u16, 5 f16).
+struct PixelOut {
+  void* dst;           // interleaved, tightly packed rows of xsize * nc samples
+  const float* alpha;  // plane of the image size in [0, 1], or NULL (opaque)
+  uint32_t xsize, type, nc, bits, swap;  // bits: sample depth of the unsigned types; swap: byte-swapped (big endian) samples
 };
 
 __device__ __forceinline__ int MirrorI(int x, int n) {
@@ -1430,6 +1638,40 @@ __device__ __forceinline__ uint8_t ToU8D(float v, float dither) {  // dither = c
 }
 __device__ __forceinline__ uint8_t ToU8(float v, int x, int y, int c) {
   return ToU8D(v, c_dither[((y + c * 13) & 31) * 32 + ((x + c * 23) & 31)]);
+}
+
+// One pixel in any output format. Colour images hand out R (and alpha) when fewer than three channels are asked for,
+// like the reference (stage_write.cc:334-370: num_color_ = 1); 8-bit samples are dithered with the channel's interleave
+// index (stage_write.cc:266-286), wider ones are not.
+__device__ __forceinline__ void StorePixel(const PixelOut& o, int x, int y, float r, float g, float b) {
+  const uint32_t nc = o.nc, ncol = nc < 3 ? 1u : 3u;
+  float v[4] = {r, g, b, 1.0f};
+  if (nc == 2 || nc == 4) {
+    const float a = o.alpha ? o.alpha[size_t(y) * o.xsize + x] : 1.0f;
+    v[ncol] = a;
+  }
+  const size_t base = (size_t(y) * o.xsize + x) * nc;
+  for (uint32_t c = 0; c < nc; c++) {
+    const float f = v[c];
+    if (o.type == 2) {
+      const float mul = float((1u << o.bits) - 1u);
+      const float t = __builtin_amdgcn_fmed3f(f * mul + c_dither[((y + int(c) * 13) & 31) * 32 + ((x + int(c) * 23) & 31)], 0.0f, mul);
+      static_cast<uint8_t*>(o.dst)[base + c] = uint8_t(__float2int_rn(t));
+    } else if (o.type == 3) {
+      const float mul = float((1u << o.bits) - 1u);
+      uint32_t u = uint32_t(__float2int_rn(__builtin_amdgcn_fmed3f(f * mul, 0.0f, mul)));
+      if (o.swap) u = ((u & 0xFF) << 8) | (u >> 8);
+      static_cast<uint16_t*>(o.dst)[base + c] = uint16_t(u);
+    } else if (o.type == 5) {
+      uint32_t u = __half_as_ushort(__float2half_rn(f));
+      if (o.swap) u = ((u & 0xFF) << 8) | (u >> 8);
+      static_cast<uint16_t*>(o.dst)[base + c] = uint16_t(u);
+    } else {
+      uint32_t u = __float_as_uint(f);
+      if (o.swap) u = __builtin_bswap32(u);
+      static_cast<uint32_t*>(o.dst)[base + c] = u;
+    }
+  }
 }
 
 }  // namespace jxlhip

@@ -10,6 +10,7 @@
 
 #include <functional>
 #include <chrono>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,9 @@ struct PassTables {
   std::vector<uint32_t> uint_cfg;       // per cluster: split_exp | msb << 8 | lsb << 16
   std::vector<uint16_t> orders;         // [13 buckets][3 channels] -> order_offset[]; natural or custom
   uint32_t order_offset[39];            // start of (bucket, channel) in `orders` (in entries)
+  // prefix-coded streams: one flat lookup table per cluster (JxlHipPassDesc::prefix_table / prefix_offset)
+  std::vector<uint32_t> prefix_table, prefix_offset;
+  uint32_t lz_min_symbol = 0, lz_min_length = 0, lz_len_cfg = 0, lz_dist_ctx = 0;
 };
 
 struct FramePlan {
@@ -75,6 +79,15 @@ struct FramePlan {
   // single-section frames: AC data starts mid-byte inside the one section
   uint32_t first_section_bit_offset = 0;
   size_t frame_end = 0;  // byte offset just after the frame
+  // Extra channels (alpha, ...): Modular-coded beside the VarDCT colour (dec_frame.cc:511-542, dec_modular.cc:209-425).
+  // `extra` is the frame's global Modular image; channels no larger than a group are complete after the DC global
+  // section, the others continue in every AC group section BEHIND the coefficient stream, whose end only the entropy
+  // decoder knows: FrameParser::FinishExtraChannels() takes the section end positions the GPU stage reports.
+  MImage extra;
+  bool extra_pending = false;   // group-coded channel data still to be decoded (FinishExtraChannels)
+  std::vector<uint64_t> toc_section_offset;  // all TOC sections (for FinishExtraChannels): byte offset in the buffer
+  std::vector<uint32_t> toc_section_size;
+  MGlobal mglobal;  // the frame's global MA tree + code (Modular streams of the AC groups use it)
 };
 
 // Optional parallel-for hook (the JxlParallelRunner of the public API is adapted onto this).
@@ -106,7 +119,7 @@ class FrameParser {
           hdr = 16;
         }
         if (bsize == 0) bsize = n - pos;
-        JXH_CHECK(bsize >= hdr && pos + bsize <= n, "bad box size");
+        JXH_CHECK(bsize >= hdr && bsize <= n - pos, "bad box size");  // (no addition: a 64-bit size cannot wrap)
         if (!memcmp(d + pos + 4, "jxlc", 4)) {
           codestream_base_ = pos + hdr;
           cs_size_ = bsize - hdr;
@@ -142,7 +155,9 @@ class FrameParser {
     JXH_CHECK(fh.upsampling == 1 || !ih.custom_upsampling, "unsupported: custom upsampling weights");
     JXH_CHECK(!fh.custom_size, "unsupported: cropped frames");
     JXH_CHECK(fh.is_last, "unsupported: multiple frames");
-    JXH_CHECK(ih.extra.empty(), "unsupported: extra channels");
+    for (size_t e = 0; e < ih.extra.size(); e++)
+      JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
+    JXH_CHECK(ih.extra.empty() || fh.upsampling == 1, "unsupported: extra channels of upsampled frames");
     JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
               "unsupported: patches/splines/noise/DC frames");
     P.dim = MakeFrameDim(fh);
@@ -192,13 +207,15 @@ class FrameParser {
       }
       const auto t1 = now();
       std::string err;
+      std::mutex err_mu;  // DC groups run on the caller's threads: the first failure is kept
       pfor(d.num_dc_groups, [&](size_t g) {
         try {
           BitReader r(data_ + base + toc.offset[1 + g], toc.size[1 + g]);
           DcGroup(r, &P, g);
           JXH_CHECK(!r.Overread(), "DC group over-read");
         } catch (const std::exception& e) {
-          err = e.what();
+          std::lock_guard<std::mutex> lk(err_mu);
+          if (err.empty()) err = e.what();
         }
       });
       JXH_CHECK(err.empty(), err);
@@ -222,6 +239,10 @@ class FrameParser {
         }
     }
     BuildBlockLists(&P);
+    if (!P.extra.ch.empty()) {
+      P.extra_pending = ExtraHasGroupData(P);
+      if (!P.extra_pending) UndoExtraTransforms(&P);
+    }
   }
 
  private:
@@ -248,14 +269,88 @@ class FrameParser {
     P->inv_global_scale = 65536.0f / float(P->global_scale);
     P->x_dm = std::pow(1.25f, 2.0f - float(P->fh.x_qm_scale));
     P->b_dm = std::pow(1.25f, 2.0f - float(P->fh.b_qm_scale));
+    MGlobal& mglobal_ = P->mglobal;
     if (br.ReadBool()) {
-      size_t limit = std::min<size_t>(size_t(1) << 22, 1024 + P->dim.xsize * P->dim.ysize / 16);
+      const size_t nb = std::max<size_t>(P->ih.extra.size(), 1);
+      size_t limit = std::min<size_t>(size_t(1) << 22, 1024 + P->dim.xsize * P->dim.ysize * nb / 16);
       DecodeTree(br, &mglobal_.tree, limit);
       DecodeHistograms(br, (mglobal_.tree.size() + 1) / 2, &mglobal_.code);
       mglobal_.have = true;
     }
-    // VarDCT frame without extra channels: the global Modular image has no channels, nothing more to read.
+    // Global Modular image = the extra channels (a VarDCT frame codes its colour elsewhere). Stream 0 holds the channels
+    // no larger than a group; the transforms stay pending until every channel is complete (dec_modular.cc:209-318).
+    P->extra.ch.clear();
+    P->extra.bitdepth = int(P->ih.bits);
+    for (size_t e = 0; e < P->ih.extra.size(); e++) P->extra.ch.emplace_back(P->dim.xsize, P->dim.ysize);
+    ModularDecode(br, &P->extra, 0, &mglobal_, P->dim.group_dim, /*undo_transforms=*/false);
   }
+
+  // Part of the global Modular image covered by a rectangle, for the channels whose shift lies in [min_shift, max_shift]
+  // (dec_modular.cc:320-425): DC groups carry the channels squeezed 8x or more, AC groups the rest.
+  static void DecodeExtraRect(BitReader& br, FramePlan* P, size_t x0, size_t y0, size_t xs, size_t ys, int min_shift, int max_shift,
+                              int stream_id) {
+    MImage& full = P->extra;
+    size_t c = full.nb_meta;
+    const size_t gdim = P->dim.group_dim;
+    while (c < full.ch.size() && full.ch[c].w <= gdim && full.ch[c].h <= gdim) c++;  // those came with stream 0
+    MImage part;
+    part.bitdepth = full.bitdepth;
+    struct Place {
+      size_t c, x, y;
+    };
+    std::vector<Place> places;
+    for (; c < full.ch.size(); c++) {
+      const MChannel& fc = full.ch[c];
+      const int shift = std::min(fc.hshift, fc.vshift);
+      if (shift < min_shift || shift > max_shift) continue;
+      const size_t rx = x0 >> fc.hshift, ry = y0 >> fc.vshift;
+      if (rx >= fc.w || ry >= fc.h) continue;
+      const size_t rw = std::min(xs >> fc.hshift, fc.w - rx), rh = std::min(ys >> fc.vshift, fc.h - ry);
+      if (!rw || !rh) continue;
+      part.ch.emplace_back(rw, rh, fc.hshift, fc.vshift);
+      places.push_back({c, rx, ry});
+    }
+    if (part.ch.empty()) return;
+    ModularDecode(br, &part, stream_id, &P->mglobal);
+    for (size_t i = 0; i < places.size(); i++) {
+      MChannel& fc = full.ch[places[i].c];
+      for (size_t y = 0; y < part.ch[i].h; y++)
+        memcpy(fc.Row(places[i].y + y) + places[i].x, part.ch[i].Row(y), part.ch[i].w * sizeof(int32_t));
+    }
+  }
+  static bool ExtraHasGroupData(const FramePlan& P) {
+    for (size_t c = P.extra.nb_meta; c < P.extra.ch.size(); c++)
+      if (P.extra.ch[c].w > P.dim.group_dim || P.extra.ch[c].h > P.dim.group_dim) return true;
+    return false;
+  }
+  static void UndoExtraTransforms(FramePlan* P) {
+    for (size_t i = P->extra.transforms.size(); i-- > 0;) InverseTransform(&P->extra, P->extra.transforms[i]);
+    P->extra.transforms.clear();
+    JXH_CHECK(P->extra.ch.size() == P->ih.extra.size(), "extra channels: channel count after the transforms");
+  }
+
+ public:
+  // Completes the extra channels of a frame whose AC group sections carry Modular data behind the coefficients.
+  // sec_end_bit[pass * num_groups + group] = bit position (from the start of the section) where that section's
+  // coefficient stream ended, as reported by the entropy stage (jxlhip_get_section_end_bits).
+  static void FinishExtraChannels(const uint8_t* data, FramePlan* P, const uint32_t* sec_end_bit) {
+    if (!P->extra_pending) return;
+    const FrameDim& d = P->dim;
+    const size_t np = P->fh.num_passes;
+    for (size_t g = 0; g < d.num_groups; g++) {
+      const size_t i = (np - 1) * d.num_groups + g;  // (streams without progressive-downsampling info: last pass only)
+      BitReader r(data + P->section_offset[i], P->section_size[i]);
+      r.Skip(sec_end_bit[i] - (i == 0 ? 0 : 0));
+      const size_t gx = g % d.xsize_groups, gy = g / d.xsize_groups;
+      DecodeExtraRect(r, P, gx * d.group_dim, gy * d.group_dim, d.group_dim, d.group_dim, 0, 2,
+                      int(1 + 3 * d.num_dc_groups + 17 + d.num_groups * (np - 1) + g));
+      JXH_CHECK(!r.Overread(), "AC group: Modular data over-read");
+    }
+    UndoExtraTransforms(P);
+    P->extra_pending = false;
+  }
+
+ private:
 
   void DcGroup(BitReader& br, FramePlan* P, size_t g) {
     const FrameDim& d = P->dim;
@@ -268,7 +363,7 @@ class FrameParser {
       float mul = 1.0f / float(1 << extra_precision);
       MImage img;
       for (int c = 0; c < 3; c++) img.ch.emplace_back(bw, bh);
-      ModularDecode(br, &img, int(1 + g), &mglobal_);
+      ModularDecode(br, &img, int(1 + g), &P->mglobal);
       const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
       float fac[3];
       for (int c = 0; c < 3; c++) fac[c] = (inv_quant_dc * dq_.dc_quant[c]) * mul;
@@ -298,6 +393,10 @@ class FrameParser {
         }
       }
     }
+    if (!P->extra.ch.empty()) {  // Modular DC group: channels of the global image squeezed 8x or more (stream 1 + ndc + g)
+      std::lock_guard<std::mutex> lk(extra_mu_);  // (DC groups run on several threads; the channel list is shared)
+      DecodeExtraRect(br, P, bx0 * 8, by0 * 8, d.dc_group_dim, d.dc_group_dim, 3, 1000, int(1 + ndc + g));
+    }
     {
       size_t count = size_t(br.Read(CeilLog2(bw * bh))) + 1;
       MImage img;
@@ -306,7 +405,7 @@ class FrameParser {
       img.ch.emplace_back(cw, ch, 3, 3);
       img.ch.emplace_back(count, 2, 0, 0);
       img.ch.emplace_back(bw, bh, 0, 0);
-      ModularDecode(br, &img, int(1 + 2 * ndc + g), &mglobal_);
+      ModularDecode(br, &img, int(1 + 2 * ndc + g), &P->mglobal);
       const size_t tiles_x = DivCeil(xb, 8);
       for (size_t y = 0; y < ch; y++)
         for (size_t x = 0; x < cw; x++) {
@@ -449,14 +548,29 @@ class FrameParser {
       T.log_alpha = code.log_alpha;
       T.num_clusters = code.num_clusters;
       T.max_num_bits = code.max_num_bits;
-      T.ctx_map = code.ctx_map;
+      T.ctx_map = code.ctx_map;  // (an LZ77 stream's extra distance context sits at the end: kept in lz_dist_ctx)
+      T.ctx_map.resize(nctx);
       T.ctx_map.resize(nctx + 16, 0);
       T.alias = code.alias;
       T.uint_cfg.resize(code.num_clusters);
       for (size_t k = 0; k < code.num_clusters; k++)
         T.uint_cfg[k] = code.cfg[k].split_exp | (code.cfg[k].msb << 8) | (code.cfg[k].lsb << 16);
-      JXH_CHECK(!T.use_prefix, "unsupported on the GPU path: prefix-coded AC coefficients");
-      JXH_CHECK(!T.lz77, "unsupported on the GPU path: LZ77 in AC coefficients");
+      if (T.use_prefix) {
+        T.alias.clear();
+        T.prefix_offset.resize(code.num_clusters);
+        for (size_t k = 0; k < code.num_clusters; k++) {
+          const PrefixCode& pc = code.prefix[k];
+          T.prefix_offset[k] = uint32_t(T.prefix_table.size()) | (uint32_t(pc.max_len) << 24);
+          JXH_CHECK(T.prefix_table.size() + pc.sym.size() < (size_t(1) << 24), "prefix tables too large");
+          for (size_t i = 0; i < pc.sym.size(); i++) T.prefix_table.push_back(uint32_t(pc.len[i]) | (uint32_t(pc.sym[i]) << 8));
+        }
+      }
+      if (T.lz77) {
+        T.lz_min_symbol = code.lz_min_symbol;
+        T.lz_min_length = code.lz_min_length;
+        T.lz_len_cfg = code.lz_len_cfg.split_exp | (code.lz_len_cfg.msb << 8) | (code.lz_len_cfg.lsb << 16);
+        T.lz_dist_ctx = code.lz_dist_ctx;
+      }
     }
     // block-context LUT: [c][ord][qf_idx][dc_ctx]
     const BlockCtxMap& bc = P->bctx;
@@ -507,7 +621,7 @@ class FrameParser {
   size_t size_;
   size_t codestream_base_ = 0, cs_size_ = 0;
   DequantTables dq_;
-  MGlobal mglobal_;
+  std::mutex extra_mu_;
   int32_t ytox_dc_ = 0, ytob_dc_ = 0;
   std::vector<uint16_t> quant_;
   std::vector<uint8_t> sharp_, quant_dc_ctx_;

@@ -1,10 +1,10 @@
-// libjxl_amd host front-end (product code; runs on the CPU ahead of the GPU hot path).
-// self-correcting weighted predictor), per-channel pixel decode, inverse RCT.
+// libjxl_amd host front-end (product code; runs on the CPU ahead of the GPU hot path): Modular sub-bitstreams — MA tree,
+// predictors (incl. the self-correcting weighted predictor), per-channel pixel decode, inverse RCT / Palette / Squeeze.
 // Follows: reference lib/jxl/modular/encoding/dec_ma.cc:107-182 (tree), encoding.cc:148-506 (channel
 // decode; this file restates the generic path, the reference's specialised fast paths are equivalent),
 // encoding.cc:554-724 (stream layout), context_predict.h:38-330 (weighted predictor), :372-560
-// (properties, predictors), modular/transform/transform.cc:36-100, rct.cc:30-147.
-// Squeeze and Palette are not implemented yet (raise jxh::Error).
+// (properties, predictors), modular/transform/transform.cc:36-100, rct.cc:30-147, palette.cc:26-202,
+// squeeze.cc:128-517 + squeeze.h:54-77.
 #ifndef JXH_MODULAR_H_
 #define JXH_MODULAR_H_
 
@@ -26,10 +26,15 @@ struct MChannel {
   const int32_t* Row(size_t y) const { return d.data() + y * w; }
 };
 
+struct SqueezeStep {  // one entry of a Squeeze transform (modular/transform/squeeze_params.cc:14-24)
+  bool horizontal = false, in_place = false;
+  uint32_t begin_c = 0, num_c = 2;
+};
 struct MTransform {
   uint32_t id = 0;  // 0 RCT, 1 Palette, 2 Squeeze
   uint32_t begin_c = 0, rct_type = 6;
   uint32_t num_c = 3, nb_colors = 256, nb_deltas = 0, predictor = 0;
+  std::vector<SqueezeStep> steps;  // Squeeze; empty in the stream = the default sequence (filled in by SqueezeMeta)
 };
 
 struct WpHeader {
@@ -305,8 +310,82 @@ static inline void ReadTransform(BitReader& br, MTransform* t) {
     t->predictor = uint32_t(br.Read(4));
     JXH_CHECK(t->predictor < 14, "invalid palette predictor");
   }
-  if (t->id == 2) throw Error("unsupported: Squeeze transform");
+  if (t->id == 2) {  // transform.cc:77-87
+    t->steps.resize(ReadU32(br, Val(0), BitsOffset(4, 1), BitsOffset(6, 9), BitsOffset(8, 41)));
+    for (SqueezeStep& q : t->steps) {
+      q.horizontal = br.ReadBool();
+      q.in_place = br.ReadBool();
+      q.begin_c = ReadU32(br, Bits(3), BitsOffset(6, 8), BitsOffset(10, 72), BitsOffset(13, 1096));
+      q.num_c = ReadU32(br, Val(1), Val(2), Val(3), BitsOffset(4, 4));
+    }
+  }
 }
+
+// ---- Squeeze (a Haar-like split of a channel into pair averages and residuals, squeeze.cc). One strided line routine
+// serves both directions: `avg` holds na averages, `res` nr residuals (nr = na or na - 1), `out` receives na + nr samples.
+// Residual i is (first - second of pair i) minus the tendency predicted from the sample before the pair, this pair's
+// average and the next one (squeeze.h:54-77); the average rounds towards the first sample.
+static inline int64_t SqueezeTendency(int64_t before, int64_t avg, int64_t next) {
+  const bool falling = before >= avg && avg >= next, rising = before <= avg && avg <= next;
+  if (!falling && !rising) return 0;
+  int64_t t = (4 * before - 3 * next - avg + (falling ? 6 : -6)) / 12;
+  const int64_t odd = t & 1, lim_a = 2 * (before - avg), lim_b = 2 * (avg - next);
+  if (falling) {
+    if (t - odd > lim_a) t = lim_a + 1;
+    if (t + (t & 1) > lim_b) t = lim_b;
+  } else {
+    if (t + odd < lim_a) t = lim_a - 1;
+    if (t - (t & 1) < lim_b) t = lim_b;
+  }
+  return t;
+}
+static inline void UnsqueezeLine(const int32_t* avg, ptrdiff_t sa, size_t na, const int32_t* res, ptrdiff_t sr, size_t nr, int32_t* out,
+                                 ptrdiff_t so) {
+  int64_t before = 0;
+  for (size_t i = 0; i < nr; i++) {
+    const int64_t a = avg[ptrdiff_t(i) * sa], next = i + 1 < na ? avg[ptrdiff_t(i + 1) * sa] : a;
+    if (i == 0) before = a;
+    const int64_t diff = int64_t(res[ptrdiff_t(i) * sr]) + SqueezeTendency(before, a, next);
+    const int64_t first = a + diff / 2, second = first - diff;
+    out[ptrdiff_t(2 * i) * so] = int32_t(first);
+    out[ptrdiff_t(2 * i + 1) * so] = int32_t(second);
+    before = second;
+  }
+  if (na > nr) out[ptrdiff_t(2 * nr) * so] = avg[ptrdiff_t(na - 1) * sa];
+}
+// Default step list (squeeze.cc:387-444): chroma-like channel pairs first, then alternate directions down to 8x8.
+static inline void DefaultSqueeze(const std::vector<MChannel>& ch, size_t nb_meta, std::vector<SqueezeStep>* steps) {
+  const size_t first = nb_meta, count = ch.size() - nb_meta;
+  size_t w = ch[first].w, h = ch[first].h;
+  steps->clear();
+  auto push = [&](bool horizontal, bool in_place, size_t begin, size_t num) {
+    SqueezeStep q;
+    q.horizontal = horizontal;
+    q.in_place = in_place;
+    q.begin_c = uint32_t(begin);
+    q.num_c = uint32_t(num);
+    steps->push_back(q);
+  };
+  if (count > 2 && ch[first + 1].w == w && ch[first + 1].h == h) {
+    push(true, false, first + 1, 2);
+    push(false, false, first + 1, 2);
+  }
+  if (w <= h && h > 8) {  // tall (or square) images start with a vertical step
+    push(false, true, first, count);
+    h = (h + 1) / 2;
+  }
+  while (w > 8 || h > 8) {
+    if (w > 8) {
+      push(true, true, first, count);
+      w = (w + 1) / 2;
+    }
+    if (h > 8) {
+      push(false, true, first, count);
+      h = (h + 1) / 2;
+    }
+  }
+}
+
 
 static inline void InvRct(MImage* img, const MTransform& t) {
   size_t m = t.begin_c;
@@ -458,13 +537,82 @@ static inline void InvPalette(MImage* img, const MTransform& t) {
   img->ch.erase(img->ch.begin());
 }
 
-static inline void MetaApply(MImage* img, const MTransform& t) {
+// Channel list after the squeeze steps (squeeze.cc:456-517): every squeezed channel halves along the step's direction
+// and gains a residual channel, right behind the range (in place) or at the end of the list.
+static inline void SqueezeMeta(MImage* img, MTransform* t) {
+  if (t->steps.empty()) DefaultSqueeze(img->ch, img->nb_meta, &t->steps);
+  for (const SqueezeStep& q : t->steps) {
+    const size_t n = img->ch.size(), b = q.begin_c, e = size_t(q.begin_c) + q.num_c;  // [b, e)
+    JXH_CHECK(q.num_c >= 1 && b < n && e <= n, "squeeze: invalid channel range");
+    if (b < img->nb_meta) {
+      JXH_CHECK(e <= img->nb_meta && q.in_place, "squeeze: bad meta channel range");
+      img->nb_meta += q.num_c;
+    }
+    size_t at = q.in_place ? e : n;
+    for (size_t c = b; c < e; c++, at++) {
+      MChannel& src = img->ch[c];
+      JXH_CHECK(src.w && src.h, "squeeze of an empty channel");
+      JXH_CHECK(src.hshift <= 30 && src.vshift <= 30, "squeeze: too many steps");
+      size_t rw = src.w, rh = src.h;
+      if (q.horizontal) {
+        src.w = (src.w + 1) / 2;
+        rw -= src.w;
+        if (src.hshift >= 0) src.hshift++;
+      } else {
+        src.h = (src.h + 1) / 2;
+        rh -= src.h;
+        if (src.vshift >= 0) src.vshift++;
+      }
+      src.d.assign(src.w * src.h, 0);
+      MChannel residual(rw, rh, src.hshift, src.vshift);
+      img->ch.insert(img->ch.begin() + at, residual);
+    }
+  }
+}
+static inline void SqueezeInverse(MImage* img, const MTransform& t) {
+  for (size_t k = t.steps.size(); k-- > 0;) {
+    const SqueezeStep& q = t.steps[k];
+    const size_t b = q.begin_c, e = size_t(q.begin_c) + q.num_c;
+    JXH_CHECK(e <= img->ch.size(), "squeeze: invalid channel range");
+    const size_t first_res = q.in_place ? e : img->ch.size() + b - e;
+    JXH_CHECK(first_res >= e && first_res + q.num_c <= img->ch.size(), "squeeze: residual channels missing");
+    if (b < img->nb_meta) {
+      JXH_CHECK(img->nb_meta >= q.num_c, "squeeze: meta channel bookkeeping");
+      img->nb_meta -= q.num_c;
+    }
+    for (size_t c = b; c < e; c++) {
+      MChannel& a = img->ch[c];
+      const MChannel& r = img->ch[first_res + (c - b)];
+      if (q.horizontal) {
+        JXH_CHECK(a.w == (a.w + r.w + 1) / 2 && a.h == r.h, "squeeze: channel sizes do not match");
+        MChannel out(a.w + r.w, a.h, a.hshift - 1, a.vshift);
+        if (r.w == 0) out.d = a.d;
+        else
+          for (size_t y = 0; y < a.h; y++) UnsqueezeLine(a.Row(y), 1, a.w, r.Row(y), 1, r.w, out.Row(y), 1);
+        img->ch[c] = out;
+      } else {
+        JXH_CHECK(a.h == (a.h + r.h + 1) / 2 && a.w == r.w, "squeeze: channel sizes do not match");
+        MChannel out(a.w, a.h + r.h, a.hshift, a.vshift - 1);
+        if (r.h == 0) out.d = a.d;
+        else
+          for (size_t x = 0; x < a.w; x++)
+            UnsqueezeLine(a.d.data() + x, ptrdiff_t(a.w), a.h, r.d.data() + x, ptrdiff_t(r.w), r.h, out.d.data() + x, ptrdiff_t(out.w));
+        img->ch[c] = out;
+      }
+    }
+    img->ch.erase(img->ch.begin() + first_res, img->ch.begin() + first_res + q.num_c);
+  }
+}
+
+static inline void MetaApply(MImage* img, MTransform& t) {
   if (t.id == 0) CheckEqualChannels(*img, t.begin_c, t.begin_c + 2);
   else if (t.id == 1) MetaPalette(img, t);
+  else SqueezeMeta(img, &t);
 }
 static inline void InverseTransform(MImage* img, const MTransform& t) {
   if (t.id == 0) InvRct(img, t);
   else if (t.id == 1) InvPalette(img, t);
+  else SqueezeInverse(img, t);
 }
 
 // Decodes one Modular stream into `img` (whose channels are pre-sized) and undoes its transforms.

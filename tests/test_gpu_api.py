@@ -1,0 +1,147 @@
+"""GPU tests (-m gpu) of the drop-in boundary and of the stream features libjxl's other efforts use: every output format
+of JxlPixelFormat, callbacks, containers and chunked input through the plain-C replay of the reference's DecodeImageJXL
+sequence; the reference's own VarDCT + alpha stream through the HIP kernels; prefix-coded and LZ77 AC streams."""
+import os
+
+import numpy as np
+import pytest
+
+import replay_util as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_float(jxlo, data):
+    o = jxlo.Decoded(data)
+    f = o.planes("rgbf").transpose(1, 2, 0).copy()  # HxWx3 float, before the 8-bit conversion
+    rgb8 = o.rgb8.copy()
+    o.close()
+    return f, rgb8
+
+
+def test_float_output_matches_oracle_float(built, tmp_path):
+    """JXL_TYPE_FLOAT (what benchmark_xl and djxl --disable_output ask for: benchmark_codec_jxl.cc:313,
+    djxl_main.cc:599-600) is written by the row-streaming filter kernel itself (stage_write.cc:334-370)."""
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(333, 222, seed=5))
+    ref_f, _ = _oracle_float(jxlo, data)
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+    assert rc == 0 and events[-2:] == ["FULL_IMAGE", "SUCCESS"], out
+    got = np.frombuffer(px, np.float32).reshape(222, 333, 3)
+    assert np.abs(got - ref_f).max() < 3e-5  # float samples in [0, 1]: the bar of the float planes, through the sRGB curve
+    # other filter configurations take the generic writer (k_color_out): same bar
+    for kw in (dict(epf_iters=2), dict(gab=0, epf_iters=0), dict(upsampling=2)):
+        data = J.encode_rgb8(J.synth_image(200, 150, seed=7), **kw)
+        ref_f, _ = _oracle_float(jxlo, data)
+        rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+        assert rc == 0, out
+        got = np.frombuffer(px, np.float32).reshape(150, 200, 3)
+        assert np.abs(got - ref_f).max() < 3e-5, kw
+
+
+@pytest.mark.parametrize("fmt,channels,extra", [("u8", 4, ()), ("u8", 3, ("callback",)), ("u16", 3, ()), ("u16", 4, ("mt",)),
+                                                ("f16", 3, ()), ("f32", 4, ("callback",)), ("u8", 3, ("chunk=1000",))])
+def test_every_pixel_format_and_delivery(built, tmp_path, fmt, channels, extra):
+    """Formats follow stage_write.cc: u8 = round(clamp(v * 255 + dither)), u16 = round(clamp(v * 65535)) (no dither),
+    f16 / f32 = the float sample; alpha of an image without alpha is opaque; buffer, callback and multithreaded
+    callback deliver the same pixels."""
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(257, 131, seed=11))
+    ref_f, ref_8 = _oracle_float(jxlo, data)
+    rc, events, out, px = R.run(R.container(data) if "chunk=1000" in extra else data, tmp_path, fmt, channels, *extra)
+    assert rc == 0, out
+    dt = {"u8": np.uint8, "u16": np.uint16, "f16": np.float16, "f32": np.float32}[fmt]
+    got = np.frombuffer(px, dt).reshape(131, 257, channels)
+    if fmt == "u8":
+        assert np.abs(got[..., :3].astype(int) - ref_8.astype(int)).max() <= 1
+    elif fmt == "u16":
+        want = np.rint(np.clip(ref_f * 65535.0, 0, 65535))
+        assert np.abs(got[..., :3].astype(np.int64) - want).max() <= 3  # 3e-5 of float difference
+    else:
+        assert np.abs(got[..., :3].astype(np.float32) - ref_f).max() < (2e-3 if fmt == "f16" else 3e-5)
+    if channels == 4:
+        opaque = {"u8": 255, "u16": 65535, "f16": 1.0, "f32": 1.0}[fmt]
+        assert (got[..., 3] == opaque).all()
+    if "mt" in extra:
+        assert "mt init=1 destroy=1" in out
+
+
+def test_linear_output(built, tmp_path):
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(200, 100, seed=2))
+    ref_f, _ = _oracle_float(jxlo, data)
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3, "linear")
+    assert rc == 0 and "COLOR_ENCODING tf=8" in out, out
+    got = np.frombuffer(px, np.float32).reshape(100, 200, 3)
+    srgb = np.where(got <= 0.0031308, got * 12.92, 1.055 * np.power(np.maximum(got, 1e-12), 1 / 2.4) - 0.055)
+    assert np.abs(srgb - ref_f).max() < 2e-3  # the same image, one transfer function apart
+    assert np.abs(got - ref_f).max() > 0.05
+
+
+def test_reference_vardct_alpha_stream_through_the_gpu(built, tmp_path):
+    """The one libjxl-made VarDCT codestream in the reference tree (lib/jxl/decode_test.cc:2512-2517: 1x1, VarDCT colour,
+    prefix-coded AC, a Squeeze-coded alpha channel) through the product: host front-end, HIP kernels, RGBA out. The
+    reference asserts only statuses for it; here the GPU pixel must equal the independent decoder's."""
+    import jxlo
+    J = built
+    data = open(os.path.join(ROOT, "tests", "golden", "ref_decode_test_1x1.jxl"), "rb").read()
+    o = jxlo.Decoded(data)
+    want = o.rgb8.copy()
+    assert want.shape == (1, 1, 4)
+    rc, events, out, px = R.run(data, tmp_path, "u8", 4)
+    assert rc == 0 and events == ["BASIC_INFO", "COLOR_ENCODING", "FRAME", "NEED_IMAGE_OUT_BUFFER", "FULL_IMAGE", "SUCCESS"], out
+    got = np.frombuffer(px, np.uint8).reshape(1, 1, 4)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    assert got[0, 0, 3] == want[0, 0, 3]  # alpha is integer work: exact
+    # stage by stage, like every other stream: coefficients bit-exact, planes within the float bar
+    f = J.Frame(data)
+    c = J.HipContext()
+    c.upload(f)
+    c.run_entropy()
+    c.sync()
+    r, flags = c.errors()
+    assert r == 0
+    assert np.array_equal(c.download("coeffs").astype(np.int32)[0, :, :64], o.planes("coeffs")[0, :, :64])
+    c.run_transform()
+    c.sync()
+    assert np.abs(c.download("xyb_idct") - o.planes("xyb_idct")).max() < 2e-5
+    c.close()
+    f.close()
+    o.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_prefix_coded_and_lz77_ac_streams(built, mode):
+    """AC streams as libjxl's fastest efforts (prefix codes, dec_huffman.h:28-41) and slowest efforts (LZ77,
+    dec_ans.h:288-353) write them: k_entropy_generic, coefficients bit-exact, pixels within the usual bar."""
+    import jxlo
+    from test_gpu_parity import _compare
+    J = built
+    data = J.encode_rgb8(J.synth_image(520, 300, seed=3), ac_code_mode=mode)
+    base = J.encode_rgb8(J.synth_image(520, 300, seed=3))
+    rgb = _compare(J, jxlo, data)
+    assert np.abs(rgb.astype(int) - J.decode_rgb8(base).astype(int)).max() <= 1  # same image as the rANS stream
+    _compare(J, jxlo, J.encode_random(300, 260, seed=5 + mode, ac_code_mode=mode))
+    _compare(J, jxlo, J.encode_rgb8(J.synth_image(300, 200, seed=4), ac_code_mode=mode, num_passes=2, num_histograms=3))
+
+
+def test_image_with_alpha_in_group_sections(built, tmp_path):
+    """An alpha channel larger than a group continues behind the coefficients of every AC group section
+    (dec_frame.cc:511-542): the entropy stage reports where each coefficient stream ended, the host decodes from there."""
+    import jxlo
+    J = built
+    rgb = J.synth_image(600, 300, seed=8)
+    alpha = ((np.mgrid[0:300, 0:600][1] * 255) // 599).astype(np.uint8)
+    data = J.encode_rgba8(np.dstack([rgb, alpha]))
+    o = jxlo.Decoded(data, dumps=False)
+    want = o.rgb8.copy()
+    assert want.shape == (300, 600, 4) and np.array_equal(want[..., 3], alpha)
+    rc, events, out, px = R.run(data, tmp_path, "u8", 4)
+    assert rc == 0, out
+    got = np.frombuffer(px, np.uint8).reshape(300, 600, 4)
+    assert np.array_equal(got[..., 3], alpha)
+    assert np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1

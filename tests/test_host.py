@@ -63,6 +63,12 @@ def test_host_rejects_bad_input(built):
     golden = os.path.join(ROOT, "tests", "golden", "fjxl_37x29_rgba_e2.jxl")
     with pytest.raises(J.JxlAmdError, match="unsupported"):
         J.Frame(open(golden, "rb").read())
+    # container boxes whose 64-bit size would wrap an offset computation: refused, nothing read past the buffer
+    sig = b"\0\0\0\x0cJXL \r\n\x87\n"
+    for size64 in (0xFFFFFFFFFFFFFFF0, 0xFFFFFFFFFFFFFFFF, 1 << 63, len(data) + 1000):
+        evil = sig + b"\0\0\0\x01jxlc" + size64.to_bytes(8, "big") + data
+        with pytest.raises(J.JxlAmdError, match="box"):
+            J.Frame(evil)
 
 
 def test_no_gpu_means_loud_failure(built):
@@ -206,3 +212,79 @@ def test_band_partition_of_group_rows():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         sharding.band_of(4, 2, 2)
+
+
+def test_c_program_replays_reference_call_sequence(built, tmp_path):
+    """tests/c/replay_decode.c makes the calls of lib/extras/dec/jxl.cc:140-669 (incl. SetCms, box buffers, JPEG buffer
+    calls, the caller's memory manager) from plain C: it must LINK against the .so and see the reference's event order.
+    Without a GPU the decode stops at the pixels (exit code 3: by design there is no CPU pixel path)."""
+    import replay_util as R
+    J = built
+    have_gpu = J.lib().jxlhip_device_count() > 0
+    data = J.encode_rgb8(J.synth_image(300, 200))
+    want_rc = 0 if have_gpu else 3
+    head = ["BASIC_INFO", "COLOR_ENCODING", "FRAME", "NEED_IMAGE_OUT_BUFFER"]
+    tail = ["FULL_IMAGE", "SUCCESS"] if have_gpu else ["ERROR"]
+    rc, events, out, _ = R.run(data, tmp_path, "f32", 3)
+    assert rc == want_rc, out
+    assert events == head + tail, out
+    assert "memory manager: allocs=" in out and "allocs=0" not in out
+    # container with the codestream split over two jxlp boxes, fed in 777-byte pieces: box events for every box in file
+    # order, NEED_MORE_INPUT until the frame is complete, then the same events
+    rc, events, out, _ = R.run(R.container(data), tmp_path, "u8", 4, "chunk=777")
+    assert rc == want_rc, out
+    boxes = [l.split(" ", 2)[2] for l in out.splitlines() if l.startswith("event BOX")]
+    assert boxes == ["JXL ", "ftyp", "Exif", "jxlp", "xml ", "jxlp"], out
+    core = [e for e in events if e not in ("BOX", "NEED_MORE_INPUT")]
+    assert core == head + tail, out
+    assert events.count("NEED_MORE_INPUT") > 10
+    assert events.index("BASIC_INFO") < events.index("NEED_MORE_INPUT") < events.index("FRAME")
+    # truncated file: NEED_MORE_INPUT at the end, like decode.cc:1505-1517
+    rc, events, out, _ = R.run(data[: len(data) // 2], tmp_path, "u8", 3, "chunk=4096")
+    assert rc == 1 and events[-1] in ("NEED_MORE_INPUT", "ERROR"), out
+    # the reference's own VarDCT + alpha stream: one extra channel of type alpha reported
+    ref = open(os.path.join(ROOT, "tests", "golden", "ref_decode_test_1x1.jxl"), "rb").read()
+    rc, events, out, _ = R.run(ref, tmp_path, "u8", 4)
+    assert rc == want_rc, out
+    assert "BASIC_INFO 1x1 bits=8 extra=1 alpha_bits=8" in out and "extra channel 0 type=0 bits=8" in out
+    assert events[:4] == head
+
+
+def test_decoder_output_color_profile_reaches_the_frame(built):
+    """JxlDecoderSetOutputColorProfile(linear) must change what the decode produces AND what GetColorAsEncodedProfile
+    reports for the data target (decode.cc:2810); other profiles are refused."""
+    J = built
+    L = J.lib()
+    vp = ctypes.c_void_p
+    L.JxlDecoderCreate.restype = vp
+    L.JxlDecoderCreate.argtypes = [vp]
+    for n in ("JxlDecoderDestroy", "JxlDecoderProcessInput", "JxlDecoderCloseInput"):
+        getattr(L, n).argtypes = [vp]
+    L.JxlDecoderSubscribeEvents.argtypes = [vp, ctypes.c_int]
+    L.JxlDecoderSetInput.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+
+    class CE(ctypes.Structure):
+        _fields_ = [("color_space", ctypes.c_int), ("white_point", ctypes.c_int), ("white_point_xy", ctypes.c_double * 2),
+                    ("primaries", ctypes.c_int), ("red", ctypes.c_double * 2), ("green", ctypes.c_double * 2),
+                    ("blue", ctypes.c_double * 2), ("transfer_function", ctypes.c_int), ("gamma", ctypes.c_double),
+                    ("rendering_intent", ctypes.c_int)]
+
+    L.JxlDecoderGetColorAsEncodedProfile.argtypes = [vp, ctypes.c_int, ctypes.POINTER(CE)]
+    L.JxlDecoderSetOutputColorProfile.argtypes = [vp, ctypes.POINTER(CE), vp, ctypes.c_size_t]
+    data = J.encode_rgb8(J.synth_image(64, 64))
+    dec = L.JxlDecoderCreate(None)
+    assert L.JxlDecoderSubscribeEvents(dec, 0x100 | 0x400) == 0
+    L.JxlDecoderSetInput(dec, data, len(data))
+    L.JxlDecoderCloseInput(dec)
+    assert L.JxlDecoderProcessInput(dec) == 0x100
+    ce = CE()
+    assert L.JxlDecoderGetColorAsEncodedProfile(dec, 1, ctypes.byref(ce)) == 0 and ce.transfer_function == 13
+    ce.transfer_function = 16  # PQ: not available on this path
+    assert L.JxlDecoderSetOutputColorProfile(dec, ctypes.byref(ce), None, 0) == 1
+    ce.transfer_function = 8  # linear
+    assert L.JxlDecoderSetOutputColorProfile(dec, ctypes.byref(ce), None, 0) == 0
+    out = CE()
+    assert L.JxlDecoderGetColorAsEncodedProfile(dec, 1, ctypes.byref(out)) == 0 and out.transfer_function == 8
+    assert L.JxlDecoderGetColorAsEncodedProfile(dec, 0, ctypes.byref(out)) == 0 and out.transfer_function == 13  # original
+    assert L.JxlDecoderProcessInput(dec) == 0x400
+    L.JxlDecoderDestroy(dec)
