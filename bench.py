@@ -29,13 +29,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable rate
 
 
-def make_stream(xsize, ysize, distance, seed=177):
+def make_stream(xsize, ysize, distance, seed=177, max_clusters=0):
     import libjxl_amd as J
-    cache = "/tmp/libjxl_amd_bench_%dx%d_d%.2f_s%d.jxl" % (xsize, ysize, distance, seed)
+    cache = "/tmp/libjxl_amd_bench_%dx%d_d%.2f_s%d_c%d.jxl" % (xsize, ysize, distance, seed, max_clusters)
     if os.path.exists(cache):
         return open(cache, "rb").read()
     img = J.synth_image(xsize, ysize, seed)
-    data = J.encode_rgb8(img, distance=distance, strategy_mode=1)
+    data = J.encode_rgb8(img, distance=distance, strategy_mode=1, max_clusters=max_clusters)
     try:
         tmp = cache + ".%d" % os.getpid()
         open(tmp, "wb").write(data)
@@ -65,6 +65,117 @@ def cpu_baseline(data, xsize, ysize, budget_s=20.0):
     best = min(times)
     return {"value": round(xsize * ysize * 1e-6 / best, 3), "unit": "MP/s", "cores": cores, "kind": "port",
             "sample": "%d full %dx%d frame decode(s) of the benchmark stream, best of %d" % (len(times), xsize, ysize, len(times))}
+
+
+def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
+    """End-to-end rate over `nframes` frames: from compressed bytes in host memory to RGB8 in (pinned) host memory, the span
+    djxl times (tools/djxl_main.cc:415-422, tools/speed_stats.cc:107). Host parse (headers, DC groups, tables: libjxl_amd's
+    host front-end), upload, the three GPU stages and the download of the pixels run as a pipeline over host threads, in
+    chunks of `chunk` frames (an entropy launch lasts as long as its slowest section whatever the number of frames, so
+    small chunks would only measure that latency): parser pool -> uploaders -> GPU stages -> downloaders, three context
+    sets rotating. Not `value`: PCIe and host bound."""
+    import concurrent.futures
+    import queue
+    import threading
+    import torch
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    chunk = max(1, min(chunk, nframes))
+    parse_threads = 4 if ncpu >= 32 else 1
+    parsers = max(1, min(16, (ncpu - 8) // parse_threads))
+    movers = 4 if ncpu >= 16 else 1  # threads of the upload pool and of the download pool
+    nsets = 3
+    sets = [[J.HipContext(device) for _ in range(chunk)] for _ in range(nsets)]
+    free_sets = queue.Queue()
+    for cs in sets:
+        free_sets.put(cs)
+    q_up, q_down = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+    # pinned (page-locked) host buffers for the pixels, one per context
+    pinned = [torch.empty((ysize, xsize, 3), dtype=torch.uint8, pin_memory=True) for _ in range(chunk * nsets)]
+    outs = {id(c): pinned[i * chunk + j].numpy() for i, cs in enumerate(sets) for j, c in enumerate(cs)}
+    errors = []
+    done = [0]
+
+    def uploader(futs, pool):
+        try:
+            for c0 in range(0, nframes, chunk):
+                fr = [f.result() for f in futs[c0:c0 + chunk]]
+                cs = free_sets.get()
+                list(pool.map(lambda cf: cf[0].upload(cf[1]), zip(cs, fr)))
+                q_up.put((cs, fr))
+        except Exception as e:  # noqa: BLE001 (reported by the caller)
+            errors.append(e)
+        q_up.put(None)
+
+    def runner():
+        try:
+            while True:
+                item = q_up.get()
+                if item is None:
+                    break
+                cs, fr = item
+                live = cs[:len(fr)]
+                J.run_entropy_batch(live)
+                J.run_transform_batch(live)
+                J.run_filter_color_batch(live)
+                q_down.put((cs, fr))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+        q_down.put(None)
+
+    def fetch(cf):
+        c, f = cf
+        J._check(J.lib().jxlhip_download_rgb8(c._h, outs[id(c)].ctypes.data, xsize * 3), "jxlhip_download_rgb8")
+        f.close()
+
+    def downloader(pool):
+        try:
+            while True:
+                item = q_down.get()
+                if item is None:
+                    break
+                cs, fr = item
+                list(pool.map(fetch, zip(cs, fr)))
+                done[0] += len(fr)
+                free_sets.put(cs)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    # warm-up: one small chunk through everything (allocations, first touch of the output pages)
+    warm = [J.Frame(datas[i % len(datas)], parse_threads) for i in range(min(chunk, 8))]
+    for cs in sets:
+        for c, f in zip(cs, warm):
+            c.upload(f)
+        live = cs[:len(warm)]
+        J.run_entropy_batch(live); J.run_transform_batch(live); J.run_filter_color_batch(live)
+        for c in live:
+            J._check(J.lib().jxlhip_download_rgb8(c._h, outs[id(c)].ctypes.data, xsize * 3), "jxlhip_download_rgb8")
+    for f in warm:
+        f.close()
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(parsers) as pool, concurrent.futures.ThreadPoolExecutor(movers) as up_pool, \
+            concurrent.futures.ThreadPoolExecutor(movers) as down_pool:
+        futs = [pool.submit(J.Frame, datas[i % len(datas)], parse_threads) for i in range(nframes)]
+        ths = [threading.Thread(target=uploader, args=(futs, up_pool)), threading.Thread(target=runner),
+               threading.Thread(target=downloader, args=(down_pool,))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    elapsed = time.perf_counter() - t0
+    for cs in sets:
+        for c in cs:
+            c.close()
+    if errors:
+        raise errors[0]
+    assert done[0] == nframes
+    return {"value": round(nframes * xsize * ysize * 1e-6 / elapsed, 1), "unit": "MP/s", "frames": nframes,
+            "ms_per_frame": round(elapsed / nframes * 1e3, 3), "host_cores": ncpu,
+            "host_threads": {"parse": "%d frames x %d threads" % (parsers, parse_threads), "upload": movers, "gpu_launch": 1, "download": movers},
+            "span": "compressed bytes in host memory -> RGB8 in pinned host memory (tools/djxl_main.cc:415-422), host parse | H2D | entropy, "
+                    "transform, filter+colour in chunks of %d frames | D2H pipelined over host threads" % chunk}
 
 
 def system_libjxl_baseline(data, xsize, ysize, threads):
@@ -137,14 +248,49 @@ def main():
                     help="one frame set, filter + colour of step k on a second stream under the entropy launch of step k + 1 "
                          "(option filter_async), instead of the default software pipeline over two frame sets")
     ap.add_argument("--no-share-planes", action="store_true", help="every context of both pipelined sets keeps its own XYB planes")
+    ap.add_argument("--sets", type=int, default=0,
+                    help="S > 0: the batch is split into S frame sets, each with its own stream running entropy -> transform -> "
+                         "filter+colour for its frames every step, all S streams free-running beside each other (no set waits for "
+                         "another: the long tail of one set's entropy launch -- its slowest section -- overlaps the other sets' "
+                         "launches). 0 = the two-set schedule selected by the other flags")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (seeds 177, 178, ...) cycled through every frame set")
+    ap.add_argument("--e2e-frames", type=int, default=1024,
+                    help="frames of the end-to-end measurement (compressed bytes in host memory -> RGB8 in host memory, host parse / "
+                         "upload / GPU stages / download pipelined over host threads); 0 = skip")
+    ap.add_argument("--max-clusters", type=int, default=0, help="sensitivity runs: histogram clusters of the synthetic encoder (0 = its default 64)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only check the multi-rank launch (gloo, no GPU needed): every rank reports, rank 0 prints the ranks it saw")
     args = ap.parse_args()
     xsize, ysize = [int(v) for v in args.size.split("x")]
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Not started by torch.distributed.run: start the N ranks ourselves, as a CHILD process and before anything here has
+        # touched the GPU (a process that has initialised HIP must never exec another program), and pass its exit code on.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a wrong n_gpus" % (args.gpus, world))
     dist = None
     import torch
+    if args.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "pid": os.getpid()})
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": sorted(s["rank"] for s in seen),
+                              "distinct_processes": len({s["pid"] for s in seen})}))
+        dist.destroy_process_group()
+        return
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -153,15 +299,27 @@ def main():
     from libjxl_amd import sharding
     J.lib()  # fails loudly if the HIP extension is missing
 
-    data = make_stream(xsize, ysize, args.distance)
-    frame = J.Frame(data, threads=min(8, os.cpu_count() or 1))
-    info = frame.info
+    # `--distinct` different frames (the synthetic image generator with seeds 177, 178, ...), cycled through every frame
+    # set: sections, token counts and entropy tables differ from frame to frame, so the workgroups of a launch do not all
+    # finish together
+    ndistinct = max(1, min(args.distinct, args.batch))
+    datas = [make_stream(xsize, ysize, args.distance, 177 + i, args.max_clusters) for i in range(ndistinct)]
+    frames = [J.Frame(d, threads=min(8, os.cpu_count() or 1)) for d in datas]
+    data, frame = datas[0], frames[0]
+    info = dict(frame.info)
+    info["ac_bytes"] = sum(f.info["ac_bytes"] for f in frames) / float(ndistinct)  # mean over the distinct frames
     # Two sets of `batch` frames: while one set is in the (latency-bound, serial per section) entropy stage, the other
     # set's coefficients go through the (bandwidth-bound) transform + filter + colour stages. Every step runs every
     # stage once over `batch` frames, so a step completes `batch` frames; a frame's latency is two steps.
-    nsets = 1 if (args.no_pipeline or args.chain) else 2
-    chain = args.chain and not args.no_pipeline
-    sets = [[J.HipContext(local_rank) for _ in range(args.batch)] for _ in range(nsets)]
+    free_running = args.sets > 0
+    nsets = args.sets if free_running else (1 if (args.no_pipeline or args.chain) else 2)
+    chain = args.chain and not args.no_pipeline and not free_running
+    if free_running:
+        per_set = [args.batch // nsets + (1 if i < args.batch % nsets else 0) for i in range(nsets)]
+        sets = [[J.HipContext(local_rank) for _ in range(n)] for n in per_set if n]
+        nsets = len(sets)
+    else:
+        sets = [[J.HipContext(local_rank) for _ in range(args.batch)] for _ in range(nsets)]
     band = None
     share = 1.0  # fraction of every frame's pixels this rank produces
     if args.shard == "bands":
@@ -170,20 +328,22 @@ def main():
         if band[0] == band[1]:
             raise SystemExit("more ranks than rows of groups: use --shard frames")
         share = (min(band[1] * 256, ysize) - band[0] * 256) / float(ysize)
-    three = args.three_stage and nsets == 2
+    three = args.three_stage and nsets == 2 and not free_running
     if three:
         for cs in sets:
             cs[0].set_option("filter_async", 1)
-    if nsets == 2 and not args.no_share_planes and not three:  # (three-stage: both sets' planes are live at once)
+    if nsets == 2 and not args.no_share_planes and not three and not free_running:  # (three-stage: both sets' planes are live at once)
         # the XYB planes of a frame only live between its transform and its filter stage, and the two sets are never in
         # those stages at the same time: set 1 keeps its planes in set 0's buffers (100 MB less per pair of 4K frames)
         for a, b in zip(sets[0], sets[1]):
             b.share_planes(a)
     if chain:
         sets[0][0].set_option("filter_async", 1)
+    nth = 0
     for cs in sets:
         for c in cs:
-            c.upload(frame, band=band)
+            c.upload(frames[nth % ndistinct], band=band)
+            nth += 1
     for cs in sets:  # prime: every set holds decoded coefficients before the first (warmup) step
         J.run_entropy_batch(cs)
     for cs in sets:
@@ -194,6 +354,15 @@ def main():
     def step():
         k = step_no[0]
         step_no[0] += 1
+        if free_running:
+            # every set: its three stages, in order, on its own stream; the host only enqueues, the streams drift apart by
+            # themselves (whoever gets resources first), so one set's latency-bound entropy launch runs beside other sets'
+            # transform / filter launches and beside other entropy launches
+            for cs in sets:
+                J.run_entropy_batch(cs)
+                J.run_transform_batch(cs)
+                J.run_filter_color_batch(cs)
+            return sets[0]
         ent = sets[k % nsets]
         down = sets[(k + 1) % nsets]
         if three:
@@ -232,7 +401,10 @@ def main():
     elapsed = time.perf_counter() - t0
     # duration of the entropy launches: HIP events on the stream each batch kernel was launched on; the events of the
     # last launch of every set are still in place after the region
-    entropy_ms = sum(cs[0].stage_ms(0) for cs in sets) / float(nsets) * args.steps
+    if free_running:  # frames-weighted mean of the sets' last entropy launches, expressed per whole batch like the other modes
+        entropy_ms = sum(cs[0].stage_ms(0) for cs in sets) * args.steps
+    else:
+        entropy_ms = sum(cs[0].stage_ms(0) for cs in sets) / float(nsets) * args.steps
     frames_local = args.batch * args.steps * share
     total_frames, max_elapsed = sharding.aggregate(frames_local, elapsed, dist)
     # transform and filter+colour: the same batched launches over one set, run alone after the timed region (inside the
@@ -245,13 +417,16 @@ def main():
             fn(sets[0])
             c.sync()
             best = min(best, c.stage_ms(which))
-        iso[which - 1] = best / args.batch
+        iso[which - 1] = best / len(sets[0])
     stage_ms = [entropy_ms / args.steps / args.batch, iso[0], iso[1]]
+    for cs in sets:  # the frame sets' device memory is released before the end-to-end measurement allocates its own
+        for c in cs:
+            c.close()
 
     if rank == 0:
         px = xsize * ysize
         mps = total_frames * px * 1e-6 / max_elapsed
-        bpp = len(data) * 8.0 / px
+        bpp = sum(len(d) for d in datas) / float(ndistinct) * 8.0 / px
         # algorithmic bytes per launch (one frame) of each stage, SURVEY.md §8d / DESIGN.md:
         alg = {
             "entropy (k_entropy_lanes)": info["ac_bytes"] + 6.0 * px,          # bitstream read + int16 coefficients written
@@ -288,10 +463,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
                 xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
-                "frames_per_step_per_gpu": args.batch, "pipeline": ("2 frame sets, 3 concurrent launches: entropy(A) | transform(B) | filter+colour(A, previous step)" if three else
+                "frames_per_step_per_gpu": args.batch, "distinct_frames": ndistinct, "pipeline": ("%d frame sets, each on its own stream (entropy -> transform -> filter+colour every step), free-running" % nsets) if free_running else ("2 frame sets, 3 concurrent launches: entropy(A) | transform(B) | filter+colour(A, previous step)" if three else
                              "2 frame sets: entropy(set A) overlaps transform+filter(set B)") if nsets == 2 else
                 ("1 frame set: entropy and transform back to back, filter+colour of step k on a second stream under the entropy launch of step k+1" if chain else "none"),
-                "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes and not three else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
+                "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes and not three and not free_running else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
                 ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -306,14 +481,14 @@ def main():
             "stage_gbs": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9, 2) for s in range(3)},
             "stage_hbm_frac": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for s in range(3)},
         }
+        if args.e2e_frames > 0 and args.shard == "frames":
+            out["e2e"] = end_to_end(J, datas, args.e2e_frames, local_rank, xsize, ysize)
         if not args.no_cpu_baseline:
             ref = system_libjxl_baseline(data, xsize, ysize, os.cpu_count() or 1)
             out["cpu_baseline"] = ref if ref else cpu_baseline(data, xsize, ysize)
         print(json.dumps(out))
-    for cs in sets:
-        for c in cs:
-            c.close()
-    frame.close()
+    for f in frames:
+        f.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -24,6 +24,8 @@ void jxlamd_frame_free(JxlAmdFrame* frame);
  * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes, then of pass 0: log2 alphabet size,
  * number of clustered histograms, context map bytes; [15] reserved (0). */
 void jxlamd_frame_info(const JxlAmdFrame* frame, uint32_t* info);
+/* Byte sizes of the frame's AC group sections, [pass * num_groups + group]; returns their number (sizes may be NULL / short). */
+size_t jxlamd_frame_section_sizes(const JxlAmdFrame* frame, uint32_t* sizes, size_t n);
 /* Size of the decoded image: the frame size, times the upsampling factor of an upsampled frame (cropped to the image). */
 void jxlamd_frame_out_size(const JxlAmdFrame* frame, uint32_t* width_height);
 int jxlamd_frame_upload(const JxlAmdFrame* frame, JxlHipContext* ctx);
@@ -38,6 +40,19 @@ void jxlamd_frame_set_linear_output(JxlAmdFrame* frame, int linear);
 int jxlamd_frame_extra_pending(const JxlAmdFrame* frame);
 int jxlamd_frame_finish_extra(JxlAmdFrame* frame, JxlHipContext* ctx);
 const int32_t* jxlamd_frame_extra_plane(const JxlAmdFrame* frame, uint32_t index);
+/* ---- Modular (lossless) frames: host parse into the plan the device decodes (csrc/host/jxh_modframe.h) ---- */
+typedef struct JxlAmdModFrame JxlAmdModFrame;
+/* Parses the first frame of a codestream as a Modular frame: headers, TOC, global tree and histograms and every stream's
+ * group header; no sample is decoded on the host. `data` must stay valid until the frame has been uploaded. */
+int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** frame);
+void jxlamd_modframe_free(JxlAmdModFrame* frame);
+/* info[0..9]: xsize, ysize, colour channels, has alpha, bits per sample, streams, channel buffers, transform operations,
+ * extra channels, compressed bytes of all sections. */
+void jxlamd_modframe_info(const JxlAmdModFrame* frame, uint32_t* info);
+/* Hands the plan to a context (jxlhip_modular_upload); then jxlhip_modular_run + jxlhip_download_pixels. */
+int jxlamd_modframe_upload(const JxlAmdModFrame* frame, JxlHipContext* ctx);
+/* Channel buffer of extra channel `index` after the run (jxlhip_modular_download_buffer), or 0xFFFFFFFF. */
+uint32_t jxlamd_modframe_extra_buffer(const JxlAmdModFrame* frame, uint32_t index);
 /* Thread-local description of the last failure of a jxlamd_* call ("" if none). */
 const char* jxlamd_last_error(void);
 #ifdef __cplusplus

@@ -212,6 +212,84 @@ int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
  * lender must have uploaded a frame at least as large and must outlive the borrower's use. */
 int jxlhip_share_planes(JxlHipContext* ctx, JxlHipContext* lender);
 
+/* ---- Modular (lossless) frames: reference lib/jxl/dec_modular.cc:209-425,564-793, modular/encoding/encoding.cc:148-724,
+ * modular/transform/{rct,palette,squeeze}.cc. The host front-end parses headers, trees and histograms and every stream's
+ * group header; the sample decode, the inverse transforms and the conversion to output samples run on the device. ---- */
+typedef struct JxlHipModTreeNode {  /* MA tree node (dec_ma.cc:107-159); property -1 = leaf */
+  int32_t property, splitval;
+  uint32_t lchild, rchild; /* leaves: lchild = context */
+  uint32_t predictor;
+  int32_t offset;
+  uint32_t multiplier, pad;
+} JxlHipModTreeNode;
+typedef struct JxlHipModCode {  /* one entropy code: the global one or a stream's own */
+  const uint8_t* ctx_map;
+  uint32_t ctx_map_size, num_clusters;
+  uint32_t use_prefix, log_alpha;
+  const void* alias;             /* ANS: num_clusters << log_alpha entries of 8 bytes (as JxlHipPassDesc::alias) */
+  const uint32_t* uint_cfg;      /* per cluster */
+  const uint32_t* prefix_table;  /* prefix codes: as JxlHipPassDesc */
+  uint32_t prefix_table_size;
+  const uint32_t* prefix_offset;
+  uint32_t lz77, lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_ctx;
+} JxlHipModCode;
+typedef struct JxlHipModRect {  /* a stream's channel: rectangle of channel buffer `buffer` */
+  uint32_t buffer, x0, y0, w, h, sig;
+} JxlHipModRect;
+typedef struct JxlHipModStream {
+  uint32_t section;      /* index into the frame's section list */
+  uint32_t bit_offset;   /* sample data start, from the section's first byte */
+  uint32_t stream_id, first_channel_index;
+  uint32_t tree, code;   /* indices into trees / codes */
+  uint32_t first_rect, num_rects;
+  int32_t wp[11];
+  uint32_t uses_wp, num_props, dist_multiplier, max_width, num_samples;
+} JxlHipModStream;
+typedef struct JxlHipModBuffer {  /* a channel buffer: w x h int32 samples (the device pool is laid out by the library) */
+  uint32_t w, h;
+} JxlHipModBuffer;
+typedef struct JxlHipModOp {  /* one inverse-transform step, in execution order */
+  uint32_t kind;          /* 0 = RCT on a rectangle, 1 = palette lookup, 2 = horizontal unsqueeze, 3 = vertical unsqueeze */
+  uint32_t buf[6];        /* RCT: 3 channels; palette: palette, index, outputs (buf[2..]); unsqueeze: averages, residuals, output */
+  uint32_t x0, y0, w, h;  /* RCT rectangle (whole channels: 0, 0, w, h) */
+  uint32_t param, nb, bit_depth;  /* RCT type; palette channels, sample depth */
+  uint32_t after_stream;  /* run after stream index + 1 streams' launch... 0xFFFFFFFF = after all streams (global transforms) */
+} JxlHipModOp;
+typedef struct JxlHipModFrameDesc {
+  uint32_t xsize, ysize;
+  const uint8_t* codestream;
+  const uint64_t* section_offset;
+  const uint32_t* section_size;
+  uint32_t num_sections;
+  const JxlHipModTreeNode* const* trees;
+  const uint32_t* tree_size;
+  uint32_t num_trees;
+  const JxlHipModCode* codes;
+  uint32_t num_codes;
+  const JxlHipModBuffer* buffers;
+  uint32_t num_buffers;
+  const JxlHipModRect* rects;
+  uint32_t num_rects;
+  const JxlHipModStream* streams;
+  uint32_t num_streams;
+  const JxlHipModOp* ops;
+  uint32_t num_ops;
+  /* output: the buffers holding the final colour channels (1 or 3) and alpha (or 0xFFFFFFFF) */
+  uint32_t out_buffer[4];
+  uint32_t num_color, has_alpha, bits, alpha_bits;
+} JxlHipModFrameDesc;
+/* Copies a Modular frame's tables and sections to the device (the arrays may be released afterwards). */
+int jxlhip_modular_upload(JxlHipContext* ctx, const JxlHipModFrameDesc* desc);
+/* Decodes every stream (one lane each), undoes the transforms and writes the pixels in the format of
+ * jxlhip_set_output_format; results through jxlhip_download_pixels / jxlhip_download_rgb8. Stage time: which = 0. */
+int jxlhip_modular_run(JxlHipContext* ctx);
+/* Same for `n` resident frames: ONE streams launch for all their streams. */
+int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n);
+/* Per-stream status words (0 = ok) and end bit positions after a run; synchronous. Returns JXLHIP_ERR_STREAM if any is set. */
+int jxlhip_modular_status(JxlHipContext* ctx, uint32_t* status, uint32_t* end_bits, size_t n);
+/* Test access: a channel buffer's int32 samples (w * h) after the run; synchronous. */
+int jxlhip_modular_download_buffer(JxlHipContext* ctx, uint32_t buffer, int32_t* dst, size_t n);
+
 /* Timing of the last run of each stage in milliseconds (HIP events on the context's stream);
  * which: 0 entropy, 1 transform, 2 filter+colour. Synchronous. */
 int jxlhip_last_stage_ms(JxlHipContext* ctx, int which, float* ms);

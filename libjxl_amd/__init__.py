@@ -62,6 +62,18 @@ def lib():
         L.jxlamd_frame_info.argtypes = [vp, u32p]
         L.jxlamd_frame_out_size.argtypes = [vp, u32p]
         L.jxlamd_frame_upload.argtypes = [vp, vp]
+        L.jxlamd_modframe_parse.argtypes = [cp, ctypes.c_size_t, ctypes.POINTER(vp)]
+        L.jxlamd_modframe_free.argtypes = [vp]
+        L.jxlamd_modframe_info.argtypes = [vp, u32p]
+        L.jxlamd_modframe_upload.argtypes = [vp, vp]
+        L.jxlamd_modframe_extra_buffer.argtypes = [vp, ctypes.c_uint32]
+        L.jxlamd_modframe_extra_buffer.restype = ctypes.c_uint32
+        L.jxlhip_modular_run.argtypes = [vp]
+        L.jxlhip_modular_run_batch.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
+        L.jxlhip_modular_status.argtypes = [vp, u32p, u32p, ctypes.c_size_t]
+        L.jxlhip_modular_download_buffer.argtypes = [vp, ctypes.c_uint32, vp, ctypes.c_size_t]
+        L.jxlhip_set_output_format.argtypes = [vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int]
+        L.jxlhip_download_pixels.argtypes = [vp, vp, ctypes.c_size_t]
         L.jxlamd_last_error.restype = cp
         L.JxlThreadParallelRunnerCreate.restype = vp
         L.JxlThreadParallelRunnerCreate.argtypes = [vp, ctypes.c_size_t]
@@ -115,6 +127,32 @@ class Frame:
             pass
 
 
+class ModFrame:
+    """Host-parsed Modular (lossless) frame: headers, trees, histograms, stream descriptors; samples stay compressed."""
+
+    INFO = ("xsize", "ysize", "num_color", "has_alpha", "bits", "num_streams", "num_buffers", "num_ops", "num_extra", "section_bytes")
+
+    def __init__(self, data):
+        L = lib()
+        self._data = bytes(data)  # must outlive upload
+        self._h = ctypes.c_void_p()
+        _check(L.jxlamd_modframe_parse(self._data, len(self._data), ctypes.byref(self._h)), "jxlamd_modframe_parse")
+        info = (ctypes.c_uint32 * 16)()
+        L.jxlamd_modframe_info(self._h, info)
+        self.info = dict(zip(self.INFO, list(info)))
+
+    def close(self):
+        if self._h:
+            lib().jxlamd_modframe_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipContext:
     """One HIP stream + the device buffers of one frame (include/jxl_amd_hip.h)."""
 
@@ -150,6 +188,41 @@ class HipContext:
         b0, b1 = band if band else (0, 0)
         _check(lib().jxlamd_frame_upload_band(frame._h, self._h, b0, b1), "jxlamd_frame_upload_band")
         self.frame_info = dict(frame.info)
+
+    def set_output_format(self, data_type=2, num_channels=3, bits=0, big_endian=False):
+        """JxlDataType numbering: 0 f32, 2 u8, 3 u16, 5 f16; call before upload."""
+        _check(lib().jxlhip_set_output_format(self._h, data_type, num_channels, bits, 1 if big_endian else 0), "jxlhip_set_output_format")
+        self._out = (data_type, num_channels)
+
+    def upload_modular(self, mframe):
+        _check(lib().jxlamd_modframe_upload(mframe._h, self._h), "jxlamd_modframe_upload")
+        self.frame_info = dict(mframe.info)
+        self.frame_info["out_xsize"], self.frame_info["out_ysize"] = mframe.info["xsize"], mframe.info["ysize"]
+
+    def run_modular(self):
+        _check(lib().jxlhip_modular_run(self._h), "jxlhip_modular_run")
+
+    def modular_status(self):
+        n = self.frame_info["num_streams"]
+        st = (ctypes.c_uint32 * max(n, 1))()
+        eb = (ctypes.c_uint32 * max(n, 1))()
+        r = lib().jxlhip_modular_status(self._h, st, eb, n)
+        return r, list(st)[:n], list(eb)[:n]
+
+    def modular_buffer(self, index):
+        need = self.frame_info["xsize"] * self.frame_info["ysize"]
+        out = np.empty(need, np.int32)
+        _check(lib().jxlhip_modular_download_buffer(self._h, index, out.ctypes.data, need), "jxlhip_modular_download_buffer")
+        return out.reshape(self.frame_info["ysize"], self.frame_info["xsize"])
+
+    def pixels(self):
+        """The interleaved result in the format of set_output_format (default RGB8)."""
+        fi = self.frame_info
+        dt, nc = getattr(self, "_out", (2, 3))
+        np_dt = {0: np.float32, 2: np.uint8, 3: np.uint16, 5: np.float16}[dt]
+        out = np.empty((fi["out_ysize"], fi["out_xsize"], nc), np_dt)
+        _check(lib().jxlhip_download_pixels(self._h, out.ctypes.data, fi["out_xsize"] * nc * out.itemsize), "jxlhip_download_pixels")
+        return out
 
     def rgb8_rows(self, y0, y1):
         fi = self.frame_info
@@ -217,6 +290,29 @@ def run_filter_color_batch(ctxs):
     _check(lib().jxlhip_run_filter_color_batch(arr, len(ctxs)), "jxlhip_run_filter_color_batch")
 
 
+def run_modular_batch(ctxs):
+    """Every stream of several resident Modular frames as one launch (jxlhip_modular_run_batch)."""
+    arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(lib().jxlhip_modular_run_batch(arr, len(ctxs)), "jxlhip_modular_run_batch")
+
+
+def decode_lossless(data, num_channels=3, data_type=2, device=0):
+    """One-shot helper: Modular (lossless) codestream -> HxWxC samples through the GPU path."""
+    f = ModFrame(data)
+    c = HipContext(device)
+    try:
+        c.set_output_format(data_type, num_channels)
+        c.upload_modular(f)
+        c.run_modular()
+        r, status, _ = c.modular_status()
+        if r:
+            raise JxlAmdError("corrupt Modular streams: %r" % [(i, s) for i, s in enumerate(status) if s])
+        return c.pixels()
+    finally:
+        c.close()
+        f.close()
+
+
 def decode_rgb8(data, device=0, threads=0):
     """One-shot helper: codestream bytes -> HxWx3 uint8 through the GPU path."""
     f = Frame(data, threads)
@@ -253,6 +349,8 @@ def _enc_lib():
         E.jxlenc_encode_rgb8.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), pp,
                                          ctypes.POINTER(ctypes.c_size_t)]
         E.jxlenc_encode_rgba8.argtypes = E.jxlenc_encode_rgb8.argtypes
+        E.jxlenc_encode_lossless.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_uint32, pp, ctypes.POINTER(ctypes.c_size_t)]
         E.jxlenc_encode_random.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), pp,
                                            ctypes.POINTER(ctypes.c_size_t)]
         E.jxlenc_synth_image.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
@@ -305,6 +403,21 @@ def encode_rgba8(img, **kw):
     n = ctypes.c_size_t()
     r = E.jxlenc_encode_rgba8(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), ctypes.byref(out), ctypes.byref(n))
     return _finish(E, r, out, n, "jxlenc_encode_rgba8")
+
+
+LOSSLESS_PREFIX, LOSSLESS_LZ77, LOSSLESS_WP, LOSSLESS_SQUEEZE, LOSSLESS_RCT, LOSSLESS_ALL_PREDICTORS, LOSSLESS_PREV_CHANNEL = 1, 2, 4, 8, 16, 32, 64
+
+
+def encode_lossless(img, flags=LOSSLESS_RCT, seed=0):
+    """HxWxC uint8 image (C = 1..4: grey, grey + alpha, RGB, RGBA) -> lossless Modular codestream. flags: LOSSLESS_*."""
+    E = _enc_lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    if img.ndim == 2:
+        img = img[..., None]
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    r = E.jxlenc_encode_lossless(img.tobytes(), img.shape[1], img.shape[0], img.shape[2], flags, seed, ctypes.byref(out), ctypes.byref(n))
+    return _finish(E, r, out, n, "jxlenc_encode_lossless")
 
 
 def encode_random(xsize, ysize, **kw):

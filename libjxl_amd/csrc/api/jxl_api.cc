@@ -19,6 +19,7 @@
 
 #include "../../../include/jxl_amd.h"
 #include "../host/jxh_frame.h"
+#include "../host/jxh_modframe.h"
 
 namespace {
 thread_local std::string g_last_error;
@@ -99,6 +100,12 @@ void jxlamd_frame_info(const JxlAmdFrame* f, uint32_t* info) {
   info[12] = P.passes.empty() ? 0 : uint32_t(P.passes[0].log_alpha);
   info[13] = P.passes.empty() ? 0 : uint32_t(P.passes[0].num_clusters);
   info[14] = P.passes.empty() ? 0 : uint32_t(P.passes[0].ctx_map.size());
+}
+
+size_t jxlamd_frame_section_sizes(const JxlAmdFrame* f, uint32_t* sizes, size_t n) {
+  const std::vector<uint32_t>& s = f->plan.section_size;
+  for (size_t i = 0; i < s.size() && i < n; i++) sizes[i] = s[i];
+  return s.size();
 }
 
 void jxlamd_frame_out_size(const JxlAmdFrame* f, uint32_t* wh) {
@@ -234,6 +241,162 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   return r;
 }
 
+// ------------------------------------------------------------------------------------------------ Modular frames
+}  // extern "C"
+struct JxlAmdModFrame {
+  jxh::ModFramePlan plan;
+  const uint8_t* data = nullptr;
+};
+extern "C" {
+int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** out) {
+  g_last_error.clear();
+  if (!data || !out) {
+    g_last_error = "invalid argument";
+    return 1;
+  }
+  *out = nullptr;
+  std::unique_ptr<JxlAmdModFrame> f(new JxlAmdModFrame);
+  try {
+    jxh::FrameParser head(data, size);  // (signature / container + image header)
+    jxh::ImageHeader ih;
+    const size_t pos = head.ParseImageHeader(&ih);
+    jxh::ModFrameParser parser(data, size);
+    parser.ParseFrame(pos, ih, &f->plan);
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return 2;
+  }
+  f->data = data;
+  *out = f.release();
+  return 0;
+}
+void jxlamd_modframe_free(JxlAmdModFrame* f) { delete f; }
+void jxlamd_modframe_info(const JxlAmdModFrame* f, uint32_t* info) {
+  const jxh::ModFramePlan& P = f->plan;
+  info[0] = uint32_t(P.dim.xsize);
+  info[1] = uint32_t(P.dim.ysize);
+  info[2] = P.num_color;
+  info[3] = P.has_alpha;
+  info[4] = P.ih.bits;
+  info[5] = uint32_t(P.streams.size());
+  info[6] = uint32_t(P.buffers.size());
+  info[7] = uint32_t(P.ops.size());
+  info[8] = uint32_t(P.ih.extra.size());
+  uint64_t total = 0;
+  for (uint32_t s : P.section_size) total += s;
+  info[9] = uint32_t(total);
+}
+uint32_t jxlamd_modframe_extra_buffer(const JxlAmdModFrame* f, uint32_t index) {
+  return f && index < f->plan.extra_buffer.size() ? f->plan.extra_buffer[index] : 0xFFFFFFFFu;
+}
+int jxlamd_modframe_upload(const JxlAmdModFrame* f, JxlHipContext* ctx) {
+  g_last_error.clear();
+  if (!f || !ctx) {
+    g_last_error = "invalid argument";
+    return 1;
+  }
+  const jxh::ModFramePlan& P = f->plan;
+  JxlHipModFrameDesc d;
+  memset(&d, 0, sizeof(d));
+  d.xsize = uint32_t(P.dim.xsize);
+  d.ysize = uint32_t(P.dim.ysize);
+  d.codestream = f->data;
+  d.section_offset = P.section_offset.data();
+  d.section_size = P.section_size.data();
+  d.num_sections = uint32_t(P.section_size.size());
+  // trees
+  std::vector<std::vector<JxlHipModTreeNode>> trees(P.trees.size());
+  std::vector<const JxlHipModTreeNode*> tree_ptr(P.trees.size());
+  std::vector<uint32_t> tree_size(P.trees.size());
+  for (size_t i = 0; i < P.trees.size(); i++) {
+    for (const jxh::TreeNode& n : P.trees[i]) {
+      JxlHipModTreeNode o;
+      o.property = n.property;
+      o.splitval = n.splitval;
+      o.lchild = n.lchild;
+      o.rchild = n.rchild;
+      o.predictor = n.predictor;
+      o.offset = int32_t(n.offset);
+      o.multiplier = n.multiplier;
+      o.pad = 0;
+      trees[i].push_back(o);
+    }
+    tree_ptr[i] = trees[i].data();
+    tree_size[i] = uint32_t(trees[i].size());
+  }
+  d.trees = tree_ptr.data();
+  d.tree_size = tree_size.data();
+  d.num_trees = uint32_t(trees.size());
+  // codes
+  std::vector<JxlHipModCode> codes(P.codes.size());
+  std::vector<std::vector<uint32_t>> cfgs(P.codes.size()), ptabs(P.codes.size()), poffs(P.codes.size());
+  for (size_t i = 0; i < P.codes.size(); i++) {
+    const jxh::EntropyCode& c = P.codes[i];
+    JxlHipModCode& o = codes[i];
+    memset(&o, 0, sizeof(o));
+    o.ctx_map = c.ctx_map.data();
+    o.ctx_map_size = uint32_t(c.ctx_map.size());
+    o.num_clusters = uint32_t(c.num_clusters);
+    o.use_prefix = c.use_prefix ? 1 : 0;
+    o.log_alpha = uint32_t(c.log_alpha);
+    o.alias = c.alias.data();
+    for (const jxh::HybridCfg& h : c.cfg) cfgs[i].push_back(h.split_exp | (h.msb << 8) | (h.lsb << 16));
+    o.uint_cfg = cfgs[i].data();
+    if (c.use_prefix) {
+      for (const jxh::PrefixCode& pc : c.prefix) {
+        poffs[i].push_back(uint32_t(ptabs[i].size()) | (uint32_t(pc.max_len) << 24));
+        for (size_t k = 0; k < pc.sym.size(); k++) ptabs[i].push_back(uint32_t(pc.len[k]) | (uint32_t(pc.sym[k]) << 8));
+      }
+      o.prefix_table = ptabs[i].data();
+      o.prefix_table_size = uint32_t(ptabs[i].size());
+      o.prefix_offset = poffs[i].data();
+    }
+    o.lz77 = c.lz77 ? 1 : 0;
+    o.lz_min_symbol = c.lz_min_symbol;
+    o.lz_min_length = c.lz_min_length;
+    o.lz_len_cfg = c.lz_len_cfg.split_exp | (c.lz_len_cfg.msb << 8) | (c.lz_len_cfg.lsb << 16);
+    o.lz_dist_ctx = c.lz_dist_ctx;
+  }
+  d.codes = codes.data();
+  d.num_codes = uint32_t(codes.size());
+  std::vector<JxlHipModBuffer> buffers;
+  for (const auto& b : P.buffers) buffers.push_back({b.first, b.second});
+  d.buffers = buffers.data();
+  d.num_buffers = uint32_t(buffers.size());
+  static_assert(sizeof(jxh::ModPlanRect) == sizeof(JxlHipModRect), "rect layout");
+  d.rects = reinterpret_cast<const JxlHipModRect*>(P.rects.data());
+  d.num_rects = uint32_t(P.rects.size());
+  static_assert(sizeof(jxh::ModPlanStream) == sizeof(JxlHipModStream), "stream layout");
+  d.streams = reinterpret_cast<const JxlHipModStream*>(P.streams.data());
+  d.num_streams = uint32_t(P.streams.size());
+  std::vector<JxlHipModOp> ops;
+  for (const jxh::ModPlanOp& q : P.ops) {
+    JxlHipModOp o;
+    memset(&o, 0, sizeof(o));
+    o.kind = q.kind;
+    memcpy(o.buf, q.buf, sizeof(o.buf));
+    o.x0 = q.x0;
+    o.y0 = q.y0;
+    o.w = q.w;
+    o.h = q.h;
+    o.param = q.param;
+    o.nb = q.nb;
+    o.bit_depth = q.bit_depth;
+    o.after_stream = 0xFFFFFFFFu;
+    ops.push_back(o);
+  }
+  d.ops = ops.data();
+  d.num_ops = uint32_t(ops.size());
+  memcpy(d.out_buffer, P.out_buffer, sizeof(d.out_buffer));
+  d.num_color = P.num_color;
+  d.has_alpha = P.has_alpha;
+  d.bits = P.ih.bits;
+  d.alpha_bits = P.alpha_bits;
+  const int r = jxlhip_modular_upload(ctx, &d);
+  if (r) g_last_error = "jxlhip_modular_upload failed (" + std::to_string(r) + ")";
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------ JxlDecoder
 void jxlamd_frame_set_linear_output(JxlAmdFrame* f, int linear) {
   if (f) f->plan.ih.linear_tf = linear != 0;
@@ -324,7 +487,8 @@ struct JxlDecoderStruct {
   bool error = false;
   jxh::ImageHeader ih;
   bool have_ih = false;
-  JxlAmdFrame* frame = nullptr;
+  JxlAmdFrame* frame = nullptr;        // a VarDCT frame ...
+  JxlAmdModFrame* mframe = nullptr;    // ... or a Modular (lossless) one
   JxlHipContext* ctx = nullptr;
   // ---- settings
   bool keep_orientation = false, unpremul = false;
@@ -379,6 +543,8 @@ bool IsBigEndian(const JxlPixelFormat& f) { return f.endianness == JXL_BIG_ENDIA
 void ResetState(JxlDecoder* d) {
   if (d->frame) jxlamd_frame_free(d->frame);
   d->frame = nullptr;
+  if (d->mframe) jxlamd_modframe_free(d->mframe);
+  d->mframe = nullptr;
   d->events = 0;
   d->in = nullptr;
   d->in_size = d->in_pos = 0;
@@ -625,6 +791,60 @@ void StoreExtraRow(const int32_t* src, size_t xs, uint32_t ch_bits, const JxlPix
   }
 }
 
+JxlDecoderStatus DeliverPixels(JxlDecoder* d, const OutFormat& of, size_t xs, size_t ys) {
+  const size_t bpp = of.nc * SampleBytes(d->fmt.data_type);
+  int r;
+  if (d->out_buf) {
+    r = jxlhip_download_pixels(d->ctx, d->out_buf, RowStride(d->fmt, xs));
+    if (r) return Fail(d, "download failed");
+  } else {
+    std::vector<uint8_t> px(xs * ys * bpp);
+    r = jxlhip_download_pixels(d->ctx, px.data(), xs * bpp);
+    if (r) return Fail(d, "download failed");
+    void* run_opaque = nullptr;
+    if (d->mt_run) {
+      run_opaque = d->mt_init(d->mt_init_opaque, 1, xs);
+      if (!run_opaque) return Fail(d, "image out init callback failed");
+    }
+    for (size_t y = 0; y < ys; y++) {
+      if (d->mt_run) d->mt_run(run_opaque, 0, 0, y, xs, px.data() + y * xs * bpp);
+      else d->callback(d->callback_opaque, 0, y, xs, px.data() + y * xs * bpp);
+    }
+    if (d->mt_run && d->mt_destroy) d->mt_destroy(run_opaque);
+  }
+  return JXL_DEC_FULL_IMAGE;
+}
+
+// A Modular (lossless) frame: every stream, the inverse transforms and the sample conversion run on the device.
+JxlDecoderStatus DecodeModularPixels(JxlDecoder* d) {
+  const OutFormat of = MapFormat(d, d->fmt);
+  if ((of.nc == 2 || of.nc == 4) && d->unpremul)
+    for (const auto& e : d->ih.extra)
+      if (e.type == 0 && e.alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
+  int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
+  if (!r) r = jxlamd_modframe_upload(d->mframe, d->ctx);
+  if (!r) r = jxlhip_modular_run(d->ctx);
+  uint32_t info[16];
+  jxlamd_modframe_info(d->mframe, info);
+  std::vector<uint32_t> status(info[5] + 1);
+  if (!r) r = jxlhip_modular_status(d->ctx, status.data(), nullptr, status.size());
+  if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ") " + g_last_error);
+  const size_t xs = info[0], ys = info[1];
+  for (const auto& eo : d->extra_out) {
+    const uint32_t buffer = jxlamd_modframe_extra_buffer(d->mframe, eo.first);
+    std::vector<int32_t> plane(xs * ys);
+    if (buffer == 0xFFFFFFFFu || jxlhip_modular_download_buffer(d->ctx, buffer, plane.data(), plane.size())) return Fail(d, "extra channel unavailable");
+    const JxlPixelFormat& f = eo.second.fmt;
+    const size_t stride = RowStride(f, xs);
+    uint32_t bits = f.data_type == JXL_TYPE_UINT8 ? 8 : 16;
+    if (d->bit_depth.type == JXL_BIT_DEPTH_FROM_CODESTREAM) bits = std::min(bits, d->ih.extra[eo.first].bits);
+    else if (d->bit_depth.type == JXL_BIT_DEPTH_CUSTOM) bits = d->bit_depth.bits_per_sample;
+    for (size_t y = 0; y < ys; y++)
+      StoreExtraRow(plane.data() + y * xs, xs, d->ih.extra[eo.first].bits, f, bits, static_cast<uint8_t*>(eo.second.buf) + y * stride);
+  }
+  return DeliverPixels(d, of, xs, ys);
+}
+
 JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   if (!d->ctx) {
     if (jxlhip_device_count() <= 0) return Fail(d, "no HIP device: libjxl_amd has no CPU decode path");
@@ -632,8 +852,9 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
     int r = jxlhip_ctx_create(dev ? atoi(dev) : 0, &d->ctx);
     if (r) return Fail(d, "jxlhip_ctx_create failed (" + std::to_string(r) + ")");
   }
-  const jxh::FramePlan& P = d->frame->plan;
   if (!d->keep_orientation && d->ih.orientation != 1) return Fail(d, "unsupported: undoing a non-identity orientation");
+  if (d->mframe) return DecodeModularPixels(d);
+  const jxh::FramePlan& P = d->frame->plan;
   const OutFormat of = MapFormat(d, d->fmt);
   int alpha_ec = -1;
   for (size_t e = 0; e < d->ih.extra.size(); e++)
@@ -671,25 +892,6 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   r = jxlhip_run_transform(d->ctx);
   if (!r) r = jxlhip_run_filter_color(d->ctx);
   if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
-  const size_t bpp = of.nc * SampleBytes(d->fmt.data_type);
-  if (d->out_buf) {
-    r = jxlhip_download_pixels(d->ctx, d->out_buf, RowStride(d->fmt, xs));
-    if (r) return Fail(d, "download failed");
-  } else {
-    std::vector<uint8_t> px(xs * ys * bpp);
-    r = jxlhip_download_pixels(d->ctx, px.data(), xs * bpp);
-    if (r) return Fail(d, "download failed");
-    void* run_opaque = nullptr;
-    if (d->mt_run) {
-      run_opaque = d->mt_init(d->mt_init_opaque, 1, xs);
-      if (!run_opaque) return Fail(d, "image out init callback failed");
-    }
-    for (size_t y = 0; y < ys; y++) {
-      if (d->mt_run) d->mt_run(run_opaque, 0, 0, y, xs, px.data() + y * xs * bpp);
-      else d->callback(d->callback_opaque, 0, y, xs, px.data() + y * xs * bpp);
-    }
-    if (d->mt_run && d->mt_destroy) d->mt_destroy(run_opaque);
-  }
   for (const auto& eo : d->extra_out) {
     const int32_t* p = jxlamd_frame_extra_plane(d->frame, eo.first);
     if (!p) return Fail(d, "extra channel unavailable");
@@ -701,7 +903,7 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
     for (size_t y = 0; y < ys; y++)
       StoreExtraRow(p + y * xs, xs, d->ih.extra[eo.first].bits, f, bits, static_cast<uint8_t*>(eo.second.buf) + y * stride);
   }
-  return JXL_DEC_FULL_IMAGE;
+  return DeliverPixels(d, of, xs, ys);
 }
 
 // Codestream step. Returns 0 = needs more codestream bytes, 1 = finished, 2 = event / status in *ev.
@@ -737,6 +939,8 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
       return 1;
     }
     int r = jxlamd_frame_parse(d->cs.p, d->cs.size, d->runner, d->runner_opaque, &d->frame);
+    if (r && g_last_error.find("Modular frames") != std::string::npos)  // a lossless frame: the Modular front-end takes it
+      r = jxlamd_modframe_parse(d->cs.p, d->cs.size, &d->mframe);
     if (r) {
       const std::string w = g_last_error;
       if (!d->cs_complete && w.find("truncated") != std::string::npos) return 0;
@@ -863,9 +1067,9 @@ JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t s
 size_t JxlDecoderReleaseInput(JxlDecoder* d) {
   if (!d->in) return 0;
   size_t remaining = d->in_size - d->in_pos;
-  if (d->container == 0 && d->frame && d->stage >= 5) {
+  if (d->container == 0 && (d->frame || d->mframe) && d->stage >= 5) {
     // bare codestream: bytes behind the last frame were copied along but are not part of it
-    const uint64_t cs_end = d->frame->plan.frame_end;
+    const uint64_t cs_end = d->frame ? d->frame->plan.frame_end : d->mframe->plan.frame_end;
     const uint64_t given = d->file_pos + d->in_pos;
     if (given > cs_end) remaining = size_t(std::min<uint64_t>(d->in_size, given - cs_end));
   }
@@ -959,7 +1163,7 @@ JxlDecoderStatus JxlDecoderGetExtraChannelName(const JxlDecoder* d, size_t index
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* d, size_t index, JxlBlendInfo* info) {
-  if (!d->frame || index >= d->ih.extra.size()) return JXL_DEC_ERROR;
+  if ((!d->frame && !d->mframe) || index >= d->ih.extra.size()) return JXL_DEC_ERROR;
   if (info) memset(info, 0, sizeof(*info));
   return JXL_DEC_SUCCESS;
 }
@@ -1011,7 +1215,7 @@ JxlDecoderStatus JxlDecoderSetOutputColorProfile(JxlDecoder* d, const JxlColorEn
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h) {
-  if (!d->frame) return JXL_DEC_ERROR;
+  if (!d->frame && !d->mframe) return JXL_DEC_ERROR;
   if (h) {
     memset(h, 0, sizeof(*h));
     h->is_last = JXL_TRUE;
@@ -1022,7 +1226,7 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* d, char* name, size_t size) {
-  if (!d->frame || !name || !size) return JXL_DEC_ERROR;
+  if ((!d->frame && !d->mframe) || !name || !size) return JXL_DEC_ERROR;
   name[0] = 0;
   return JXL_DEC_SUCCESS;
 }
@@ -1033,7 +1237,7 @@ static JxlDecoderStatus CheckFormat(const JxlDecoder* d, const JxlPixelFormat* f
   if (!d->have_ih || !f) return JXL_DEC_ERROR;
   if (f->num_channels < 1 || f->num_channels > 4 || !KnownType(f->data_type)) return JXL_DEC_ERROR;
   if (f->num_channels < 3 && !d->ih.gray) return JXL_DEC_ERROR;  // decode.cc:2512-2520: grayscale output of a colour image
-  if (d->ih.gray) return JXL_DEC_ERROR;                          // (grey VarDCT images are not on this path)
+  if (d->ih.gray && !d->mframe) return JXL_DEC_ERROR;            // (grey images: Modular frames only on this path)
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* f, size_t* size) {

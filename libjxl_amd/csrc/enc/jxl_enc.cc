@@ -22,6 +22,7 @@
 
 #include "../host/jxh_bits.h"
 #include "../host/jxh_entropy.h"
+#include "../host/jxh_modular.h"
 #include "../host/jxh_vardct.h"
 
 namespace jxe {
@@ -520,7 +521,9 @@ static void WriteCodeHeader(BitWriter& bw, const EncCode& code) {
 
 // Replaces runs that repeat the values `distance` tokens back (distance 1, 2 or 3: zero runs and short periodic
 // patterns) by LZ77 copies. The copy's length token takes the context of the first value it replaces.
-static void Lz77Pass(std::vector<Token>* tokens, uint32_t dist_ctx) {
+// num_special: 120 in streams with a distance multiplier (Modular: the first 120 distance values are the 2-D "special
+// distances", plain distances follow, dec_ans.h:122-145,308-316), 0 in AC coefficient streams.
+static void Lz77Pass(std::vector<Token>* tokens, uint32_t dist_ctx, uint32_t num_special = 0) {
   const std::vector<Token>& in = *tokens;
   std::vector<Token> out;
   out.reserve(in.size());
@@ -536,7 +539,7 @@ static void Lz77Pass(std::vector<Token>* tokens, uint32_t dist_ctx) {
     }
     if (best_len >= 6) {
       out.push_back({in[i].ctx, kLzLenFlag | uint32_t(best_len - kLzMinLength)});
-      out.push_back({dist_ctx, uint32_t(best_d - 1)});
+      out.push_back({dist_ctx, uint32_t(best_d - 1) + num_special});
       i += best_len;
     } else {
       out.push_back(in[i++]);
@@ -1500,6 +1503,11 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
     f.ytob[i] = int8_t(int(rng.Below(17)) - 8);
   }
   for (auto& s : f.sharp) s = uint8_t(rng.Below(8));
+  const bool basis_mode = p.strategy_mode == 3;  // known-answer streams: see below
+  if (basis_mode) {
+    std::fill(f.ytox.begin(), f.ytox.end(), 0);
+    std::fill(f.ytob.begin(), f.ytob.end(), 0);
+  }
   uint32_t mask = p.strategy_mask ? p.strategy_mask : 0x7FFFFFFu;
   std::vector<int> allowed;
   for (int s = 0; s < 27; s++)
@@ -1536,7 +1544,7 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
   const float dc_step[3] = {inv_quant_dc / 4096.0f, inv_quant_dc / 512.0f, inv_quant_dc / 256.0f};
   // smooth-ish random DC in a plausible XYB range
   for (auto& d : f.dc) d.assign(f.xb * f.yb, 0);
-  {
+  if (!basis_mode) {
     float vy = 0.4f, vx = 0.0f, vb = 0.0f;
     for (size_t by = 0; by < f.yb; by++)
       for (size_t bx = 0; bx < f.xb; bx++) {
@@ -1551,6 +1559,7 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
   }
   const size_t xg = DivCeil(xs, 256), yg = DivCeil(ys, 256);
   f.coeffs.assign(xg * yg, {});
+  size_t basis_count = 0;
   for (size_t g = 0; g < xg * yg; g++) {
     std::vector<int32_t>& co = f.coeffs[g];
     co.assign(3 * 65536, 0);
@@ -1565,6 +1574,20 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
         const size_t cx = jxh::kCoveredX[st], cy = jxh::kCoveredY[st];
         const size_t size = cx * cy * 64, cstride = std::max(cx, cy) * 8, lrows = std::min(cx, cy), lcols = std::max(cx, cy);
         const float density = p.zero_ac ? 0.0f : 0.02f + 0.25f * rng.Uniform();  // per-block sparsity
+        if (basis_mode) {
+          // Known-answer stream (strategy_mode 3): DC zero, no chroma from luma, and every varblock carries ONE non-zero
+          // coefficient, in Y: the j-th varblock of the frame (raster order of groups, then decode order) gets natural
+          // position number (j * stride) mod (positions outside the lowest-frequency corner), stride = `seed` | 1. The
+          // decoded block is then a single basis function of the inverse transform, times the dequantisation weight.
+          size_t n_pos = size - lrows * lcols, want = (basis_count++ * size_t(p.seed | 1)) % n_pos, seen = 0;
+          for (size_t k = 0; k < size; k++) {
+            const size_t row = k / cstride, col = k % cstride;
+            if (row < lrows && col < lcols) continue;
+            if (seen++ == want) co[65536 + offset + k] = 3;
+          }
+          offset += size;
+          continue;
+        }
         for (int c = 0; c < 3; c++) {
           int32_t* q = co.data() + size_t(c) * 65536 + offset;
           for (size_t k = 0; k < size; k++) {
@@ -1583,6 +1606,441 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
       }
   }
   Assemble(f, p, out);
+}
+
+
+// ---------------------------------------------------------------- Modular (lossless) frames
+// A small lossless encoder for tests and the lossless benchmark stream (BASELINE.json configs[3]): 8-bit grey / RGB (+
+// alpha), non-XYB, groups of 256, one global MA tree. `flags`: bit 0 = prefix codes instead of rANS, bit 1 = LZ77,
+// bit 2 = weighted-predictor leaves and a split on its error property, bit 3 = Squeeze (default steps), bit 4 = RCT
+// (YCoCg) over the colour channels, bit 5 = every leaf uses a different predictor (all 14 occur), bit 6 = a split on a
+// previous-channel property (16: |value| of the channel before). Lossless: whatever decodes it must return the input.
+struct LosslessOptions {
+  uint32_t flags;
+  uint32_t seed;
+};
+struct LChannel {
+  size_t w = 0, h = 0;
+  int hshift = 0, vshift = 0;
+  std::vector<int32_t> d;
+  int32_t* Row(size_t y) { return d.data() + y * w; }
+  const int32_t* Row(size_t y) const { return d.data() + y * w; }
+};
+static void FwdSqueezeLine(const int32_t* in, ptrdiff_t si, size_t n, int32_t* avg, ptrdiff_t sa, int32_t* res, ptrdiff_t sr) {
+  // enc side of squeeze.cc: pair averages (rounded towards the first sample) and residuals minus the smooth tendency
+  const size_t na = (n + 1) / 2, nr = n / 2;
+  auto pair_avg = [&](size_t i) -> int64_t {
+    if (2 * i + 1 < n) {
+      const int64_t A = in[ptrdiff_t(2 * i) * si], B = in[ptrdiff_t(2 * i + 1) * si];
+      return (A + B + (A > B)) >> 1;
+    }
+    return in[ptrdiff_t(2 * i) * si];
+  };
+  for (size_t i = 0; i < nr; i++) {
+    const int64_t A = in[ptrdiff_t(2 * i) * si], B = in[ptrdiff_t(2 * i + 1) * si];
+    const int64_t a = pair_avg(i), next = i + 1 < na ? pair_avg(i + 1) : a, before = i ? in[ptrdiff_t(2 * i - 1) * si] : a;
+    avg[ptrdiff_t(i) * sa] = int32_t(a);
+    res[ptrdiff_t(i) * sr] = int32_t((A - B) - jxh::SqueezeTendency(before, a, next));
+  }
+  if (na > nr) avg[ptrdiff_t(na - 1) * sa] = in[ptrdiff_t(n - 1) * si];
+}
+
+static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, const LosslessOptions& o, std::vector<uint8_t>* out) {
+  const bool gray = nc <= 2, alpha = nc == 2 || nc == 4;
+  const uint32_t flags = o.flags;
+  const size_t gdim = 256, xg = DivCeil(xs, gdim), yg = DivCeil(ys, gdim), num_groups = xg * yg;
+  const size_t xdg = DivCeil(xs, gdim * 8), ydg = DivCeil(ys, gdim * 8), ndc = xdg * ydg;
+  // ---- channels + forward transforms
+  std::vector<LChannel> ch(nc);
+  for (size_t c = 0; c < nc; c++) {
+    ch[c].w = xs;
+    ch[c].h = ys;
+    ch[c].d.resize(xs * ys);
+    for (size_t i = 0; i < xs * ys; i++) ch[c].d[i] = px[i * nc + c];
+  }
+  const bool rct = (flags & 16) && !gray;
+  if (rct)  // forward YCoCg (rct.cc, type 6): the decoder computes tmp = Y - (Cg >> 1), G = Cg + tmp, B = tmp - (Co >> 1), R = B + Co
+    for (size_t i = 0; i < xs * ys; i++) {
+      const int32_t R = ch[0].d[i], G = ch[1].d[i], B = ch[2].d[i];
+      const int32_t Co = R - B, tmp = B + (Co >> 1), Cg = G - tmp, Y = tmp + (Cg >> 1);
+      ch[0].d[i] = Y;
+      ch[1].d[i] = Co;
+      ch[2].d[i] = Cg;
+    }
+  const bool squeeze = (flags & 8) != 0;
+  std::vector<jxh::SqueezeStep> steps;
+  if (squeeze) {
+    std::vector<jxh::MChannel> shapes(nc);
+    for (size_t c = 0; c < nc; c++) {
+      shapes[c].w = xs;
+      shapes[c].h = ys;
+    }
+    jxh::DefaultSqueeze(shapes, 0, &steps);
+    for (const jxh::SqueezeStep& q : steps) {
+      const size_t b = q.begin_c, e = b + q.num_c;
+      size_t at = q.in_place ? e : ch.size();
+      for (size_t c = b; c < e; c++, at++) {
+        const LChannel src = ch[c];
+        LChannel a, r;
+        a.hshift = r.hshift = src.hshift + (q.horizontal ? 1 : 0);
+        a.vshift = r.vshift = src.vshift + (q.horizontal ? 0 : 1);
+        if (q.horizontal) {
+          a.w = (src.w + 1) / 2;
+          a.h = src.h;
+          r.w = src.w - a.w;
+          r.h = src.h;
+        } else {
+          a.w = src.w;
+          a.h = (src.h + 1) / 2;
+          r.w = src.w;
+          r.h = src.h - a.h;
+        }
+        a.d.assign(a.w * a.h, 0);
+        r.d.assign(r.w * r.h, 0);
+        if (q.horizontal) {
+          std::vector<int32_t> dummy(1);
+          for (size_t y = 0; y < src.h; y++) FwdSqueezeLine(src.Row(y), 1, src.w, a.Row(y), 1, r.w ? r.Row(y) : dummy.data(), 1);
+        } else {
+          std::vector<int32_t> dummy(1);
+          for (size_t x = 0; x < src.w; x++)
+            FwdSqueezeLine(src.d.data() + x, ptrdiff_t(src.w), src.h, a.d.data() + x, ptrdiff_t(a.w), r.h ? r.d.data() + x : dummy.data(), ptrdiff_t(r.w));
+        }
+        ch[c] = a;
+        ch.insert(ch.begin() + at, r);
+      }
+    }
+  }
+  // ---- the global tree: split on the channel index, optionally on the WP error / gradient property / previous channel
+  struct Leaf {
+    uint32_t predictor;
+    int ctx;
+  };
+  struct Node {
+    int prop;
+    int32_t split;
+    int l, r;
+    Leaf leaf;
+  };
+  std::vector<Node> nodes;
+  int num_leaves = 0;
+  auto pick_predictor = [&](int k) -> uint32_t {
+    if (flags & 32) return uint32_t((k + o.seed) % 14);
+    return (flags & 4) ? 6u : 5u;
+  };
+  // BFS construction: chain over channel index (up to 6 buckets), each with optional sub-splits
+  {
+    struct Todo { int id; int lo, hi; int depth; };  // channel range [lo, hi]
+    const int maxc = int(std::min<size_t>(ch.size(), 6)) - 1;
+    nodes.push_back({-2, 0, 0, 0, {0, 0}});
+    std::vector<Todo> queue{{0, 0, maxc, 0}};
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+      const Todo t = queue[qi];
+      if (t.lo < t.hi) {
+        const int mid = (t.lo + t.hi) / 2;  // property 0 > mid ? left : right
+        nodes[t.id].prop = 0;
+        nodes[t.id].split = mid;
+        nodes[t.id].l = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        nodes[t.id].r = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        queue.push_back({nodes[t.id].l, mid + 1, t.hi, 0});
+        queue.push_back({nodes[t.id].r, t.lo, mid, 0});
+      } else if (t.depth == 0 && (flags & 4)) {  // WP error property
+        nodes[t.id].prop = 15;
+        nodes[t.id].split = 0;
+        nodes[t.id].l = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        nodes[t.id].r = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        queue.push_back({nodes[t.id].l, t.lo, t.hi, 1});
+        queue.push_back({nodes[t.id].r, t.lo, t.hi, 1});
+      } else if (t.depth <= 1 && (flags & 64) && t.lo > 0) {  // previous channel's |value|
+        nodes[t.id].prop = 16;
+        nodes[t.id].split = 20;
+        nodes[t.id].l = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        nodes[t.id].r = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        queue.push_back({nodes[t.id].l, t.lo, t.hi, 2});
+        queue.push_back({nodes[t.id].r, t.lo, t.hi, 2});
+      } else if (t.depth <= 2) {  // gradient property 9 against the local magnitude
+        nodes[t.id].prop = 5;  // |left|
+        nodes[t.id].split = 40;
+        nodes[t.id].l = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        nodes[t.id].r = int(nodes.size());
+        nodes.push_back({-2, 0, 0, 0, {0, 0}});
+        queue.push_back({nodes[t.id].l, t.lo, t.hi, 3});
+        queue.push_back({nodes[t.id].r, t.lo, t.hi, 3});
+      } else {
+        nodes[t.id].prop = -1;
+        nodes[t.id].leaf = {pick_predictor(num_leaves), num_leaves};
+        num_leaves++;
+      }
+    }
+  }
+  std::vector<Token> tree_tokens;
+  for (const Node& n : nodes) {
+    if (n.prop < 0) {
+      tree_tokens.push_back({1, 0});
+      tree_tokens.push_back({2, n.leaf.predictor});
+      tree_tokens.push_back({3, 0});
+      tree_tokens.push_back({4, 0});
+      tree_tokens.push_back({5, 0});
+    } else {
+      tree_tokens.push_back({1, uint32_t(n.prop + 1)});
+      tree_tokens.push_back({0, PackSigned(n.split)});
+    }
+  }
+  const bool uses_wp = (flags & 4) || ((flags & 32) != 0);
+  // ---- tokenise a stream: the same walk as encoding.cc:148-506 with the sample known
+  jxh::WpHeader wph;
+  auto tokenise = [&](const std::vector<const LChannel*>& part, const std::vector<std::pair<size_t, size_t>>& origin,
+                      const std::vector<std::pair<size_t, size_t>>& size, int stream_id, int first_index, std::vector<Token>* toks) {
+    for (size_t ci = 0; ci < part.size(); ci++) {
+      const LChannel& full = *part[ci];
+      const size_t w = size[ci].first, h = size[ci].second, ox = origin[ci].first, oy = origin[ci].second;
+      if (!w || !h) continue;
+      auto at = [&](const LChannel& c, size_t cox, size_t coy, ptrdiff_t x, ptrdiff_t y) -> int64_t { return c.Row(coy + size_t(y))[cox + size_t(x)]; };
+      // previous channel of the same shape (for property 16..19)
+      int ref = -1;
+      for (int j = int(ci) - 1; j >= 0; j--)
+        if (size[j] == size[ci] && part[j]->hshift == full.hshift && part[j]->vshift == full.vshift) {
+          ref = j;
+          break;
+        }
+      jxh::WpState wp(wph, w);
+      int32_t prev_p9 = 0;
+      for (size_t y = 0; y < h; y++) {
+        prev_p9 = 0;
+        for (size_t x = 0; x < w; x++) {
+          const int64_t left = x ? at(full, ox, oy, x - 1, y) : (y ? at(full, ox, oy, x, y - 1) : 0);
+          const int64_t top = y ? at(full, ox, oy, x, y - 1) : left;
+          const int64_t topleft = (x && y) ? at(full, ox, oy, x - 1, y - 1) : left;
+          const int64_t topright = (x + 1 < w && y) ? at(full, ox, oy, x + 1, y - 1) : top;
+          const int64_t leftleft = x > 1 ? at(full, ox, oy, x - 2, y) : left;
+          const int64_t toptop = y > 1 ? at(full, ox, oy, x, y - 2) : top;
+          const int64_t toprightright = (x + 2 < w && y) ? at(full, ox, oy, x + 2, y - 1) : topright;
+          int32_t props[20] = {0};
+          props[0] = int32_t(first_index + int(ci));
+          props[1] = stream_id;
+          props[2] = int32_t(y);
+          props[3] = int32_t(x);
+          props[4] = int32_t(top > 0 ? top : -top);
+          props[5] = int32_t(left > 0 ? left : -left);
+          props[6] = int32_t(top);
+          props[7] = int32_t(left);
+          props[8] = int32_t(left - prev_p9);
+          props[9] = int32_t(left + top - topleft);
+          prev_p9 = props[9];
+          int64_t wp_pred = 0;
+          if (uses_wp) wp_pred = wp.Predict(x, y, w, top, left, topright, topleft, toptop, &props[15]);
+          if (ref >= 0) {
+            const LChannel& rc = *part[ref];
+            const size_t rx = origin[ref].first, ry = origin[ref].second;
+            const int64_t v = at(rc, rx, ry, x, y), vl = x ? at(rc, rx, ry, x - 1, y) : 0;
+            const int64_t vt = y ? at(rc, rx, ry, x, y - 1) : vl, vtl = (x && y) ? at(rc, rx, ry, x - 1, y - 1) : vl;
+            const int64_t vp = jxh::ClampedGradient(int32_t(vl), int32_t(vt), int32_t(vtl));
+            props[16] = int32_t(v < 0 ? -v : v);
+            props[17] = int32_t(v);
+            props[18] = int32_t(v - vp < 0 ? vp - v : v - vp);
+            props[19] = int32_t(v - vp);
+          }
+          int pos = 0;
+          while (nodes[pos].prop >= 0) pos = props[nodes[pos].prop] > nodes[pos].split ? nodes[pos].l : nodes[pos].r;
+          const Leaf& lf = nodes[pos].leaf;
+          const int64_t guess = jxh::PredictOne(lf.predictor, left, top, toptop, topleft, topright, leftleft, toprightright, wp_pred);
+          const int64_t cur = at(full, ox, oy, x, y);
+          toks->push_back({uint32_t(lf.ctx), PackSigned(int32_t(cur - guess))});
+          if (uses_wp) wp.Update(cur, x, y, w);
+        }
+      }
+    }
+  };
+  // stream 0: channels no larger than a group; groups: rectangles by shift bracket (dec_modular.cc:320-425)
+  size_t first_big = 0;
+  while (first_big < ch.size() && ch[first_big].w <= gdim && ch[first_big].h <= gdim) first_big++;
+  std::vector<Token> global_tokens;
+  {
+    std::vector<const LChannel*> part;
+    std::vector<std::pair<size_t, size_t>> org, sz;
+    for (size_t c = 0; c < first_big; c++) {
+      part.push_back(&ch[c]);
+      org.push_back({0, 0});
+      sz.push_back({ch[c].w, ch[c].h});
+    }
+    tokenise(part, org, sz, 0, 0, &global_tokens);
+  }
+  auto group_tokens = [&](size_t x0, size_t y0, size_t span, int min_shift, int max_shift, int stream_id, std::vector<Token>* toks) {
+    std::vector<const LChannel*> part;
+    std::vector<std::pair<size_t, size_t>> org, sz;
+    for (size_t c = first_big; c < ch.size(); c++) {
+      const LChannel& fc = ch[c];
+      const int shift = std::min(fc.hshift, fc.vshift);
+      if (shift < min_shift || shift > max_shift) continue;
+      const size_t rx = x0 >> fc.hshift, ry = y0 >> fc.vshift;
+      if (rx >= fc.w || ry >= fc.h) continue;
+      const size_t rw = std::min(span >> fc.hshift, fc.w - rx), rh = std::min(span >> fc.vshift, fc.h - ry);
+      if (!rw || !rh) continue;
+      part.push_back(&fc);
+      org.push_back({rx, ry});
+      sz.push_back({rw, rh});
+    }
+    if (part.empty()) return false;
+    tokenise(part, org, sz, stream_id, 0, toks);
+    return true;
+  };
+  const bool multi = num_groups > 1;
+  std::vector<std::vector<Token>> dc_tokens(multi ? ndc : 0), ac_tokens(multi ? num_groups : 0);
+  std::vector<uint8_t> dc_present(dc_tokens.size(), 0), ac_present(ac_tokens.size(), 0);
+  if (multi) {
+#pragma omp parallel for schedule(dynamic)
+    for (size_t g = 0; g < ndc; g++)
+      dc_present[g] = group_tokens((g % xdg) * gdim * 8, (g / xdg) * gdim * 8, gdim * 8, 3, 1000, int(1 + ndc + g), &dc_tokens[g]);
+#pragma omp parallel for schedule(dynamic)
+    for (size_t g = 0; g < num_groups; g++)
+      ac_present[g] = group_tokens((g % xg) * gdim, (g / xg) * gdim, gdim, 0, 2, int(1 + 3 * ndc + 17 + g), &ac_tokens[g]);
+  }
+  // ---- codes
+  jxh::HybridCfg cfg420;
+  cfg420.split_exp = 4;
+  cfg420.split_token = 16;
+  cfg420.msb = 2;
+  cfg420.lsb = 0;
+  EncCode tree_code, code;
+  BuildCode({&tree_tokens}, 6, 6, cfg420, &tree_code);
+  const int mode = int(flags & 3);
+  std::vector<std::vector<Token>*> streams{&global_tokens};
+  for (auto& t : dc_tokens) streams.push_back(&t);
+  for (auto& t : ac_tokens) streams.push_back(&t);
+  if (mode & 2)
+    for (auto* t : streams) Lz77Pass(t, uint32_t(num_leaves), 120);
+  std::vector<const std::vector<Token>*> all(streams.begin(), streams.end());
+  BuildCode(all, size_t(num_leaves) + ((mode & 2) ? 1 : 0), 32, cfg420, &code, mode);
+  // ---- sections
+  auto write_stream_header = [&](BitWriter& bw, bool global) {
+    bw.Write(1, 1);  // use the global tree
+    bw.Write(1, 1);  // default weighted-predictor header
+    if (!global) {
+      bw.Write(2, 0);  // no transforms
+      return;
+    }
+    const uint32_t nt = (rct ? 1 : 0) + (squeeze ? 1 : 0);
+    bw.Write(2, nt);  // U32(Val(0), Val(1), BitsOffset(4, 2), ...): 0, 1 or selector 2 + 4 bits
+    if (nt == 2) bw.Write(4, 0);
+    if (rct) {
+      bw.Write(2, 0);  // RCT
+      bw.Write(2, 0);  // begin_c = 0 (3 bits follow)
+      bw.Write(3, 0);
+      bw.Write(2, 0);  // type 6 (YCoCg)
+    }
+    if (squeeze) {
+      bw.Write(2, 2);  // Squeeze
+      bw.Write(2, 0);  // default parameters
+    }
+  };
+  std::vector<std::vector<uint8_t>> sections;
+  auto dc_global = [&](BitWriter& bw) {
+    bw.Write(1, 1);  // default DC dequantisation
+    bw.Write(1, 1);  // global tree present
+    WriteCodeHeader(bw, tree_code);
+    WriteTokens(bw, tree_tokens.data(), tree_tokens.size(), tree_code);
+    WriteCodeHeader(bw, code);
+    write_stream_header(bw, true);
+    if (!global_tokens.empty()) WriteTokens(bw, global_tokens.data(), global_tokens.size(), code);
+  };
+  if (!multi) {
+    BitWriter bw;
+    dc_global(bw);
+    bw.ZeroPad();
+    sections.push_back(bw.bytes());
+  } else {
+    sections.resize(2 + ndc + num_groups);
+    {
+      BitWriter bw;
+      dc_global(bw);
+      bw.ZeroPad();
+      sections[0] = bw.bytes();
+    }
+    for (size_t g = 0; g < ndc; g++) {
+      BitWriter bw;
+      if (dc_present[g]) {
+        write_stream_header(bw, false);
+        WriteTokens(bw, dc_tokens[g].data(), dc_tokens[g].size(), code);
+      }
+      bw.ZeroPad();
+      sections[1 + g] = bw.bytes();
+    }
+#pragma omp parallel for schedule(dynamic)
+    for (size_t g = 0; g < num_groups; g++) {
+      BitWriter bw;
+      if (ac_present[g]) {
+        write_stream_header(bw, false);
+        WriteTokens(bw, ac_tokens[g].data(), ac_tokens[g].size(), code);
+      }
+      bw.ZeroPad();
+      sections[2 + ndc + g] = bw.bytes();
+    }
+  }
+  // ---- headers
+  BitWriter bw;
+  bw.Write(16, 0x0AFF);
+  bw.Write(1, 0);  // not "small"
+  WriteSizeDim(bw, uint32_t(ys));
+  bw.Write(3, 0);
+  WriteSizeDim(bw, uint32_t(xs));
+  bw.Write(1, 0);  // ImageMetadata not all_default
+  bw.Write(1, 0);  // no extra_fields
+  bw.Write(1, 0);  // integer samples
+  bw.Write(2, 0);  //   8 bits
+  bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
+  bw.Write(2, alpha ? 1 : 0);  // extra channels
+  if (alpha) bw.Write(1, 1);   //   all_default: 8-bit alpha
+  bw.Write(1, 0);  // xyb_encoded = false
+  if (!gray) {
+    bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
+  } else {
+    bw.Write(1, 0);  // not all_default
+    bw.Write(1, 0);  // no ICC
+    bw.Write(2, 1);  // colour space: grey
+    bw.Write(2, 1);  // white point D65
+    bw.Write(1, 0);  // no gamma
+    bw.Write(2, 2);  // transfer function: enum selector 2 + 4 bits, value 13 (sRGB)
+    bw.Write(4, 13 - 2);
+    bw.Write(2, 1);  // rendering intent: relative
+  }
+  bw.Write(2, 0);  // no extensions
+  bw.Write(1, 1);  // CustomTransformData all_default
+  bw.ZeroPad();
+  // FrameHeader
+  bw.Write(1, 0);  // not all_default
+  bw.Write(2, 0);  // regular frame
+  bw.Write(1, 1);  // Modular
+  bw.Write(2, 0);  // flags 0
+  bw.Write(1, 0);  // (not XYB:) no YCbCr
+  bw.Write(2, 0);  // upsampling 1
+  if (alpha) bw.Write(2, 0);
+  bw.Write(2, 1);  // group_size_shift 1 (256)
+  bw.Write(2, 0);  // one pass
+  bw.Write(1, 0);  // no custom size
+  bw.Write(2, 0);  // blend mode replace
+  if (alpha) bw.Write(2, 0);
+  bw.Write(1, 1);  // is_last
+  bw.Write(2, 0);  // no name
+  bw.Write(1, 0);  // loop filter not all_default
+  bw.Write(1, 0);  // no gaborish
+  bw.Write(2, 0);  // no EPF
+  bw.Write(2, 0);  // no loop-filter extensions
+  bw.Write(2, 0);  // no frame-header extensions
+  bw.Write(1, 0);  // TOC not permuted
+  bw.ZeroPad();
+  for (const auto& sct : sections) {
+    static const uint32_t bits[4] = {10, 14, 22, 30}, offs[4] = {0, 1024, 17408, 4211712};
+    WriteU32Sel(bw, uint32_t(sct.size()), bits, offs);
+  }
+  bw.ZeroPad();
+  *out = bw.bytes();
+  for (const auto& sct : sections) out->insert(out->end(), sct.begin(), sct.end());
 }
 
 }  // namespace jxe
@@ -1663,6 +2121,20 @@ int jxlenc_encode_rgba8(const uint8_t* rgba, uint32_t xs, uint32_t ys, const Jxl
   std::vector<uint8_t> v;
   try {
     jxe::EncodeImage(rgb.data(), xs, ys, q, &v, 0, 0, &alpha);
+  } catch (...) {
+    return -2;
+  }
+  return Finish(v, out, n);
+}
+
+// Lossless (Modular frame) stream of an interleaved 8-bit image with 1-4 channels; see jxe::EncodeLossless for `flags`.
+int jxlenc_encode_lossless(const uint8_t* px, uint32_t xs, uint32_t ys, uint32_t channels, uint32_t flags, uint32_t seed, uint8_t** out,
+                           size_t* n) {
+  if (!px || !xs || !ys || channels < 1 || channels > 4) return -1;
+  std::vector<uint8_t> v;
+  try {
+    jxe::LosslessOptions o{flags, seed};
+    jxe::EncodeLossless(px, xs, ys, channels, o, &v);
   } catch (...) {
     return -2;
   }

@@ -16,6 +16,7 @@
 #include "jxl_hip_kernels.h"
 #include "jxl_hip_entropy_lanes.h"
 #include "jxl_hip_filter_fused.h"
+#include "jxl_hip_modular.h"
 
 namespace {
 #include "../host/afv_basis.inc"
@@ -81,6 +82,21 @@ struct JxlHipContext {
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
   Buf plane[3], rgb, tlist, scratch, sec_end, lz_window;
   bool generic_codec = false;  // a pass is prefix-coded or uses LZ77: k_entropy_generic decodes the frame
+  // ---- Modular frame (jxlhip_modular_upload): channel pool, tables, stream descriptors, inverse-transform operations
+  struct Modular {
+    bool have = false;
+    Buf pool, sections, blob, streams, rects, status, end_bits, scratch, windows, batch_streams;
+    std::vector<size_t> buf_off;            // per channel buffer: first int32 of the pool
+    std::vector<uint32_t> buf_w, buf_h;
+    std::vector<JxlHipModOp> ops;
+    std::vector<jxlhip::ModStream> streams_host;  // device pointers filled in
+    std::vector<uint32_t> stream_samples;
+    uint32_t out_buffer[4] = {0, 0, 0, 0};
+    uint32_t num_color = 3, has_alpha = 0, bits = 8, alpha_bits = 8, xs = 0, ys = 0, nstreams = 0;
+    std::vector<const JxlHipContext*> batch_ctxs;
+    std::vector<uint64_t> batch_gens;
+    uint32_t batch_n = 0;
+  } mod;
   size_t plane_bytes = 0;  // bytes of plane[0] the current frame needs
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
   Buf batch_wave_ls;
@@ -258,7 +274,8 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window};
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
+                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -1330,6 +1347,388 @@ extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   return c->lanes ? jxlhip_run_entropy_batch(&c, 1) : RunEntropySingle(c);
+}
+
+
+// ------------------------------------------------------------------------------------------------ Modular frames
+extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc* d) {
+  if (!c || !d || !d->xsize || !d->ysize || !d->num_sections || !d->num_trees || !d->num_codes || d->num_trees != d->num_codes)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (d->num_color != 1 && d->num_color != 3) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  JxlHipContext::Modular& M = c->mod;
+  M.have = false;
+  c->have_frame = false;
+  int r;
+  // ---- channel pool
+  M.buf_off.assign(d->num_buffers, 0);
+  M.buf_w.assign(d->num_buffers, 0);
+  M.buf_h.assign(d->num_buffers, 0);
+  size_t pool = 0;
+  for (uint32_t i = 0; i < d->num_buffers; i++) {
+    M.buf_off[i] = pool;
+    M.buf_w[i] = d->buffers[i].w;
+    M.buf_h[i] = d->buffers[i].h;
+    pool += (size_t(d->buffers[i].w) * d->buffers[i].h + 3) & ~size_t(3);
+  }
+  if ((r = M.pool.Ensure((pool + 4) * 4))) return r;
+  // ---- sections, 4-byte aligned, zero padded
+  std::vector<size_t> sec_off(d->num_sections);
+  size_t total = 0;
+  for (uint32_t i = 0; i < d->num_sections; i++) {
+    sec_off[i] = total;
+    total += (size_t(d->section_size[i]) + 3 + 8) & ~size_t(3);
+  }
+  std::vector<uint8_t> packed(total + 16, 0);
+  for (uint32_t i = 0; i < d->num_sections; i++) memcpy(packed.data() + sec_off[i], d->codestream + d->section_offset[i], d->section_size[i]);
+  if ((r = Upload(c, M.sections, packed.data(), packed.size()))) return r;
+  // ---- trees and codes: one blob, device pointers patched in
+  std::vector<uint8_t> blob;
+  auto put = [&](const void* src, size_t bytes) {
+    const size_t at = (blob.size() + 15) & ~size_t(15);
+    blob.resize(at + bytes);
+    if (bytes) memcpy(blob.data() + at, src, bytes);
+    return at;
+  };
+  std::vector<size_t> tree_at(d->num_trees), code_at(d->num_codes);
+  std::vector<std::vector<size_t>> code_parts(d->num_codes);  // ctx_map, alias, cfg, prefix_table, prefix_offset
+  for (uint32_t i = 0; i < d->num_trees; i++) {
+    static_assert(sizeof(JxlHipModTreeNode) == sizeof(jxlhip::ModTreeNode), "tree node layout");
+    for (uint32_t k = 0; k < d->tree_size[i]; k++) {  // every index the walk can follow must exist
+      const JxlHipModTreeNode& nd = d->trees[i][k];
+      if (nd.property >= int32_t(jxlhip::kModMaxProps)) return JXLHIP_ERR_UNSUPPORTED;
+      if (nd.property >= 0 && (nd.lchild >= d->tree_size[i] || nd.rchild >= d->tree_size[i])) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (nd.property < 0 && (nd.predictor > 13 || nd.lchild >= d->codes[i].ctx_map_size)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    }
+    tree_at[i] = put(d->trees[i], size_t(d->tree_size[i]) * sizeof(JxlHipModTreeNode));
+  }
+  for (uint32_t i = 0; i < d->num_codes; i++) {
+    const JxlHipModCode& k = d->codes[i];
+    if (!d->tree_size[i]) {  // (an absent global tree)
+      code_parts[i] = {0, 0, 0, 0, 0};
+      continue;
+    }
+    if (!k.num_clusters || k.num_clusters > 256 || !k.ctx_map_size) return JXLHIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t j = 0; j < k.ctx_map_size; j++)
+      if (k.ctx_map[j] >= k.num_clusters) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (!k.use_prefix && (k.log_alpha < 5 || k.log_alpha > 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (k.use_prefix)
+      for (uint32_t j = 0; j < k.num_clusters; j++) {
+        const uint32_t first = k.prefix_offset[j] & 0xFFFFFFu, max_len = k.prefix_offset[j] >> 24;
+        if (max_len > 15 || size_t(first) + (size_t(1) << max_len) > k.prefix_table_size) return JXLHIP_ERR_INVALID_ARGUMENT;
+        for (size_t q = 0; q < (size_t(1) << max_len); q++)
+          if ((k.prefix_table[first + q] & 0xFF) > max_len) return JXLHIP_ERR_INVALID_ARGUMENT;
+      }
+    if (k.lz77 && (k.lz_dist_ctx >= k.num_clusters || !k.lz_min_length)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    code_parts[i] = {put(k.ctx_map, k.ctx_map_size), put(k.alias, k.use_prefix ? 0 : (size_t(k.num_clusters) << k.log_alpha) * 8),
+                     put(k.uint_cfg, size_t(k.num_clusters) * 4), put(k.prefix_table, k.use_prefix ? size_t(k.prefix_table_size) * 4 : 0),
+                     put(k.prefix_offset, k.use_prefix ? size_t(k.num_clusters) * 4 : 0)};
+  }
+  const size_t codes_at = (blob.size() + 15) & ~size_t(15);
+  blob.resize(codes_at + size_t(d->num_codes) * sizeof(jxlhip::ModCode));
+  if ((r = M.blob.Ensure(blob.size() + 16))) return r;
+  uint8_t* dev = M.blob.as<uint8_t>();
+  for (uint32_t i = 0; i < d->num_codes; i++) {
+    const JxlHipModCode& k = d->codes[i];
+    jxlhip::ModCode mc;
+    memset(&mc, 0, sizeof(mc));
+    mc.ctx_map = dev + code_parts[i][0];
+    mc.alias = reinterpret_cast<const uint2*>(dev + code_parts[i][1]);
+    mc.cfg = reinterpret_cast<const uint32_t*>(dev + code_parts[i][2]);
+    mc.prefix_table = reinterpret_cast<const uint32_t*>(dev + code_parts[i][3]);
+    mc.prefix_offset = reinterpret_cast<const uint32_t*>(dev + code_parts[i][4]);
+    mc.log_alpha = k.log_alpha;
+    mc.use_prefix = k.use_prefix;
+    mc.lz77 = k.lz77;
+    mc.lz_min_symbol = k.lz_min_symbol;
+    mc.lz_min_length = k.lz_min_length;
+    mc.lz_len_cfg = k.lz_len_cfg;
+    mc.lz_dist_ctx = k.lz_dist_ctx;
+    memcpy(blob.data() + codes_at + size_t(i) * sizeof(mc), &mc, sizeof(mc));
+  }
+  HIP_TRY(hipMemcpyAsync(M.blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
+  // ---- rectangles and streams
+  std::vector<jxlhip::ModChannel> rects(d->num_rects ? d->num_rects : 1);
+  for (uint32_t i = 0; i < d->num_rects; i++) {
+    const JxlHipModRect& q = d->rects[i];
+    if (q.buffer >= d->num_buffers || uint64_t(q.x0) + q.w > M.buf_w[q.buffer] || uint64_t(q.y0) + q.h > M.buf_h[q.buffer])
+      return JXLHIP_ERR_INVALID_ARGUMENT;
+    rects[i].data = M.pool.as<int32_t>() + M.buf_off[q.buffer] + size_t(q.y0) * M.buf_w[q.buffer] + q.x0;
+    rects[i].stride = M.buf_w[q.buffer];
+    rects[i].w = q.w;
+    rects[i].h = q.h;
+    rects[i].sig = q.sig;
+  }
+  if ((r = Upload(c, M.rects, rects.data(), rects.size() * sizeof(rects[0])))) return r;
+  M.nstreams = d->num_streams;
+  if ((r = M.status.Ensure(size_t(d->num_streams + 1) * 4))) return r;
+  if ((r = M.end_bits.Ensure(size_t(d->num_streams + 1) * 4))) return r;
+  size_t scratch_ints = 0, window_words = 0;
+  std::vector<size_t> scratch_at(d->num_streams, 0), window_at(d->num_streams, 0);
+  std::vector<uint32_t> window_mask(d->num_streams, 0);
+  for (uint32_t i = 0; i < d->num_streams; i++) {
+    const JxlHipModStream& q = d->streams[i];
+    if (q.section >= d->num_sections || q.tree >= d->num_trees || q.code >= d->num_codes || !d->tree_size[q.tree] ||
+        uint64_t(q.first_rect) + q.num_rects > d->num_rects || q.bit_offset > uint64_t(d->section_size[q.section]) * 8 ||
+        q.num_props < 16 || q.num_props > uint32_t(jxlhip::kModMaxProps))
+      return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (q.uses_wp) {
+      scratch_at[i] = scratch_ints;
+      scratch_ints += size_t(q.max_width + 2) * 2 * 5;
+    }
+    if (d->codes[q.code].lz77) {
+      uint32_t w = 256;
+      while (w < q.num_samples && w < (1u << 20)) w <<= 1;  // as large as the stream can fill, at most the format's 2^20
+      window_at[i] = window_words;
+      window_mask[i] = w - 1;
+      window_words += w;
+    }
+  }
+  if ((r = M.scratch.Ensure((scratch_ints + 4) * 4))) return r;
+  if ((r = M.windows.Ensure((window_words + 4) * 4))) return r;
+  M.streams_host.assign(d->num_streams, jxlhip::ModStream());
+  M.stream_samples.assign(d->num_streams, 0);
+  for (uint32_t i = 0; i < d->num_streams; i++) {
+    const JxlHipModStream& q = d->streams[i];
+    jxlhip::ModStream& o = M.streams_host[i];
+    memset(&o, 0, sizeof(o));
+    o.words = reinterpret_cast<const uint32_t*>(M.sections.as<uint8_t>() + sec_off[q.section]);
+    o.bit_offset = q.bit_offset;
+    o.size_bytes = d->section_size[q.section];
+    o.tree = reinterpret_cast<const jxlhip::ModTreeNode*>(dev + tree_at[q.tree]);
+    o.code = reinterpret_cast<const jxlhip::ModCode*>(dev + codes_at) + q.code;
+    o.channels = M.rects.as<jxlhip::ModChannel>() + q.first_rect;
+    o.num_channels = q.num_rects;
+    o.stream_id = q.stream_id;
+    o.first_channel_index = q.first_channel_index;
+    memcpy(o.wp, q.wp, sizeof(o.wp));
+    o.uses_wp = q.uses_wp;
+    o.num_props = q.num_props;
+    o.dist_multiplier = q.dist_multiplier;
+    o.wp_scratch = q.uses_wp ? M.scratch.as<int32_t>() + scratch_at[i] : nullptr;
+    o.lz_window = d->codes[q.code].lz77 ? M.windows.as<uint32_t>() + window_at[i] : nullptr;
+    o.lz_window_mask = window_mask[i];
+    o.status = M.status.as<uint32_t>() + i;
+    o.end_bit = M.end_bits.as<uint32_t>() + i;
+    M.stream_samples[i] = q.num_samples;
+  }
+  if ((r = Upload(c, M.streams, M.streams_host.data(), M.streams_host.size() * sizeof(jxlhip::ModStream)))) return r;
+  // ---- operations and output
+  M.ops.assign(d->ops, d->ops + d->num_ops);
+  for (const JxlHipModOp& op : M.ops) {
+    const uint32_t nbuf = op.kind == 0 ? 3 : (op.kind == 1 ? 2 + op.nb : 3);
+    if (op.kind > 3 || nbuf > 6) return JXLHIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t j = 0; j < nbuf; j++)
+      if (op.buf[j] >= d->num_buffers) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (op.kind == 0) {
+      for (int j = 0; j < 3; j++)
+        if (uint64_t(op.x0) + op.w > M.buf_w[op.buf[j]] || uint64_t(op.y0) + op.h > M.buf_h[op.buf[j]]) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (op.param >= 42) return JXLHIP_ERR_INVALID_ARGUMENT;
+    } else if (op.kind == 1) {
+      if (op.nb < 1 || op.nb > 4 || M.buf_h[op.buf[0]] < op.nb || op.param != M.buf_w[op.buf[0]]) return JXLHIP_ERR_INVALID_ARGUMENT;
+      for (uint32_t j = 1; j < 2 + op.nb; j++)
+        if (M.buf_w[op.buf[j]] != op.w || M.buf_h[op.buf[j]] != op.h) return JXLHIP_ERR_INVALID_ARGUMENT;
+    } else {
+      const uint32_t a = op.buf[0], q = op.buf[1], o = op.buf[2];
+      const bool hz = op.kind == 2;
+      const uint32_t na = hz ? M.buf_w[a] : M.buf_h[a], nr = hz ? M.buf_w[q] : M.buf_h[q], no = hz ? M.buf_w[o] : M.buf_h[o];
+      const uint32_t la = hz ? M.buf_h[a] : M.buf_w[a], lr = hz ? M.buf_h[q] : M.buf_w[q], lo = hz ? M.buf_h[o] : M.buf_w[o];
+      if (na + nr != no || (nr != na && nr + 1 != na) || la != lr || la != lo) return JXLHIP_ERR_INVALID_ARGUMENT;
+    }
+  }
+  for (uint32_t j = 0; j < d->num_color + (d->has_alpha ? 1 : 0); j++) {
+    if (d->out_buffer[j] >= d->num_buffers || M.buf_w[d->out_buffer[j]] != d->xsize || M.buf_h[d->out_buffer[j]] != d->ysize)
+      return JXLHIP_ERR_INVALID_ARGUMENT;
+    M.out_buffer[j] = d->out_buffer[j];
+  }
+  M.num_color = d->num_color;
+  M.has_alpha = d->has_alpha;
+  M.bits = d->bits;
+  M.alpha_bits = d->alpha_bits;
+  if (!M.bits || M.bits > 24 || !M.alpha_bits || M.alpha_bits > 24) return JXLHIP_ERR_INVALID_ARGUMENT;
+  M.xs = d->xsize;
+  M.ys = d->ysize;
+  c->oxs = c->xs = d->xsize;
+  c->oys = c->ys = d->ysize;
+  if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the staging vectors are locals
+  M.have = true;
+  M.batch_ctxs.clear();
+  c->generation++;
+  return 0;
+}
+
+static int ModularLaunchOps(JxlHipContext* c, hipStream_t st) {
+  JxlHipContext::Modular& M = c->mod;
+  int32_t* pool = M.pool.as<int32_t>();
+  for (const JxlHipModOp& op : M.ops) {
+    if (op.kind == 0) {
+      jxlhip::ModRct p;
+      for (int j = 0; j < 3; j++) {
+        p.stride[j] = M.buf_w[op.buf[j]];
+        p.c[j] = pool + M.buf_off[op.buf[j]] + size_t(op.y0) * p.stride[j] + op.x0;
+      }
+      p.w = op.w;
+      p.h = op.h;
+      p.type = op.param;
+      if (op.w && op.h) hipLaunchKernelGGL(jxlhip::k_modular_rct, dim3((op.w + 255) / 256, op.h), dim3(256), 0, st, p);
+    } else if (op.kind == 1) {
+      jxlhip::ModPalette p;
+      memset(&p, 0, sizeof(p));
+      p.palette = pool + M.buf_off[op.buf[0]];
+      p.index = pool + M.buf_off[op.buf[1]];
+      for (uint32_t j = 0; j < op.nb; j++) p.out[j] = pool + M.buf_off[op.buf[2 + j]];
+      p.palette_w = op.param;
+      p.nb = op.nb;
+      p.w = op.w;
+      p.h = op.h;
+      p.bit_depth = op.bit_depth;
+      p.index_stride = op.w;
+      p.out_stride = op.w;
+      if (op.w && op.h) hipLaunchKernelGGL(jxlhip::k_modular_palette, dim3((op.w + 255) / 256, op.h), dim3(256), 0, st, p);
+    } else {
+      const uint32_t a = op.buf[0], q = op.buf[1], o = op.buf[2];
+      const bool hz = op.kind == 2;
+      jxlhip::ModUnsqueeze p;
+      p.avg = pool + M.buf_off[a];
+      p.res = pool + M.buf_off[q];
+      p.out = pool + M.buf_off[o];
+      p.lines = hz ? M.buf_h[a] : M.buf_w[a];
+      p.na = hz ? M.buf_w[a] : M.buf_h[a];
+      p.nr = hz ? M.buf_w[q] : M.buf_h[q];
+      p.avg_line = hz ? M.buf_w[a] : 1;
+      p.avg_step = hz ? 1 : M.buf_w[a];
+      p.res_line = hz ? M.buf_w[q] : 1;
+      p.res_step = hz ? 1 : M.buf_w[q];
+      p.out_line = hz ? M.buf_w[o] : 1;
+      p.out_step = hz ? 1 : M.buf_w[o];
+      if (p.lines) hipLaunchKernelGGL(jxlhip::k_modular_unsqueeze, dim3((p.lines + 63) / 64), dim3(64), 0, st, p);
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  jxlhip::ModOutput o;
+  memset(&o, 0, sizeof(o));
+  for (uint32_t j = 0; j < M.num_color + (M.has_alpha ? 1 : 0); j++) {
+    o.ch[j] = pool + M.buf_off[M.out_buffer[j]];
+    o.stride[j] = M.xs;
+  }
+  o.num_color = M.num_color;
+  o.has_alpha = M.has_alpha;
+  o.bits = M.bits;
+  o.alpha_bits = M.alpha_bits;
+  o.w = M.xs;
+  o.h = M.ys;
+  o.po.dst = c->rgb.p;
+  o.po.alpha = nullptr;
+  o.po.xsize = M.xs;
+  o.po.type = c->out_type;
+  o.po.nc = c->out_nc;
+  o.po.bits = c->out_bits;
+  o.po.swap = c->out_swap;
+  hipLaunchKernelGGL(jxlhip::k_modular_output, dim3((M.xs + 255) / 256, M.ys), dim3(256), 0, st, o);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n) {
+  if (!ctxs || !n) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JxlHipContext* c0 = ctxs[0];
+  for (size_t i = 0; i < n; i++) {
+    if (!ctxs[i] || ctxs[i]->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (!ctxs[i]->mod.have) return JXLHIP_ERR_NO_FRAME;
+    if (size_t(ctxs[i]->oxs) * ctxs[i]->oys * OutPixelBytes(ctxs[i]) > ctxs[i]->rgb.cap) return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
+  HIP_TRY(hipSetDevice(c0->device));
+  JxlHipContext::Modular& M0 = c0->mod;
+  bool same = M0.batch_ctxs.size() == n;
+  for (size_t i = 0; same && i < n; i++) same = M0.batch_ctxs[i] == ctxs[i] && M0.batch_gens[i] == ctxs[i]->generation;
+  if (!same) {
+    // every stream of every frame, largest first: the lanes of a wave then carry streams of similar length
+    struct Ref {
+      uint32_t samples;
+      const jxlhip::ModStream* s;
+    };
+    std::vector<Ref> all;
+    for (size_t i = 0; i < n; i++)
+      for (size_t j = 0; j < ctxs[i]->mod.streams_host.size(); j++) all.push_back({ctxs[i]->mod.stream_samples[j], &ctxs[i]->mod.streams_host[j]});
+    std::stable_sort(all.begin(), all.end(), [](const Ref& a, const Ref& b) { return a.samples > b.samples; });
+    std::vector<jxlhip::ModStream> flat(all.size() ? all.size() : 1);
+    for (size_t i = 0; i < all.size(); i++) flat[i] = *all[i].s;
+    int r = M0.batch_streams.Ensure(flat.size() * sizeof(jxlhip::ModStream));
+    if (r) return r;
+    HIP_TRY(hipMemcpy(M0.batch_streams.p, flat.data(), flat.size() * sizeof(jxlhip::ModStream), hipMemcpyHostToDevice));
+    M0.batch_ctxs.assign(ctxs, ctxs + n);
+    M0.batch_gens.resize(n);
+    for (size_t i = 0; i < n; i++) M0.batch_gens[i] = ctxs[i]->generation;
+    M0.batch_n = uint32_t(all.size());
+  }
+  for (size_t i = 0; i < n; i++) {
+    int pw = ApplyPendingWait(ctxs[i]);
+    if (pw) return pw;
+  }
+  for (size_t i = 1; i < n; i++) {  // the launch runs on the first context's stream, after what the others still have in flight
+    if (!ctxs[i]->down_done) HIP_TRY(hipEventCreateWithFlags(&ctxs[i]->down_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctxs[i]->down_done, ctxs[i]->stream));
+    HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->down_done, 0));
+  }
+  HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
+  if (M0.batch_n) {
+    hipLaunchKernelGGL(jxlhip::k_modular_streams, dim3((M0.batch_n + 63) / 64), dim3(64), 0, c0->stream,
+                       M0.batch_streams.as<jxlhip::ModStream>(), M0.batch_n);
+    HIP_TRY(hipGetLastError());
+  }
+  for (size_t i = 0; i < n; i++) {
+    int r = ModularLaunchOps(ctxs[i], c0->stream);
+    if (r) return r;
+  }
+  HIP_TRY(hipEventRecord(c0->ev[1], c0->stream));
+  c0->ev_valid[0] = true;
+  if (n > 1) {
+    if (!c0->batch_done) HIP_TRY(hipEventCreateWithFlags(&c0->batch_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c0->batch_done, c0->stream));
+    for (size_t i = 1; i < n; i++) ctxs[i]->pending_wait = c0->batch_done;
+  }
+  for (size_t i = 0; i < n; i++) ctxs[i]->have_frame = true;  // (the pixel download entry points need it)
+  return 0;
+}
+extern "C" int jxlhip_modular_run(JxlHipContext* c) { return jxlhip_modular_run_batch(&c, 1); }
+
+extern "C" int jxlhip_modular_status(JxlHipContext* c, uint32_t* status, uint32_t* end_bits, size_t n) {
+  if (!c || !status) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->mod.have) return JXLHIP_ERR_NO_FRAME;
+  if (n < c->mod.nstreams) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->mod.nstreams) {
+    HIP_TRY(hipMemcpy(status, c->mod.status.p, size_t(c->mod.nstreams) * 4, hipMemcpyDeviceToHost));
+    if (end_bits) HIP_TRY(hipMemcpy(end_bits, c->mod.end_bits.p, size_t(c->mod.nstreams) * 4, hipMemcpyDeviceToHost));
+  }
+  for (uint32_t i = 0; i < c->mod.nstreams; i++)
+    if (status[i]) return JXLHIP_ERR_STREAM;
+  return 0;
+}
+
+extern "C" int jxlhip_modular_download_buffer(JxlHipContext* c, uint32_t buffer, int32_t* dst, size_t n) {
+  if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->mod.have) return JXLHIP_ERR_NO_FRAME;
+  if (buffer >= c->mod.buf_off.size() || n < size_t(c->mod.buf_w[buffer]) * c->mod.buf_h[buffer]) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(dst, c->mod.pool.as<int32_t>() + c->mod.buf_off[buffer], size_t(c->mod.buf_w[buffer]) * c->mod.buf_h[buffer] * 4,
+                    hipMemcpyDeviceToHost));
+  return 0;
 }
 
 extern "C" {

@@ -334,7 +334,9 @@ __device__ __forceinline__ uint32_t GenericUint(GenericReader& r, uint32_t cfg, 
 __device__ __forceinline__ uint32_t GenericRead(GenericReader& r, uint32_t cluster) {
   const PassDev& T = *r.T;
   if (T.lz77 && r.num_to_copy > 0) {
-    const uint32_t v = r.window[(r.copy_pos++) & (kLzWindow - 1)];
+    // (copy_pos == num_decoded only for a copy at the very start of a stream, distance 0: zeros, dec_ans.h:320-327)
+    const uint32_t v = r.copy_pos >= r.num_decoded ? 0u : r.window[r.copy_pos & (kLzWindow - 1)];
+    r.copy_pos++;
     r.num_to_copy--;
     r.window[(r.num_decoded++) & (kLzWindow - 1)] = v;
     return v;
@@ -352,7 +354,8 @@ __device__ __forceinline__ uint32_t GenericRead(GenericReader& r, uint32_t clust
       r.num_to_copy = 0;
       return 0;
     }
-    const uint32_t v = distance == 0 ? 0u : r.window[(r.copy_pos++) & (kLzWindow - 1)];
+    const uint32_t v = distance == 0 ? 0u : r.window[r.copy_pos & (kLzWindow - 1)];
+    r.copy_pos++;
     r.num_to_copy--;
     r.window[(r.num_decoded++) & (kLzWindow - 1)] = v;
     return v;

@@ -1,0 +1,303 @@
+// Known-answer tests of the host bitstream layers, compiled by the test suite once against the PRODUCT's host front-end
+// (libjxl_amd/csrc/host/jxh_*.h) and once, with -DKAT_ORACLE, against the oracle's headers. The expectations come from
+// the reference's own tests and from reference-ENCODER output, never from the other decoder:
+//   alias    every symbol's offsets enumerate 0 .. freq-1 exactly once over the 4096 slots (ans_common_test.cc:26-44)
+//   hybrid   the worked examples of lib/jxl/dec_ans.h:47-67 and the round trip of entropy_coder_test.cc:38-59
+//   lehmer   random permutations -> Lehmer code -> DecodeLehmer (lehmer_code_test.cc)
+//   fjxl F.jxl F.raw W H C   a Modular (lossless) file written by the reference's enc_fast_lossless.cc decodes, through
+//            this front-end's bit reader / headers / TOC / prefix + LZ77 entropy coder / MA-tree channel decode / inverse
+//            transforms, to exactly the raw interleaved 8-bit samples it was made from.
+// usage: host_kats {alias|hybrid|lehmer|fjxl ...};  exit code 0 = pass, message on stderr otherwise.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifdef KAT_ORACLE
+#include "../../oracle/jxlo_bits.h"
+#include "../../oracle/jxlo_entropy.h"
+#include "../../oracle/jxlo_headers.h"
+#include "../../oracle/jxlo_modular.h"
+namespace H = jxlo;
+#else
+#include "../../libjxl_amd/csrc/host/jxh_bits.h"
+#include "../../libjxl_amd/csrc/host/jxh_entropy.h"
+#include "../../libjxl_amd/csrc/host/jxh_headers.h"
+#include "../../libjxl_amd/csrc/host/jxh_modular.h"
+namespace H = jxh;
+#endif
+
+#define REQUIRE(cond, ...)                \
+  do {                                    \
+    if (!(cond)) {                        \
+      fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+      fprintf(stderr, __VA_ARGS__);       \
+      fprintf(stderr, "\n");              \
+      return 1;                           \
+    }                                     \
+  } while (0)
+
+static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+static uint32_t Rnd(uint32_t n) {
+  g_rng ^= g_rng << 13;
+  g_rng ^= g_rng >> 7;
+  g_rng ^= g_rng << 17;
+  return uint32_t((g_rng >> 11) % n);
+}
+
+static int VerifyAlias(const std::vector<int32_t>& dist, int log_alpha) {
+  std::vector<H::AliasEntry> table(size_t(1) << log_alpha);
+  H::InitAliasTable(dist, log_alpha, table.data());
+  const int log_entry = 12 - log_alpha;
+  std::vector<std::vector<uint32_t>> offsets(dist.size());
+  for (uint32_t slot = 0; slot < 4096; slot++) {
+    const H::AliasEntry& e = table[slot >> log_entry];
+    const uint32_t pos = slot & ((1u << log_entry) - 1);
+    uint32_t sym, off, freq;
+    if (pos >= e.cutoff) {
+      sym = e.right_value;
+      off = e.offsets1 + pos;
+      freq = e.freq1;
+    } else {
+      sym = slot >> log_entry;
+      off = pos;
+      freq = e.freq0;
+    }
+    REQUIRE(sym < dist.size(), "slot %u maps to symbol %u outside the alphabet", slot, sym);
+    REQUIRE(freq == uint32_t(dist[sym]) || (dist[sym] == 4096 && (freq & 0xFFF) == 0), "slot %u: frequency %u of symbol %u, expected %d", slot,
+            freq, sym, dist[sym]);
+    offsets[sym].push_back(off);
+  }
+  for (size_t s = 0; s < dist.size(); s++) {
+    REQUIRE(offsets[s].size() == size_t(dist[s]), "symbol %zu owns %zu slots, expected %d", s, offsets[s].size(), dist[s]);
+    std::vector<bool> seen(offsets[s].size(), false);
+    for (uint32_t o : offsets[s]) {
+      REQUIRE(o < seen.size() && !seen[o], "symbol %zu: offset %u repeated or out of range", s, o);
+      seen[o] = true;
+    }
+  }
+  return 0;
+}
+static int TestAlias() {
+  if (VerifyAlias({2048, 2048}, 8)) return 1;  // AliasDistributionSmoke
+  if (VerifyAlias({4096}, 8)) return 1;
+  if (VerifyAlias({0, 0, 0, 4096, 0}, 8)) return 1;
+  for (int log_alpha = 5; log_alpha <= 8; log_alpha++)
+    for (int rep = 0; rep < 200; rep++) {
+      const size_t n = 1 + Rnd(1u << log_alpha);
+      std::vector<int32_t> d(n, 0);
+      int32_t left = 4096;
+      // random composition of 4096, some symbols empty
+      for (size_t i = 0; i + 1 < n && left > 0; i++) {
+        if (Rnd(4) == 0) continue;
+        const int32_t v = int32_t(Rnd(uint32_t(std::min<int32_t>(left, 1 + 8192 / int32_t(n)))));
+        d[i] = v;
+        left -= v;
+      }
+      d[n - 1] += left;
+      if (VerifyAlias(d, log_alpha)) {
+        fprintf(stderr, "  (log_alpha %d, alphabet %zu, repetition %d)\n", log_alpha, n, rep);
+        return 1;
+      }
+    }
+  return 0;
+}
+
+// value -> (token, nbits, bits) as the reference's encoder side defines it (dec_ans.h:47-67, HybridUintConfig::Encode)
+static void HybridEncode(uint32_t se, uint32_t msb, uint32_t lsb, uint32_t value, uint32_t* token, uint32_t* nbits, uint32_t* bits) {
+  if (value < (1u << se)) {
+    *token = value;
+    *nbits = *bits = 0;
+    return;
+  }
+  uint32_t n = 31;
+  while (!(value >> n)) n--;
+  const uint32_t m = value - (1u << n);
+  *token = (1u << se) + ((n - se) << (msb + lsb)) + ((m >> (n - msb)) << lsb) + (m & ((1u << lsb) - 1));
+  *nbits = n - msb - lsb;
+  *bits = (value >> lsb) & ((1u << *nbits) - 1);
+}
+static int TestHybrid() {
+  struct Ex { uint32_t n, token, nbits, bits; };
+  static const Ex kExamples[] = {{0, 0, 0, 0},   {15, 15, 0, 0}, {16, 16, 2, 0}, {17, 16, 2, 1}, {20, 17, 2, 0},
+                                 {24, 18, 2, 0}, {28, 19, 2, 0}, {32, 20, 3, 0}, {65535, 63, 13, 0x1FFF}};  // dec_ans.h:58-67
+  H::HybridCfg c;
+  c.split_exp = 4;
+  c.split_token = 16;
+  c.msb = 2;
+  c.lsb = 0;
+  for (const Ex& e : kExamples) {
+    uint8_t buf[8] = {uint8_t(e.bits), uint8_t(e.bits >> 8), 0, 0, 0, 0, 0, 0};
+    H::BitReader br(buf, sizeof(buf));
+    const uint32_t v = H::SymbolReader::ReadHybrid(c, e.token, &br);
+    REQUIRE(v == e.n, "token %u + bits %u decodes to %u, the reference's example says %u", e.token, e.bits, v, e.n);
+    REQUIRE(br.BitPos() == e.nbits, "token %u consumed %zu bits, expected %u", e.token, size_t(br.BitPos()), e.nbits);
+  }
+  static const uint32_t kConfigs[][3] = {{0, 0, 0}, {4, 1, 1}, {4, 2, 0}, {4, 1, 0}, {5, 2, 1}, {8, 0, 0}, {15, 0, 0}, {3, 3, 0}};
+  for (const auto& k : kConfigs) {
+    c.split_exp = k[0];
+    c.split_token = 1u << k[0];
+    c.msb = k[1];
+    c.lsb = k[2];
+    for (int i = 0; i < 200000; i++) {
+      const uint32_t value = i < 70000 ? uint32_t(i) : Rnd(1u << 24);
+      uint32_t token, nbits, bits;
+      HybridEncode(k[0], k[1], k[2], value, &token, &nbits, &bits);
+      uint8_t buf[8] = {uint8_t(bits), uint8_t(bits >> 8), uint8_t(bits >> 16), uint8_t(bits >> 24), 0, 0, 0, 0};
+      H::BitReader br(buf, sizeof(buf));
+      const uint32_t v = H::SymbolReader::ReadHybrid(c, token, &br);
+      REQUIRE(v == value && br.BitPos() == nbits, "config %u/%u/%u: %u -> token %u -> %u", k[0], k[1], k[2], value, token, v);
+    }
+  }
+  for (int32_t i = -1000; i < 1000; i++) {  // PackUnpack (entropy_coder_test.cc:20-27)
+    const uint32_t packed = i >= 0 ? uint32_t(i) * 2 : uint32_t(-(i + 1)) * 2 + 1;
+    REQUIRE(H::UnpackSigned(packed) == i, "UnpackSigned(%u) != %d", packed, i);
+  }
+  return 0;
+}
+
+static int TestLehmer() {
+  for (int rep = 0; rep < 300; rep++) {
+    const size_t n = 1 + Rnd(rep < 200 ? 64 : 5000);
+    std::vector<uint32_t> perm(n);
+    for (size_t i = 0; i < n; i++) perm[i] = uint32_t(i);
+    for (size_t i = n; i > 1; i--) std::swap(perm[i - 1], perm[Rnd(uint32_t(i))]);
+    // Lehmer code by definition: code[i] = number of later elements smaller than perm[i]
+    std::vector<uint32_t> code(n);
+    for (size_t i = 0; i < n; i++) {
+      uint32_t c = 0;
+      for (size_t j = i + 1; j < n; j++) c += perm[j] < perm[i];
+      code[i] = c;
+    }
+    std::vector<uint32_t> back;
+    H::DecodeLehmer(code, &back);
+    REQUIRE(back == perm, "permutation of %zu entries does not round-trip", n);
+  }
+  return 0;
+}
+
+// A whole Modular frame with this front-end's pieces (frame walk: dec_frame.cc:135-434 for frame_header.encoding ==
+// kModular; dec_modular.cc:209-425).
+static int TestFjxl(const char* jxl_path, const char* raw_path, size_t W, size_t Hh, size_t C) {
+  auto slurp = [](const char* p, std::vector<uint8_t>* v) {
+    FILE* f = fopen(p, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    v->resize(size_t(ftell(f)));
+    fseek(f, 0, SEEK_SET);
+    const bool ok = fread(v->data(), 1, v->size(), f) == v->size();
+    fclose(f);
+    return ok;
+  };
+  std::vector<uint8_t> data, raw;
+  REQUIRE(slurp(jxl_path, &data) && slurp(raw_path, &raw), "cannot read the fixture");
+  REQUIRE(raw.size() == W * Hh * C, "raw size");
+  try {
+    REQUIRE(data.size() > 2 && data[0] == 0xFF && data[1] == 0x0A, "not a bare codestream");
+    H::BitReader br(data.data(), data.size());
+    br.Skip(16);
+    H::ImageHeader ih;
+    H::ReadImageHeader(br, &ih);
+    REQUIRE(ih.xsize == W && ih.ysize == Hh, "image size %ux%u", ih.xsize, ih.ysize);
+    const size_t ncolor = ih.gray ? 1 : 3;
+    REQUIRE(ncolor + ih.extra.size() == C, "channel count %zu + %zu", ncolor, ih.extra.size());
+    REQUIRE(!ih.xyb_encoded && ih.bits == 8, "fjxl writes non-XYB 8-bit images");
+    H::FrameHeader fh;
+    H::ReadFrameHeader(br, ih, &fh);
+    REQUIRE(fh.modular && fh.is_last && fh.num_passes == 1 && fh.upsampling == 1, "frame header");
+    const H::FrameDim d = H::MakeFrameDim(fh);
+    const size_t entries = d.num_groups == 1 ? 1 : 2 + d.num_dc_groups + d.num_groups;
+    H::Toc toc;
+    H::ReadToc(br, entries, &toc);
+    const size_t base = br.BitPos() / 8;
+    REQUIRE(base + toc.total == data.size(), "TOC: sections end at %zu, file has %zu bytes", size_t(base + toc.total), data.size());
+    H::MGlobal mg;
+    H::MImage full;
+    full.bitdepth = 8;
+    for (size_t c = 0; c < C; c++) full.ch.emplace_back(d.xsize, d.ysize);
+    auto dc_global = [&](H::BitReader& r) {
+      REQUIRE(r.ReadBool(), "DC dequant must be default in a Modular frame written by fjxl");
+      if (r.ReadBool()) {
+        H::DecodeTree(r, &mg.tree, 1 << 20);
+        H::DecodeHistograms(r, (mg.tree.size() + 1) / 2, &mg.code);
+        mg.have = true;
+      }
+      H::ModularDecode(r, &full, 0, &mg, d.group_dim, /*undo_transforms=*/false);
+      return 0;
+    };
+    auto group = [&](H::BitReader& r, size_t x0, size_t y0, size_t xs, size_t ys, int min_shift, int max_shift, int stream) {
+      H::MImage part;
+      part.bitdepth = 8;
+      std::vector<size_t> which, px, py;
+      size_t c = full.nb_meta;
+      while (c < full.ch.size() && full.ch[c].w <= d.group_dim && full.ch[c].h <= d.group_dim) c++;
+      for (; c < full.ch.size(); c++) {
+        H::MChannel& fc = full.ch[c];
+        const int shift = std::min(fc.hshift, fc.vshift);
+        if (shift < min_shift || shift > max_shift) continue;
+        const size_t rx = x0 >> fc.hshift, ry = y0 >> fc.vshift;
+        if (rx >= fc.w || ry >= fc.h) continue;
+        const size_t rw = std::min(xs >> fc.hshift, fc.w - rx), rh = std::min(ys >> fc.vshift, fc.h - ry);
+        if (!rw || !rh) continue;
+        part.ch.emplace_back(rw, rh, fc.hshift, fc.vshift);
+        which.push_back(c);
+        px.push_back(rx);
+        py.push_back(ry);
+      }
+      if (part.ch.empty()) return;
+      H::ModularDecode(r, &part, stream, &mg);
+      for (size_t i = 0; i < which.size(); i++)
+        for (size_t y = 0; y < part.ch[i].h; y++)
+          memcpy(full.ch[which[i]].Row(py[i] + y) + px[i], part.ch[i].Row(y), part.ch[i].w * sizeof(int32_t));
+    };
+    const uint8_t* sec = data.data() + base;
+    if (entries == 1) {
+      H::BitReader r(sec + toc.offset[0], toc.size[0]);
+      if (dc_global(r)) return 1;
+      group(r, 0, 0, d.dc_group_dim, d.dc_group_dim, 3, 1000, int(1 + d.num_dc_groups));
+      group(r, 0, 0, d.group_dim, d.group_dim, 0, 2, int(1 + 3 * d.num_dc_groups + 17));
+      REQUIRE(!r.Overread(), "section over-read");
+    } else {
+      {
+        H::BitReader r(sec + toc.offset[0], toc.size[0]);
+        if (dc_global(r)) return 1;
+        REQUIRE(!r.Overread(), "DC global over-read");
+      }
+      for (size_t g = 0; g < d.num_dc_groups; g++) {
+        H::BitReader r(sec + toc.offset[1 + g], toc.size[1 + g]);
+        const size_t gx = g % d.xsize_dc_groups, gy = g / d.xsize_dc_groups;
+        group(r, gx * d.dc_group_dim, gy * d.dc_group_dim, d.dc_group_dim, d.dc_group_dim, 3, 1000, int(1 + d.num_dc_groups + g));
+        REQUIRE(!r.Overread(), "DC group over-read");
+      }
+      for (size_t g = 0; g < d.num_groups; g++) {
+        const size_t i = 2 + d.num_dc_groups + g;
+        H::BitReader r(sec + toc.offset[i], toc.size[i]);
+        const size_t gx = g % d.xsize_groups, gy = g / d.xsize_groups;
+        group(r, gx * d.group_dim, gy * d.group_dim, d.group_dim, d.group_dim, 0, 2, int(1 + 3 * d.num_dc_groups + 17 + g));
+        REQUIRE(!r.Overread(), "AC group %zu over-read", g);
+      }
+    }
+    for (size_t i = full.transforms.size(); i-- > 0;) H::InverseTransform(&full, full.transforms[i]);
+    REQUIRE(full.ch.size() == C, "channels after the inverse transforms: %zu", full.ch.size());
+    size_t bad = 0;
+    for (size_t y = 0; y < Hh; y++)
+      for (size_t x = 0; x < W; x++)
+        for (size_t c = 0; c < C; c++) bad += full.ch[c].Row(y)[x] != int32_t(raw[(y * W + x) * C + c]);
+    REQUIRE(bad == 0, "%zu of %zu samples differ from the encoder's input", bad, W * Hh * C);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "FAIL: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  const std::string t = argv[1];
+  if (t == "alias") return TestAlias();
+  if (t == "hybrid") return TestHybrid();
+  if (t == "lehmer") return TestLehmer();
+  if (t == "fjxl" && argc == 7) return TestFjxl(argv[2], argv[3], size_t(atol(argv[4])), size_t(atol(argv[5])), size_t(atol(argv[6])));
+  return 2;
+}

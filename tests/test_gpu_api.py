@@ -77,7 +77,8 @@ def test_linear_output(built, tmp_path):
     rc, events, out, px = R.run(data, tmp_path, "f32", 3, "linear")
     assert rc == 0 and "COLOR_ENCODING tf=8" in out, out
     got = np.frombuffer(px, np.float32).reshape(100, 200, 3)
-    srgb = np.where(got <= 0.0031308, got * 12.92, 1.055 * np.power(np.maximum(got, 1e-12), 1 / 2.4) - 0.055)
+    a = np.abs(got)  # (the transfer function is odd: out-of-gamut negatives keep their sign, stage_from_linear.cc:42-54)
+    srgb = np.sign(got) * np.where(a <= 0.0031308, a * 12.92, 1.055 * np.power(np.maximum(a, 1e-12), 1 / 2.4) - 0.055)
     assert np.abs(srgb - ref_f).max() < 2e-3  # the same image, one transfer function apart
     assert np.abs(got - ref_f).max() > 0.05
 

@@ -1,0 +1,137 @@
+"""GPU tests (-m gpu) of Modular (lossless) decode, SURVEY.md §8 row f1 / BASELINE.json configs[3]. The expectations are
+reference-pinned: the fjxl fixtures are output of the reference's own enc_fast_lossless.cc, and the image each was made
+from is a deterministic function of its name -- so the HIP path must reproduce it BIT-EXACTLY, no oracle in between."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+MANIFEST = json.load(open(os.path.join(ROOT, "tests", "golden", "fjxl_manifest.json")))
+FJXL = os.path.join(ROOT, "oracle", "_ref", "fjxl_enc")
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_fjxl_fixture_bit_exact_on_gpu(built, name):
+    import make_fjxl_golden as G
+    J = built
+    img = G.golden_image(name)
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+    out = J.decode_lossless(data, num_channels=img.shape[2])
+    assert out.shape == img.shape
+    assert np.array_equal(out, img), "%d samples differ" % int((out != img).sum())
+
+
+def test_lossless_formats_and_channel_subsets(built):
+    """u16 / f32 output of 8-bit lossless data: exact multiples (v * 257, v / 255); RGB output of an RGBA file drops alpha,
+    RGBA output of an RGB file is opaque."""
+    import make_fjxl_golden as G
+    J = built
+    name = "fjxl_520x260_rgba_e5"
+    img = G.golden_image(name)
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+    assert np.array_equal(J.decode_lossless(data, 3), img[..., :3])
+    assert np.array_equal(J.decode_lossless(data, 4, data_type=3), img.astype(np.uint16) * 257)
+    f = J.decode_lossless(data, 4, data_type=0)
+    assert np.abs(f - img.astype(np.float32) / 255.0).max() < 1e-6
+    rgb_name = "fjxl_300x280_rgb_e2"
+    out = J.decode_lossless(open(os.path.join(ROOT, "tests", "golden", rgb_name + ".jxl"), "rb").read(), 4)
+    assert np.array_equal(out[..., :3], G.golden_image(rgb_name)) and (out[..., 3] == 255).all()
+
+
+@pytest.mark.skipif(not os.path.exists(FJXL), reason="the reference encoder binary (oracle/_ref/fjxl_enc) is not built here")
+@pytest.mark.parametrize("size,channels,effort", [((3840, 2160), 3, 2), ((1000, 700), 4, 1), ((640, 480), 1, 3), ((777, 513), 3, 0),
+                                                  ((2048, 2048), 4, 5)])
+def test_live_reference_encoder_output_on_gpu(built, tmp_path, size, channels, effort):
+    """Fresh output of the reference's encoder (configs[3]: 3840x2160 lossless), decoded by the HIP path: bit-exact."""
+    J = built
+    w, h = size
+    rgb = J.synth_image(w, h, seed=31 + effort)
+    y, x = np.mgrid[0:h, 0:w]
+    planes = [rgb[..., 1]] if channels == 1 else [rgb[..., 0], rgb[..., 1], rgb[..., 2]]
+    if channels == 4:
+        planes.append(((x * 3 + y * 5) % 256).astype(np.uint8))
+    img = np.ascontiguousarray(np.stack(planes, -1))
+    raw = os.path.join(str(tmp_path), "in.raw")
+    out = os.path.join(str(tmp_path), "out.jxl")
+    img.tofile(raw)
+    subprocess.run([FJXL, raw, str(w), str(h), str(channels), "8", str(effort), out], check=True)
+    got = J.decode_lossless(open(out, "rb").read(), channels)
+    assert np.array_equal(got, img), "%d samples differ" % int((got != img).sum())
+
+
+def test_lossless_through_the_decoder_api(built, tmp_path):
+    """The JxlDecoder boundary hands Modular frames to the same path (plain-C replay program)."""
+    import make_fjxl_golden as G
+    import replay_util as R
+    name = "fjxl_300x280_rgb_e2"
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3)
+    assert rc == 0 and events[-2:] == ["FULL_IMAGE", "SUCCESS"], out
+    assert np.array_equal(np.frombuffer(px, np.uint8).reshape(280, 300, 3), G.golden_image(name))
+    name = "fjxl_520x260_rgba_e5"
+    data = open(os.path.join(ROOT, "tests", "golden", name + ".jxl"), "rb").read()
+    rc, events, out, px = R.run(R.container(data), tmp_path, "u8", 4, "chunk=5000")
+    assert rc == 0, out
+    assert np.array_equal(np.frombuffer(px, np.uint8).reshape(260, 520, 4), G.golden_image(name))
+
+
+def _lossless_image(J, w, h, channels, seed):
+    rgb = J.synth_image(w, h, seed=seed)
+    y, x = np.mgrid[0:h, 0:w]
+    alpha = ((x * 3 + y * 5) % 256).astype(np.uint8)
+    if channels == 1:
+        return np.ascontiguousarray(rgb[..., 1:2])
+    if channels == 2:
+        return np.ascontiguousarray(np.dstack([rgb[..., 1], alpha]))
+    return np.ascontiguousarray(rgb if channels == 3 else np.dstack([rgb, alpha]))
+
+
+@pytest.mark.parametrize("flags,size,channels", [
+    (0, (300, 280), 3),                      # rANS, gradient predictor, one tree leaf per channel
+    (16, (300, 280), 3),                     # + RCT (YCoCg)
+    (16 | 4, (520, 300), 4),                 # + weighted predictor, split on its error property
+    (16 | 8, (600, 400), 3),                 # + Squeeze: stream 0, DC groups and AC groups all carry channels
+    (1 | 2 | 16, (300, 280), 3),             # prefix codes + LZ77 (special distances)
+    (32 | 64 | 2, (280, 300), 2),            # all 14 predictors, previous-channel property, LZ77 over rANS
+    (16 | 4 | 8 | 32 | 64, (700, 300), 4),   # everything at once
+    (4 | 8, (64, 48), 1),                    # a single-section frame
+    (16, (1, 1), 3),
+])
+def test_lossless_round_trip_every_feature(built, flags, size, channels):
+    """Streams of the repository's lossless test encoder (rANS or prefix codes, LZ77 with special distances, MA trees over
+    the channel / weighted-predictor-error / neighbourhood / previous-channel properties, all 14 predictors, RCT, Squeeze):
+    lossless, so the HIP path must return the encoder's INPUT exactly -- an expectation no decoder produced."""
+    J = built
+    img = _lossless_image(J, size[0], size[1], channels, seed=7 + flags)
+    data = J.encode_lossless(img, flags, seed=flags)
+    out = J.decode_lossless(data, num_channels=channels)
+    assert out.shape == img.shape
+    assert np.array_equal(out, img), "%d samples differ" % int((out != img).sum())
+
+
+def test_4k_lossless_squeeze_ma_tree(built):
+    """BASELINE.json configs[3]: 3840x2160 Modular lossless (Squeeze + MA tree), integer bit-exact; and the same frames in
+    one batched launch."""
+    J = built
+    img = _lossless_image(J, 3840, 2160, 3, seed=177)
+    flags = J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP
+    data = J.encode_lossless(img, flags)
+    assert np.array_equal(J.decode_lossless(data, 3), img)
+    frames = [J.ModFrame(data) for _ in range(3)]
+    ctxs = [J.HipContext() for _ in range(3)]
+    for c, f in zip(ctxs, frames):
+        c.upload_modular(f)
+    J.run_modular_batch(ctxs)
+    for c in ctxs:
+        r, status, _ = c.modular_status()
+        assert r == 0 and not any(status)
+        assert np.array_equal(c.pixels(), img)
+        c.close()
+    for f in frames:
+        f.close()

@@ -514,3 +514,80 @@ def test_jxl_decoder_api_full_image(built):
     assert L.JxlDecoderProcessInput(dec) == 0x1000
     assert np.abs(buf.reshape(222, 333, 3).astype(int) - ref.astype(int)).max() <= 1
     L.JxlDecoderDestroy(dec)
+
+
+# ---- closed-form known answers through the HIP kernels (the same streams and bar as tests/test_oracle.py)
+@pytest.mark.parametrize("strategy", [0, 4, 5, 6, 7, 8, 9, 10, 11, 18, 19, 20, 21, 22, 23, 24, 25, 26])
+def test_idct_basis_functions_gpu(built, strategy):
+    """Every coefficient position of every DCT-family strategy, one per varblock: the block the transform kernels produce
+    must be that position's float64 basis function (lib/jxl/dct_for_test.h:23-94) within the reference's per-basis-vector
+    bar 1e-7 * N (dct_test.cc:191-216). Covers k_idct_fast (8..32), k_dct (64 class) and k_dct_big (128 / 256 class),
+    the scan-order coefficient layout and the coefficient orders, against a closed form instead of the oracle."""
+    from test_oracle import basis_stream, check_basis_planes
+    J = built
+    data, blocks, shape = basis_stream(J, strategy)
+    f = J.Frame(data)
+    c = J.HipContext()
+    try:
+        c.upload(f)
+        c.run_entropy()
+        c.run_transform()
+        c.sync()
+        r, flags = c.errors()
+        assert r == 0
+        worst = check_basis_planes(c.download("xyb_idct")[1], blocks, shape)
+    finally:
+        c.close()
+        f.close()
+    assert worst < 2e-7 * max(shape) + 1e-6, worst
+
+
+def test_16k_frame_whole_and_in_8_bands(built):
+    """BASELINE.json configs[2]: a 16384x16384 d1.0 frame. Whole-frame decode against the oracle (coefficients bit-exact,
+    RGB8 within one level on < 0.1 % of the samples), then the 8-band split the multi-GPU mode uses (band r = rows of
+    groups sharding.band_of(64, r, 8), decoded with one group row of overlap either side, no exchange): the stitched bands
+    must be bit-identical to the whole-frame decode."""
+    import jxlo
+    from libjxl_amd import sharding
+    J = built
+    N = 16384
+    data = J.encode_rgb8(J.synth_image(N, N, seed=21), distance=1.0)
+    f = J.Frame(data, threads=16)
+    assert f.info["num_groups"] == 4096 and f.info["num_dc_groups"] == 64
+    c = J.HipContext()
+    try:
+        c.upload(f)
+        c.run_entropy()
+        c.sync()
+        r, flags = c.errors()
+        assert r == 0 and not any(flags)
+        co = c.download("coeffs")
+        c.run_transform()
+        c.run_filter_color()
+        c.sync()
+        whole = c.rgb8()
+        o = jxlo.Decoded(data)
+        ref = o.planes("coeffs")
+        used = _used_mask(o)
+        for g in range(0, 4096, 37):  # every 37th group: ~110 groups spread over the frame
+            assert np.array_equal(co[g, :, :used[g]].astype(np.int32), ref[g, :, :used[g]]), "coefficients differ in group %d" % g
+        del co, ref
+        want = o.rgb8
+        bad = 0
+        for y0 in range(0, N, 2048):  # row blocks: keeps the int conversions small
+            d = np.abs(whole[y0:y0 + 2048].astype(np.int16) - want[y0:y0 + 2048].astype(np.int16))
+            assert d.max() <= 1
+            bad += int((d > 0).sum())
+        assert bad < 1e-3 * N * N * 3
+        o.close()
+        del want
+        for rank in range(8):
+            b0, b1 = sharding.band_of(64, rank, 8)
+            assert b1 - b0 == 8
+            c.upload(f, band=(b0, b1))
+            c.run_all()
+            rows = c.rgb8_rows(b0 * 256, b1 * 256)
+            assert np.array_equal(rows, whole[b0 * 256:b1 * 256]), "band %d differs from the whole-frame decode" % rank
+    finally:
+        c.close()
+        f.close()

@@ -199,6 +199,24 @@ def test_sharding_two_ranks_gloo(built, tmp_path):
     assert line == "RESULT [0, 2, 4, 6, 8] 10.0 2.0"
 
 
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus N` with no launcher around it must start N ranks itself (child torch.distributed.run,
+    before any GPU call) and report n_gpus = N; started by a launcher with a different world size it must refuse."""
+    pytest.importorskip("torch")
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out == {"launch_check": True, "n_gpus": 2, "ranks": [0, 1], "distinct_processes": 2}
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stdout + r.stderr)
+
+
 def test_band_partition_of_group_rows():
     """sharding.band_of: contiguous, disjoint, complete; sizes within one row; 16K = 64 rows -> 8 bands of 8."""
     from libjxl_amd import sharding

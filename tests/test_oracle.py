@@ -148,3 +148,69 @@ def test_oracle_rejects_corrupt_streams(built):
         bad[i] ^= 0x5A
     with pytest.raises(RuntimeError):
         jxlo.Decoded(bytes(bad))
+
+
+# ---- closed-form known answers for the inverse transforms (lib/jxl/dct_for_test.h:23-94, tolerance dct_test.cc:191-216)
+DCT_STRATEGIES = {0: (8, 8), 4: (16, 16), 5: (32, 32), 6: (16, 8), 7: (8, 16), 8: (32, 8), 9: (8, 32), 10: (32, 16), 11: (16, 32),
+                  18: (64, 64), 19: (64, 32), 20: (32, 64), 21: (128, 128), 22: (128, 64), 23: (64, 128), 24: (256, 256),
+                  25: (256, 128), 26: (128, 256)}  # AcStrategy raw value -> (rows, columns) of pixels
+
+
+def basis_stream(J, strategy, stride=7):
+    """A stream whose every varblock is `strategy` with ONE non-zero Y coefficient (the test encoder's strategy_mode 3)
+    and the list of (block y0, block x0, natural position) it holds, in the encoder's block numbering."""
+    R, C = DCT_STRATEGIES[strategy]
+    n_pos = R * C - (R // 8) * (C // 8)
+    count = min(n_pos, 256 if R * C > 1024 else n_pos)
+    cols = max(1, min(256 // C, int(np.ceil(np.sqrt(count * R / C)))))
+    per_group_rows = 256 // R
+    rows = -(-count // cols)
+    rows = -(-rows // per_group_rows) * per_group_rows if rows > per_group_rows else rows
+    xs, ys = cols * C, rows * R
+    data = J.encode_random(xs, ys, strategy_mode=3, strategy_mask=1 << strategy, seed=stride, gab=0, epf_iters=0, skip_dc_smoothing=1)
+    # block numbering: groups in raster order, blocks in raster order of their top-left corner inside each group
+    blocks = []
+    for gy in range(0, ys, 256):
+        for gx in range(0, xs, 256):
+            for y0 in range(gy, min(gy + 256, ys), R):
+                for x0 in range(gx, min(gx + 256, xs), C):
+                    blocks.append((y0, x0))
+    lrows, lcols, cstride = min(R, C) // 8, max(R, C) // 8, max(R, C)
+    naturals = [k for k in range(R * C) if not (k // cstride < lrows and k % cstride < lcols)]
+    return data, [(y0, x0, naturals[(j * (stride | 1)) % n_pos]) for j, (y0, x0) in enumerate(blocks)], (R, C)
+
+
+def basis_function(R, C, k):
+    """The float64 definition (dct_for_test.h:23-62): coefficient k of the R x C block -> pixels. Coefficients are stored
+    with the short side as rows (coeff_order_fwd.h:27-43); square and tall blocks are stored transposed."""
+    if R < C:
+        ky, kx = divmod(k, C)
+    else:
+        kx, ky = divmod(k, R)
+    y = (np.arange(R) + 0.5)[:, None]
+    x = (np.arange(C) + 0.5)[None, :]
+    return (np.sqrt(2.0) if ky else 1.0) * np.cos(y * ky * np.pi / R) * (np.sqrt(2.0) if kx else 1.0) * np.cos(x * kx * np.pi / C)
+
+
+def check_basis_planes(plane_y, blocks, shape):
+    """Every block must be ONE basis function (up to the dequantisation scale): max |block / scale - basis| within the
+    reference's per-basis-vector bar 1e-7 * N (dct_test.cc:211), N = the longer side, times 2 for the two passes."""
+    R, C = shape
+    worst = 0.0
+    for y0, x0, k in blocks:
+        got = plane_y[y0:y0 + R, x0:x0 + C].astype(np.float64)
+        want = basis_function(R, C, k)
+        scale = (got * want).sum() / (want * want).sum()
+        assert scale > 0, (y0, x0, k)
+        worst = max(worst, np.abs(got / scale - want).max())
+    return worst
+
+
+@pytest.mark.parametrize("strategy", sorted(DCT_STRATEGIES))
+def test_idct_basis_functions_oracle(built, strategy):
+    import jxlo
+    data, blocks, shape = basis_stream(built, strategy)
+    o = jxlo.Decoded(data)
+    worst = check_basis_planes(o.planes("xyb_idct")[1], blocks, shape)
+    o.close()
+    assert worst < 2e-7 * max(shape) + 1e-6, worst
