@@ -97,13 +97,20 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     outs = {id(c): pinned[i * chunk + j].numpy() for i, cs in enumerate(sets) for j, c in enumerate(cs)}
     errors = []
     done = [0]
+    busy = {"wait_parse": 0.0, "wait_free_set": 0.0, "upload": 0.0, "gpu_stages": 0.0, "download": 0.0}
 
     def uploader(futs, pool):
         try:
             for c0 in range(0, nframes, chunk):
+                t_a = time.perf_counter()
                 fr = [f.result() for f in futs[c0:c0 + chunk]]
+                t_b = time.perf_counter()
                 cs = free_sets.get()
+                t_c = time.perf_counter()
                 list(pool.map(lambda cf: cf[0].upload(cf[1]), zip(cs, fr)))
+                busy["wait_parse"] += t_b - t_a
+                busy["wait_free_set"] += t_c - t_b
+                busy["upload"] += time.perf_counter() - t_c
                 q_up.put((cs, fr))
         except Exception as e:  # noqa: BLE001 (reported by the caller)
             errors.append(e)
@@ -117,9 +124,12 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
                     break
                 cs, fr = item
                 live = cs[:len(fr)]
+                t_a = time.perf_counter()
                 J.run_entropy_batch(live)
                 J.run_transform_batch(live)
                 J.run_filter_color_batch(live)
+                live[0].sync()  # (the set's stream: the stage times below are real, the downloads start on finished pixels)
+                busy["gpu_stages"] += time.perf_counter() - t_a
                 q_down.put((cs, fr))
         except Exception as e:  # noqa: BLE001
             errors.append(e)
@@ -137,7 +147,9 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
                 if item is None:
                     break
                 cs, fr = item
+                t_a = time.perf_counter()
                 list(pool.map(fetch, zip(cs, fr)))
+                busy["download"] += time.perf_counter() - t_a
                 done[0] += len(fr)
                 free_sets.put(cs)
         except Exception as e:  # noqa: BLE001
@@ -146,8 +158,8 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     # warm-up: one small chunk through everything (allocations, first touch of the output pages)
     warm = [J.Frame(datas[i % len(datas)], parse_threads) for i in range(min(chunk, 8))]
     for cs in sets:
-        for c, f in zip(cs, warm):
-            c.upload(f)
+        for i, c in enumerate(cs):  # every context allocates its device buffers now, not inside the timed region
+            c.upload(warm[i % len(warm)])
         live = cs[:len(warm)]
         J.run_entropy_batch(live); J.run_transform_batch(live); J.run_filter_color_batch(live)
         for c in live:
@@ -173,6 +185,7 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     assert done[0] == nframes
     return {"value": round(nframes * xsize * ysize * 1e-6 / elapsed, 1), "unit": "MP/s", "frames": nframes,
             "ms_per_frame": round(elapsed / nframes * 1e3, 3), "host_cores": ncpu,
+            "stage_busy_ms_per_frame": {k: round(v / nframes * 1e3, 3) for k, v in busy.items()},
             "host_threads": {"parse": "%d frames x %d threads" % (parsers, parse_threads), "upload": movers, "gpu_launch": 1, "download": movers},
             "span": "compressed bytes in host memory -> RGB8 in pinned host memory (tools/djxl_main.cc:415-422), host parse | H2D | entropy, "
                     "transform, filter+colour in chunks of %d frames | D2H pipelined over host threads" % chunk}
@@ -228,6 +241,88 @@ def system_libjxl_baseline(data, xsize, ysize, threads):
         return None
 
 
+def lossless_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, ysize):
+    """BASELINE.json configs[3]: Modular lossless decode. A step decodes `--batch` frames (every stream of every frame as one
+    lane of ONE k_modular_streams launch, then the inverse transforms and the sample conversion per frame)."""
+    import numpy as np
+    batch = args.batch if args.batch != 640 else 96  # (the VarDCT default would not fit: ~0.35 GB of channel buffers per frame)
+    ndistinct = max(1, min(args.distinct, batch))
+    flags = J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP
+    datas = []
+    for i in range(ndistinct):
+        cache = "/tmp/libjxl_amd_bench_lossless_%dx%d_s%d.jxl" % (xsize, ysize, 177 + i)
+        if os.path.exists(cache):
+            datas.append(open(cache, "rb").read())
+            continue
+        d = J.encode_lossless(J.synth_image(xsize, ysize, 177 + i), flags)
+        try:
+            open(cache + ".%d" % os.getpid(), "wb").write(d)
+            os.replace(cache + ".%d" % os.getpid(), cache)
+        except OSError:
+            pass
+        datas.append(d)
+    frames = [J.ModFrame(d) for d in datas]
+    ctxs = [J.HipContext(local_rank) for _ in range(batch)]
+    for i, c in enumerate(ctxs):
+        c.upload_modular(frames[i % ndistinct])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        J.run_modular_batch(ctxs)
+    r, status, _ = ctxs[0].modular_status()
+    if r:
+        raise SystemExit("corrupt Modular streams: %r" % status)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        J.run_modular_batch(ctxs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    total_frames, max_elapsed = sharding.aggregate(batch * args.steps, elapsed, dist)
+    launch_ms = ctxs[0].stage_ms(0)
+    if rank == 0:
+        px = xsize * ysize
+        comp = sum(len(d) for d in datas) / float(ndistinct)
+        streams = sum(f.info["num_streams"] for f in frames) / float(ndistinct)
+        # algorithmic bytes per frame: compressed bytes read + every decoded sample written once as int32 (3 channels) by the
+        # stream kernel; the inverse transforms and the conversion move another ~(2 * 12 + 12 + 3) B/px in their own launches
+        alg = comp + 12.0 * px
+        out = {"metric": "megapixels/sec decode, %dx%d Modular lossless (Squeeze + MA tree)" % (xsize, ysize),
+               "value": round(total_frames * px * 1e-6 / max_elapsed, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(max_elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+               "config": {"workload": "%dx%d RGB8 Modular lossless decode (RCT + Squeeze + MA tree with weighted predictor, rANS), %d "
+                                      "frames/step/GPU, inputs resident in HBM" % (xsize, ysize, batch),
+                          "bpp": round(comp * 8.0 / px, 3), "streams_per_frame": streams, "distinct_frames": ndistinct,
+                          "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
+               "roofline": {"bound": "hbm", "kernel": "k_modular_streams + inverse transforms + output (one timed span)",
+                            "achieved": round(alg * batch / (launch_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg * batch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                            "frames_per_launch": batch, "launch_ms": round(launch_ms, 3),
+                            "note": "a Modular stream is a pixel-serial adaptive decode (one lane per stream): latency-bound, not HBM-bound"}}
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import jxlo
+            t = []
+            for _ in range(2):
+                t1 = time.time()
+                jxlo.Decoded(datas[0], dumps=False).close()
+                t.append(time.time() - t1)
+            out["cpu_baseline"] = {"value": round(px * 1e-6 / min(t), 3), "unit": "MP/s", "cores": 1, "kind": "port",
+                                   "sample": "2 full frame decodes of the benchmark stream by the oracle (scalar, one thread), best"}
+        print(json.dumps(out))
+    for c in ctxs:
+        c.close()
+    for f in frames:
+        f.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +353,9 @@ def main():
                     help="frames of the end-to-end measurement (compressed bytes in host memory -> RGB8 in host memory, host parse / "
                          "upload / GPU stages / download pipelined over host threads); 0 = skip")
     ap.add_argument("--max-clusters", type=int, default=0, help="sensitivity runs: histogram clusters of the synthetic encoder (0 = its default 64)")
+    ap.add_argument("--workload", choices=("vardct", "lossless"), default="vardct",
+                    help="vardct: BASELINE.json configs[1] (the headline); lossless: configs[3], 3840x2160 Modular lossless "
+                         "(Squeeze + MA tree + weighted predictor) through k_modular_streams")
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the multi-rank launch (gloo, no GPU needed): every rank reports, rank 0 prints the ranks it saw")
     args = ap.parse_args()
@@ -298,6 +396,8 @@ def main():
     import libjxl_amd as J
     from libjxl_amd import sharding
     J.lib()  # fails loudly if the HIP extension is missing
+    if args.workload == "lossless":
+        return lossless_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, ysize)
 
     # `--distinct` different frames (the synthetic image generator with seeds 177, 178, ...), cycled through every frame
     # set: sections, token counts and entropy tables differ from frame to frame, so the workgroups of a launch do not all

@@ -1288,14 +1288,27 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
         const float* ms = P.dequant_scan + (mc - P.dequant);
         const uint32_t ke = P.kend[bidx * 3 + c];
         const uint32_t k1 = ke < uint32_t(SIZE) ? ke : uint32_t(SIZE);
-#pragma unroll 4
-        for (uint32_t k = CX * CY + t; k < k1; k += TB) {
-          const int q = int(gqc[k]);
-          const uint32_t pos = order[k];
-          const float w = ms[k];
-          if (q) {
-            const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
-            l[(idx >> LOGC) * S + (idx & (C - 1))] += QuantBias(c, q, P.biases) * (w * mul);
+        // four scan positions per thread and round: one 8-byte (int16) coefficient load, one 8-byte load of their positions
+        // and one 16-byte load of their weights instead of four rounds of 2 + 2 + 4 bytes (the kernel is bound by the number
+        // of its small memory operations, not by their bytes); all three tables are 16-byte aligned per (block, channel)
+        struct alignas(sizeof(CoefT) * 4) Coef4 {
+          CoefT v[4];
+        };
+        for (uint32_t k4 = uint32_t(t) * 4; k4 < k1; k4 += TB * 4) {
+          const Coef4 q4 = *reinterpret_cast<const Coef4*>(gqc + k4);
+          const ushort4 p4 = *reinterpret_cast<const ushort4*>(order + k4);
+          const float4 w4 = *reinterpret_cast<const float4*>(ms + k4);
+          const uint32_t pos4[4] = {p4.x, p4.y, p4.z, p4.w};
+          const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t k = k4 + j;
+            const int q = int(q4.v[j]);
+            if (k >= uint32_t(CX * CY) && k < k1 && q) {  // (entries below the lowest-frequency corner / beyond kend are unspecified)
+              const uint32_t pos = pos4[j];
+              const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
+              l[(idx >> LOGC) * S + (idx & (C - 1))] += QuantBias(c, q, P.biases) * (wv[j] * mul);
+            }
           }
         }
       } else {

@@ -312,6 +312,8 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
       for (uint32_t i = 0; i < span * 5; i++) S.wp_scratch[i] = 0;
     }
     const ptrdiff_t stride = ptrdiff_t(ch.stride);
+#pragma unroll
+    for (int i = 16; i < kModMaxProps; i++) props[i] = 0;  // slots of previous channels this channel does not have
     props[0] = int32_t(S.first_channel_index + ci);
     props[1] = int32_t(S.stream_id);
     for (uint32_t y = 0; y < ch.h && !r.err; y++) {

@@ -135,3 +135,20 @@ def test_4k_lossless_squeeze_ma_tree(built):
         c.close()
     for f in frames:
         f.close()
+
+
+def test_reference_wasm_cross_stream_on_gpu(built, tmp_path):
+    """crossJxl of tools/wasm_demo/jxl_decoder_test.js:33-40: a libjxl-made (jxl_from_tree) 20x20 Modular frame with a
+    palette and an MA tree, decoded by k_modular_streams; integer work, so exactly the independent decoder's samples.
+    The reference's own test decodes it to 16-bit RGB (6 bytes per pixel, :124-126)."""
+    import jxlo
+    import replay_util as R
+    J = built
+    data = open(os.path.join(ROOT, "tests", "golden", "ref_wasm_cross.jxl"), "rb").read()
+    want = jxlo.Decoded(data, dumps=False).rgb8
+    got = J.decode_lossless(data, 3)
+    assert got.shape == (20, 20, 3) and np.array_equal(got, want)
+    assert len(np.unique(got.reshape(-1, 3), axis=0)) >= 2  # (a drawing, not a flat field)
+    rc, events, out, px = R.run(data, tmp_path, "u16", 3)
+    assert rc == 0, out
+    assert np.array_equal(np.frombuffer(px, np.uint16).reshape(20, 20, 3), want.astype(np.uint16) * 257)
