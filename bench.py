@@ -336,6 +336,8 @@ def main():
                          "of 256x256 groups of every frame per rank (strong scaling, no exchange between ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one frame set: entropy, then transform+filter, in sequence")
+    ap.add_argument("--two-set", action="store_true",
+                    help="the round-1 schedule: entropy(set A) beside transform(B) -> filter+colour(B), the sets' XYB planes shared")
     ap.add_argument("--three-stage", action="store_true",
                     help="two frame sets, three concurrent launches per step: entropy(A) | transform(B) | filter+colour(A, planes of "
                          "the previous step; option filter_async), instead of entropy(A) | transform(B) -> filter(B)")
@@ -428,7 +430,9 @@ def main():
         if band[0] == band[1]:
             raise SystemExit("more ranks than rows of groups: use --shard frames")
         share = (min(band[1] * 256, ysize) - band[0] * 256) / float(ysize)
-    three = args.three_stage and nsets == 2 and not free_running
+    # default: three concurrent launches per step (entropy(A) | transform(B) | filter+colour(A, previous step)): with frames
+    # that differ, an entropy launch ends with a long tail (its slowest section); the third stream keeps the machine busy
+    three = not args.two_set and nsets == 2 and not free_running
     if three:
         for cs in sets:
             cs[0].set_option("filter_async", 1)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profiles (run on the GPU box): rocprofv3 kernel statistics of the default bench command and of the same frames
+# with the stages run one after the other (--no-pipeline: every kernel alone on the GPU), and FETCH_SIZE / WRITE_SIZE per
+# kernel in separate --pmc passes. Raw rocprofv3 output stays in /tmp; only the summaries go to OUTDIR (gpurun_out/...),
+# from where they are copied into profiles/.
+# usage: bash scripts/profile_round.sh OUTDIR TAG [bench args]
+OUT=${1:-gpurun_out/prof}
+TAG=${2:-r02}
+shift 2 || true
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/$OUT
+RAW=/tmp/prof_raw_$$
+mkdir -p $RAW
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --e2e-frames 0 $@"
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -o s -- $BENCH > $R/$OUT/${TAG}_bench.json 2> $RAW/stats.log
+cp $(find $RAW/stats -name "*kernel_stats.csv" | head -1) $R/$OUT/${TAG}_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/iso -o s -- $BENCH --no-pipeline > $R/$OUT/${TAG}_bench_isolated.json 2> $RAW/iso.log
+cp $(find $RAW/iso -name "*kernel_stats.csv" | head -1) $R/$OUT/${TAG}_kernel_stats_isolated.csv
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $RAW/f -o f -- $BENCH > /dev/null 2> $RAW/f.log
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $RAW/w -o w -- $BENCH > /dev/null 2> $RAW/w.log
+python3 $R/scripts/pmc_summary.py $(find $RAW/f -name "*counter_collection.csv" | head -1) $(find $RAW/w -name "*counter_collection.csv" | head -1) $R/$OUT/${TAG}_pmc_traffic.json 640
+tail -1 $R/$OUT/${TAG}_bench.json | cut -c1-300
+head -8 $R/$OUT/${TAG}_kernel_stats.csv | cut -c1-200
+rm -rf $RAW
