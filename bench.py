@@ -83,11 +83,22 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     except AttributeError:
         ncpu = os.cpu_count() or 1
     chunk = max(1, min(chunk, nframes))
-    parse_threads = 4 if ncpu >= 32 else 1
-    parsers = max(1, min(16, (ncpu - 8) // parse_threads))
-    movers = 4 if ncpu >= 16 else 1  # threads of the upload pool and of the download pool
-    nsets = 3
+    # CPUs this process really gets (a container's CPU share does not show in the affinity mask): CPU time / wall time of
+    # 64 frame parses on 64 threads. The host front-end is the end-to-end bottleneck, so the pools are sized by it.
+    with concurrent.futures.ThreadPoolExecutor(64) as cal:
+        w0, c0 = time.perf_counter(), time.process_time()
+        for fr in list(cal.map(lambda i: J.Frame(datas[i % len(datas)], 1), range(128))):
+            fr.close()
+        ncpu_eff = max(1.0, min(float(ncpu), (time.process_time() - c0) / (time.perf_counter() - w0)))
+    parse_threads = 1  # one frame per thread: frames in parallel, not DC groups in parallel
+    parsers = max(1, min(64, int(round(ncpu_eff)) - 2))
+    movers = 4 if ncpu_eff >= 8 else (2 if ncpu_eff >= 4 else 1)  # threads of the upload pool and of the download pool
+    nsets = 4  # one being uploaded, two on the GPU (the entropy launch of one beside the transform / filter of the other), one downloading
     sets = [[J.HipContext(device) for _ in range(chunk)] for _ in range(nsets)]
+    try:
+        sets[0][0].set_option("blocking_sync", 1)  # waiting threads sleep: the CPUs are needed by the parsers
+    except J.JxlAmdError:
+        pass
     free_sets = queue.Queue()
     for cs in sets:
         free_sets.put(cs)
@@ -97,7 +108,8 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     outs = {id(c): pinned[i * chunk + j].numpy() for i, cs in enumerate(sets) for j, c in enumerate(cs)}
     errors = []
     done = [0]
-    busy = {"wait_parse": 0.0, "wait_free_set": 0.0, "upload": 0.0, "gpu_stages": 0.0, "download": 0.0}
+    busy = {"wait_parse": 0.0, "wait_free_set": 0.0, "upload": 0.0, "gpu_stages": 0.0, "gpu_enqueue": 0.0, "enq_entropy": 0.0, "enq_transform": 0.0, "download": 0.0}
+    kernel_ms = [0.0, 0.0, 0.0]
 
     def uploader(futs, pool):
         try:
@@ -116,24 +128,41 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
             errors.append(e)
         q_up.put(None)
 
+    runners_left = [2]
+    lock = threading.Lock()
+
     def runner():
         try:
             while True:
                 item = q_up.get()
                 if item is None:
+                    q_up.put(None)  # (for the other runner)
                     break
                 cs, fr = item
                 live = cs[:len(fr)]
                 t_a = time.perf_counter()
                 J.run_entropy_batch(live)
+                t_e = time.perf_counter()
                 J.run_transform_batch(live)
+                t_t = time.perf_counter()
                 J.run_filter_color_batch(live)
-                live[0].sync()  # (the set's stream: the stage times below are real, the downloads start on finished pixels)
-                busy["gpu_stages"] += time.perf_counter() - t_a
+                t_b = time.perf_counter()
+                live[0].sync()  # (the set's stream: the downloads start on finished pixels)
+                with lock:
+                    busy["gpu_stages"] += time.perf_counter() - t_a
+                    busy["gpu_enqueue"] += t_b - t_a
+                    busy["enq_entropy"] += t_e - t_a
+                    busy["enq_transform"] += t_t - t_e
+                    for k in range(3):
+                        kernel_ms[k] += live[0].stage_ms(k)
                 q_down.put((cs, fr))
         except Exception as e:  # noqa: BLE001
             errors.append(e)
-        q_down.put(None)
+        with lock:
+            runners_left[0] -= 1
+            last = runners_left[0] == 0
+        if last:
+            q_down.put(None)
 
     def fetch(cf):
         c, f = cf
@@ -160,9 +189,10 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     for cs in sets:
         for i, c in enumerate(cs):  # every context allocates its device buffers now, not inside the timed region
             c.upload(warm[i % len(warm)])
-        live = cs[:len(warm)]
-        J.run_entropy_batch(live); J.run_transform_batch(live); J.run_filter_color_batch(live)
-        for c in live:
+        # the whole set once: the batch descriptions of its first context get their final size here (growing them later
+        # means hipFree, which waits for everything the device has in flight)
+        J.run_entropy_batch(cs); J.run_transform_batch(cs); J.run_filter_color_batch(cs)
+        for c in cs[:len(warm)]:
             J._check(J.lib().jxlhip_download_rgb8(c._h, outs[id(c)].ctypes.data, xsize * 3), "jxlhip_download_rgb8")
     for f in warm:
         f.close()
@@ -170,7 +200,7 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     with concurrent.futures.ThreadPoolExecutor(parsers) as pool, concurrent.futures.ThreadPoolExecutor(movers) as up_pool, \
             concurrent.futures.ThreadPoolExecutor(movers) as down_pool:
         futs = [pool.submit(J.Frame, datas[i % len(datas)], parse_threads) for i in range(nframes)]
-        ths = [threading.Thread(target=uploader, args=(futs, up_pool)), threading.Thread(target=runner),
+        ths = [threading.Thread(target=uploader, args=(futs, up_pool)), threading.Thread(target=runner), threading.Thread(target=runner),
                threading.Thread(target=downloader, args=(down_pool,))]
         for t in ths:
             t.start()
@@ -184,11 +214,14 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
         raise errors[0]
     assert done[0] == nframes
     return {"value": round(nframes * xsize * ysize * 1e-6 / elapsed, 1), "unit": "MP/s", "frames": nframes,
-            "ms_per_frame": round(elapsed / nframes * 1e3, 3), "host_cores": ncpu,
+            "ms_per_frame": round(elapsed / nframes * 1e3, 3), "host_cores": round(ncpu_eff, 1), "host_cores_visible": ncpu,
             "stage_busy_ms_per_frame": {k: round(v / nframes * 1e3, 3) for k, v in busy.items()},
-            "host_threads": {"parse": "%d frames x %d threads" % (parsers, parse_threads), "upload": movers, "gpu_launch": 1, "download": movers},
+            "kernel_ms_per_frame": {"entropy": round(kernel_ms[0] / nframes, 3), "transform": round(kernel_ms[1] / nframes, 3),
+                                    "filter+colour": round(kernel_ms[2] / nframes, 3)},
+            "host_threads": {"parse": "%d frames x %d threads" % (parsers, parse_threads), "upload": movers, "gpu_launch": 2, "download": movers},
             "span": "compressed bytes in host memory -> RGB8 in pinned host memory (tools/djxl_main.cc:415-422), host parse | H2D | entropy, "
-                    "transform, filter+colour in chunks of %d frames | D2H pipelined over host threads" % chunk}
+                    "transform, filter+colour in chunks of %d frames, two chunks on the GPU at a time | D2H pipelined over host threads; "
+                    "stage_busy_ms_per_frame = wall time of each pipeline thread (gpu_stages: summed over its two threads)" % chunk}
 
 
 def system_libjxl_baseline(data, xsize, ysize, threads):
@@ -248,9 +281,11 @@ def lossless_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize
     batch = args.batch if args.batch != 640 else 96  # (the VarDCT default would not fit: ~0.35 GB of channel buffers per frame)
     ndistinct = max(1, min(args.distinct, batch))
     flags = J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP
+    if args.lossless_flags >= 0:  # measurement aid: other feature sets of the synthetic encoder
+        flags = args.lossless_flags
     datas = []
     for i in range(ndistinct):
-        cache = "/tmp/libjxl_amd_bench_lossless_%dx%d_s%d.jxl" % (xsize, ysize, 177 + i)
+        cache = "/tmp/libjxl_amd_bench_lossless_%dx%d_s%d_f%d.jxl" % (xsize, ysize, 177 + i, flags)
         if os.path.exists(cache):
             datas.append(open(cache, "rb").read())
             continue
@@ -351,13 +386,15 @@ def main():
                          "another: the long tail of one set's entropy launch -- its slowest section -- overlaps the other sets' "
                          "launches). 0 = the two-set schedule selected by the other flags")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames (seeds 177, 178, ...) cycled through every frame set")
-    ap.add_argument("--e2e-frames", type=int, default=1024,
+    ap.add_argument("--e2e-frames", type=int, default=2048,
                     help="frames of the end-to-end measurement (compressed bytes in host memory -> RGB8 in host memory, host parse / "
                          "upload / GPU stages / download pipelined over host threads); 0 = skip")
     ap.add_argument("--max-clusters", type=int, default=0, help="sensitivity runs: histogram clusters of the synthetic encoder (0 = its default 64)")
     ap.add_argument("--workload", choices=("vardct", "lossless"), default="vardct",
                     help="vardct: BASELINE.json configs[1] (the headline); lossless: configs[3], 3840x2160 Modular lossless "
                          "(Squeeze + MA tree + weighted predictor) through k_modular_streams")
+    ap.add_argument("--lossless-flags", type=int, default=-1,
+                    help="--workload lossless: feature bits of the synthetic encoder (libjxl_amd.LOSSLESS_*) instead of RCT + Squeeze + WP")
     ap.add_argument("--launch-check", action="store_true",
                     help="only check the multi-rank launch (gloo, no GPU needed): every rank reports, rank 0 prints the ranks it saw")
     args = ap.parse_args()

@@ -200,7 +200,9 @@ int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_
  * transform_batch, filter_color_batch, entropy_batch, ... on one frame set then overlaps every filter + colour launch
  * with the next entropy launch (which touches neither planes nor pixels): the LDS-hungry entropy and transform kernels
  * never share the GPU, the LDS-free filter fills the gaps of the latency-bound entropy kernel. The library keeps the
- * order: the next transform, upload, download or sync of any frame of the set waits for the filter launch. */
+ * order: the next transform, upload, download or sync of any frame of the set waits for the filter launch.
+ * "blocking_sync" = 1 (process-wide for the context's device): host threads that wait for the device sleep instead of
+ * spinning; for servers that pipeline frames over more host threads than they have CPUs to spare. */
 int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
 
 /* Memory sharing for pipelined frame sets (call before jxlhip_frame_upload): `ctx` keeps its inverse-transform output (the

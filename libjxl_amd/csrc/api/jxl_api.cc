@@ -235,8 +235,7 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
     d.out_ysize = uint32_t(P.ih.ysize);
     d.upsampling_kernel = ups_kernel.data();
   }
-  int r = jxlhip_frame_upload(ctx, &d);
-  if (r == 0) r = jxlhip_sync(ctx);  // `pd` and the staging copies are locals
+  int r = jxlhip_frame_upload(ctx, &d);  // (copies everything it keeps: `pd` and the other locals may go)
   if (r) g_last_error = "jxlhip_frame_upload failed (" + std::to_string(r) + ")";
   return r;
 }

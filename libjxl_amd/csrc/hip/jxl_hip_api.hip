@@ -8,7 +8,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <unistd.h>
+#include <mutex>
 #include <new>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -28,10 +32,35 @@ namespace {
     if (e_ != hipSuccess) return -int(e_);     \
   } while (0)
 
+// "blocking_sync" option: waits of this library poll + sleep (hipStreamSynchronize / hipEventSynchronize spin).
+std::atomic<bool> g_yield_waits{false};
+inline hipError_t WaitStream(hipStream_t st) {
+  if (!g_yield_waits.load(std::memory_order_relaxed)) return hipStreamSynchronize(st);
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q != hipErrorNotReady) return q;
+    usleep(200);
+  }
+}
+inline hipError_t WaitEvent(hipEvent_t ev) {
+  if (!g_yield_waits.load(std::memory_order_relaxed)) return hipEventSynchronize(ev);
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q != hipErrorNotReady) return q;
+    usleep(100);
+  }
+}
+
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
+  bool view = false;  // p points into another allocation (a frame's table blob): nothing to free
   int Ensure(size_t n) {
+    if (view) {
+      p = nullptr;
+      cap = 0;
+      view = false;
+    }
     if (n <= cap && p) return 0;
     if (p) {
       hipError_t e = hipFree(p);
@@ -49,9 +78,10 @@ struct Buf {
     return 0;
   }
   void Free() {
-    if (p) (void)hipFree(p);
+    if (p && !view) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    view = false;
   }
   template <typename T>
   T* as() const { return static_cast<T*>(p); }
@@ -59,6 +89,23 @@ struct Buf {
 
 struct PassBufs {
   Buf ctx_map, alias, cfg, orders, ptable, poffset;
+};
+
+// One launch of the Modular transform / output kernels over the frames of a set (ModularBuildOps).
+struct ModLaunch {
+  uint32_t kind;  // 0 RCT, 1 palette, 2 unsqueeze, 3 output
+  size_t offset;  // of the first parameter block in the blob
+  uint32_t count, gx, gy;
+};
+
+// Pinned host staging block of a context: every table of a frame is assembled in it and leaves through asynchronous
+// copies on the context's stream, so that an upload neither blocks on pageable-memory copies nor synchronises per table.
+// The block is reused by the next upload once `done` (recorded after the upload's last copy) has passed.
+struct Stage {
+  uint8_t* p = nullptr;
+  size_t cap = 0, used = 0;
+  hipEvent_t done = nullptr;
+  bool recorded = false;
 };
 
 constexpr int kEntropyWPG = 4;  // waves (= AC sections) per workgroup of the scalar-form entropy kernel
@@ -73,6 +120,12 @@ struct JxlHipContext {
   hipEvent_t ev[6] = {};
   bool ev_valid[3] = {false, false, false};
   Buf basis;
+  Stage stage;
+  // jxlhip_frame_upload: every table of the frame lives in one device allocation laid out like the staging block, filled
+  // by ONE host-to-device copy at the end of the upload (HIP serialises API calls of all host threads: twenty small
+  // copies per frame capped a multi-threaded uploader at ~0.6 ms per frame); the tables' Bufs are views into it.
+  Buf frame_blob;
+  bool blob_mode = false;
   bool have_frame = false;
   // geometry
   uint32_t xs = 0, ys = 0, xb = 0, yb = 0, xg = 0, ng = 0, np = 0, xp = 0, yp = 0, coef_bits = 16;
@@ -95,7 +148,10 @@ struct JxlHipContext {
     uint32_t num_color = 3, has_alpha = 0, bits = 8, alpha_bits = 8, xs = 0, ys = 0, nstreams = 0;
     std::vector<const JxlHipContext*> batch_ctxs;
     std::vector<uint64_t> batch_gens;
-    uint32_t batch_n = 0;
+    uint32_t batch_n = 0, batch_tree_cap = 0, batch_table_cap = 0;
+    std::vector<uint32_t> code_table_words;  // per entropy code: words of its symbol tables (ModCode::table_words)
+    Buf batch_ops;                            // parameter blocks of the set's transform / output launches
+    std::vector<ModLaunch> batch_launches;
   } mod;
   size_t plane_bytes = 0;  // bytes of plane[0] the current frame needs
   Buf ep_dev;                         // device copy of `ep` (the entropy kernel reads it through the scalar cache)
@@ -275,7 +331,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
-                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams};
+                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -287,6 +343,8 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   }
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
+  if (c->stage.done) (void)hipEventDestroy(c->stage.done);
+  if (c->stage.p) (void)hipHostFree(c->stage.p);
   if (c->batch_done) (void)hipEventDestroy(c->batch_done);
   if (c->down_done) (void)hipEventDestroy(c->down_done);
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
@@ -308,15 +366,141 @@ static int ApplyPendingWait(JxlHipContext* c) {
   return 0;
 }
 
-static int Upload(JxlHipContext* c, Buf& b, const void* src, size_t bytes) {
+// Table uploads go through one high-priority stream per device, not through the contexts' own streams: streams share a
+// few hardware queues, and a copy queued behind another context's 100 ms entropy launch on the same queue waits for it
+// (6.6 ms per upload in the end-to-end pipeline against 0.7 ms alone). A priority stream gets a queue of its own.
+static hipStream_t CopyStream(int device) {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  if (device < 0 || device >= 64) return nullptr;
+  if (!streams[device]) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithPriority(&streams[device], hipStreamNonBlocking, hi) != hipSuccess) streams[device] = nullptr;
+  }
+  return streams[device];
+}
+
+// Start of an upload: the previous upload's copies have left the staging block.
+static int StageReset(JxlHipContext* c) {
+  Stage& s = c->stage;
+  if (!s.done) HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+  if (s.recorded) HIP_TRY(hipEventSynchronize(s.done));
+  else if (s.used) HIP_TRY(hipStreamSynchronize(c->stream));  // (an upload that failed half way)
+  s.recorded = false;
+  s.used = 0;
+  return 0;
+}
+static int StageAlloc(JxlHipContext* c, size_t bytes, void** out) {
+  Stage& s = c->stage;
+  const size_t need = (bytes + 63) & ~size_t(63);
+  if (s.used + need > s.cap) {  // a larger block: copies out of the current one may still be in flight
+    if (c->blob_mode) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the blob's bound was wrong: the views would dangle)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hipStream_t cs = CopyStream(c->device)) HIP_TRY(hipStreamSynchronize(cs));
+    size_t want = s.cap * 2 > need ? s.cap * 2 : need;
+    if (want < (size_t(1) << 22)) want = size_t(1) << 22;
+    if (s.p) HIP_TRY(hipHostFree(s.p));
+    s.p = nullptr;
+    s.cap = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.p), want, hipHostMallocDefault));
+    s.cap = want;
+    s.used = 0;
+  }
+  *out = s.p + s.used;
+  s.used += need;
+  return 0;
+}
+// Copies `bytes` already assembled in the staging block (`staged`, from StageAlloc) to `b`.
+static int UploadStaged(JxlHipContext* c, Buf& b, const void* staged, size_t bytes) {
+  if (c->blob_mode) {
+    const size_t at = size_t(static_cast<const uint8_t*>(staged) - c->stage.p);
+    if (!staged || at + (bytes ? bytes : 16) > c->frame_blob.cap) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the bound was wrong)
+    if (!b.view) b.Free();
+    b.p = c->frame_blob.as<uint8_t>() + at;
+    b.cap = bytes ? bytes : 16;
+    b.view = true;
+    return 0;
+  }
   int r = b.Ensure(bytes ? bytes : 16);
   if (r) return r;
-  if (bytes) HIP_TRY(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  if (bytes) HIP_TRY(hipMemcpyAsync(b.p, staged, bytes, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+static int UploadStaged(JxlHipContext* c, Buf& b, const void* staged, size_t bytes);
+static int Upload(JxlHipContext* c, Buf& b, const void* src, size_t bytes) {
+  void* st = nullptr;
+  int r = StageAlloc(c, bytes ? bytes : 16, &st);  // (blob mode: an empty table still gets a valid address)
+  if (r) return r;
+  if (bytes) memcpy(st, src, bytes);
+  return UploadStaged(c, b, st, bytes);
+}
+// Small host-to-device copies of launch descriptions (parameter blocks, work lists): through the context's staging block
+// and the copy stream like the tables, complete when End() returns.
+struct ParamCopy {
+  JxlHipContext* c = nullptr;
+  hipStream_t cs = nullptr;
+  int Begin(JxlHipContext* ctx) {
+    c = ctx;
+    cs = CopyStream(c->device);
+    if (!cs) cs = c->stream;
+    return StageReset(c);
+  }
+  int Add(void* dst, const void* src, size_t bytes) {
+    if (!bytes) return 0;
+    void* st = nullptr;
+    int r = StageAlloc(c, bytes, &st);
+    if (r) return r;
+    memcpy(st, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, cs));
+    return 0;
+  }
+  int End() {
+    HIP_TRY(hipEventRecord(c->stage.done, cs));
+    c->stage.recorded = true;
+    HIP_TRY(WaitEvent(c->stage.done));
+    return 0;
+  }
+};
+
+// Blob mode: sizes the staging block and the device blob for `bound` bytes of tables; until BlobEnd, Upload / UploadStaged
+// only place tables (the Bufs become views at the staging offsets) and BlobEnd copies everything at once.
+static int BlobBegin(JxlHipContext* c, size_t bound) {
+  Stage& s = c->stage;
+  if (s.cap < bound) {
+    void* dummy = nullptr;
+    int r = StageAlloc(c, bound, &dummy);  // grows the block (the stream is idle here: StageReset ran)
+    if (r) return r;
+    s.used = 0;
+  }
+  int r = c->frame_blob.Ensure(s.cap);
+  if (r) return r;
+  c->blob_mode = true;
+  return 0;
+}
+static int BlobEnd(JxlHipContext* c) {
+  c->blob_mode = false;
+  hipStream_t cs = CopyStream(c->device);
+  if (!cs) cs = c->stream;
+  if (c->stage.used) HIP_TRY(hipMemcpyAsync(c->frame_blob.p, c->stage.p, c->stage.used, hipMemcpyHostToDevice, cs));
+  HIP_TRY(hipEventRecord(c->stage.done, cs));
+  c->stage.recorded = true;
   return 0;
 }
 
 int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (!c || !d) return JXLHIP_ERR_INVALID_ARGUMENT;
+  // measurement aid: JXLHIP_UPLOAD_PROF=1 prints where the host time of an upload goes (microseconds per phase)
+  const bool prof = EnvInt("JXLHIP_UPLOAD_PROF", 0) != 0;
+  std::chrono::steady_clock::time_point tp0 = std::chrono::steady_clock::now();
+  std::string prof_line;
+  auto lap = [&](const char* what) {
+    if (!prof) return;
+    const auto now = std::chrono::steady_clock::now();
+    prof_line += std::string(what) + " " + std::to_string(std::chrono::duration_cast<std::chrono::microseconds>(now - tp0).count()) + "  ";
+    tp0 = now;
+  };
   if (!d->xsize || !d->ysize || !d->num_groups || !d->num_passes || d->num_passes > 11) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (d->coef_bits != 16 && d->coef_bits != 32) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (d->xsize_blocks != (d->xsize + 7) / 8 || d->ysize_blocks != (d->ysize + 7) / 8) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -328,6 +512,10 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   {
     int pw = ApplyPendingWait(c);
     if (pw) return pw;
+    if ((pw = StageReset(c))) return pw;
+    // the tables are overwritten from the copy stream: whatever still reads the old ones has to be finished
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
   }
   c->have_frame = false;
   c->xs = d->xsize; c->ys = d->ysize; c->xb = d->xsize_blocks; c->yb = d->ysize_blocks;
@@ -381,6 +569,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     }
     if (prev_end != d->num_blocks) return JXLHIP_ERR_INVALID_ARGUMENT;
   }
+  lap("validate");
   // ---- pack the AC sections at 16-byte aligned offsets
   const size_t nsec = size_t(d->num_groups) * d->num_passes;
   std::vector<uint32_t> sec_word(nsec), sec_size(nsec);
@@ -390,10 +579,42 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     sec_size[i] = d->section_size[i];
     total += (size_t(d->section_size[i]) + 15 + 4) & ~size_t(15);
   }
-  std::vector<uint8_t> packed(total + 256, 0);  // the lane kernel prefetches up to 64 bytes past a section
-  for (size_t i = 0; i < nsec; i++) memcpy(packed.data() + size_t(sec_word[i]) * 4, d->codestream + d->section_offset[i], d->section_size[i]);
   int r;
-  if ((r = Upload(c, c->sections, packed.data(), packed.size()))) return r;
+  {
+    // every table this upload places (each rounded up to the staging granule), generously
+    size_t bound = 65536;
+    auto add = [&](size_t bytes) { bound += (bytes + 16 + 127) & ~size_t(63); };
+    const size_t nblk_b = size_t(d->xsize_blocks) * d->ysize_blocks, ntiles_b = size_t((d->xsize_blocks + 7) / 8) * ((d->ysize_blocks + 7) / 8);
+    add(total + 256); add(nsec * 4); add(nsec * 4);
+    add(size_t(d->num_blocks) * sizeof(JxlHipVarBlock)); add((size_t(d->num_groups) + 1) * 4); add(d->block_ctx_lut_size);
+    add(size_t(d->dequant_floats) * 4); add(nblk_b * 12); add(nblk_b * 4); add(ntiles_b); add(ntiles_b);
+    for (uint32_t p = 0; p < d->num_passes; p++) {
+      const JxlHipPassDesc& q = d->passes[p];
+      if (q.num_clusters > 256 || (!q.use_prefix && q.log_alpha > 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
+      add(q.ctx_map_size); add(q.use_prefix ? 0 : (size_t(q.num_clusters) << q.log_alpha) * 8); add(size_t(q.num_clusters) * 4);
+      add(size_t(q.orders_size) * 2); add(size_t(q.prefix_table_size) * 4); add(size_t(q.num_clusters) * 4);
+    }
+    add(size_t(d->num_passes) * sizeof(jxlhip::PassDev)); add(64 * 25 * 4); add((size_t(d->num_blocks) + 1) * 4);
+    add((size_t(d->num_blocks) + 16) * 4); add(sizeof(jxlhip::EntropyParams)); add(size_t(d->dequant_floats) * 4);
+    if ((r = BlobBegin(c, bound))) return r;
+  }
+  struct BlobGuard {  // whatever the outcome, later uploads of other kinds see the plain mode
+    JxlHipContext* c;
+    ~BlobGuard() { c->blob_mode = false; }
+  } blob_guard{c};
+  {
+    uint8_t* packed = nullptr;  // (+ 256: the lane kernel prefetches up to 64 bytes past a section)
+    if ((r = StageAlloc(c, total + 256, reinterpret_cast<void**>(&packed)))) return r;
+    size_t end = 0;
+    for (size_t i = 0; i < nsec; i++) {
+      const size_t at = size_t(sec_word[i]) * 4;
+      memset(packed + end, 0, at - end);
+      memcpy(packed + at, d->codestream + d->section_offset[i], d->section_size[i]);
+      end = at + d->section_size[i];
+    }
+    memset(packed + end, 0, total + 256 - end);
+    if ((r = UploadStaged(c, c->sections, packed, total + 256))) return r;
+  }
   if ((r = Upload(c, c->sec_word, sec_word.data(), nsec * 4))) return r;
   if ((r = Upload(c, c->sec_size, sec_size.data(), nsec * 4))) return r;
   c->sec_size_host = sec_size;
@@ -412,8 +633,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   }
   c->pass_clusters.assign(d->num_passes, 0);
   c->pass_log_alpha.assign(d->num_passes, 0);
-  // the staging vectors die at the end of this call: finish these copies now
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  lap("sections");
   if ((r = Upload(c, c->blocks, d->blocks, size_t(d->num_blocks) * sizeof(JxlHipVarBlock)))) return r;
   if ((r = Upload(c, c->gbb, d->group_block_begin, (size_t(d->num_groups) + 1) * 4))) return r;
   if ((r = Upload(c, c->bctx_lut, d->block_ctx_lut, d->block_ctx_lut_size))) return r;
@@ -424,6 +644,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   const size_t ntiles = size_t((c->xb + 7) / 8) * ((c->yb + 7) / 8);
   if ((r = Upload(c, c->ytox, d->ytox, ntiles))) return r;
   if ((r = Upload(c, c->ytob, d->ytob, ntiles))) return r;
+  lap("planes");
   // ---- per-pass tables
   if (c->pass_bufs.size() < d->num_passes) c->pass_bufs.resize(d->num_passes);
   std::vector<jxlhip::PassDev> pd(d->num_passes);
@@ -483,7 +704,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     pd[p].alias_lds = 0;
   }
   if ((r = Upload(c, c->passes_dev, pd.data(), pd.size() * sizeof(jxlhip::PassDev)))) return r;
-  HIP_TRY(hipStreamSynchronize(c->stream));  // `pd` is a local
+  lap("tables");
   // ---- work buffers
   // (progressive frames: the natural-layout buffer + one scan-order buffer per pass for the lane kernel)
   const size_t coef_bytes = size_t(d->num_groups) * 3 * 65536 * (d->coef_bits / 8);
@@ -502,8 +723,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
   if (c->ups != 1) {
     if ((r = Upload(c, c->ups_kernel, d->upsampling_kernel, size_t(c->ups) * c->ups * 25 * 4))) return r;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller's table may be a temporary
   }
+  lap("buffers");
   // ---- transform work lists (block indices bucketed by strategy)
   {
     std::vector<uint32_t> count(27, 0);
@@ -523,7 +744,6 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       list[c->list_begin[s] + fill[s]++] = i;
     }
     if ((r = Upload(c, c->tlist, list.data(), list.size() * 4))) return r;
-    HIP_TRY(hipStreamSynchronize(c->stream));
     uint32_t big = 0;
     for (int s = 21; s < 27; s++) big = big > count[s] ? big : count[s];
     if (big) {
@@ -531,6 +751,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       if ((r = c->scratch.Ensure(size_t(chunk) * 3 * 2 * 65536 * 4))) return r;
     }
   }
+  lap("lists");
   // ---- kernel parameter blocks
   jxlhip::EntropyParams& ep = c->ep;
   memset(&ep, 0, sizeof(ep));
@@ -616,17 +837,16 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       recs[i] = rec;
     }
     if ((r = Upload(c, c->block_recs, recs.data(), recs.size() * 4))) return r;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `recs` is a local
     ep.block_recs = c->block_recs.as<uint32_t>();
   }
+  lap("records");
   if (c->scan_order) {
     c->blocks_host.assign(d->blocks, d->blocks + d->num_blocks);
     c->gbb_host.assign(d->group_block_begin, d->group_block_begin + d->num_groups + 1);
     c->orders_host.assign(d->passes[0].orders, d->passes[0].orders + d->passes[0].orders_size);
     memcpy(c->order_offset_host, d->passes[0].order_offset, sizeof(c->order_offset_host));
   }
-  if ((r = c->ep_dev.Ensure(sizeof(ep)))) return r;
-  HIP_TRY(hipMemcpy(c->ep_dev.p, &ep, sizeof(ep), hipMemcpyHostToDevice));
+  if ((r = Upload(c, c->ep_dev, &ep, sizeof(ep)))) return r;
   c->generation++;
 
   jxlhip::TransformParams& tp = c->tp;
@@ -688,7 +908,6 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       }
     }
     if ((r = Upload(c, c->dequant_scan, scan.data(), scan.size() * 4))) return r;
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `scan` is a local
     tp.dequant_scan = c->dequant_scan.as<float>();
   }
   memcpy(tp.order_offset, d->passes[0].order_offset, sizeof(tp.order_offset));
@@ -716,6 +935,13 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->epf_pass2 = d->epf_pass2_sigma_scale;
   c->epf_border = d->epf_border_sad_mul;
   c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = false;
+  if ((r = BlobEnd(c))) return r;  // (records the staging block's event on the copy stream)
+  // The tables are resident when the call returns (batch launches over this context run on other contexts' streams).
+  // (Leaving the copies of many contexts in flight at once instead, ordered by events, made every later kernel of the
+  // process ~1.35x slower on this runtime: scripts/async_probe.py.)
+  HIP_TRY(WaitEvent(c->stage.done));
+  lap("rest");
+  if (prof) fprintf(stderr, "[upload] %s\n", prof_line.c_str());
   c->have_frame = true;
   return 0;
 }
@@ -932,9 +1158,14 @@ static int PrepareDownstream(JxlHipContext* c0, JxlHipContext* const* ctxs, size
   if ((r = c0->tb_params.Ensure(n * sizeof(tparams[0])))) return r;
   if ((r = c0->tb_desc.Ensure((desc.size() + 1) * sizeof(uint2)))) return r;
   if ((r = c0->fb_params.Ensure(n * sizeof(fparams[0])))) return r;
-  HIP_TRY(hipMemcpy(c0->tb_params.p, tparams.data(), n * sizeof(tparams[0]), hipMemcpyHostToDevice));
-  if (!desc.empty()) HIP_TRY(hipMemcpy(c0->tb_desc.p, desc.data(), desc.size() * sizeof(uint2), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c0->fb_params.p, fparams.data(), n * sizeof(fparams[0]), hipMemcpyHostToDevice));
+  {
+    ParamCopy pc;
+    if ((r = pc.Begin(c0))) return r;
+    if ((r = pc.Add(c0->tb_params.p, tparams.data(), n * sizeof(tparams[0])))) return r;
+    if ((r = pc.Add(c0->tb_desc.p, desc.data(), desc.size() * sizeof(uint2)))) return r;
+    if ((r = pc.Add(c0->fb_params.p, fparams.data(), n * sizeof(fparams[0])))) return r;
+    if ((r = pc.End())) return r;
+  }
   c0->db_ctxs.assign(ctxs, ctxs + n);
   c0->db_gens.resize(n);
   for (size_t i = 0; i < n; i++) c0->db_gens[i] = ctxs[i]->generation;
@@ -1238,11 +1469,13 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   int r;
   if ((r = c0->batch_params.Ensure(params.size() * sizeof(params[0])))) return r;
   if ((r = c0->batch_map.Ensure(map.size() * 4))) return r;
-  HIP_TRY(hipMemcpy(c0->batch_params.p, params.data(), params.size() * sizeof(params[0]), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c0->batch_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+  ParamCopy pc;
+  if ((r = pc.Begin(c0))) return r;
+  if ((r = pc.Add(c0->batch_params.p, params.data(), params.size() * sizeof(params[0])))) return r;
+  if ((r = pc.Add(c0->batch_map.p, map.data(), map.size() * 4))) return r;
   if (!wave_ls.empty()) {
     if ((r = c0->batch_wave_ls.Ensure(wave_ls.size()))) return r;
-    HIP_TRY(hipMemcpy(c0->batch_wave_ls.p, wave_ls.data(), wave_ls.size(), hipMemcpyHostToDevice));
+    if ((r = pc.Add(c0->batch_wave_ls.p, wave_ls.data(), wave_ls.size()))) return r;
   }
   if (!list.empty()) {
     // one buffer: section list | unit descriptors (16-byte aligned) | queue counters | populated lanes per wave
@@ -1253,12 +1486,13 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     memcpy(blob.data() + o_units, unit_desc.data(), unit_desc.size() * 4);
     memcpy(blob.data() + o_wl, wave_lanes.data(), wave_lanes.size());
     if ((r = c0->batch_lanes.Ensure(total))) return r;
-    HIP_TRY(hipMemcpy(c0->batch_lanes.p, blob.data(), total, hipMemcpyHostToDevice));
+    if ((r = pc.Add(c0->batch_lanes.p, blob.data(), total))) return r;
     c0->batch_off_units = o_units;
     c0->batch_off_queue = o_queue;
     c0->batch_off_wave_lanes = o_wl;
     c0->batch_units = unit_desc.size() / 4;
   }
+  if ((r = pc.End())) return r;
   c0->batch_ctxs.assign(ctxs, ctxs + n);
   c0->batch_gens.resize(n);
   for (size_t i = 0; i < n; i++) c0->batch_gens[i] = ctxs[i]->generation;
@@ -1293,12 +1527,24 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   }
   const int kernel = all_scan ? 2 : 1;
   HIP_TRY(hipSetDevice(c0->device));
+  // measurement aid: JXLHIP_BATCH_PROF=1 prints the host time of the phases of this call (microseconds)
+  const bool prof = EnvInt("JXLHIP_BATCH_PROF", 0) != 0;
+  std::chrono::steady_clock::time_point tp0 = std::chrono::steady_clock::now();
+  std::string prof_line;
+  auto lap = [&](const char* what) {
+    if (!prof) return;
+    const auto now = std::chrono::steady_clock::now();
+    prof_line += std::string(what) + " " + std::to_string(std::chrono::duration_cast<std::chrono::microseconds>(now - tp0).count()) + "  ";
+    tp0 = now;
+  };
   if (!c0->batch_done) HIP_TRY(hipEventCreateWithFlags(&c0->batch_done, hipEventDisableTiming));
   int r = PrepareBatch(c0, ctxs, n, kernel);
   if (r) return r;
+  lap("prepare");
   // the batch kernel runs on the first context's stream, after whatever the other contexts still have in flight
-  for (size_t i = 1; i < n; i++)
+  for (size_t i = 1; i < n; i++) {
     if (ctxs[i]->ev_valid[2]) HIP_TRY(hipStreamWaitEvent(c0->stream, ctxs[i]->ev[5], 0));
+  }
   hipEvent_t waited = nullptr;
   for (size_t i = 0; i < n; i++)
     if (ctxs[i]->pending_wait) {  // results of an earlier batch launch that nobody consumed: order after that launch
@@ -1306,6 +1552,7 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
       waited = ctxs[i]->pending_wait;
       ctxs[i]->pending_wait = nullptr;
     }
+  lap("waits");
   HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
   for (size_t i = 0; i < n; i++)  // (the lane kernel writes every section's flag word itself, unless passes share it)
     if (kernel != 2 || ctxs[i]->np > 1) HIP_TRY(hipMemsetAsync(ctxs[i]->errors.p, 0, size_t(ctxs[i]->ng) * 4, c0->stream));
@@ -1331,6 +1578,8 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
       else hipLaunchKernelGGL(jxlhip::k_merge_passes<int32_t>, dim3(m.num_blocks), dim3(64), 0, c0->stream, m);
       HIP_TRY(hipGetLastError());
     }
+  lap("launch");
+  if (prof) fprintf(stderr, "[entropy batch] %s\n", prof_line.c_str());
   HIP_TRY(hipEventRecord(c0->ev[1], c0->stream));
   c0->ev_valid[0] = true;
   if (n > 1) {
@@ -1359,6 +1608,7 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
   {
     int pw = ApplyPendingWait(c);
     if (pw) return pw;
+    if ((pw = StageReset(c))) return pw;
   }
   JxlHipContext::Modular& M = c->mod;
   M.have = false;
@@ -1397,14 +1647,27 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
   std::vector<size_t> tree_at(d->num_trees), code_at(d->num_codes);
   std::vector<std::vector<size_t>> code_parts(d->num_codes);  // ctx_map, alias, cfg, prefix_table, prefix_offset
   for (uint32_t i = 0; i < d->num_trees; i++) {
-    static_assert(sizeof(JxlHipModTreeNode) == sizeof(jxlhip::ModTreeNode), "tree node layout");
+    // the kernel's 16-byte nodes: leaves carry -1 - predictor, the offset, the histogram their context maps to, the multiplier
+    std::vector<jxlhip::ModTreeNode> packed_tree(d->tree_size[i]);
     for (uint32_t k = 0; k < d->tree_size[i]; k++) {  // every index the walk can follow must exist
       const JxlHipModTreeNode& nd = d->trees[i][k];
       if (nd.property >= int32_t(jxlhip::kModMaxProps)) return JXLHIP_ERR_UNSUPPORTED;
       if (nd.property >= 0 && (nd.lchild >= d->tree_size[i] || nd.rchild >= d->tree_size[i])) return JXLHIP_ERR_INVALID_ARGUMENT;
-      if (nd.property < 0 && (nd.predictor > 13 || nd.lchild >= d->codes[i].ctx_map_size)) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (nd.property < 0 && (nd.predictor > 13 || nd.lchild >= d->codes[i].ctx_map_size || !d->codes[i].ctx_map)) return JXLHIP_ERR_INVALID_ARGUMENT;
+      jxlhip::ModTreeNode& o = packed_tree[k];
+      if (nd.property >= 0) {
+        o.property = nd.property;
+        o.splitval = nd.splitval;
+        o.lchild = nd.lchild;
+        o.rchild = nd.rchild;
+      } else {
+        o.property = -1 - int32_t(nd.predictor);
+        o.splitval = nd.offset;
+        o.lchild = d->codes[i].ctx_map[nd.lchild];
+        o.rchild = nd.multiplier;
+      }
     }
-    tree_at[i] = put(d->trees[i], size_t(d->tree_size[i]) * sizeof(JxlHipModTreeNode));
+    tree_at[i] = put(packed_tree.data(), packed_tree.size() * sizeof(jxlhip::ModTreeNode));
   }
   for (uint32_t i = 0; i < d->num_codes; i++) {
     const JxlHipModCode& k = d->codes[i];
@@ -1432,6 +1695,7 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
   blob.resize(codes_at + size_t(d->num_codes) * sizeof(jxlhip::ModCode));
   if ((r = M.blob.Ensure(blob.size() + 16))) return r;
   uint8_t* dev = M.blob.as<uint8_t>();
+  M.code_table_words.assign(d->num_codes, 0);
   for (uint32_t i = 0; i < d->num_codes; i++) {
     const JxlHipModCode& k = d->codes[i];
     jxlhip::ModCode mc;
@@ -1448,6 +1712,10 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
     mc.lz_min_length = k.lz_min_length;
     mc.lz_len_cfg = k.lz_len_cfg;
     mc.lz_dist_ctx = k.lz_dist_ctx;
+    mc.num_clusters = k.num_clusters;
+    if (d->tree_size[i])
+      mc.table_words = k.use_prefix ? k.prefix_table_size + 2 * k.num_clusters : ((k.num_clusters << k.log_alpha) * 2 + k.num_clusters);
+    M.code_table_words[i] = mc.table_words;
     memcpy(blob.data() + codes_at + size_t(i) * sizeof(mc), &mc, sizeof(mc));
   }
   HIP_TRY(hipMemcpyAsync(M.blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, c->stream));
@@ -1478,7 +1746,7 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
       return JXLHIP_ERR_INVALID_ARGUMENT;
     if (q.uses_wp) {
       scratch_at[i] = scratch_ints;
-      scratch_ints += size_t(q.max_width + 2) * 2 * 5;
+      scratch_ints += size_t(q.max_width + 2) * 2 * jxlhip::kModWpEntry;
     }
     if (d->codes[q.code].lz77) {
       uint32_t w = 256;
@@ -1500,6 +1768,7 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
     o.bit_offset = q.bit_offset;
     o.size_bytes = d->section_size[q.section];
     o.tree = reinterpret_cast<const jxlhip::ModTreeNode*>(dev + tree_at[q.tree]);
+    o.tree_nodes = d->tree_size[q.tree];
     o.code = reinterpret_cast<const jxlhip::ModCode*>(dev + codes_at) + q.code;
     o.channels = M.rects.as<jxlhip::ModChannel>() + q.first_rect;
     o.num_channels = q.num_rects;
@@ -1562,75 +1831,137 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
   return 0;
 }
 
-static int ModularLaunchOps(JxlHipContext* c, hipStream_t st) {
-  JxlHipContext::Modular& M = c->mod;
-  int32_t* pool = M.pool.as<int32_t>();
-  for (const JxlHipModOp& op : M.ops) {
-    if (op.kind == 0) {
-      jxlhip::ModRct p;
-      for (int j = 0; j < 3; j++) {
-        p.stride[j] = M.buf_w[op.buf[j]];
-        p.c[j] = pool + M.buf_off[op.buf[j]] + size_t(op.y0) * p.stride[j] + op.x0;
+// The inverse transforms and the pixel writer of a set of frames, as launches over parameter-block arrays: launch k does
+// the k-th transform of every frame that has one (one launch per kind), so a frame's steps stay in order on the stream
+// and a step of all frames shares the device. Built once per set (cached with the stream list), blocks in `out` (host),
+// launches in `launches`.
+static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<uint8_t>* blob, std::vector<ModLaunch>* launches) {
+  blob->clear();
+  launches->clear();
+  size_t levels = 0;
+  for (size_t i = 0; i < n; i++) levels = std::max(levels, ctxs[i]->mod.ops.size());
+  auto append = [&](const void* p, size_t bytes) {
+    const size_t at = blob->size();
+    blob->resize(at + bytes);
+    memcpy(blob->data() + at, p, bytes);
+  };
+  auto align = [&]() { blob->resize((blob->size() + 15) & ~size_t(15)); };
+  for (size_t level = 0; level < levels; level++) {
+    for (uint32_t kind = 0; kind < 3; kind++) {
+      align();
+      ModLaunch L{kind, blob->size(), 0, 0, 0};
+      for (size_t i = 0; i < n; i++) {
+        const JxlHipContext::Modular& M = ctxs[i]->mod;
+        if (level >= M.ops.size()) continue;
+        const JxlHipModOp& op = M.ops[level];
+        int32_t* pool = M.pool.as<int32_t>();
+        if (kind == 0 && op.kind == 0) {
+          jxlhip::ModRct p;
+          memset(&p, 0, sizeof(p));
+          for (int j = 0; j < 3; j++) {
+            p.stride[j] = M.buf_w[op.buf[j]];
+            p.c[j] = pool + M.buf_off[op.buf[j]] + size_t(op.y0) * p.stride[j] + op.x0;
+          }
+          p.w = op.w;
+          p.h = op.h;
+          p.type = op.param;
+          if (!op.w || !op.h) continue;
+          append(&p, sizeof(p));
+          L.count++;
+          L.gx = std::max(L.gx, (op.w + 255) / 256);
+          L.gy = std::max(L.gy, op.h);
+        } else if (kind == 1 && op.kind == 1) {
+          jxlhip::ModPalette p;
+          memset(&p, 0, sizeof(p));
+          p.palette = pool + M.buf_off[op.buf[0]];
+          p.index = pool + M.buf_off[op.buf[1]];
+          for (uint32_t j = 0; j < op.nb; j++) p.out[j] = pool + M.buf_off[op.buf[2 + j]];
+          p.palette_w = op.param;
+          p.nb = op.nb;
+          p.w = op.w;
+          p.h = op.h;
+          p.bit_depth = op.bit_depth;
+          p.index_stride = op.w;
+          p.out_stride = op.w;
+          if (!op.w || !op.h) continue;
+          append(&p, sizeof(p));
+          L.count++;
+          L.gx = std::max(L.gx, (op.w + 255) / 256);
+          L.gy = std::max(L.gy, op.h);
+        } else if (kind == 2 && op.kind >= 2) {
+          const uint32_t a = op.buf[0], q = op.buf[1], o = op.buf[2];
+          const bool hz = op.kind == 2;
+          jxlhip::ModUnsqueeze p;
+          memset(&p, 0, sizeof(p));
+          p.avg = pool + M.buf_off[a];
+          p.res = pool + M.buf_off[q];
+          p.out = pool + M.buf_off[o];
+          p.lines = hz ? M.buf_h[a] : M.buf_w[a];
+          p.na = hz ? M.buf_w[a] : M.buf_h[a];
+          p.nr = hz ? M.buf_w[q] : M.buf_h[q];
+          p.avg_line = hz ? M.buf_w[a] : 1;
+          p.avg_step = hz ? 1 : M.buf_w[a];
+          p.res_line = hz ? M.buf_w[q] : 1;
+          p.res_step = hz ? 1 : M.buf_w[q];
+          p.out_line = hz ? M.buf_w[o] : 1;
+          p.out_step = hz ? 1 : M.buf_w[o];
+          if (!p.lines) continue;
+          append(&p, sizeof(p));
+          L.count++;
+          L.gx = std::max(L.gx, (p.lines + 63) / 64);
+          L.gy = 1;
+        }
       }
-      p.w = op.w;
-      p.h = op.h;
-      p.type = op.param;
-      if (op.w && op.h) hipLaunchKernelGGL(jxlhip::k_modular_rct, dim3((op.w + 255) / 256, op.h), dim3(256), 0, st, p);
-    } else if (op.kind == 1) {
-      jxlhip::ModPalette p;
-      memset(&p, 0, sizeof(p));
-      p.palette = pool + M.buf_off[op.buf[0]];
-      p.index = pool + M.buf_off[op.buf[1]];
-      for (uint32_t j = 0; j < op.nb; j++) p.out[j] = pool + M.buf_off[op.buf[2 + j]];
-      p.palette_w = op.param;
-      p.nb = op.nb;
-      p.w = op.w;
-      p.h = op.h;
-      p.bit_depth = op.bit_depth;
-      p.index_stride = op.w;
-      p.out_stride = op.w;
-      if (op.w && op.h) hipLaunchKernelGGL(jxlhip::k_modular_palette, dim3((op.w + 255) / 256, op.h), dim3(256), 0, st, p);
-    } else {
-      const uint32_t a = op.buf[0], q = op.buf[1], o = op.buf[2];
-      const bool hz = op.kind == 2;
-      jxlhip::ModUnsqueeze p;
-      p.avg = pool + M.buf_off[a];
-      p.res = pool + M.buf_off[q];
-      p.out = pool + M.buf_off[o];
-      p.lines = hz ? M.buf_h[a] : M.buf_w[a];
-      p.na = hz ? M.buf_w[a] : M.buf_h[a];
-      p.nr = hz ? M.buf_w[q] : M.buf_h[q];
-      p.avg_line = hz ? M.buf_w[a] : 1;
-      p.avg_step = hz ? 1 : M.buf_w[a];
-      p.res_line = hz ? M.buf_w[q] : 1;
-      p.res_step = hz ? 1 : M.buf_w[q];
-      p.out_line = hz ? M.buf_w[o] : 1;
-      p.out_step = hz ? 1 : M.buf_w[o];
-      if (p.lines) hipLaunchKernelGGL(jxlhip::k_modular_unsqueeze, dim3((p.lines + 63) / 64), dim3(64), 0, st, p);
+      if (L.count) launches->push_back(L);
     }
-    HIP_TRY(hipGetLastError());
   }
-  jxlhip::ModOutput o;
-  memset(&o, 0, sizeof(o));
-  for (uint32_t j = 0; j < M.num_color + (M.has_alpha ? 1 : 0); j++) {
-    o.ch[j] = pool + M.buf_off[M.out_buffer[j]];
-    o.stride[j] = M.xs;
+  align();
+  ModLaunch L{3, blob->size(), 0, 0, 0};
+  for (size_t i = 0; i < n; i++) {
+    const JxlHipContext* c = ctxs[i];
+    const JxlHipContext::Modular& M = c->mod;
+    int32_t* pool = M.pool.as<int32_t>();
+    jxlhip::ModOutput o;
+    memset(&o, 0, sizeof(o));
+    for (uint32_t j = 0; j < M.num_color + (M.has_alpha ? 1 : 0); j++) {
+      o.ch[j] = pool + M.buf_off[M.out_buffer[j]];
+      o.stride[j] = M.xs;
+    }
+    o.num_color = M.num_color;
+    o.has_alpha = M.has_alpha;
+    o.bits = M.bits;
+    o.alpha_bits = M.alpha_bits;
+    o.w = M.xs;
+    o.h = M.ys;
+    o.po.dst = c->rgb.p;
+    o.po.alpha = nullptr;
+    o.po.xsize = M.xs;
+    o.po.type = c->out_type;
+    o.po.nc = c->out_nc;
+    o.po.bits = c->out_bits;
+    o.po.swap = c->out_swap;
+    append(&o, sizeof(o));
+    L.count++;
+    L.gx = std::max(L.gx, (M.xs + 255) / 256);
+    L.gy = std::max(L.gy, M.ys);
   }
-  o.num_color = M.num_color;
-  o.has_alpha = M.has_alpha;
-  o.bits = M.bits;
-  o.alpha_bits = M.alpha_bits;
-  o.w = M.xs;
-  o.h = M.ys;
-  o.po.dst = c->rgb.p;
-  o.po.alpha = nullptr;
-  o.po.xsize = M.xs;
-  o.po.type = c->out_type;
-  o.po.nc = c->out_nc;
-  o.po.bits = c->out_bits;
-  o.po.swap = c->out_swap;
-  hipLaunchKernelGGL(jxlhip::k_modular_output, dim3((M.xs + 255) / 256, M.ys), dim3(256), 0, st, o);
-  HIP_TRY(hipGetLastError());
+  launches->push_back(L);
+}
+static int ModularLaunchOps(const std::vector<ModLaunch>& launches, const uint8_t* dev, hipStream_t st) {
+  for (const ModLaunch& L : launches)
+    for (uint32_t z = 0; z < L.count; z += 65535) {  // grid z / y limit
+      const uint32_t zn = std::min<uint32_t>(L.count - z, 65535);
+      const uint32_t gy = std::min<uint32_t>(L.gy, 4096);  // (the row loops stride by the grid)
+      if (L.kind == 0)
+        hipLaunchKernelGGL(jxlhip::k_modular_rct, dim3(L.gx, gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::ModRct*>(dev + L.offset) + z);
+      else if (L.kind == 1)
+        hipLaunchKernelGGL(jxlhip::k_modular_palette, dim3(L.gx, gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::ModPalette*>(dev + L.offset) + z);
+      else if (L.kind == 2)
+        hipLaunchKernelGGL(jxlhip::k_modular_unsqueeze, dim3(L.gx, zn), dim3(64), 0, st, reinterpret_cast<const jxlhip::ModUnsqueeze*>(dev + L.offset) + z);
+      else
+        hipLaunchKernelGGL(jxlhip::k_modular_output, dim3(L.gx, gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::ModOutput*>(dev + L.offset) + z);
+      HIP_TRY(hipGetLastError());
+    }
   return 0;
 }
 
@@ -1665,6 +1996,20 @@ extern "C" int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n) {
     M0.batch_gens.resize(n);
     for (size_t i = 0; i < n; i++) M0.batch_gens[i] = ctxs[i]->generation;
     M0.batch_n = uint32_t(all.size());
+    uint32_t cap = 0;  // LDS room for the largest tree of the batch that fits (waves whose streams share a tree stage it)
+    for (const Ref& q : all)
+      if (q.s->tree_nodes <= jxlhip::kModTreeLdsNodes && q.s->tree_nodes > cap) cap = q.s->tree_nodes;
+    M0.batch_tree_cap = cap;
+    uint32_t tcap = 0;  // likewise for the largest set of symbol tables that fits
+    for (size_t i = 0; i < n; i++)
+      for (uint32_t w : ctxs[i]->mod.code_table_words)
+        if (w <= jxlhip::kModTableLdsWords && w > tcap) tcap = w;
+    M0.batch_table_cap = tcap;
+    std::vector<uint8_t> ops_blob;
+    ModularBuildOps(ctxs, n, &ops_blob, &M0.batch_launches);
+    r = M0.batch_ops.Ensure(ops_blob.size() + 16);
+    if (r) return r;
+    if (!ops_blob.empty()) HIP_TRY(hipMemcpy(M0.batch_ops.p, ops_blob.data(), ops_blob.size(), hipMemcpyHostToDevice));
   }
   for (size_t i = 0; i < n; i++) {
     int pw = ApplyPendingWait(ctxs[i]);
@@ -1677,12 +2022,21 @@ extern "C" int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n) {
   }
   HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
   if (M0.batch_n) {
-    hipLaunchKernelGGL(jxlhip::k_modular_streams, dim3((M0.batch_n + 63) / 64), dim3(64), 0, c0->stream,
-                       M0.batch_streams.as<jxlhip::ModStream>(), M0.batch_n);
+    // A stream is a chain of dependent latencies: as few streams per wave as still leaves every SIMD of the device a
+    // few waves (JXLHIP_MOD_LANES overrides: measurement aid)
+    uint32_t lanes = 1;
+    while (lanes < 64 && M0.batch_n / lanes > 2048) lanes *= 2;
+    const int forced = EnvInt("JXLHIP_MOD_LANES", 0);
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) lanes = uint32_t(forced);
+    const uint32_t lds = jxlhip::ModLdsBytes(lanes, M0.batch_tree_cap, M0.batch_table_cap);
+    if (lds > 48 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(jxlhip::k_modular_streams), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(jxlhip::k_modular_streams, dim3((M0.batch_n + lanes - 1) / lanes), dim3(64), lds, c0->stream,
+                       M0.batch_streams.as<jxlhip::ModStream>(), M0.batch_n, lanes, M0.batch_tree_cap, M0.batch_table_cap);
     HIP_TRY(hipGetLastError());
   }
-  for (size_t i = 0; i < n; i++) {
-    int r = ModularLaunchOps(ctxs[i], c0->stream);
+  {
+    int r = ModularLaunchOps(M0.batch_launches, M0.batch_ops.as<uint8_t>(), c0->stream);
     if (r) return r;
   }
   HIP_TRY(hipEventRecord(c0->ev[1], c0->stream));
@@ -1834,6 +2188,13 @@ int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
     c->filter_async = value != 0;
     return 0;
   }
+  if (std::string(name) == "blocking_sync") {
+    // Host threads waiting for the device in this library's calls poll and sleep instead of spinning inside the runtime
+    // (the whole process, not only this context): for hosts that pipeline many frames over more threads than they have
+    // CPUs to spare.
+    g_yield_waits.store(value != 0);
+    return 0;
+  }
   return JXLHIP_ERR_INVALID_ARGUMENT;
 }
 
@@ -1895,7 +2256,7 @@ int jxlhip_sync(JxlHipContext* c) {
     int pw = ApplyPendingWait(c);
     if (pw) return pw;
   }
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(WaitStream(c->stream));
   return 0;
 }
 
@@ -1909,7 +2270,7 @@ int jxlhip_download_rgb8(JxlHipContext* c, uint8_t* dst, size_t stride) {
     if (pw) return pw;
   }
   HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, size_t(c->oxs) * 3, size_t(c->oxs) * 3, c->oys, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(WaitStream(c->stream));
   return 0;
 }
 

@@ -10,8 +10,14 @@
 // A Modular stream (one group x a subset of channels) is a pixel-serial adaptive decode: every sample's context comes
 // from the MA tree evaluated on already-decoded neighbours. The parallelism is ACROSS streams, exactly as for the AC
 // sections of VarDCT: k_modular_streams gives every LANE its own stream (a 4K lossless frame has 135 group streams,
-// a batch of frames fills the machine). Tables (tree nodes, alias / prefix tables, context maps) stay in global memory:
-// they differ per stream when the encoder used local trees, and the walk is bound by its dependent loads either way.
+// a batch of frames fills the machine). A wave carries only a few streams (the host picks 1..64 per wave so that all SIMDs
+// hold waves): the decode is a chain of dependent latencies, not issue bound, and lanes of one wave wait for each other's
+// divergent tree walks. Per sample the chain is: MA-tree walk (16-byte nodes, from LDS when the wave's streams share a
+// tree that fits, else global; the properties sit in an LDS array indexed by the node), one alias-table / prefix-table
+// lookup in global memory, the predictor. Nothing else on the chain touches memory: the neighbourhood (W, WW, NW, N, NE,
+// NEE, NN) and the weighted predictor's error rows are sliding windows in registers fed by loads issued one sample
+// ahead, the bit reader keeps its next word loaded ahead, and the code's tables are addressed through a register copy of
+// the descriptor.
 // The host front-end (csrc/host/jxh_modframe.h) parses every stream's group header (transforms, optional local tree and
 // histograms) and hands the kernel flat descriptors; samples are written straight into the frame's channel buffers.
 #ifndef JXL_HIP_MODULAR_H_
@@ -21,14 +27,11 @@
 
 namespace jxlhip {
 
-struct ModTreeNode {  // 32 bytes
-  int32_t property;   // -1 = leaf
-  int32_t splitval;
-  uint32_t lchild, rchild;  // leaves: lchild = context id
-  uint32_t predictor;
-  int32_t offset;
-  uint32_t multiplier;
-  uint32_t pad;
+struct ModTreeNode {  // 16 bytes (jxlhip_modular_upload packs the boundary's nodes): one load per step of the walk
+  int32_t property;   // decision: the property tested (>= 0); leaf: -1 - predictor
+  int32_t splitval;   // leaf: offset
+  uint32_t lchild;    // leaf: histogram (the context already mapped through the code's context map)
+  uint32_t rchild;    // leaf: multiplier
 };
 
 struct ModCode {  // one entropy code (global or local to a stream); pointers into device memory
@@ -37,7 +40,10 @@ struct ModCode {  // one entropy code (global or local to a stream); pointers in
   const uint32_t* cfg;      // per cluster: split_exp | msb << 8 | lsb << 16
   const uint32_t* prefix_table;
   const uint32_t* prefix_offset;
-  uint32_t log_alpha, use_prefix, lz77, lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_ctx, pad;
+  uint32_t log_alpha, use_prefix, lz77, lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_ctx;
+  uint32_t table_words;     // 32-bit words of the symbol tables a wave may stage in LDS: the alias table (ANS) or the prefix
+                            // table, then one word per cluster (cfg), then for prefix codes one more per cluster (offsets)
+  uint32_t num_clusters, pad[3];
 };
 
 struct ModChannel {  // one channel of a stream: a rectangle of a frame channel buffer
@@ -52,6 +58,7 @@ struct ModStream {
   uint32_t bit_offset;     // where the stream's sample data begins
   uint32_t size_bytes;     // section size: reads beyond it are zero, consuming beyond it is an error
   const ModTreeNode* tree;
+  uint32_t tree_nodes;
   const ModCode* code;
   const ModChannel* channels;
   uint32_t num_channels;
@@ -80,30 +87,63 @@ __constant__ int8_t c_special_distances[120][2] = {
     {8, 0},  {4, 7},  {-4, 7}, {7, 4},  {-7, 4}, {8, 1},  {8, 2},  {6, 6},  {-6, 6}, {8, 3},  {5, 7},  {-5, 7},
     {7, 5},  {-7, 5}, {8, 4},  {6, 7},  {-6, 7}, {7, 6},  {-7, 6}, {8, 5},  {7, 7},  {-7, 7}, {8, 6},  {8, 7}};
 
+// Bit reader with the next word loaded ahead (the refill that consumes it issues the following load).
+struct ModBits {
+  const uint32_t* p;
+  uint32_t idx, nwords, next;
+  uint64_t buf;
+  int bits;
+};
+__device__ __forceinline__ void MbInit(ModBits& b, const uint32_t* words, uint32_t nwords, uint32_t first_word) {
+  b.p = words;
+  b.nwords = nwords;
+  b.idx = first_word;
+  b.buf = 0;
+  b.bits = 0;
+  b.next = b.idx < b.nwords ? b.p[b.idx] : 0u;
+}
+__device__ __forceinline__ void MbRefill(ModBits& b) {
+  if (b.bits < 32) {
+    b.buf |= uint64_t(b.next) << b.bits;
+    b.bits += 32;
+    b.idx++;
+    b.next = b.idx < b.nwords ? b.p[b.idx] : 0u;
+  }
+}
+__device__ __forceinline__ uint32_t MbRead(ModBits& b, uint32_t n) {  // n <= 32, caller refilled
+  const uint32_t v = uint32_t(b.buf & ((uint64_t(1) << n) - 1));
+  b.buf >>= n;
+  b.bits -= int(n);
+  return v;
+}
+
 struct ModReader {
-  BitReader br;
+  ModBits br;
   uint32_t state;
-  const ModCode* code;
+  ModCode T;  // register copy of the stream's code descriptor
+  const uint32_t* ltab;  // the code's tables in LDS (alias or prefix table | cfg | prefix offsets), or NULL
   uint32_t* window;
   uint32_t mask, num_decoded, num_to_copy, copy_pos, num_special, dist_mult, err;
 };
 __device__ __forceinline__ uint32_t ModSymbol(ModReader& r, uint32_t cluster) {
-  const ModCode& T = *r.code;
-  BrRefill(r.br);
+  const ModCode& T = r.T;
+  MbRefill(r.br);
   if (T.use_prefix) {
-    const uint32_t po = T.prefix_offset[cluster], max_len = po >> 24;
-    if (max_len == 0) return T.prefix_table[po & 0xFFFFFFu] >> 8;
-    const uint32_t e = T.prefix_table[(po & 0xFFFFFFu) + uint32_t(r.br.buf & ((1u << max_len) - 1))];
-    BrRead(r.br, e & 0xFF);
+    const uint32_t po = r.ltab ? r.ltab[T.table_words - T.num_clusters + cluster] : T.prefix_offset[cluster], max_len = po >> 24;
+    const uint32_t at = (po & 0xFFFFFFu) + (max_len ? uint32_t(r.br.buf & ((1u << max_len) - 1)) : 0u);
+    const uint32_t e = r.ltab ? r.ltab[at] : T.prefix_table[at];
+    if (max_len == 0) return e >> 8;
+    MbRead(r.br, e & 0xFF);
     return e >> 8;
   }
   const uint32_t log_entry = 12 - T.log_alpha;
   const uint32_t res = r.state & 0xFFFu, i = res >> log_entry, pos = res & ((1u << log_entry) - 1);
-  const uint2 e = T.alias[(cluster << T.log_alpha) + i];
+  const uint32_t slot = (cluster << T.log_alpha) + i;
+  const uint2 e = r.ltab ? *reinterpret_cast<const uint2*>(r.ltab + 2 * slot) : T.alias[slot];
   const uint32_t cutoff = e.x & 0xFF, right = (e.x >> 8) & 0xFF, freq0 = e.x >> 16, offsets1 = e.y & 0xFFFF, freq1 = e.y >> 16;
   const bool greater = pos >= cutoff;
   r.state = (greater ? freq1 : freq0) * (r.state >> 12) + (greater ? offsets1 : 0u) + pos;
-  if (r.state < (1u << 16)) r.state = (r.state << 16) | BrRead(r.br, 16);
+  if (r.state < (1u << 16)) r.state = (r.state << 16) | MbRead(r.br, 16);
   return greater ? right : i;
 }
 __device__ __forceinline__ uint32_t ModUint(ModReader& r, uint32_t cfg, uint32_t token) {
@@ -111,13 +151,13 @@ __device__ __forceinline__ uint32_t ModUint(ModReader& r, uint32_t cfg, uint32_t
   if (token < (1u << split_exp)) return token;
   const uint32_t nbits = (split_exp - (msb + lsb) + ((token - (1u << split_exp)) >> (msb + lsb))) & 31u;
   const uint32_t low = token & ((1u << lsb) - 1), hi = token >> lsb;
-  BrRefill(r.br);
-  const uint32_t bits = BrRead(r.br, nbits);
+  MbRefill(r.br);
+  const uint32_t bits = MbRead(r.br, nbits);
   return (((((1u << msb) | (hi & ((1u << msb) - 1))) << nbits) | bits) << lsb) | low;
 }
 // dec_ans.h:288-353 (ReadHybridUintClusteredInlined with LZ77)
 __device__ __forceinline__ uint32_t ModRead(ModReader& r, uint32_t cluster) {
-  const ModCode& T = *r.code;
+  const ModCode& T = r.T;
   if (T.lz77 && r.num_to_copy > 0) {
     // (copy_pos == num_decoded only for a copy at the very start of a stream, distance 0: zeros, dec_ans.h:320-327)
     const uint32_t v = r.copy_pos >= r.num_decoded ? 0u : r.window[r.copy_pos & r.mask];
@@ -126,11 +166,13 @@ __device__ __forceinline__ uint32_t ModRead(ModReader& r, uint32_t cluster) {
     r.window[(r.num_decoded++) & r.mask] = v;
     return v;
   }
+  const uint32_t cfg_at = T.use_prefix ? T.table_words - 2 * T.num_clusters : T.table_words - T.num_clusters;
+  const uint32_t cfg = r.ltab ? r.ltab[cfg_at + cluster] : T.cfg[cluster];  // (issued with the symbol's table lookup: one round trip for both)
   const uint32_t token = ModSymbol(r, cluster);
   if (T.lz77 && token >= T.lz_min_symbol) {
     r.num_to_copy = ModUint(r, T.lz_len_cfg, token - T.lz_min_symbol) + T.lz_min_length;
     const uint32_t dtok = ModSymbol(r, T.lz_dist_ctx);
-    uint32_t distance = ModUint(r, T.cfg[T.lz_dist_ctx], dtok);
+    uint32_t distance = ModUint(r, r.ltab ? r.ltab[cfg_at + T.lz_dist_ctx] : T.cfg[T.lz_dist_ctx], dtok);
     if (distance < r.num_special) {
       const int d = int(c_special_distances[distance][0]) + int(r.dist_mult) * int(c_special_distances[distance][1]);
       distance = d > 1 ? uint32_t(d) : 1u;
@@ -152,7 +194,7 @@ __device__ __forceinline__ uint32_t ModRead(ModReader& r, uint32_t cluster) {
     r.window[(r.num_decoded++) & r.mask] = v;
     return v;
   }
-  const uint32_t v = ModUint(r, T.cfg[cluster], token);
+  const uint32_t v = ModUint(r, cfg, token);
   if (T.lz77) r.window[(r.num_decoded++) & r.mask] = v;
   return v;
 }
@@ -166,36 +208,33 @@ __device__ __forceinline__ int32_t ModClampedGradient(int32_t n, int32_t w, int3
 __device__ __forceinline__ int64_t ModAbs64(int64_t v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int ModFloorLog2(uint64_t v) { return 63 - __clzll(static_cast<long long>(v)); }
 
-// Self-correcting weighted predictor (context_predict.h:66-218). State: per row-parity arrays of width + 2 entries:
-// error[2][w + 2], pred_errors[4][2][w + 2] in the stream's scratch.
+// Self-correcting weighted predictor (context_predict.h:66-218). The reference keeps five arrays of two rows (the true
+// errors and the four sub-predictors' errors, where an error is also added to the entry above and to the right); here a
+// row entry is {sub-predictor errors 0..3, true error, pad x 3} (32 bytes, two rows of width + 2 entries in the stream's
+// scratch), and everything a sample reads lives in registers: the entries above (N, NW, NE) slide along the row, the
+// "+= above right" lands in the register that becomes N of the next sample (it is never read from memory again: the row
+// above is overwritten two rows later), the entry two to the right is loaded one sample ahead, and a sample's own entry
+// is a fire-and-forget store for the row below.
 struct ModWp {
-  int32_t* error;        // [2 * (w + 2)]
-  uint32_t* pred_err[4];  // each [2 * (w + 2)]
+  uint32_t peN[4], peNW[4], peNE[4];
+  int32_t teW, teN, teNW, teNE;
   int64_t prediction[4];
   int64_t pred;
-  const int32_t* hd;     // p1C p2C p3Ca p3Cb p3Cc p3Cd p3Ce w0 w1 w2 w3
 };
+constexpr uint32_t kModWpEntry = 8;  // ints per row entry
 __device__ __forceinline__ uint32_t ModErrorWeight(uint64_t x, uint32_t maxweight) {
   int shift = ModFloorLog2(x + 1) - 5;
   if (shift < 0) shift = 0;
   const uint32_t div = (1u << 24) / (uint32_t(x >> shift) + 1u);
   return uint32_t(4 + ((uint64_t(maxweight) * div) >> shift));
 }
-__device__ __forceinline__ int64_t ModWpPredict(ModWp& s, uint32_t x, uint32_t y, uint32_t xsize, int64_t N, int64_t W, int64_t NE, int64_t NW,
-                                               int64_t NN, int32_t* max_err_prop) {
-  const uint32_t cur = (y & 1) ? 0 : (xsize + 2), prev = (y & 1) ? (xsize + 2) : 0;
-  const uint32_t pos_N = prev + x;
-  const uint32_t pos_NE = x < xsize - 1 ? pos_N + 1 : pos_N;
-  const uint32_t pos_NW = x > 0 ? pos_N - 1 : pos_N;
+__device__ __forceinline__ int64_t ModWpPredict(ModWp& s, const int32_t* hd, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN,
+                                               int32_t* max_err_prop) {
   uint32_t weights[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const uint32_t e = s.pred_err[i][pos_N] + s.pred_err[i][pos_NE] + s.pred_err[i][pos_NW];
-    weights[i] = ModErrorWeight(e, uint32_t(s.hd[7 + i]));
-  }
+  for (int i = 0; i < 4; i++) weights[i] = ModErrorWeight(s.peN[i] + s.peNE[i] + s.peNW[i], uint32_t(hd[7 + i]));
   N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
-  const int64_t teW = x == 0 ? 0 : s.error[cur + x - 1];
-  const int64_t teN = s.error[pos_N], teNW = s.error[pos_NW], teNE = s.error[pos_NE];
+  const int64_t teW = s.teW, teN = s.teN, teNW = s.teNW, teNE = s.teNE;
   const int64_t sumWN = teN + teW;
   {
     int64_t p = teW;
@@ -205,9 +244,9 @@ __device__ __forceinline__ int64_t ModWpPredict(ModWp& s, uint32_t x, uint32_t y
     *max_err_prop = int32_t(p);
   }
   s.prediction[0] = W + NE - N;
-  s.prediction[1] = N - (((sumWN + teNE) * s.hd[0]) >> 5);
-  s.prediction[2] = W - (((sumWN + teNW) * s.hd[1]) >> 5);
-  s.prediction[3] = N - ((teNW * s.hd[2] + teN * s.hd[3] + teNE * s.hd[4] + (NN - N) * s.hd[5] + (NW - W) * s.hd[6]) >> 5);
+  s.prediction[1] = N - (((sumWN + teNE) * hd[0]) >> 5);
+  s.prediction[2] = W - (((sumWN + teNW) * hd[1]) >> 5);
+  s.prediction[3] = N - ((teNW * hd[2] + teN * hd[3] + teNE * hd[4] + (NN - N) * hd[5] + (NW - W) * hd[6]) >> 5);
   {  // WeightedAverage
     uint32_t ws = weights[0] + weights[1] + weights[2] + weights[3];
     const int lw = ModFloorLog2(ws);
@@ -227,16 +266,27 @@ __device__ __forceinline__ int64_t ModWpPredict(ModWp& s, uint32_t x, uint32_t y
   s.pred = s.pred < mn ? mn : (s.pred > mx ? mx : s.pred);
   return (s.pred + 3) >> 3;
 }
-__device__ __forceinline__ void ModWpUpdate(ModWp& s, int64_t val, uint32_t x, uint32_t y, uint32_t xsize) {
-  const uint32_t cur = (y & 1) ? 0 : (xsize + 2), prev = (y & 1) ? (xsize + 2) : 0;
+// After sample x of a row `w` wide got value `val`: stores the sample's entry into `cur_entry` (row y, for row y + 1) and
+// slides the window to sample x + 1; `ahead` is the entry of the row above at x + 2 (zeros in the first row).
+__device__ __forceinline__ void ModWpUpdate(ModWp& s, int64_t val, int32_t* cur_entry, const int4& ahead_pe, int32_t ahead_te, bool ahead_valid) {
   val *= 8;
-  s.error[cur + x] = int32_t(s.pred - val);
+  const int32_t te = int32_t(s.pred - val);
+  uint32_t err[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) err[i] = uint32_t((ModAbs64(s.prediction[i] - val) + 3) >> 3);
+  *reinterpret_cast<int4*>(cur_entry) = make_int4(int(err[0]), int(err[1]), int(err[2]), int(err[3]));
+  cur_entry[4] = te;
+  const uint32_t ahead[4] = {uint32_t(ahead_pe.x), uint32_t(ahead_pe.y), uint32_t(ahead_pe.z), uint32_t(ahead_pe.w)};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int64_t err = (ModAbs64(s.prediction[i] - val) + 3) >> 3;
-    s.pred_err[i][cur + x] = uint32_t(err);
-    s.pred_err[i][prev + x + 1] += uint32_t(err);
+    s.peNW[i] = s.peN[i];
+    s.peN[i] = s.peNE[i] + err[i];  // the reference's "+= above right"
+    s.peNE[i] = ahead_valid ? ahead[i] : s.peN[i];  // (last sample of a row: its NE is its N)
   }
+  s.teNW = s.teN;
+  s.teN = s.teNE;
+  s.teNE = ahead_valid ? ahead_te : s.teN;
+  s.teW = te;
 }
 
 __device__ __forceinline__ int64_t ModPredict(uint32_t p, int64_t left, int64_t top, int64_t toptop, int64_t topleft, int64_t topright,
@@ -263,110 +313,251 @@ __device__ __forceinline__ int64_t ModPredict(uint32_t p, int64_t left, int64_t 
 }
 
 constexpr int kModMaxProps = 16 + 4 * 4;  // property 15 + up to four referenced previous channels (host refuses trees beyond)
+constexpr uint32_t kModTreeLdsNodes = 2048;  // largest tree kept in LDS (32 KB)
 
-// One lane per stream. `streams` holds `n` descriptors.
-__global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams, uint32_t n) {
-  const uint32_t si = blockIdx.x * 64 + threadIdx.x;
-  if (si >= n) return;
-  const ModStream& S = streams[si];
+constexpr uint32_t kModTableLdsWords = 8192;  // largest symbol-table set kept in LDS (32 KB)
+
+// Dynamic LDS of a workgroup (one wave, `lanes` streams): the properties [property][lane], then `tree_cap` tree nodes,
+// then `table_cap` words of symbol tables.
+__host__ __device__ inline uint32_t ModLdsBytes(uint32_t lanes, uint32_t tree_cap, uint32_t table_cap) {
+  return kModMaxProps * lanes * 4 + tree_cap * 16 + table_cap * 4;
+}
+
+// One lane per stream, `lanes` (a power of two, <= 64) streams per workgroup; `streams` holds `n` descriptors.
+__global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams, uint32_t n, uint32_t lanes, uint32_t tree_cap, uint32_t table_cap) {
+  extern __shared__ __align__(16) uint8_t mod_lds[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t si = blockIdx.x * lanes + lane;
+  const bool active = lane < lanes && si < n;
+  int32_t* const lprops = reinterpret_cast<int32_t*>(mod_lds) + lane;  // property q at lprops[q * lanes]
+  int4* const ltree = reinterpret_cast<int4*>(mod_lds + kModMaxProps * lanes * 4);
+  ModStream S;
+  if (active) S = streams[si];
+  else memset(&S, 0, sizeof(S));
+  // ---- the tree goes to LDS when every stream of the wave walks the same one and it fits
+  const uint64_t tree_bits = reinterpret_cast<uint64_t>(S.tree);
+  const uint32_t first_lo = __builtin_amdgcn_readfirstlane(uint32_t(tree_bits)), first_hi = __builtin_amdgcn_readfirstlane(uint32_t(tree_bits >> 32));
+  const uint32_t first_nodes = __builtin_amdgcn_readfirstlane(S.tree_nodes);
+  const bool same = !active || (uint32_t(tree_bits) == first_lo && uint32_t(tree_bits >> 32) == first_hi);
+  const bool tree_lds = __builtin_amdgcn_ballot_w64(same) == ~0ull && first_nodes <= tree_cap && first_nodes != 0;
+  if (tree_lds) {
+    const int4* src = reinterpret_cast<const int4*>((uint64_t(first_hi) << 32) | first_lo);
+    for (uint32_t i = lane; i < first_nodes; i += 64) ltree[i] = src[i];
+  }
+  // ---- likewise the symbol tables of the streams' entropy code
   ModReader r;
-  r.code = S.code;
+  if (active) r.T = *S.code;
+  else memset(&r.T, 0, sizeof(r.T));
+  uint32_t* const ltab = reinterpret_cast<uint32_t*>(mod_lds + kModMaxProps * lanes * 4 + tree_cap * 16);
+  {
+    const uint64_t code_bits = reinterpret_cast<uint64_t>(S.code);
+    const uint32_t c_lo = __builtin_amdgcn_readfirstlane(uint32_t(code_bits)), c_hi = __builtin_amdgcn_readfirstlane(uint32_t(code_bits >> 32));
+    const uint32_t words = __builtin_amdgcn_readfirstlane(r.T.table_words);
+    const bool same_code = !active || (uint32_t(code_bits) == c_lo && uint32_t(code_bits >> 32) == c_hi);
+    const bool code_lds = __builtin_amdgcn_ballot_w64(same_code) == ~0ull && words <= table_cap && words != 0;
+    r.ltab = code_lds ? ltab : nullptr;
+    if (code_lds) {
+      // (lane 0 is active: its register copy of the descriptor names the tables)
+      const uint64_t t0 = reinterpret_cast<uint64_t>(r.T.use_prefix ? static_cast<const void*>(r.T.prefix_table) : static_cast<const void*>(r.T.alias));
+      const uint64_t t1 = reinterpret_cast<uint64_t>(r.T.cfg), t2 = reinterpret_cast<uint64_t>(r.T.prefix_offset);
+      const uint32_t* src0 = reinterpret_cast<const uint32_t*>((uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(t0 >> 32))) << 32) | __builtin_amdgcn_readfirstlane(uint32_t(t0)));
+      const uint32_t* src1 = reinterpret_cast<const uint32_t*>((uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(t1 >> 32))) << 32) | __builtin_amdgcn_readfirstlane(uint32_t(t1)));
+      const uint32_t* src2 = reinterpret_cast<const uint32_t*>((uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(t2 >> 32))) << 32) | __builtin_amdgcn_readfirstlane(uint32_t(t2)));
+      const uint32_t ncl = __builtin_amdgcn_readfirstlane(r.T.num_clusters), pfx = __builtin_amdgcn_readfirstlane(r.T.use_prefix);
+      const uint32_t main_words = words - ncl * (pfx ? 2 : 1);
+      for (uint32_t i = lane; i < main_words; i += 64) ltab[i] = src0[i];
+      for (uint32_t i = lane; i < ncl; i += 64) ltab[main_words + i] = src1[i];
+      if (pfx)
+        for (uint32_t i = lane; i < ncl; i += 64) ltab[main_words + ncl + i] = src2[i];
+    }
+  }
+  __syncthreads();
+  if (!active) return;
   r.window = S.lz_window;
   r.mask = S.lz_window_mask;
   r.num_decoded = r.num_to_copy = r.copy_pos = 0;
   r.dist_mult = S.dist_multiplier;
   r.num_special = S.dist_multiplier ? 120u : 0u;
   r.err = 0;
-  r.br.p = S.words;
-  r.br.nwords = (S.size_bytes + 3) / 4;
-  r.br.idx = S.bit_offset >> 5;
-  r.br.buf = 0;
-  r.br.bits = 0;
-  BrRefill(r.br);
-  if (S.bit_offset & 31) BrRead(r.br, S.bit_offset & 31);
+  MbInit(r.br, S.words, (S.size_bytes + 3) / 4, S.bit_offset >> 5);
+  MbRefill(r.br);
+  if (S.bit_offset & 31) MbRead(r.br, S.bit_offset & 31);
   r.state = 0x13u << 16;
-  if (!S.code->use_prefix) {
-    BrRefill(r.br);
-    r.state = BrRead(r.br, 16);
-    BrRefill(r.br);
-    r.state |= BrRead(r.br, 16) << 16;
+  if (!r.T.use_prefix) {
+    MbRefill(r.br);
+    r.state = MbRead(r.br, 16);
+    MbRefill(r.br);
+    r.state |= MbRead(r.br, 16) << 16;
   }
-  const ModTreeNode* tree = S.tree;
-  int32_t props[kModMaxProps];
+  const int4* const gtree = reinterpret_cast<const int4*>(S.tree);
+  auto node = [&](uint32_t pos) -> int4 { return tree_lds ? ltree[pos] : gtree[pos]; };
 #pragma unroll
-  for (int i = 0; i < kModMaxProps; i++) props[i] = 0;
+  for (int i = 0; i < kModMaxProps; i++) lprops[i * lanes] = 0;
+  const bool wp_on = S.uses_wp != 0;
   for (uint32_t ci = 0; ci < S.num_channels && !r.err; ci++) {
     const ModChannel ch = S.channels[ci];
     if (!ch.w || !ch.h) continue;
+    const uint32_t w = ch.w;
     // previous channels of the same shape, nearest first (context_predict.h:419-451)
-    const ModChannel* refs[4];
+    const int32_t* ref_data[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t ref_stride[4] = {0, 0, 0, 0};
     uint32_t nrefs = 0;
-    for (int j = int(ci) - 1; j >= 0 && nrefs * 4 < S.num_props - 16 && nrefs < 4; j--)
-      if (S.channels[j].sig == ch.sig && S.channels[j].w == ch.w && S.channels[j].h == ch.h) refs[nrefs++] = &S.channels[j];
-    ModWp wp;
-    wp.hd = S.wp;
-    if (S.uses_wp) {
-      const uint32_t span = 2 * (ch.w + 2);
-      wp.error = S.wp_scratch;
-      for (int i = 0; i < 4; i++) wp.pred_err[i] = reinterpret_cast<uint32_t*>(S.wp_scratch) + span * (1 + i);
-      for (uint32_t i = 0; i < span * 5; i++) S.wp_scratch[i] = 0;
+    for (int j = int(ci) - 1; j >= 0 && nrefs * 4 < S.num_props - 16 && nrefs < 4; j--) {
+      const ModChannel o = S.channels[j];
+      if (o.sig == ch.sig && o.w == ch.w && o.h == ch.h) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (uint32_t(q) == nrefs) {
+            ref_data[q] = o.data;
+            ref_stride[q] = o.stride;
+          }
+        nrefs++;
+      }
     }
     const ptrdiff_t stride = ptrdiff_t(ch.stride);
 #pragma unroll
-    for (int i = 16; i < kModMaxProps; i++) props[i] = 0;  // slots of previous channels this channel does not have
-    props[0] = int32_t(S.first_channel_index + ci);
-    props[1] = int32_t(S.stream_id);
+    for (int i = 16; i < kModMaxProps; i++) lprops[i * lanes] = 0;  // slots of previous channels this channel does not have
+    lprops[0] = int32_t(S.first_channel_index + ci);
+    lprops[1 * lanes] = int32_t(S.stream_id);
+    // properties 0 and 1 are constant over the channel: their decisions at the top of the tree are taken once
+    uint32_t root = 0;
+    for (;;) {
+      const int4 nd = node(root);
+      if (nd.x != 0 && nd.x != 1) break;
+      const int32_t v = nd.x == 0 ? int32_t(S.first_channel_index + ci) : int32_t(S.stream_id);
+      root = v > nd.y ? uint32_t(nd.z) : uint32_t(nd.w);
+    }
+    ModWp wp;
     for (uint32_t y = 0; y < ch.h && !r.err; y++) {
-      int32_t* p = ch.data + size_t(y) * ch.stride;
-      props[2] = int32_t(y);
-      props[9] = 0;
-      for (uint32_t x = 0; x < ch.w; x++) {
-        const int32_t* pp = p + x;
-        const int64_t left = x ? pp[-1] : (y ? pp[-stride] : 0);
-        const int64_t top = y ? pp[-stride] : left;
-        const int64_t topleft = (x && y) ? pp[-1 - stride] : left;
-        const int64_t topright = (x + 1 < ch.w && y) ? pp[1 - stride] : top;
-        const int64_t leftleft = x > 1 ? pp[-2] : left;
-        const int64_t toptop = y > 1 ? pp[-2 * stride] : top;
-        const int64_t toprightright = (x + 2 < ch.w && y) ? pp[2 - stride] : topright;
-        props[3] = int32_t(x);
-        props[4] = int32_t(top > 0 ? top : -top);
-        props[5] = int32_t(left > 0 ? left : -left);
-        props[6] = int32_t(top);
-        props[7] = int32_t(left);
-        props[8] = int32_t(left - props[9]);  // uses the previous pixel's property 9
-        props[9] = int32_t(left + top - topleft);
-        props[10] = int32_t(left - topleft);
-        props[11] = int32_t(topleft - top);
-        props[12] = int32_t(top - topright);
-        props[13] = int32_t(top - toptop);
-        props[14] = int32_t(left - leftleft);
+      int32_t* const p = ch.data + size_t(y) * ch.stride;
+      const int32_t* const pN = p - stride;       // read only when y > 0
+      const int32_t* const pNN = p - 2 * stride;  // read only when y > 1
+      lprops[2 * lanes] = int32_t(y);
+      int32_t prev9 = 0;
+      // the row above at x, x - 1, x + 1, x + 2 and two rows above at x: a sliding window (raw samples; the edge rules
+      // are applied where the neighbours are formed)
+      int32_t rN = y ? pN[0] : 0, rNW = 0, rNE = (y && w > 1) ? pN[1] : 0, rNEE = (y && w > 2) ? pN[2] : 0;
+      int32_t rNN = y > 1 ? pNN[0] : 0;
+      int32_t rW = 0, rWW = 0;
+      // previous channels: this row and the one above at x and x - 1
+      int32_t rv[4] = {0, 0, 0, 0}, rvl[4] = {0, 0, 0, 0}, rvt[4] = {0, 0, 0, 0}, rvtl[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (uint32_t(j) < nrefs) {
+          rv[j] = ref_data[j][size_t(y) * ref_stride[j]];
+          rvt[j] = y ? ref_data[j][size_t(y - 1) * ref_stride[j]] : 0;
+        }
+      int32_t* wcur = nullptr;
+      const int32_t* wprev = nullptr;
+      if (wp_on) {
+        wcur = S.wp_scratch + size_t((y & 1) ? 0 : (w + 2)) * kModWpEntry;
+        wprev = S.wp_scratch + size_t((y & 1) ? (w + 2) : 0) * kModWpEntry;
+        int4 n0 = make_int4(0, 0, 0, 0), n1 = make_int4(0, 0, 0, 0);
+        int32_t t0 = 0, t1 = 0;
+        if (y) {
+          n0 = *reinterpret_cast<const int4*>(wprev);
+          t0 = wprev[4];
+          if (w > 1) {
+            n1 = *reinterpret_cast<const int4*>(wprev + kModWpEntry);
+            t1 = wprev[kModWpEntry + 4];
+          } else {
+            n1 = n0;
+            t1 = t0;
+          }
+        }
+        wp.peN[0] = wp.peNW[0] = uint32_t(n0.x); wp.peN[1] = wp.peNW[1] = uint32_t(n0.y);
+        wp.peN[2] = wp.peNW[2] = uint32_t(n0.z); wp.peN[3] = wp.peNW[3] = uint32_t(n0.w);
+        wp.peNE[0] = uint32_t(n1.x); wp.peNE[1] = uint32_t(n1.y); wp.peNE[2] = uint32_t(n1.z); wp.peNE[3] = uint32_t(n1.w);
+        wp.teN = wp.teNW = t0;
+        wp.teNE = t1;
+        wp.teW = 0;
+      }
+      for (uint32_t x = 0; x < w; x++) {
+        // ---- loads for the next sample first (nothing below waits for them)
+        const int32_t aNEE = (y && x + 3 < w) ? pN[x + 3] : 0;
+        const int32_t aNN = (y > 1 && x + 1 < w) ? pNN[x + 1] : 0;
+        int4 a_pe = make_int4(0, 0, 0, 0);
+        int32_t a_te = 0;
+        const bool a_valid = x + 2 < w;
+        if (wp_on && y && a_valid) {
+          a_pe = *reinterpret_cast<const int4*>(wprev + size_t(x + 2) * kModWpEntry);
+          a_te = wprev[size_t(x + 2) * kModWpEntry + 4];
+        }
+        int32_t av[4] = {0, 0, 0, 0}, avt[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (uint32_t(j) < nrefs && x + 1 < w) {
+            av[j] = ref_data[j][size_t(y) * ref_stride[j] + x + 1];
+            avt[j] = y ? ref_data[j][size_t(y - 1) * ref_stride[j] + x + 1] : 0;
+          }
+        // ---- neighbours (encoding.cc / context_predict.h edge rules)
+        const int64_t left = x ? rW : (y ? rN : 0);
+        const int64_t top = y ? rN : left;
+        const int64_t topleft = (x && y) ? rNW : left;
+        const int64_t topright = (x + 1 < w && y) ? rNE : top;
+        const int64_t leftleft = x > 1 ? rWW : left;
+        const int64_t toptop = y > 1 ? rNN : top;
+        const int64_t toprightright = (x + 2 < w && y) ? rNEE : topright;
+        const int32_t p9 = int32_t(left + top - topleft);
+        lprops[3 * lanes] = int32_t(x);
+        lprops[4 * lanes] = int32_t(top > 0 ? top : -top);
+        lprops[5 * lanes] = int32_t(left > 0 ? left : -left);
+        lprops[6 * lanes] = int32_t(top);
+        lprops[7 * lanes] = int32_t(left);
+        lprops[8 * lanes] = int32_t(left - prev9);  // uses the previous pixel's property 9
+        lprops[9 * lanes] = p9;
+        prev9 = p9;
+        lprops[10 * lanes] = int32_t(left - topleft);
+        lprops[11 * lanes] = int32_t(topleft - top);
+        lprops[12 * lanes] = int32_t(top - topright);
+        lprops[13 * lanes] = int32_t(top - toptop);
+        lprops[14 * lanes] = int32_t(left - leftleft);
         int64_t wp_pred = 0;
-        if (S.uses_wp) wp_pred = ModWpPredict(wp, x, y, ch.w, top, left, topright, topleft, toptop, &props[15]);
-        for (uint32_t j = 0; j < nrefs; j++) {
-          const int32_t* rp = refs[j]->data + size_t(y) * refs[j]->stride;
-          const int32_t* rprev = refs[j]->data + size_t(y ? y - 1 : 0) * refs[j]->stride;
-          const int64_t v = rp[x];
-          const int64_t vl = x ? rp[x - 1] : 0;
-          const int64_t vt = y ? rprev[x] : vl;
-          const int64_t vtl = (x && y) ? rprev[x - 1] : vl;
-          const int64_t vp = ModClampedGradient(int32_t(vl), int32_t(vt), int32_t(vtl));
-          props[16 + 4 * j] = int32_t(ModAbs64(v));
-          props[17 + 4 * j] = int32_t(v);
-          props[18 + 4 * j] = int32_t(ModAbs64(v - vp));
-          props[19 + 4 * j] = int32_t(v - vp);
+        if (wp_on) {
+          int32_t max_err = 0;
+          wp_pred = ModWpPredict(wp, S.wp, top, left, topright, topleft, toptop, &max_err);
+          lprops[15 * lanes] = max_err;
         }
-        uint32_t pos = 0;
-        ModTreeNode nd = tree[0];
-        while (nd.property >= 0) {
-          pos = props[nd.property < kModMaxProps ? nd.property : 0] > nd.splitval ? nd.lchild : nd.rchild;
-          nd = tree[pos];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (uint32_t(j) < nrefs) {
+            const int64_t v = rv[j];
+            const int64_t vl = x ? rvl[j] : 0;
+            const int64_t vt = y ? rvt[j] : vl;
+            const int64_t vtl = (x && y) ? rvtl[j] : vl;
+            const int64_t vp = ModClampedGradient(int32_t(vl), int32_t(vt), int32_t(vtl));
+            lprops[(16 + 4 * j) * lanes] = int32_t(ModAbs64(v));
+            lprops[(17 + 4 * j) * lanes] = int32_t(v);
+            lprops[(18 + 4 * j) * lanes] = int32_t(ModAbs64(v - vp));
+            lprops[(19 + 4 * j) * lanes] = int32_t(v - vp);
+          }
+        // ---- MA tree walk
+        int4 nd = node(root);
+        while (nd.x >= 0) {
+          const uint32_t pos = lprops[uint32_t(nd.x) * lanes] > nd.y ? uint32_t(nd.z) : uint32_t(nd.w);
+          nd = node(pos);
         }
-        const int64_t guess = int64_t(nd.offset) + ModPredict(nd.predictor, left, top, toptop, topleft, topright, leftleft, toprightright, wp_pred);
-        const uint32_t v = ModRead(r, S.code->ctx_map[nd.lchild]);
-        const int64_t val = int64_t(int32_t((v >> 1) ^ (0u - (v & 1)))) * int64_t(nd.multiplier) + guess;
-        p[x] = int32_t(val);
-        if (S.uses_wp) ModWpUpdate(wp, p[x], x, y, ch.w);
+        const int64_t guess = int64_t(nd.y) + ModPredict(uint32_t(-1 - nd.x), left, top, toptop, topleft, topright, leftleft, toprightright, wp_pred);
+        const uint32_t v = ModRead(r, uint32_t(nd.z));
+        const int64_t val = int64_t(int32_t((v >> 1) ^ (0u - (v & 1)))) * int64_t(uint32_t(nd.w)) + guess;
+        const int32_t out = int32_t(val);
+        p[x] = out;
+        if (wp_on) ModWpUpdate(wp, out, wcur + size_t(x) * kModWpEntry, a_pe, a_te, a_valid);
+        // ---- slide the windows
+        rWW = rW;
+        rW = out;
+        rNW = rN;
+        rN = rNE;
+        rNE = rNEE;
+        rNEE = aNEE;
+        rNN = aNN;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          rvl[j] = rv[j];
+          rvtl[j] = rvt[j];
+          rv[j] = av[j];
+          rvt[j] = avt[j];
+        }
       }
     }
   }
@@ -384,9 +575,13 @@ struct ModRct {
   uint32_t stride[3];
   uint32_t w, h, type;
 };
-__global__ __launch_bounds__(256) void k_modular_rct(ModRct P) {  // rct.cc:97-147
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= P.w || y >= P.h) return;
+// Every transform kernel takes an array of parameter blocks, one per blockIdx.z: a launch does the same step of many
+// frames (their k-th inverse transform), grid x / y sized for the largest.
+__global__ __launch_bounds__(256) void k_modular_rct(const ModRct* ops) {  // rct.cc:97-147
+  const ModRct& P = ops[blockIdx.z];
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= P.w) return;
+  for (uint32_t y = blockIdx.y; y < P.h; y += gridDim.y) {
   const uint32_t perm = P.type / 7, custom = P.type % 7, second = custom >> 1, third = custom & 1;
   int32_t x0 = P.c[0][size_t(y) * P.stride[0] + x], x1 = P.c[1][size_t(y) * P.stride[1] + x], x2 = P.c[2][size_t(y) * P.stride[2] + x];
   int32_t o0, o1, o2;
@@ -408,6 +603,7 @@ __global__ __launch_bounds__(256) void k_modular_rct(ModRct P) {  // rct.cc:97-1
   P.c[perm % 3][size_t(y) * P.stride[perm % 3] + x] = o0;
   P.c[(perm + 1 + perm / 3) % 3][size_t(y) * P.stride[(perm + 1 + perm / 3) % 3] + x] = o1;
   P.c[(perm + 2 - perm / 3) % 3][size_t(y) * P.stride[(perm + 2 - perm / 3) % 3] + x] = o2;
+  }
 }
 
 __device__ __forceinline__ int64_t ModSmoothTendency(int64_t before, int64_t avg, int64_t next) {  // squeeze.h:54-77
@@ -431,24 +627,38 @@ struct ModUnsqueeze {
   uint32_t lines, na, nr;             // lines to do; averages / residuals per line
   uint32_t avg_line, avg_step, res_line, res_step, out_line, out_step;  // strides between lines / between samples of a line
 };
-// One thread per line (a row for a horizontal step, a column for a vertical one): squeeze.cc:128-330.
-__global__ __launch_bounds__(64) void k_modular_unsqueeze(ModUnsqueeze P) {
+// One thread per line (a row for a horizontal step, a column for a vertical one): squeeze.cc:128-330. A line is a serial
+// chain through the smooth-tendency term; its loads are issued four samples ahead of that chain.
+__global__ __launch_bounds__(64) void k_modular_unsqueeze(const ModUnsqueeze* ops) {
+  const ModUnsqueeze& P = ops[blockIdx.y];
   const uint32_t l = blockIdx.x * 64 + threadIdx.x;
   if (l >= P.lines) return;
   const int32_t* avg = P.avg + size_t(l) * P.avg_line;
   const int32_t* res = P.res + size_t(l) * P.res_line;
   int32_t* out = P.out + size_t(l) * P.out_line;
-  int64_t before = 0;
-  for (uint32_t i = 0; i < P.nr; i++) {
-    const int64_t a = avg[size_t(i) * P.avg_step], next = i + 1 < P.na ? avg[size_t(i + 1) * P.avg_step] : a;
-    if (i == 0) before = a;
-    const int64_t diff = int64_t(res[size_t(i) * P.res_step]) + ModSmoothTendency(before, a, next);
-    const int64_t first = a + diff / 2, second = first - diff;
-    out[size_t(2 * i) * P.out_step] = int32_t(first);
-    out[size_t(2 * i + 1) * P.out_step] = int32_t(second);
-    before = second;
+  const uint32_t nr = P.nr, na = P.na;
+  const size_t as = P.avg_step, rs = P.res_step, os = P.out_step;
+  int64_t a = nr ? avg[0] : 0, before = a;
+  for (uint32_t i = 0; i < nr; i += 4) {
+    int32_t an[4], rr[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      an[k] = i + k + 1 < na ? avg[size_t(i + k + 1) * as] : 0;
+      rr[k] = i + k < nr ? res[size_t(i + k) * rs] : 0;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      if (i + k >= nr) break;
+      const int64_t next = i + k + 1 < na ? int64_t(an[k]) : a;
+      const int64_t diff = int64_t(rr[k]) + ModSmoothTendency(before, a, next);
+      const int64_t first = a + diff / 2, second = first - diff;
+      out[size_t(2 * (i + k)) * os] = int32_t(first);
+      out[size_t(2 * (i + k) + 1) * os] = int32_t(second);
+      before = second;
+      a = next;
+    }
   }
-  if (P.na > P.nr) out[size_t(2 * P.nr) * P.out_step] = avg[size_t(P.na - 1) * P.avg_step];
+  if (na > nr) out[size_t(2 * nr) * os] = avg[size_t(na - 1) * as];
 }
 
 struct ModPalette {  // palette.cc:26-202, the form without delta entries and predictor (nb_deltas == 0, predictor 0)
@@ -493,14 +703,17 @@ __device__ __forceinline__ int32_t ModPaletteValue(const ModPalette& P, int inde
   }
   return P.palette[size_t(c) * P.palette_w + index];
 }
-__global__ __launch_bounds__(256) void k_modular_palette(ModPalette P) {
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= P.w || y >= P.h) return;
-  int index = P.index[size_t(y) * P.index_stride + x];
-  if (P.nb == 1) index = index < 0 ? 0 : (index >= int(P.palette_w) ? int(P.palette_w) - 1 : index);
-  int32_t v[4];
-  for (uint32_t c = 0; c < P.nb; c++) v[c] = ModPaletteValue(P, index, c);
-  for (uint32_t c = 0; c < P.nb; c++) P.out[c][size_t(y) * P.out_stride + x] = v[c];  // (out[0] may alias the index channel)
+__global__ __launch_bounds__(256) void k_modular_palette(const ModPalette* ops) {
+  const ModPalette& P = ops[blockIdx.z];
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= P.w) return;
+  for (uint32_t y = blockIdx.y; y < P.h; y += gridDim.y) {
+    int index = P.index[size_t(y) * P.index_stride + x];
+    if (P.nb == 1) index = index < 0 ? 0 : (index >= int(P.palette_w) ? int(P.palette_w) - 1 : index);
+    int32_t v[4];
+    for (uint32_t c = 0; c < P.nb; c++) v[c] = ModPaletteValue(P, index, c);
+    for (uint32_t c = 0; c < P.nb; c++) P.out[c][size_t(y) * P.out_stride + x] = v[c];  // (out[0] may alias the index channel)
+  }
 }
 
 // ---- integer channels -> interleaved output samples (non-XYB Modular frames: dec_modular.cc:564-793 converts the
@@ -511,9 +724,11 @@ struct ModOutput {
   uint32_t num_color, has_alpha, bits, alpha_bits, w, h;
   PixelOut po;           // po.nc: 1 / 2 (grey, grey + alpha) or 3 / 4
 };
-__global__ __launch_bounds__(256) void k_modular_output(ModOutput P) {
-  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= P.w || y >= P.h) return;
+__global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
+  const ModOutput& P = ops[blockIdx.z];
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= P.w) return;
+  for (uint32_t y = blockIdx.y; y < P.h; y += gridDim.y) {
   const float mul = 1.0f / float((uint64_t(1) << P.bits) - 1);
   float v[4];
   for (uint32_t c = 0; c < P.num_color; c++) v[c] = float(P.ch[c][size_t(y) * P.stride[c] + x]) * mul;
@@ -543,6 +758,7 @@ __global__ __launch_bounds__(256) void k_modular_output(ModOutput P) {
       if (P.po.swap) u = __builtin_bswap32(u);
       static_cast<uint32_t*>(P.po.dst)[base + c] = u;
     }
+  }
   }
 }
 

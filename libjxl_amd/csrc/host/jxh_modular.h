@@ -208,19 +208,73 @@ static inline int64_t PredictOne(uint32_t p, int64_t left, int64_t top, int64_t 
   }
 }
 
-// Decodes one channel (generic MA-tree path).
+// A channel whose part of the tree is one leaf (no decision left once the channel index and the stream id are known:
+// what simple encoders and libjxl's fast efforts emit): no properties, one histogram, the predictor a compile-time
+// constant for the common ones (P < 0: `leaf.predictor` at run time).
+template <int P>
+static inline void DecodeLeafChannel(SymbolReader& rd, size_t cluster, const TreeNode& leaf, MChannel& c) {
+  const ptrdiff_t stride = ptrdiff_t(c.w);
+  const uint32_t predictor = P < 0 ? leaf.predictor : uint32_t(P);
+  const int64_t offset = leaf.offset, mul = int64_t(leaf.multiplier);
+  for (size_t y = 0; y < c.h; y++) {
+    int32_t* p = c.Row(y);
+    for (size_t x = 0; x < c.w; x++) {
+      const int32_t* pp = p + x;
+      const int64_t left = x ? pp[-1] : (y ? pp[-stride] : 0);
+      const int64_t top = y ? pp[-stride] : left;
+      const int64_t topleft = (x && y) ? pp[-1 - stride] : left;
+      const int64_t topright = (x + 1 < c.w && y) ? pp[1 - stride] : top;
+      const int64_t leftleft = x > 1 ? pp[-2] : left;
+      const int64_t toptop = y > 1 ? pp[-2 * stride] : top;
+      const int64_t toprightright = (x + 2 < c.w && y) ? pp[2 - stride] : topright;
+      const int64_t guess = offset + PredictOne(predictor, left, top, toptop, topleft, topright, leftleft, toprightright, 0);
+      const uint32_t v = rd.ReadClustered(cluster);
+      p[x] = int32_t(int64_t(UnpackSigned(v)) * mul + guess);
+    }
+  }
+}
+
+// Decodes one channel (encoding.cc:148-506).
 static inline void DecodeChannel(BitReader& br, SymbolReader& rd, const EntropyCode& code, const MTree& tree,
                                  const WpHeader& wph, int chan, int stream_id, MImage* img) {
   (void)br;
   MChannel& c = img->ch[chan];
   if (c.w == 0 || c.h == 0) return;
-  // number of properties needed
+  // decisions on the channel index and the stream id are the same for every sample of the channel: taken once
+  size_t root = 0;
+  while (tree[root].property == 0 || tree[root].property == 1) {
+    const TreeNode& n = tree[root];
+    root = (n.property == 0 ? chan : stream_id) > n.splitval ? n.lchild : n.rchild;
+  }
+  // what the rest of the tree looks at
   int max_prop = 15;
   bool uses_wp = false;
-  for (const auto& n : tree) {
-    if (n.property >= 0) max_prop = std::max(max_prop, n.property);
-    if (n.property == 15) uses_wp = true;
-    if (n.property < 0 && n.predictor == 6) uses_wp = true;
+  {
+    std::vector<uint32_t> todo{uint32_t(root)};
+    while (!todo.empty()) {
+      const TreeNode& n = tree[todo.back()];
+      todo.pop_back();
+      if (n.property >= 0) {
+        max_prop = std::max(max_prop, n.property);
+        if (n.property == 15) uses_wp = true;
+        todo.push_back(n.lchild);
+        todo.push_back(n.rchild);
+      } else if (n.predictor == 6) {
+        uses_wp = true;
+      }
+    }
+  }
+  if (tree[root].property < 0 && !uses_wp) {
+    const TreeNode& leaf = tree[root];
+    const size_t cluster = code.ctx_map[leaf.lchild];
+    switch (leaf.predictor) {
+      case 0: DecodeLeafChannel<0>(rd, cluster, leaf, c); break;
+      case 1: DecodeLeafChannel<1>(rd, cluster, leaf, c); break;
+      case 2: DecodeLeafChannel<2>(rd, cluster, leaf, c); break;
+      case 5: DecodeLeafChannel<5>(rd, cluster, leaf, c); break;
+      default: DecodeLeafChannel<-1>(rd, cluster, leaf, c); break;
+    }
+    return;
   }
   size_t num_props = 16;
   if (max_prop >= 16) num_props = 16 + DivCeil(size_t(max_prop - 16 + 1), 4) * 4;
@@ -232,7 +286,7 @@ static inline void DecodeChannel(BitReader& br, SymbolReader& rd, const EntropyC
     refs.push_back(j);
   }
   std::vector<int32_t> props(num_props, 0);
-  WpState wp(wph, c.w);
+  WpState wp(wph, uses_wp ? c.w : 0);  // (two rows of state per sub-predictor: only when the tree asks for it)
   const ptrdiff_t stride = ptrdiff_t(c.w);
   for (size_t y = 0; y < c.h; y++) {
     int32_t* p = c.Row(y);
@@ -279,7 +333,7 @@ static inline void DecodeChannel(BitReader& br, SymbolReader& rd, const EntropyC
         props[off++] = int32_t(v - vp);
       }
       // tree walk
-      size_t pos = 0;
+      size_t pos = root;
       while (tree[pos].property >= 0) {
         const TreeNode& n = tree[pos];
         pos = props[n.property] > n.splitval ? n.lchild : n.rchild;
