@@ -579,14 +579,14 @@ def main():
         achieved = alg[names[dom]] / (stage_ms[dom] * 1e-3) / 1e9
         frames_per_launch = args.batch if dom == 0 else 1
         # HBM traffic of the dominant kernel: PMC counters from separate rocprofv3 passes of this command (committed
-        # summary; FETCH_SIZE + WRITE_SIZE per dispatch), only quoted when taken at the same frames per launch
+        # summary; 2 x FETCH_SIZE + WRITE_SIZE per dispatch), only quoted when taken at the same frames per launch
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
             key = ["k_entropy_lanes", "k_idct_fast<short, 4, 4>", "k_filter_rows2"][dom]
             for name, v in pmc.items():
                 if key in name and pmc.get("_frames_per_launch") == args.batch:
-                    traffic = int((v["fetch_kib_per_dispatch"] + v["write_kib_per_dispatch"]) * 1024)
+                    traffic = int(v["hbm_kib_per_dispatch"] * 1024)  # FETCH_SIZE doubled (gfx950: the guide's correction) + WRITE_SIZE
         except (OSError, ValueError, KeyError, TypeError):
             pass
         out = {
