@@ -447,6 +447,13 @@ def main():
     data, frame = datas[0], frames[0]
     info = dict(frame.info)
     info["ac_bytes"] = sum(f.info["ac_bytes"] for f in frames) / float(ndistinct)  # mean over the distinct frames
+    # LDS of one entropy workgroup (one frame: jxl_hip_entropy_lanes.h LanesLdsLayout): alias tables, context map,
+    # nnz / config tables, 64 lanes of rings and line buffers; a CU has 160 KB
+    tables = []
+    for f in frames:
+        lds = (f.info["num_clusters"] << f.info["log_alpha"]) * 8 + ((f.info["ctx_map_size"] + 15) & ~15) + 128 + 512 + 64 * 200
+        tables.append({"clusters": f.info["num_clusters"], "log_alpha": f.info["log_alpha"], "lds_bytes": lds,
+                       "workgroups_per_cu": (160 * 1024) // lds})
     # Two sets of `batch` frames: while one set is in the (latency-bound, serial per section) entropy stage, the other
     # set's coefficients go through the (bandwidth-bound) transform + filter + colour stages. Every step runs every
     # stage once over `batch` frames, so a step completes `batch` frames; a frame's latency is two steps.
@@ -604,7 +611,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
                 xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
-                "frames_per_step_per_gpu": args.batch, "distinct_frames": ndistinct, "pipeline": ("%d frame sets, each on its own stream (entropy -> transform -> filter+colour every step), free-running" % nsets) if free_running else ("2 frame sets, 3 concurrent launches: entropy(A) | transform(B) | filter+colour(A, previous step)" if three else
+                "frames_per_step_per_gpu": args.batch, "distinct_frames": ndistinct, "entropy_tables": tables, "pipeline": ("%d frame sets, each on its own stream (entropy -> transform -> filter+colour every step), free-running" % nsets) if free_running else ("2 frame sets, 3 concurrent launches: entropy(A) | transform(B) | filter+colour(A, previous step)" if three else
                              "2 frame sets: entropy(set A) overlaps transform+filter(set B)") if nsets == 2 else
                 ("1 frame set: entropy and transform back to back, filter+colour of step k on a second stream under the entropy launch of step k+1" if chain else "none"),
                 "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes and not three and not free_running else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else

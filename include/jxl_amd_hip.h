@@ -126,14 +126,21 @@ typedef struct JxlHipFrameDesc {
    * upsampling_kernel the factor * factor 5x5 kernels, [factor * oy + ox][5 * (iy + 2) + ix + 2]. */
   uint32_t upsampling, out_xsize, out_ysize;
   const float* upsampling_kernel;
+  /* Noise synthesis (frame flag kNoise; dec_noise.cc:43-164, render_pipeline/stage_noise.cc:64-310): has_noise != 0 adds
+   * noise to the filtered X, Y, B before the colour conversion, strength from the pixel's intensity through the 8-point
+   * LUT; the generators are seeded with the frame's visible / non-visible index and each 256x256 group's origin. Only
+   * for frames that are not upsampled. */
+  uint32_t has_noise;
+  float noise_lut[8];
+  uint32_t noise_frame_index[2];
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);
 int jxlhip_ctx_create(int device, JxlHipContext** ctx);
 void jxlhip_ctx_destroy(JxlHipContext* ctx);
 
-/* Copies every table and the AC sections of the frame to the device (asynchronously on the context's stream;
- * the host arrays may be released after jxlhip_sync). Re-uses device buffers across frames when they fit. */
+/* Copies every table and the AC sections of the frame to the device; everything the call keeps has been copied when it
+ * returns (the host arrays may be released). Re-uses device buffers across frames when they fit. */
 int jxlhip_frame_upload(JxlHipContext* ctx, const JxlHipFrameDesc* desc);
 
 /* The three stages of the hot path. Inputs must be resident (jxlhip_frame_upload). */

@@ -227,6 +227,9 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.linear_output = P.ih.linear_tf;
   d.band_group_row_begin = group_row_begin;
   d.band_group_row_end = group_row_end;
+  d.has_noise = P.has_noise ? 1 : 0;
+  memcpy(d.noise_lut, P.noise_lut, sizeof(d.noise_lut));
+  d.noise_frame_index[0] = d.noise_frame_index[1] = 0;  // the first (and only) frame of the image
   std::vector<float> ups_kernel;
   if (P.fh.upsampling != 1) {
     UpsamplingKernels(P.fh.upsampling, &ups_kernel);

@@ -757,7 +757,7 @@ struct Params {
   int32_t custom_lf;       // 1 = non-default loop filter header: Gaborish weights, EPF sharpness LUT, channel scales and
                            //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
   int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS (libjxl's fastest efforts), bit 1 = LZ77
-  int32_t reserved[1];
+  int32_t noise;           // > 0: frame flag kNoise with the strength LUT point i = min(1023, noise + 40 * i) / 1024
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -1015,6 +1015,8 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   // ---- sections
   auto write_dc_global = [&](BitWriter& bw) {
+    if (p.noise > 0)  // NoiseParams: eight 10-bit LUT points (dec_noise.cc:154-164)
+      for (int i = 0; i < 8; i++) bw.Write(10, uint32_t(std::min(1023, p.noise + 40 * i)));
     if (!p.custom_lf) {
       bw.Write(1, 1);  // DC dequant all_default
     } else {
@@ -1179,6 +1181,9 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(1, 0);  // VarDCT
   if (f.flags == 0) {
     bw.Write(2, 0);
+  } else if (f.flags <= 16) {  // U64 selector 1: 1 + 4 bits
+    bw.Write(2, 1);
+    bw.Write(4, f.flags - 1);
   } else {  // U64 selector 2: 17 + 8 bits
     bw.Write(2, 2);
     bw.Write(8, f.flags - 17);
@@ -1301,7 +1306,7 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     }
   }
   f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
-  f.flags = p.skip_dc_smoothing ? 128 : 0;
+  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0);
   f.acs.assign(f.xb * f.yb, 0xFF);
   f.qf.assign(f.xb * f.yb, 0);
   f.sharp.assign(f.xb * f.yb, 4);
@@ -1492,7 +1497,7 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
   f.quant_dc = 8 + rng.Below(16);
   f.gab = p.gab < 0 ? 1 : p.gab;
   f.epf_iters = p.epf_iters < 0 ? 1 : p.epf_iters;
-  f.flags = p.skip_dc_smoothing ? 128 : 0;
+  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0);
   f.acs.assign(f.xb * f.yb, 0xFF);
   f.qf.assign(f.xb * f.yb, 0);
   f.sharp.assign(f.xb * f.yb, 0);
@@ -2063,7 +2068,7 @@ struct JxlEncParams {
   int32_t custom_lf;       // 1 = non-default loop filter header: Gaborish weights, EPF sharpness LUT, channel scales and
                            //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
   int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS, bit 1 = LZ77
-  int32_t reserved[1];
+  int32_t noise;           // > 0: noise synthesis, see jxe::Params
 };
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {

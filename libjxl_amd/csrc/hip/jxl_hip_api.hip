@@ -177,6 +177,12 @@ struct JxlHipContext {
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
   // output pixel format (jxlhip_set_output_format; JxlDataType numbering): RGB8 by default
   uint32_t out_type = 2, out_nc = 3, out_bits = 8, out_swap = 0;
+  // noise synthesis (JxlHipFrameDesc::has_noise): raw random planes [3][ys][xs], LUT, seeds, base colour correlation
+  Buf noise;
+  bool has_noise = false;
+  float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t noise_seed[2] = {0, 0};
+  float noise_ytox = 0.0f, noise_ytob = 1.0f;
   Buf alpha;                // f32 plane of the image size (jxlhip_set_alpha), used by 2- and 4-channel output
   bool have_alpha = false;
   bool color_out = false;   // the pixels come from k_color_out / k_upsample_color's generic writer (set at upload)
@@ -331,7 +337,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
-                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob};
+                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise};
   for (Buf* b : all) b->Free();
   for (auto& pb : c->pass_bufs) {
     pb.ctx_map.Free();
@@ -718,6 +724,18 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   // (k_color_out on the filtered planes, or k_upsample_color)
   c->color_out = !OutIsRgb8(c) && !(OutIsRgbF32(c) && c->ups == 1 && (c->gab && c->epf_iters == 1) &&
                                     !EnvInt("JXLHIP_FILTER_TILES", 0) && !EnvInt("JXLHIP_FILTER_ROWS1", 0));
+  // noise is added to the filtered planes between the filter launch and the colour conversion
+  c->has_noise = d->has_noise != 0;
+  if (c->has_noise) {
+    if (c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
+    c->color_out = true;
+    memcpy(c->noise_lut, d->noise_lut, sizeof(c->noise_lut));
+    c->noise_seed[0] = d->noise_frame_index[0];
+    c->noise_seed[1] = d->noise_frame_index[1];
+    c->noise_ytox = d->base_corr_x;
+    c->noise_ytob = d->base_corr_b;
+    if ((r = c->noise.Ensure(size_t(c->xs) * c->ys * 3 * 4))) return r;
+  }
   if (c->have_alpha && c->alpha.cap < size_t(c->oxs) * c->oys * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
   if ((c->keep_filtered || c->ups != 1 || c->color_out) && (r = c->plane[1].Ensure(plane_bytes))) return r;
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
@@ -2118,6 +2136,30 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
       default: r = LaunchFused<true, 3>(c0, g); break;
     }
     if (r) return r;
+  }
+  for (size_t i = 0; i < n; i++) {
+    const JxlHipContext* c = ctxs[i];
+    if (!c->has_noise) continue;
+    jxlhip::NoiseParams np;
+    memset(&np, 0, sizeof(np));
+    np.raw = c->noise.as<float>();
+    np.planes = c->plane[1].as<float>();
+    np.xsize = c->xs;
+    np.ysize = c->ys;
+    np.xp = c->xp;
+    np.yp = c->yp;
+    np.xgroups = c->xg;
+    np.ngroups = c->ng;
+    np.seed[0] = c->noise_seed[0];
+    np.seed[1] = c->noise_seed[1];
+    memcpy(np.lut, c->noise_lut, sizeof(np.lut));
+    np.ytox = c->noise_ytox;
+    np.ytob = c->noise_ytob;
+    np.y_begin = c->band_y0;
+    np.y_end = c->band_y1;
+    hipLaunchKernelGGL(jxlhip::k_noise_random, dim3((c->ng * 8 + 63) / 64), dim3(64), 0, ls, np);
+    hipLaunchKernelGGL(jxlhip::k_noise_add, dim3((c->xs + 63) / 64, (c->band_y1 - c->band_y0 + 3) / 4), dim3(256), 0, ls, np);
+    HIP_TRY(hipGetLastError());
   }
   for (size_t i = 0; i < n; i++) {
     const JxlHipContext* c = ctxs[i];

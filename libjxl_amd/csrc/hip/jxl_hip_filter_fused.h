@@ -871,5 +871,104 @@ __global__ __launch_bounds__(kFusedThreads) void k_filter_fused(const FusedFilte
   }
 }
 
+// ---- noise synthesis (frame flag kNoise)
+// Replaces lib/jxl/dec_noise.cc:43-110 (Random3Planes: one Xorshift128+ generator of 8 lanes per 256x256 group of the
+// image, seeded by the frame indices and the group origin, fills the group's three planes one after the other, 16 floats
+// in [1, 2) per step, a last partial step per row), xorshift128plus-inl.h:30-96, and render_pipeline/stage_noise.cc:
+// 262-310 (5x5 high-pass of the random planes, mirrored at the image edges) + :64-260 (strength from the pixel's
+// intensity through the 8-point LUT; the noise goes to X, Y, B with the base colour correlation).
+struct NoiseParams {
+  float* raw;       // [3][ysize][xsize] random planes (k_noise_random -> k_noise_add)
+  float* planes;    // filtered X, Y, B: [3][yp][xp] (modified in place)
+  uint32_t xsize, ysize, xp, yp, xgroups, ngroups;
+  uint32_t seed[2];
+  float lut[8];
+  float ytox, ytob;
+  uint32_t y_begin, y_end;  // pixel rows to produce (band decode)
+};
+__device__ __forceinline__ uint64_t NoiseSplitMix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// One thread per (group, generator lane): the generator is serial over the group's rows and planes; lane i of a step
+// yields floats 2i and 2i + 1 of the step's 16.
+__global__ __launch_bounds__(64) void k_noise_random(NoiseParams P) {
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t g = t >> 3, lane = t & 7;
+  if (g >= P.ngroups) return;
+  const uint32_t x0 = (g % P.xgroups) * 256, y0 = (g / P.xgroups) * 256;
+  uint64_t s0 = NoiseSplitMix64(((uint64_t(P.seed[0]) << 32) + P.seed[1]) + 0x9E3779B97F4A7C15ull);
+  uint64_t s1 = NoiseSplitMix64(((uint64_t(x0) << 32) + y0) + 0x9E3779B97F4A7C15ull);
+  for (uint32_t i = 0; i < lane; i++) {
+    s0 = NoiseSplitMix64(s0);
+    s1 = NoiseSplitMix64(s1);
+  }
+  const uint32_t w = min(256u, P.xsize - x0), h = min(256u, P.ysize - y0);
+  const uint32_t steps = (w > 16 ? (w - 16 + 15) / 16 : 0) + 1;  // whole steps while x + 16 < w, then one for the rest
+  for (uint32_t c = 0; c < 3; c++)
+    for (uint32_t y = 0; y < h; y++) {
+      float* row = P.raw + (size_t(c) * P.ysize + y0 + y) * P.xsize + x0;
+      for (uint32_t b = 0; b < steps; b++) {
+        uint64_t a = s0;
+        const uint64_t bb = s1;
+        const uint64_t bits = a + bb;
+        s0 = bb;
+        a ^= a << 23;
+        a ^= bb ^ (a >> 18) ^ (bb >> 5);
+        s1 = a;
+        const uint32_t x = b * 16 + 2 * lane;
+        if (x < w) row[x] = __uint_as_float((uint32_t(bits) >> 9) | 0x3F800000u);
+        if (x + 1 < w) row[x + 1] = __uint_as_float((uint32_t(bits >> 32) >> 9) | 0x3F800000u);
+      }
+    }
+}
+__device__ __forceinline__ uint32_t NoiseMirror(int v, int n) {
+  while (v < 0 || v >= n) v = v < 0 ? -v - 1 : 2 * n - 1 - v;
+  return uint32_t(v);
+}
+__device__ __forceinline__ float NoiseStrength(const float* lut, float x) {
+  const float scaled = fmaxf(0.0f, x * 6.0f);
+  float fl = floorf(scaled), frac = scaled - fl;
+  if (scaled >= 7.0f) {
+    fl = 6.0f;
+    frac = 1.0f;
+  }
+  const int i = int(fl);
+  const float lo = i == 0 ? lut[0] : i == 1 ? lut[1] : i == 2 ? lut[2] : i == 3 ? lut[3] : i == 4 ? lut[4] : i == 5 ? lut[5] : lut[6];
+  const float hi = i == 0 ? lut[1] : i == 1 ? lut[2] : i == 2 ? lut[3] : i == 3 ? lut[4] : i == 4 ? lut[5] : i == 5 ? lut[6] : lut[7];
+  return __builtin_amdgcn_fmed3f((hi - lo) * frac + lo, 0.0f, 1.0f);
+}
+__global__ __launch_bounds__(256) void k_noise_add(NoiseParams P) {
+  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = P.y_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.xsize || y >= P.y_end) return;
+  float rnd[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float* pl = P.raw + size_t(c) * P.ysize * P.xsize;
+    float others = 0.0f, centre = 0.0f;
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++) {
+      const float* row = pl + size_t(NoiseMirror(int(y) + dy, int(P.ysize))) * P.xsize;
+#pragma unroll
+      for (int dx = -2; dx <= 2; dx++) {
+        const float v = row[NoiseMirror(int(x) + dx, int(P.xsize))];
+        if (dx == 0 && dy == 0) centre = v;
+        else others += v;
+      }
+    }
+    rnd[c] = (others * 0.16f + centre * -3.84f) * 0.22f;
+  }
+  const size_t plane = size_t(P.xp) * P.yp, i = size_t(y) * P.xp + x;
+  const float vx = P.planes[i], vy = P.planes[plane + i], vb = P.planes[2 * plane + i];
+  const float str_g = NoiseStrength(P.lut, (vy - vx) * 0.5f), str_r = NoiseStrength(P.lut, (vy + vx) * 0.5f);
+  const float red = str_r * (0.0078125f * rnd[0] + 0.9921875f * rnd[2]);
+  const float green = str_g * (0.0078125f * rnd[1] + 0.9921875f * rnd[2]);
+  const float rg = red + green;
+  P.planes[i] = (P.ytox * rg + (red - green)) + vx;
+  P.planes[plane + i] = vy + rg;
+  P.planes[2 * plane + i] = P.ytob * rg + vb;
+}
+
 }  // namespace jxlhip
 #endif  // JXL_HIP_FILTER_FUSED_H_

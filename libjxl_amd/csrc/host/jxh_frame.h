@@ -74,6 +74,8 @@ struct FramePlan {
   size_t num_histograms = 1;
   std::vector<PassTables> passes;
   // AC sections: for pass p, group g: index p * num_groups + g
+  float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // noise synthesis (frame flag kNoise): strength LUT
+  bool has_noise = false;
   std::vector<uint64_t> section_offset;  // byte offset inside the codestream buffer handed to ParseFrame
   std::vector<uint32_t> section_size;
   // single-section frames: AC data starts mid-byte inside the one section
@@ -158,8 +160,9 @@ class FrameParser {
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(ih.extra.empty() || fh.upsampling == 1, "unsupported: extra channels of upsampled frames");
-    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
-              "unsupported: patches/splines/noise/DC frames");
+    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kUseDcFrame)),
+              "unsupported: patches/splines/DC frames");
+    JXH_CHECK(!(fh.flags & FrameHeader::kNoise) || fh.upsampling == 1, "unsupported: noise on upsampled frames");
     P.dim = MakeFrameDim(fh);
     const FrameDim& d = P.dim;
     const size_t np = fh.num_passes;
@@ -247,6 +250,11 @@ class FrameParser {
 
  private:
   void DcGlobal(BitReader& br, FramePlan* P) {
+    if (P->fh.flags & FrameHeader::kNoise) {  // dec_frame.cc:294-296, dec_noise.cc:154-164: eight 10-bit LUT points
+      for (float& v : P->noise_lut) v = float(br.Read(10)) / 1024.0f;
+      // (the reference skips the stage when every point is below 1e-3: noise.h:35-40)
+      for (float v : P->noise_lut) P->has_noise = P->has_noise || std::fabs(v) > 1e-3f;
+    }
     if (!br.ReadBool()) {
       for (int c = 0; c < 3; c++) {
         dq_.dc_quant[c] = ReadF16(br) * (1.0f / 128.0f);

@@ -70,7 +70,10 @@ class Decoded:
         p = lib().jxlo_buffer(self._h, name.encode(), ctypes.byref(n))
         if not p or not n.value:
             return None
-        return np.frombuffer(ctypes.string_at(p, n.value), dtype=_DTYPES[name]).copy()
+        # (a view of the oracle's memory, then one copy: ctypes.string_at cannot make objects of 2 GiB and more, and the
+        # coefficients of a 16384x16384 frame are 3 GiB)
+        raw = (ctypes.c_uint8 * n.value).from_address(p)
+        return np.frombuffer(raw, dtype=_DTYPES[name]).copy()
 
     @property
     def rgb8(self):

@@ -64,6 +64,8 @@ struct FrameState {
   uint32_t color_factor = 84;
   float base_corr_x = 0.0f, base_corr_b = 1.0f;
   int32_t ytox_dc = 0, ytob_dc = 0;
+  float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool has_noise = false;
   MGlobal mglobal;
   MImage full;  // global modular image (extra channels, or colour for Modular frames)
   size_t modular_color_channels = 0;
@@ -78,9 +80,12 @@ struct FrameState {
 
 static void DecodeDcGlobal(BitReader& br, FrameState* s) {
   const FrameHeader& fh = s->fh;
-  JXLO_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kNoise)),
-             "unsupported: patches/splines/noise");
+  JXLO_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines)), "unsupported: patches/splines");
   JXLO_CHECK(!(fh.flags & FrameHeader::kUseDcFrame), "unsupported: DC frames");
+  if (fh.flags & FrameHeader::kNoise) {  // dec_frame.cc:294-296, dec_noise.cc:154-164: eight 10-bit LUT points
+    for (float& v : s->noise_lut) v = float(br.Read(10)) / 1024.0f;
+    s->has_noise = true;
+  }
   // DequantMatrices::DecodeDC
   if (!br.ReadBool()) {
     for (int c = 0; c < 3; c++) {
@@ -605,6 +610,20 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       Upsample(crop, fh.upsampling, xs, ys, &up);
       cur = &up;
     }
+    Planes3 noisy;
+    if (s->has_noise) {  // (the reference skips the stage when every LUT point is below 1e-3: noise.h:35-40)
+      bool any = false;
+      for (float v : s->noise_lut) any = any || std::fabs(v) > 1e-3f;
+      if (any) {
+        noisy = *cur;
+        AddNoise(&noisy, xs, ys, s->noise_lut, s->base_corr_x, s->base_corr_b, 0, 0);
+        cur = &noisy;
+        if (want_dumps && fh.upsampling == 1) {  // (the dump then holds what the colour conversion reads)
+          for (int c = 0; c < 3; c++)
+            memcpy(out->xyb_filtered.data() + c * d.xsize_padded * d.ysize, cur->p[c].data(), d.xsize_padded * d.ysize * sizeof(float));
+        }
+      }
+    }
     OpsinParams op = MakeOpsinParams(ih);
 #pragma omp parallel for schedule(static)
     for (size_t y = 0; y < ys; y++)
@@ -755,6 +774,13 @@ const void* jxlo_buffer(JxloHandle* h, const char* name, size_t* nbytes) {
 #undef JXLO_BUF
   *nbytes = 0;
   return nullptr;
+}
+
+// Known-answer hook for the noise generator: `vectors` steps of the single-seed generator, 8 values each
+// (lib/jxl/xorshift128plus_test.cc:60-257 holds the expected values for seed 12345).
+void jxlo_xorshift_fill(uint64_t seed, uint64_t* out, size_t vectors) {
+  jxlo::Xorshift128Plus rng(seed);
+  for (size_t i = 0; i < vectors; i++) rng.Fill(out + 8 * i);
 }
 
 }  // extern "C"

@@ -11,6 +11,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "jxlo_headers.h"
@@ -181,6 +183,118 @@ static inline void Upsample(const Planes3& in, uint32_t N, size_t out_xs, size_t
             out->p[c][Y * out_xs + X] = r;
           }
       }
+}
+
+// ---- noise synthesis (frame flag kNoise): lib/jxl/xorshift128plus-inl.h:30-96 (generator), dec_noise.cc:43-110 (one
+// generator per 256x256 group of the image, seeded by the frame indices and the group origin, fills three planes one after
+// the other, 16 floats in [1, 2) per step), render_pipeline/stage_noise.cc:262-310 (5x5 high-pass) and :64-260 (strength
+// from the pixel's intensity through the 8-point LUT, added to X, Y, B), dec_cache.cc:216-219 (after upsampling).
+struct Xorshift128Plus {
+  uint64_t s0[8], s1[8];
+  static uint64_t SplitMix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  explicit Xorshift128Plus(uint64_t seed) {
+    s0[0] = SplitMix64(seed + 0x9E3779B97F4A7C15ull);
+    s1[0] = SplitMix64(s0[0]);
+    for (int i = 1; i < 8; i++) {
+      s0[i] = SplitMix64(s1[i - 1]);
+      s1[i] = SplitMix64(s0[i]);
+    }
+  }
+  Xorshift128Plus(uint32_t seed1, uint32_t seed2, uint32_t seed3, uint32_t seed4) {
+    s0[0] = SplitMix64(((uint64_t(seed1) << 32) + seed2) + 0x9E3779B97F4A7C15ull);
+    s1[0] = SplitMix64(((uint64_t(seed3) << 32) + seed4) + 0x9E3779B97F4A7C15ull);
+    for (int i = 1; i < 8; i++) {
+      s0[i] = SplitMix64(s0[i - 1]);
+      s1[i] = SplitMix64(s1[i - 1]);
+    }
+  }
+  void Fill(uint64_t* bits) {
+    for (int i = 0; i < 8; i++) {
+      uint64_t a = s0[i];
+      const uint64_t b = s1[i];
+      bits[i] = a + b;
+      s0[i] = b;
+      a ^= a << 23;
+      a ^= b ^ (a >> 18) ^ (b >> 5);
+      s1[i] = a;
+    }
+  }
+};
+
+// Fills the three image-sized planes (stride xs) with the raw random values.
+static inline void NoiseRandom(size_t xs, size_t ys, uint32_t visible_frame_index, uint32_t nonvisible_frame_index,
+                               std::vector<float> out[3]) {
+  for (int c = 0; c < 3; c++) out[c].assign(xs * ys, 0.0f);
+  const size_t kGroup = 256;
+  for (size_t y0 = 0; y0 < ys; y0 += kGroup)
+    for (size_t x0 = 0; x0 < xs; x0 += kGroup) {
+      Xorshift128Plus rng(visible_frame_index, nonvisible_frame_index, uint32_t(x0), uint32_t(y0));
+      const size_t w = std::min(kGroup, xs - x0), h = std::min(kGroup, ys - y0);
+      for (int c = 0; c < 3; c++)
+        for (size_t y = 0; y < h; y++) {
+          float* row = out[c].data() + (y0 + y) * xs + x0;
+          uint64_t batch[8];
+          auto put = [&](size_t x) {  // the 16 floats of `batch` at row[x ..], as far as the row goes
+            for (size_t i = 0; i < 16 && x + i < w; i++) {
+              const uint32_t bits = uint32_t(batch[i >> 1] >> (32 * (i & 1)));
+              const uint32_t f = (bits >> 9) | 0x3F800000u;
+              memcpy(&row[x + i], &f, 4);
+            }
+          };
+          size_t x = 0;
+          for (; x + 16 < w; x += 16) {
+            rng.Fill(batch);
+            put(x);
+          }
+          rng.Fill(batch);
+          put(x);
+        }
+    }
+}
+
+static inline float NoiseStrength(const float* lut, float x) {
+  float scaled = std::max(0.0f, x * 6.0f);
+  float fl = std::floor(scaled), frac = scaled - fl;
+  if (scaled >= 7.0f) {
+    fl = 6.0f;
+    frac = 1.0f;
+  }
+  const int i = int(fl);
+  const float v = (lut[i + 1] - lut[i]) * frac + lut[i];
+  return std::min(std::max(v, 0.0f), 1.0f);
+}
+
+// Adds the noise to the X, Y, B planes `img` (image size xs x ys inside).
+static inline void AddNoise(Planes3* img, size_t xs, size_t ys, const float* lut, float ytox, float ytob, uint32_t visible_frame_index,
+                            uint32_t nonvisible_frame_index) {
+  std::vector<float> raw[3];
+  NoiseRandom(xs, ys, visible_frame_index, nonvisible_frame_index, raw);
+  auto at = [&](int c, int64_t x, int64_t y) { return raw[c][size_t(Mirror(y, int64_t(ys))) * xs + size_t(Mirror(x, int64_t(xs)))]; };
+#pragma omp parallel for schedule(static)
+  for (size_t y = 0; y < ys; y++)
+    for (size_t x = 0; x < xs; x++) {
+      float rnd[3];
+      for (int c = 0; c < 3; c++) {
+        float others = 0.0f;
+        for (int dy = -2; dy <= 2; dy++)
+          for (int dx = -2; dx <= 2; dx++)
+            if (dx || dy) others += at(c, int64_t(x) + dx, int64_t(y) + dy);
+        rnd[c] = (others * 0.16f + at(c, int64_t(x), int64_t(y)) * -3.84f) * 0.22f;
+      }
+      const size_t i = y * img->stride + x;
+      const float vx = img->p[0][i], vy = img->p[1][i];
+      const float str_g = NoiseStrength(lut, (vy - vx) * 0.5f), str_r = NoiseStrength(lut, (vy + vx) * 0.5f);
+      const float red = str_r * (0.0078125f * rnd[0] + 0.9921875f * rnd[2]);
+      const float green = str_g * (0.0078125f * rnd[1] + 0.9921875f * rnd[2]);
+      const float rg = red + green;
+      img->p[0][i] = (ytox * rg + (red - green)) + vx;
+      img->p[1][i] = vy + rg;
+      img->p[2][i] = ytob * rg + img->p[2][i];
+    }
 }
 
 static inline void XybToRgb(const OpsinParams& op, float X, float Y, float B, float* r, float* g, float* b) {

@@ -69,6 +69,9 @@ def _compare(J, jxlo, data, check_rgb=True):
     ((520, 300), dict(epf_iters=0, gab=0)),               # no filters
     ((777, 513), dict(strategy_mode=2, random_cmap=1)),   # random DCT-family tiling up to 256x256, random CfL
     ((300, 200), dict(skip_dc_smoothing=1)),
+    ((600, 400), dict(noise=40)),                         # noise synthesis (frame flag kNoise), several 256x256 generators
+    ((257, 255), dict(noise=200, distance=2.0)),          # ... ragged groups (partial last generator step per row), EPF2
+    ((520, 300), dict(noise=80, custom_cmap=1)),          # ... with a coded base colour correlation
     ((1000, 700), dict(num_histograms=3)),                # several AC histogram sets (libjxl's streaming encoder)
     ((1300, 1100), dict(num_histograms=30, strategy_mode=2, distance=2.0)),  # one set per group
     ((600, 400), dict(custom_cmap=1, random_cmap=1)),     # coded colour correlation (factor, bases, DC factors), qm scales

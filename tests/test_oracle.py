@@ -214,3 +214,45 @@ def test_idct_basis_functions_oracle(built, strategy):
     worst = check_basis_planes(o.planes("xyb_idct")[1], blocks, shape)
     o.close()
     assert worst < 2e-7 * max(shape) + 1e-6, worst
+
+
+# First vectors of kExpected in lib/jxl/xorshift128plus_test.cc:60-257 (Xorshift128Plus rng(12345), successive Fill()s).
+XORSHIFT_12345 = [
+    [0x6E901576D477CBB1, 0xE9E53789195DA2A2, 0xB681F6DDA5E0AE99, 0x8EFD18CE21FD6896, 0xA898A80DF75CF532, 0x50CEB2C9E2DE7E32,
+     0x3CA7C2FEB25C0DD0, 0xA4D0866B80B4D836],
+    [0x8CD6A1E6233D3A26, 0x3D4603ADE98B112D, 0xDC427AF674019E36, 0xE28B4D230705AC53, 0x7297E9BBA88783DD, 0x34D3D23CFCD9B41A,
+     0x5A223615ADBE96B8, 0xE5EB529027CFBD01],
+    [0xC1894CF00DFAC6A2, 0x18EDF8AE9085E404, 0x8E936625296B4CCD, 0x31971EF3A14A899B, 0xBE87535FCE0BF26A, 0x576F7A752BC6649F,
+     0xA44CBADCE0C6B937, 0x3DBA819BB17A353A],
+    [0x27CE38DFCC1C5EB6, 0x920BEB5606340256, 0x3986CBC40C9AFC2C, 0xE22BCB3EEB1E191E, 0x6E1FCDD3602A8FBA, 0x052CB044E5415A29,
+     0x46266646EFB9ECD7, 0x8F44914618D29335],
+]
+
+
+def test_noise_generator_known_answers(built):
+    """The noise generator (xorshift128plus-inl.h) against the reference's own golden values."""
+    import ctypes
+    import jxlo
+    L = jxlo.lib()
+    L.jxlo_xorshift_fill.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
+    out = (ctypes.c_uint64 * (8 * len(XORSHIFT_12345)))()
+    L.jxlo_xorshift_fill(12345, out, len(XORSHIFT_12345))
+    assert [list(out[8 * i:8 * i + 8]) for i in range(len(XORSHIFT_12345))] == XORSHIFT_12345
+
+
+def test_noise_stream_statistics(built):
+    """A frame with the noise flag: the synthesis is zero-mean high-pass noise whose strength follows the LUT
+    (stage_noise.cc:64-260): the image keeps its mean, gains variance, and a zero LUT leaves it untouched."""
+    import jxlo
+    J = built
+    img = np.full((160, 288, 3), 128, np.uint8)
+    base = jxlo.Decoded(J.encode_rgb8(img))
+    noisy = jxlo.Decoded(J.encode_rgb8(img, noise=60))
+    a, b = base.planes("xyb_filtered")[1][:, :288], noisy.planes("xyb_filtered")[1][:, :288]
+    assert abs(float(b.mean() - a.mean())) < 2e-3
+    assert float(b.std()) > float(a.std()) + 0.005
+    # neighbouring 256-wide groups use different generators: no repetition across the group boundary
+    d = (b - a)
+    assert np.abs(d[:, 0:32] - d[:, 256:288]).max() > 1e-3
+    base.close()
+    noisy.close()
