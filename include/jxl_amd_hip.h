@@ -212,6 +212,11 @@ int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_
  * spinning; for servers that pipeline frames over more host threads than they have CPUs to spare. */
 int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
 
+/* Debug aid: with JXLHIP_GUARD=1 in the environment every device buffer of a context is allocated with a 4 KiB guard
+ * band either side, filled with a pattern. Waits for the device, then *touched = 0 when every band is intact, else
+ * (1-based buffer index << 2) | (1 = band before, 2 = band after) of the first buffer a kernel wrote next to. */
+int jxlhip_check_guards(JxlHipContext* ctx, uint32_t* touched);
+
 /* Memory sharing for pipelined frame sets (call before jxlhip_frame_upload): `ctx` keeps its inverse-transform output (the
  * 3 f32 XYB planes, 12 B/pixel: the largest buffer of a context) in `lender`'s plane buffer instead of allocating its
  * own; lender = NULL undoes it. The planes only live between a frame's transform and its filter + colour stage, so

@@ -175,6 +175,12 @@ class HipContext:
         except Exception:
             pass
 
+    def check_guards(self):
+        """JXLHIP_GUARD=1 debug aid: 0 when no kernel wrote next to one of this context's device buffers."""
+        t = ctypes.c_uint32()
+        _check(lib().jxlhip_check_guards(self._h, ctypes.byref(t)), "jxlhip_check_guards")
+        return int(t.value)
+
     def set_option(self, name, value):
         _check(lib().jxlhip_set_option(self._h, name.encode(), int(value)), "jxlhip_set_option")
 

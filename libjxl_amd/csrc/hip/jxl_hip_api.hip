@@ -51,10 +51,21 @@ inline hipError_t WaitEvent(hipEvent_t ev) {
   }
 }
 
+// JXLHIP_GUARD=1 (debug aid, read at every allocation): every device buffer gets a guard band either side, filled with a
+// pattern that jxlhip_check_guards() verifies: stray WRITES of a kernel next to its buffers show up in a test instead of
+// silently landing in a neighbour (stray reads still only show as faults).
+constexpr size_t kGuardBytes = 4096;
+constexpr int kGuardByte = 0xA5;
+inline bool GuardOn() {
+  const char* e = getenv("JXLHIP_GUARD");
+  return e && *e && atoi(e) != 0;
+}
+
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
   bool view = false;  // p points into another allocation (a frame's table blob): nothing to free
+  void* base = nullptr;  // the allocation when it has guard bands (p = base + kGuardBytes), else NULL
   int Ensure(size_t n) {
     if (view) {
       p = nullptr;
@@ -63,12 +74,26 @@ struct Buf {
     }
     if (n <= cap && p) return 0;
     if (p) {
-      hipError_t e = hipFree(p);
-      p = nullptr;
+      hipError_t e = hipFree(base ? base : p);
+      p = base = nullptr;
       cap = 0;
       if (e != hipSuccess) return -int(e);
     }
     size_t want = n < 256 ? 256 : n;
+    if (GuardOn()) {
+      want = (want + 255) & ~size_t(255);
+      hipError_t e = hipMalloc(&base, want + 2 * kGuardBytes);
+      if (e == hipSuccess) e = hipMemset(base, kGuardByte, kGuardBytes);
+      if (e == hipSuccess) e = hipMemset(static_cast<uint8_t*>(base) + kGuardBytes + want, kGuardByte, kGuardBytes);
+      if (e != hipSuccess) {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        return -int(e);
+      }
+      p = static_cast<uint8_t*>(base) + kGuardBytes;
+      cap = want;
+      return 0;
+    }
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {
       p = nullptr;
@@ -78,10 +103,23 @@ struct Buf {
     return 0;
   }
   void Free() {
-    if (p && !view) (void)hipFree(p);
-    p = nullptr;
+    if (p && !view) (void)hipFree(base ? base : p);
+    p = base = nullptr;
     cap = 0;
     view = false;
+  }
+  // 0 = both guard bands intact (or none), 1 = the band before, 2 = the band after, 3 = both were written to
+  int GuardsTouched() const {
+    if (!base || view) return 0;
+    std::vector<uint8_t> h(2 * kGuardBytes);
+    if (hipMemcpy(h.data(), base, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    if (hipMemcpy(h.data() + kGuardBytes, static_cast<uint8_t*>(base) + kGuardBytes + cap, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    int r = 0;
+    for (size_t i = 0; i < kGuardBytes; i++) {
+      if (h[i] != kGuardByte) r |= 1;
+      if (h[kGuardBytes + i] != kGuardByte) r |= 2;
+    }
+    return r;
   }
   template <typename T>
   T* as() const { return static_cast<T*>(p); }
@@ -329,24 +367,23 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
   return 0;
 }
 
+static std::vector<Buf*> AllBufs(JxlHipContext* c) {
+  std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
+                &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
+                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise};
+  for (auto& pb : c->pass_bufs)
+    for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset}) all.push_back(b);
+  return all;
+}
+
 void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  Buf* all[] = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
-                &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
-                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise};
+  std::vector<Buf*> all = AllBufs(c);
   for (Buf* b : all) b->Free();
-  for (auto& pb : c->pass_bufs) {
-    pb.ctx_map.Free();
-    pb.alias.Free();
-    pb.cfg.Free();
-    pb.orders.Free();
-    pb.ptable.Free();
-    pb.poffset.Free();
-  }
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stage.done) (void)hipEventDestroy(c->stage.done);
@@ -2289,6 +2326,20 @@ int jxlhip_run_all(JxlHipContext* c) {
   if (!r) r = jxlhip_run_transform(c);
   if (!r) r = jxlhip_run_filter_color(c);
   return r;
+}
+
+int jxlhip_check_guards(JxlHipContext* c, uint32_t* touched) {
+  if (!c || !touched) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  *touched = 0;
+  uint32_t index = 0;
+  for (Buf* b : AllBufs(c)) {
+    index++;
+    const int t = b->GuardsTouched();
+    if (t && !*touched) *touched = index << 2 | uint32_t(t);  // which buffer (1-based position in AllBufs), which side
+  }
+  return 0;
 }
 
 int jxlhip_sync(JxlHipContext* c) {

@@ -360,9 +360,14 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
       // (lane 0 is active: its register copy of the descriptor names the tables)
       const uint64_t t0 = reinterpret_cast<uint64_t>(r.T.use_prefix ? static_cast<const void*>(r.T.prefix_table) : static_cast<const void*>(r.T.alias));
       const uint64_t t1 = reinterpret_cast<uint64_t>(r.T.cfg), t2 = reinterpret_cast<uint64_t>(r.T.prefix_offset);
-      const uint32_t* src0 = reinterpret_cast<const uint32_t*>((uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(t0 >> 32))) << 32) | __builtin_amdgcn_readfirstlane(uint32_t(t0)));
-      const uint32_t* src1 = reinterpret_cast<const uint32_t*>((uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(t1 >> 32))) << 32) | __builtin_amdgcn_readfirstlane(uint32_t(t1)));
-      const uint32_t* src2 = reinterpret_cast<const uint32_t*>((uint64_t(__builtin_amdgcn_readfirstlane(uint32_t(t2 >> 32))) << 32) | __builtin_amdgcn_readfirstlane(uint32_t(t2)));
+      // (the builtin returns int: both halves go through uint32_t, or a low half with its top bit set sign-extends)
+      auto uniform = [](uint64_t v) {
+        const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v)))), hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
+        return (uint64_t(hi) << 32) | uint64_t(lo);
+      };
+      const uint32_t* src0 = reinterpret_cast<const uint32_t*>(uniform(t0));
+      const uint32_t* src1 = reinterpret_cast<const uint32_t*>(uniform(t1));
+      const uint32_t* src2 = reinterpret_cast<const uint32_t*>(uniform(t2));
       const uint32_t ncl = __builtin_amdgcn_readfirstlane(r.T.num_clusters), pfx = __builtin_amdgcn_readfirstlane(r.T.use_prefix);
       const uint32_t main_words = words - ncl * (pfx ? 2 : 1);
       for (uint32_t i = lane; i < main_words; i += 64) ltab[i] = src0[i];

@@ -69,6 +69,25 @@ def test_every_pixel_format_and_delivery(built, tmp_path, fmt, channels, extra):
         assert "mt init=1 destroy=1" in out
 
 
+def test_noise_frame_through_the_decoder_api(built, tmp_path):
+    """A frame with noise synthesis (frame flag kNoise: dec_noise.cc, stage_noise.cc) through JxlDecoder: the generator is
+    deterministic (seeded by the frame index and the group origins), so the pixels must equal the oracle's."""
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(300, 270, seed=9), noise=50)
+    plain = J.encode_rgb8(J.synth_image(300, 270, seed=9))
+    ref_f, ref_8 = _oracle_float(jxlo, data)
+    _, plain_8 = _oracle_float(jxlo, plain)
+    assert np.abs(ref_8.astype(int) - plain_8.astype(int)).mean() > 1.0  # (the stream really carries noise)
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3)
+    assert rc == 0 and events[-2:] == ["FULL_IMAGE", "SUCCESS"], out
+    got = np.frombuffer(px, np.uint8).reshape(270, 300, 3)
+    assert np.abs(got.astype(int) - ref_8.astype(int)).max() <= 1
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.float32).reshape(270, 300, 3) - ref_f).max() < 5e-5
+
+
 def test_linear_output(built, tmp_path):
     import jxlo
     J = built

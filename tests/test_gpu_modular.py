@@ -115,6 +115,18 @@ def test_lossless_round_trip_every_feature(built, flags, size, channels):
     assert np.array_equal(out, img), "%d samples differ" % int((out != img).sum())
 
 
+@pytest.mark.parametrize("lanes", [4, 64])
+def test_several_streams_per_wave(built, lanes, monkeypatch):
+    """Small frames put one stream in a wave; sets of many frames put up to 64 (jxlhip_modular_run_batch chooses): the
+    multi-lane form of the stream kernel (shared tree and symbol tables in LDS, divergent lanes) on every feature."""
+    J = built
+    monkeypatch.setenv("JXLHIP_MOD_LANES", str(lanes))
+    for flags, size, channels in ((0, (300, 280), 3), (16 | 4 | 8 | 32 | 64, (700, 300), 4), (1 | 2 | 16, (300, 280), 3)):
+        img = _lossless_image(J, size[0], size[1], channels, seed=11 + flags)
+        out = J.decode_lossless(J.encode_lossless(img, flags, seed=flags), num_channels=channels)
+        assert np.array_equal(out, img), (lanes, flags)
+
+
 def test_4k_lossless_squeeze_ma_tree(built):
     """BASELINE.json configs[3]: 3840x2160 Modular lossless (Squeeze + MA tree), integer bit-exact; and the same frames in
     one batched launch."""

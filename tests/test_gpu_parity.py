@@ -436,6 +436,44 @@ def test_band_decode_matches_whole_frame(built, kind):
     f.close()
 
 
+def test_no_kernel_writes_outside_its_buffers(built, monkeypatch):
+    """Debug build aid (JXLHIP_GUARD=1): every device buffer sits between two 4 KiB guard bands that no kernel may touch.
+    A tour of the kernels: ragged sizes (also heights that are multiples of 64), every filter depth, upsampling, two
+    passes, prefix / LZ77 codes, noise, int32 coefficients, and Modular frames with every feature."""
+    J = built
+    monkeypatch.setenv("JXLHIP_GUARD", "1")
+    cases = [((257, 255), dict()), ((512, 512), dict(distance=2.0)), ((520, 300), dict(distance=4.5, gab=0)),
+             ((300, 200), dict(upsampling=2)), ((520, 300), dict(num_passes=2)), ((300, 280), dict(ac_code_mode=3)),
+             ((600, 400), dict(noise=40)), ((777, 513), dict(strategy_mode=2, random_cmap=1)), ((64, 64), dict(big_coeffs=1, strategy_mode=2))]
+    for size, kw in cases:
+        if kw.get("big_coeffs"):
+            data = J.encode_random(size[0], size[1], **kw)
+        else:
+            data = J.encode_rgb8(J.synth_image(size[0], size[1], seed=5), **kw)
+        f = J.Frame(data, threads=2)
+        c = J.HipContext()
+        try:
+            c.upload(f)
+            c.run_all()
+            c.sync()
+            assert c.check_guards() == 0, (size, kw, c.check_guards())
+        finally:
+            c.close()
+            f.close()
+    img = J.synth_image(700, 300, seed=4)
+    for flags in (0, 16 | 4 | 8, 1 | 2 | 16):
+        f = J.ModFrame(J.encode_lossless(img, flags))
+        c = J.HipContext()
+        try:
+            c.upload_modular(f)
+            c.run_modular()
+            c.sync()
+            assert c.check_guards() == 0, (flags, c.check_guards())
+        finally:
+            c.close()
+            f.close()
+
+
 def test_corrupt_sections_are_flagged_not_fatal(built):
     J = built
     data = bytearray(J.encode_rgb8(J.synth_image(520, 300)))
