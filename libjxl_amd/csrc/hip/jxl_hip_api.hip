@@ -126,7 +126,7 @@ struct Buf {
 };
 
 struct PassBufs {
-  Buf ctx_map, alias, cfg, orders, ptable, poffset;
+  Buf ctx_map, alias, cfg, orders, ptable, poffset, alias_packed;
 };
 
 // One launch of the Modular transform / output kernels over the frames of a set (ModularBuildOps).
@@ -197,6 +197,7 @@ struct JxlHipContext {
   size_t batch_off_units = 0, batch_off_queue = 0, batch_off_wave_lanes = 0, batch_units = 0;  // layout of batch_lanes
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
   uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64, batch_wpg = 4;
+  bool batch_galias = false;  // the lane kernel reads its alias tables from global memory (PrepareBatch)
   int batch_kernel = -1;
   std::vector<uint32_t> sec_size_host, sec_sel_host, pass_clusters, pass_log_alpha;
   // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
@@ -373,7 +374,7 @@ static std::vector<Buf*> AllBufs(JxlHipContext* c) {
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise};
   for (auto& pb : c->pass_bufs)
-    for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset}) all.push_back(b);
+    for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset, &pb.alias_packed}) all.push_back(b);
   return all;
 }
 
@@ -635,6 +636,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       const JxlHipPassDesc& q = d->passes[p];
       if (q.num_clusters > 256 || (!q.use_prefix && q.log_alpha > 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
       add(q.ctx_map_size); add(q.use_prefix ? 0 : (size_t(q.num_clusters) << q.log_alpha) * 8); add(size_t(q.num_clusters) * 4);
+      add(q.use_prefix ? 0 : (size_t(q.num_clusters) << q.log_alpha) * 8);  // (the lane kernel's packed form)
       add(size_t(q.orders_size) * 2); add(size_t(q.prefix_table_size) * 4); add(size_t(q.num_clusters) * 4);
     }
     add(size_t(d->num_passes) * sizeof(jxlhip::PassDev)); add(64 * 25 * 4); add((size_t(d->num_blocks) + 1) * 4);
@@ -717,10 +719,27 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     alias_bytes_max = alias_bytes > alias_bytes_max ? alias_bytes : alias_bytes_max;
     if ((r = Upload(c, pb.ctx_map, s.ctx_map, s.ctx_map_size))) return r;
     if ((r = Upload(c, pb.alias, s.alias, alias_bytes))) return r;
+    {
+      // alias entry {cutoff u8, right u8, freq0 u16 | offsets1 u16, freq1 u16} -> the lane kernel's form
+      //   x = (freq0 - 1) & 0xFFF | cutoff << 24                    taken when pos <  cutoff: symbol = slot, offset = pos
+      //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24    taken when pos >= cutoff
+      void* st = nullptr;
+      if ((r = StageAlloc(c, alias_bytes ? alias_bytes : 16, &st))) return r;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(s.alias);
+      uint32_t* dst = static_cast<uint32_t*>(st);
+      for (size_t i = 0; i < alias_bytes / 8; i++) {
+        const uint32_t ex = src[2 * i], ey = src[2 * i + 1];
+        const uint32_t cutoff = ex & 0xFF, right = (ex >> 8) & 0xFF, freq0 = ex >> 16, offs1 = ey & 0xFFFF, freq1 = ey >> 16;
+        dst[2 * i] = ((freq0 - 1) & 0xFFFu) | (cutoff << 24);
+        dst[2 * i + 1] = ((freq1 - 1) & 0xFFFu) | ((offs1 & 0xFFFu) << 12) | (right << 24);
+      }
+      if ((r = UploadStaged(c, pb.alias_packed, st, alias_bytes))) return r;
+    }
     if ((r = Upload(c, pb.cfg, s.uint_cfg, size_t(s.num_clusters) * 4))) return r;
     if ((r = Upload(c, pb.orders, s.orders, size_t(s.orders_size) * 2))) return r;
     pd[p].ctx_map = pb.ctx_map.as<uint8_t>();
     pd[p].alias = pb.alias.as<uint2>();
+    pd[p].alias_packed = pb.alias_packed.as<uint2>();
     pd[p].cfg = pb.cfg.as<uint32_t>();
     pd[p].orders = pb.orders.as<uint16_t>();
     memcpy(pd[p].order_offset, s.order_offset, sizeof(s.order_offset));
@@ -846,8 +865,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   // single-pass frames whose tables fit LDS are decoded by the lane-parallel kernel into scan order
   // (its packed block records hold the block contexts in 4 bits each: the codestream allows at most 16)
   c->lanes = EntropyKernelChoice() == 2 && ep.num_bctx <= 16 && d->num_passes <= 8 && !generic;
-  for (uint32_t p = 0; c->lanes && p < d->num_passes; p++)
-    c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64).total <= kLdsBudget;
+  for (uint32_t p = 0; c->lanes && p < d->num_passes; p++)  // (alias tables that do not fit LDS are read in place)
+    c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64, false).total <= kLdsBudget;
   c->scan_order = c->lanes && d->num_passes == 1;
   c->lane_multi = c->lanes && d->num_passes > 1;
   const size_t kend_per_pass = size_t(d->num_blocks ? d->num_blocks : 1) * 3;
@@ -1330,19 +1349,23 @@ static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_
   return 0;
 }
 
-template <typename CoefT, int WPG, bool AIDS>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS>
 static int LaunchEntropyLanesW(JxlHipContext* c0);
+template <typename CoefT, bool GALIAS>
+static int LaunchEntropyLanesG(JxlHipContext* c0) {
+  if (EnvInt("JXLHIP_LANES_DEBUG", 0) || EnvInt("JXLHIP_LANES_PROF", 0))  // measurement aids: instrumented build of the kernel
+    return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, true, GALIAS>(c0)
+                              : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, true, GALIAS>(c0) : LaunchEntropyLanesW<CoefT, 4, true, GALIAS>(c0));
+  return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, false, GALIAS>(c0)
+                            : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, false, GALIAS>(c0) : LaunchEntropyLanesW<CoefT, 4, false, GALIAS>(c0));
+}
 template <typename CoefT>
 static int LaunchEntropyLanes(JxlHipContext* c0) {
-  if (EnvInt("JXLHIP_LANES_DEBUG", 0) || EnvInt("JXLHIP_LANES_PROF", 0))  // measurement aids: instrumented build of the kernel
-    return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, true>(c0)
-                              : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, true>(c0) : LaunchEntropyLanesW<CoefT, 4, true>(c0));
-  return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, false>(c0)
-                            : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, false>(c0) : LaunchEntropyLanesW<CoefT, 4, false>(c0));
+  return c0->batch_galias ? LaunchEntropyLanesG<CoefT, true>(c0) : LaunchEntropyLanesG<CoefT, false>(c0);
 }
-template <typename CoefT, int WPG, bool AIDS>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS>
 static int LaunchEntropyLanesW(JxlHipContext* c0) {
-  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS>;
+  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS, GALIAS>;
   if (c0->batch_lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
   jxlhip::EntropyLaneBatch b;
@@ -1503,13 +1526,28 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
         wave_lanes.push_back(uint8_t(cnt));
       }
     }
-    for (size_t wg = 0; wg < map.size(); wg++) {  // LDS of the launch = the largest workgroup
-      const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg]) * 4] & 0xFFFF];
-      const uint32_t up = unit_desc[size_t(map[wg]) * 4 + 3];  // the unit's pass
-      size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[up], c->pass_log_alpha[up], 0, 0).wave0;
-      for (uint32_t w = 0; w < wpg; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * wpg + w];
-      lds = l > lds ? l : lds;
-    }
+    // LDS of the launch = the largest workgroup. With the alias tables in LDS a CU holds 160 KB / that many workgroups;
+    // when that leaves part of the launch waiting for a second round (libjxl-sized tables: 128 clusters x 2^6 slots are
+    // 64 KB), the tables stay in global memory instead: a cached global round trip on every token's serial chain, but
+    // every frame resident (JXLHIP_GALIAS = 0 / 1 forces either form: measurement aid)
+    size_t lds_by_form[2] = {0, 0};
+    for (int form = 0; form < 2; form++)
+      for (size_t wg = 0; wg < map.size(); wg++) {
+        const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg]) * 4] & 0xFFFF];
+        const uint32_t up = unit_desc[size_t(map[wg]) * 4 + 3];  // the unit's pass
+        size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[up], c->pass_log_alpha[up], 0, 0, form == 0).wave0;
+        for (uint32_t w = 0; w < wpg; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * wpg + w];
+        lds_by_form[form] = l > lds_by_form[form] ? l : lds_by_form[form];
+      }
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c0->device);
+    const size_t resident = lds_by_form[0] ? size_t(dev_cus) * ((160 * 1024) / lds_by_form[0]) : map.size();
+    bool galias = lds_by_form[0] > kLdsBudget || resident < map.size();
+    const int forced_form = EnvInt("JXLHIP_GALIAS", -1);
+    if (forced_form == 0 && lds_by_form[0] <= kLdsBudget) galias = false;
+    if (forced_form == 1) galias = true;
+    c0->batch_galias = galias;
+    lds = lds_by_form[galias ? 1 : 0];
     if (EnvInt("JXLHIP_PACK_DEBUG", 0))
       fprintf(stderr, "[pack] units %zu sections %zu lanes(min) %zu lanes/wave %u waves/wg %u workgroups %zu lds %zu\n", units.size(),
               total_sections, min_total, lanes_per_wave, wpg, map.size(), lds);

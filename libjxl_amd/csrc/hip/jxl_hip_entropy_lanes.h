@@ -65,11 +65,12 @@ constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 2 mir
 constexpr uint32_t kLanesBlockRing = 8;             // packed block records, u32
 constexpr int kLanesTrips = 4;                      // hot trips per control check
 constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 2) * 4 + kLanesBlockRing * 4;
+// alias_lds = false: the alias tables stay in global memory (k_entropy_lanes<..., GALIAS = true>).
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
-                                                   uint32_t waves, uint32_t lanes) {
+                                                   uint32_t waves, uint32_t lanes, bool alias_lds = true) {
   LanesLds l;
   l.alias = 0;
-  l.ctx = (num_clusters << log_alpha) * 8;
+  l.ctx = alias_lds ? (num_clusters << log_alpha) * 8 : 0;
   l.ctx2 = l.ctx + ((num_hist * nctx + 16 + 15) & ~15u);
   l.cfg = l.ctx2 + 64 * 2;
   l.wave0 = l.cfg + 256 * 2;
@@ -83,9 +84,12 @@ __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t n
 // lane's column of the stream ring.
 // FLAT = true: no branches (the renormalisation and the extra bits are computed for every lane and selected), so that a
 // hot trip is one basic block whose independent instructions the scheduler can interleave with the serial chain.
-template <bool FLAT = false>
+// GALIAS = true: the alias entry comes from `galias` (global memory, same packed form) instead of LDS offset 0: one
+// cached global round trip on the serial chain per token, in exchange for 16-64 KB less LDS per frame.
+template <bool FLAT = false, bool GALIAS = false>
 __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
-                                               uint32_t log_ls, const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry) {
+                                               uint32_t log_ls, const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry,
+                                               const uint2* galias = nullptr) {
   const uint32_t ctxe = l_cfg[cluster];
   // the bit window (96 bits: 16 renormalisation bits + up to 31 extra bits from any bit offset) is read unconditionally
   // and up front (volatile: not sunk into the branches), so that it shares one LDS round trip with the alias entry;
@@ -97,7 +101,8 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
   const uint32_t w2 = *(LdsVolatile)(ring + s0 + 2 * LS);
   const uint32_t boff = bitpos & 31;
   const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & ((1u << log_entry) - 1);
-  const uint2 e = *reinterpret_cast<const uint2*>(lds + (cluster << (15 - log_entry)) + slot * 8);  // 8 << log_alpha per cluster
+  const uint2 e = GALIAS ? galias[(cluster << (12 - log_entry)) + slot]
+                         : *reinterpret_cast<const uint2*>(lds + (cluster << (15 - log_entry)) + slot * 8);  // 8 << log_alpha per cluster
   const bool gt = pos >= (e.x >> 24);
   const uint32_t x = gt ? e.y : e.x;
   uint32_t tok = gt ? (x >> 24) : slot;
@@ -141,8 +146,8 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
   return tok;
 }
 
-// AIDS = false compiles the measurement aids (B.prof, B.debug) out.
-template <typename CoefT, int WPG, bool AIDS>
+// AIDS = false compiles the measurement aids (B.prof, B.debug) out. GALIAS: see LaneSymbol.
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS = false>
 __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_) {
   EntropyLaneBatch B = B_;
   if (!AIDS) {
@@ -168,7 +173,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   const uint32_t LS = 1u << log_ls;
   uint32_t wave_off = 0;  // the per-wave regions are packed one after the other
   for (uint32_t w = 0; w < wave; w++) wave_off += kLanesPerLaneBytes << wls[w];
-  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, 0, 0);
+  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, 0, 0, !GALIAS);
+  const uint2* const galias = T.alias_packed;
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
   uint8_t* l_ctx = lds_raw + L.ctx;                                      // context -> histogram (cluster)
   uint16_t* l_cfg = reinterpret_cast<uint16_t*>(lds_raw + L.cfg);        // per cluster: split_exp | msb << 4 | lsb << 8
@@ -192,12 +198,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
     // alias entry {cutoff u8, right u8, freq0 u16 | offsets1 u16, freq1 u16} ->
     //   x = (freq0 - 1) & 0xFFF | cutoff << 24                    taken when pos <  cutoff: symbol = slot, offset = pos
     //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24    taken when pos >= cutoff
-    const uint32_t n_alias = nclusters << log_alpha;
-    for (uint32_t i = tid; i < n_alias; i += 64 * WPG) {
-      const uint2 e = T.alias[i];
-      const uint32_t cutoff = e.x & 0xFF, right = (e.x >> 8) & 0xFF, freq0 = e.x >> 16, offs1 = e.y & 0xFFFF, freq1 = e.y >> 16;
-      l_alias[i] = make_uint2(((freq0 - 1) & 0xFFFu) | (cutoff << 24), ((freq1 - 1) & 0xFFFu) | ((offs1 & 0xFFFu) << 12) | (right << 24));
-    }
+    // (repacked by jxlhip_frame_upload: PassDev::alias_packed)
+    const uint32_t n_alias = GALIAS ? 0u : nclusters << log_alpha;
+    for (uint32_t i = tid; i < n_alias; i += 64 * WPG) l_alias[i] = galias[i];
     if (tid < 64) l_nnz2[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 2);
     uint32_t* z = reinterpret_cast<uint32_t*>(l_nz);
     for (uint32_t i = lane; i < kLanesNzRows * LS / 4; i += 64) z[i] = 0;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             else pred = (uint32_t(line[lbx * LS]) + line[(lbx - 1) * LS] + 1) >> 1;
             uint32_t nzb = pred >= 64 ? 64 : pred;
             nzb = nzb < 8 ? nzb : 4 + nzb / 2;
-            const uint32_t tok = LaneSymbol(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
+            const uint32_t tok = LaneSymbol<false, GALIAS>(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry, galias);
             const uint32_t covered = 1u << log2c;
             size = covered * 64;
             kidx = bi * 3 + c;
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays): read here, with
         // everything else, so that no LDS read is waited for at the end of the trip
         const uint32_t nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
-        const uint32_t tok = LaneSymbol<true>(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry);
+        const uint32_t tok = LaneSymbol<true, GALIAS>(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry, galias);
         const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
         const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
         // Coefficients leave in aligned 8-byte chunks (4 x int16 / 2 x int32), shifted into a register pair from the top:

@@ -69,6 +69,10 @@ struct PassDev {
   uint32_t use_prefix, lz77, lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_ctx;
   const uint32_t* prefix_table;
   const uint32_t* prefix_offset;
+  // the alias entries as the lane kernel reads them (x = (freq0 - 1) & 0xFFF | cutoff << 24, y = (freq1 - 1) & 0xFFF |
+  // offsets1 << 12 | right << 24): staged into LDS, or read in place when the tables are too large to keep the frames
+  // of a launch resident
+  const uint2* alias_packed;
 };
 
 struct EntropyParams {

@@ -436,6 +436,15 @@ def test_band_decode_matches_whole_frame(built, kind):
     f.close()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(num_passes=2), dict(num_histograms=3, strategy_mode=2), dict(max_clusters=200, distance=0.5)])
+def test_lane_kernel_with_alias_tables_in_global_memory(built, kw, monkeypatch):
+    """Sets of frames whose alias tables would not leave every frame resident (libjxl-sized tables: 128+ clusters) run
+    the lane kernel with the tables read in place (JXLHIP_GALIAS=1 forces that form): same coefficients, bit for bit."""
+    import jxlo
+    monkeypatch.setenv("JXLHIP_GALIAS", "1")
+    _compare(built, jxlo, built.encode_rgb8(built.synth_image(600, 420, seed=13), **kw))
+
+
 def test_no_kernel_writes_outside_its_buffers(built, monkeypatch):
     """Debug build aid (JXLHIP_GUARD=1): every device buffer sits between two 4 KiB guard bands that no kernel may touch.
     A tour of the kernels: ragged sizes (also heights that are multiples of 64), every filter depth, upsampling, two
