@@ -29,13 +29,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable rate
 
 
-def make_stream(xsize, ysize, distance, seed=177, max_clusters=0):
+def make_stream(xsize, ysize, distance, seed=177, max_clusters=0, ac_code_mode=0):
     import libjxl_amd as J
-    cache = "/tmp/libjxl_amd_bench_%dx%d_d%.2f_s%d_c%d.jxl" % (xsize, ysize, distance, seed, max_clusters)
+    cache = "/tmp/libjxl_amd_bench_%dx%d_d%.2f_s%d_c%d_m%d.jxl" % (xsize, ysize, distance, seed, max_clusters, ac_code_mode)
     if os.path.exists(cache):
         return open(cache, "rb").read()
     img = J.synth_image(xsize, ysize, seed)
-    data = J.encode_rgb8(img, distance=distance, strategy_mode=1, max_clusters=max_clusters)
+    data = J.encode_rgb8(img, distance=distance, strategy_mode=1, max_clusters=max_clusters, ac_code_mode=ac_code_mode)
     try:
         tmp = cache + ".%d" % os.getpid()
         open(tmp, "wb").write(data)
@@ -393,6 +393,8 @@ def main():
     ap.add_argument("--workload", choices=("vardct", "lossless"), default="vardct",
                     help="vardct: BASELINE.json configs[1] (the headline); lossless: configs[3], 3840x2160 Modular lossless "
                          "(Squeeze + MA tree + weighted predictor) through k_modular_streams")
+    ap.add_argument("--ac-code-mode", type=int, default=0,
+                    help="sensitivity runs: AC coefficient streams with prefix codes (1: what libjxl's fastest efforts emit), LZ77 (2) or both (3)")
     ap.add_argument("--lossless-flags", type=int, default=-1,
                     help="--workload lossless: feature bits of the synthetic encoder (libjxl_amd.LOSSLESS_*) instead of RCT + Squeeze + WP")
     ap.add_argument("--launch-check", action="store_true",
@@ -442,7 +444,7 @@ def main():
     # set: sections, token counts and entropy tables differ from frame to frame, so the workgroups of a launch do not all
     # finish together
     ndistinct = max(1, min(args.distinct, args.batch))
-    datas = [make_stream(xsize, ysize, args.distance, 177 + i, args.max_clusters) for i in range(ndistinct)]
+    datas = [make_stream(xsize, ysize, args.distance, 177 + i, args.max_clusters, args.ac_code_mode) for i in range(ndistinct)]
     frames = [J.Frame(d, threads=min(8, os.cpu_count() or 1)) for d in datas]
     data, frame = datas[0], frames[0]
     info = dict(frame.info)

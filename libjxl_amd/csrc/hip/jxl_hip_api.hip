@@ -172,7 +172,8 @@ struct JxlHipContext {
   // buffers
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
   Buf plane[3], rgb, tlist, scratch, sec_end, lz_window;
-  bool generic_codec = false;  // a pass is prefix-coded or uses LZ77: k_entropy_generic decodes the frame
+  bool generic_codec = false;  // a pass is prefix-coded or uses LZ77 (k_entropy_generic decodes the frame unless lane_prefix)
+  bool lane_prefix = false;    // every pass is prefix-coded without LZ77: the lane kernel's prefix form decodes the frame
   // ---- Modular frame (jxlhip_modular_upload): channel pool, tables, stream descriptors, inverse-transform operations
   struct Modular {
     bool have = false;
@@ -198,6 +199,7 @@ struct JxlHipContext {
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
   uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64, batch_wpg = 4;
   bool batch_galias = false;  // the lane kernel reads its alias tables from global memory (PrepareBatch)
+  bool batch_prefix = false;  // ... decodes prefix codes
   int batch_kernel = -1;
   std::vector<uint32_t> sec_size_host, sec_sel_host, pass_clusters, pass_log_alpha;
   // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
@@ -864,9 +866,13 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (size_t(d->block_ctx_lut_size) < size_t(3) * 13 * ep.nq * ep.ndc) return JXLHIP_ERR_INVALID_ARGUMENT;
   // single-pass frames whose tables fit LDS are decoded by the lane-parallel kernel into scan order
   // (its packed block records hold the block contexts in 4 bits each: the codestream allows at most 16)
-  c->lanes = EntropyKernelChoice() == 2 && ep.num_bctx <= 16 && d->num_passes <= 8 && !generic;
+  bool all_prefix = true;
+  for (uint32_t p = 0; p < d->num_passes; p++) all_prefix = all_prefix && d->passes[p].use_prefix;
+  c->lane_prefix = all_prefix && !any_lz77 && !EnvInt("JXLHIP_NO_LANE_PREFIX", 0);
+  c->lanes = EntropyKernelChoice() == 2 && ep.num_bctx <= 16 && d->num_passes <= 8 && (!generic || c->lane_prefix);
   for (uint32_t p = 0; c->lanes && p < d->num_passes; p++)  // (alias tables that do not fit LDS are read in place)
-    c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64, false).total <= kLdsBudget;
+    c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64, false, c->lane_prefix).total <= kLdsBudget;
+  if (!c->lanes) c->lane_prefix = false;
   c->scan_order = c->lanes && d->num_passes == 1;
   c->lane_multi = c->lanes && d->num_passes > 1;
   const size_t kend_per_pass = size_t(d->num_blocks ? d->num_blocks : 1) * 3;
@@ -1349,7 +1355,7 @@ static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_
   return 0;
 }
 
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX = false>
 static int LaunchEntropyLanesW(JxlHipContext* c0);
 template <typename CoefT, bool GALIAS>
 static int LaunchEntropyLanesG(JxlHipContext* c0) {
@@ -1361,11 +1367,15 @@ static int LaunchEntropyLanesG(JxlHipContext* c0) {
 }
 template <typename CoefT>
 static int LaunchEntropyLanes(JxlHipContext* c0) {
+  if (c0->batch_prefix)  // (no instrumented build of the prefix form)
+    return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, false, true, true>(c0)
+                              : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, false, true, true>(c0)
+                                                    : LaunchEntropyLanesW<CoefT, 4, false, true, true>(c0));
   return c0->batch_galias ? LaunchEntropyLanesG<CoefT, true>(c0) : LaunchEntropyLanesG<CoefT, false>(c0);
 }
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX>
 static int LaunchEntropyLanesW(JxlHipContext* c0) {
-  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS, GALIAS>;
+  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS, GALIAS, PREFIX>;
   if (c0->batch_lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
   jxlhip::EntropyLaneBatch b;
@@ -1535,7 +1545,8 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
       for (size_t wg = 0; wg < map.size(); wg++) {
         const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg]) * 4] & 0xFFFF];
         const uint32_t up = unit_desc[size_t(map[wg]) * 4 + 3];  // the unit's pass
-        size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[up], c->pass_log_alpha[up], 0, 0, form == 0).wave0;
+        size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[up], c->pass_log_alpha[up], 0, 0, form == 0 && !c0->lane_prefix,
+                                          c0->lane_prefix).wave0;
         for (uint32_t w = 0; w < wpg; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * wpg + w];
         lds_by_form[form] = l > lds_by_form[form] ? l : lds_by_form[form];
       }
@@ -1546,7 +1557,9 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     const int forced_form = EnvInt("JXLHIP_GALIAS", -1);
     if (forced_form == 0 && lds_by_form[0] <= kLdsBudget) galias = false;
     if (forced_form == 1) galias = true;
+    if (c0->lane_prefix) galias = true;  // (prefix codes have no alias tables: the two forms are the same)
     c0->batch_galias = galias;
+    c0->batch_prefix = c0->lane_prefix;
     lds = lds_by_form[galias ? 1 : 0];
     if (EnvInt("JXLHIP_PACK_DEBUG", 0))
       fprintf(stderr, "[pack] units %zu sections %zu lanes(min) %zu lanes/wave %u waves/wg %u workgroups %zu lds %zu\n", units.size(),
@@ -1606,7 +1619,7 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
     if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
     if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
     if (c->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
-    if (!c->lanes || c->coef_bits != c0->coef_bits) all_scan = false;
+    if (!c->lanes || c->coef_bits != c0->coef_bits || c->lane_prefix != c0->lane_prefix) all_scan = false;
     if (c->lanes || c->generic_codec || !c->alias_lds || c->ep.num_hist != 1 || c->np != 1 || c->coef_bits != c0->coef_bits ||
         c->ng > 0xFFFF * kEntropyWPG || EntropyKernelChoice() == 0)
       all_uni = false;

@@ -56,7 +56,7 @@ struct EntropyLaneBatch {
 
 // LDS layout of one workgroup (byte offsets, every region 16-byte aligned); the host sizes the launch with it.
 struct LanesLds {
-  uint32_t alias, ctx, ctx2, cfg, wave0, per_wave, total;
+  uint32_t alias, ctx, ctx2, cfg, poff, wave0, per_wave, total;
 };
 // Per-wave LDS, all [row][lane] with a row stride of `lanes` entries (conflict-free, and a wave that populates few lanes
 // needs little LDS, which keeps room on the CU for the bandwidth-bound kernels running beside this one):
@@ -65,15 +65,17 @@ constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 2 mir
 constexpr uint32_t kLanesBlockRing = 8;             // packed block records, u32
 constexpr int kLanesTrips = 4;                      // hot trips per control check
 constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 2) * 4 + kLanesBlockRing * 4;
-// alias_lds = false: the alias tables stay in global memory (k_entropy_lanes<..., GALIAS = true>).
+// alias_lds = false: the alias tables stay in global memory (k_entropy_lanes<..., GALIAS = true>); prefix = true: prefix
+// codes (no alias tables at all; the per-cluster table offsets get a 1 KB region).
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
-                                                   uint32_t waves, uint32_t lanes, bool alias_lds = true) {
+                                                   uint32_t waves, uint32_t lanes, bool alias_lds = true, bool prefix = false) {
   LanesLds l;
   l.alias = 0;
   l.ctx = alias_lds ? (num_clusters << log_alpha) * 8 : 0;
   l.ctx2 = l.ctx + ((num_hist * nctx + 16 + 15) & ~15u);
   l.cfg = l.ctx2 + 64 * 2;
-  l.wave0 = l.cfg + 256 * 2;
+  l.poff = l.cfg + 256 * 2;
+  l.wave0 = l.poff + (prefix ? 256 * 4 : 0);
   l.per_wave = kLanesPerLaneBytes * lanes;
   l.total = l.wave0 + waves * l.per_wave;
   return l;
@@ -86,11 +88,42 @@ __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t n
 // hot trip is one basic block whose independent instructions the scheduler can interleave with the serial chain.
 // GALIAS = true: the alias entry comes from `galias` (global memory, same packed form) instead of LDS offset 0: one
 // cached global round trip on the serial chain per token, in exchange for 16-64 KB less LDS per frame.
-template <bool FLAT = false, bool GALIAS = false>
+// PREFIX = true: a prefix code instead of rANS (dec_huffman.h:28-41 in the table form the host builds: l_poff[cluster] =
+// first entry | longest code << 24, ptable[first + next `longest` bits] = symbol << 8 | code length); `state` is unused.
+template <bool FLAT = false, bool GALIAS = false, bool PREFIX = false>
 __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
                                                uint32_t log_ls, const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry,
-                                               const uint2* galias = nullptr) {
+                                               const uint2* galias = nullptr, const uint32_t* l_poff = nullptr,
+                                               const uint32_t* ptable = nullptr) {
   const uint32_t ctxe = l_cfg[cluster];
+  if (PREFIX) {
+    const uint32_t po = l_poff[cluster];
+    const uint32_t s0 = ((bitpos >> 5) & (kLanesRingWords - 1)) << log_ls;
+    typedef const volatile __attribute__((address_space(3))) uint32_t* LdsVolatile;
+    const uint32_t w0 = *(LdsVolatile)(ring + s0);
+    const uint32_t w1 = *(LdsVolatile)(ring + s0 + LS);
+    const uint32_t w2 = *(LdsVolatile)(ring + s0 + 2 * LS);
+    const uint32_t boff = bitpos & 31;
+    const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, boff);
+    const uint32_t e = ptable[(po & 0xFFFFFFu) + (win & ((1u << (po >> 24)) - 1))];
+    uint32_t tok = e >> 8;
+    const uint32_t len = e & 0xFFu;
+    bitpos += len;
+    const uint32_t boff2 = boff + len;  // < 47
+    const uint32_t se = ctxe & 15;
+    const bool take = tok >= (1u << se);
+    if (FLAT && !__builtin_amdgcn_ballot_w64(take)) return tok;
+    if (take) {
+      const uint32_t msb = (ctxe >> 4) & 15, lsb = (ctxe >> 8) & 15;
+      const uint32_t nb = (se - (msb + lsb) + ((tok - (1u << se)) >> (msb + lsb))) & 31u;
+      const uint32_t low = tok & ((1u << lsb) - 1), top = tok >> lsb;
+      const bool up = boff2 >= 32;
+      const uint32_t xb = __builtin_amdgcn_alignbit(up ? w2 : w1, up ? w1 : w0, boff2 & 31) & ((1u << nb) - 1);
+      bitpos += nb;
+      tok = (((((1u << msb) | (top & ((1u << msb) - 1))) << nb) | xb) << lsb) | low;
+    }
+    return tok;
+  }
   // the bit window (96 bits: 16 renormalisation bits + up to 31 extra bits from any bit offset) is read unconditionally
   // and up front (volatile: not sunk into the branches), so that it shares one LDS round trip with the alias entry;
   // LS is a power of two
@@ -147,7 +180,7 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
 }
 
 // AIDS = false compiles the measurement aids (B.prof, B.debug) out. GALIAS: see LaneSymbol.
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS = false>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS = false, bool PREFIX = false>
 __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_) {
   EntropyLaneBatch B = B_;
   if (!AIDS) {
@@ -173,8 +206,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   const uint32_t LS = 1u << log_ls;
   uint32_t wave_off = 0;  // the per-wave regions are packed one after the other
   for (uint32_t w = 0; w < wave; w++) wave_off += kLanesPerLaneBytes << wls[w];
-  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, 0, 0, !GALIAS);
+  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, 0, 0, !GALIAS && !PREFIX, PREFIX);
   const uint2* const galias = T.alias_packed;
+  uint32_t* const l_poff = reinterpret_cast<uint32_t*>(lds_raw + L.poff);  // (PREFIX only)
+  const uint32_t* const ptable = T.prefix_table;
   uint2* l_alias = reinterpret_cast<uint2*>(lds_raw + L.alias);
   uint8_t* l_ctx = lds_raw + L.ctx;                                      // context -> histogram (cluster)
   uint16_t* l_cfg = reinterpret_cast<uint16_t*>(lds_raw + L.cfg);        // per cluster: split_exp | msb << 4 | lsb << 8
@@ -199,7 +234,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
     //   x = (freq0 - 1) & 0xFFF | cutoff << 24                    taken when pos <  cutoff: symbol = slot, offset = pos
     //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24    taken when pos >= cutoff
     // (repacked by jxlhip_frame_upload: PassDev::alias_packed)
-    const uint32_t n_alias = GALIAS ? 0u : nclusters << log_alpha;
+    if (PREFIX)
+      for (uint32_t i = tid; i < nclusters; i += 64 * WPG) l_poff[i] = T.prefix_offset[i];
+    const uint32_t n_alias = (GALIAS || PREFIX) ? 0u : nclusters << log_alpha;
     for (uint32_t i = tid; i < n_alias; i += 64 * WPG) l_alias[i] = galias[i];
     if (tid < 64) l_nnz2[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 2);
     uint32_t* z = reinterpret_cast<uint32_t*>(l_nz);
@@ -293,8 +330,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           uint32_t sel = hb ? uint32_t(win) & ((1u << hb) - 1) : 0;
           if (sel != wg_sel) err = kErrSelector;  // (the host packed the section by the selector it read: cannot differ)
           ctx_base = 0;
-          state = uint32_t(win >> hb);
-          bitpos += hb + 32;
+          state = PREFIX ? 0x13u << 16 : uint32_t(win >> hb);  // (prefix codes carry no state: what the end check expects)
+          bitpos += hb + (PREFIX ? 0 : 32);
         } else {
           ci++;
           if (ci >= 3) {
@@ -337,7 +374,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             else pred = (uint32_t(line[lbx * LS]) + line[(lbx - 1) * LS] + 1) >> 1;
             uint32_t nzb = pred >= 64 ? 64 : pred;
             nzb = nzb < 8 ? nzb : 4 + nzb / 2;
-            const uint32_t tok = LaneSymbol<false, GALIAS>(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry, galias);
+            const uint32_t tok = LaneSymbol<false, GALIAS, PREFIX>(l_ctx[ctx_base + nzb * num_bctx + bctx], state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry, galias, l_poff, ptable);
             const uint32_t covered = 1u << log2c;
             size = covered * 64;
             kidx = bi * 3 + c;
@@ -422,7 +459,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays): read here, with
         // everything else, so that no LDS read is waited for at the end of the trip
         const uint32_t nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
-        const uint32_t tok = LaneSymbol<true, GALIAS>(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry, galias);
+        const uint32_t tok = LaneSymbol<true, GALIAS, PREFIX>(ctxe, state, bitpos, ring, LS, log_ls, lds_raw, l_cfg, log_entry, galias, l_poff, ptable);
         const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
         const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
         // Coefficients leave in aligned 8-byte chunks (4 x int16 / 2 x int32), shifted into a register pair from the top:

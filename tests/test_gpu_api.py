@@ -137,7 +137,8 @@ def test_reference_vardct_alpha_stream_through_the_gpu(built, tmp_path):
 @pytest.mark.parametrize("mode", [1, 2, 3])
 def test_prefix_coded_and_lz77_ac_streams(built, mode):
     """AC streams as libjxl's fastest efforts (prefix codes, dec_huffman.h:28-41) and slowest efforts (LZ77,
-    dec_ans.h:288-353) write them: k_entropy_generic, coefficients bit-exact, pixels within the usual bar."""
+    dec_ans.h:288-353) write them: prefix codes alone on the lane kernel's prefix form, anything with LZ77 on
+    k_entropy_generic; coefficients bit-exact, pixels within the usual bar."""
     import jxlo
     from test_gpu_parity import _compare
     J = built
@@ -147,6 +148,34 @@ def test_prefix_coded_and_lz77_ac_streams(built, mode):
     assert np.abs(rgb.astype(int) - J.decode_rgb8(base).astype(int)).max() <= 1  # same image as the rANS stream
     _compare(J, jxlo, J.encode_random(300, 260, seed=5 + mode, ac_code_mode=mode))
     _compare(J, jxlo, J.encode_rgb8(J.synth_image(300, 200, seed=4), ac_code_mode=mode, num_passes=2, num_histograms=3))
+
+
+def test_prefix_streams_on_both_kernels_and_in_a_batch(built, monkeypatch):
+    """Prefix-coded frames: the lane kernel's prefix form against the wave-per-section kernel (JXLHIP_NO_LANE_PREFIX=1),
+    and a set of frames (one launch) against single decodes."""
+    J = built
+    imgs = [J.synth_image(600, 420, seed=20 + i) for i in range(3)]
+    datas = [J.encode_rgb8(im, ac_code_mode=1, distance=1.0 + 0.5 * i) for i, im in enumerate(imgs)]
+    single = [J.decode_rgb8(d) for d in datas]
+    monkeypatch.setenv("JXLHIP_NO_LANE_PREFIX", "1")
+    generic = [J.decode_rgb8(d) for d in datas]
+    monkeypatch.delenv("JXLHIP_NO_LANE_PREFIX")
+    for a, b in zip(single, generic):
+        assert np.array_equal(a, b)
+    frames = [J.Frame(d) for d in datas]
+    ctxs = [J.HipContext() for _ in datas]
+    for c, f in zip(ctxs, frames):
+        c.upload(f)
+    J.run_entropy_batch(ctxs)
+    J.run_transform_batch(ctxs)
+    J.run_filter_color_batch(ctxs)
+    for c, want in zip(ctxs, single):
+        assert np.array_equal(c.rgb8(), want)
+        r, flags = c.errors()
+        assert r == 0 and not any(flags)
+    for c, f in zip(ctxs, frames):
+        c.close()
+        f.close()
 
 
 def test_image_with_alpha_in_group_sections(built, tmp_path):
