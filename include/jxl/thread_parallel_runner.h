@@ -14,14 +14,6 @@ JXL_THREADS_EXPORT JxlParallelRetCode JxlThreadParallelRunner(void* runner_opaqu
 JXL_THREADS_EXPORT void* JxlThreadParallelRunnerCreate(const JxlMemoryManager* memory_manager, size_t num_worker_threads);
 JXL_THREADS_EXPORT void JxlThreadParallelRunnerDestroy(void* runner_opaque);
 JXL_THREADS_EXPORT size_t JxlThreadParallelRunnerDefaultNumWorkerThreads(void);
-/* Resizable variant (reference lib/include/jxl/resizable_parallel_runner.h). */
-JXL_THREADS_EXPORT JxlParallelRetCode JxlResizableParallelRunner(void* runner_opaque, void* jpegxl_opaque,
-                                                                 JxlParallelRunInit init, JxlParallelRunFunction func,
-                                                                 uint32_t start_range, uint32_t end_range);
-JXL_THREADS_EXPORT void* JxlResizableParallelRunnerCreate(const JxlMemoryManager* memory_manager);
-JXL_THREADS_EXPORT void JxlResizableParallelRunnerSetThreads(void* runner_opaque, size_t num_threads);
-JXL_THREADS_EXPORT uint32_t JxlResizableParallelRunnerSuggestThreads(uint64_t xsize, uint64_t ysize);
-JXL_THREADS_EXPORT void JxlResizableParallelRunnerDestroy(void* runner_opaque);
 #ifdef __cplusplus
 }
 #endif

@@ -1,9 +1,10 @@
 // libjxl_amd — host side of the drop-in boundary: the JxlDecoder* C API subset (include/jxl/decode.h), the
-// JxlThreadParallelRunner / JxlResizableParallelRunner (include/jxl/thread_parallel_runner.h) and the frame-level
+// JxlThreadParallelRunner / JxlResizableParallelRunner (include/jxl/thread_parallel_runner.h, resizable_parallel_runner.h) and the frame-level
 // helpers of include/jxl_amd.h. Mirrors the behaviour of reference lib/jxl/decode.cc (event order, status values,
 // sticky errors, caller-owned input/output) for whole-file input; pixels come from the HIP layer only — if no
 // MI355X/HIP device is usable every decode fails with JXL_DEC_ERROR (there is deliberately no CPU fallback).
 #include <jxl/decode.h>
+#include <jxl/resizable_parallel_runner.h>
 #include <jxl/thread_parallel_runner.h>
 
 #include <atomic>

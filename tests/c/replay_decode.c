@@ -5,6 +5,7 @@
  * usage: replay_decode IN.jxl OUT.raw {u8|u16|f16|f32} CHANNELS [callback|mt] [chunk=N] [linear]
  * Prints one line per event; exit code 0 = decoded, 3 = stopped at the pixels because no GPU is present, else failure. */
 #include <jxl/decode.h>
+#include <jxl/resizable_parallel_runner.h>
 #include <jxl/thread_parallel_runner.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -25,7 +25,7 @@ def _declared_functions(header):
 
 def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(built.LIB_PATH)
-    headers = ["jxl_amd_hip.h", "jxl_amd.h", "jxl/decode.h", "jxl/thread_parallel_runner.h"]
+    headers = ["jxl_amd_hip.h", "jxl_amd.h", "jxl/decode.h", "jxl/thread_parallel_runner.h", "jxl/resizable_parallel_runner.h"]
     missing = []
     total = 0
     for h in headers:
