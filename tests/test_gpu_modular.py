@@ -115,6 +115,40 @@ def test_lossless_round_trip_every_feature(built, flags, size, channels):
     assert np.array_equal(out, img), "%d samples differ" % int((out != img).sum())
 
 
+@pytest.mark.parametrize("flags", [16 | 4 | 8, 1 | 2 | 16])
+def test_corrupt_modular_streams_are_flagged_not_fatal(built, flags):
+    """Damaged sample data (bytes flipped deep inside the group sections) must end as an error status of the affected
+    streams - ANS final state, over-read or LZ77 overflow - never as a device fault: every table index the kernel forms
+    is validated at upload or bounded by construction, every sample write stays inside its channel rectangle."""
+    J = built
+    img = _lossless_image(J, 600, 400, 3, seed=3)
+    data = bytearray(J.encode_lossless(img, flags))
+    rng = np.random.default_rng(5)
+    for pos in rng.integers(len(data) // 2, len(data) - 8, 40):
+        data[int(pos)] ^= 0x5A
+    try:
+        f = J.ModFrame(bytes(data))
+    except J.JxlAmdError:
+        return  # (the damage reached a header the host front-end checks)
+    c = J.HipContext()
+    try:
+        c.upload_modular(f)
+        c.run_modular()
+        r, status, _ = c.modular_status()
+        assert r != 0 and any(status), "40 flipped bytes went unnoticed"
+        # the context stays usable
+        g = J.ModFrame(J.encode_lossless(img, flags))
+        c.upload_modular(g)
+        c.run_modular()
+        r, status, _ = c.modular_status()
+        assert r == 0 and not any(status)
+        assert np.array_equal(c.pixels(), img)
+        g.close()
+    finally:
+        c.close()
+        f.close()
+
+
 @pytest.mark.parametrize("lanes", [4, 64])
 def test_several_streams_per_wave(built, lanes, monkeypatch):
     """Small frames put one stream in a wave; sets of many frames put up to 64 (jxlhip_modular_run_batch chooses): the
