@@ -631,9 +631,10 @@ def main():
             "stage_gbs": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9, 2) for s in range(3)},
             "stage_hbm_frac": {names[s]: round(alg[names[s]] / (stage_ms[s] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for s in range(3)},
         }
-        if args.e2e_frames > 0 and args.shard == "frames":
+        # (the end-to-end and the CPU legs: one-GPU runs only, so that the ranks of a scaling run end together)
+        if args.e2e_frames > 0 and args.shard == "frames" and world == 1:
             out["e2e"] = end_to_end(J, datas, args.e2e_frames, local_rank, xsize, ysize)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             ref = system_libjxl_baseline(data, xsize, ysize, os.cpu_count() or 1)
             out["cpu_baseline"] = ref if ref else cpu_baseline(data, xsize, ysize)
         print(json.dumps(out))
