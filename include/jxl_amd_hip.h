@@ -59,9 +59,12 @@ typedef struct JxlHipPassDesc {
   uint32_t orders_size;
   uint32_t order_offset[39];  /* [bucket * 3 + channel] -> first entry in `orders` */
   uint32_t shift;             /* left shift applied to this pass's coefficients */
-  /* Prefix-coded streams (dec_huffman.h:28-41; libjxl's fastest efforts) instead of rANS: per cluster
-   * prefix_offset[cluster] = first entry of its lookup table | max code length << 24 (0 = one symbol, no bits),
-   * prefix_table[first + (next max_len bits)] = code length | symbol << 8. alias / log_alpha are unused then. */
+  /* Prefix-coded streams (dec_huffman.h:28-41; libjxl's fastest efforts) instead of rANS, as two-level lookup tables
+   * (like the reference's own decoder, dec_huffman.cc): per cluster prefix_offset[cluster] = first entry of its root
+   * table | root index bits R << 24 (R = min(8, longest code); 0 = one symbol, no bits). Root entry, indexed by the next
+   * R bits of the stream (first bit = bit 0): code of <= R bits: symbol << 8 | code length; longer codes: (second-level
+   * table, relative to the root's first entry) << 8 | 0x80 | S; second-level entry, indexed by the S bits after the
+   * first R: symbol << 8 | total code length. alias / log_alpha are unused then. */
   uint32_t use_prefix;
   const uint32_t* prefix_table;
   uint32_t prefix_table_size;

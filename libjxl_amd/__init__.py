@@ -130,7 +130,8 @@ class Frame:
 class ModFrame:
     """Host-parsed Modular (lossless) frame: headers, trees, histograms, stream descriptors; samples stay compressed."""
 
-    INFO = ("xsize", "ysize", "num_color", "has_alpha", "bits", "num_streams", "num_buffers", "num_ops", "num_extra", "section_bytes")
+    INFO = ("xsize", "ysize", "num_color", "has_alpha", "bits", "num_streams", "num_buffers", "num_ops", "num_extra", "section_bytes",
+            "max_table_words", "lz77", "max_tree_nodes")
 
     def __init__(self, data):
         L = lib()

@@ -288,6 +288,22 @@ void jxlamd_modframe_info(const JxlAmdModFrame* f, uint32_t* info) {
   uint64_t total = 0;
   for (uint32_t s : P.section_size) total += s;
   info[9] = uint32_t(total);
+  // largest symbol-table set (32-bit words as the stream kernel stages them), LZ77 anywhere, largest tree
+  uint32_t words = 0, lz = 0, nodes = 0;
+  for (size_t i = 0; i < P.codes.size(); i++) {
+    const jxh::EntropyCode& c = P.codes[i];
+    if (P.trees[i].empty()) continue;
+    std::vector<uint32_t> ptab;
+    if (c.use_prefix)
+      for (const jxh::PrefixCode& pc : c.prefix) (void)jxh::AppendPrefixTables(pc, &ptab);
+    const uint32_t w = c.use_prefix ? uint32_t(ptab.size() + 2 * c.num_clusters) : uint32_t((c.num_clusters << c.log_alpha) * 2 + c.num_clusters);
+    words = std::max(words, w);
+    lz |= c.lz77 ? 1u : 0u;
+    nodes = std::max<uint32_t>(nodes, uint32_t(P.trees[i].size()));
+  }
+  info[10] = words;
+  info[11] = lz;
+  info[12] = nodes;
 }
 uint32_t jxlamd_modframe_extra_buffer(const JxlAmdModFrame* f, uint32_t index) {
   return f && index < f->plan.extra_buffer.size() ? f->plan.extra_buffer[index] : 0xFFFFFFFFu;
@@ -346,10 +362,7 @@ int jxlamd_modframe_upload(const JxlAmdModFrame* f, JxlHipContext* ctx) {
     for (const jxh::HybridCfg& h : c.cfg) cfgs[i].push_back(h.split_exp | (h.msb << 8) | (h.lsb << 16));
     o.uint_cfg = cfgs[i].data();
     if (c.use_prefix) {
-      for (const jxh::PrefixCode& pc : c.prefix) {
-        poffs[i].push_back(uint32_t(ptabs[i].size()) | (uint32_t(pc.max_len) << 24));
-        for (size_t k = 0; k < pc.sym.size(); k++) ptabs[i].push_back(uint32_t(pc.len[k]) | (uint32_t(pc.sym[k]) << 8));
-      }
+      for (const jxh::PrefixCode& pc : c.prefix) poffs[i].push_back(jxh::AppendPrefixTables(pc, &ptabs[i]));
       o.prefix_table = ptabs[i].data();
       o.prefix_table_size = uint32_t(ptabs[i].size());
       o.prefix_offset = poffs[i].data();

@@ -188,6 +188,7 @@ struct JxlHipContext {
     std::vector<const JxlHipContext*> batch_ctxs;
     std::vector<uint64_t> batch_gens;
     uint32_t batch_n = 0, batch_tree_cap = 0, batch_table_cap = 0;
+    bool batch_wp = true, batch_refs = true;
     std::vector<uint32_t> code_table_words;  // per entropy code: words of its symbol tables (ModCode::table_words)
     Buf batch_ops;                            // parameter blocks of the set's transform / output launches
     std::vector<ModLaunch> batch_launches;
@@ -294,6 +295,25 @@ static size_t OutSampleBytes(const JxlHipContext* c) { return c->out_type == 2 ?
 static size_t OutPixelBytes(const JxlHipContext* c) { return OutSampleBytes(c) * c->out_nc; }
 static bool OutIsRgb8(const JxlHipContext* c) { return c->out_type == 2 && c->out_nc == 3 && c->out_bits == 8; }
 static bool OutIsRgbF32(const JxlHipContext* c) { return c->out_type == 0 && c->out_nc == 3 && !c->out_swap; }
+
+// Every index PrefixLookup (jxl_hip_kernels.h) can form from a cluster's two-level tables stays inside `table`, and
+// every code length it can return is at most 15 bits.
+static bool ValidPrefixTables(uint32_t offset_word, const uint32_t* table, size_t table_size) {
+  const size_t first = offset_word & 0xFFFFFFu, root_bits = offset_word >> 24;
+  if (root_bits > 15 || first + (size_t(1) << root_bits) > table_size) return false;
+  for (size_t r = 0; r < (size_t(1) << root_bits); r++) {
+    const uint32_t e = table[first + r];
+    if (!(e & 0x80u)) {
+      if ((e & 0xFFu) > 15) return false;
+      continue;
+    }
+    const size_t sub_bits = e & 0x7Fu, sub = first + (e >> 8);
+    if (sub_bits == 0 || root_bits + sub_bits > 15 || sub + (size_t(1) << sub_bits) > table_size) return false;
+    for (size_t j = 0; j < (size_t(1) << sub_bits); j++)
+      if ((table[sub + j] & 0x80u) || (table[sub + j] & 0xFFu) > 15) return false;
+  }
+  return true;
+}
 
 static int EnvInt(const char* name, int def) {
   const char* e = getenv(name);
@@ -705,10 +725,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     if (s.use_prefix) {  // every table index the kernel can form must be inside the table
       if (!s.prefix_offset || !s.prefix_table) return JXLHIP_ERR_INVALID_ARGUMENT;
       for (uint32_t i = 0; i < s.num_clusters; i++) {
-        const uint32_t first = s.prefix_offset[i] & 0xFFFFFFu, max_len = s.prefix_offset[i] >> 24;
-        if (max_len > 15 || size_t(first) + (size_t(1) << max_len) > s.prefix_table_size) return JXLHIP_ERR_INVALID_ARGUMENT;
-        for (size_t j = 0; j < (size_t(1) << max_len); j++)
-          if ((s.prefix_table[first + j] & 0xFF) > max_len) return JXLHIP_ERR_INVALID_ARGUMENT;
+        if (!ValidPrefixTables(s.prefix_offset[i], s.prefix_table, s.prefix_table_size)) return JXLHIP_ERR_INVALID_ARGUMENT;
       }
     }
     if (s.lz77 && (s.lz_dist_ctx >= s.num_clusters || s.lz_min_length == 0)) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -1787,10 +1804,7 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
     if (!k.use_prefix && (k.log_alpha < 5 || k.log_alpha > 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
     if (k.use_prefix)
       for (uint32_t j = 0; j < k.num_clusters; j++) {
-        const uint32_t first = k.prefix_offset[j] & 0xFFFFFFu, max_len = k.prefix_offset[j] >> 24;
-        if (max_len > 15 || size_t(first) + (size_t(1) << max_len) > k.prefix_table_size) return JXLHIP_ERR_INVALID_ARGUMENT;
-        for (size_t q = 0; q < (size_t(1) << max_len); q++)
-          if ((k.prefix_table[first + q] & 0xFF) > max_len) return JXLHIP_ERR_INVALID_ARGUMENT;
+        if (!ValidPrefixTables(k.prefix_offset[j], k.prefix_table, k.prefix_table_size)) return JXLHIP_ERR_INVALID_ARGUMENT;
       }
     if (k.lz77 && (k.lz_dist_ctx >= k.num_clusters || !k.lz_min_length)) return JXLHIP_ERR_INVALID_ARGUMENT;
     code_parts[i] = {put(k.ctx_map, k.ctx_map_size), put(k.alias, k.use_prefix ? 0 : (size_t(k.num_clusters) << k.log_alpha) * 8),
@@ -2106,6 +2120,11 @@ extern "C" int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n) {
     for (const Ref& q : all)
       if (q.s->tree_nodes <= jxlhip::kModTreeLdsNodes && q.s->tree_nodes > cap) cap = q.s->tree_nodes;
     M0.batch_tree_cap = cap;
+    M0.batch_wp = M0.batch_refs = false;  // the kernel form: what some stream of the launch needs
+    for (const Ref& q : all) {
+      M0.batch_wp = M0.batch_wp || q.s->uses_wp != 0;
+      M0.batch_refs = M0.batch_refs || q.s->num_props > 16;
+    }
     uint32_t tcap = 0;  // likewise for the largest set of symbol tables that fits
     for (size_t i = 0; i < n; i++)
       for (uint32_t w : ctxs[i]->mod.code_table_words)
@@ -2135,9 +2154,11 @@ extern "C" int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n) {
     const int forced = EnvInt("JXLHIP_MOD_LANES", 0);
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64) lanes = uint32_t(forced);
     const uint32_t lds = jxlhip::ModLdsBytes(lanes, M0.batch_tree_cap, M0.batch_table_cap);
+    auto kernel = M0.batch_wp ? (M0.batch_refs ? jxlhip::k_modular_streams<true, true> : jxlhip::k_modular_streams<true, false>)
+                              : (M0.batch_refs ? jxlhip::k_modular_streams<false, true> : jxlhip::k_modular_streams<false, false>);
     if (lds > 48 * 1024)
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(jxlhip::k_modular_streams), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-    hipLaunchKernelGGL(jxlhip::k_modular_streams, dim3((M0.batch_n + lanes - 1) / lanes), dim3(64), lds, c0->stream,
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+    hipLaunchKernelGGL(kernel, dim3((M0.batch_n + lanes - 1) / lanes), dim3(64), lds, c0->stream,
                        M0.batch_streams.as<jxlhip::ModStream>(), M0.batch_n, lanes, M0.batch_tree_cap, M0.batch_table_cap);
     HIP_TRY(hipGetLastError());
   }

@@ -88,8 +88,8 @@ __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t n
 // hot trip is one basic block whose independent instructions the scheduler can interleave with the serial chain.
 // GALIAS = true: the alias entry comes from `galias` (global memory, same packed form) instead of LDS offset 0: one
 // cached global round trip on the serial chain per token, in exchange for 16-64 KB less LDS per frame.
-// PREFIX = true: a prefix code instead of rANS (dec_huffman.h:28-41 in the table form the host builds: l_poff[cluster] =
-// first entry | longest code << 24, ptable[first + next `longest` bits] = symbol << 8 | code length); `state` is unused.
+// PREFIX = true: a prefix code instead of rANS (dec_huffman.h:28-41 in the two-level table form the host builds:
+// l_poff[cluster] = first entry | root bits << 24, see PrefixLookup); `state` is unused.
 template <bool FLAT = false, bool GALIAS = false, bool PREFIX = false>
 __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state, uint32_t& bitpos, const uint32_t* ring, uint32_t LS,
                                                uint32_t log_ls, const uint8_t* lds, const uint16_t* l_cfg, uint32_t log_entry,
@@ -105,7 +105,7 @@ __device__ __forceinline__ uint32_t LaneSymbol(uint32_t cluster, uint32_t& state
     const uint32_t w2 = *(LdsVolatile)(ring + s0 + 2 * LS);
     const uint32_t boff = bitpos & 31;
     const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, boff);
-    const uint32_t e = ptable[(po & 0xFFFFFFu) + (win & ((1u << (po >> 24)) - 1))];
+    const uint32_t e = PrefixLookup(ptable + (po & 0xFFFFFFu), po >> 24, win);
     uint32_t tok = e >> 8;
     const uint32_t len = e & 0xFFu;
     bitpos += len;

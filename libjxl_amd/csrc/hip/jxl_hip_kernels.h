@@ -299,6 +299,14 @@ __global__ __launch_bounds__(64) void k_entropy_ans(EntropyParams P) {
 // The streams libjxl's fastest and slowest efforts write: prefix codes instead of rANS (dec_huffman.h:28-41, dec_ans.h:
 // 170-197) and / or LZ77 copies of earlier values (dec_ans.h:288-353). Same walk as k_entropy_ans, tables in global
 // memory, one lane per section: the correctness path for these streams, not a tuned one.
+// Prefix-code lookup in the two-level tables the host builds (jxh_entropy.h AppendPrefixTables): `tab` = the cluster's
+// root, `root_bits` its index width, `bits` = the next >= 15 bits of the stream. Returns symbol << 8 | code length.
+__device__ __forceinline__ uint32_t PrefixLookup(const uint32_t* tab, uint32_t root_bits, uint32_t bits) {
+  uint32_t e = tab[bits & ((1u << root_bits) - 1)];
+  if (e & 0x80u) e = tab[(e >> 8) + ((bits >> root_bits) & ((1u << (e & 0x7Fu)) - 1))];
+  return e;
+}
+
 struct GenericReader {
   BitReader br;
   uint32_t state;
@@ -311,9 +319,8 @@ __device__ __forceinline__ uint32_t GenericSymbol(GenericReader& r, uint32_t clu
   const PassDev& T = *r.T;
   BrRefill(r.br);
   if (T.use_prefix) {
-    const uint32_t po = T.prefix_offset[cluster], max_len = po >> 24;
-    if (max_len == 0) return T.prefix_table[po & 0xFFFFFFu] >> 8;
-    const uint32_t e = T.prefix_table[(po & 0xFFFFFFu) + uint32_t(r.br.buf & ((1u << max_len) - 1))];
+    const uint32_t po = T.prefix_offset[cluster];
+    const uint32_t e = PrefixLookup(T.prefix_table + (po & 0xFFFFFFu), po >> 24, uint32_t(r.br.buf));
     BrRead(r.br, e & 0xFF);
     return e >> 8;
   }

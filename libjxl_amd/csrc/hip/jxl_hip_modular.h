@@ -87,6 +87,23 @@ __constant__ int8_t c_special_distances[120][2] = {
     {8, 0},  {4, 7},  {-4, 7}, {7, 4},  {-7, 4}, {8, 1},  {8, 2},  {6, 6},  {-6, 6}, {8, 3},  {5, 7},  {-5, 7},
     {7, 5},  {-7, 5}, {8, 4},  {6, 7},  {-6, 7}, {7, 6},  {-7, 6}, {8, 5},  {7, 7},  {-7, 7}, {8, 6},  {8, 7}};
 
+// Four consecutive samples of a channel row in one 16-byte access (rows are only 4-byte aligned). A lane's accesses go to
+// cache lines of its own, and the memory pipeline takes such a wave-instruction one lane at a time: the stream kernel is
+// bound by the NUMBER of its global accesses per sample (~70 G lane-accesses/s for the whole device), so samples move
+// four at a time.
+typedef int32_t ModI4 __attribute__((ext_vector_type(4), aligned(4)));
+// Samples [pos, pos + 4) of `row`, zeros outside [0, w) or when the row does not exist.
+__device__ __forceinline__ ModI4 ModLoadChunk(const int32_t* row, uint32_t pos, uint32_t w, bool row_exists) {
+  ModI4 v = {0, 0, 0, 0};
+  if (!row_exists || pos >= w) return v;
+  if (pos + 3 < w) return *reinterpret_cast<const ModI4*>(row + pos);
+  v.x = row[pos];
+  if (pos + 1 < w) v.y = row[pos + 1];
+  if (pos + 2 < w) v.z = row[pos + 2];
+  return v;
+}
+__device__ __forceinline__ int32_t ModPick(const ModI4& v, uint32_t k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+
 // Bit reader with the next word loaded ahead (the refill that consumes it issues the following load).
 struct ModBits {
   const uint32_t* p;
@@ -124,15 +141,27 @@ struct ModReader {
   const uint32_t* ltab;  // the code's tables in LDS (alias or prefix table | cfg | prefix offsets), or NULL
   uint32_t* window;
   uint32_t mask, num_decoded, num_to_copy, copy_pos, num_special, dist_mult, err;
+  ModI4 wlast;  // the last four window values (LZ77): the window itself is written four values at a time
 };
+// LZ77 window (dec_ans.h:288-353): value `v` becomes entry num_decoded; entries reach memory as aligned 16-byte chunks.
+__device__ __forceinline__ void ModWindowPush(ModReader& r, uint32_t v) {
+  r.wlast.x = r.wlast.y;
+  r.wlast.y = r.wlast.z;
+  r.wlast.z = r.wlast.w;
+  r.wlast.w = int32_t(v);
+  r.num_decoded++;
+  if ((r.num_decoded & 3u) == 0) *reinterpret_cast<ModI4*>(r.window + ((r.num_decoded - 4) & r.mask)) = r.wlast;
+}
+__device__ __forceinline__ uint32_t ModWindowGet(const ModReader& r, uint32_t pos) {  // pos < num_decoded
+  if (pos + 4 >= r.num_decoded) return uint32_t(ModPick(r.wlast, pos + 4 - r.num_decoded));
+  return r.window[pos & r.mask];
+}
 __device__ __forceinline__ uint32_t ModSymbol(ModReader& r, uint32_t cluster) {
   const ModCode& T = r.T;
   MbRefill(r.br);
   if (T.use_prefix) {
-    const uint32_t po = r.ltab ? r.ltab[T.table_words - T.num_clusters + cluster] : T.prefix_offset[cluster], max_len = po >> 24;
-    const uint32_t at = (po & 0xFFFFFFu) + (max_len ? uint32_t(r.br.buf & ((1u << max_len) - 1)) : 0u);
-    const uint32_t e = r.ltab ? r.ltab[at] : T.prefix_table[at];
-    if (max_len == 0) return e >> 8;
+    const uint32_t po = r.ltab ? r.ltab[T.table_words - T.num_clusters + cluster] : T.prefix_offset[cluster];
+    const uint32_t e = PrefixLookup((r.ltab ? r.ltab : T.prefix_table) + (po & 0xFFFFFFu), po >> 24, uint32_t(r.br.buf));
     MbRead(r.br, e & 0xFF);
     return e >> 8;
   }
@@ -160,10 +189,10 @@ __device__ __forceinline__ uint32_t ModRead(ModReader& r, uint32_t cluster) {
   const ModCode& T = r.T;
   if (T.lz77 && r.num_to_copy > 0) {
     // (copy_pos == num_decoded only for a copy at the very start of a stream, distance 0: zeros, dec_ans.h:320-327)
-    const uint32_t v = r.copy_pos >= r.num_decoded ? 0u : r.window[r.copy_pos & r.mask];
+    const uint32_t v = r.copy_pos >= r.num_decoded ? 0u : ModWindowGet(r, r.copy_pos);
     r.copy_pos++;
     r.num_to_copy--;
-    r.window[(r.num_decoded++) & r.mask] = v;
+    ModWindowPush(r, v);
     return v;
   }
   const uint32_t cfg_at = T.use_prefix ? T.table_words - 2 * T.num_clusters : T.table_words - T.num_clusters;
@@ -188,14 +217,14 @@ __device__ __forceinline__ uint32_t ModRead(ModReader& r, uint32_t cluster) {
       return 0;
     }
     // (distance 0 only at the very start of a stream: the reference zero-fills the window then)
-    const uint32_t v = distance == 0 ? 0u : r.window[(r.copy_pos++) & r.mask];
-    if (distance == 0) r.copy_pos++;
+    const uint32_t v = distance == 0 ? 0u : ModWindowGet(r, r.copy_pos);
+    r.copy_pos++;
     r.num_to_copy--;
-    r.window[(r.num_decoded++) & r.mask] = v;
+    ModWindowPush(r, v);
     return v;
   }
   const uint32_t v = ModUint(r, cfg, token);
-  if (T.lz77) r.window[(r.num_decoded++) & r.mask] = v;
+  if (T.lz77) ModWindowPush(r, v);
   return v;
 }
 
@@ -324,6 +353,9 @@ __host__ __device__ inline uint32_t ModLdsBytes(uint32_t lanes, uint32_t tree_ca
 }
 
 // One lane per stream, `lanes` (a power of two, <= 64) streams per workgroup; `streams` holds `n` descriptors.
+// WP / REFS = false compile the weighted predictor / the previous-channel properties out (the host picks the form no
+// stream of the launch needs more than): half the registers, twice the waves per SIMD to hide the chain's latencies.
+template <bool WP, bool REFS>
 __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams, uint32_t n, uint32_t lanes, uint32_t tree_cap, uint32_t table_cap) {
   extern __shared__ __align__(16) uint8_t mod_lds[];
   const uint32_t lane = threadIdx.x;
@@ -381,6 +413,7 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
   r.window = S.lz_window;
   r.mask = S.lz_window_mask;
   r.num_decoded = r.num_to_copy = r.copy_pos = 0;
+  r.wlast = ModI4{0, 0, 0, 0};
   r.dist_mult = S.dist_multiplier;
   r.num_special = S.dist_multiplier ? 120u : 0u;
   r.err = 0;
@@ -398,7 +431,7 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
   auto node = [&](uint32_t pos) -> int4 { return tree_lds ? ltree[pos] : gtree[pos]; };
 #pragma unroll
   for (int i = 0; i < kModMaxProps; i++) lprops[i * lanes] = 0;
-  const bool wp_on = S.uses_wp != 0;
+  const bool wp_on = WP && S.uses_wp != 0;
   for (uint32_t ci = 0; ci < S.num_channels && !r.err; ci++) {
     const ModChannel ch = S.channels[ci];
     if (!ch.w || !ch.h) continue;
@@ -407,7 +440,7 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
     const int32_t* ref_data[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t ref_stride[4] = {0, 0, 0, 0};
     uint32_t nrefs = 0;
-    for (int j = int(ci) - 1; j >= 0 && nrefs * 4 < S.num_props - 16 && nrefs < 4; j--) {
+    for (int j = int(ci) - 1; REFS && j >= 0 && nrefs * 4 < S.num_props - 16 && nrefs < 4; j--) {
       const ModChannel o = S.channels[j];
       if (o.sig == ch.sig && o.w == ch.w && o.h == ch.h) {
 #pragma unroll
@@ -441,14 +474,19 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
       int32_t prev9 = 0;
       // the row above at x, x - 1, x + 1, x + 2 and two rows above at x: a sliding window (raw samples; the edge rules
       // are applied where the neighbours are formed)
-      int32_t rN = y ? pN[0] : 0, rNW = 0, rNE = (y && w > 1) ? pN[1] : 0, rNEE = (y && w > 2) ? pN[2] : 0;
-      int32_t rNN = y > 1 ? pNN[0] : 0;
+      // (fed by 16-byte chunks: cN / cNN hold the chunk the next look-ahead values come from, nN / nNN the one after it,
+      // loaded four samples ahead of its first use)
+      ModI4 cN = ModLoadChunk(pN, 0, w, y > 0), nN = ModLoadChunk(pN, 4, w, y > 0);
+      ModI4 cNN = ModLoadChunk(pNN, 0, w, y > 1), nNN = ModLoadChunk(pNN, 4, w, y > 1);
+      int32_t rN = cN.x, rNW = 0, rNE = cN.y, rNEE = cN.z;
+      int32_t rNN = cNN.x;
       int32_t rW = 0, rWW = 0;
+      ModI4 outv = {0, 0, 0, 0};  // the last samples of this row, stored four at a time
       // previous channels: this row and the one above at x and x - 1
       int32_t rv[4] = {0, 0, 0, 0}, rvl[4] = {0, 0, 0, 0}, rvt[4] = {0, 0, 0, 0}, rvtl[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        if (uint32_t(j) < nrefs) {
+        if (REFS && uint32_t(j) < nrefs) {
           rv[j] = ref_data[j][size_t(y) * ref_stride[j]];
           rvt[j] = y ? ref_data[j][size_t(y - 1) * ref_stride[j]] : 0;
         }
@@ -479,8 +517,17 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
       }
       for (uint32_t x = 0; x < w; x++) {
         // ---- loads for the next sample first (nothing below waits for them)
-        const int32_t aNEE = (y && x + 3 < w) ? pN[x + 3] : 0;
-        const int32_t aNN = (y > 1 && x + 1 < w) ? pNN[x + 1] : 0;
+        // pN[x + 3] and pNN[x + 1] out of the chunks (zeros beyond the row: the edge rules never use them)
+        if (((x + 3) & 3) == 0) {
+          cN = nN;
+          nN = ModLoadChunk(pN, x + 7, w, y > 0);
+        }
+        if (((x + 1) & 3) == 0) {
+          cNN = nNN;
+          nNN = ModLoadChunk(pNN, x + 5, w, y > 1);
+        }
+        const int32_t aNEE = ModPick(cN, (x + 3) & 3);
+        const int32_t aNN = ModPick(cNN, (x + 1) & 3);
         int4 a_pe = make_int4(0, 0, 0, 0);
         int32_t a_te = 0;
         const bool a_valid = x + 2 < w;
@@ -491,7 +538,7 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
         int32_t av[4] = {0, 0, 0, 0}, avt[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (uint32_t(j) < nrefs && x + 1 < w) {
+          if (REFS && uint32_t(j) < nrefs && x + 1 < w) {
             av[j] = ref_data[j][size_t(y) * ref_stride[j] + x + 1];
             avt[j] = y ? ref_data[j][size_t(y - 1) * ref_stride[j] + x + 1] : 0;
           }
@@ -525,7 +572,7 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
         }
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          if (uint32_t(j) < nrefs) {
+          if (REFS && uint32_t(j) < nrefs) {
             const int64_t v = rv[j];
             const int64_t vl = x ? rvl[j] : 0;
             const int64_t vt = y ? rvt[j] : vl;
@@ -546,7 +593,18 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
         const uint32_t v = ModRead(r, uint32_t(nd.z));
         const int64_t val = int64_t(int32_t((v >> 1) ^ (0u - (v & 1)))) * int64_t(uint32_t(nd.w)) + guess;
         const int32_t out = int32_t(val);
-        p[x] = out;
+        outv.x = outv.y;
+        outv.y = outv.z;
+        outv.z = outv.w;
+        outv.w = out;
+        if ((x & 3) == 3) {
+          *reinterpret_cast<ModI4*>(p + (x - 3)) = outv;
+        } else if (x + 1 == w) {  // the row's last one to three samples
+          const uint32_t part = (x & 3) + 1;
+          if (part == 3) p[x - 2] = outv.y;
+          if (part >= 2) p[x - 1] = outv.z;
+          p[x] = outv.w;
+        }
         if (wp_on) ModWpUpdate(wp, out, wcur + size_t(x) * kModWpEntry, a_pe, a_te, a_valid);
         // ---- slide the windows
         rWW = rW;
@@ -557,7 +615,7 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
         rNEE = aNEE;
         rNN = aNN;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; REFS && j < 4; j++) {
           rvl[j] = rv[j];
           rvtl[j] = rvt[j];
           rv[j] = av[j];

@@ -42,6 +42,37 @@ struct PrefixCode {
   std::vector<uint8_t> len;
 };
 
+// The lookup form the GPU kernels read (two levels, like the reference's own decoder: dec_huffman.cc, 8 root bits):
+// appends `pc`'s tables to `table` and returns the cluster's offset word = first entry | root bits R << 24.
+//   root, 2^R entries indexed by the next R bits of the stream (first bit = bit 0), R = min(8, longest code):
+//     code of <= R bits:  symbol << 8 | length
+//     longer codes:       (second-level table, relative to the root's first entry) << 8 | 0x80 | S
+//   second level, 2^S entries indexed by the S bits after the first R:  symbol << 8 | total length
+constexpr int kPrefixRootBits = 8;
+static inline uint32_t AppendPrefixTables(const PrefixCode& pc, std::vector<uint32_t>* table) {
+  const size_t first = table->size();
+  const int R = std::min(kPrefixRootBits, pc.max_len);
+  JXH_CHECK(pc.max_len <= 15 && pc.sym.size() == (size_t(1) << pc.max_len), "prefix code: malformed lookup table");
+  table->resize(first + (size_t(1) << R));
+  for (size_t r = 0; r < (size_t(1) << R); r++) {
+    if (pc.len[r] <= R) {
+      (*table)[first + r] = uint32_t(pc.len[r]) | (uint32_t(pc.sym[r]) << 8);
+      continue;
+    }
+    int longest = 0;
+    for (size_t j = 0; j < (size_t(1) << (pc.max_len - R)); j++) longest = std::max(longest, int(pc.len[r | (j << R)]));
+    const int S = longest - R;
+    const size_t sub = table->size();
+    (*table)[first + r] = uint32_t((sub - first) << 8) | 0x80u | uint32_t(S);
+    for (size_t j = 0; j < (size_t(1) << S); j++) {
+      const size_t i = r | (j << R);
+      table->push_back(uint32_t(pc.len[i]) | (uint32_t(pc.sym[i]) << 8));
+    }
+  }
+  JXH_CHECK(table->size() < (size_t(1) << 24), "prefix tables too large");
+  return uint32_t(first) | (uint32_t(R) << 24);
+}
+
 struct EntropyCode {
   bool use_prefix = false;
   int log_alpha = 8;

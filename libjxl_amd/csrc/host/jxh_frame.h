@@ -568,9 +568,7 @@ class FrameParser {
         T.prefix_offset.resize(code.num_clusters);
         for (size_t k = 0; k < code.num_clusters; k++) {
           const PrefixCode& pc = code.prefix[k];
-          T.prefix_offset[k] = uint32_t(T.prefix_table.size()) | (uint32_t(pc.max_len) << 24);
-          JXH_CHECK(T.prefix_table.size() + pc.sym.size() < (size_t(1) << 24), "prefix tables too large");
-          for (size_t i = 0; i < pc.sym.size(); i++) T.prefix_table.push_back(uint32_t(pc.len[i]) | (uint32_t(pc.sym[i]) << 8));
+          T.prefix_offset[k] = AppendPrefixTables(pc, &T.prefix_table);
         }
       }
       if (T.lz77) {
