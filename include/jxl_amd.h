@@ -55,6 +55,11 @@ int jxlamd_modframe_upload(const JxlAmdModFrame* frame, JxlHipContext* ctx);
 uint32_t jxlamd_modframe_extra_buffer(const JxlAmdModFrame* frame, uint32_t index);
 /* Thread-local description of the last failure of a jxlamd_* call ("" if none). */
 const char* jxlamd_last_error(void);
+/* Decodes a coded ICC profile: the entropy-coded, predicted byte stream that follows the headers of an image whose
+ * ImageMetadata.color_encoding has want_icc (lib/jxl/icc_codec.cc:128-428). Returns 0 on success; *profile_size = bytes
+ * of the profile, *coded_bits = exact length of the coded form; the profile is copied when out_size is large enough. */
+int jxlamd_icc_decode(const uint8_t* coded, size_t size, uint8_t* out, size_t out_size, size_t* profile_size, size_t* coded_bits);
+
 #ifdef __cplusplus
 }
 #endif

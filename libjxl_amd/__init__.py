@@ -374,6 +374,30 @@ def _params(**kw):
     return p
 
 
+def icc_decode(coded):
+    """Coded ICC profile (the stream behind an image's headers) -> (profile bytes, exact length of the coded form in bits)."""
+    L = lib()
+    L.jxlamd_icc_decode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                    ctypes.POINTER(ctypes.c_size_t)]
+    n, bits = ctypes.c_size_t(), ctypes.c_size_t()
+    _check(L.jxlamd_icc_decode(coded, len(coded), None, 0, ctypes.byref(n), ctypes.byref(bits)), "jxlamd_icc_decode")
+    out = ctypes.create_string_buffer(max(1, n.value))
+    _check(L.jxlamd_icc_decode(coded, len(coded), out, n.value, ctypes.byref(n), ctypes.byref(bits)), "jxlamd_icc_decode")
+    return out.raw[:n.value], bits.value
+
+
+def set_embedded_icc(coded=None):
+    """Test aid: the synthetic encoders embed this coded ICC profile (want_icc) in the streams they write from now on
+    (None: no profile again)."""
+    E = _enc_lib()
+    E.jxlenc_set_embedded_icc.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t]
+    if not coded:
+        E.jxlenc_set_embedded_icc(b"", 0, 0)
+        return
+    _, bits = icc_decode(coded)
+    E.jxlenc_set_embedded_icc(coded, len(coded), bits)
+
+
 def synth_image(xsize, ysize, seed=177):
     """Deterministic synthetic RGB8 test image (gradient background, rectangles, discs, texture, noise)."""
     a = np.zeros((ysize, xsize, 3), np.uint8)

@@ -244,6 +244,26 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   return r;
 }
 
+// Decodes a coded ICC profile (the byte stream that follows the headers of an image with want_icc: jxh_icc.h). Returns
+// 0 and the profile size / the exact number of bits the coded form takes; copies the profile when `out` has room.
+int jxlamd_icc_decode(const uint8_t* coded, size_t size, uint8_t* out, size_t out_size, size_t* profile_size, size_t* coded_bits) {
+  g_last_error.clear();
+  try {
+    std::vector<uint8_t> padded(coded, coded + size);
+    padded.resize(size + 16, 0);
+    jxh::BitReader br(padded.data(), size);
+    std::vector<uint8_t> icc;
+    jxh::ReadIcc(br, &icc);
+    if (profile_size) *profile_size = icc.size();
+    if (coded_bits) *coded_bits = br.BitPos();
+    if (out && out_size >= icc.size()) memcpy(out, icc.data(), icc.size());
+    return 0;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ Modular frames
 }  // extern "C"
 struct JxlAmdModFrame {
@@ -1183,8 +1203,17 @@ JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* d, size_t 
   if (info) memset(info, 0, sizeof(*info));
   return JXL_DEC_SUCCESS;
 }
+// The embedded ICC profile (ImageMetadata.color_encoding.want_icc, decoded by the host front-end: jxh_icc.h) answers for
+// the ORIGINAL colours, and for the pixels of images that are not XYB-coded (their samples are passed through); the
+// pixels of XYB images are sRGB / linear sRGB whatever the original profile was (no CMS is ever called).
+static const std::vector<uint8_t>* EmbeddedIcc(const JxlDecoder* d, JxlColorProfileTarget target) {
+  if (!d->ih.want_icc) return nullptr;
+  if (target == JXL_COLOR_PROFILE_TARGET_ORIGINAL || !d->ih.xyb_encoded) return &d->ih.icc;
+  return nullptr;
+}
 JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* d, JxlColorProfileTarget target, JxlColorEncoding* ce) {
   if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
+  if (EmbeddedIcc(d, target)) return JXL_DEC_ERROR;  // (decode.h:728-730: only the ICC form exists then)
   if (ce) {
     memset(ce, 0, sizeof(*ce));
     ce->color_space = d->ih.gray ? JXL_COLOR_SPACE_GRAY : JXL_COLOR_SPACE_RGB;
@@ -1202,12 +1231,20 @@ JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* d, JxlColo
   }
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* d, JxlColorProfileTarget, size_t* size) {
+JxlDecoderStatus JxlDecoderGetICCProfileSize(const JxlDecoder* d, JxlColorProfileTarget target, size_t* size) {
   if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
-  if (size) *size = 0;  // no ICC synthesis: the encoded profile is the primary representation (size 0 = none)
+  const std::vector<uint8_t>* icc = EmbeddedIcc(d, target);
+  // (without an embedded profile: no ICC synthesis, the encoded profile is the primary representation: size 0 = none)
+  if (size) *size = icc ? icc->size() : 0;
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder*, JxlColorProfileTarget, uint8_t*, size_t) { return JXL_DEC_ERROR; }
+JxlDecoderStatus JxlDecoderGetColorAsICCProfile(const JxlDecoder* d, JxlColorProfileTarget target, uint8_t* out, size_t size) {
+  if (!d->have_ih) return JXL_DEC_NEED_MORE_INPUT;
+  const std::vector<uint8_t>* icc = EmbeddedIcc(d, target);
+  if (!icc || !out || size < icc->size()) return JXL_DEC_ERROR;
+  memcpy(out, icc->data(), icc->size());
+  return JXL_DEC_SUCCESS;
+}
 JxlDecoderStatus JxlDecoderSetPreferredColorProfile(JxlDecoder* d, const JxlColorEncoding* ce) {
   return JxlDecoderSetOutputColorProfile(d, ce, nullptr, 0);
 }

@@ -735,6 +735,17 @@ struct FrameModel {
   std::vector<uint8_t> alpha;     // optional 8-bit alpha plane (xs * ys): one Modular-coded extra channel (dec_frame.cc:511-542)
 };
 
+// Test aid: a coded ICC profile (the byte stream lib/jxl/icc_codec.cc reads: U64 size, histograms, ANS data) that the
+// next streams carry after their headers, with ImageMetadata.color_encoding.want_icc set (jxlenc_set_embedded_icc).
+static std::vector<uint8_t> g_embedded_icc;
+static size_t g_embedded_icc_bits = 0;  // its exact length (the decoder aligns to a byte right after the last bit)
+static void AppendEmbeddedIcc(BitWriter& bw) {
+  for (size_t i = 0; i < g_embedded_icc_bits; i += 8) {
+    const unsigned n = unsigned(std::min<size_t>(8, g_embedded_icc_bits - i));
+    bw.Write(n, g_embedded_icc[i / 8] & ((1u << n) - 1));
+  }
+}
+
 struct Params {
   float distance;
   int32_t epf_iters;       // -1 = choose from distance like the reference (enc_frame.cc:317-341)
@@ -1159,8 +1170,21 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   WriteSizeDim(bw, uint32_t(ups == 1 ? f.ys : f.img_ys));
   bw.Write(3, 0);  // no aspect-ratio shortcut
   WriteSizeDim(bw, uint32_t(ups == 1 ? f.xs : f.img_xs));
-  if (!have_alpha) {
+  const bool with_icc = !g_embedded_icc.empty();
+  if (!have_alpha && !with_icc) {
     bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
+  } else if (!have_alpha) {
+    bw.Write(1, 0);  // not all_default
+    bw.Write(1, 0);  // no extra_fields
+    bw.Write(1, 0);  // integer samples
+    bw.Write(2, 0);  //   8 bits
+    bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
+    bw.Write(2, 0);  // no extra channels
+    bw.Write(1, 1);  // xyb_encoded
+    bw.Write(1, 0);  // ColorEncoding not all_default (color_encoding_internal.cc:144-158)
+    bw.Write(1, 1);  //   want_icc
+    bw.Write(2, 0);  //   colour space RGB
+    bw.Write(2, 0);  // no extensions
   } else {           // image_metadata.cc:283-356
     bw.Write(1, 0);  // not all_default
     bw.Write(1, 0);  // no extra_fields
@@ -1170,10 +1194,17 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(2, 1);  // one extra channel
     bw.Write(1, 1);  //   ExtraChannelInfo all_default: 8-bit alpha
     bw.Write(1, 1);  // xyb_encoded
-    bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
+    if (!with_icc) {
+      bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
+    } else {
+      bw.Write(1, 0);
+      bw.Write(1, 1);  //   want_icc
+      bw.Write(2, 0);  //   colour space RGB
+    }
     bw.Write(2, 0);  // no extensions
   }
   bw.Write(1, 1);  // CustomTransformData all_default
+  if (with_icc) AppendEmbeddedIcc(bw);  // (decode.cc: after the transform data, before the byte boundary)
   bw.ZeroPad();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
@@ -2002,7 +2033,12 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(2, alpha ? 1 : 0);  // extra channels
   if (alpha) bw.Write(1, 1);   //   all_default: 8-bit alpha
   bw.Write(1, 0);  // xyb_encoded = false
-  if (!gray) {
+  const bool with_icc = !g_embedded_icc.empty() && !gray;
+  if (with_icc) {
+    bw.Write(1, 0);  // not all_default
+    bw.Write(1, 1);  //   want_icc
+    bw.Write(2, 0);  //   colour space RGB
+  } else if (!gray) {
     bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
   } else {
     bw.Write(1, 0);  // not all_default
@@ -2016,6 +2052,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   }
   bw.Write(2, 0);  // no extensions
   bw.Write(1, 1);  // CustomTransformData all_default
+  if (with_icc) AppendEmbeddedIcc(bw);
   bw.ZeroPad();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
@@ -2070,6 +2107,12 @@ struct JxlEncParams {
   int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS, bit 1 = LZ77
   int32_t noise;           // > 0: noise synthesis, see jxe::Params
 };
+
+// The next encoded streams embed this coded ICC profile of exactly `bits` bits (n = 0: none again). Test aid, not thread-safe.
+void jxlenc_set_embedded_icc(const uint8_t* coded, size_t n, size_t bits) {
+  jxe::g_embedded_icc.assign(coded, coded + n);
+  jxe::g_embedded_icc_bits = bits <= n * 8 ? bits : n * 8;
+}
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
   *out = static_cast<uint8_t*>(malloc(v.size()));

@@ -2126,9 +2126,10 @@ extern "C" int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n) {
       M0.batch_refs = M0.batch_refs || q.s->num_props > 16;
     }
     uint32_t tcap = 0;  // likewise for the largest set of symbol tables that fits
+    const uint32_t table_limit = uint32_t(EnvInt("JXLHIP_MOD_TABLE_WORDS", int(jxlhip::kModTableLdsWords)));  // (measurement aid)
     for (size_t i = 0; i < n; i++)
       for (uint32_t w : ctxs[i]->mod.code_table_words)
-        if (w <= jxlhip::kModTableLdsWords && w > tcap) tcap = w;
+        if (w <= table_limit && w > tcap) tcap = w;
     M0.batch_table_cap = tcap;
     std::vector<uint8_t> ops_blob;
     ModularBuildOps(ctxs, n, &ops_blob, &M0.batch_launches);

@@ -14,6 +14,7 @@
 
 #include "jxh_bits.h"
 #include "jxh_entropy.h"
+#include "jxh_icc.h"
 
 namespace jxh {
 
@@ -35,6 +36,8 @@ struct ImageHeader {
   bool xyb_encoded = true;
   bool gray = false;
   bool linear_tf = false;  // output transfer function: false = sRGB, true = linear
+  bool want_icc = false;   // the original colours are described by an embedded ICC profile ...
+  std::vector<uint8_t> icc;  // ... decoded here (jxh_icc.h)
   bool have_animation = false, have_timecodes = false;
   float intensity_target = 255.0f;
   // CustomTransformData / OpsinInverseMatrix
@@ -79,11 +82,13 @@ static inline uint32_t AspectRatioX(uint32_t ysize, uint32_t ratio) {
 
 static inline void ReadColorEncoding(BitReader& br, ImageHeader* h) {
   if (br.ReadBool()) return;  // all_default: sRGB
-  bool want_icc = br.ReadBool();
+  h->want_icc = br.ReadBool();
   uint32_t cs = ReadEnum(br);  // 0 RGB, 1 Gray, 2 XYB, 3 Unknown
-  JXH_CHECK(!want_icc, "unsupported: ICC profile");
   JXH_CHECK(cs == 0 || cs == 1, "unsupported: colour space");
   h->gray = cs == 1;
+  // an embedded ICC profile describes the ORIGINAL colours (it follows the headers: ReadImageHeader); the enum fields are
+  // absent then (color_encoding_internal.cc:151-158). XYB images are still decoded to sRGB, the others keep their samples.
+  if (h->want_icc) return;
   uint32_t wp = ReadEnum(br);
   JXH_CHECK(wp == 1, "unsupported: white point");
   if (cs == 0) {
@@ -180,6 +185,7 @@ static inline void ReadImageHeader(BitReader& br, ImageHeader* h) {
     if (mask & 4) for (int i = 0; i < 210; i++) ReadF16(br);
     h->custom_upsampling = mask != 0;
   }
+  if (h->want_icc) ReadIcc(br, &h->icc);  // decode.cc: after the transform data, before the byte boundary
   br.ToByteBoundary();
 }
 

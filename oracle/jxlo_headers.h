@@ -35,6 +35,7 @@ struct ImageHeader {
   bool xyb_encoded = true;
   bool gray = false;
   bool linear_tf = false;  // output transfer function: false = sRGB, true = linear
+  bool want_icc = false;   // an ICC profile is embedded (the oracle skips it: it only checks pixels)
   bool have_animation = false, have_timecodes = false;
   float intensity_target = 255.0f;
   // CustomTransformData / OpsinInverseMatrix
@@ -79,11 +80,14 @@ static inline uint32_t AspectRatioX(uint32_t ysize, uint32_t ratio) {
 
 static inline void ReadColorEncoding(BitReader& br, ImageHeader* h) {
   if (br.ReadBool()) return;  // all_default: sRGB
-  bool want_icc = br.ReadBool();
+  const bool want_icc = br.ReadBool();
+  h->want_icc = want_icc;
   uint32_t cs = ReadEnum(br);  // 0 RGB, 1 Gray, 2 XYB, 3 Unknown
-  JXLO_CHECK(!want_icc, "unsupported: ICC profile");
+  // (an embedded ICC profile describes the original colours; the enum fields are absent then,
+  // color_encoding_internal.cc:151-158, and the coded profile follows the headers: SkipIcc)
   JXLO_CHECK(cs == 0 || cs == 1, "unsupported: colour space");
   h->gray = cs == 1;
+  if (want_icc) return;
   uint32_t wp = ReadEnum(br);
   JXLO_CHECK(wp == 1, "unsupported: white point");
   if (cs == 0) {
@@ -96,6 +100,35 @@ static inline void ReadColorEncoding(BitReader& br, ImageHeader* h) {
   JXLO_CHECK(tf == 13 || tf == 8, "unsupported: transfer function");
   h->linear_tf = tf == 8;
   (void)ReadEnum(br);  // rendering intent
+}
+
+// The coded ICC profile (lib/jxl/icc_codec.cc:306-428): an entropy-coded byte stream whose length is only known once it
+// is decoded; the context of a byte comes from the two bytes before it (icc_codec_common.cc:20-48,172-176). The oracle
+// only checks pixels: it decodes the bytes to get past them and drops them (the product's decoder is pinned by the
+// reference's own vector in tests/test_kats.py).
+static inline void SkipIcc(BitReader& br) {
+  auto kind = [](uint8_t b, bool second) -> int {
+    if (('a' <= b && b <= 'z') || ('A' <= b && b <= 'Z')) return 0;
+    if (('0' <= b && b <= '9') || b == '.' || b == ',') return 1;
+    if (second) return b < 16 ? 2 : (b > 240 ? 3 : 4);
+    if (b <= 1) return 2 + b;
+    if (b < 16) return 4;
+    if (b == 255) return 6;
+    return b > 240 ? 5 : 7;
+  };
+  const uint64_t n = ReadU64(br);
+  JXLO_CHECK(n <= (uint64_t(1) << 28), "ICC: encoded profile too large");
+  EntropyCode code;
+  DecodeHistograms(br, 41, &code);
+  SymbolReader rd(&code, &br);
+  uint8_t b1 = 0, b2 = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint32_t v = rd.Read(i <= 128 ? 0 : size_t(1 + kind(b1, false) + 8 * kind(b2, true)));
+    JXLO_CHECK(v < 256 && !br.Overread(), "ICC: corrupt profile");
+    b2 = b1;
+    b1 = uint8_t(v);
+  }
+  JXLO_CHECK(rd.FinalStateOk(), "ICC: bad ANS final state");
 }
 
 static inline void ReadImageHeader(BitReader& br, ImageHeader* h) {
@@ -180,6 +213,7 @@ static inline void ReadImageHeader(BitReader& br, ImageHeader* h) {
     if (mask & 4) for (int i = 0; i < 210; i++) ReadF16(br);
     h->custom_upsampling = mask != 0;
   }
+  if (h->want_icc) SkipIcc(br);
   br.ToByteBoundary();
 }
 

@@ -7,7 +7,9 @@
 //   fjxl F.jxl F.raw W H C   a Modular (lossless) file written by the reference's enc_fast_lossless.cc decodes, through
 //            this front-end's bit reader / headers / TOC / prefix + LZ77 entropy coder / MA-tree channel decode / inverse
 //            transforms, to exactly the raw interleaved 8-bit samples it was made from.
-// usage: host_kats {alias|hybrid|lehmer|fjxl ...};  exit code 0 = pass, message on stderr otherwise.
+//   icc ENC ICC   (product only) the reference's own ICC codec vector (icc_codec_test.cc:52-211): the coded stream ENC must
+//            decode to the profile ICC byte for byte, and damaged copies of it must be rejected, not crash.
+// usage: host_kats {alias|hybrid|lehmer|fjxl ...|icc ...};  exit code 0 = pass, message on stderr otherwise.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -292,12 +294,61 @@ static int TestFjxl(const char* jxl_path, const char* raw_path, size_t W, size_t
   return 0;
 }
 
+#ifndef KAT_ORACLE
+static bool Slurp(const char* path, std::vector<uint8_t>* out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  uint8_t buf[4096];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out->insert(out->end(), buf, buf + n);
+  fclose(f);
+  return true;
+}
+static int TestIcc(const char* enc_path, const char* icc_path) {
+  std::vector<uint8_t> enc, want;
+  REQUIRE(Slurp(enc_path, &enc) && Slurp(icc_path, &want), "cannot read the fixtures");
+  {
+    std::vector<uint8_t> padded = enc;
+    padded.resize(padded.size() + 16, 0);
+    H::BitReader br(padded.data(), padded.size());
+    std::vector<uint8_t> got;
+    try {
+      H::ReadIcc(br, &got);
+    } catch (const std::exception& e) {
+      REQUIRE(false, "the reference's coded profile was rejected: %s", e.what());
+    }
+    REQUIRE(got == want, "decoded profile differs from the reference's (%zu vs %zu bytes)", got.size(), want.size());
+    REQUIRE((br.BitPos() + 7) / 8 <= enc.size(), "read past the coded profile");
+  }
+  // damaged streams: an error or a (different) profile, never a crash or an endless loop
+  size_t rejected = 0;
+  for (size_t trial = 0; trial < 400; trial++) {
+    std::vector<uint8_t> bad = enc;
+    bad[Rnd(uint32_t(bad.size()))] ^= uint8_t(1u << Rnd(8));
+    if (trial & 1) bad.resize(Rnd(uint32_t(bad.size())) + 1);
+    bad.resize(bad.size() + 16, 0);
+    H::BitReader br(bad.data(), bad.size() - 16);
+    std::vector<uint8_t> got;
+    try {
+      H::ReadIcc(br, &got);
+    } catch (const std::exception&) {
+      rejected++;
+    }
+  }
+  REQUIRE(rejected > 200, "only %zu of 400 damaged streams were rejected", rejected);
+  return 0;
+}
+#endif
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string t = argv[1];
   if (t == "alias") return TestAlias();
   if (t == "hybrid") return TestHybrid();
   if (t == "lehmer") return TestLehmer();
+#ifndef KAT_ORACLE
+  if (t == "icc" && argc == 4) return TestIcc(argv[2], argv[3]);
+#endif
   if (t == "fjxl" && argc == 7) return TestFjxl(argv[2], argv[3], size_t(atol(argv[4])), size_t(atol(argv[5])), size_t(atol(argv[6])));
   return 2;
 }

@@ -137,7 +137,10 @@ int main(int argc, char** argv) {
       size_t icc_size = 1;
       memset(&cms, 0, sizeof(cms));
       if (JxlDecoderSetCms(dec, cms) != JXL_DEC_SUCCESS) return 2; /* jxl.cc:406 */
-      if (JxlDecoderGetColorAsEncodedProfile(dec, JXL_COLOR_PROFILE_TARGET_DATA, &ce) != JXL_DEC_SUCCESS) return 2;
+      memset(&ce, 0, sizeof(ce));
+      ce.transfer_function = (JxlTransferFunction)-1;
+      /* (jxl.cc:430-440 tolerates images whose pixels only have an ICC description) */
+      if (JxlDecoderGetColorAsEncodedProfile(dec, JXL_COLOR_PROFILE_TARGET_DATA, &ce) != JXL_DEC_SUCCESS && linear) return 2;
       if (linear) {
         ce.transfer_function = JXL_TRANSFER_FUNCTION_LINEAR;
         if (JxlDecoderSetOutputColorProfile(dec, &ce, NULL, 0) != JXL_DEC_SUCCESS) return 2;
@@ -145,6 +148,20 @@ int main(int argc, char** argv) {
       }
       if (JxlDecoderGetICCProfileSize(dec, JXL_COLOR_PROFILE_TARGET_DATA, &icc_size) != JXL_DEC_SUCCESS) icc_size = 0;
       printf("event COLOR_ENCODING tf=%d icc=%zu\n", (int)ce.transfer_function, icc_size);
+      {
+        /* the original profile, as jxl.cc:411-428 fetches it */
+        size_t orig = 0;
+        if (JxlDecoderGetICCProfileSize(dec, JXL_COLOR_PROFILE_TARGET_ORIGINAL, &orig) == JXL_DEC_SUCCESS && orig) {
+          unsigned char* icc = (unsigned char*)malloc(orig);
+          unsigned long long h = 1469598103934665603ull;
+          size_t i;
+          if (!icc || JxlDecoderGetColorAsICCProfile(dec, JXL_COLOR_PROFILE_TARGET_ORIGINAL, icc, orig) != JXL_DEC_SUCCESS) return 2;
+          for (i = 0; i < orig; i++) h = (h ^ icc[i]) * 1099511628211ull;
+          printf("original icc size=%zu fnv1a=%016llx encoded_profile=%d\n", orig, h,
+                 JxlDecoderGetColorAsEncodedProfile(dec, JXL_COLOR_PROFILE_TARGET_ORIGINAL, NULL) == JXL_DEC_SUCCESS);
+          free(icc);
+        }
+      }
     } else if (st == JXL_DEC_FRAME) {
       char name[4];
       if (JxlDecoderGetFrameHeader(dec, &fh) != JXL_DEC_SUCCESS) return 2;

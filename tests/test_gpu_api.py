@@ -88,6 +88,39 @@ def test_noise_frame_through_the_decoder_api(built, tmp_path):
     assert np.abs(np.frombuffer(px, np.float32).reshape(270, 300, 3) - ref_f).max() < 5e-5
 
 
+def test_images_with_an_embedded_icc_profile(built, tmp_path):
+    """Streams whose original colours are described by an ICC profile (want_icc): the profile - here the reference's own
+    test vector, lib/jxl/icc_codec_test.cc:52-211 - comes back through JxlDecoderGetICCProfileSize /
+    JxlDecoderGetColorAsICCProfile(ORIGINAL) byte for byte, the structured profile is reported absent for it
+    (decode.h:728-730), and the pixels are those of the same image without a profile: XYB frames are rendered to sRGB,
+    Modular frames keep their samples (whose profile, target DATA, is then the embedded one)."""
+    J = built
+    g = os.path.join(ROOT, "tests", "golden")
+    coded = open(os.path.join(g, "ref_icc_test_profile.enc"), "rb").read()
+    want = open(os.path.join(g, "ref_icc_test_profile.icc"), "rb").read()
+    h = 1469598103934665603
+    for b in want:
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    img = J.synth_image(300, 200, seed=6)
+    plain, plain_l = J.encode_rgb8(img), J.encode_lossless(img, J.LOSSLESS_RCT)
+    J.set_embedded_icc(coded)
+    try:
+        with_icc, with_icc_l = J.encode_rgb8(img), J.encode_lossless(img, J.LOSSLESS_RCT)
+    finally:
+        J.set_embedded_icc(None)
+    _, _, _, px0 = R.run(plain, tmp_path, "u8", 3)
+    rc, events, out, px = R.run(with_icc, tmp_path, "u8", 3)
+    assert rc == 0 and events[-2:] == ["FULL_IMAGE", "SUCCESS"], out
+    assert "original icc size=%d fnv1a=%016x encoded_profile=0" % (len(want), h) in out, out
+    assert "COLOR_ENCODING tf=13 icc=0" in out  # the pixels: sRGB
+    assert px == px0
+    rc, events, out, px = R.run(with_icc_l, tmp_path, "u8", 3)
+    assert rc == 0 and events[-2:] == ["FULL_IMAGE", "SUCCESS"], out
+    assert "original icc size=%d fnv1a=%016x" % (len(want), h) in out
+    assert "COLOR_ENCODING tf=-1 icc=%d" % len(want) in out, out  # the pixels are in the embedded profile's space
+    assert np.array_equal(np.frombuffer(px, np.uint8).reshape(200, 300, 3), img)
+
+
 def test_linear_output(built, tmp_path):
     import jxlo
     J = built

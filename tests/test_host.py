@@ -37,6 +37,40 @@ def test_library_exports_every_declared_symbol(built):
     assert not missing, missing
 
 
+def test_streams_with_an_embedded_icc_profile_parse(built):
+    """want_icc streams: the host front-end decodes the profile (the reference's own vector: tests/test_kats.py pins the
+    decoder), finds the frame behind it, and the oracle, which only skips the profile, decodes the same pixels."""
+    import jxlo
+    J = built
+    g = os.path.join(ROOT, "tests", "golden")
+    coded = open(os.path.join(g, "ref_icc_test_profile.enc"), "rb").read()
+    want = open(os.path.join(g, "ref_icc_test_profile.icc"), "rb").read()
+    icc, bits = J.icc_decode(coded)
+    assert icc == want and len(coded) * 8 - 8 < bits <= len(coded) * 8
+    with pytest.raises(J.JxlAmdError):
+        J.icc_decode(coded[:100])
+    img = J.synth_image(200, 120, seed=8)
+    plain = J.encode_rgb8(img)
+    J.set_embedded_icc(coded)
+    try:
+        data, lossless = J.encode_rgb8(img), J.encode_lossless(img, J.LOSSLESS_RCT)
+    finally:
+        J.set_embedded_icc(None)
+    assert len(data) > len(plain) + 380
+    f = J.Frame(data)
+    assert f.info["xsize"] == 200 and f.info["ysize"] == 120
+    f.close()
+    a, b = jxlo.Decoded(plain, dumps=False), jxlo.Decoded(data, dumps=False)
+    assert np.array_equal(a.rgb8, b.rgb8)
+    c = jxlo.Decoded(lossless, dumps=False)
+    assert np.array_equal(c.rgb8, img)
+    m = J.ModFrame(lossless)
+    assert m.info["xsize"] == 200
+    m.close()
+    for o in (a, b, c):
+        o.close()
+
+
 def test_frame_plan_matches_oracle(built):
     import jxlo
     J = built

@@ -38,6 +38,16 @@ def test_reference_closed_form_kats(which, kat):
     assert r.returncode == 0, r.stderr
 
 
+def test_embedded_icc_profile_reference_vector():
+    """lib/jxl/icc_codec_test.cc:52-211 (kEncodedTestProfile -> kTestProfile), extracted by tests/golden/make_icc_golden.py:
+    the product's ICC decoder (41-context entropy decode + the inverse of the profile predictor) against the reference's
+    own coded profile, plus 400 damaged copies."""
+    g = os.path.join(ROOT, "tests", "golden")
+    r = subprocess.run([_binary("product"), "icc", os.path.join(g, "ref_icc_test_profile.enc"), os.path.join(g, "ref_icc_test_profile.icc")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+
+
 MANIFEST = json.load(open(os.path.join(ROOT, "tests", "golden", "fjxl_manifest.json")))
 
 
