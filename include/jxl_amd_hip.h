@@ -215,6 +215,11 @@ int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_
  * spinning; for servers that pipeline frames over more host threads than they have CPUs to spare. */
 int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
 
+/* Test entry: runs the colour stage alone (XYB -> linear RGB -> sRGB transfer function unless linear_output) on n
+ * XYB triples, planar [3][n], with the opsin parameters of the frame the context last uploaded; interleaved f32 RGB out.
+ * For the reference's closed-form colour tests (lib/jxl/opsin_image_test.cc) against the kernel itself. */
+int jxlhip_debug_color(JxlHipContext* ctx, const float* xyb, size_t n, int linear_output, float* rgb);
+
 /* Debug aid: with JXLHIP_GUARD=1 in the environment every device buffer of a context is allocated with a 4 KiB guard
  * band either side, filled with a pattern. Waits for the device, then *touched = 0 when every band is intact, else
  * (1-based buffer index << 2) | (1 = band before, 2 = band after) of the first buffer a kernel wrote next to. */

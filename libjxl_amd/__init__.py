@@ -176,6 +176,16 @@ class HipContext:
         except Exception:
             pass
 
+    def debug_color(self, xyb, linear=False):
+        """Test entry: the colour stage alone on XYB triples (array [3, n]) -> float RGB [n, 3]."""
+        xyb = np.ascontiguousarray(xyb, np.float32)
+        n = xyb.shape[1]
+        out = np.empty((n, 3), np.float32)
+        L = lib()
+        L.jxlhip_debug_color.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        _check(L.jxlhip_debug_color(self._h, xyb.ctypes.data, n, 1 if linear else 0, out.ctypes.data), "jxlhip_debug_color")
+        return out
+
     def check_guards(self):
         """JXLHIP_GUARD=1 debug aid: 0 when no kernel wrote next to one of this context's device buffers."""
         t = ctypes.c_uint32()

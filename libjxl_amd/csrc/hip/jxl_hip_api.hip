@@ -2401,6 +2401,46 @@ int jxlhip_run_all(JxlHipContext* c) {
   return r;
 }
 
+// Test entry: the colour stage alone (k_color_out: XYB -> linear RGB -> transfer function) on `n` caller-supplied XYB
+// triples, planar [3][n], with the opsin parameters of the frame the context last uploaded; f32 RGB out, interleaved.
+// For the closed-form colour tests of the reference (opsin_image_test.cc) against the kernel itself.
+int jxlhip_debug_color(JxlHipContext* c, const float* xyb, size_t n, int linear_output, float* rgb) {
+  if (!c || !xyb || !rgb || !n || n > (1u << 24)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  Buf in, out;
+  int r;
+  if ((r = in.Ensure(n * 12)) || (r = out.Ensure(n * 12))) {
+    in.Free();
+    out.Free();
+    return r;
+  }
+  hipError_t e = hipMemcpy(in.p, xyb, n * 12, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    jxlhip::ColorOutParams cp;
+    memset(&cp, 0, sizeof(cp));
+    cp.f = c->fp;
+    cp.f.in = in.as<float>();
+    cp.f.xs = cp.f.xp = uint32_t(n);
+    cp.f.ys = cp.f.yp = 1;
+    cp.f.y_begin = 0;
+    cp.f.y_end = 1;
+    cp.f.linear_output = linear_output;
+    cp.po.dst = out.p;
+    cp.po.xsize = uint32_t(n);
+    cp.po.type = 0;
+    cp.po.nc = 3;
+    cp.po.bits = 32;
+    hipLaunchKernelGGL(jxlhip::k_color_out, dim3(uint32_t((n + 63) / 64), 1), dim3(256), 0, c->stream, cp);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(rgb, out.p, n * 12, hipMemcpyDeviceToHost);
+  }
+  in.Free();
+  out.Free();
+  return e == hipSuccess ? 0 : -int(e);
+}
+
 int jxlhip_check_guards(JxlHipContext* c, uint32_t* touched) {
   if (!c || !touched) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));

@@ -776,6 +776,25 @@ const void* jxlo_buffer(JxloHandle* h, const char* name, size_t* nbytes) {
   return nullptr;
 }
 
+// Known-answer hook for the colour stage: n XYB triples, planar [3][n], through XybToRgb (+ the sRGB transfer function
+// unless linear) with the default opsin parameters; interleaved RGB out (lib/jxl/opsin_image_test.cc's closed forms).
+void jxlo_color_kat(const float* xyb, size_t n, int linear, float* rgb) {
+  jxlo::ImageHeader ih;
+  const jxlo::OpsinParams op = jxlo::MakeOpsinParams(ih);
+  for (size_t i = 0; i < n; i++) {
+    float r, g, b;
+    jxlo::XybToRgb(op, xyb[i], xyb[n + i], xyb[2 * n + i], &r, &g, &b);
+    if (!linear) {
+      r = jxlo::LinearToSrgb(r);
+      g = jxlo::LinearToSrgb(g);
+      b = jxlo::LinearToSrgb(b);
+    }
+    rgb[3 * i] = r;
+    rgb[3 * i + 1] = g;
+    rgb[3 * i + 2] = b;
+  }
+}
+
 // Known-answer hook for the noise generator: `vectors` steps of the single-seed generator, 8 values each
 // (lib/jxl/xorshift128plus_test.cc:60-257 holds the expected values for seed 12345).
 void jxlo_xorshift_fill(uint64_t seed, uint64_t* out, size_t vectors) {

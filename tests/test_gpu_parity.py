@@ -445,6 +445,22 @@ def test_lane_kernel_with_alias_tables_in_global_memory(built, kw, monkeypatch):
     _compare(built, jxlo, built.encode_rgb8(built.synth_image(600, 420, seed=13), **kw))
 
 
+def test_colour_stage_closed_forms_gpu(built):
+    """The colour kernel itself (k_color_out through jxlhip_debug_color) against the definition of XYB and the reference's
+    closed-form colour tests (tests/color_kat.py: opsin_image_test.cc:28-135): roundtrip of the 13 colours of
+    OpsinRoundtrip, every grey of VerifyGray and a 9x9x9 lattice through float64 forward XYB, linear and sRGB-encoded."""
+    import color_kat
+    J = built
+    f = J.Frame(J.encode_rgb8(J.synth_image(64, 64, seed=1)))
+    c = J.HipContext()
+    try:
+        c.upload(f)
+        color_kat.check(lambda xyb, linear: c.debug_color(xyb, linear))
+    finally:
+        c.close()
+        f.close()
+
+
 def test_no_kernel_writes_outside_its_buffers(built, monkeypatch):
     """Debug build aid (JXLHIP_GUARD=1): every device buffer sits between two 4 KiB guard bands that no kernel may touch.
     A tour of the kernels: ragged sizes (also heights that are multiples of 64), every filter depth, upsampling, two

@@ -256,3 +256,21 @@ def test_noise_stream_statistics(built):
     assert np.abs(d[:, 0:32] - d[:, 256:288]).max() > 1e-3
     base.close()
     noisy.close()
+
+
+def test_colour_stage_closed_forms_oracle(built):
+    """XYB -> linear sRGB -> sRGB of the oracle against the definition of XYB and the reference's own closed forms
+    (tests/color_kat.py: opsin_image_test.cc:28-135): pins the inverse opsin matrix, the biases, the cube and the transfer
+    function against numbers no decoder produced."""
+    import ctypes
+    import jxlo
+    import color_kat
+    L = jxlo.lib()
+    L.jxlo_color_kat.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+
+    def convert(xyb, linear):
+        xyb = np.ascontiguousarray(xyb, np.float32)
+        out = np.empty((xyb.shape[1], 3), np.float32)
+        L.jxlo_color_kat(xyb.ctypes.data, xyb.shape[1], 1 if linear else 0, out.ctypes.data)
+        return out
+    color_kat.check(convert)
