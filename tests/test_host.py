@@ -2,6 +2,7 @@
 front-end (csrc/host) agrees with the oracle on everything it parses, the API fails loudly without a GPU, and the
 multi-rank sharding/aggregation logic works under gloo with world_size 2.  No compute calls need a GPU here."""
 import ctypes
+import json
 import os
 import re
 import socket
@@ -361,3 +362,37 @@ def test_reference_wasm_demo_streams(built, tmp_path):
     f.close()
     rc, events, out, _ = R.run(cross, tmp_path, "u16", 3)
     assert "BASIC_INFO 20x20" in out and events[:4] == ["BASIC_INFO", "COLOR_ENCODING", "FRAME", "NEED_IMAGE_OUT_BUFFER"], out
+
+
+def _c_array(path, name):
+    """The integer initialiser list of the C array `name` in `path`."""
+    import re
+    text = open(os.path.join(ROOT, path)).read()
+    m = re.search(r"\b%s\[[^\]]*\]\s*=\s*\{(.*?)\};" % re.escape(name), text, re.S)
+    assert m, (path, name)
+    return [int(t, 0) for t in re.findall(r"0x[0-9a-fA-F]+|\d+", re.sub(r"//.*", "", m.group(1)))]
+
+
+def test_context_model_tables_match_the_reference_source():
+    """The AC context model's constant tables as the reference's source has them (tests/golden/ref_constant_tables.json,
+    extracted by tests/golden/make_tables_golden.py from lib/jxl/ac_context.h:29-42,91-96 and coeff_order.h:44-46) against
+    every copy in this repository: the product's host and device tables, the arithmetic forms the kernels use, the
+    oracle's and the test encoder's. A shared transcription error would pass every encoder -> decoder test."""
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_constant_tables.json")))
+    freq, nnz = ref["kCoeffFreqContext"], ref["kCoeffNumNonzeroContext"]
+    assert _c_array("libjxl_amd/csrc/host/jxh_vardct.h", "kCoeffFreqContext") == freq
+    assert _c_array("libjxl_amd/csrc/host/jxh_vardct.h", "kCoeffNumNonzeroContext") == nnz
+    assert _c_array("oracle/jxlo_vardct.h", "kCoeffFreqContext") == freq
+    assert _c_array("oracle/jxlo_vardct.h", "kCoeffNumNonzeroContext") == nnz
+    assert _c_array("libjxl_amd/csrc/hip/jxl_hip_kernels.h", "c_coeff_nnz_ctx")[1:] == nnz[1:]
+    assert _c_array("libjxl_amd/csrc/hip/jxl_hip_kernels.h", "c_coeff_freq_ctx")[1:] == freq[1:]
+    # the lane kernel's arithmetic form of kCoeffFreqContext (jxl_hip_entropy_lanes.h): min(b - 1, 7 + b / 2, 15 + b / 4)
+    assert [min(b - 1, 7 + b // 2, 15 + b // 4) for b in range(1, 64)] == freq[1:]
+    for path, name in (("libjxl_amd/csrc/host/jxh_vardct.h", "kStrategyOrder"), ("libjxl_amd/csrc/hip/jxl_hip_kernels.h", "c_strategy_order"),
+                       ("oracle/jxlo_vardct.h", "kStrategyOrder")):
+        assert _c_array(path, name) == ref["kStrategyOrder"], path
+    for path in ("libjxl_amd/csrc/host/jxh_vardct.h", "oracle/jxlo_vardct.h"):
+        assert _c_array(path, "kDefault") == ref["kDefaultCtxMap"], path
+        assert _c_array(path, "kCoveredX") == ref["covered_blocks_x"] and _c_array(path, "kCoveredY") == ref["covered_blocks_y"], path
+        assert _c_array(path, "kStrategyQuantTable") == ref["strategy_to_quant_table"], path
+    assert _c_array("libjxl_amd/csrc/hip/jxl_hip_kernels.h", "c_strategy_qtable") == ref["strategy_to_quant_table"]
