@@ -251,17 +251,18 @@ struct ModWp {
   int64_t pred;
 };
 constexpr uint32_t kModWpEntry = 8;  // ints per row entry
-__device__ __forceinline__ uint32_t ModErrorWeight(uint64_t x, uint32_t maxweight) {
-  int shift = ModFloorLog2(x + 1) - 5;
+// `ldiv` = (1 << 24) / (i + 1) for i in 0..63 in LDS (the reference's divlookup, context_predict.h:79-90): both
+// divisions of the predictor have divisors of at most 64, and an integer division is ~30 vector instructions here.
+__device__ __forceinline__ uint32_t ModErrorWeight(uint32_t x, uint32_t maxweight, const uint32_t* ldiv) {
+  int shift = 58 - int(__clzll(static_cast<long long>(uint64_t(x) + 1)));  // floor(log2(x + 1)) - 5, x any 32-bit value
   if (shift < 0) shift = 0;
-  const uint32_t div = (1u << 24) / (uint32_t(x >> shift) + 1u);
-  return uint32_t(4 + ((uint64_t(maxweight) * div) >> shift));
+  return uint32_t(4 + ((uint64_t(maxweight) * ldiv[x >> shift]) >> shift));  // (x >> shift is at most 63)
 }
 __device__ __forceinline__ int64_t ModWpPredict(ModWp& s, const int32_t* hd, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN,
-                                               int32_t* max_err_prop) {
+                                               int32_t* max_err_prop, const uint32_t* ldiv) {
   uint32_t weights[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) weights[i] = ModErrorWeight(s.peN[i] + s.peNE[i] + s.peNW[i], uint32_t(hd[7 + i]));
+  for (int i = 0; i < 4; i++) weights[i] = ModErrorWeight(s.peN[i] + s.peNE[i] + s.peNW[i], uint32_t(hd[7 + i]), ldiv);
   N *= 8; W *= 8; NE *= 8; NW *= 8; NN *= 8;
   const int64_t teW = s.teW, teN = s.teN, teNW = s.teNW, teNE = s.teNE;
   const int64_t sumWN = teN + teW;
@@ -288,7 +289,7 @@ __device__ __forceinline__ int64_t ModWpPredict(ModWp& s, const int32_t* hd, int
     int64_t sum = (ws >> 1) - 1;
 #pragma unroll
     for (int i = 0; i < 4; i++) sum += s.prediction[i] * int64_t(weights[i]);
-    s.pred = (sum * int64_t((1u << 24) / ws)) >> 24;
+    s.pred = (sum * int64_t(ldiv[(ws - 1) & 63])) >> 24;  // (ws is in 13..31)
   }
   if (((teN ^ teW) | (teN ^ teNW)) > 0) return (s.pred + 3) >> 3;
   const int64_t mx = W > NE ? (W > N ? W : N) : (NE > N ? NE : N), mn = W < NE ? (W < N ? W : N) : (NE < N ? NE : N);
@@ -349,7 +350,7 @@ constexpr uint32_t kModTableLdsWords = 8192;  // largest symbol-table set kept i
 // Dynamic LDS of a workgroup (one wave, `lanes` streams): the properties [property][lane], then `tree_cap` tree nodes,
 // then `table_cap` words of symbol tables.
 __host__ __device__ inline uint32_t ModLdsBytes(uint32_t lanes, uint32_t tree_cap, uint32_t table_cap) {
-  return kModMaxProps * lanes * 4 + tree_cap * 16 + table_cap * 4;
+  return kModMaxProps * lanes * 4 + tree_cap * 16 + table_cap * 4 + 64 * 4;  // (+ the weighted predictor's division table)
 }
 
 // One lane per stream, `lanes` (a power of two, <= 64) streams per workgroup; `streams` holds `n` descriptors.
@@ -381,6 +382,8 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
   if (active) r.T = *S.code;
   else memset(&r.T, 0, sizeof(r.T));
   uint32_t* const ltab = reinterpret_cast<uint32_t*>(mod_lds + kModMaxProps * lanes * 4 + tree_cap * 16);
+  uint32_t* const ldiv = ltab + table_cap;
+  if (WP) ldiv[lane] = (1u << 24) / (lane + 1);
   {
     const uint64_t code_bits = reinterpret_cast<uint64_t>(S.code);
     const uint32_t c_lo = __builtin_amdgcn_readfirstlane(uint32_t(code_bits)), c_hi = __builtin_amdgcn_readfirstlane(uint32_t(code_bits >> 32));
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(64) void k_modular_streams(const ModStream* streams
         int64_t wp_pred = 0;
         if (wp_on) {
           int32_t max_err = 0;
-          wp_pred = ModWpPredict(wp, S.wp, top, left, topright, topleft, toptop, &max_err);
+          wp_pred = ModWpPredict(wp, S.wp, top, left, topright, topleft, toptop, &max_err, ldiv);
           lprops[15 * lanes] = max_err;
         }
 #pragma unroll
