@@ -373,6 +373,29 @@ def _c_array(path, name):
     return [int(t, 0) for t in re.findall(r"0x[0-9a-fA-F]+|\d+", re.sub(r"//.*", "", m.group(1)))]
 
 
+def test_icc_stream_delivered_in_small_pieces(built, tmp_path):
+    """An image whose headers are followed by a 389-byte coded ICC profile, fed 100 bytes at a time inside a container:
+    the decoder asks for more input until the profile is complete (it cannot know where the profile ends before
+    decoding it), then reports BASIC_INFO / COLOR_ENCODING with the profile available as the ORIGINAL one."""
+    import replay_util as R
+    J = built
+    g = os.path.join(ROOT, "tests", "golden")
+    coded = open(os.path.join(g, "ref_icc_test_profile.enc"), "rb").read()
+    want = open(os.path.join(g, "ref_icc_test_profile.icc"), "rb").read()
+    J.set_embedded_icc(coded)
+    try:
+        data = J.encode_rgb8(J.synth_image(200, 120, seed=8))
+    finally:
+        J.set_embedded_icc(None)
+    rc, events, out, _ = R.run(R.container(data), tmp_path, "u8", 3, "chunk=100")
+    assert rc == (0 if J.lib().jxlhip_device_count() > 0 else 3), out
+    assert "original icc size=%d" % len(want) in out, out
+    core = [e for e in events if e not in ("BOX", "NEED_MORE_INPUT")]
+    assert core[:4] == ["BASIC_INFO", "COLOR_ENCODING", "FRAME", "NEED_IMAGE_OUT_BUFFER"], out
+    first_info = events.index("BASIC_INFO")
+    assert events[:first_info].count("NEED_MORE_INPUT") >= 3  # the ~400 bytes of profile arrive in 100-byte pieces
+
+
 def test_context_model_tables_match_the_reference_source():
     """The AC context model's constant tables as the reference's source has them (tests/golden/ref_constant_tables.json,
     extracted by tests/golden/make_tables_golden.py from lib/jxl/ac_context.h:29-42,91-96 and coeff_order.h:44-46) against
