@@ -175,6 +175,11 @@ int jxlhip_download_rgb8(JxlHipContext* ctx, uint8_t* dst, size_t stride);
  * unsigned types (0 = full width), big_endian swaps the bytes of multi-byte samples. RGB8 is written by every filter
  * kernel and RGB f32 by the row-streaming one (the d1.0 configuration); other formats cost one more pass over the planes. */
 int jxlhip_set_output_format(JxlHipContext* ctx, uint32_t data_type, uint32_t num_channels, uint32_t bits_per_sample, int big_endian);
+/* The pixels are written with the image's orientation undone (JxlOrientation / EXIF numbering 1..8; 1 = as coded), the
+ * way the reference's write stage does it (render_pipeline/stage_write.cc:292-306,441-458,664-699): for 5..8 the rows
+ * of the output are columns of the image (jxlhip_download_pixels then hands out xsize rows of ysize pixels). Call before
+ * the upload. */
+int jxlhip_set_output_orientation(JxlHipContext* ctx, uint32_t orientation);
 /* Alpha plane of the image (f32 in [0, 1], xsize * ysize, host memory; copied synchronously) for 2- and 4-channel output;
  * NULL = opaque again. */
 int jxlhip_set_alpha(JxlHipContext* ctx, const float* alpha, uint32_t xsize, uint32_t ysize);

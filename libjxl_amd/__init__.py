@@ -211,6 +211,13 @@ class HipContext:
         _check(lib().jxlhip_set_output_format(self._h, data_type, num_channels, bits, 1 if big_endian else 0), "jxlhip_set_output_format")
         self._out = (data_type, num_channels)
 
+    def set_output_orientation(self, orientation=1):
+        """Undo this image orientation (1..8, EXIF numbering) in the pixel writer; call before upload."""
+        L = lib()
+        L.jxlhip_set_output_orientation.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        _check(L.jxlhip_set_output_orientation(self._h, int(orientation)), "jxlhip_set_output_orientation")
+        self._transposed = orientation > 4
+
     def upload_modular(self, mframe):
         _check(lib().jxlamd_modframe_upload(mframe._h, self._h), "jxlamd_modframe_upload")
         self.frame_info = dict(mframe.info)
@@ -237,8 +244,11 @@ class HipContext:
         fi = self.frame_info
         dt, nc = getattr(self, "_out", (2, 3))
         np_dt = {0: np.float32, 2: np.uint8, 3: np.uint16, 5: np.float16}[dt]
-        out = np.empty((fi["out_ysize"], fi["out_xsize"], nc), np_dt)
-        _check(lib().jxlhip_download_pixels(self._h, out.ctypes.data, fi["out_xsize"] * nc * out.itemsize), "jxlhip_download_pixels")
+        oxs, oys = fi["out_xsize"], fi["out_ysize"]
+        if getattr(self, "_transposed", False):
+            oxs, oys = oys, oxs
+        out = np.empty((oys, oxs, nc), np_dt)
+        _check(lib().jxlhip_download_pixels(self._h, out.ctypes.data, oxs * nc * out.itemsize), "jxlhip_download_pixels")
         return out
 
     def rgb8_rows(self, y0, y1):
@@ -406,6 +416,15 @@ def set_embedded_icc(coded=None):
         return
     _, bits = icc_decode(coded)
     E.jxlenc_set_embedded_icc(coded, len(coded), bits)
+
+
+def set_orientation(orientation=1):
+    """Test aid: the synthetic encoders declare this image orientation (1..8, EXIF numbering) in the streams they write
+    from now on (1: none again)."""
+    E = _enc_lib()
+    E.jxlenc_set_orientation.argtypes = [ctypes.c_uint32]
+    E.jxlenc_set_orientation.restype = None
+    E.jxlenc_set_orientation(int(orientation))
 
 
 def synth_image(xsize, ysize, seed=177):

@@ -827,6 +827,28 @@ void StoreExtraRow(const int32_t* src, size_t xs, uint32_t ch_bits, const JxlPix
   }
 }
 
+// The orientation the output undoes (decode.cc:2233-2240): 1 when the caller keeps the coded orientation.
+uint32_t UndoOrientation(const JxlDecoder* d) { return d->keep_orientation ? 1u : d->ih.orientation; }
+size_t OrientedXsize(const JxlDecoder* d) { return UndoOrientation(d) > 4 ? d->ih.ysize : d->ih.xsize; }
+size_t OrientedYsize(const JxlDecoder* d) { return UndoOrientation(d) > 4 ? d->ih.xsize : d->ih.ysize; }
+
+// Extra-channel planes take the same flips and transpose as the colour pixels (stage_write.cc:441-458, 664-699); the
+// colour writer does them on the device, these small integer planes are permuted while they are stored.
+std::vector<int32_t> OrientPlane(const int32_t* src, size_t xs, size_t ys, uint32_t orientation) {
+  static const uint8_t kBits[9] = {0, 0, 1, 3, 2, 4, 6, 7, 5};  // mirror x | mirror y << 1 | transpose << 2
+  const uint32_t bits = kBits[orientation];
+  std::vector<int32_t> out(xs * ys);
+  for (size_t y = 0; y < ys; y++) {
+    const size_t oy = (bits & 2) ? ys - 1 - y : y;
+    for (size_t x = 0; x < xs; x++) {
+      const size_t ox = (bits & 1) ? xs - 1 - x : x;
+      out[(bits & 4) ? ox * ys + oy : oy * xs + ox] = src[y * xs + x];
+    }
+  }
+  return out;
+}
+
+// `xs`, `ys`: the size of the delivered (oriented) image.
 JxlDecoderStatus DeliverPixels(JxlDecoder* d, const OutFormat& of, size_t xs, size_t ys) {
   const size_t bpp = of.nc * SampleBytes(d->fmt.data_type);
   int r;
@@ -858,6 +880,7 @@ JxlDecoderStatus DecodeModularPixels(JxlDecoder* d) {
     for (const auto& e : d->ih.extra)
       if (e.type == 0 && e.alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
+  if (!r) r = jxlhip_set_output_orientation(d->ctx, UndoOrientation(d));
   if (!r) r = jxlamd_modframe_upload(d->mframe, d->ctx);
   if (!r) r = jxlhip_modular_run(d->ctx);
   uint32_t info[16];
@@ -865,11 +888,13 @@ JxlDecoderStatus DecodeModularPixels(JxlDecoder* d) {
   std::vector<uint32_t> status(info[5] + 1);
   if (!r) r = jxlhip_modular_status(d->ctx, status.data(), nullptr, status.size());
   if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ") " + g_last_error);
-  const size_t xs = info[0], ys = info[1];
+  const uint32_t orientation = UndoOrientation(d);
+  const size_t xs = orientation > 4 ? info[1] : info[0], ys = orientation > 4 ? info[0] : info[1];
   for (const auto& eo : d->extra_out) {
     const uint32_t buffer = jxlamd_modframe_extra_buffer(d->mframe, eo.first);
     std::vector<int32_t> plane(xs * ys);
     if (buffer == 0xFFFFFFFFu || jxlhip_modular_download_buffer(d->ctx, buffer, plane.data(), plane.size())) return Fail(d, "extra channel unavailable");
+    if (orientation != 1) plane = OrientPlane(plane.data(), info[0], info[1], orientation);
     const JxlPixelFormat& f = eo.second.fmt;
     const size_t stride = RowStride(f, xs);
     uint32_t bits = f.data_type == JXL_TYPE_UINT8 ? 8 : 16;
@@ -888,7 +913,6 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
     int r = jxlhip_ctx_create(dev ? atoi(dev) : 0, &d->ctx);
     if (r) return Fail(d, "jxlhip_ctx_create failed (" + std::to_string(r) + ")");
   }
-  if (!d->keep_orientation && d->ih.orientation != 1) return Fail(d, "unsupported: undoing a non-identity orientation");
   if (d->mframe) return DecodeModularPixels(d);
   const jxh::FramePlan& P = d->frame->plan;
   const OutFormat of = MapFormat(d, d->fmt);
@@ -901,7 +925,9 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   const bool want_alpha = (of.nc == 2 || of.nc == 4) && alpha_ec >= 0;
   if (want_alpha && d->unpremul && d->ih.extra[alpha_ec].alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
   jxlamd_frame_set_linear_output(d->frame, d->want_linear >= 0 ? d->want_linear : (P.ih.linear_tf ? 1 : 0));
+  const uint32_t orientation = UndoOrientation(d);
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
+  if (!r) r = jxlhip_set_output_orientation(d->ctx, orientation);
   if (!r) r = jxlhip_set_alpha(d->ctx, nullptr, 0, 0);
   if (!r) r = jxlamd_frame_upload(d->frame, d->ctx);
   if (!r) r = jxlhip_run_entropy(d->ctx);
@@ -915,7 +941,7 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   }
   uint32_t out_wh[2];
   jxlamd_frame_out_size(d->frame, out_wh);
-  const size_t xs = out_wh[0], ys = out_wh[1];
+  size_t xs = out_wh[0], ys = out_wh[1];
   if (want_alpha) {
     const int32_t* a = jxlamd_frame_extra_plane(d->frame, uint32_t(alpha_ec));
     if (!a) return Fail(d, "alpha channel unavailable");
@@ -928,9 +954,16 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   r = jxlhip_run_transform(d->ctx);
   if (!r) r = jxlhip_run_filter_color(d->ctx);
   if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
+  const size_t coded_xs = xs, coded_ys = ys;
+  if (orientation > 4) std::swap(xs, ys);
   for (const auto& eo : d->extra_out) {
     const int32_t* p = jxlamd_frame_extra_plane(d->frame, eo.first);
     if (!p) return Fail(d, "extra channel unavailable");
+    std::vector<int32_t> oriented;
+    if (orientation != 1) {
+      oriented = OrientPlane(p, coded_xs, coded_ys, orientation);
+      p = oriented.data();
+    }
     const JxlPixelFormat& f = eo.second.fmt;
     const size_t stride = RowStride(f, xs);
     uint32_t bits = f.data_type == JXL_TYPE_UINT8 ? 8 : 16;
@@ -1156,8 +1189,8 @@ JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* d, JxlBasicInfo* info)
   if (info) {
     memset(info, 0, sizeof(*info));
     info->have_container = d->container == 1;
-    info->xsize = d->ih.xsize;
-    info->ysize = d->ih.ysize;
+    info->xsize = uint32_t(OrientedXsize(d));
+    info->ysize = uint32_t(OrientedYsize(d));
     info->bits_per_sample = d->ih.bits;
     info->exponent_bits_per_sample = d->ih.exp_bits;
     info->intensity_target = d->ih.intensity_target;
@@ -1172,8 +1205,8 @@ JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* d, JxlBasicInfo* info)
         info->alpha_premultiplied = e.alpha_associated;
         break;
       }
-    info->intrinsic_xsize = d->ih.xsize;
-    info->intrinsic_ysize = d->ih.ysize;
+    info->intrinsic_xsize = info->xsize;
+    info->intrinsic_ysize = info->ysize;
   }
   return JXL_DEC_SUCCESS;
 }
@@ -1272,8 +1305,8 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
   if (h) {
     memset(h, 0, sizeof(*h));
     h->is_last = JXL_TRUE;
-    h->layer_info.xsize = d->ih.xsize;
-    h->layer_info.ysize = d->ih.ysize;
+    h->layer_info.xsize = uint32_t(OrientedXsize(d));  // decode.cc:2714-2722
+    h->layer_info.ysize = uint32_t(OrientedYsize(d));
     h->layer_info.blend_info.blendmode = JXL_BLEND_REPLACE;
   }
   return JXL_DEC_SUCCESS;
@@ -1295,8 +1328,8 @@ static JxlDecoderStatus CheckFormat(const JxlDecoder* d, const JxlPixelFormat* f
 }
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* f, size_t* size) {
   if (CheckFormat(d, f) != JXL_DEC_SUCCESS || !size) return JXL_DEC_ERROR;
-  const size_t stride = RowStride(*f, d->ih.xsize);
-  *size = stride * (d->ih.ysize - 1) + size_t(d->ih.xsize) * f->num_channels * SampleBytes(f->data_type);
+  const size_t xs = OrientedXsize(d), ys = OrientedYsize(d);
+  *size = RowStride(*f, xs) * (ys - 1) + xs * f->num_channels * SampleBytes(f->data_type);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetImageOutBuffer(JxlDecoder* d, const JxlPixelFormat* f, void* buffer, size_t size) {
@@ -1339,7 +1372,8 @@ JxlDecoderStatus JxlDecoderExtraChannelBufferSize(const JxlDecoder* d, const Jxl
   if (!d->have_ih || !f || !size || index >= d->ih.extra.size() || !KnownType(f->data_type)) return JXL_DEC_ERROR;
   JxlPixelFormat one = *f;
   one.num_channels = 1;  // decode.cc:2608-2625: the channel count of the format is ignored
-  *size = RowStride(one, d->ih.xsize) * (d->ih.ysize - 1) + size_t(d->ih.xsize) * SampleBytes(f->data_type);
+  const size_t xs = OrientedXsize(d), ys = OrientedYsize(d);
+  *size = RowStride(one, xs) * (ys - 1) + xs * SampleBytes(f->data_type);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetExtraChannelBuffer(JxlDecoder* d, const JxlPixelFormat* f, void* buffer, size_t size, uint32_t index) {

@@ -737,6 +737,22 @@ struct FrameModel {
 
 // Test aid: a coded ICC profile (the byte stream lib/jxl/icc_codec.cc reads: U64 size, histograms, ANS data) that the
 // next streams carry after their headers, with ImageMetadata.color_encoding.want_icc set (jxlenc_set_embedded_icc).
+// jxlenc_set_orientation: the ImageMetadata orientation the next streams carry (1..8; 1 writes no extra_fields).
+static uint32_t g_orientation = 1;
+// image_metadata.cc:283-300: extra_fields = orientation, no intrinsic size, no preview, no animation.
+static void WriteExtraFields(BitWriter& bw) {
+  if (g_orientation == 1) {
+    bw.Write(1, 0);
+    return;
+  }
+  bw.Write(1, 1);
+  bw.Write(3, g_orientation - 1);
+  bw.Write(3, 0);
+}
+// image_metadata.cc:340-344: with extra_fields a ToneMapping bundle follows the colour encoding (all_default here).
+static void WriteToneMapping(BitWriter& bw) {
+  if (g_orientation != 1) bw.Write(1, 1);
+}
 static std::vector<uint8_t> g_embedded_icc;
 static size_t g_embedded_icc_bits = 0;  // its exact length (the decoder aligns to a byte right after the last bit)
 static void AppendEmbeddedIcc(BitWriter& bw) {
@@ -1171,36 +1187,25 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(3, 0);  // no aspect-ratio shortcut
   WriteSizeDim(bw, uint32_t(ups == 1 ? f.xs : f.img_xs));
   const bool with_icc = !g_embedded_icc.empty();
-  if (!have_alpha && !with_icc) {
+  if (!have_alpha && !with_icc && g_orientation == 1) {
     bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
-  } else if (!have_alpha) {
-    bw.Write(1, 0);  // not all_default
-    bw.Write(1, 0);  // no extra_fields
-    bw.Write(1, 0);  // integer samples
-    bw.Write(2, 0);  //   8 bits
-    bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
-    bw.Write(2, 0);  // no extra channels
-    bw.Write(1, 1);  // xyb_encoded
-    bw.Write(1, 0);  // ColorEncoding not all_default (color_encoding_internal.cc:144-158)
-    bw.Write(1, 1);  //   want_icc
-    bw.Write(2, 0);  //   colour space RGB
-    bw.Write(2, 0);  // no extensions
   } else {           // image_metadata.cc:283-356
     bw.Write(1, 0);  // not all_default
-    bw.Write(1, 0);  // no extra_fields
+    WriteExtraFields(bw);
     bw.Write(1, 0);  // integer samples
     bw.Write(2, 0);  //   8 bits
     bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
-    bw.Write(2, 1);  // one extra channel
-    bw.Write(1, 1);  //   ExtraChannelInfo all_default: 8-bit alpha
+    bw.Write(2, have_alpha ? 1 : 0);  // extra channels
+    if (have_alpha) bw.Write(1, 1);   //   ExtraChannelInfo all_default: 8-bit alpha
     bw.Write(1, 1);  // xyb_encoded
     if (!with_icc) {
       bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
     } else {
-      bw.Write(1, 0);
+      bw.Write(1, 0);  // ColorEncoding not all_default (color_encoding_internal.cc:144-158)
       bw.Write(1, 1);  //   want_icc
       bw.Write(2, 0);  //   colour space RGB
     }
+    WriteToneMapping(bw);
     bw.Write(2, 0);  // no extensions
   }
   bw.Write(1, 1);  // CustomTransformData all_default
@@ -2026,7 +2031,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(3, 0);
   WriteSizeDim(bw, uint32_t(xs));
   bw.Write(1, 0);  // ImageMetadata not all_default
-  bw.Write(1, 0);  // no extra_fields
+  WriteExtraFields(bw);
   bw.Write(1, 0);  // integer samples
   bw.Write(2, 0);  //   8 bits
   bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
@@ -2050,6 +2055,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
     bw.Write(4, 13 - 2);
     bw.Write(2, 1);  // rendering intent: relative
   }
+  WriteToneMapping(bw);
   bw.Write(2, 0);  // no extensions
   bw.Write(1, 1);  // CustomTransformData all_default
   if (with_icc) AppendEmbeddedIcc(bw);
@@ -2113,6 +2119,9 @@ void jxlenc_set_embedded_icc(const uint8_t* coded, size_t n, size_t bits) {
   jxe::g_embedded_icc.assign(coded, coded + n);
   jxe::g_embedded_icc_bits = bits <= n * 8 ? bits : n * 8;
 }
+
+// The next encoded streams declare this orientation (1..8, codestream_header.h:45-54; 1 = identity). Test aid, not thread-safe.
+void jxlenc_set_orientation(uint32_t orientation) { jxe::g_orientation = orientation >= 1 && orientation <= 8 ? orientation : 1; }
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
   *out = static_cast<uint8_t*>(malloc(v.size()));

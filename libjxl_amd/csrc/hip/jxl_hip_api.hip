@@ -219,6 +219,7 @@ struct JxlHipContext {
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
   // output pixel format (jxlhip_set_output_format; JxlDataType numbering): RGB8 by default
   uint32_t out_type = 2, out_nc = 3, out_bits = 8, out_swap = 0;
+  uint32_t out_orient = 0;  // jxlhip_set_output_orientation: PixelOut::orient bits (0 = the image as coded)
   // noise synthesis (JxlHipFrameDesc::has_noise): raw random planes [3][ys][xs], LUT, seeds, base colour correlation
   Buf noise;
   bool has_noise = false;
@@ -799,6 +800,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   // (k_color_out on the filtered planes, or k_upsample_color)
   c->color_out = !OutIsRgb8(c) && !(OutIsRgbF32(c) && c->ups == 1 && (c->gab && c->epf_iters == 1) &&
                                     !EnvInt("JXLHIP_FILTER_TILES", 0) && !EnvInt("JXLHIP_FILTER_ROWS1", 0));
+  if (c->out_orient) c->color_out = true;  // (the oriented layout is written by the generic writer)
   // noise is added to the filtered planes between the filter launch and the colour conversion
   c->has_noise = d->has_noise != 0;
   if (c->has_noise) {
@@ -2056,6 +2058,8 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
     o.po.dst = c->rgb.p;
     o.po.alpha = nullptr;
     o.po.xsize = M.xs;
+    o.po.ysize = M.ys;
+    o.po.orient = c->out_orient;
     o.po.type = c->out_type;
     o.po.nc = c->out_nc;
     o.po.bits = c->out_bits;
@@ -2280,6 +2284,8 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
       po.dst = c->rgb.p;
       po.alpha = c->have_alpha ? c->alpha.as<float>() : nullptr;
       po.xsize = c->oxs;
+      po.ysize = c->oys;
+      po.orient = c->out_orient;
       po.type = c->out_type;
       po.nc = c->out_nc;
       po.bits = c->out_bits;
@@ -2364,6 +2370,15 @@ int jxlhip_set_output_format(JxlHipContext* c, uint32_t data_type, uint32_t num_
   return 0;
 }
 
+int jxlhip_set_output_orientation(JxlHipContext* c, uint32_t orientation) {
+  if (!c || orientation < 1 || orientation > 8) return JXLHIP_ERR_INVALID_ARGUMENT;
+  // EXIF numbering -> mirror x (1) | mirror y (2) | transpose (4): stage_write.cc:441-458
+  static const uint8_t kBits[9] = {0, 0, 1, 3, 2, 4, 6, 7, 5};
+  c->out_orient = kBits[orientation];
+  c->generation++;
+  return 0;
+}
+
 int jxlhip_set_alpha(JxlHipContext* c, const float* alpha, uint32_t xsize, uint32_t ysize) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!alpha) {
@@ -2382,14 +2397,15 @@ int jxlhip_set_alpha(JxlHipContext* c, const float* alpha, uint32_t xsize, uint3
 int jxlhip_download_pixels(JxlHipContext* c, void* dst, size_t stride) {
   if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
-  const size_t row = size_t(c->oxs) * OutPixelBytes(c);
+  const bool transposed = (c->out_orient & 4) != 0;  // rows of the output are columns of the image
+  const size_t row = size_t(transposed ? c->oys : c->oxs) * OutPixelBytes(c), rows = transposed ? c->oxs : c->oys;
   if (stride < row) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   {
     int pw = ApplyPendingWait(c);
     if (pw) return pw;
   }
-  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, row, row, c->oys, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpy2DAsync(dst, stride, c->rgb.p, row, row, rows, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -2428,6 +2444,7 @@ int jxlhip_debug_color(JxlHipContext* c, const float* xyb, size_t n, int linear_
     cp.f.linear_output = linear_output;
     cp.po.dst = out.p;
     cp.po.xsize = uint32_t(n);
+    cp.po.ysize = 1;
     cp.po.type = 0;
     cp.po.nc = 3;
     cp.po.bits = 32;
@@ -2484,6 +2501,7 @@ int jxlhip_download_rgb8_rows(JxlHipContext* c, uint8_t* dst, size_t stride, uin
   if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
   if (stride < size_t(c->oxs) * 3 || y_begin >= y_end || y_end > c->oys || !OutIsRgb8(c)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (c->out_orient & 4) return JXLHIP_ERR_INVALID_ARGUMENT;  // a transposed output has other rows: jxlhip_download_pixels
   HIP_TRY(hipSetDevice(c->device));
   {
     int pw = ApplyPendingWait(c);

@@ -1631,10 +1631,20 @@ struct FilterParams {
 // Every output format of the boundary (JxlPixelFormat; stage_write.cc:266-286,334-370,548-590): written by k_color_out
 // and k_upsample_color. `type` uses the JxlDataType values (0 f32, 2 u8, 3 u16, 5 f16).
 struct PixelOut {
-  void* dst;           // interleaved, tightly packed rows of xsize * nc samples
+  void* dst;           // interleaved, tightly packed rows of samples
   const float* alpha;  // plane of the image size in [0, 1], or NULL (opaque)
   uint32_t xsize, type, nc, bits, swap;  // bits: sample depth of the unsigned types; swap: byte-swapped (big endian) samples
+  // Undoing the image's orientation (stage_write.cc:292-306,341-343,441-458,664-699): bit 0 = mirror x, bit 1 = mirror y,
+  // bit 2 = transpose (rows of the output are columns of the image: ysize samples long). 0 = rows of xsize pixels.
+  uint32_t orient, ysize;
 };
+// Where pixel (x, y) of the decoded image goes and which dither cell it takes (the reference dithers after the flips).
+__device__ __forceinline__ size_t PixelOutIndex(const PixelOut& o, int x, int y, int* dx, int* dy) {
+  const int ox = (o.orient & 1) ? int(o.xsize) - 1 - x : x, oy = (o.orient & 2) ? int(o.ysize) - 1 - y : y;
+  *dx = ox;
+  *dy = oy;
+  return (o.orient & 4) ? size_t(ox) * o.ysize + oy : size_t(oy) * o.xsize + ox;
+}
 
 __device__ __forceinline__ int MirrorI(int x, int n) {
   while (x < 0 || x >= n) x = x < 0 ? -x - 1 : 2 * n - 1 - x;
@@ -1677,12 +1687,13 @@ __device__ __forceinline__ void StorePixel(const PixelOut& o, int x, int y, floa
     const float a = o.alpha ? o.alpha[size_t(y) * o.xsize + x] : 1.0f;
     v[ncol] = a;
   }
-  const size_t base = (size_t(y) * o.xsize + x) * nc;
+  int dx, dy;
+  const size_t base = PixelOutIndex(o, x, y, &dx, &dy) * nc;
   for (uint32_t c = 0; c < nc; c++) {
     const float f = v[c];
     if (o.type == 2) {
       const float mul = float((1u << o.bits) - 1u);
-      const float t = __builtin_amdgcn_fmed3f(f * mul + c_dither[((y + int(c) * 13) & 31) * 32 + ((x + int(c) * 23) & 31)], 0.0f, mul);
+      const float t = __builtin_amdgcn_fmed3f(f * mul + c_dither[((dy + int(c) * 13) & 31) * 32 + ((dx + int(c) * 23) & 31)], 0.0f, mul);
       static_cast<uint8_t*>(o.dst)[base + c] = uint8_t(__float2int_rn(t));
     } else if (o.type == 3) {
       const float mul = float((1u << o.bits) - 1u);

@@ -803,12 +803,13 @@ __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   float s[4];
   for (uint32_t c = 0; c < ncol; c++) s[c] = v[P.num_color == 1 ? 0 : c];  // grey images replicate into RGB output
   if (nc == 2 || nc == 4) s[ncol] = a;
-  const size_t base = (size_t(y) * P.po.xsize + x) * nc;
+  int dx, dy;
+  const size_t base = PixelOutIndex(P.po, int(x), int(y), &dx, &dy) * nc;
   for (uint32_t c = 0; c < nc; c++) {
     const float f = s[c];
     if (P.po.type == 2) {
       const float m = float((1u << P.po.bits) - 1u);
-      const float t = __builtin_amdgcn_fmed3f(f * m + c_dither[((y + c * 13) & 31) * 32 + ((x + c * 23) & 31)], 0.0f, m);
+      const float t = __builtin_amdgcn_fmed3f(f * m + c_dither[((uint32_t(dy) + c * 13) & 31) * 32 + ((uint32_t(dx) + c * 23) & 31)], 0.0f, m);
       static_cast<uint8_t*>(P.po.dst)[base + c] = uint8_t(__float2int_rn(t));
     } else if (P.po.type == 3) {
       const float m = float((1u << P.po.bits) - 1u);

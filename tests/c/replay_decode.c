@@ -58,12 +58,16 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[3], "u16")) format.data_type = JXL_TYPE_UINT16;
   if (!strcmp(argv[3], "f16")) format.data_type = JXL_TYPE_FLOAT16;
   if (!strcmp(argv[3], "f32")) format.data_type = JXL_TYPE_FLOAT;
-  int use_callback = 0, use_mt = 0, linear = 0;
+  int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0;
+  uint8_t* ec_pixels[4] = {NULL, NULL, NULL, NULL};
+  size_t ec_sizes[4] = {0, 0, 0, 0};
   size_t chunk = 0;
   for (int i = 5; i < argc; i++) {
     if (!strcmp(argv[i], "callback")) use_callback = 1;
     if (!strcmp(argv[i], "mt")) use_mt = 1;
     if (!strcmp(argv[i], "linear")) linear = 1;
+    if (!strcmp(argv[i], "keep")) keep = 1; /* the pixels as coded, the orientation left to the caller */
+    if (!strcmp(argv[i], "ec")) want_ec = 1; /* also fetch every extra channel into its own buffer (jxl.cc:571-590) */
     if (!strncmp(argv[i], "chunk=", 6)) chunk = (size_t)atol(argv[i] + 6);
   }
   if (JxlSignatureCheck(bytes, size) == JXL_SIG_INVALID) return 2;
@@ -75,7 +79,7 @@ int main(int argc, char** argv) {
   int events = JXL_DEC_BASIC_INFO | JXL_DEC_FULL_IMAGE | JXL_DEC_COLOR_ENCODING | JXL_DEC_FRAME | JXL_DEC_PREVIEW_IMAGE | JXL_DEC_BOX;
   if (JxlDecoderSubscribeEvents(dec, events) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetRenderSpotcolors(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
-  if (JxlDecoderSetKeepOrientation(dec, JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
+  if (JxlDecoderSetKeepOrientation(dec, keep ? JXL_TRUE : JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetUnpremultiplyAlpha(dec, JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetCoalescing(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetDecompressBoxes(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
@@ -124,6 +128,7 @@ int main(int argc, char** argv) {
       if (JxlDecoderGetBasicInfo(dec, &info) != JXL_DEC_SUCCESS) return 2;
       printf("event BASIC_INFO %ux%u bits=%u extra=%u alpha_bits=%u container=%d\n", info.xsize, info.ysize, info.bits_per_sample,
              info.num_extra_channels, info.alpha_bits, info.have_container);
+      printf("orientation=%d\n", (int)info.orientation);
       for (uint32_t i = 0; i < info.num_extra_channels; i++) {
         JxlExtraChannelInfo eci;
         char name[8];
@@ -188,6 +193,12 @@ int main(int argc, char** argv) {
       for (uint32_t i = 0; i < info.num_extra_channels; i++) {
         size_t ec_size = 0;
         if (JxlDecoderExtraChannelBufferSize(dec, &format, &ec_size, i) != JXL_DEC_SUCCESS) return 2;
+        if (want_ec && i < 4) {
+          if (ec_size != (size_t)info.xsize * info.ysize * (g_bpp / format.num_channels)) return 2;
+          ec_pixels[i] = (uint8_t*)calloc(ec_size, 1);
+          ec_sizes[i] = ec_size;
+          if (JxlDecoderSetExtraChannelBuffer(dec, &format, ec_pixels[i], ec_size, i) != JXL_DEC_SUCCESS) return 2;
+        }
       }
     } else if (st == JXL_DEC_FULL_IMAGE) {
       printf("event FULL_IMAGE\n");
@@ -206,6 +217,8 @@ int main(int argc, char** argv) {
   if (rc == 0 && g_pixels) {
     FILE* o = fopen(argv[2], "wb");
     fwrite(g_pixels, 1, g_stride * info.ysize, o);
+    for (int i = 0; i < 4; i++) /* the extra channel planes follow the pixels */
+      if (ec_pixels[i]) fwrite(ec_pixels[i], 1, ec_sizes[i], o);
     fclose(o);
   }
   if (use_mt) printf("mt init=%d destroy=%d\n", g_mt_inits, g_mt_destroys);

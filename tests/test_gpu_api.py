@@ -227,3 +227,67 @@ def test_image_with_alpha_in_group_sections(built, tmp_path):
     got = np.frombuffer(px, np.uint8).reshape(300, 600, 4)
     assert np.array_equal(got[..., 3], alpha)
     assert np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1
+
+
+def _oriented(img, orientation):
+    """The image a viewer shows for `orientation` (EXIF numbering): mirror y, mirror x, then transpose, as the reference's
+    writer applies them (stage_write.cc:441-458, 664-699)."""
+    bits = [0, 0, 1, 3, 2, 4, 6, 7, 5][orientation]
+    if bits & 2:
+        img = img[::-1]
+    if bits & 1:
+        img = img[:, ::-1]
+    if bits & 4:
+        img = img.transpose(1, 0, 2)
+    return np.ascontiguousarray(img)
+
+
+@pytest.mark.parametrize("orientation", [2, 3, 4, 5, 6, 7, 8])
+def test_orientation_is_undone_by_the_pixel_writer(built, tmp_path, orientation):
+    """JxlDecoderSetKeepOrientation(false) (the default, and what DecodeImageJXL asks for: jxl.cc:213): basic info,
+    buffer size and frame header give the oriented size (decode.cc:985-990, 2233-2240) and the pixels and extra channel
+    planes arrive flipped / transposed. With keep_orientation the coded image comes back and the orientation is
+    reported. The oracle renders the coded orientation; numpy applies the reference's flips to it."""
+    import jxlo
+    J = built
+    xs, ys = 301, 143
+    rgb = J.synth_image(xs, ys, seed=21)
+    alpha = ((np.mgrid[0:ys, 0:xs][0] * 7 + np.mgrid[0:ys, 0:xs][1] * 3) & 255).astype(np.uint8)
+    J.set_orientation(orientation)
+    try:
+        vardct = J.encode_rgba8(np.dstack([rgb, alpha]), epf_iters=1)
+        lossless = J.encode_lossless(np.dstack([rgb, alpha]))
+    finally:
+        J.set_orientation(1)
+    oxs, oys = (ys, xs) if orientation > 4 else (xs, ys)
+    for name, data in (("vardct", vardct), ("lossless", lossless)):
+        o = jxlo.Decoded(data, dumps=False)
+        coded8 = o.rgb8.copy()
+        o.close()
+        assert coded8.shape == (ys, xs, 4) and np.array_equal(coded8[..., 3], alpha), name
+        want = _oriented(coded8, orientation)
+        rc, events, out, px = R.run(data, tmp_path, "u8", 4, "ec")
+        assert rc == 0, out
+        assert "event BASIC_INFO %ux%u " % (oxs, oys) in out and "orientation=1" in out, out
+        assert "event FRAME %ux%u " % (oxs, oys) in out, out
+        got = np.frombuffer(px[:oxs * oys * 4], np.uint8).reshape(oys, oxs, 4)
+        assert np.array_equal(got[..., 3], want[..., 3]), name
+        if name == "lossless":
+            assert np.array_equal(got, want)
+        else:
+            assert np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1  # (dither cell of the new place)
+        ec = np.frombuffer(px[oxs * oys * 4:], np.uint8).reshape(oys, oxs)
+        assert np.array_equal(ec, want[..., 3]), name
+        # float samples carry no dither: the oriented oracle floats, at the bar of the unoriented test
+        if name == "vardct":
+            o = jxlo.Decoded(data)
+            ref_f = _oriented(o.planes("rgbf").transpose(1, 2, 0).copy(), orientation)
+            o.close()
+            rc, events, out, px = R.run(data, tmp_path, "f32", 3, "callback")
+            assert rc == 0, out
+            assert np.abs(np.frombuffer(px, np.float32).reshape(oys, oxs, 3) - ref_f).max() < 5e-5
+        # keep_orientation: the coded pixels, the orientation left to the caller
+        rc, events, out, px = R.run(data, tmp_path, "u8", 4, "keep")
+        assert rc == 0 and "event BASIC_INFO %ux%u " % (xs, ys) in out and "orientation=%d" % orientation in out, out
+        got = np.frombuffer(px, np.uint8).reshape(ys, xs, 4)
+        assert np.abs(got.astype(int) - coded8.astype(int)).max() <= (0 if name == "lossless" else 1)
