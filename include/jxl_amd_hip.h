@@ -317,6 +317,34 @@ int jxlhip_modular_status(JxlHipContext* ctx, uint32_t* status, uint32_t* end_bi
 /* Test access: a channel buffer's int32 samples (w * h) after the run; synchronous. */
 int jxlhip_modular_download_buffer(JxlHipContext* ctx, uint32_t buffer, int32_t* dst, size_t n);
 
+/* ---- Forward path (first slice): the pixel-domain half of a VarDCT encode on the device.
+ * Replaces, behind lib/jxl/enc_frame.cc:1135-1166's per-group loop: SRGBToXYB (enc_xyb.cc:152-174), the Gaborish
+ * sharpening (enc_gaborish.cc:21-70) and ComputeCoefficients (enc_group.cc:380-533: forward transform, DC from the
+ * lowest frequencies, AC quantisation with chroma-from-luma from the dequantised Y). Transform selection and the quant
+ * field are this library's own simple activity heuristics, not the reference's search (enc_ac_strategy.cc,
+ * enc_adaptive_quantization.cc): the output is a valid model of a frame, not libjxl's choice of one. Entropy coding
+ * and the headers stay on the host (csrc/enc). */
+typedef struct {
+  uint32_t xsize, ysize;
+  float distance;         /* Butteraugli-style target: scales the thresholds of the transform selection */
+  uint32_t gaborish;      /* 1: pre-sharpen with the approximate inverse of the decoder's Gaborish blur */
+  uint32_t strategy_mode; /* 0: DCT8 only, 1: activity-driven DCT 8..64 incl. rectangles */
+  uint32_t global_scale, quant_dc; /* Quantizer parameters of the frame (quantizer.h:82-114) */
+  float quant_ac;         /* AC quant target the quant field is built around */
+  /* dequantisation tables, as JxlHipFrameDesc: kind k, channel c at dequant[dequant_offset[k] + c * dequant_size[k]] */
+  const float* dequant;
+  uint32_t dequant_floats;
+  uint32_t dequant_offset[17], dequant_size[17];
+} JxlHipEncDesc;
+/* rgb: interleaved sRGB8 in host memory, `stride` bytes per row. Outputs (host memory): acs[yb * xb] = (strategy << 1) |
+ * first-block bit, qf[yb * xb] (quant field at first blocks), dc[3][yb * xb] quantised DC stored X, Y, B, and
+ * coeffs[groups][3][65536] quantised AC, block-contiguous per 256x256 group in raster order of the first blocks
+ * (xb = ceil(xsize / 8), groups = ceil(xsize / 256) * ceil(ysize / 256)). Synchronous. */
+int jxlhip_enc_forward(JxlHipContext* ctx, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* desc, uint8_t* acs, int32_t* qf,
+                       int32_t* dc, int32_t* coeffs);
+/* Kernel time of the last jxlhip_enc_forward (HIP events around the launches, copies excluded), milliseconds. */
+int jxlhip_enc_last_ms(JxlHipContext* ctx, float* ms);
+
 /* Timing of the last run of each stage in milliseconds (HIP events on the context's stream);
  * which: 0 entropy, 1 transform, 2 filter+colour. Synchronous. */
 int jxlhip_last_stage_ms(JxlHipContext* ctx, int which, float* ms);

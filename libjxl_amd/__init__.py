@@ -453,6 +453,51 @@ def encode_rgb8(img, **kw):
     return _finish(E, r, out, n, "jxlenc_encode_rgb8")
 
 
+def encode_rgb8_gpu(img, ctx, timings=None, **kw):
+    """VarDCT-encodes an RGB8 image with the pixel-domain half (colour, sharpening, transform selection, forward DCT,
+    quantisation) on the GPU (jxlhip_enc_forward on `ctx`) and entropy coding / headers on the host. `timings` (a dict)
+    receives forward_s (the call, copies included), assemble_s and kernels_ms (HIP events around the launches)."""
+    E, L = _enc_lib(), lib()
+    pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8))
+    E.jxlenc_encode_rgb8_forward.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), ctypes.c_void_p,
+                                             ctypes.c_void_p, pp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_double)]
+    L.jxlhip_enc_last_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    img = np.ascontiguousarray(img, np.uint8)
+    p = _params(**kw)
+    out, n = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t()
+    secs = (ctypes.c_double * 2)()
+    fn = ctypes.cast(L.jxlhip_enc_forward, ctypes.c_void_p)
+    r = E.jxlenc_encode_rgb8_forward(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), fn, ctx._h, ctypes.byref(out),
+                                     ctypes.byref(n), secs)
+    data = _finish(E, r, out, n, "jxlenc_encode_rgb8_forward")
+    if timings is not None:
+        ms = ctypes.c_float()
+        _check(L.jxlhip_enc_last_ms(ctx._h, ctypes.byref(ms)), "jxlhip_enc_last_ms")
+        timings.update(forward_s=secs[0], assemble_s=secs[1], kernels_ms=ms.value)
+    return data
+
+
+def enc_forward_model(img, ctx=None, **kw):
+    """Test access: the raw outputs of one forward call (acs, qf, dc, coeffs) from the GPU path on `ctx`, or from the
+    CPU stream writer's own model code when ctx is None."""
+    E = _enc_lib()
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    E.jxlenc_forward_model.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    img = np.ascontiguousarray(img, np.uint8)
+    ys, xs = img.shape[:2]
+    xb, yb, ng = (xs + 7) // 8, (ys + 7) // 8, ((xs + 255) // 256) * ((ys + 255) // 256)
+    acs, qf = np.zeros((yb, xb), np.uint8), np.zeros((yb, xb), np.int32)
+    dc, co = np.zeros((3, yb, xb), np.int32), np.zeros((ng, 3, 65536), np.int32)
+    p = _params(**kw)
+    fn = ctypes.cast(lib().jxlhip_enc_forward if ctx is not None else E.jxlenc_forward_cpu, ctypes.c_void_p)
+    r = E.jxlenc_forward_model(img.tobytes(), xs, ys, ctypes.byref(p), fn, ctx._h if ctx is not None else None, acs.ctypes.data,
+                               qf.ctypes.data, dc.ctypes.data, co.ctypes.data)
+    if r:
+        raise JxlAmdError("jxlenc_forward_model failed (%d)" % r)
+    return dict(acs=acs, qf=qf, dc=dc, coeffs=co)
+
+
 def encode_rgba8(img, **kw):
     """RGBA8 image -> VarDCT codestream with alpha as a (lossless) Modular-coded extra channel."""
     E = _enc_lib()

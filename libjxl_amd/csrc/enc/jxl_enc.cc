@@ -12,13 +12,18 @@
 // dec_modular.cc:427-562, dec_group.cc:469-639, dec_ans.cc:58-376, dec_context_map.cc:48-95, dec_ma.cc:107-159.
 // This is a growth seed for the "VarDCT encoder forward path" row of SURVEY.md §8f, not a quality-tuned encoder.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <queue>
+#include <stdexcept>
+#include <string>
 #include <vector>
+
+#include "../../../include/jxl_amd_hip.h"  // JxlHipEncDesc: the forward path's descriptor (no link dependency)
 
 #include "../host/jxh_bits.h"
 #include "../host/jxh_entropy.h"
@@ -1306,19 +1311,94 @@ static void QuantParams(float distance, FrameModel* f, float* quant_ac) {
   *quant_ac = qac;
 }
 
+// The pixel-domain half of the encode done elsewhere (the HIP forward path, jxlhip_enc_forward of include/jxl_amd_hip.h,
+// whose signature this is): the caller hands the function and its context over, this library does not link against it.
+typedef int (*ForwardFn)(void* ctx, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* desc, uint8_t* acs, int32_t* qf, int32_t* dc,
+                         int32_t* coeffs);
+struct ForwardHook {
+  ForwardFn fn;
+  void* ctx;
+  double seconds[2];  // out: forward call, assembly (entropy coding + headers)
+  // test access: when set, the raw outputs of the forward call are copied here and nothing is assembled
+  uint8_t* cap_acs = nullptr;
+  int32_t *cap_qf = nullptr, *cap_dc = nullptr, *cap_coeffs = nullptr;
+};
+
+static double NowSeconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// model_only: stop before the bitstream assembly and hand the frame model out (the CPU form of the forward path).
 static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out, size_t img_xs = 0,
-                        size_t img_ys = 0, const std::vector<uint8_t>* alpha = nullptr) {
+                        size_t img_ys = 0, const std::vector<uint8_t>* alpha = nullptr, ForwardHook* hook = nullptr,
+                        FrameModel* model_only = nullptr) {
   FrameModel f;
   if (alpha) f.alpha = *alpha;
   f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
   f.img_xs = img_xs ? img_xs : xs;
   f.img_ys = img_ys ? img_ys : ys;
   const size_t xp = f.xb * 8, yp = f.yb * 8;
-  std::vector<float> xyb[3];
-  RgbToXyb(rgb, xs, ys, xp, yp, xyb);
   float quant_ac;
   QuantParams(p.distance, &f, &quant_ac);
   f.gab = p.gab < 0 ? 1 : p.gab;
+  if (hook) {
+    // image mode with the default colour correlation only: what the device path implements
+    if (p.strategy_mode > 1 || p.random_cmap || p.custom_cmap) throw std::runtime_error("forward hook: unsupported parameters");
+    const double t0 = NowSeconds();
+    f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
+    f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0);
+    f.sharp.assign(f.xb * f.yb, 4);
+    f.ytox.assign(DivCeil(f.xb, 8) * DivCeil(f.yb, 8), 0);
+    f.ytob.assign(f.ytox.size(), 0);
+    jxh::DequantTables dq;
+    JxlHipEncDesc d;
+    memset(&d, 0, sizeof(d));
+    std::vector<float> flat;
+    for (int k = 0; k < 17; k++) {
+      if (k == 13 || k == 14 || k == 15 || k == 16) {  // 128 / 256 point tables: never selected here, not built
+        d.dequant_offset[k] = 0;
+        d.dequant_size[k] = 0;
+        continue;
+      }
+      dq.Compute(k);
+      d.dequant_offset[k] = uint32_t(flat.size());
+      d.dequant_size[k] = uint32_t(dq.table[k].size() / 3);
+      flat.insert(flat.end(), dq.table[k].begin(), dq.table[k].end());
+    }
+    d.dequant = flat.data();
+    d.dequant_floats = uint32_t(flat.size());
+    d.xsize = uint32_t(xs);
+    d.ysize = uint32_t(ys);
+    d.distance = p.distance;
+    d.gaborish = f.gab ? 1 : 0;
+    d.strategy_mode = uint32_t(p.strategy_mode);
+    d.global_scale = f.global_scale;
+    d.quant_dc = f.quant_dc;
+    d.quant_ac = quant_ac;
+    const size_t nb = f.xb * f.yb, ng = DivCeil(xs, 256) * DivCeil(ys, 256);
+    f.acs.assign(nb, 0);
+    f.qf.assign(nb, 0);
+    std::vector<int32_t> dc(3 * nb), co(ng * 3 * 65536);
+    const int r = hook->fn(hook->ctx, rgb, xs * 3, &d, f.acs.data(), f.qf.data(), dc.data(), co.data());
+    if (r) throw std::runtime_error("forward hook failed (" + std::to_string(r) + ")");
+    if (hook->cap_acs) {
+      memcpy(hook->cap_acs, f.acs.data(), nb);
+      memcpy(hook->cap_qf, f.qf.data(), nb * 4);
+      memcpy(hook->cap_dc, dc.data(), dc.size() * 4);
+      memcpy(hook->cap_coeffs, co.data(), co.size() * 4);
+      return;
+    }
+    for (int c = 0; c < 3; c++) f.dc[c].assign(dc.begin() + c * nb, dc.begin() + (c + 1) * nb);
+    f.coeffs.resize(ng);
+    for (size_t g = 0; g < ng; g++) f.coeffs[g].assign(co.begin() + g * 3 * 65536, co.begin() + (g + 1) * 3 * 65536);
+    const double t1 = NowSeconds();
+    Assemble(f, p, out);
+    hook->seconds[0] = t1 - t0;
+    hook->seconds[1] = NowSeconds() - t1;
+    return;
+  }
+  std::vector<float> xyb[3];
+  RgbToXyb(rgb, xs, ys, xp, yp, xyb);
   if (f.gab) {
     // Approximate inverse of the decoder's Gaborish blur K (3x3, default weights): y <- y + (x - K*y), 4 rounds.
     const float w1 = 1.1f * 0.104699568f, w2 = 1.1f * 0.055680538f, nrm = 1.0f / (1.0f + 4 * (w1 + w2));
@@ -1516,6 +1596,10 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
         }
         offset += size;
       }
+  }
+  if (model_only) {
+    *model_only = std::move(f);
+    return;
   }
   Assemble(f, p, out);
 }
@@ -2160,6 +2244,83 @@ int jxlenc_encode_rgb8(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEn
     return -2;
   }
   return Finish(v, out, n);
+}
+
+// jxlenc_encode_rgb8 with the pixel-domain half (colour, sharpening, transform selection, forward DCT, quantisation) done
+// by `forward` (jxlhip_enc_forward and its context); entropy coding and headers here. seconds (may be NULL): forward
+// call, assembly.
+int jxlenc_encode_rgb8_forward(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, jxe::ForwardFn forward, void* ctx,
+                               uint8_t** out, size_t* n, double* seconds) {
+  if (!rgb || !xs || !ys || !p || p->distance <= 0 || !forward) return -1;
+  jxe::Params q;
+  memcpy(&q, p, sizeof(q));
+  if (q.upsampling > 1) return -1;
+  std::vector<uint8_t> v;
+  jxe::ForwardHook hook = {forward, ctx, {0, 0}};
+  try {
+    jxe::EncodeImage(rgb, xs, ys, q, &v, 0, 0, nullptr, &hook);
+  } catch (...) {
+    return -2;
+  }
+  if (seconds) {
+    seconds[0] = hook.seconds[0];
+    seconds[1] = hook.seconds[1];
+  }
+  return Finish(v, out, n);
+}
+
+// The CPU form of the forward path, with jxlhip_enc_forward's signature (ctx unused): what the GPU tests compare the
+// device path with, array by array, and what lets the hook plumbing be tested without a GPU.
+int jxlenc_forward_cpu(void*, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* d, uint8_t* acs, int32_t* qf, int32_t* dc,
+                       int32_t* coeffs) {
+  if (!rgb || !d || !acs || !qf || !dc || !coeffs || stride < size_t(d->xsize) * 3) return -1;
+  jxe::Params q;
+  memset(&q, 0, sizeof(q));
+  q.distance = d->distance;
+  q.epf_iters = -1;
+  q.gab = int32_t(d->gaborish);
+  q.strategy_mode = int32_t(d->strategy_mode);
+  q.seed = 1;
+  std::vector<uint8_t> tight;
+  if (stride != size_t(d->xsize) * 3) {
+    tight.resize(size_t(d->xsize) * d->ysize * 3);
+    for (uint32_t y = 0; y < d->ysize; y++) memcpy(tight.data() + size_t(y) * d->xsize * 3, rgb + y * stride, size_t(d->xsize) * 3);
+    rgb = tight.data();
+  }
+  jxe::FrameModel f;
+  try {
+    jxe::EncodeImage(rgb, d->xsize, d->ysize, q, nullptr, 0, 0, nullptr, nullptr, &f);
+  } catch (...) {
+    return -2;
+  }
+  if (f.global_scale != d->global_scale || f.quant_dc != d->quant_dc) return -3;  // the descriptor is not this distance's
+  const size_t nb = f.xb * f.yb;
+  memcpy(acs, f.acs.data(), nb);
+  memcpy(qf, f.qf.data(), nb * 4);
+  for (int c = 0; c < 3; c++) memcpy(dc + c * nb, f.dc[c].data(), nb * 4);
+  for (size_t g = 0; g < f.coeffs.size(); g++) memcpy(coeffs + g * 3 * 65536, f.coeffs[g].data(), size_t(3) * 65536 * 4);
+  return 0;
+}
+
+// Test access: the raw outputs of one forward call made with the descriptor jxlenc_encode_rgb8_forward builds
+// (acs / qf: yb * xb, dc: 3 * yb * xb, coeffs: groups * 3 * 65536).
+int jxlenc_forward_model(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, jxe::ForwardFn forward, void* ctx,
+                         uint8_t* acs, int32_t* qf, int32_t* dc, int32_t* coeffs) {
+  if (!rgb || !xs || !ys || !p || p->distance <= 0 || !forward || !acs || !qf || !dc || !coeffs) return -1;
+  jxe::Params q;
+  memcpy(&q, p, sizeof(q));
+  jxe::ForwardHook hook = {forward, ctx, {0, 0}};
+  hook.cap_acs = acs;
+  hook.cap_qf = qf;
+  hook.cap_dc = dc;
+  hook.cap_coeffs = coeffs;
+  std::vector<uint8_t> v;
+  try {
+    jxe::EncodeImage(rgb, xs, ys, q, &v, 0, 0, nullptr, &hook);
+  } catch (...) {
+    return -2;
+  }
+  return 0;
 }
 
 // RGBA8 image: the colour as jxlenc_encode_rgb8, alpha (channel 3) losslessly as a Modular-coded extra channel.

@@ -21,6 +21,7 @@
 #include "jxl_hip_entropy_lanes.h"
 #include "jxl_hip_filter_fused.h"
 #include "jxl_hip_modular.h"
+#include "jxl_hip_enc.h"
 
 namespace {
 #include "../host/afv_basis.inc"
@@ -219,6 +220,10 @@ struct JxlHipContext {
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
   // output pixel format (jxlhip_set_output_format; JxlDataType numbering): RGB8 by default
   uint32_t out_type = 2, out_nc = 3, out_bits = 8, out_swap = 0;
+  // forward (encoder) path, jxlhip_enc_forward: device buffers and the kernel time of the last call
+  Buf enc_rgb, enc_planes[3], enc_act, enc_acs, enc_qf, enc_off, enc_dc, enc_coef, enc_lut, enc_dq;
+  hipEvent_t enc_ev[2] = {nullptr, nullptr};
+  bool enc_timed = false;
   uint32_t out_orient = 0;  // jxlhip_set_output_orientation: PixelOut::orient bits (0 = the image as coded)
   // noise synthesis (JxlHipFrameDesc::has_noise): raw random planes [3][ys][xs], LUT, seeds, base colour correlation
   Buf noise;
@@ -395,7 +400,8 @@ static std::vector<Buf*> AllBufs(JxlHipContext* c) {
   std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
-                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise};
+                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise,
+                &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq};
   for (auto& pb : c->pass_bufs)
     for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset, &pb.alias_packed}) all.push_back(b);
   return all;
@@ -409,6 +415,8 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   std::vector<Buf*> all = AllBufs(c);
   for (Buf* b : all) b->Free();
   for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->enc_ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stage.done) (void)hipEventDestroy(c->stage.done);
   if (c->stage.p) (void)hipHostFree(c->stage.p);
@@ -2598,6 +2606,111 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
         }
       }
   }
+  return 0;
+}
+
+// ---- forward path: see jxl_hip_enc.h
+int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* d, uint8_t* acs, int32_t* qf, int32_t* dc,
+                       int32_t* coeffs) {
+  if (!c || !rgb || !d || !acs || !qf || !dc || !coeffs) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!d->xsize || !d->ysize || d->xsize > (1u << 18) || d->ysize > (1u << 18) || stride < size_t(d->xsize) * 3) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!(d->distance > 0) || !d->global_scale || !d->quant_dc || !d->dequant || d->strategy_mode > 1) return JXLHIP_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < 17; k++)
+    if (size_t(d->dequant_offset[k]) + 3 * size_t(d->dequant_size[k]) > d->dequant_floats) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  jxlhip::EncFwd P;
+  memset(&P, 0, sizeof(P));
+  P.xs = d->xsize;
+  P.ys = d->ysize;
+  P.xb = (P.xs + 7) / 8;
+  P.yb = (P.ys + 7) / 8;
+  P.xp = P.xb * 8;
+  P.yp = P.yb * 8;
+  P.xg = (P.xs + 255) / 256;
+  P.yg = (P.ys + 255) / 256;
+  const size_t nb = size_t(P.xb) * P.yb, plane = size_t(P.xp) * P.yp, ng = size_t(P.xg) * P.yg;
+  int r;
+  if ((r = c->enc_rgb.Ensure(stride * P.ys)) || (r = c->enc_act.Ensure(nb * 4)) || (r = c->enc_acs.Ensure(nb)) || (r = c->enc_qf.Ensure(nb * 4)) ||
+      (r = c->enc_off.Ensure(nb * 4)) || (r = c->enc_dc.Ensure(3 * nb * 4)) || (r = c->enc_coef.Ensure(ng * 3 * 65536 * 4)) ||
+      (r = c->enc_lut.Ensure(256 * 4)) || (r = c->enc_dq.Ensure(size_t(d->dequant_floats) * 4)))
+    return r;
+  for (auto& b : c->enc_planes)
+    if ((r = b.Ensure(3 * plane * 4))) return r;
+  for (auto& ev : c->enc_ev)
+    if (!ev) HIP_TRY(hipEventCreate(&ev));
+  float lut[256];
+  for (int i = 0; i < 256; i++) {
+    const float v = float(i) / 255.0f;
+    lut[i] = v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);  // sRGB EOTF (transfer_functions-inl.h TF_SRGB)
+  }
+  HIP_TRY(hipMemcpyAsync(c->enc_lut.p, lut, sizeof(lut), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->enc_dq.p, d->dequant, size_t(d->dequant_floats) * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->enc_rgb.p, rgb, stride * P.ys, hipMemcpyHostToDevice, c->stream));
+  P.rgb = c->enc_rgb.as<uint8_t>();
+  P.rgb_stride = stride;
+  P.srgb_lut = c->enc_lut.as<float>();
+  P.act = c->enc_act.as<float>();
+  P.acs = c->enc_acs.as<uint8_t>();
+  P.qf = c->enc_qf.as<int32_t>();
+  P.coef_off = c->enc_off.as<uint32_t>();
+  constexpr size_t kBasisFloats = 87381;
+  P.basis_t = c->basis.as<float>() + kBasisFloats + 3;
+  P.dequant = c->enc_dq.as<float>();
+  memcpy(P.dq_offset, d->dequant_offset, sizeof(P.dq_offset));
+  memcpy(P.dq_size, d->dequant_size, sizeof(P.dq_size));
+  P.dc = c->enc_dc.as<int32_t>();
+  P.coeffs = c->enc_coef.as<int32_t>();
+  P.distance = d->distance;
+  P.quant_ac = d->quant_ac;
+  P.inv_gs = 65536.0f / float(d->global_scale);
+  P.x_dm = std::pow(1.25f, 2.0f - 3.0f);  // x_qm_scale 3, b_qm_scale 2 (dec_cache.h:161-162)
+  P.b_dm = std::pow(1.25f, 2.0f - 2.0f);
+  const float inv_quant_dc = P.inv_gs / float(d->quant_dc);
+  P.dc_step[0] = inv_quant_dc / 4096.0f;
+  P.dc_step[1] = inv_quant_dc / 512.0f;
+  P.dc_step[2] = inv_quant_dc / 256.0f;
+  P.strategy_mode = d->strategy_mode;
+  HIP_TRY(hipEventRecord(c->enc_ev[0], c->stream));
+  // colour: into planes[0] when there is no sharpening, else into the `orig` set
+  float* sets[3] = {c->enc_planes[0].as<float>(), c->enc_planes[1].as<float>(), c->enc_planes[2].as<float>()};
+  const dim3 px_grid((P.xp + 255) / 256, P.yp);
+  P.planes = d->gaborish ? sets[2] : sets[0];
+  hipLaunchKernelGGL(jxlhip::k_enc_xyb, px_grid, dim3(256), 0, c->stream, P);
+  if (d->gaborish) {
+    // 4 rounds: orig = sets[2]; in = orig, out = sets[0]; then 0 -> 1 -> 0 -> 1; the last result is copied by renaming
+    const dim3 g3(px_grid.x, px_grid.y, 3);
+    const float* in = sets[2];
+    float* out = sets[0];
+    for (int it = 0; it < 4; it++) {
+      hipLaunchKernelGGL(jxlhip::k_enc_sharpen, g3, dim3(256), 0, c->stream, static_cast<const float*>(sets[2]), in, out, P.xp, P.yp);
+      in = out;
+      out = out == sets[0] ? sets[1] : sets[0];
+    }
+    P.planes = const_cast<float*>(in);
+  }
+  hipLaunchKernelGGL(jxlhip::k_enc_activity, dim3((P.xb + 7) / 8, P.yb), dim3(64), 0, c->stream, P);
+  const uint32_t tiles = ((P.xb + 7) / 8) * ((P.yb + 7) / 8);
+  hipLaunchKernelGGL(jxlhip::k_enc_select, dim3((tiles + 63) / 64), dim3(64), 0, c->stream, P);
+  hipLaunchKernelGGL(jxlhip::k_enc_offsets, dim3((uint32_t(ng) + 63) / 64), dim3(64), 0, c->stream, P);
+  HIP_TRY(hipMemsetAsync(c->enc_coef.p, 0, ng * 3 * 65536 * 4, c->stream));
+  hipLaunchKernelGGL(jxlhip::k_enc_transform<256>, dim3(uint32_t(nb)), dim3(256), 0, c->stream, P);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->enc_ev[1], c->stream));
+  c->enc_timed = true;
+  HIP_TRY(hipMemcpyAsync(acs, c->enc_acs.p, nb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(qf, c->enc_qf.p, nb * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(dc, c->enc_dc.p, 3 * nb * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(coeffs, c->enc_coef.p, ng * 3 * 65536 * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int jxlhip_enc_last_ms(JxlHipContext* c, float* ms) {
+  if (!c || !ms) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->enc_timed) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->enc_ev[1]));
+  HIP_TRY(hipEventElapsedTime(ms, c->enc_ev[0], c->enc_ev[1]));
   return 0;
 }
 

@@ -1,0 +1,83 @@
+"""GPU tests (-m gpu) of the forward VarDCT path (first slice): jxlhip_enc_forward against the CPU
+stream writer's model of the same frame, array by array, and encode -> decode round trips through the GPU decoder.
+
+What pins what: the decoder (inverse DCT, dequantisation, colour) is pinned against the reference, so a
+round trip at a stated quality pins the forward transform, the quantiser and the colour conversion as its inverse; the
+transform selection / quant field are this repo's own heuristics and are only checked against their CPU form."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _psnr(a, b):
+    return 10 * np.log10(255.0 ** 2 / np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+
+
+@pytest.mark.parametrize("size,kw", [((301, 143), {}), ((512, 512), dict(distance=2.0)), ((640, 333), dict(strategy_mode=0)),
+                                     ((257, 260), dict(gab=0, distance=0.5)), ((1000, 700), dict(distance=4.0))])
+def test_forward_path_matches_the_cpu_model(built, size, kw):
+    """Same float expressions in the same order with contraction off: transform selection and quant field agree except
+    where log2f / cbrtf differ in the last place, coefficients and DC except at rounding ties."""
+    J = built
+    img = J.synth_image(size[0], size[1], seed=31)
+    ctx = J.HipContext()
+    gpu = J.enc_forward_model(img, ctx, **kw)
+    cpu = J.enc_forward_model(img, None, **kw)
+    ctx.close()
+    same_acs = gpu["acs"] == cpu["acs"]
+    assert same_acs.mean() > 0.995, "transform selection differs on %.3f%% of the blocks" % (100 - 100 * same_acs.mean())
+    if same_acs.all():
+        assert (gpu["qf"] != cpu["qf"]).mean() < 0.005 and np.abs(gpu["qf"] - cpu["qf"]).max() <= 1
+        assert np.abs(gpu["dc"] - cpu["dc"]).max() <= 1 and (gpu["dc"] != cpu["dc"]).mean() < 0.002
+        diff = gpu["coeffs"] != cpu["coeffs"]
+        assert diff.mean() < 0.002, diff.mean()
+        if (gpu["qf"] == cpu["qf"]).all():
+            assert np.abs(gpu["coeffs"] - cpu["coeffs"]).max() <= 1
+    nz = np.count_nonzero(gpu["coeffs"])
+    assert 0.5 < nz / max(1, np.count_nonzero(cpu["coeffs"])) < 2.0
+
+
+@pytest.mark.parametrize("distance,floor", [(0.5, 39.0), (1.0, 37.0), (2.0, 33.5), (4.0, 30.5)])
+def test_gpu_encoded_stream_round_trips(built, distance, floor):
+    """Encode on the GPU, decode on the GPU and with the oracle: same pixels from both decoders, quality as the CPU
+    writer's stream of the same image, size within a few percent of it."""
+    import jxlo
+    J = built
+    img = J.synth_image(777, 555, seed=17)
+    ctx = J.HipContext()
+    t = {}
+    data = J.encode_rgb8_gpu(img, ctx, timings=t, distance=distance)
+    ctx.close()
+    assert t["kernels_ms"] > 0
+    ref = J.encode_rgb8(img, distance=distance)
+    assert abs(len(data) - len(ref)) < 0.03 * len(ref)
+    got = J.decode_rgb8(data)
+    o = jxlo.Decoded(data, dumps=False)
+    want = o.rgb8.copy()
+    o.close()
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    p_gpu, p_cpu = _psnr(got, img), _psnr(J.decode_rgb8(ref), img)
+    assert p_gpu > floor and abs(p_gpu - p_cpu) < 0.1, (p_gpu, p_cpu)
+
+
+def test_forward_dct_of_the_basis_functions(built):
+    """dct_test.cc's closed form, through the whole forward path: an image whose Y plane is one DCT basis function
+    quantises to a single non-zero AC coefficient per block at that frequency. A grey cosine pattern has X = 0 and
+    B = Y in XYB up to the opsin non-linearity, so the check is on the dominant coefficient of Y."""
+    J = built
+    ctx = J.HipContext()
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    for (ky, kx) in ((0, 1), (3, 0), (2, 5), (7, 7)):
+        wave = np.cos((xx % 8 + 0.5) * kx * np.pi / 8) * np.cos((yy % 8 + 0.5) * ky * np.pi / 8)
+        grey = np.clip(128 + 60 * wave, 0, 255).astype(np.uint8)
+        m = J.enc_forward_model(np.dstack([grey] * 3), ctx, strategy_mode=0, gab=0, distance=1.0)
+        # 64 DCT8 blocks; a square transform's coefficients are stored transposed (coeff_order_fwd.h:27-43: [kx][ky])
+        y = m["coeffs"][0, 1].reshape(-1, 8, 8)[:64]
+        peak = np.abs(y).reshape(64, 64).argmax(axis=1)
+        assert (peak == kx * 8 + ky).all(), (ky, kx, peak[:4])
+        others = np.abs(y).reshape(64, 64).copy()
+        others[:, kx * 8 + ky] = 0
+        assert others.max() * 8 <= np.abs(y[:, kx, ky]).min(), (ky, kx)
+    ctx.close()
