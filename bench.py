@@ -358,6 +358,71 @@ def lossless_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize
         dist.destroy_process_group()
 
 
+def encode_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, ysize):
+    """BASELINE.json configs[4] (VarDCT encode), first slice: the forward path on the GPU (colour, sharpening, transform
+    selection, forward DCT, quantisation: jxlhip_enc_forward). A step runs the kernel sequence over `--batch` frames with
+    the RGB8 input resident in HBM; entropy coding stays on the host and is reported in `e2e`, not in `value`."""
+    batch = args.batch if args.batch != 640 else 64
+    img = J.synth_image(xsize, ysize, 177)
+    ctx = J.HipContext(local_rank)
+    t = {}
+    data = J.encode_rgb8_gpu(img, ctx, timings=t, distance=args.distance)  # (leaves the image resident on the device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        ctx.enc_rerun(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        span_ms, transform_ms = ctx.enc_rerun(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    total_frames, max_elapsed = sharding.aggregate(batch * args.steps, elapsed, dist)
+    if rank == 0:
+        px = xsize * ysize
+        # forward transform kernel: reads the three f32 planes once, writes int32 coefficients once
+        alg = 24.0 * px
+        out = {"metric": "megapixels/sec VarDCT encode forward path, %dx%d d%.1f" % (xsize, ysize, args.distance),
+               "value": round(total_frames * px * 1e-6 / max_elapsed, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(max_elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%dx%d RGB8 -> XYB, sharpening, transform selection, forward DCT 8..64, quantisation with "
+                                      "chroma-from-luma (pixel-domain half of a VarDCT encode), %d frames/step/GPU, input resident in "
+                                      "HBM; entropy coding on the host is outside `value` (see e2e)" % (xsize, ysize, batch),
+                          "bytes_out": len(data), "bpp": round(len(data) * 8.0 / px, 3),
+                          "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
+               "roofline": {"bound": "hbm", "kernel": "k_enc_transform_tile", "achieved": round(alg / (transform_ms * 1e-3) / 1e9, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (transform_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                            "traffic": None, "launch_ms": round(transform_ms, 4), "algorithmic_bytes_per_launch": alg,
+                            "kernels_ms_per_frame": round(span_ms / batch, 4)}}
+        if world == 1:
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                J.encode_rgb8_gpu(img, ctx, timings=t, distance=args.distance)
+                dt = time.perf_counter() - t1
+                if best is None or dt < best[0]:
+                    best = (dt, dict(t))
+            out["e2e"] = {"value": round(px * 1e-6 / best[0], 2), "unit": "MP/s", "seconds_per_frame": round(best[0], 4),
+                          "forward_call_s": round(best[1]["forward_s"], 4), "host_entropy_coding_s": round(best[1]["assemble_s"], 4),
+                          "note": "one frame, RGB8 in host memory to codestream bytes: upload, kernels, download, host rANS coding"}
+            if not args.no_cpu_baseline:
+                t1, c1 = time.perf_counter(), time.process_time()
+                J.enc_forward_model(img, None, distance=args.distance)
+                dt = time.perf_counter() - t1
+                cores = max(1, int(round((time.process_time() - c1) / dt)))  # the cores the OpenMP loops really got (cgroup share)
+                out["cpu_baseline"] = {"value": round(px * 1e-6 / dt, 3), "unit": "MP/s", "cores": cores, "kind": "port",
+                                       "sample": "the same forward path of one frame by the CPU stream writer (OpenMP over groups)"}
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -390,7 +455,7 @@ def main():
                     help="frames of the end-to-end measurement (compressed bytes in host memory -> RGB8 in host memory, host parse / "
                          "upload / GPU stages / download pipelined over host threads); 0 = skip")
     ap.add_argument("--max-clusters", type=int, default=0, help="sensitivity runs: histogram clusters of the synthetic encoder (0 = its default 64)")
-    ap.add_argument("--workload", choices=("vardct", "lossless"), default="vardct",
+    ap.add_argument("--workload", choices=("vardct", "lossless", "encode"), default="vardct",
                     help="vardct: BASELINE.json configs[1] (the headline); lossless: configs[3], 3840x2160 Modular lossless "
                          "(Squeeze + MA tree + weighted predictor) through k_modular_streams")
     ap.add_argument("--ac-code-mode", type=int, default=0,
@@ -437,6 +502,8 @@ def main():
     import libjxl_amd as J
     from libjxl_amd import sharding
     J.lib()  # fails loudly if the HIP extension is missing
+    if args.workload == "encode":
+        return encode_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, ysize)
     if args.workload == "lossless":
         return lossless_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, ysize)
 

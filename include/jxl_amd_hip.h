@@ -342,8 +342,13 @@ typedef struct {
  * (xb = ceil(xsize / 8), groups = ceil(xsize / 256) * ceil(ysize / 256)). Synchronous. */
 int jxlhip_enc_forward(JxlHipContext* ctx, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* desc, uint8_t* acs, int32_t* qf,
                        int32_t* dc, int32_t* coeffs);
+/* Measurement: runs the kernel sequence of the last jxlhip_enc_forward `times` more times on its input, which is still
+ * resident on the device (no copies); jxlhip_enc_last_ms then gives the time of all `times` passes. Synchronous. */
+int jxlhip_enc_forward_rerun(JxlHipContext* ctx, uint32_t times);
 /* Kernel time of the last jxlhip_enc_forward (HIP events around the launches, copies excluded), milliseconds. */
 int jxlhip_enc_last_ms(JxlHipContext* ctx, float* ms);
+/* The forward-transform kernel alone (the last pass of the last call), milliseconds. */
+int jxlhip_enc_last_transform_ms(JxlHipContext* ctx, float* ms);
 
 /* Timing of the last run of each stage in milliseconds (HIP events on the context's stream);
  * which: 0 entropy, 1 transform, 2 filter+colour. Synchronous. */

@@ -218,6 +218,19 @@ class HipContext:
         _check(L.jxlhip_set_output_orientation(self._h, int(orientation)), "jxlhip_set_output_orientation")
         self._transposed = orientation > 4
 
+    def enc_rerun(self, times=1):
+        """Measurement: the forward-path kernels of the last encode_rgb8_gpu on this context, `times` more times on the
+        resident input. Returns (ms of all passes, ms of the transform kernel of the last pass)."""
+        L = lib()
+        L.jxlhip_enc_forward_rerun.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.jxlhip_enc_last_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.jxlhip_enc_last_transform_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        _check(L.jxlhip_enc_forward_rerun(self._h, times), "jxlhip_enc_forward_rerun")
+        a, b = ctypes.c_float(), ctypes.c_float()
+        _check(L.jxlhip_enc_last_ms(self._h, ctypes.byref(a)), "jxlhip_enc_last_ms")
+        _check(L.jxlhip_enc_last_transform_ms(self._h, ctypes.byref(b)), "jxlhip_enc_last_transform_ms")
+        return a.value, b.value
+
     def upload_modular(self, mframe):
         _check(lib().jxlamd_modframe_upload(mframe._h, self._h), "jxlamd_modframe_upload")
         self.frame_info = dict(mframe.info)

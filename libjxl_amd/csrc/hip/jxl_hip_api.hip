@@ -222,8 +222,10 @@ struct JxlHipContext {
   uint32_t out_type = 2, out_nc = 3, out_bits = 8, out_swap = 0;
   // forward (encoder) path, jxlhip_enc_forward: device buffers and the kernel time of the last call
   Buf enc_rgb, enc_planes[3], enc_act, enc_acs, enc_qf, enc_off, enc_dc, enc_coef, enc_lut, enc_dq;
-  hipEvent_t enc_ev[2] = {nullptr, nullptr};
+  hipEvent_t enc_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // whole sequence; the transform kernel of its last pass
   bool enc_timed = false;
+  jxlhip::EncFwd enc_last;     // the parameters of the last jxlhip_enc_forward (its input stays resident): jxlhip_enc_forward_rerun
+  bool enc_last_gaborish = false;
   uint32_t out_orient = 0;  // jxlhip_set_output_orientation: PixelOut::orient bits (0 = the image as coded)
   // noise synthesis (JxlHipFrameDesc::has_noise): raw random planes [3][ys][xs], LUT, seeds, base colour correlation
   Buf noise;
@@ -2610,6 +2612,41 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
 }
 
 // ---- forward path: see jxl_hip_enc.h
+// The kernel sequence of the forward path on the context's stream (P.planes is set on the way).
+static int EncLaunch(JxlHipContext* c, jxlhip::EncFwd& P, bool gaborish) {
+  const size_t nb = size_t(P.xb) * P.yb, ng = size_t(P.xg) * P.yg;
+  // colour: into planes[0] when there is no sharpening, else into the `orig` set
+  float* sets[3] = {c->enc_planes[0].as<float>(), c->enc_planes[1].as<float>(), c->enc_planes[2].as<float>()};
+  const dim3 px_grid((P.xp + 255) / 256, P.yp);
+  P.planes = gaborish ? sets[2] : sets[0];
+  hipLaunchKernelGGL(jxlhip::k_enc_xyb, px_grid, dim3(256), 0, c->stream, P);
+  if (gaborish) {
+    // 4 rounds: orig = sets[2]; in = orig, out = sets[0]; then 0 -> 1 -> 0 -> 1; the last result is copied by renaming
+    const dim3 g3(px_grid.x, px_grid.y, 3);
+    const float* in = sets[2];
+    float* out = sets[0];
+    for (int it = 0; it < 4; it++) {
+      hipLaunchKernelGGL(jxlhip::k_enc_sharpen, g3, dim3(256), 0, c->stream, static_cast<const float*>(sets[2]), in, out, P.xp, P.yp);
+      in = out;
+      out = out == sets[0] ? sets[1] : sets[0];
+    }
+    P.planes = const_cast<float*>(in);
+  }
+  hipLaunchKernelGGL(jxlhip::k_enc_activity, dim3((P.xb + 7) / 8, P.yb), dim3(64), 0, c->stream, P);
+  const uint32_t tiles = ((P.xb + 7) / 8) * ((P.yb + 7) / 8);
+  hipLaunchKernelGGL(jxlhip::k_enc_select, dim3(tiles), dim3(64), 0, c->stream, P);
+  hipLaunchKernelGGL(jxlhip::k_enc_offsets, dim3(uint32_t(ng)), dim3(64), 0, c->stream, P);
+  HIP_TRY(hipMemsetAsync(c->enc_coef.p, 0, ng * 3 * 65536 * 4, c->stream));
+  HIP_TRY(hipEventRecord(c->enc_ev[2], c->stream));
+  if (getenv("JXLHIP_ENC_BLOCK_KERNEL"))  // the one-workgroup-per-transform form (kept as the simple statement of the algorithm)
+    hipLaunchKernelGGL(jxlhip::k_enc_transform<256>, dim3(uint32_t(nb)), dim3(256), 0, c->stream, P);
+  else
+    hipLaunchKernelGGL(jxlhip::k_enc_transform_tile, dim3(tiles), dim3(256), 0, c->stream, P);
+  HIP_TRY(hipEventRecord(c->enc_ev[3], c->stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* d, uint8_t* acs, int32_t* qf, int32_t* dc,
                        int32_t* coeffs) {
   if (!c || !rgb || !d || !acs || !qf || !dc || !coeffs) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -2671,30 +2708,9 @@ int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, cons
   P.dc_step[2] = inv_quant_dc / 256.0f;
   P.strategy_mode = d->strategy_mode;
   HIP_TRY(hipEventRecord(c->enc_ev[0], c->stream));
-  // colour: into planes[0] when there is no sharpening, else into the `orig` set
-  float* sets[3] = {c->enc_planes[0].as<float>(), c->enc_planes[1].as<float>(), c->enc_planes[2].as<float>()};
-  const dim3 px_grid((P.xp + 255) / 256, P.yp);
-  P.planes = d->gaborish ? sets[2] : sets[0];
-  hipLaunchKernelGGL(jxlhip::k_enc_xyb, px_grid, dim3(256), 0, c->stream, P);
-  if (d->gaborish) {
-    // 4 rounds: orig = sets[2]; in = orig, out = sets[0]; then 0 -> 1 -> 0 -> 1; the last result is copied by renaming
-    const dim3 g3(px_grid.x, px_grid.y, 3);
-    const float* in = sets[2];
-    float* out = sets[0];
-    for (int it = 0; it < 4; it++) {
-      hipLaunchKernelGGL(jxlhip::k_enc_sharpen, g3, dim3(256), 0, c->stream, static_cast<const float*>(sets[2]), in, out, P.xp, P.yp);
-      in = out;
-      out = out == sets[0] ? sets[1] : sets[0];
-    }
-    P.planes = const_cast<float*>(in);
-  }
-  hipLaunchKernelGGL(jxlhip::k_enc_activity, dim3((P.xb + 7) / 8, P.yb), dim3(64), 0, c->stream, P);
-  const uint32_t tiles = ((P.xb + 7) / 8) * ((P.yb + 7) / 8);
-  hipLaunchKernelGGL(jxlhip::k_enc_select, dim3((tiles + 63) / 64), dim3(64), 0, c->stream, P);
-  hipLaunchKernelGGL(jxlhip::k_enc_offsets, dim3((uint32_t(ng) + 63) / 64), dim3(64), 0, c->stream, P);
-  HIP_TRY(hipMemsetAsync(c->enc_coef.p, 0, ng * 3 * 65536 * 4, c->stream));
-  hipLaunchKernelGGL(jxlhip::k_enc_transform<256>, dim3(uint32_t(nb)), dim3(256), 0, c->stream, P);
-  HIP_TRY(hipGetLastError());
+  if ((r = EncLaunch(c, P, d->gaborish != 0))) return r;
+  c->enc_last = P;
+  c->enc_last_gaborish = d->gaborish != 0;
   HIP_TRY(hipEventRecord(c->enc_ev[1], c->stream));
   c->enc_timed = true;
   HIP_TRY(hipMemcpyAsync(acs, c->enc_acs.p, nb, hipMemcpyDeviceToHost, c->stream));
@@ -2705,12 +2721,35 @@ int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, cons
   return 0;
 }
 
+int jxlhip_enc_forward_rerun(JxlHipContext* c, uint32_t times) {
+  if (!c || !times || times > 4096) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->enc_timed) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventRecord(c->enc_ev[0], c->stream));
+  for (uint32_t i = 0; i < times; i++) {
+    int r = EncLaunch(c, c->enc_last, c->enc_last_gaborish);
+    if (r) return r;
+  }
+  HIP_TRY(hipEventRecord(c->enc_ev[1], c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int jxlhip_enc_last_ms(JxlHipContext* c, float* ms) {
   if (!c || !ms) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->enc_timed) return JXLHIP_ERR_NO_FRAME;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipEventSynchronize(c->enc_ev[1]));
   HIP_TRY(hipEventElapsedTime(ms, c->enc_ev[0], c->enc_ev[1]));
+  return 0;
+}
+
+int jxlhip_enc_last_transform_ms(JxlHipContext* c, float* ms) {
+  if (!c || !ms) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->enc_timed) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->enc_ev[3]));
+  HIP_TRY(hipEventElapsedTime(ms, c->enc_ev[2], c->enc_ev[3]));
   return 0;
 }
 

@@ -90,90 +90,108 @@ __global__ void k_enc_activity(EncFwd P) {
   if (live && row == 0) P.act[size_t(by) * P.xb + bx] = a / 64;
 }
 
-// Transform selection and quant field of one 64x64 tile (8x8 blocks): every candidate is aligned to its own size, so the
-// greedy raster scan of the CPU writer never looks outside the tile it is in.
-__global__ void k_enc_select(EncFwd P) {
+// Transform selection and quant field of one 64x64 tile (8x8 blocks) per wave: every candidate is aligned to its own
+// size, so the greedy raster scan of the CPU writer never looks outside the tile it is in. The activity tests of every
+// (position, candidate) pair are evaluated by the lanes in parallel; only the occupancy bookkeeping of the scan is serial.
+__global__ __launch_bounds__(64) void k_enc_select(EncFwd P) {
 #pragma clang fp contract(off)
-  const uint32_t tiles_x = (P.xb + 7) / 8, tiles_y = (P.yb + 7) / 8;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= tiles_x * tiles_y) return;
+  const uint32_t tiles_x = (P.xb + 7) / 8;
+  const uint32_t t = blockIdx.x, lane = threadIdx.x, x = lane & 7, y = lane >> 3;
+  __shared__ float s_act[64];
+  __shared__ uint32_t s_pass[64];
+  __shared__ uint8_t s_acs[64];
   const uint32_t bx0 = (t % tiles_x) * 8, by0 = (t / tiles_x) * 8;
   const uint32_t w = min(8u, P.xb - bx0), h = min(8u, P.yb - by0);
-  uint8_t acs[64];
-  float act[64];
-  for (uint32_t i = 0; i < 64; i++) {
-    acs[i] = 0xFF;
-    const uint32_t x = i & 7, y = i >> 3;
-    act[i] = (x < w && y < h) ? P.act[size_t(by0 + y) * P.xb + bx0 + x] : 0.0f;
-  }
+  const bool inside = x < w && y < h;
+  s_act[lane] = inside ? P.act[size_t(by0 + y) * P.xb + bx0 + x] : 0.0f;
+  s_acs[lane] = 0xFF;
+  __syncthreads();
   const float T64 = 0.004f * P.distance, T32 = 0.008f * P.distance, T16 = 0.016f * P.distance, TR = 0.011f * P.distance;
+  const uint8_t cand[11] = {18, 20, 19, 5, 11, 10, 4, 9, 8, 7, 6};  // in the order the scan tries them
+  const float thr[11] = {T64, T64 * 1.3f, T64 * 1.3f, T32, TR, TR, T16, T16 * 0.8f, T16 * 0.8f, T16 * 1.5f, T16 * 1.5f};
   auto region_max = [&](uint32_t bx, uint32_t by, uint32_t cx, uint32_t cy) {
     float m = 0.0f;
-    for (uint32_t y = 0; y < cy; y++)
-      for (uint32_t x = 0; x < cx; x++) m = fmaxf(m, act[(by + y) * 8 + bx + x]);
+    for (uint32_t yy = 0; yy < cy; yy++)
+      for (uint32_t xx = 0; xx < cx; xx++) m = fmaxf(m, s_act[(by + yy) * 8 + bx + xx]);
     return m;
   };
-  auto ok = [&](uint32_t bx, uint32_t by, int cand, float thr) {
-    const uint32_t cx = c_covered_x[cand], cy = c_covered_y[cand];
-    if (bx % cx || by % cy || bx + cx > w || by + cy > h) return false;
-    for (uint32_t y = 0; y < cy; y++)
-      for (uint32_t x = 0; x < cx; x++)
-        if (acs[(by + y) * 8 + bx + x] != 0xFF) return false;
-    return region_max(bx, by, cx, cy) < thr;
-  };
-  for (uint32_t by = 0; by < h; by++)
-    for (uint32_t bx = 0; bx < w; bx++) {
-      if (acs[by * 8 + bx] != 0xFF) continue;
-      int st = 0;
-      if (P.strategy_mode == 1) {
-        if (ok(bx, by, 18, T64)) st = 18;
-        else if (ok(bx, by, 20, T64 * 1.3f)) st = 20;
-        else if (ok(bx, by, 19, T64 * 1.3f)) st = 19;
-        else if (ok(bx, by, 5, T32)) st = 5;
-        else if (ok(bx, by, 11, TR)) st = 11;
-        else if (ok(bx, by, 10, TR)) st = 10;
-        else if (ok(bx, by, 4, T16)) st = 4;
-        else if (ok(bx, by, 9, T16 * 0.8f)) st = 9;
-        else if (ok(bx, by, 8, T16 * 0.8f)) st = 8;
-        else if (ok(bx, by, 7, T16 * 1.5f)) st = 7;
-        else if (ok(bx, by, 6, T16 * 1.5f)) st = 6;
-      }
-      const uint32_t cx = c_covered_x[st], cy = c_covered_y[st];
-      for (uint32_t y = 0; y < cy; y++)
-        for (uint32_t x = 0; x < cx; x++) acs[(by + y) * 8 + bx + x] = uint8_t((st << 1) | ((x | y) == 0));
+  uint32_t pass = 0;
+  if (inside && P.strategy_mode == 1)
+    for (int s = 0; s < 11; s++) {
+      const uint32_t cx = c_covered_x[cand[s]], cy = c_covered_y[cand[s]];
+      if (x % cx || y % cy || x + cx > w || y + cy > h) continue;
+      if (region_max(x, y, cx, cy) < thr[s]) pass |= 1u << s;
     }
-  for (uint32_t by = 0; by < h; by++)
-    for (uint32_t bx = 0; bx < w; bx++) {
-      const uint8_t a = acs[by * 8 + bx];
-      const size_t bi = size_t(by0 + by) * P.xb + bx0 + bx;
-      P.acs[bi] = a;
-      int32_t q = 0;
-      if (a & 1) {
-        const int st = a >> 1;
-        const float m = region_max(bx, by, c_covered_x[st], c_covered_y[st]);
-        float mul = 1.35f - 0.12f * log2f(1.0f + m * 400.0f);
-        mul = fmaxf(0.8f, fminf(1.4f, mul));
-        q = max(1, min(256, int(P.quant_ac * mul * P.inv_gs + 0.5f)));
+  s_pass[lane] = pass;
+  __syncthreads();
+  if (lane == 0) {
+    uint64_t occupied = 0;
+    for (uint32_t by = 0; by < h; by++)
+      for (uint32_t bx = 0; bx < w; bx++) {
+        if (occupied >> (by * 8 + bx) & 1) continue;
+        int st = 0;
+        uint64_t mask = uint64_t(1) << (by * 8 + bx);
+        for (uint32_t ps = s_pass[by * 8 + bx]; ps; ps &= ps - 1) {
+          const int s = __builtin_ctz(ps);
+          const uint32_t cx = c_covered_x[cand[s]], cy = c_covered_y[cand[s]];
+          const uint64_t row = ((uint64_t(1) << cx) - 1) << bx;  // cx <= 8
+          uint64_t m = 0;
+          for (uint32_t yy = 0; yy < cy; yy++) m |= row << ((by + yy) * 8);
+          if (occupied & m) continue;
+          st = cand[s];
+          mask = m;
+          break;
+        }
+        occupied |= mask;
+        const uint32_t cx = c_covered_x[st], cy = c_covered_y[st];
+        for (uint32_t yy = 0; yy < cy; yy++)
+          for (uint32_t xx = 0; xx < cx; xx++) s_acs[(by + yy) * 8 + bx + xx] = uint8_t((st << 1) | ((xx | yy) == 0));
       }
-      P.qf[bi] = q;
-    }
+  }
+  __syncthreads();
+  if (!inside) return;
+  const uint8_t a = s_acs[lane];
+  const size_t bi = size_t(by0 + y) * P.xb + bx0 + x;
+  P.acs[bi] = a;
+  int32_t q = 0;
+  if (a & 1) {
+    const int st = a >> 1;
+    const float m = region_max(x, y, c_covered_x[st], c_covered_y[st]);
+    float mul = 1.35f - 0.12f * log2f(1.0f + m * 400.0f);
+    mul = fmaxf(0.8f, fminf(1.4f, mul));
+    q = max(1, min(256, int(P.quant_ac * mul * P.inv_gs + 0.5f)));
+  }
+  P.qf[bi] = q;
 }
 
-// Coefficient offsets of the first blocks of one 256x256 group, in the raster order the bitstream uses.
-__global__ void k_enc_offsets(EncFwd P) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.xg * P.yg) return;
+// Coefficient offsets of the first blocks of one 256x256 group, in the raster order the bitstream uses: one wave per
+// group, 16 consecutive raster positions per lane, exclusive scan across the lanes.
+__global__ __launch_bounds__(64) void k_enc_offsets(EncFwd P) {
+  const uint32_t g = blockIdx.x, lane = threadIdx.x;
   const uint32_t bx0 = (g % P.xg) * 32, by0 = (g / P.xg) * 32;
-  const uint32_t gw = min(32u, P.xb - bx0), gh = min(32u, P.yb - by0);
-  uint32_t offset = 0;
-  for (uint32_t by = 0; by < gh; by++)
-    for (uint32_t bx = 0; bx < gw; bx++) {
-      const size_t bi = size_t(by0 + by) * P.xb + bx0 + bx;
-      const uint8_t a = P.acs[bi];
-      if (!(a & 1)) continue;
-      P.coef_off[bi] = offset;
-      offset += 64u << c_log2_covered[a >> 1];
+  const uint32_t gw = min(32u, P.xb - bx0), gh = min(32u, P.yb - by0), n = gw * gh;
+  uint32_t sizes[16], sum = 0;
+  for (uint32_t j = 0; j < 16; j++) {
+    const uint32_t i = lane * 16 + j;
+    uint32_t sz = 0;
+    if (i < n) {
+      const uint8_t a = P.acs[size_t(by0 + i / gw) * P.xb + bx0 + i % gw];
+      if (a & 1) sz = 64u << c_log2_covered[a >> 1];
     }
+    sizes[j] = sz;
+    sum += sz;
+  }
+  uint32_t incl = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (int(lane) >= d) incl += o;
+  }
+  uint32_t offset = incl - sum;
+  for (uint32_t j = 0; j < 16; j++) {
+    const uint32_t i = lane * 16 + j;
+    if (i < n && sizes[j]) P.coef_off[size_t(by0 + i / gw) * P.xb + bx0 + i % gw] = offset;
+    offset += sizes[j];
+  }
 }
 
 __device__ __forceinline__ int32_t EncQuant(float v) {
@@ -265,6 +283,149 @@ __global__ __launch_bounds__(kThreads) void k_enc_transform(EncFwd P) {
       dst[k] = q;
     }
     __syncthreads();
+  }
+}
+
+// The same work for one 64x64 tile (8x8 blocks) per workgroup, every transform of the tile at once: the tile's samples,
+// the row-pass result and the DCT matrices of 1..64 points sit in LDS; thread (column, 16-row band) accumulates 8 rows
+// against one matrix element at a time, so that a matrix read serves 8 multiply-adds and the sample reads are
+// broadcasts. Sums run in the CPU writer's order (x = 0.., y = 0..), products are not contracted.
+__global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
+#pragma clang fp contract(off)
+  constexpr int kBasisLds = 5461;  // (4^7 - 1) / 3: levels 0..6
+  __shared__ float s_px[64 * 64], s_t[64 * 64], s_basis[kBasisLds], s_ydc[64];
+  __shared__ uint32_t s_info[64], s_off[64];
+  __shared__ int32_t s_qf[64];
+  const uint32_t tiles_x = (P.xb + 7) / 8;
+  const uint32_t bx0 = (blockIdx.x % tiles_x) * 8, by0 = (blockIdx.x / tiles_x) * 8, tid = threadIdx.x;
+  const uint32_t w = min(8u, P.xb - bx0), h = min(8u, P.yb - by0);
+  for (int i = tid; i < kBasisLds; i += 256) s_basis[i] = P.basis_t[i];
+  if (tid < 64) s_info[tid] = 0xFFFFFFFFu;
+  __syncthreads();
+  if (tid < 64) {
+    const uint32_t x = tid & 7, y = tid >> 3;
+    if (x < w && y < h) {
+      const size_t bi = size_t(by0 + y) * P.xb + bx0 + x;
+      const uint8_t a = P.acs[bi];
+      if (a & 1) {
+        const uint32_t st = a >> 1, cx = c_covered_x[st], cy = c_covered_y[st], off = P.coef_off[bi];
+        const int32_t q = P.qf[bi];
+        for (uint32_t dy = 0; dy < cy; dy++)
+          for (uint32_t dx = 0; dx < cx; dx++) {
+            const uint32_t cell = (y + dy) * 8 + x + dx;
+            s_info[cell] = x | y << 3 | st << 6;
+            s_off[cell] = off;
+            s_qf[cell] = q;
+          }
+      }
+    }
+  }
+  const uint32_t col = tid & 63, band = tid >> 6;  // this thread: tile column `col`, cell rows 2 * band and 2 * band + 1
+  const uint32_t g = (by0 / 32) * P.xg + bx0 / 32;
+  const size_t plane = size_t(P.xp) * P.yp, nb = size_t(P.xb) * P.yb;
+  const float biases1 = 1.0f - 0.07005449891748593f, biases3 = 0.145f;
+  float ydeq[2][8];
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    __syncthreads();
+    {
+      const float* src = P.planes + plane * c + size_t(by0) * 8 * P.xp + size_t(bx0) * 8;
+      for (uint32_t i = tid; i < 4096; i += 256) {
+        const uint32_t y = i >> 6, x = i & 63;
+        s_px[i] = (x < w * 8 && y < h * 8) ? src[size_t(y) * P.xp + x] : 0.0f;
+      }
+    }
+    __syncthreads();
+    // rows: s_t[y][kx] = sum_x px[y][x0 + x] * B_C[x][kx]
+    for (uint32_t half = 0; half < 2; half++) {
+      const uint32_t cr = band * 2 + half, info = s_info[cr * 8 + (col >> 3)];
+      if (info == 0xFFFFFFFFu) continue;
+      const uint32_t ox = info & 7, C = uint32_t(c_covered_x[info >> 6]) * 8, kx = col - ox * 8;
+      const float* B = s_basis + (C * C - 1) / 3 + kx;
+      const float* px = s_px + cr * 8 * 64 + ox * 8;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t x = 0; x < C; x++) {
+        const float b = B[x * C];
+        for (int j = 0; j < 8; j++) acc[j] += px[j * 64 + x] * b;
+      }
+      for (int j = 0; j < 8; j++) s_t[(cr * 8 + j) * 64 + col] = acc[j];
+    }
+    __syncthreads();
+    // columns: coefficient (ky, kx) at s_px[y0 + ky][col], natural layout
+    for (uint32_t half = 0; half < 2; half++) {
+      const uint32_t cr = band * 2 + half, info = s_info[cr * 8 + (col >> 3)];
+      if (info == 0xFFFFFFFFu) continue;
+      const uint32_t st = info >> 6, oy = (info >> 3) & 7, R = uint32_t(c_covered_y[st]) * 8, C = uint32_t(c_covered_x[st]) * 8;
+      const uint32_t ky0 = (cr - oy) * 8;
+      const float* B = s_basis + (R * R - 1) / 3 + ky0;
+      const float* tc = s_t + oy * 8 * 64 + col;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t y = 0; y < R; y++) {
+        const float v = tc[y * 64];
+        for (int j = 0; j < 8; j++) acc[j] += v * B[y * R + j];
+      }
+      const float norm = 1.0f / (float(R) * float(C));
+      for (int j = 0; j < 8; j++) s_px[(cr * 8 + j) * 64 + col] = acc[j] * norm;
+    }
+    __syncthreads();
+    // DC of every covered block from the lowest-frequency corner
+    if (tid < 64 && s_info[tid] != 0xFFFFFFFFu) {
+      const uint32_t info = s_info[tid], st = info >> 6, ox = info & 7, oy = (info >> 3) & 7;
+      const int cx = c_covered_x[st], cy = c_covered_y[st], x = int(tid & 7) - int(ox), y = int(tid >> 3) - int(oy);
+      const float* brr = s_basis + (cy * cy - 1) / 3;
+      const float* bcc = s_basis + (cx * cx - 1) / 3;
+      float s = 0;
+      for (int ky = 0; ky < cy; ky++)
+        for (int kx = 0; kx < cx; kx++) {
+          const float llf = s_px[(oy * 8 + ky) * 64 + ox * 8 + kx] / (c_resample[cy - 1 + ky] * c_resample[cx - 1 + kx]);
+          s += llf * brr[y * cy + ky] * bcc[x * cx + kx];
+        }
+      const size_t di = size_t(by0 + (tid >> 3)) * P.xb + bx0 + (tid & 7);
+      if (c == 1) {
+        const int32_t qy = int32_t(lroundf(s / P.dc_step[1]));
+        s_ydc[tid] = float(qy) * P.dc_step[1];
+        P.dc[nb + di] = qy;
+      } else if (c == 0) {
+        P.dc[di] = int32_t(lroundf((s - 0.0f * s_ydc[tid]) / P.dc_step[0]));
+      } else {
+        P.dc[2 * nb + di] = int32_t(lroundf((s - 1.0f * s_ydc[tid]) / P.dc_step[2]));
+      }
+    }
+    // quantisation of this thread's 2 x 8 coefficients
+    for (uint32_t half = 0; half < 2; half++) {
+      const uint32_t cr = band * 2 + half, cell = cr * 8 + (col >> 3), info = s_info[cell];
+      if (info == 0xFFFFFFFFu) continue;
+      const uint32_t st = info >> 6, ox = info & 7, oy = (info >> 3) & 7;
+      const uint32_t cx = c_covered_x[st], cy = c_covered_y[st], R = cy * 8, C = cx * 8;
+      const uint32_t kx = col - ox * 8, ky0 = (cr - oy) * 8;
+      const int kind = c_strategy_qtable[st];
+      const float scaled = P.inv_gs / float(s_qf[cell]);
+      const float mulc = c == 0 ? scaled * P.x_dm : (c == 1 ? scaled : scaled * P.b_dm);
+      const float cc = c == 0 ? 0.0f : 1.0f;
+      const float* m = P.dequant + P.dq_offset[kind] + size_t(c) * P.dq_size[kind];
+      int32_t* dst = P.coeffs + (size_t(g) * 3 + c) * 65536 + s_off[cell];
+      int32_t q[8];
+      for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t ky = ky0 + j, k = R < C ? ky * C + kx : kx * R + ky;
+        q[j] = 0;
+        if (ky < cy && kx < cx) continue;  // lowest frequencies: carried by the DC image
+        const float v = s_px[(cr * 8 + j) * 64 + col], step = m[k] * mulc;
+        if (c == 1) {
+          q[j] = EncQuant(v / step);
+          const float ybias = q[j] == 0 ? 0.0f : (q[j] == 1 ? biases1 : (q[j] == -1 ? -biases1 : float(q[j]) - biases3 / float(q[j])));
+          ydeq[half][j] = ybias * step;
+        } else {
+          q[j] = EncQuant((v - cc * ydeq[half][j]) / step);
+        }
+      }
+      if (R < C) {
+        for (uint32_t j = 0; j < 8; j++) dst[(ky0 + j) * C + kx] = q[j];
+      } else {  // 8 consecutive coefficients of column kx
+        int4* d4 = reinterpret_cast<int4*>(dst + kx * R + ky0);
+        d4[0] = make_int4(q[0], q[1], q[2], q[3]);
+        d4[1] = make_int4(q[4], q[5], q[6], q[7]);
+      }
+    }
   }
 }
 
