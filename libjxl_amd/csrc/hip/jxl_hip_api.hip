@@ -2621,16 +2621,21 @@ static int EncLaunch(JxlHipContext* c, jxlhip::EncFwd& P, bool gaborish) {
   P.planes = gaborish ? sets[2] : sets[0];
   hipLaunchKernelGGL(jxlhip::k_enc_xyb, px_grid, dim3(256), 0, c->stream, P);
   if (gaborish) {
-    // 4 rounds: orig = sets[2]; in = orig, out = sets[0]; then 0 -> 1 -> 0 -> 1; the last result is copied by renaming
-    const dim3 g3(px_grid.x, px_grid.y, 3);
-    const float* in = sets[2];
-    float* out = sets[0];
-    for (int it = 0; it < 4; it++) {
-      hipLaunchKernelGGL(jxlhip::k_enc_sharpen, g3, dim3(256), 0, c->stream, static_cast<const float*>(sets[2]), in, out, P.xp, P.yp);
-      in = out;
-      out = out == sets[0] ? sets[1] : sets[0];
+    if (getenv("JXLHIP_ENC_SHARPEN_ROUNDS")) {  // the one-round-per-launch form: orig = sets[2]; 2 -> 0 -> 1 -> 0 -> 1
+      const dim3 g3(px_grid.x, px_grid.y, 3);
+      const float* in = sets[2];
+      float* out = sets[0];
+      for (int it = 0; it < 4; it++) {
+        hipLaunchKernelGGL(jxlhip::k_enc_sharpen, g3, dim3(256), 0, c->stream, static_cast<const float*>(sets[2]), in, out, P.xp, P.yp);
+        in = out;
+        out = out == sets[0] ? sets[1] : sets[0];
+      }
+      P.planes = const_cast<float*>(in);
+    } else {
+      hipLaunchKernelGGL(jxlhip::k_enc_sharpen4, dim3((P.xp + 63) / 64, (P.yp + 31) / 32, 3), dim3(256), 0, c->stream,
+                         static_cast<const float*>(sets[2]), sets[0], P.xp, P.yp);
+      P.planes = sets[0];
     }
-    P.planes = const_cast<float*>(in);
   }
   hipLaunchKernelGGL(jxlhip::k_enc_activity, dim3((P.xb + 7) / 8, P.yb), dim3(64), 0, c->stream, P);
   const uint32_t tiles = ((P.xb + 7) / 8) * ((P.yb + 7) / 8);

@@ -69,6 +69,49 @@ __global__ void k_enc_sharpen(const float* __restrict__ orig, const float* __res
   out[plane + size_t(yy) * xp + xx] = centre + (orig[plane + size_t(yy) * xp + xx] - blur);
 }
 
+// The four rounds in one launch: a 64x32 tile with a 4-sample apron in LDS; round k is computed on the tile grown by
+// 4 - k samples, so the last round has every neighbour it needs. Neighbour coordinates are clamped in IMAGE coordinates
+// exactly like the one-round kernel does, so positions outside the image are never read and each sample sees the same
+// operands in the same order as there.
+__global__ __launch_bounds__(256) void k_enc_sharpen4(const float* __restrict__ orig, float* __restrict__ out, uint32_t xp, uint32_t yp) {
+#pragma clang fp contract(off)
+  constexpr int TW = 64, TH = 32, H = 4, LW = TW + 2 * H, LH = TH + 2 * H;
+  __shared__ float s_o[LW * LH], s_a[LW * LH], s_b[LW * LH];
+  const int tx0 = int(blockIdx.x) * TW - H, ty0 = int(blockIdx.y) * TH - H, tid = threadIdx.x;
+  const size_t plane = size_t(xp) * yp * blockIdx.z;
+  for (int i = tid; i < LW * LH; i += 256) {
+    const int gx = tx0 + i % LW, gy = ty0 + i / LW;
+    if (gx < 0 || gy < 0 || gx >= int(xp) || gy >= int(yp)) continue;
+    const float v = orig[plane + size_t(gy) * xp + gx];
+    s_o[i] = v;
+    s_a[i] = v;
+  }
+  __syncthreads();
+  const float w1 = 1.1f * 0.104699568f, w2 = 1.1f * 0.055680538f, nrm = 1.0f / (1.0f + 4 * (w1 + w2));
+  float* y = s_a;
+  float* t = s_b;
+  for (int it = 1; it <= 4; it++) {
+    for (int i = tid; i < LW * LH; i += 256) {
+      const int lx = i % LW, ly = i / LW, gx = tx0 + lx, gy = ty0 + ly;  // (constant divisors)
+      if (lx < it || ly < it || lx >= LW - it || ly >= LH - it) continue;
+      if (gx < 0 || gy < 0 || gx >= int(xp) || gy >= int(yp)) continue;
+      const int x0 = (gx ? gx - 1 : 0) - tx0, x1 = (gx + 1 < int(xp) ? gx + 1 : int(xp) - 1) - tx0;
+      const int y0 = ((gy ? gy - 1 : 0) - ty0) * LW, y1 = ((gy + 1 < int(yp) ? gy + 1 : int(yp) - 1) - ty0) * LW, yc = ly * LW;
+      const float side = y[yc + x0] + y[yc + x1] + y[y0 + lx] + y[y1 + lx];
+      const float corner = y[y0 + x0] + y[y0 + x1] + y[y1 + x0] + y[y1 + x1];
+      const float centre = y[yc + lx];
+      const float blur = (centre + w1 * side + w2 * corner) * nrm;
+      const float v = centre + (s_o[yc + lx] - blur);
+      if (it == 4) out[plane + size_t(gy) * xp + gx] = v;
+      else t[yc + lx] = v;
+    }
+    __syncthreads();
+    float* sw = y;
+    y = t;
+    t = sw;
+  }
+}
+
 // Mean absolute deviation of Y from the block mean, per 8x8 block: a wave per 8 blocks (lane = block * 8 + row).
 __global__ void k_enc_activity(EncFwd P) {
 #pragma clang fp contract(off)
@@ -293,7 +336,10 @@ __global__ __launch_bounds__(kThreads) void k_enc_transform(EncFwd P) {
 __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
 #pragma clang fp contract(off)
   constexpr int kBasisLds = 5461;  // (4^7 - 1) / 3: levels 0..6
-  __shared__ float s_px[64 * 64], s_t[64 * 64], s_basis[kBasisLds], s_ydc[64];
+  // (the level of N points starts at (N * N - 1) / 3, which is 1 mod 4: shifted by 3 floats so that rows are 16-byte aligned)
+  __shared__ __attribute__((aligned(16))) float s_px[64 * 64], s_t[64 * 64], s_basis_raw[kBasisLds + 3];
+  __shared__ float s_ydc[64];
+  float* const s_basis = s_basis_raw + 3;
   __shared__ uint32_t s_info[64], s_off[64];
   __shared__ int32_t s_qf[64];
   const uint32_t tiles_x = (P.xb + 7) / 8;
@@ -344,9 +390,16 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
       const float* B = s_basis + (C * C - 1) / 3 + kx;
       const float* px = s_px + cr * 8 * 64 + ox * 8;
       float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (uint32_t x = 0; x < C; x++) {
-        const float b = B[x * C];
-        for (int j = 0; j < 8; j++) acc[j] += px[j * 64 + x] * b;
+      for (uint32_t x = 0; x < C; x += 4) {  // four samples of each of the 8 rows per LDS read (a broadcast within a block)
+        float4 v[8];
+        for (int j = 0; j < 8; j++) v[j] = *reinterpret_cast<const float4*>(px + j * 64 + x);
+        const float b0 = B[x * C], b1 = B[(x + 1) * C], b2 = B[(x + 2) * C], b3 = B[(x + 3) * C];
+        for (int j = 0; j < 8; j++) {
+          acc[j] += v[j].x * b0;
+          acc[j] += v[j].y * b1;
+          acc[j] += v[j].z * b2;
+          acc[j] += v[j].w * b3;
+        }
       }
       for (int j = 0; j < 8; j++) s_t[(cr * 8 + j) * 64 + col] = acc[j];
     }
@@ -362,7 +415,15 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
       float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (uint32_t y = 0; y < R; y++) {
         const float v = tc[y * 64];
-        for (int j = 0; j < 8; j++) acc[j] += v * B[y * R + j];
+        const float4 ba = *reinterpret_cast<const float4*>(B + y * R), bb = *reinterpret_cast<const float4*>(B + y * R + 4);
+        acc[0] += v * ba.x;
+        acc[1] += v * ba.y;
+        acc[2] += v * ba.z;
+        acc[3] += v * ba.w;
+        acc[4] += v * bb.x;
+        acc[5] += v * bb.y;
+        acc[6] += v * bb.z;
+        acc[7] += v * bb.w;
       }
       const float norm = 1.0f / (float(R) * float(C));
       for (int j = 0; j < 8; j++) s_px[(cr * 8 + j) * 64 + col] = acc[j] * norm;
