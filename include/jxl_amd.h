@@ -19,6 +19,14 @@ typedef struct JxlAmdFrame JxlAmdFrame;
 /* Parses the first frame of a codestream (bare or in a `jxlc` container). `data` must stay valid until the frame
  * has been uploaded. runner may be NULL (sequential). Returns 0 or a non-zero code; see jxlamd_last_error(). */
 int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runner, void* runner_opaque, JxlAmdFrame** frame);
+/* The frame that starts at byte `frame_pos` of the buffer (the jxlamd_frame_end() of the one before it; 0 = the first),
+ * `frame_index` its position in the codestream. Frames after the first exist in animations whose frames each replace the
+ * whole canvas (decode.cc:1346-1350; full size, BlendMode kReplace, a duration): anything layered, blended, cropped or
+ * referenced is refused. */
+int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
+                          void* runner_opaque, JxlAmdFrame** frame);
+/* Byte offset just behind the frame, and its animation fields {duration in ticks, is_last, timecode}. */
+size_t jxlamd_frame_end(const JxlAmdFrame* frame, uint32_t* duration_last_timecode);
 void jxlamd_frame_free(JxlAmdFrame* frame);
 /* info[0..15]: xsize, ysize, xsize_blocks, ysize_blocks, num_groups, num_dc_groups, num_passes, used_acs mask,
  * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes, then of pass 0: log2 alphabet size,
@@ -45,6 +53,9 @@ typedef struct JxlAmdModFrame JxlAmdModFrame;
 /* Parses the first frame of a codestream as a Modular frame: headers, TOC, global tree and histograms and every stream's
  * group header; no sample is decoded on the host. `data` must stay valid until the frame has been uploaded. */
 int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** frame);
+/* As jxlamd_frame_parse_at / jxlamd_frame_end, for Modular frames. */
+int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlAmdModFrame** frame);
+size_t jxlamd_modframe_end(const JxlAmdModFrame* frame, uint32_t* duration_last_timecode);
 void jxlamd_modframe_free(JxlAmdModFrame* frame);
 /* info[0..9]: xsize, ysize, colour channels, has alpha, bits per sample, streams, channel buffers, transform operations,
  * extra channels, compressed bytes of all sections. */

@@ -94,17 +94,23 @@ class Frame:
     INFO = ("xsize", "ysize", "xsize_blocks", "ysize_blocks", "num_groups", "num_dc_groups", "num_passes", "used_acs",
             "epf_iters", "gab", "coef_bits", "ac_bytes", "log_alpha", "num_clusters", "ctx_map_size")
 
-    def __init__(self, data, threads=0):
+    def __init__(self, data, threads=0, frame_pos=0, frame_index=0):
+        """frame_pos / frame_index: a later frame of an animation (frame_pos = the `end` of the frame before it)."""
         L = lib()
         self._data = bytes(data)  # must outlive upload
         self._h = ctypes.c_void_p()
+        L.jxlamd_frame_parse_at.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        L.jxlamd_frame_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        L.jxlamd_frame_end.restype = ctypes.c_size_t
         runner = None
         pool = None
         if threads > 0:
             pool = L.JxlThreadParallelRunnerCreate(None, threads)
             runner = ctypes.cast(L.JxlThreadParallelRunner, ctypes.c_void_p)
         try:
-            _check(L.jxlamd_frame_parse(self._data, len(self._data), runner, pool, ctypes.byref(self._h)), "jxlamd_frame_parse")
+            _check(L.jxlamd_frame_parse_at(self._data, len(self._data), frame_pos, frame_index, runner, pool, ctypes.byref(self._h)),
+                   "jxlamd_frame_parse_at")
         finally:
             if pool:
                 L.JxlThreadParallelRunnerDestroy(pool)
@@ -114,6 +120,9 @@ class Frame:
         wh = (ctypes.c_uint32 * 2)()
         L.jxlamd_frame_out_size(self._h, wh)
         self.info["out_xsize"], self.info["out_ysize"] = int(wh[0]), int(wh[1])  # the image (upsampled frames: > frame size)
+        t = (ctypes.c_uint32 * 3)()
+        self.end = int(L.jxlamd_frame_end(self._h, t))  # byte offset behind the frame
+        self.duration, self.is_last, self.timecode = int(t[0]), bool(t[1]), int(t[2])
 
     def close(self):
         if self._h:
@@ -133,14 +142,22 @@ class ModFrame:
     INFO = ("xsize", "ysize", "num_color", "has_alpha", "bits", "num_streams", "num_buffers", "num_ops", "num_extra", "section_bytes",
             "max_table_words", "lz77", "max_tree_nodes")
 
-    def __init__(self, data):
+    def __init__(self, data, frame_pos=0, frame_index=0):
         L = lib()
         self._data = bytes(data)  # must outlive upload
         self._h = ctypes.c_void_p()
-        _check(L.jxlamd_modframe_parse(self._data, len(self._data), ctypes.byref(self._h)), "jxlamd_modframe_parse")
+        L.jxlamd_modframe_parse_at.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t,
+                                               ctypes.POINTER(ctypes.c_void_p)]
+        L.jxlamd_modframe_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        L.jxlamd_modframe_end.restype = ctypes.c_size_t
+        _check(L.jxlamd_modframe_parse_at(self._data, len(self._data), frame_pos, frame_index, ctypes.byref(self._h)),
+               "jxlamd_modframe_parse_at")
         info = (ctypes.c_uint32 * 16)()
         L.jxlamd_modframe_info(self._h, info)
         self.info = dict(zip(self.INFO, list(info)))
+        t = (ctypes.c_uint32 * 3)()
+        self.end = int(L.jxlamd_modframe_end(self._h, t))
+        self.duration, self.is_last, self.timecode = int(t[0]), bool(t[1]), int(t[2])
 
     def close(self):
         if self._h:
@@ -438,6 +455,29 @@ def set_orientation(orientation=1):
     E.jxlenc_set_orientation.argtypes = [ctypes.c_uint32]
     E.jxlenc_set_orientation.restype = None
     E.jxlenc_set_orientation(int(orientation))
+
+
+def encode_animation(frames, durations, tps=(10, 1), num_loops=0, lossless=False, **kw):
+    """Test aid: an animation of full-size frames that replace each other (no layers, blending, crops or references):
+    frames[i] (HxWx3 or HxWx4 uint8, all of one size) is shown for durations[i] ticks of tps[0] / tps[1] per second."""
+    E = _enc_lib()
+    E.jxlenc_set_animation.argtypes = [ctypes.c_int] + [ctypes.c_uint32] * 4 + [ctypes.c_int]
+    E.jxlenc_set_animation.restype = None
+    E.jxlenc_last_header_bytes.restype = ctypes.c_size_t
+    out = b""
+    try:
+        for i, (img, dur) in enumerate(zip(frames, durations)):
+            E.jxlenc_set_animation(1, tps[0], tps[1], num_loops, dur, 1 if i == len(frames) - 1 else 0)
+            if lossless:
+                d = encode_lossless(img, **kw)
+            elif img.shape[2] == 4:
+                d = encode_rgba8(img, **kw)
+            else:
+                d = encode_rgb8(img, **kw)
+            out += d if i == 0 else d[E.jxlenc_last_header_bytes():]
+    finally:
+        E.jxlenc_set_animation(0, 10, 1, 0, 0, 1)
+    return out
 
 
 def synth_image(xsize, ysize, seed=177):

@@ -54,6 +54,11 @@ extern "C" {
 const char* jxlamd_last_error(void) { return g_last_error.c_str(); }
 
 int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runner, void* runner_opaque, JxlAmdFrame** out) {
+  return jxlamd_frame_parse_at(data, size, 0, 0, runner, runner_opaque, out);
+}
+
+int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
+                          void* runner_opaque, JxlAmdFrame** out) {
   g_last_error.clear();
   if (!data || !out) {
     g_last_error = "invalid argument";
@@ -65,7 +70,11 @@ int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runne
     jxh::FrameParser parser(data, size);
     jxh::ImageHeader ih;
     size_t pos = parser.ParseImageHeader(&ih);
-    parser.ParseFrame(pos, ih, &f->plan, MakeParallelFor(runner, runner_opaque));
+    if (frame_pos) {
+      if (frame_pos < pos || frame_pos >= size) throw std::runtime_error("truncated frame");
+      pos = frame_pos;
+    }
+    parser.ParseFrame(pos, ih, &f->plan, MakeParallelFor(runner, runner_opaque), frame_index);
   } catch (const std::exception& e) {
     g_last_error = e.what();
     return 2;
@@ -81,6 +90,14 @@ int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runne
 }
 
 void jxlamd_frame_free(JxlAmdFrame* f) { delete f; }
+size_t jxlamd_frame_end(const JxlAmdFrame* f, uint32_t* t) {
+  if (t) {
+    t[0] = f->plan.fh.duration;
+    t[1] = f->plan.fh.is_last;
+    t[2] = f->plan.fh.timecode;
+  }
+  return f->plan.frame_end;
+}
 
 void jxlamd_frame_info(const JxlAmdFrame* f, uint32_t* info) {
   const jxh::FramePlan& P = f->plan;
@@ -230,7 +247,9 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.band_group_row_end = group_row_end;
   d.has_noise = P.has_noise ? 1 : 0;
   memcpy(d.noise_lut, P.noise_lut, sizeof(d.noise_lut));
-  d.noise_frame_index[0] = d.noise_frame_index[1] = 0;  // the first (and only) frame of the image
+  // dec_frame.cc:160-168: the number of visible frames before this one, and of invisible ones since (none are accepted)
+  d.noise_frame_index[0] = uint32_t(P.frame_index);
+  d.noise_frame_index[1] = 0;
   std::vector<float> ups_kernel;
   if (P.fh.upsampling != 1) {
     UpsamplingKernels(P.fh.upsampling, &ups_kernel);
@@ -272,6 +291,10 @@ struct JxlAmdModFrame {
 };
 extern "C" {
 int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** out) {
+  return jxlamd_modframe_parse_at(data, size, 0, 0, out);
+}
+
+int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlAmdModFrame** out) {
   g_last_error.clear();
   if (!data || !out) {
     g_last_error = "invalid argument";
@@ -282,9 +305,13 @@ int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** out
   try {
     jxh::FrameParser head(data, size);  // (signature / container + image header)
     jxh::ImageHeader ih;
-    const size_t pos = head.ParseImageHeader(&ih);
+    size_t pos = head.ParseImageHeader(&ih);
+    if (frame_pos) {
+      if (frame_pos < pos || frame_pos >= size) throw std::runtime_error("truncated frame");
+      pos = frame_pos;
+    }
     jxh::ModFrameParser parser(data, size);
-    parser.ParseFrame(pos, ih, &f->plan);
+    parser.ParseFrame(pos, ih, &f->plan, frame_index);
   } catch (const std::exception& e) {
     g_last_error = e.what();
     return 2;
@@ -294,6 +321,14 @@ int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** out
   return 0;
 }
 void jxlamd_modframe_free(JxlAmdModFrame* f) { delete f; }
+size_t jxlamd_modframe_end(const JxlAmdModFrame* f, uint32_t* t) {
+  if (t) {
+    t[0] = f->plan.fh.duration;
+    t[1] = f->plan.fh.is_last;
+    t[2] = f->plan.fh.timecode;
+  }
+  return f->plan.frame_end;
+}
 void jxlamd_modframe_info(const JxlAmdModFrame* f, uint32_t* info) {
   const jxh::ModFramePlan& P = f->plan;
   info[0] = uint32_t(P.dim.xsize);
@@ -523,6 +558,8 @@ struct JxlDecoderStruct {
   bool error = false;
   jxh::ImageHeader ih;
   bool have_ih = false;
+  size_t frame_pos = 0, frame_index = 0;  // where the current frame starts in `cs` (0 = behind the image header), its number
+  size_t skip_frames = 0;                 // JxlDecoderSkipFrames
   JxlAmdFrame* frame = nullptr;        // a VarDCT frame ...
   JxlAmdModFrame* mframe = nullptr;    // ... or a Modular (lossless) one
   JxlHipContext* ctx = nullptr;
@@ -598,6 +635,7 @@ void ResetState(JxlDecoder* d) {
   d->cs.size = 0;
   d->cs_complete = false;
   d->stage = 0;
+  d->frame_pos = d->frame_index = d->skip_frames = 0;
   d->error = false;
   d->have_ih = false;
   d->have_out = false;
@@ -975,6 +1013,24 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   return DeliverPixels(d, of, xs, ys);
 }
 
+// Drops the current frame and moves to the one behind it; false (stage 6) when it was the last.
+bool NextFrame(JxlDecoder* d) {
+  uint32_t t[3];
+  const size_t end = d->frame ? jxlamd_frame_end(d->frame, t) : jxlamd_modframe_end(d->mframe, t);
+  if (t[1]) {
+    d->stage = 6;
+    return false;
+  }
+  if (d->frame) jxlamd_frame_free(d->frame);
+  if (d->mframe) jxlamd_modframe_free(d->mframe);
+  d->frame = nullptr;
+  d->mframe = nullptr;
+  d->frame_pos = end;
+  d->frame_index++;
+  d->stage = 2;
+  return true;
+}
+
 // Codestream step. Returns 0 = needs more codestream bytes, 1 = finished, 2 = event / status in *ev.
 int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
   if (d->stage == 0) {
@@ -1002,41 +1058,59 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
       return 2;
     }
   }
-  if (d->stage == 2) {
-    if (!(d->events & (JXL_DEC_FRAME | JXL_DEC_FULL_IMAGE))) {
-      d->stage = 6;
-      return 1;
+  for (;;) {
+    if (d->stage == 2) {
+      if (!(d->events & (JXL_DEC_FRAME | JXL_DEC_FULL_IMAGE))) {
+        d->stage = 6;
+        return 1;
+      }
+      int r = jxlamd_frame_parse_at(d->cs.p, d->cs.size, d->frame_pos, d->frame_index, d->runner, d->runner_opaque, &d->frame);
+      if (r && g_last_error.find("Modular frames") != std::string::npos)  // a lossless frame: the Modular front-end takes it
+        r = jxlamd_modframe_parse_at(d->cs.p, d->cs.size, d->frame_pos, d->frame_index, &d->mframe);
+      if (r) {
+        const std::string w = g_last_error;
+        if (!d->cs_complete && w.find("truncated") != std::string::npos) return 0;
+        *ev = Fail(d, w);
+        return 2;
+      }
+      d->stage = 3;
+      if (d->skip_frames > 0) {  // decode.cc:1359-1408: nothing can reference a frame accepted here, so skipping drops it whole
+        d->skip_frames--;
+        if (!NextFrame(d)) return 1;
+        continue;
+      }
+      if (d->events & JXL_DEC_FRAME) {
+        *ev = JXL_DEC_FRAME;
+        return 2;
+      }
     }
-    int r = jxlamd_frame_parse(d->cs.p, d->cs.size, d->runner, d->runner_opaque, &d->frame);
-    if (r && g_last_error.find("Modular frames") != std::string::npos)  // a lossless frame: the Modular front-end takes it
-      r = jxlamd_modframe_parse(d->cs.p, d->cs.size, &d->mframe);
-    if (r) {
-      const std::string w = g_last_error;
-      if (!d->cs_complete && w.find("truncated") != std::string::npos) return 0;
-      *ev = Fail(d, w);
+    if (d->stage == 3) {
+      if (!(d->events & JXL_DEC_FULL_IMAGE)) {  // decode.cc:1431-1437: headers only, the frame's bytes are skipped
+        if (!NextFrame(d)) return 1;
+        continue;
+      }
+      d->stage = 4;
+    }
+    if (d->stage == 4) {
+      if (!d->have_out) {
+        *ev = JXL_DEC_NEED_IMAGE_OUT_BUFFER;
+        return 2;
+      }
+      *ev = DecodePixels(d);
+      if (*ev == JXL_DEC_FULL_IMAGE) d->stage = 5;
       return 2;
     }
-    d->stage = 3;
-    if (d->events & JXL_DEC_FRAME) {
-      *ev = JXL_DEC_FRAME;
-      return 2;
+    if (d->stage == 5) {
+      // decode.cc:1540-1550: the output buffers belong to one frame; the next one asks again
+      d->have_out = false;
+      d->out_buf = nullptr;
+      d->callback = nullptr;
+      d->mt_run = nullptr;
+      d->extra_out.clear();
+      if (!NextFrame(d)) return 1;
+      continue;
     }
-  }
-  if (d->stage == 3) {
-    if (!(d->events & JXL_DEC_FULL_IMAGE)) {
-      d->stage = 6;
-      return 1;
-    }
-    d->stage = 4;
-  }
-  if (d->stage == 4) {
-    if (!d->have_out) {
-      *ev = JXL_DEC_NEED_IMAGE_OUT_BUFFER;
-      return 2;
-    }
-    *ev = DecodePixels(d);
-    if (*ev == JXL_DEC_FULL_IMAGE) d->stage = 5;
-    return 2;
+    break;
   }
   d->stage = 6;
   return 1;
@@ -1096,7 +1170,7 @@ void JxlDecoderRewind(JxlDecoder* d) {
   d->unpremul = up;
   d->decompress_boxes = db;
 }
-void JxlDecoderSkipFrames(JxlDecoder*, size_t) {}
+void JxlDecoderSkipFrames(JxlDecoder* d, size_t amount) { d->skip_frames += amount; }
 JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* d) { return d->stage >= 3 && d->stage < 5 ? (d->stage = 6, JXL_DEC_SUCCESS) : JXL_DEC_ERROR; }
 
 JxlDecoderStatus JxlDecoderSetParallelRunner(JxlDecoder* d, JxlParallelRunner runner, void* opaque) {
@@ -1205,6 +1279,13 @@ JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* d, JxlBasicInfo* info)
         info->alpha_premultiplied = e.alpha_associated;
         break;
       }
+    if (d->ih.have_animation) {  // decode.cc:2258-2266
+      info->have_animation = JXL_TRUE;
+      info->animation.tps_numerator = d->ih.anim_tps_num;
+      info->animation.tps_denominator = d->ih.anim_tps_den;
+      info->animation.num_loops = d->ih.anim_loops;
+      info->animation.have_timecodes = d->ih.have_timecodes ? JXL_TRUE : JXL_FALSE;
+    }
     info->intrinsic_xsize = info->xsize;
     info->intrinsic_ysize = info->ysize;
   }
@@ -1304,7 +1385,12 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
   if (!d->frame && !d->mframe) return JXL_DEC_ERROR;
   if (h) {
     memset(h, 0, sizeof(*h));
-    h->is_last = JXL_TRUE;
+    uint32_t t[3];
+    if (d->frame) jxlamd_frame_end(d->frame, t);
+    else jxlamd_modframe_end(d->mframe, t);
+    h->duration = t[0];  // decode.cc:2700-2712
+    h->is_last = t[1] ? JXL_TRUE : JXL_FALSE;
+    h->timecode = t[2];
     h->layer_info.xsize = uint32_t(OrientedXsize(d));  // decode.cc:2714-2722
     h->layer_info.ysize = uint32_t(OrientedYsize(d));
     h->layer_info.blend_info.blendmode = JXL_BLEND_REPLACE;

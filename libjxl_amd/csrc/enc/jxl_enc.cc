@@ -744,19 +744,51 @@ struct FrameModel {
 // next streams carry after their headers, with ImageMetadata.color_encoding.want_icc set (jxlenc_set_embedded_icc).
 // jxlenc_set_orientation: the ImageMetadata orientation the next streams carry (1..8; 1 writes no extra_fields).
 static uint32_t g_orientation = 1;
-// image_metadata.cc:283-300: extra_fields = orientation, no intrinsic size, no preview, no animation.
+// jxlenc_set_animation: the next streams are frames of an animation (ImageMetadata.have_animation with this
+// AnimationHeader; each frame header carries `duration` ticks and `is_last`). A whole animation is the first frame's
+// stream followed by the frame parts (from jxlenc_last_header_bytes() on) of the others.
+struct AnimationState {
+  bool enabled = false;
+  uint32_t tps_num = 10, tps_den = 1, loops = 0, duration = 1;
+  bool is_last = true;
+};
+static AnimationState g_anim;
+static size_t g_last_header_bytes = 0;  // where the frame header of the last written stream starts
+static bool ExtraFields() { return g_orientation != 1 || g_anim.enabled; }
+// image_metadata.cc:283-300: extra_fields = orientation, no intrinsic size, no preview, animation (:235-250).
 static void WriteExtraFields(BitWriter& bw) {
-  if (g_orientation == 1) {
+  if (!ExtraFields()) {
     bw.Write(1, 0);
     return;
   }
   bw.Write(1, 1);
   bw.Write(3, g_orientation - 1);
-  bw.Write(3, 0);
+  bw.Write(2, 0);  // no intrinsic size, no preview
+  bw.Write(1, g_anim.enabled ? 1 : 0);
+  if (g_anim.enabled) {
+    static const uint32_t nb[4] = {0, 0, 10, 30}, no[4] = {100, 1000, 1, 1};
+    static const uint32_t db[4] = {0, 0, 8, 10}, dof[4] = {1, 1001, 1, 1};
+    static const uint32_t lb[4] = {0, 3, 16, 32}, lo[4] = {0, 0, 0, 0};
+    WriteU32Sel(bw, g_anim.tps_num, nb, no);
+    WriteU32Sel(bw, g_anim.tps_den, db, dof);
+    WriteU32Sel(bw, g_anim.loops, lb, lo);
+    bw.Write(1, 0);  // no timecodes
+  }
 }
 // image_metadata.cc:340-344: with extra_fields a ToneMapping bundle follows the colour encoding (all_default here).
 static void WriteToneMapping(BitWriter& bw) {
-  if (g_orientation != 1) bw.Write(1, 1);
+  if (ExtraFields()) bw.Write(1, 1);
+}
+// frame_header.cc:130-150, 372-399: the animation fields of a frame header, is_last, and (not last) save_as_reference 0.
+// A frame with a duration and no reference slot cannot be referenced: no save_before_color_transform bit follows.
+static void WriteFrameTiming(BitWriter& bw) {
+  if (g_anim.enabled) {
+    static const uint32_t b[4] = {0, 0, 8, 32}, o[4] = {0, 1, 0, 0};
+    WriteU32Sel(bw, g_anim.duration, b, o);
+  }
+  const bool last = !g_anim.enabled || g_anim.is_last;
+  bw.Write(1, last ? 1 : 0);
+  if (!last) bw.Write(2, 0);  // save_as_reference 0
 }
 static std::vector<uint8_t> g_embedded_icc;
 static size_t g_embedded_icc_bits = 0;  // its exact length (the decoder aligns to a byte right after the last bit)
@@ -1192,7 +1224,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(3, 0);  // no aspect-ratio shortcut
   WriteSizeDim(bw, uint32_t(ups == 1 ? f.xs : f.img_xs));
   const bool with_icc = !g_embedded_icc.empty();
-  if (!have_alpha && !with_icc && g_orientation == 1) {
+  if (!have_alpha && !with_icc && !ExtraFields()) {
     bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
   } else {           // image_metadata.cc:283-356
     bw.Write(1, 0);  // not all_default
@@ -1216,6 +1248,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(1, 1);  // CustomTransformData all_default
   if (with_icc) AppendEmbeddedIcc(bw);  // (decode.cc: after the transform data, before the byte boundary)
   bw.ZeroPad();
+  g_last_header_bytes = bw.bytes().size();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
   bw.Write(2, 0);  // regular frame
@@ -1243,7 +1276,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(1, 0);  // no custom size/origin
   bw.Write(2, 0);  // blend mode: replace
   if (have_alpha) bw.Write(2, 0);  // the extra channel's blend mode: replace
-  bw.Write(1, 1);  // is_last
+  WriteFrameTiming(bw);
   bw.Write(2, 0);  // no name
   bw.Write(1, 0);  // loop filter not all_default
   bw.Write(1, f.gab ? 1 : 0);
@@ -2144,6 +2177,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(1, 1);  // CustomTransformData all_default
   if (with_icc) AppendEmbeddedIcc(bw);
   bw.ZeroPad();
+  g_last_header_bytes = bw.bytes().size();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
   bw.Write(2, 0);  // regular frame
@@ -2157,7 +2191,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(1, 0);  // no custom size
   bw.Write(2, 0);  // blend mode replace
   if (alpha) bw.Write(2, 0);
-  bw.Write(1, 1);  // is_last
+  WriteFrameTiming(bw);
   bw.Write(2, 0);  // no name
   bw.Write(1, 0);  // loop filter not all_default
   bw.Write(1, 0);  // no gaborish
@@ -2206,6 +2240,18 @@ void jxlenc_set_embedded_icc(const uint8_t* coded, size_t n, size_t bits) {
 
 // The next encoded streams declare this orientation (1..8, codestream_header.h:45-54; 1 = identity). Test aid, not thread-safe.
 void jxlenc_set_orientation(uint32_t orientation) { jxe::g_orientation = orientation >= 1 && orientation <= 8 ? orientation : 1; }
+
+// Animation mode for the next streams (enabled = 0: stills again). Test aid, not thread-safe.
+void jxlenc_set_animation(int enabled, uint32_t tps_numerator, uint32_t tps_denominator, uint32_t num_loops, uint32_t duration, int is_last) {
+  jxe::g_anim.enabled = enabled != 0;
+  jxe::g_anim.tps_num = tps_numerator;
+  jxe::g_anim.tps_den = tps_denominator;
+  jxe::g_anim.loops = num_loops;
+  jxe::g_anim.duration = duration;
+  jxe::g_anim.is_last = is_last != 0;
+}
+// Byte offset of the frame header in the stream written last (signature + image header come before it).
+size_t jxlenc_last_header_bytes(void) { return jxe::g_last_header_bytes; }
 
 static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
   *out = static_cast<uint8_t*>(malloc(v.size()));

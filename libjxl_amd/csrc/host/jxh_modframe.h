@@ -56,14 +56,17 @@ class ModFrameParser {
  public:
   ModFrameParser(const uint8_t* data, size_t size) : data_(data), size_(size) {}
 
-  void ParseFrame(size_t pos, const ImageHeader& ih, ModFramePlan* plan) {
+  void ParseFrame(size_t pos, const ImageHeader& ih, ModFramePlan* plan, size_t frame_index = 0) {
     ModFramePlan& P = *plan;
     P.ih = ih;
     BitReader br(data_ + pos, size_ - pos);
     ReadFrameHeader(br, ih, &P.fh);
     const FrameHeader& fh = P.fh;
     JXH_CHECK(fh.modular, "not a Modular frame");
-    JXH_CHECK(fh.frame_type == 0 && fh.is_last, "unsupported: non-regular / multiple frames");
+    JXH_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
+    // (several frames: as FrameParser::ParseFrame, an animation of frames that replace the whole canvas)
+    JXH_CHECK(fh.is_last || (ih.have_animation && fh.duration > 0), "unsupported: layered frames (zero duration, not last)");
+    JXH_CHECK((fh.is_last && frame_index == 0) || fh.blend_mode == 0, "unsupported: blended frames");
     JXH_CHECK(!ih.xyb_encoded && !fh.ycbcr, "unsupported: XYB or YCbCr Modular frames");
     JXH_CHECK(fh.upsampling == 1 && !fh.custom_size && fh.num_passes == 1, "unsupported: upsampled / cropped / multi-pass Modular frames");
     for (uint32_t u : fh.ec_upsampling) JXH_CHECK(u == 1, "unsupported: upsampled extra channels");

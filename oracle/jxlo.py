@@ -32,6 +32,7 @@ def lib():
         L.jxlo_buffer.restype = ctypes.c_void_p
         L.jxlo_buffer.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t)]
         L.jxlo_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        L.jxlo_animation.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.jxlo_out_size.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.jxlo_free.argtypes = [ctypes.c_void_p]
         L.jxlo_set_threads.argtypes = [ctypes.c_int]
@@ -48,10 +49,10 @@ _DTYPES = {"rgb8": np.uint8, "rgbf": np.float32, "coeffs": np.int32, "nzeros": n
 
 
 class Decoded:
-    def __init__(self, data, dumps=True):
+    def __init__(self, data, dumps=True, frame=0):
         L = lib()
         data = bytes(data)
-        self._h = L.jxlo_decode(data, len(data), 1 if dumps else 0)
+        self._h = L.jxlo_decode(data, len(data), (1 if dumps else 0) | frame << 8)
         err = L.jxlo_error(self._h)
         if err:
             msg = err.decode()
@@ -64,6 +65,10 @@ class Decoded:
         wh = (ctypes.c_uint32 * 2)()
         L.jxlo_out_size(self._h, wh)
         self.out_size = (int(wh[0]), int(wh[1]))  # the image: frame size ("xsize", "ysize") times its upsampling factor
+        a = (ctypes.c_uint32 * 7)()
+        L.jxlo_animation(self._h, a)
+        self.animation = dict(zip(("have_animation", "tps_numerator", "tps_denominator", "num_loops", "duration", "is_last", "timecode"),
+                                  list(a)))
 
     def buffer(self, name):
         n = ctypes.c_size_t()

@@ -57,6 +57,7 @@ struct FrameState {
   const ImageHeader* ih;
   FrameHeader fh;
   FrameDim dim;
+  size_t frame_index = 0;  // = the visible frames before this one (dec_frame.cc:160-168): every accepted frame is visible
   // DC global
   DequantTables dq;
   uint32_t global_scale = 1, quant_dc = 16;
@@ -447,17 +448,22 @@ static void ReconstructGroup(FrameState* s, size_t g, const int32_t* coeffs) {
     }
 }
 
-static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool want_dumps) {
+// frame_index: position of the frame in the codestream (0 = first). A codestream with several frames is accepted when
+// each one shows alone (decode.cc:1346-1350 is_last_of_still: last, or an animation frame with a duration) and replaces
+// the whole canvas (full size, BlendMode kReplace): an animation without layers, references or crops.
+static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool want_dumps, size_t frame_index = 0) {
   FrameState st;
   FrameState* s = &st;
   s->out = out;
   s->ih = &ih;
+  s->frame_index = frame_index;
   ReadFrameHeader(br, ih, &s->fh);
   const FrameHeader& fh = s->fh;
   JXLO_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
   JXLO_CHECK(fh.upsampling == 1 || (!fh.modular && !ih.custom_upsampling), "unsupported: upsampled Modular frames / custom weights");
   JXLO_CHECK(!fh.custom_size, "unsupported: cropped frames");
-  JXLO_CHECK(fh.is_last, "unsupported: multiple frames");
+  JXLO_CHECK(fh.is_last || (ih.have_animation && fh.duration > 0), "unsupported: layered frames (zero duration, not last)");
+  JXLO_CHECK((fh.is_last && frame_index == 0) || fh.blend_mode == 0, "unsupported: blended frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
   JXLO_CHECK(fh.modular || ih.xyb_encoded, "unsupported: non-XYB VarDCT");
   JXLO_CHECK(!(fh.modular && ih.xyb_encoded), "unsupported: XYB Modular frames");
@@ -616,7 +622,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       for (float v : s->noise_lut) any = any || std::fabs(v) > 1e-3f;
       if (any) {
         noisy = *cur;
-        AddNoise(&noisy, xs, ys, s->noise_lut, s->base_corr_x, s->base_corr_b, 0, 0);
+        AddNoise(&noisy, xs, ys, s->noise_lut, s->base_corr_x, s->base_corr_b, uint32_t(s->frame_index), 0);
         cur = &noisy;
         if (want_dumps && fh.upsampling == 1) {  // (the dump then holds what the colour conversion reads)
           for (int c = 0; c < 3; c++)
@@ -670,7 +676,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     }
 }
 
-static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dumps) {
+static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dumps, size_t frame_index = 0) {
   // bare codestream, or a container whose first codestream box is `jxlc`
   static const uint8_t kContainer[12] = {0, 0, 0, 0xC, 'J', 'X', 'L', ' ', 0xD, 0xA, 0x87, 0xA};
   if (size >= 12 && !memcmp(data, kContainer, 12)) {
@@ -702,7 +708,14 @@ static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dum
   BitReader br(data, size);
   br.Skip(16);
   ReadImageHeader(br, &out->ih);
-  DecodeFrame(br, out->ih, out, want_dumps);
+  for (size_t i = 0;; i++) {
+    DecodeFrame(br, out->ih, out, want_dumps && i == frame_index, i);
+    if (i == frame_index) break;
+    JXLO_CHECK(!out->fh.is_last, "no such frame");
+    const ImageHeader ih = out->ih;
+    *out = Decoded();  // (frames before the wanted one are decoded and dropped: test sizes)
+    out->ih = ih;
+  }
 }
 
 }  // namespace jxlo
@@ -715,11 +728,12 @@ struct JxloHandle {
   std::string error;
 };
 
-// flags: bit0 = keep intermediate dumps. Returns a handle (never NULL); check jxlo_error().
+// flags: bit0 = keep intermediate dumps, bits 8.. = index of the frame to decode (animations). Returns a handle (never NULL);
+// check jxlo_error().
 JxloHandle* jxlo_decode(const uint8_t* data, size_t size, int flags) {
   JxloHandle* h = new JxloHandle;
   try {
-    jxlo::Decode(data, size, &h->d, (flags & 1) != 0);
+    jxlo::Decode(data, size, &h->d, (flags & 1) != 0, size_t(flags) >> 8);
   } catch (const std::exception& e) {
     h->error = e.what();
     if (h->error.empty()) h->error = "unknown error";
@@ -757,6 +771,17 @@ void jxlo_info(JxloHandle* h, uint32_t* info) {
   info[13] = d.used_acs;
   info[14] = d.ih.bits;
   info[15] = uint32_t(d.ac_symbols);
+}
+// Animation: {have_animation, tps numerator, tps denominator, loops, duration of the decoded frame, its is_last, its timecode}
+void jxlo_animation(JxloHandle* h, uint32_t* a) {
+  const jxlo::Decoded& d = h->d;
+  a[0] = d.ih.have_animation;
+  a[1] = d.ih.anim_tps_num;
+  a[2] = d.ih.anim_tps_den;
+  a[3] = d.ih.anim_loops;
+  a[4] = d.fh.duration;
+  a[5] = d.fh.is_last;
+  a[6] = d.fh.timecode;
 }
 // Named buffers: "rgb8","rgbf","coeffs","nzeros","xyb_idct","xyb_filtered","dc","acs","quant","sharpness","ytox",
 // "ytob","inv_sigma","quant_dc","modular". Returns pointer and byte size (0 if absent).

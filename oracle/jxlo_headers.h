@@ -37,6 +37,7 @@ struct ImageHeader {
   bool linear_tf = false;  // output transfer function: false = sRGB, true = linear
   bool want_icc = false;   // an ICC profile is embedded (the oracle skips it: it only checks pixels)
   bool have_animation = false, have_timecodes = false;
+  uint32_t anim_tps_num = 0, anim_tps_den = 0, anim_loops = 0;  // AnimationHeader (image_metadata.cc:235-250)
   float intensity_target = 255.0f;
   // CustomTransformData / OpsinInverseMatrix
   float inv_opsin[9] = {11.031566901960783f,  -9.866943921568629f, -0.16462299647058826f,
@@ -164,9 +165,9 @@ static inline void ReadImageHeader(BitReader& br, ImageHeader* h) {
       JXLO_CHECK(!have_preview, "unsupported: preview frame");
       h->have_animation = br.ReadBool();
       if (h->have_animation) {
-        ReadU32(br, Val(100), Val(1000), BitsOffset(10, 1), BitsOffset(30, 1));
-        ReadU32(br, Val(1), Val(1001), BitsOffset(8, 1), BitsOffset(10, 1));
-        ReadU32(br, Val(0), Bits(3), Bits(16), Bits(32));
+        h->anim_tps_num = ReadU32(br, Val(100), Val(1000), BitsOffset(10, 1), BitsOffset(30, 1));
+        h->anim_tps_den = ReadU32(br, Val(1), Val(1001), BitsOffset(8, 1), BitsOffset(10, 1));
+        h->anim_loops = ReadU32(br, Val(0), Bits(3), Bits(16), Bits(32));
         h->have_timecodes = br.ReadBool();
       }
     }
@@ -245,6 +246,8 @@ struct FrameHeader {
   uint32_t xsize = 0, ysize = 0;  // frame dimensions (filled from image if not custom)
   bool is_last = true;
   uint32_t save_as_reference = 0;
+  uint32_t duration = 0, timecode = 0;  // AnimationFrame (frame_header.cc:130-150), in ticks of the image's AnimationHeader
+  uint32_t blend_mode = 0;              // BlendMode of the colour channels: 0 = replace
   bool save_before_color_transform = false;
   LoopFilter lf;
   static const uint64_t kNoise = 1, kPatches = 2, kSplines = 16, kUseDcFrame = 32, kSkipDcSmoothing = 128;
@@ -365,19 +368,18 @@ static inline void ReadFrameHeader(BitReader& br, const ImageHeader& ih, FrameHe
       ReadBlendingInfo(br, ih.extra.size(), partial, &m);
     }
     if (ih.have_animation) {
-      ReadU32(br, Val(0), Val(1), Bits(8), Bits(32));
-      if (ih.have_timecodes) br.Read(32);
+      f->duration = ReadU32(br, Val(0), Val(1), Bits(8), Bits(32));
+      if (ih.have_timecodes) f->timecode = uint32_t(br.Read(32));
     }
+    f->blend_mode = blend_mode;
     f->is_last = br.ReadBool();
   } else {
     f->is_last = false;
   }
   if (f->frame_type != 1 && !f->is_last) f->save_as_reference = ReadU32(br, Val(0), Val(1), Val(2), Val(3));
   if (f->frame_type != 1) {
-    bool can_ref = !f->is_last && (f->save_as_reference != 0 || f->frame_type == 2);  // CanBeReferenced
-    // Reference: frame_header.h CanBeReferenced(): !is_last && frame_type != DC && (duration==0 || save_as_reference!=0).
-    // Without animation every frame has duration 0.
-    can_ref = !f->is_last;
+    // frame_header.h:373-379 CanBeReferenced(): !is_last && frame_type != DC && (duration == 0 || save_as_reference != 0)
+    const bool can_ref = !f->is_last && (f->duration == 0 || f->save_as_reference != 0);
     if (can_ref && blend_mode == 0 && !partial && (f->frame_type == 0 || f->frame_type == 3)) {
       f->save_before_color_transform = br.ReadBool();
     } else if (f->frame_type == 2) {

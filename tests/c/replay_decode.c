@@ -58,7 +58,8 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[3], "u16")) format.data_type = JXL_TYPE_UINT16;
   if (!strcmp(argv[3], "f16")) format.data_type = JXL_TYPE_FLOAT16;
   if (!strcmp(argv[3], "f32")) format.data_type = JXL_TYPE_FLOAT;
-  int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0;
+  int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0, multi = 0, frames_done = 0;
+  size_t skip = 0;
   uint8_t* ec_pixels[4] = {NULL, NULL, NULL, NULL};
   size_t ec_sizes[4] = {0, 0, 0, 0};
   size_t chunk = 0;
@@ -66,6 +67,8 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "callback")) use_callback = 1;
     if (!strcmp(argv[i], "mt")) use_mt = 1;
     if (!strcmp(argv[i], "linear")) linear = 1;
+    if (!strcmp(argv[i], "frames")) multi = 1; /* animation: every frame's pixels are appended to the output file */
+    if (!strncmp(argv[i], "skip=", 5)) skip = (size_t)atol(argv[i] + 5); /* JxlDecoderSkipFrames before decoding */
     if (!strcmp(argv[i], "keep")) keep = 1; /* the pixels as coded, the orientation left to the caller */
     if (!strcmp(argv[i], "ec")) want_ec = 1; /* also fetch every extra channel into its own buffer (jxl.cc:571-590) */
     if (!strncmp(argv[i], "chunk=", 6)) chunk = (size_t)atol(argv[i] + 6);
@@ -83,6 +86,7 @@ int main(int argc, char** argv) {
   if (JxlDecoderSetUnpremultiplyAlpha(dec, JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetCoalescing(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetDecompressBoxes(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
+  if (skip) JxlDecoderSkipFrames(dec, skip);
   /* input in one piece, or in chunks the way a streaming caller feeds it (decode.h: unprocessed bytes are re-supplied) */
   size_t given = chunk && chunk < size ? chunk : size, consumed = 0;
   if (JxlDecoderSetInput(dec, bytes, given) != JXL_DEC_SUCCESS) return 2;
@@ -173,12 +177,16 @@ int main(int argc, char** argv) {
       if (JxlDecoderGetFrameName(dec, name, sizeof(name)) != JXL_DEC_SUCCESS) return 2;
       printf("event FRAME %ux%u last=%d downsampling=%zu\n", fh.layer_info.xsize, fh.layer_info.ysize, fh.is_last,
              JxlDecoderGetIntendedDownsamplingRatio(dec));
+      if (info.have_animation)
+        printf("animation tps=%u/%u loops=%u duration=%u timecode=%u\n", info.animation.tps_numerator, info.animation.tps_denominator,
+               info.animation.num_loops, fh.duration, fh.timecode);
     } else if (st == JXL_DEC_NEED_IMAGE_OUT_BUFFER) {
       size_t buffer_size = 0;
       if (JxlDecoderImageOutBufferSize(dec, &format, &buffer_size) != JXL_DEC_SUCCESS) return 2;
       g_bpp = format.num_channels * (format.data_type == JXL_TYPE_UINT8 ? 1 : (format.data_type == JXL_TYPE_FLOAT ? 4 : 2));
       g_stride = (size_t)info.xsize * g_bpp;
       if (buffer_size != g_stride * info.ysize) return 2;
+      free(g_pixels);
       g_pixels = (uint8_t*)calloc(buffer_size, 1);
       printf("event NEED_IMAGE_OUT_BUFFER size=%zu\n", buffer_size);
       if (use_mt) {
@@ -202,6 +210,12 @@ int main(int argc, char** argv) {
       }
     } else if (st == JXL_DEC_FULL_IMAGE) {
       printf("event FULL_IMAGE\n");
+      if (multi && g_pixels) {
+        FILE* o = fopen(argv[2], frames_done ? "ab" : "wb");
+        fwrite(g_pixels, 1, g_stride * info.ysize, o);
+        fclose(o);
+        frames_done++;
+      }
     } else if (st == JXL_DEC_SUCCESS) {
       printf("event SUCCESS\n");
       rc = 0;
@@ -214,7 +228,7 @@ int main(int argc, char** argv) {
   if (have_box_buffer) JxlDecoderReleaseBoxBuffer(dec);
   JxlDecoderReleaseJPEGBuffer(dec); /* jxl.cc:658 */
   printf("unprocessed=%zu\n", JxlDecoderReleaseInput(dec));
-  if (rc == 0 && g_pixels) {
+  if (rc == 0 && g_pixels && !multi) {
     FILE* o = fopen(argv[2], "wb");
     fwrite(g_pixels, 1, g_stride * info.ysize, o);
     for (int i = 0; i < 4; i++) /* the extra channel planes follow the pixels */
