@@ -114,7 +114,7 @@ static inline float FastLog2f(float x) {
   memcpy(&xb, &x, 4);
   int32_t eb = xb - 0x3f2aaaab;
   int32_t es = eb >> 23;
-  int32_t mb = xb - (es << 23);
+  int32_t mb = xb - int32_t(uint32_t(es) << 23);  // (es may be negative)
   float m;
   memcpy(&m, &mb, 4);
   float ev = float(es);

@@ -63,3 +63,39 @@ def test_front_end_decodes_reference_encoder_output(which, name, tmp_path):
     r = subprocess.run([_binary(which), "fjxl", os.path.join(ROOT, "tests", "golden", name + ".jxl"), raw, str(w), str(h), str(c)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
+
+
+def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
+    """tests/c/host_fuzz.cc: the product's host parsers (image header + ICC, VarDCT frame plan with its host Modular
+    decode of the DC groups, Modular frame plan, several frames) built with AddressSanitizer + UBSan, over streams of
+    every feature the writer has, each damaged 150 times (seeded). Damage must end in jxh::Error; any sanitizer report
+    or crash fails. (GPU sanitizers are not available on the pool: the device side has guard bands instead.)"""
+    import numpy as np
+    J = built
+    out = os.path.join(str(tmp_path), "host_fuzz")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wall",
+                    "-Wno-unused-function", os.path.join(ROOT, "tests", "c", "host_fuzz.cc"), "-o", out], check=True)
+    img = J.synth_image(300, 200, seed=5)
+    frames = [J.synth_image(200, 150, seed=s) for s in (1, 2)]
+    J.set_embedded_icc(open(os.path.join(ROOT, "tests", "golden", "ref_icc_test_profile.enc"), "rb").read())
+    try:
+        with_icc = J.encode_rgb8(img)
+    finally:
+        J.set_embedded_icc(None)
+    J.set_orientation(6)
+    try:
+        oriented = J.encode_lossless(img)
+    finally:
+        J.set_orientation(1)
+    streams = [J.encode_rgb8(img), J.encode_rgba8(np.dstack([img, img[..., 0]])), J.encode_random(264, 200, seed=3),
+               J.encode_rgb8(img, ac_code_mode=3, num_passes=2, custom_orders=1, custom_bctx=1, noise=50), J.encode_rgb8(img, upsampling=2),
+               J.encode_lossless(img, J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP),
+               J.encode_lossless(np.dstack([img, img[..., 1]]), J.LOSSLESS_RCT), J.encode_animation(frames, [1, 2]),
+               J.encode_animation(frames, [1, 2], lossless=True), with_icc, oriented]
+    files = []
+    for i, s in enumerate(streams):
+        files.append(os.path.join(str(tmp_path), "s%d.jxl" % i))
+        open(files[-1], "wb").write(s)
+    r = subprocess.run([out, "150"] + files, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "refused" in r.stdout
