@@ -1,0 +1,177 @@
+// Sanitizer harness of the decode.h state machine (libjxl_amd/csrc/api/jxl_api.cc): signature check, container walk
+// (box sizes, jxlp order, brob), chunked input with JxlDecoderReleaseInput, box buffers, header events, ICC getters and
+// the frame walk of animations, over damaged files fed in random pieces. Built by tests/test_kats.py with
+// -fsanitize=address,undefined. The pixel stages need a GPU and are not part of this: the HIP layer's entry points are
+// defined here as "no device" doubles (a decoder that reaches them returns JXL_DEC_ERROR, which is a valid end).
+// Every run must end in JXL_DEC_SUCCESS / JXL_DEC_ERROR / input exhausted within a bounded number of calls.
+// usage: api_fuzz rounds file...
+#include "../../libjxl_amd/csrc/api/jxl_api.cc"
+
+extern "C" {
+int jxlhip_device_count(void) { return 0; }
+int jxlhip_ctx_create(int, JxlHipContext**) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+void jxlhip_ctx_destroy(JxlHipContext*) {}
+int jxlhip_download_pixels(JxlHipContext*, void*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_frame_upload(JxlHipContext*, const JxlHipFrameDesc*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_get_errors(JxlHipContext*, uint32_t*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_get_section_end_bits(JxlHipContext*, uint32_t*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_modular_download_buffer(JxlHipContext*, uint32_t, int32_t*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_modular_run(JxlHipContext*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_modular_status(JxlHipContext*, uint32_t*, uint32_t*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_modular_upload(JxlHipContext*, const JxlHipModFrameDesc*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_run_entropy(JxlHipContext*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_run_filter_color(JxlHipContext*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_run_transform(JxlHipContext*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_set_alpha(JxlHipContext*, const float*, uint32_t, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_set_output_format(JxlHipContext*, uint32_t, uint32_t, uint32_t, int) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_set_output_orientation(JxlHipContext*, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+}
+
+static uint64_t g_rng = 0x9E3779B97F4A7C15ull;
+static uint32_t Rnd(uint32_t n) {
+  g_rng ^= g_rng << 13;
+  g_rng ^= g_rng >> 7;
+  g_rng ^= g_rng << 17;
+  return uint32_t((g_rng >> 11) % (n ? n : 1));
+}
+
+// One decode of `v` fed in pieces of at most `chunk` bytes. Returns 0 = ended (success, error or out of input), 1 = stuck.
+static int Walk(const std::vector<uint8_t>& v, size_t chunk, bool want_pixels, size_t* ended_ok) {
+  JxlDecoder* dec = JxlDecoderCreate(nullptr);
+  if (!dec) return 1;
+  int events = JXL_DEC_BASIC_INFO | JXL_DEC_COLOR_ENCODING | JXL_DEC_FRAME | JXL_DEC_BOX;
+  if (want_pixels) events |= JXL_DEC_FULL_IMAGE;
+  JxlDecoderSubscribeEvents(dec, events);
+  JxlDecoderSetDecompressBoxes(dec, Rnd(2) ? JXL_TRUE : JXL_FALSE);
+  if (Rnd(4) == 0) JxlDecoderSkipFrames(dec, 1);
+  size_t given = std::min(chunk, v.size()), consumed = 0;
+  JxlDecoderSetInput(dec, v.data(), given);
+  if (given == v.size()) JxlDecoderCloseInput(dec);
+  uint8_t box_buffer[48];
+  bool have_box_buffer = false;
+  int rc = 1;
+  for (int calls = 0; calls < 200000; calls++) {
+    const JxlDecoderStatus st = JxlDecoderProcessInput(dec);
+    if (st == JXL_DEC_SUCCESS) {
+      ++*ended_ok;
+      rc = 0;
+      break;
+    }
+    if (st == JXL_DEC_ERROR) {
+      rc = 0;
+      break;
+    }
+    if (st == JXL_DEC_NEED_MORE_INPUT) {
+      const size_t left = JxlDecoderReleaseInput(dec);
+      if (left > given) break;  // more handed back than was given: stuck / corrupt accounting
+      consumed += given - left;
+      if (consumed + left >= v.size()) {
+        rc = 0;  // the file ended inside something: the caller's problem, a clean end for the decoder
+        break;
+      }
+      given = std::min(v.size() - consumed, left + 1 + Rnd(uint32_t(chunk)));
+      JxlDecoderSetInput(dec, v.data() + consumed, given);
+      if (consumed + given == v.size()) JxlDecoderCloseInput(dec);
+    } else if (st == JXL_DEC_BASIC_INFO) {
+      JxlBasicInfo info;
+      JxlDecoderGetBasicInfo(dec, &info);
+      for (uint32_t i = 0; i < info.num_extra_channels && i < 8; i++) {
+        JxlExtraChannelInfo eci;
+        char name[16];
+        JxlDecoderGetExtraChannelInfo(dec, i, &eci);
+        JxlDecoderGetExtraChannelName(dec, i, name, sizeof(name));
+      }
+    } else if (st == JXL_DEC_COLOR_ENCODING) {
+      JxlColorEncoding ce;
+      JxlDecoderGetColorAsEncodedProfile(dec, JXL_COLOR_PROFILE_TARGET_DATA, &ce);
+      for (JxlColorProfileTarget t : {JXL_COLOR_PROFILE_TARGET_ORIGINAL, JXL_COLOR_PROFILE_TARGET_DATA}) {
+        size_t n = 0;
+        if (JxlDecoderGetICCProfileSize(dec, t, &n) == JXL_DEC_SUCCESS && n && n < (1u << 24)) {
+          std::vector<uint8_t> icc(n);
+          JxlDecoderGetColorAsICCProfile(dec, t, icc.data(), n);
+        }
+      }
+    } else if (st == JXL_DEC_FRAME) {
+      JxlFrameHeader fh;
+      char name[8];
+      JxlDecoderGetFrameHeader(dec, &fh);
+      JxlDecoderGetFrameName(dec, name, sizeof(name));
+    } else if (st == JXL_DEC_BOX) {
+      JxlBoxType type;
+      uint64_t size = 0;
+      if (have_box_buffer) JxlDecoderReleaseBoxBuffer(dec);
+      JxlDecoderGetBoxType(dec, type, JXL_TRUE);
+      JxlDecoderGetBoxSizeRaw(dec, &size);
+      JxlDecoderSetBoxBuffer(dec, box_buffer, sizeof(box_buffer));
+      have_box_buffer = true;
+    } else if (st == JXL_DEC_BOX_NEED_MORE_OUTPUT) {
+      JxlDecoderReleaseBoxBuffer(dec);
+      JxlDecoderSetBoxBuffer(dec, box_buffer, sizeof(box_buffer));
+    } else if (st == JXL_DEC_NEED_IMAGE_OUT_BUFFER) {
+      JxlPixelFormat f = {3, JXL_TYPE_UINT8, JXL_NATIVE_ENDIAN, 0};
+      size_t n = 0;
+      if (JxlDecoderImageOutBufferSize(dec, &f, &n) != JXL_DEC_SUCCESS || n > (size_t(1) << 28)) {
+        rc = 0;
+        break;
+      }
+      static std::vector<uint8_t> px;
+      px.resize(n);
+      if (JxlDecoderSetImageOutBuffer(dec, &f, px.data(), n) != JXL_DEC_SUCCESS) {
+        rc = 0;
+        break;
+      }
+    } else {
+      rc = 0;  // another event (JPEG reconstruction ...): nothing to do for it here
+      if (st == JXL_DEC_FULL_IMAGE) continue;
+      break;
+    }
+  }
+  if (have_box_buffer) JxlDecoderReleaseBoxBuffer(dec);
+  JxlDecoderReleaseInput(dec);
+  JxlDecoderDestroy(dec);
+  return rc;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  const int rounds = atoi(argv[1]);
+  size_t total = 0, ok = 0;
+  for (int a = 2; a < argc; a++) {
+    FILE* f = fopen(argv[a], "rb");
+    if (!f) return 2;
+    std::vector<uint8_t> orig;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) orig.insert(orig.end(), buf, buf + n);
+    fclose(f);
+    size_t clean = 0;
+    if (Walk(orig, orig.size(), false, &clean) || !clean) {
+      fprintf(stderr, "FAIL: the undamaged file %s does not reach JXL_DEC_SUCCESS\n", argv[a]);
+      return 1;
+    }
+    for (int r = 0; r < rounds; r++) {
+      std::vector<uint8_t> v = orig;
+      const uint32_t kind = Rnd(5);
+      const size_t span = Rnd(3) ? std::min<size_t>(v.size(), 32 + Rnd(512)) : v.size();
+      if (kind == 0) {
+        for (uint32_t i = 0, k = 1 + Rnd(4); i < k; i++) v[Rnd(uint32_t(span))] = uint8_t(Rnd(256));
+      } else if (kind == 1) {
+        v[Rnd(uint32_t(span))] ^= uint8_t(1u << Rnd(8));
+      } else if (kind == 2) {
+        v.resize(Rnd(uint32_t(v.size())));
+      } else if (kind == 3) {
+        const size_t at = Rnd(uint32_t(span)), len = std::min<size_t>(v.size() - at, 1 + Rnd(16));
+        memset(v.data() + at, Rnd(2) ? 0xFF : 0, len);
+      }  // kind 4: undamaged, only the chunking varies
+      if (v.empty()) continue;
+      total++;
+      const size_t chunk = Rnd(2) ? 1 + Rnd(64) : 1 + Rnd(uint32_t(v.size()));
+      if (Walk(v, chunk, Rnd(3) == 0, &ok)) {
+        fprintf(stderr, "FAIL: decoder stuck on a damaged copy of %s (round %d, kind %u, chunk %zu)\n", argv[a], r, kind, chunk);
+        return 1;
+      }
+    }
+  }
+  printf("api_fuzz: %zu runs, %zu reached JXL_DEC_SUCCESS\n", total, ok);
+  return 0;
+}

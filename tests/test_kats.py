@@ -99,3 +99,33 @@ def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
     r = subprocess.run([out, "150"] + files, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "refused" in r.stdout
+
+
+def test_decoder_api_under_sanitizers_on_damaged_files(built, tmp_path):
+    """tests/c/api_fuzz.cc: the decode.h state machine (container walk, chunked input, box buffers, header events, ICC
+    getters, animation frame walk, SkipFrames) built with AddressSanitizer + UBSan around libjxl_amd/csrc/api/jxl_api.cc,
+    over bare and boxed files, damaged and fed in random pieces. Every run must end (success, error or end of input)
+    within a bounded number of calls; a sanitizer report, a crash or a decoder that keeps asking fails."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import replay_util as R
+    J = built
+    out = os.path.join(str(tmp_path), "api_fuzz")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wall",
+                    "-Wno-unused-function", "-Wno-subobject-linkage", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "api_fuzz.cc"), "-o", out, "-lpthread"], check=True)
+    img = J.synth_image(300, 200, seed=5)
+    frames = [J.synth_image(200, 150, seed=s) for s in (1, 2, 3)]
+    J.set_embedded_icc(open(os.path.join(ROOT, "tests", "golden", "ref_icc_test_profile.enc"), "rb").read())
+    try:
+        with_icc = J.encode_rgb8(img)
+    finally:
+        J.set_embedded_icc(None)
+    anim = J.encode_animation(frames, [1, 2, 3])
+    files = []
+    for i, s in enumerate([J.encode_rgb8(img), R.container(J.encode_rgb8(img)), R.container(with_icc, pieces=3), anim,
+                           R.container(anim, pieces=4), R.container(J.encode_lossless(img), pieces=1)]):
+        files.append(os.path.join(str(tmp_path), "f%d.jxl" % i))
+        open(files[-1], "wb").write(s)
+    r = subprocess.run([out, "60"] + files, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "reached JXL_DEC_SUCCESS" in r.stdout
