@@ -23,6 +23,7 @@
 #include "jxlo_headers.h"
 #include "jxlo_modular.h"
 #include "jxlo_render.h"
+#include "jxlo_splines.h"
 #include "jxlo_vardct.h"
 
 namespace jxlo {
@@ -65,6 +66,8 @@ struct FrameState {
   uint32_t color_factor = 84;
   float base_corr_x = 0.0f, base_corr_b = 1.0f;
   int32_t ytox_dc = 0, ytob_dc = 0;
+  Splines splines;
+  bool has_splines = false;
   float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool has_noise = false;
   MGlobal mglobal;
@@ -81,7 +84,12 @@ struct FrameState {
 
 static void DecodeDcGlobal(BitReader& br, FrameState* s) {
   const FrameHeader& fh = s->fh;
-  JXLO_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines)), "unsupported: patches/splines");
+  JXLO_CHECK(!(fh.flags & FrameHeader::kPatches), "unsupported: patches");
+  if (fh.flags & FrameHeader::kSplines) {  // dec_frame.cc:289-293
+    JXLO_CHECK(fh.upsampling == 1, "unsupported: splines on upsampled frames");
+    DecodeSplines(br, s->dim.xsize * s->dim.ysize, &s->splines);
+    s->has_splines = true;
+  }
   JXLO_CHECK(!(fh.flags & FrameHeader::kUseDcFrame), "unsupported: DC frames");
   if (fh.flags & FrameHeader::kNoise) {  // dec_frame.cc:294-296, dec_noise.cc:154-164: eight 10-bit LUT points
     for (float& v : s->noise_lut) v = float(br.Read(10)) / 1024.0f;
@@ -608,6 +616,16 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       for (int c = 0; c < 3; c++)
         memcpy(out->xyb_filtered.data() + c * d.xsize_padded * d.ysize, cur->p[c].data(), d.xsize_padded * d.ysize * sizeof(float));
     }
+    Planes3 splined;
+    if (s->has_splines) {  // dec_cache.cc:198-201: after the filters, before upsampling and noise
+      InitSplineDrawCache(&s->splines, d.xsize, d.ysize, s->base_corr_x, s->base_corr_b);  // dec_frame.cc:303-308
+      splined = *cur;
+      DrawSplines(s->splines, splined.p[0].data(), splined.p[1].data(), splined.p[2].data(), splined.stride, d.xsize, d.ysize);
+      cur = &splined;
+      if (want_dumps)
+        for (int c = 0; c < 3; c++)
+          memcpy(out->xyb_filtered.data() + c * d.xsize_padded * d.ysize, cur->p[c].data(), d.xsize_padded * d.ysize * sizeof(float));
+    }
     Planes3 up;
     if (fh.upsampling != 1) {
       Planes3 crop;  // the filters work on the padded stride; the upsampler mirrors about the frame size
@@ -652,6 +670,10 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     for (int c = 0; c < 3; c++) {
       const MChannel& ch = s->full.ch[ncol == 1 ? 0 : c];
       for (size_t i = 0; i < xs * ys; i++) out->rgbf[c * xs * ys + i] = float(ch.d[i]) * factor;
+    }
+    if (s->has_splines) {  // the same stage on the three colour channels of a Modular frame (default colour correlation: 0, 1)
+      InitSplineDrawCache(&s->splines, xs, ys, s->base_corr_x, s->base_corr_b);
+      DrawSplines(s->splines, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs, xs, ys);
     }
     if (want_dumps) {
       out->modular.resize(s->full.ch.size() * xs * ys);
