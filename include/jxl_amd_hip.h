@@ -74,6 +74,16 @@ typedef struct JxlHipPassDesc {
   uint32_t lz77, lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_ctx;
 } JxlHipPassDesc;
 
+/* The draw cache of a frame's splines: segments of 8 floats {centre x, centre y, maximum distance, 1 / sigma,
+ * sigma / 4 * intensity, colour X, Y, B} (splines.h:44-51); row y draws segments row_segments[row_start[y] ..
+ * row_start[y + 1]) in that order. num_segments = 0: no splines. */
+typedef struct JxlHipSplines {
+  uint32_t num_segments, num_row_segments;
+  const float* segments;
+  const uint32_t* row_start; /* ysize + 1 entries */
+  const uint32_t* row_segments;
+} JxlHipSplines;
+
 typedef struct JxlHipFrameDesc {
   uint32_t xsize, ysize;
   uint32_t xsize_blocks, ysize_blocks;
@@ -136,6 +146,9 @@ typedef struct JxlHipFrameDesc {
   uint32_t has_noise;
   float noise_lut[8];
   uint32_t noise_frame_index[2];
+  /* Splines (render_pipeline/stage_splines.cc; the draw cache of lib/jxl/splines.cc:661-768, built by the host): drawn
+   * over the filtered planes before noise and colour conversion. Only for frames that are not upsampled. */
+  JxlHipSplines splines;
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);
@@ -304,6 +317,8 @@ typedef struct JxlHipModFrameDesc {
   /* output: the buffers holding the final colour channels (1 or 3) and alpha (or 0xFFFFFFFF) */
   uint32_t out_buffer[4];
   uint32_t num_color, has_alpha, bits, alpha_bits;
+  /* splines over the three colour channels (as floats, before the sample conversion); colour images only */
+  JxlHipSplines splines;
 } JxlHipModFrameDesc;
 /* Copies a Modular frame's tables and sections to the device (the arrays may be released afterwards). */
 int jxlhip_modular_upload(JxlHipContext* ctx, const JxlHipModFrameDesc* desc);

@@ -457,6 +457,31 @@ def set_orientation(orientation=1):
     E.jxlenc_set_orientation(int(orientation))
 
 
+def set_splines(splines=None, quantization_adjustment=0):
+    """Test aid: the next streams carry these quantised splines (None: none again). Each spline is a dict: points (list of
+    integer (x, y) control points), color ([3][32] integer DCT coefficients of X, Y, B along the arc) and sigma ([32])."""
+    E = _enc_lib()
+    E.jxlenc_set_splines.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_size_t]
+    E.jxlenc_set_splines.restype = None
+    if not splines:
+        E.jxlenc_set_splines(None, 0)
+        return
+    flat = [int(quantization_adjustment), len(splines)]
+    for sp in splines:
+        pts = [(int(x), int(y)) for x, y in sp["points"]]
+        flat += [pts[0][0], pts[0][1], len(pts) - 1]
+        pdx = pdy = 0
+        for (x0, y0), (x1, y1) in zip(pts, pts[1:]):  # double deltas (splines.cc:411-431)
+            dx, dy = x1 - x0, y1 - y0
+            flat += [dx - pdx, dy - pdy]
+            pdx, pdy = dx, dy
+        for c in range(3):
+            flat += [int(v) for v in sp["color"][c]]
+        flat += [int(v) for v in sp["sigma"]]
+    arr = (ctypes.c_int32 * len(flat))(*flat)
+    E.jxlenc_set_splines(arr, len(flat))
+
+
 def encode_animation(frames, durations, tps=(10, 1), num_loops=0, lossless=False, **kw):
     """Test aid: an animation of full-size frames that replace each other (no layers, blending, crops or references):
     frames[i] (HxWx3 or HxWx4 uint8, all of one size) is shown for durations[i] ticks of tps[0] / tps[1] per second."""

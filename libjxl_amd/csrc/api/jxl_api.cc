@@ -53,6 +53,17 @@ extern "C" {
 
 const char* jxlamd_last_error(void) { return g_last_error.c_str(); }
 
+// image_features.splines -> JxlHipSplines (the arrays stay owned by the plan)
+static void FillSplines(bool has, const jxh::Splines& s, JxlHipSplines* out) {
+  memset(out, 0, sizeof(*out));
+  if (!has || s.segments.empty()) return;
+  out->num_segments = uint32_t(s.segments.size() / 8);
+  out->num_row_segments = uint32_t(s.row_segments.size());
+  out->segments = s.segments.data();
+  out->row_start = s.row_start.data();
+  out->row_segments = s.row_segments.data();
+}
+
 int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runner, void* runner_opaque, JxlAmdFrame** out) {
   return jxlamd_frame_parse_at(data, size, 0, 0, runner, runner_opaque, out);
 }
@@ -246,6 +257,7 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.band_group_row_begin = group_row_begin;
   d.band_group_row_end = group_row_end;
   d.has_noise = P.has_noise ? 1 : 0;
+  FillSplines(P.has_splines, P.splines, &d.splines);
   memcpy(d.noise_lut, P.noise_lut, sizeof(d.noise_lut));
   // dec_frame.cc:160-168: the number of visible frames before this one, and of invisible ones since (none are accepted)
   d.noise_frame_index[0] = uint32_t(P.frame_index);
@@ -463,6 +475,7 @@ int jxlamd_modframe_upload(const JxlAmdModFrame* f, JxlHipContext* ctx) {
   d.has_alpha = P.has_alpha;
   d.bits = P.ih.bits;
   d.alpha_bits = P.alpha_bits;
+  FillSplines(P.has_splines, P.splines, &d.splines);
   const int r = jxlhip_modular_upload(ctx, &d);
   if (r) g_last_error = "jxlhip_modular_upload failed (" + std::to_string(r) + ")";
   return r;

@@ -790,6 +790,54 @@ static void WriteFrameTiming(BitWriter& bw) {
   bw.Write(1, last ? 1 : 0);
   if (!last) bw.Write(2, 0);  // save_as_reference 0
 }
+// jxlenc_set_splines: the quantised spline dictionary the next streams carry (frame flag kSplines), flat:
+// [quantisation adjustment, number of splines, then per spline: start x, start y, number of further control points,
+// their double deltas (x, y each), 3 x 32 colour DCT coefficients (X, Y, B), 32 sigma DCT coefficients]. Written the way
+// Splines::Decode reads it (splines.cc:596-648): 6 contexts, starting points as deltas of each other, ANS coded.
+static std::vector<int32_t> g_splines;
+static void WriteCodeHeader(BitWriter& bw, const EncCode& code);
+static void WriteSplines(BitWriter& bw) {
+  const int32_t* d = g_splines.data();
+  const int32_t adjust = *d++;
+  const size_t n = size_t(*d++);
+  std::vector<Token> tk;
+  tk.push_back({2, uint32_t(n - 1)});
+  struct One {
+    int64_t x, y;
+    const int32_t *deltas, *dct;
+    size_t nd;
+  };
+  std::vector<One> sp(n);
+  for (auto& o : sp) {
+    o.x = *d++;
+    o.y = *d++;
+    o.nd = size_t(*d++);
+    o.deltas = d;
+    d += 2 * o.nd;
+    o.dct = d;
+    d += 128;
+  }
+  int64_t lx = 0, ly = 0;
+  auto pack = [](int64_t v) { return v >= 0 ? uint32_t(v) * 2 : uint32_t(-(v + 1)) * 2 + 1; };
+  for (size_t i = 0; i < n; i++) {
+    tk.push_back({1, i ? pack(sp[i].x - lx) : uint32_t(sp[i].x)});
+    tk.push_back({1, i ? pack(sp[i].y - ly) : uint32_t(sp[i].y)});
+    lx = sp[i].x;
+    ly = sp[i].y;
+  }
+  tk.push_back({0, pack(adjust)});
+  for (const auto& o : sp) {
+    tk.push_back({3, uint32_t(o.nd)});
+    for (size_t i = 0; i < 2 * o.nd; i++) tk.push_back({4, pack(o.deltas[i])});
+    for (size_t i = 0; i < 128; i++) tk.push_back({5, pack(o.dct[i])});
+  }
+  jxh::HybridCfg cfg;
+  cfg.split_exp = 4; cfg.split_token = 16; cfg.msb = 2; cfg.lsb = 0;
+  EncCode code;
+  BuildCode({&tk}, 6, 6, cfg, &code);
+  WriteCodeHeader(bw, code);
+  WriteTokens(bw, tk.data(), tk.size(), code);
+}
 static std::vector<uint8_t> g_embedded_icc;
 static size_t g_embedded_icc_bits = 0;  // its exact length (the decoder aligns to a byte right after the last bit)
 static void AppendEmbeddedIcc(BitWriter& bw) {
@@ -1079,6 +1127,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   // ---- sections
   auto write_dc_global = [&](BitWriter& bw) {
+    if (!g_splines.empty()) WriteSplines(bw);  // (dec_frame.cc:289-296: splines, then noise)
     if (p.noise > 0)  // NoiseParams: eight 10-bit LUT points (dec_noise.cc:154-164)
       for (int i = 0; i < 8; i++) bw.Write(10, uint32_t(std::min(1023, p.noise + 40 * i)));
     if (!p.custom_lf) {
@@ -1379,7 +1428,7 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     if (p.strategy_mode > 1 || p.random_cmap || p.custom_cmap) throw std::runtime_error("forward hook: unsupported parameters");
     const double t0 = NowSeconds();
     f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
-    f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0);
+    f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16);
     f.sharp.assign(f.xb * f.yb, 4);
     f.ytox.assign(DivCeil(f.xb, 8) * DivCeil(f.yb, 8), 0);
     f.ytob.assign(f.ytox.size(), 0);
@@ -1455,7 +1504,7 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     }
   }
   f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
-  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0);
+  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16);
   f.acs.assign(f.xb * f.yb, 0xFF);
   f.qf.assign(f.xb * f.yb, 0);
   f.sharp.assign(f.xb * f.yb, 4);
@@ -1650,7 +1699,7 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
   f.quant_dc = 8 + rng.Below(16);
   f.gab = p.gab < 0 ? 1 : p.gab;
   f.epf_iters = p.epf_iters < 0 ? 1 : p.epf_iters;
-  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0);
+  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16);
   f.acs.assign(f.xb * f.yb, 0xFF);
   f.qf.assign(f.xb * f.yb, 0);
   f.sharp.assign(f.xb * f.yb, 0);
@@ -2099,6 +2148,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   };
   std::vector<std::vector<uint8_t>> sections;
   auto dc_global = [&](BitWriter& bw) {
+    if (!g_splines.empty()) WriteSplines(bw);
     bw.Write(1, 1);  // default DC dequantisation
     bw.Write(1, 1);  // global tree present
     WriteCodeHeader(bw, tree_code);
@@ -2182,7 +2232,12 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(1, 0);  // not all_default
   bw.Write(2, 0);  // regular frame
   bw.Write(1, 1);  // Modular
-  bw.Write(2, 0);  // flags 0
+  if (g_splines.empty()) {
+    bw.Write(2, 0);  // flags 0
+  } else {
+    bw.Write(2, 1);  // flags = kSplines (16): U64 selector 1, 1 + 4 bits
+    bw.Write(4, 15);
+  }
   bw.Write(1, 0);  // (not XYB:) no YCbCr
   bw.Write(2, 0);  // upsampling 1
   if (alpha) bw.Write(2, 0);
@@ -2240,6 +2295,9 @@ void jxlenc_set_embedded_icc(const uint8_t* coded, size_t n, size_t bits) {
 
 // The next encoded streams declare this orientation (1..8, codestream_header.h:45-54; 1 = identity). Test aid, not thread-safe.
 void jxlenc_set_orientation(uint32_t orientation) { jxe::g_orientation = orientation >= 1 && orientation <= 8 ? orientation : 1; }
+
+// Spline dictionary of the next streams (n = 0: none again); layout at jxe::g_splines. Test aid, not thread-safe.
+void jxlenc_set_splines(const int32_t* data, size_t n) { jxe::g_splines.assign(data, data + n); }
 
 // Animation mode for the next streams (enabled = 0: stills again). Test aid, not thread-safe.
 void jxlenc_set_animation(int enabled, uint32_t tps_numerator, uint32_t tps_denominator, uint32_t num_loops, uint32_t duration, int is_last) {

@@ -227,6 +227,9 @@ struct JxlHipContext {
   jxlhip::EncFwd enc_last;     // the parameters of the last jxlhip_enc_forward (its input stays resident): jxlhip_enc_forward_rerun
   bool enc_last_gaborish = false;
   uint32_t out_orient = 0;  // jxlhip_set_output_orientation: PixelOut::orient bits (0 = the image as coded)
+  // splines (JxlHipSplines): the draw cache on the device; for a Modular frame also the float planes they are drawn over
+  Buf spl_seg, spl_row_start, spl_row_seg, spl_planes;
+  uint32_t spl_segments = 0;
   // noise synthesis (JxlHipFrameDesc::has_noise): raw random planes [3][ys][xs], LUT, seeds, base colour correlation
   Buf noise;
   bool has_noise = false;
@@ -402,7 +405,7 @@ static std::vector<Buf*> AllBufs(JxlHipContext* c) {
   std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
-                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise,
+                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes,
                 &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq};
   for (auto& pb : c->pass_bufs)
     for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset, &pb.alias_packed}) all.push_back(b);
@@ -506,6 +509,7 @@ static int UploadStaged(JxlHipContext* c, Buf& b, const void* staged, size_t byt
   return 0;
 }
 static int UploadStaged(JxlHipContext* c, Buf& b, const void* staged, size_t bytes);
+static int UploadSplines(JxlHipContext* c, const JxlHipSplines& sp, uint32_t ysize);
 static int Upload(JxlHipContext* c, Buf& b, const void* src, size_t bytes) {
   void* st = nullptr;
   int r = StageAlloc(c, bytes ? bytes : 16, &st);  // (blob mode: an empty table still gets a valid address)
@@ -674,6 +678,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     }
     add(size_t(d->num_passes) * sizeof(jxlhip::PassDev)); add(64 * 25 * 4); add((size_t(d->num_blocks) + 1) * 4);
     add((size_t(d->num_blocks) + 16) * 4); add(sizeof(jxlhip::EntropyParams)); add(size_t(d->dequant_floats) * 4);
+    add(size_t(d->splines.num_segments) * 32); add((size_t(d->ysize) + 1) * 4); add(size_t(d->splines.num_row_segments) * 4 + 16);
     if ((r = BlobBegin(c, bound))) return r;
   }
   struct BlobGuard {  // whatever the outcome, later uploads of other kinds see the plain mode
@@ -823,6 +828,12 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     c->noise_ytob = d->base_corr_b;
     if ((r = c->noise.Ensure(size_t(c->xs) * c->ys * 3 * 4))) return r;
   }
+  // splines are drawn over the filtered planes before noise and the colour conversion
+  if (d->splines.num_segments) {
+    if (c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
+    c->color_out = true;
+  }
+  if ((r = UploadSplines(c, d->splines, c->ys))) return r;
   if (c->have_alpha && c->alpha.cap < size_t(c->oxs) * c->oys * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
   if ((c->keep_filtered || c->ups != 1 || c->color_out) && (r = c->plane[1].Ensure(plane_bytes))) return r;
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
@@ -1734,6 +1745,25 @@ extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
 }
 
 
+// The draw cache of a frame's splines to the device (validated: every index a kernel forms from it is in range).
+static int UploadSplines(JxlHipContext* c, const JxlHipSplines& sp, uint32_t ysize) {
+  c->spl_segments = 0;
+  if (!sp.num_segments) return 0;
+  if (!sp.segments || !sp.row_start || !sp.row_segments || sp.num_segments > (1u << 26) || sp.num_row_segments > (1u << 30))
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (sp.row_start[0] != 0 || sp.row_start[ysize] != sp.num_row_segments) return JXLHIP_ERR_INVALID_ARGUMENT;
+  for (uint32_t y = 0; y < ysize; y++)
+    if (sp.row_start[y] > sp.row_start[y + 1]) return JXLHIP_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < sp.num_row_segments; i++)
+    if (sp.row_segments[i] >= sp.num_segments) return JXLHIP_ERR_INVALID_ARGUMENT;
+  int r;
+  if ((r = Upload(c, c->spl_seg, sp.segments, size_t(sp.num_segments) * 32))) return r;
+  if ((r = Upload(c, c->spl_row_start, sp.row_start, (size_t(ysize) + 1) * 4))) return r;
+  if ((r = Upload(c, c->spl_row_seg, sp.row_segments, std::max<size_t>(4, size_t(sp.num_row_segments) * 4)))) return r;
+  c->spl_segments = sp.num_segments;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ Modular frames
 extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc* d) {
   if (!c || !d || !d->xsize || !d->ysize || !d->num_sections || !d->num_trees || !d->num_codes || d->num_trees != d->num_codes)
@@ -1957,6 +1987,9 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
   c->oys = c->ys = d->ysize;
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
   HIP_TRY(hipStreamSynchronize(c->stream));  // the staging vectors are locals
+  if (d->splines.num_segments && d->num_color != 3) return JXLHIP_ERR_UNSUPPORTED;
+  if ((r = UploadSplines(c, d->splines, d->ysize))) return r;
+  if (c->spl_segments && (r = c->spl_planes.Ensure(size_t(d->xsize) * d->ysize * 3 * 4))) return r;
   M.have = true;
   M.batch_ctxs.clear();
   c->generation++;
@@ -2047,6 +2080,49 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
       if (L.count) launches->push_back(L);
     }
   }
+  // frames with splines: colour samples to float planes (kind 4), the splines over them (kind 5), then the output reads them
+  for (uint32_t pass = 4; pass <= 5; pass++) {
+    align();
+    ModLaunch S{pass, blob->size(), 0, 0, 0};
+    for (size_t i = 0; i < n; i++) {
+      const JxlHipContext* c = ctxs[i];
+      const JxlHipContext::Modular& M = c->mod;
+      if (!c->spl_segments) continue;
+      if (pass == 4) {
+        jxlhip::ModOutput o;
+        memset(&o, 0, sizeof(o));
+        for (uint32_t j = 0; j < 3; j++) {
+          o.ch[j] = M.pool.as<int32_t>() + M.buf_off[M.out_buffer[j]];
+          o.stride[j] = M.xs;
+        }
+        o.num_color = 3;
+        o.bits = M.bits;
+        o.w = M.xs;
+        o.h = M.ys;
+        o.fplanes = c->spl_planes.as<float>();
+        o.fmode = 1;
+        append(&o, sizeof(o));
+        S.gx = std::max(S.gx, (M.xs + 255) / 256);
+      } else {
+        jxlhip::SplineParams sp;
+        memset(&sp, 0, sizeof(sp));
+        sp.planes = c->spl_planes.as<float>();
+        sp.segments = c->spl_seg.as<float>();
+        sp.row_start = c->spl_row_start.as<uint32_t>();
+        sp.row_segments = c->spl_row_seg.as<uint32_t>();
+        sp.stride = M.xs;
+        sp.plane_stride = size_t(M.xs) * M.ys;
+        sp.xsize = M.xs;
+        sp.y_begin = 0;
+        sp.y_end = M.ys;
+        append(&sp, sizeof(sp));
+        S.gx = 1;
+      }
+      S.count++;
+      S.gy = std::max(S.gy, M.ys);
+    }
+    if (S.count) launches->push_back(S);
+  }
   align();
   ModLaunch L{3, blob->size(), 0, 0, 0};
   for (size_t i = 0; i < n; i++) {
@@ -2055,6 +2131,10 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
     int32_t* pool = M.pool.as<int32_t>();
     jxlhip::ModOutput o;
     memset(&o, 0, sizeof(o));
+    if (c->spl_segments) {
+      o.fplanes = c->spl_planes.as<float>();
+      o.fmode = 2;
+    }
     for (uint32_t j = 0; j < M.num_color + (M.has_alpha ? 1 : 0); j++) {
       o.ch[j] = pool + M.buf_off[M.out_buffer[j]];
       o.stride[j] = M.xs;
@@ -2092,6 +2172,8 @@ static int ModularLaunchOps(const std::vector<ModLaunch>& launches, const uint8_
         hipLaunchKernelGGL(jxlhip::k_modular_palette, dim3(L.gx, gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::ModPalette*>(dev + L.offset) + z);
       else if (L.kind == 2)
         hipLaunchKernelGGL(jxlhip::k_modular_unsqueeze, dim3(L.gx, zn), dim3(64), 0, st, reinterpret_cast<const jxlhip::ModUnsqueeze*>(dev + L.offset) + z);
+      else if (L.kind == 5)  // (one workgroup per row: the full height, not the strided grid of the sample kernels)
+        hipLaunchKernelGGL(jxlhip::k_splines_add_batch, dim3(L.gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::SplineParams*>(dev + L.offset) + z);
       else
         hipLaunchKernelGGL(jxlhip::k_modular_output, dim3(L.gx, gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::ModOutput*>(dev + L.offset) + z);
       HIP_TRY(hipGetLastError());
@@ -2260,6 +2342,23 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
       default: r = LaunchFused<true, 3>(c0, g); break;
     }
     if (r) return r;
+  }
+  for (size_t i = 0; i < n; i++) {
+    const JxlHipContext* c = ctxs[i];
+    if (!c->spl_segments) continue;
+    jxlhip::SplineParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.planes = c->plane[1].as<float>();
+    sp.segments = c->spl_seg.as<float>();
+    sp.row_start = c->spl_row_start.as<uint32_t>();
+    sp.row_segments = c->spl_row_seg.as<uint32_t>();
+    sp.stride = c->xp;
+    sp.plane_stride = size_t(c->xp) * c->yp;
+    sp.xsize = c->xs;
+    sp.y_begin = c->band_y0;
+    sp.y_end = c->band_y1;
+    hipLaunchKernelGGL(jxlhip::k_splines_add, dim3(c->band_y1 - c->band_y0), dim3(256), 0, ls, sp);
+    HIP_TRY(hipGetLastError());
   }
   for (size_t i = 0; i < n; i++) {
     const JxlHipContext* c = ctxs[i];

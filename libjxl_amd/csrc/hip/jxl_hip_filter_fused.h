@@ -970,5 +970,59 @@ __global__ __launch_bounds__(256) void k_noise_add(NoiseParams P) {
   P.planes[2 * plane + i] = P.ytob * rg + vb;
 }
 
+// ---- splines (render_pipeline/stage_splines.cc, lib/jxl/splines.cc:84-133,178-187): every row adds the segments of its
+// list, in list order, to the three colour planes: a Gaussian-like splat around the segment centre, FastErff
+// (fast_math-inl.h:126-148) of the distance. One workgroup per row; a thread owns the samples x = tid (mod 256), so the
+// additions to one sample happen in segment order without synchronisation.
+struct SplineParams {
+  float* planes;              // [3] planes, `plane_stride` floats apart, rows of `stride` floats
+  const float* segments;      // 8 floats each: centre x, y, maximum distance, 1 / sigma, sigma / 4 * intensity, colour[3]
+  const uint32_t* row_start;  // [ysize + 1]
+  const uint32_t* row_segments;
+  size_t stride, plane_stride;
+  uint32_t xsize, y_begin, y_end;
+};
+__device__ __forceinline__ float SplineErf(float x) {
+  const float a = fabsf(x);
+  const float d1 = __builtin_fmaf(a, 7.77394369e-02f, 2.05260015e-04f);
+  const float d2 = __builtin_fmaf(d1, a, 2.32120216e-01f);
+  const float d3 = __builtin_fmaf(d2, a, 2.77820801e-01f);
+  const float d4 = __builtin_fmaf(d3, a, 1.0f);
+  const float d5 = d4 * d4;
+  const float inv = 1.0f / d5;
+  const float r = __builtin_fmaf(-inv, inv, 1.0f);
+  return x <= 0.0f ? -r : r;
+}
+__device__ __forceinline__ void SplinesAddRow(const SplineParams& P, uint32_t y) {
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = P.row_start[y]; i < P.row_start[y + 1]; i++) {
+    const float* g = P.segments + size_t(P.row_segments[i]) * 8;
+    const float cx = g[0], cy = g[1], maxd = g[2], inv_sigma = g[3], s4i = g[4];
+    const long long start = llroundf(cx - maxd), end = llroundf(cx + maxd);
+    if (end < 0 || start >= (long long)P.xsize) continue;
+    const uint32_t x0 = uint32_t(max(0ll, start)), x1 = uint32_t(min((long long)P.xsize, end + 1));
+    const float dy = float(y) - cy;
+    for (uint32_t x = (x0 & ~255u) + tid; x < x1; x += 256) {
+      if (x < x0) continue;
+      const float dx = float(int(x)) - cx;
+      const float distance = sqrtf(__builtin_fmaf(dx, dx, dy * dy));
+      const float f = SplineErf(__builtin_fmaf(distance, 0.5f, 0.353553391f) * inv_sigma) -
+                      SplineErf(__builtin_fmaf(distance, 0.5f, -0.353553391f) * inv_sigma);
+      const float local = s4i * (f * f);
+      float* p = P.planes + size_t(y) * P.stride + x;
+      for (int c = 0; c < 3; c++) p[c * P.plane_stride] = __builtin_fmaf(g[5 + c], local, p[c * P.plane_stride]);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_splines_add(SplineParams P) {
+  const uint32_t y = P.y_begin + blockIdx.x;
+  if (y < P.y_end) SplinesAddRow(P, y);
+}
+__global__ __launch_bounds__(256) void k_splines_add_batch(const SplineParams* ops) {
+  const SplineParams& P = ops[blockIdx.y];
+  const uint32_t y = P.y_begin + blockIdx.x;
+  if (y < P.y_end) SplinesAddRow(P, y);
+}
+
 }  // namespace jxlhip
 #endif  // JXL_HIP_FILTER_FUSED_H_

@@ -789,6 +789,10 @@ struct ModOutput {
   uint32_t stride[4];
   uint32_t num_color, has_alpha, bits, alpha_bits, w, h;
   PixelOut po;           // po.nc: 1 / 2 (grey, grey + alpha) or 3 / 4
+  // frames with splines: fmode 1 = only write the colour samples as floats to fplanes ([3][h][w]; the splines are then
+  // drawn over them), fmode 2 = take the colour from fplanes instead of the integer channels; 0 = neither
+  float* fplanes;
+  uint32_t fmode;
 };
 __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   const ModOutput& P = ops[blockIdx.z];
@@ -798,6 +802,12 @@ __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   const float mul = 1.0f / float((uint64_t(1) << P.bits) - 1);
   float v[4];
   for (uint32_t c = 0; c < P.num_color; c++) v[c] = float(P.ch[c][size_t(y) * P.stride[c] + x]) * mul;
+  if (P.fmode == 1) {
+    for (uint32_t c = 0; c < 3; c++) P.fplanes[(size_t(c) * P.h + y) * P.w + x] = v[c];
+    continue;
+  }
+  if (P.fmode == 2)
+    for (uint32_t c = 0; c < 3; c++) v[c] = P.fplanes[(size_t(c) * P.h + y) * P.w + x];
   const float a = P.has_alpha ? float(P.ch[P.num_color][size_t(y) * P.stride[P.num_color] + x]) * (1.0f / float((uint64_t(1) << P.alpha_bits) - 1)) : 1.0f;
   const uint32_t nc = P.po.nc, ncol = nc < 3 ? 1u : 3u;
   float s[4];

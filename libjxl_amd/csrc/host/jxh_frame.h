@@ -18,6 +18,7 @@
 #include "jxh_entropy.h"
 #include "jxh_headers.h"
 #include "jxh_modular.h"
+#include "jxh_splines.h"
 #include "jxh_vardct.h"
 
 namespace jxh {
@@ -76,6 +77,8 @@ struct FramePlan {
   // AC sections: for pass p, group g: index p * num_groups + g
   float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // noise synthesis (frame flag kNoise): strength LUT
   bool has_noise = false;
+  Splines splines;  // frame flag kSplines: dictionary + draw cache (jxh_splines.h)
+  bool has_splines = false;
   std::vector<uint64_t> section_offset;  // byte offset inside the codestream buffer handed to ParseFrame
   std::vector<uint32_t> section_size;
   // single-section frames: AC data starts mid-byte inside the one section
@@ -166,8 +169,8 @@ class FrameParser {
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(ih.extra.empty() || fh.upsampling == 1, "unsupported: extra channels of upsampled frames");
-    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kUseDcFrame)),
-              "unsupported: patches/splines/DC frames");
+    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kUseDcFrame)), "unsupported: patches/DC frames");
+    JXH_CHECK(!(fh.flags & FrameHeader::kSplines) || fh.upsampling == 1, "unsupported: splines on upsampled frames");
     JXH_CHECK(!(fh.flags & FrameHeader::kNoise) || fh.upsampling == 1, "unsupported: noise on upsampled frames");
     P.dim = MakeFrameDim(fh);
     const FrameDim& d = P.dim;
@@ -256,6 +259,10 @@ class FrameParser {
 
  private:
   void DcGlobal(BitReader& br, FramePlan* P) {
+    if (P->fh.flags & FrameHeader::kSplines) {  // dec_frame.cc:289-293
+      DecodeSplines(br, P->dim.xsize * P->dim.ysize, &P->splines);
+      P->has_splines = true;
+    }
     if (P->fh.flags & FrameHeader::kNoise) {  // dec_frame.cc:294-296, dec_noise.cc:154-164: eight 10-bit LUT points
       for (float& v : P->noise_lut) v = float(br.Read(10)) / 1024.0f;
       // (the reference skips the stage when every point is below 1e-3: noise.h:35-40)
@@ -280,6 +287,8 @@ class FrameParser {
       ytob_dc_ = int32_t(br.Read(8)) - 128;
     }
     P->color_scale = 1.0f / float(color_factor);
+    // dec_frame.cc:303-308: the draw cache uses the base colour correlation just read
+    if (P->has_splines) InitSplineDrawCache(&P->splines, P->dim.xsize, P->dim.ysize, P->base_corr_x, P->base_corr_b);
     P->inv_global_scale = 65536.0f / float(P->global_scale);
     P->x_dm = std::pow(1.25f, 2.0f - float(P->fh.x_qm_scale));
     P->b_dm = std::pow(1.25f, 2.0f - float(P->fh.b_qm_scale));

@@ -17,6 +17,7 @@
 #include "jxh_entropy.h"
 #include "jxh_headers.h"
 #include "jxh_modular.h"
+#include "jxh_splines.h"
 
 namespace jxh {
 
@@ -50,6 +51,8 @@ struct ModFramePlan {
   uint32_t num_color = 3, has_alpha = 0, alpha_bits = 8;
   std::vector<uint32_t> extra_buffer;    // per extra channel: the buffer that holds it after the inverse transforms
   size_t frame_end = 0;
+  Splines splines;  // frame flag kSplines: drawn over the colour channels before the sample conversion
+  bool has_splines = false;
 };
 
 class ModFrameParser {
@@ -70,8 +73,8 @@ class ModFrameParser {
     JXH_CHECK(!ih.xyb_encoded && !fh.ycbcr, "unsupported: XYB or YCbCr Modular frames");
     JXH_CHECK(fh.upsampling == 1 && !fh.custom_size && fh.num_passes == 1, "unsupported: upsampled / cropped / multi-pass Modular frames");
     for (uint32_t u : fh.ec_upsampling) JXH_CHECK(u == 1, "unsupported: upsampled extra channels");
-    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kSplines | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
-              "unsupported: patches/splines/noise/DC frames");
+    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
+              "unsupported: patches/noise/DC frames");
     JXH_CHECK(!ih.floating && ih.bits <= 16, "unsupported: float or > 16-bit samples");
     P.dim = MakeFrameDim(fh);
     const FrameDim& d = P.dim;
@@ -90,6 +93,12 @@ class ModFrameParser {
     P.trees.assign(1, MTree());
     P.codes.assign(1, EntropyCode());
     BitReader g(data_ + P.section_offset[0], P.section_size[0]);
+    if (fh.flags & FrameHeader::kSplines) {  // dec_frame.cc:289-308; a Modular frame has the default colour correlation (0, 1)
+      JXH_CHECK(!ih.gray, "unsupported: splines on grey images");
+      DecodeSplines(g, d.xsize * d.ysize, &P.splines);
+      InitSplineDrawCache(&P.splines, d.xsize, d.ysize, 0.0f, 1.0f);
+      P.has_splines = true;
+    }
     if (!g.ReadBool())
       for (int c = 0; c < 3; c++) ReadF16(g);
     bool have_global = false;

@@ -345,16 +345,17 @@ def test_decoder_output_color_profile_reaches_the_frame(built):
 
 def test_reference_wasm_demo_streams(built, tmp_path):
     """The two codestreams of the reference's tools/wasm_demo/jxl_decoder_test.js:25-40 (made by libjxl's jxl_from_tree).
-    splinesJxl: the reference asserts 320x320 (:63-64); its frame carries splines, which this path refuses -- after the
-    header events, with an error, never with wrong pixels. crossJxl: a 20x20 Modular frame (:117-131: 'px = 20 * 20')
+    splinesJxl: the reference asserts 320x320 (:63-64); a Modular frame whose content is one spline: the front-end plans it
+    with its draw cache (pixels: tests/test_splines.py). crossJxl: a 20x20 Modular frame (:117-131: 'px = 20 * 20')
     with a palette and an MA tree: the product's Modular front-end plans it."""
     import replay_util as R
     J = built
     splines = open(os.path.join(ROOT, "tests", "golden", "ref_wasm_splines.jxl"), "rb").read()
     rc, events, out, _ = R.run(splines, tmp_path, "u8", 3)
-    assert "BASIC_INFO 320x320" in out and events[:2] == ["BASIC_INFO", "COLOR_ENCODING"] and events[-1] == "ERROR" and rc == 1, out
-    with pytest.raises(J.JxlAmdError, match="unsupported"):
-        J.ModFrame(splines)
+    assert "BASIC_INFO 320x320" in out and events[:4] == ["BASIC_INFO", "COLOR_ENCODING", "FRAME", "NEED_IMAGE_OUT_BUFFER"], out
+    f = J.ModFrame(splines)
+    assert (f.info["xsize"], f.info["ysize"], f.info["num_color"]) == (320, 320, 3)
+    f.close()
     cross = open(os.path.join(ROOT, "tests", "golden", "ref_wasm_cross.jxl"), "rb").read()
     f = J.ModFrame(cross)
     assert (f.info["xsize"], f.info["ysize"], f.info["num_color"], f.info["bits"]) == (20, 20, 3, 8)

@@ -87,7 +87,14 @@ def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
         oriented = J.encode_lossless(img)
     finally:
         J.set_orientation(1)
-    streams = [J.encode_rgb8(img), J.encode_rgba8(np.dstack([img, img[..., 0]])), J.encode_random(264, 200, seed=3),
+    J.set_splines([dict(points=[(20, 30), (120, 90), (220, 40)], color=[[40] + [0] * 31, [300, 10] + [0] * 30, [0] * 32], sigma=[12] + [0] * 31),
+                   dict(points=[(50, 180), (150, 120)], color=[[0] * 32, [-200] + [0] * 31, [100] + [0] * 31], sigma=[6, 2] + [0] * 30)])
+    try:
+        with_splines = [J.encode_rgb8(img), J.encode_lossless(img)]
+    finally:
+        J.set_splines(None)
+    with_splines.append(open(os.path.join(ROOT, "tests", "golden", "ref_wasm_splines.jxl"), "rb").read())
+    streams = with_splines + [J.encode_rgb8(img), J.encode_rgba8(np.dstack([img, img[..., 0]])), J.encode_random(264, 200, seed=3),
                J.encode_rgb8(img, ac_code_mode=3, num_passes=2, custom_orders=1, custom_bctx=1, noise=50), J.encode_rgb8(img, upsampling=2),
                J.encode_lossless(img, J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP),
                J.encode_lossless(np.dstack([img, img[..., 1]]), J.LOSSLESS_RCT), J.encode_animation(frames, [1, 2]),
