@@ -27,6 +27,18 @@ int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, si
                           void* runner_opaque, JxlAmdFrame** frame);
 /* Byte offset just behind the frame, and its animation fields {duration in ticks, is_last, timecode}. */
 size_t jxlamd_frame_end(const JxlAmdFrame* frame, uint32_t* duration_last_timecode);
+/* Where a frame sits on the canvas and how it combines with the reference slots (frame_header.h: FrameOrigin,
+ * BlendingInfo, save_as_reference; blending.cc): what a caller needs to compose frames on a JxlHipCanvas. */
+typedef struct {
+  int32_t x0, y0;
+  uint32_t xsize, ysize;
+  uint32_t custom_size;
+  uint32_t mode, alpha_mode, source, alpha_source, clamp, alpha_clamp;
+  uint32_t duration, is_last, save_as_reference, save_before_color_transform;
+} JxlAmdFramePlacement;
+void jxlamd_frame_placement(const JxlAmdFrame* frame, JxlAmdFramePlacement* placement);
+/* The frame's position among the shown / invisible frames (seeds its noise: dec_frame.cc:160-168); before upload. */
+void jxlamd_frame_set_indices(JxlAmdFrame* frame, uint32_t visible_index, uint32_t nonvisible_index);
 void jxlamd_frame_free(JxlAmdFrame* frame);
 /* info[0..15]: xsize, ysize, xsize_blocks, ysize_blocks, num_groups, num_dc_groups, num_passes, used_acs mask,
  * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes, then of pass 0: log2 alphabet size,
@@ -56,6 +68,7 @@ int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** fra
 /* As jxlamd_frame_parse_at / jxlamd_frame_end, for Modular frames. */
 int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlAmdModFrame** frame);
 size_t jxlamd_modframe_end(const JxlAmdModFrame* frame, uint32_t* duration_last_timecode);
+void jxlamd_modframe_placement(const JxlAmdModFrame* frame, JxlAmdFramePlacement* placement);
 void jxlamd_modframe_free(JxlAmdModFrame* frame);
 /* info[0..9]: xsize, ysize, colour channels, has alpha, bits per sample, streams, channel buffers, transform operations,
  * extra channels, compressed bytes of all sections. */

@@ -332,6 +332,30 @@ int jxlhip_modular_status(JxlHipContext* ctx, uint32_t* status, uint32_t* end_bi
 /* Test access: a channel buffer's int32 samples (w * h) after the run; synchronous. */
 int jxlhip_modular_download_buffer(JxlHipContext* ctx, uint32_t buffer, int32_t* dst, size_t n);
 
+/* ---- Canvas: the frames of a multi-frame codestream composed on the device (lib/jxl/blending.cc, alpha.cc,
+ * render_pipeline/stage_blending.cc; dec_cache.cc:268-290 for where it sits: after the colour conversion, in the output
+ * colour space). A frame is decoded by a context into f32 x 4 pixels (jxlhip_set_output_format(ctx, 0, 4, 0, 0), no
+ * orientation), blended into the canvas with the reference slot its header names, optionally kept in a slot, and the
+ * canvas is what jxlhip_canvas_download converts to the caller's format. */
+typedef struct JxlHipCanvas JxlHipCanvas;
+int jxlhip_canvas_create(int device, uint32_t xsize, uint32_t ysize, uint32_t has_alpha, uint32_t alpha_premultiplied, JxlHipCanvas** canvas);
+void jxlhip_canvas_destroy(JxlHipCanvas* canvas);
+typedef struct JxlHipBlend {
+  int32_t x0, y0;             /* FrameOrigin: where the frame's top-left sample sits on the canvas (may be outside) */
+  uint32_t mode, alpha_mode;  /* BlendMode of colour / alpha: 0 replace, 1 add, 2 blend, 3 alpha-weighted add, 4 multiply */
+  uint32_t source, alpha_source; /* reference slots 0..3 the backgrounds come from (never written: zeros) */
+  uint32_t clamp, alpha_clamp;
+  int32_t save_slot;          /* 0..3: the blended canvas is also kept in this slot; -1: not kept */
+} JxlHipBlend;
+/* Blends the pixels `frame` holds (its last run, f32 x 4) into the canvas. */
+int jxlhip_canvas_blend(JxlHipCanvas* canvas, JxlHipContext* frame, const JxlHipBlend* blend);
+/* The canvas in a sample format (as jxlhip_set_output_format) and orientation (as jxlhip_set_output_orientation), into
+ * host memory; rows of `stride` bytes. Synchronous. */
+int jxlhip_canvas_download(JxlHipCanvas* canvas, uint32_t data_type, uint32_t num_channels, uint32_t bits_per_sample, int big_endian,
+                           uint32_t orientation, void* dst, size_t stride);
+/* The canvas alpha plane as floats (xsize * ysize, not oriented). Synchronous. */
+int jxlhip_canvas_download_alpha(JxlHipCanvas* canvas, float* dst, size_t n);
+
 /* ---- Forward path (first slice): the pixel-domain half of a VarDCT encode on the device.
  * Replaces, behind lib/jxl/enc_frame.cc:1135-1166's per-group loop: SRGBToXYB (enc_xyb.cc:152-174), the Gaborish
  * sharpening (enc_gaborish.cc:21-70) and ComputeCoefficients (enc_group.cc:380-533: forward transform, DC from the

@@ -505,6 +505,41 @@ def encode_animation(frames, durations, tps=(10, 1), num_loops=0, lossless=False
     return out
 
 
+def encode_layers(layers, tps=None, num_loops=0, lossless=False, **kw):
+    """Test aid: a codestream of several frames composed on a canvas (blending.cc): layers[i] is a dict with img (HxWx3 or
+    HxWx4 uint8; layers[0] covers the whole canvas at the origin and gives its size) and optionally x0, y0 (crop origin),
+    mode / alpha_mode (BlendMode of colour / alpha: 0 replace, 1 add, 2 blend, 3 alpha-weighted add, 4 multiply), source /
+    alpha_source (reference slots), clamp, save_as (slot the blended canvas is kept in) and duration. tps = (numerator,
+    denominator) makes it an animation (frames with duration > 0 are shown); tps = None a layered still (only the last
+    frame is shown)."""
+    E = _enc_lib()
+    E.jxlenc_set_animation.argtypes = [ctypes.c_int] + [ctypes.c_uint32] * 4 + [ctypes.c_int]
+    E.jxlenc_set_animation.restype = None
+    E.jxlenc_set_layer.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_uint32] * 8 + [ctypes.c_int]
+    E.jxlenc_set_layer.restype = None
+    E.jxlenc_last_header_bytes.restype = ctypes.c_size_t
+    ch, cw = layers[0]["img"].shape[:2]
+    out = b""
+    try:
+        for i, L in enumerate(layers):
+            img = L["img"]
+            E.jxlenc_set_animation(1, tps[0] if tps else 10, tps[1] if tps else 1, num_loops, L.get("duration", 0),
+                                   1 if i == len(layers) - 1 else 0)
+            E.jxlenc_set_layer(1, L.get("x0", 0), L.get("y0", 0), cw, ch, L.get("mode", 0), L.get("alpha_mode", 0), L.get("source", 0),
+                               L.get("alpha_source", L.get("source", 0)), L.get("clamp", 0), L.get("save_as", 0), 1 if tps else 0)
+            if lossless:
+                d = encode_lossless(img, **kw)
+            elif img.shape[2] == 4:
+                d = encode_rgba8(img, **kw)
+            else:
+                d = encode_rgb8(img, **kw)
+            out += d if i == 0 else d[E.jxlenc_last_header_bytes():]
+    finally:
+        E.jxlenc_set_layer(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1)
+        E.jxlenc_set_animation(0, 10, 1, 0, 0, 1)
+    return out
+
+
 def synth_image(xsize, ysize, seed=177):
     """Deterministic synthetic RGB8 test image (gradient background, rectangles, discs, texture, noise)."""
     a = np.zeros((ysize, xsize, 3), np.uint8)

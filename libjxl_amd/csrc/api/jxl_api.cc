@@ -100,6 +100,37 @@ int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, si
   return 0;
 }
 
+static void FillPlacement(const jxh::ImageHeader& ih, const jxh::FrameHeader& fh, size_t xs, size_t ys, JxlAmdFramePlacement* p) {
+  memset(p, 0, sizeof(*p));
+  p->x0 = fh.x0;
+  p->y0 = fh.y0;
+  p->xsize = uint32_t(xs);
+  p->ysize = uint32_t(ys);
+  p->custom_size = fh.custom_size;
+  p->mode = fh.blend.mode;
+  p->source = fh.blend.source;
+  p->clamp = fh.blend.clamp;
+  if (!ih.extra.empty() && !fh.ec_blend.empty()) {
+    p->alpha_mode = fh.ec_blend[0].mode;
+    p->alpha_source = fh.ec_blend[0].source;
+    p->alpha_clamp = fh.ec_blend[0].clamp;
+  }
+  p->duration = fh.duration;
+  p->is_last = fh.is_last;
+  p->save_as_reference = fh.save_as_reference;
+  p->save_before_color_transform = fh.save_before_color_transform;
+}
+void jxlamd_frame_placement(const JxlAmdFrame* f, JxlAmdFramePlacement* p) {
+  FillPlacement(f->plan.ih, f->plan.fh, f->plan.dim.xsize * f->plan.fh.upsampling, f->plan.dim.ysize * f->plan.fh.upsampling, p);
+  if (f->plan.fh.upsampling != 1) {
+    p->xsize = uint32_t(f->plan.ih.xsize);
+    p->ysize = uint32_t(f->plan.ih.ysize);
+  }
+}
+void jxlamd_frame_set_indices(JxlAmdFrame* f, uint32_t visible_index, uint32_t nonvisible_index) {
+  f->plan.frame_index = visible_index;
+  f->plan.nonvisible_index = nonvisible_index;
+}
 void jxlamd_frame_free(JxlAmdFrame* f) { delete f; }
 size_t jxlamd_frame_end(const JxlAmdFrame* f, uint32_t* t) {
   if (t) {
@@ -261,7 +292,7 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   memcpy(d.noise_lut, P.noise_lut, sizeof(d.noise_lut));
   // dec_frame.cc:160-168: the number of visible frames before this one, and of invisible ones since (none are accepted)
   d.noise_frame_index[0] = uint32_t(P.frame_index);
-  d.noise_frame_index[1] = 0;
+  d.noise_frame_index[1] = uint32_t(P.nonvisible_index);
   std::vector<float> ups_kernel;
   if (P.fh.upsampling != 1) {
     UpsamplingKernels(P.fh.upsampling, &ups_kernel);
@@ -331,6 +362,9 @@ int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos,
   f->data = data;
   *out = f.release();
   return 0;
+}
+void jxlamd_modframe_placement(const JxlAmdModFrame* f, JxlAmdFramePlacement* p) {
+  FillPlacement(f->plan.ih, f->plan.fh, f->plan.dim.xsize, f->plan.dim.ysize, p);
 }
 void jxlamd_modframe_free(JxlAmdModFrame* f) { delete f; }
 size_t jxlamd_modframe_end(const JxlAmdModFrame* f, uint32_t* t) {
@@ -573,6 +607,10 @@ struct JxlDecoderStruct {
   bool have_ih = false;
   size_t frame_pos = 0, frame_index = 0;  // where the current frame starts in `cs` (0 = behind the image header), its number
   size_t skip_frames = 0;                 // JxlDecoderSkipFrames
+  // frames composed on a canvas (several frames, crops, blending): jxlhip_canvas_*; shown / invisible frame counters
+  JxlHipCanvas* canvas = nullptr;
+  bool canvas_mode = false, frame_shown = true, frame_skipped = false;
+  size_t visible_index = 0, nonvisible_index = 0;
   JxlAmdFrame* frame = nullptr;        // a VarDCT frame ...
   JxlAmdModFrame* mframe = nullptr;    // ... or a Modular (lossless) one
   JxlHipContext* ctx = nullptr;
@@ -649,6 +687,12 @@ void ResetState(JxlDecoder* d) {
   d->cs_complete = false;
   d->stage = 0;
   d->frame_pos = d->frame_index = d->skip_frames = 0;
+  if (d->canvas) jxlhip_canvas_destroy(d->canvas);
+  d->canvas = nullptr;
+  d->canvas_mode = false;
+  d->frame_shown = true;
+  d->frame_skipped = false;
+  d->visible_index = d->nonvisible_index = 0;
   d->error = false;
   d->have_ih = false;
   d->have_out = false;
@@ -925,13 +969,16 @@ JxlDecoderStatus DeliverPixels(JxlDecoder* d, const OutFormat& of, size_t xs, si
 }
 
 // A Modular (lossless) frame: every stream, the inverse transforms and the sample conversion run on the device.
-JxlDecoderStatus DecodeModularPixels(JxlDecoder* d) {
-  const OutFormat of = MapFormat(d, d->fmt);
+JxlDecoderStatus BlendIntoCanvas(JxlDecoder* d);
+const OutFormat kCanvasFormat = {0, 4, 0, 0};  // what a frame headed for the canvas is decoded into: f32 x 4, as coded
+
+JxlDecoderStatus DecodeModularPixels(JxlDecoder* d, bool to_canvas) {
+  const OutFormat of = to_canvas ? kCanvasFormat : MapFormat(d, d->fmt);
   if ((of.nc == 2 || of.nc == 4) && d->unpremul)
     for (const auto& e : d->ih.extra)
       if (e.type == 0 && e.alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
-  if (!r) r = jxlhip_set_output_orientation(d->ctx, UndoOrientation(d));
+  if (!r) r = jxlhip_set_output_orientation(d->ctx, to_canvas ? 1 : UndoOrientation(d));
   if (!r) r = jxlamd_modframe_upload(d->mframe, d->ctx);
   if (!r) r = jxlhip_modular_run(d->ctx);
   uint32_t info[16];
@@ -939,6 +986,7 @@ JxlDecoderStatus DecodeModularPixels(JxlDecoder* d) {
   std::vector<uint32_t> status(info[5] + 1);
   if (!r) r = jxlhip_modular_status(d->ctx, status.data(), nullptr, status.size());
   if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ") " + g_last_error);
+  if (to_canvas) return BlendIntoCanvas(d);
   const uint32_t orientation = UndoOrientation(d);
   const size_t xs = orientation > 4 ? info[1] : info[0], ys = orientation > 4 ? info[0] : info[1];
   for (const auto& eo : d->extra_out) {
@@ -957,16 +1005,17 @@ JxlDecoderStatus DecodeModularPixels(JxlDecoder* d) {
   return DeliverPixels(d, of, xs, ys);
 }
 
-JxlDecoderStatus DecodePixels(JxlDecoder* d) {
+JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
   if (!d->ctx) {
     if (jxlhip_device_count() <= 0) return Fail(d, "no HIP device: libjxl_amd has no CPU decode path");
     const char* dev = getenv("JXLHIP_DEVICE");
     int r = jxlhip_ctx_create(dev ? atoi(dev) : 0, &d->ctx);
     if (r) return Fail(d, "jxlhip_ctx_create failed (" + std::to_string(r) + ")");
   }
-  if (d->mframe) return DecodeModularPixels(d);
+  if (d->mframe) return DecodeModularPixels(d, to_canvas);
   const jxh::FramePlan& P = d->frame->plan;
-  const OutFormat of = MapFormat(d, d->fmt);
+  const OutFormat of = to_canvas ? kCanvasFormat : MapFormat(d, d->fmt);
+  jxlamd_frame_set_indices(d->frame, uint32_t(d->visible_index), uint32_t(d->nonvisible_index));
   int alpha_ec = -1;
   for (size_t e = 0; e < d->ih.extra.size(); e++)
     if (d->ih.extra[e].type == 0) {
@@ -976,7 +1025,8 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   const bool want_alpha = (of.nc == 2 || of.nc == 4) && alpha_ec >= 0;
   if (want_alpha && d->unpremul && d->ih.extra[alpha_ec].alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
   jxlamd_frame_set_linear_output(d->frame, d->want_linear >= 0 ? d->want_linear : (P.ih.linear_tf ? 1 : 0));
-  const uint32_t orientation = UndoOrientation(d);
+  const uint32_t orientation = to_canvas ? 1 : UndoOrientation(d);
+  if (to_canvas && d->want_linear >= 0 && d->want_linear != (P.ih.linear_tf ? 1 : 0)) return Fail(d, "unsupported: blending with a changed transfer function");
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
   if (!r) r = jxlhip_set_output_orientation(d->ctx, orientation);
   if (!r) r = jxlhip_set_alpha(d->ctx, nullptr, 0, 0);
@@ -985,7 +1035,7 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   std::vector<uint32_t> flags(P.dim.num_groups);
   if (!r) r = jxlhip_get_errors(d->ctx, flags.data(), flags.size());
   if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
-  const bool need_extra = want_alpha || !d->extra_out.empty();
+  const bool need_extra = want_alpha || (!to_canvas && !d->extra_out.empty());
   if (need_extra && jxlamd_frame_extra_pending(d->frame)) {
     r = jxlamd_frame_finish_extra(d->frame, d->ctx);
     if (r) return Fail(d, "extra channels: " + g_last_error);
@@ -1005,6 +1055,7 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   r = jxlhip_run_transform(d->ctx);
   if (!r) r = jxlhip_run_filter_color(d->ctx);
   if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
+  if (to_canvas) return BlendIntoCanvas(d);
   const size_t coded_xs = xs, coded_ys = ys;
   if (orientation > 4) std::swap(xs, ys);
   for (const auto& eo : d->extra_out) {
@@ -1026,6 +1077,90 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d) {
   return DeliverPixels(d, of, xs, ys);
 }
 
+void Placement(const JxlDecoder* d, JxlAmdFramePlacement* p) {
+  if (d->frame) jxlamd_frame_placement(d->frame, p);
+  else jxlamd_modframe_placement(d->mframe, p);
+}
+// frame_header.h:373-379
+bool CanBeReferenced(const JxlAmdFramePlacement& p) { return !p.is_last && (p.duration == 0 || p.save_as_reference != 0); }
+// blending.cc:22-40 NeedsBlending, plus: anything another frame may later be blended with
+bool NeedsCanvas(const JxlAmdFramePlacement& p) { return p.custom_size || p.mode != 0 || p.alpha_mode != 0 || !p.is_last; }
+
+// The frame the context just decoded (f32 x 4) goes onto the canvas: blending.cc / stage_blending.cc on the device.
+JxlDecoderStatus BlendIntoCanvas(JxlDecoder* d) {
+  JxlAmdFramePlacement p;
+  Placement(d, &p);
+  const bool has_alpha = !d->ih.extra.empty() && d->ih.extra[0].type == 0;
+  if (d->ih.extra.size() > 1 || (!d->ih.extra.empty() && !has_alpha)) return Fail(d, "unsupported: blending with extra channels other than alpha");
+  if (CanBeReferenced(p) && p.save_before_color_transform) return Fail(d, "unsupported: frames saved before the colour transform");
+  int r = 0;
+  if (!d->canvas) {
+    const char* dev = getenv("JXLHIP_DEVICE");
+    r = jxlhip_canvas_create(dev ? atoi(dev) : 0, uint32_t(d->ih.xsize), uint32_t(d->ih.ysize), has_alpha ? 1 : 0,
+                             has_alpha && d->ih.extra[0].alpha_associated ? 1 : 0, &d->canvas);
+    if (r) return Fail(d, "jxlhip_canvas_create failed (" + std::to_string(r) + ")");
+  }
+  JxlHipBlend b;
+  memset(&b, 0, sizeof(b));
+  b.x0 = p.x0;
+  b.y0 = p.y0;
+  b.mode = p.mode;
+  b.alpha_mode = p.alpha_mode;
+  b.source = p.source;
+  b.alpha_source = p.alpha_source;
+  b.clamp = p.clamp;
+  b.alpha_clamp = p.alpha_clamp;
+  b.save_slot = CanBeReferenced(p) ? int32_t(p.save_as_reference) : -1;
+  r = jxlhip_canvas_blend(d->canvas, d->ctx, &b);
+  if (r) return Fail(d, "jxlhip_canvas_blend failed (" + std::to_string(r) + ")");
+  return JXL_DEC_SUCCESS;
+}
+
+// The canvas in the caller's format: what DeliverPixels does for a frame decoded straight into that format.
+JxlDecoderStatus DeliverCanvas(JxlDecoder* d) {
+  const OutFormat of = MapFormat(d, d->fmt);
+  if ((of.nc == 2 || of.nc == 4) && d->unpremul)
+    for (const auto& e : d->ih.extra)
+      if (e.type == 0 && e.alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
+  const uint32_t orientation = UndoOrientation(d);
+  const size_t xs = OrientedXsize(d), ys = OrientedYsize(d);
+  const size_t bpp = of.nc * SampleBytes(d->fmt.data_type);
+  for (const auto& eo : d->extra_out) {  // the alpha plane of the canvas, as the integers its bit depth gives
+    if (eo.first != 0 || d->ih.extra.empty() || d->ih.extra[0].type != 0) return Fail(d, "extra channel unavailable");
+    std::vector<float> a(size_t(d->ih.xsize) * d->ih.ysize);
+    if (jxlhip_canvas_download_alpha(d->canvas, a.data(), a.size())) return Fail(d, "download failed");
+    const uint32_t ch_bits = d->ih.extra[0].bits;
+    const float mul = float((uint64_t(1) << ch_bits) - 1);
+    std::vector<int32_t> plane(a.size());
+    for (size_t i = 0; i < a.size(); i++) plane[i] = int32_t(std::nearbyint(std::min(1.0f, std::max(0.0f, a[i])) * mul));
+    if (orientation != 1) plane = OrientPlane(plane.data(), d->ih.xsize, d->ih.ysize, orientation);
+    const JxlPixelFormat& f = eo.second.fmt;
+    uint32_t bits = f.data_type == JXL_TYPE_UINT8 ? 8 : 16;
+    if (d->bit_depth.type == JXL_BIT_DEPTH_FROM_CODESTREAM) bits = std::min(bits, ch_bits);
+    else if (d->bit_depth.type == JXL_BIT_DEPTH_CUSTOM) bits = d->bit_depth.bits_per_sample;
+    const size_t stride = RowStride(f, xs);
+    for (size_t y = 0; y < ys; y++) StoreExtraRow(plane.data() + y * xs, xs, ch_bits, f, bits, static_cast<uint8_t*>(eo.second.buf) + y * stride);
+  }
+  if (d->out_buf) {
+    if (jxlhip_canvas_download(d->canvas, of.type, of.nc, of.bits, of.big_endian, orientation, d->out_buf, RowStride(d->fmt, xs)))
+      return Fail(d, "download failed");
+  } else {
+    std::vector<uint8_t> px(xs * ys * bpp);
+    if (jxlhip_canvas_download(d->canvas, of.type, of.nc, of.bits, of.big_endian, orientation, px.data(), xs * bpp)) return Fail(d, "download failed");
+    void* run_opaque = nullptr;
+    if (d->mt_run) {
+      run_opaque = d->mt_init(d->mt_init_opaque, 1, xs);
+      if (!run_opaque) return Fail(d, "image out init callback failed");
+    }
+    for (size_t y = 0; y < ys; y++) {
+      if (d->mt_run) d->mt_run(run_opaque, 0, 0, y, xs, px.data() + y * xs * bpp);
+      else d->callback(d->callback_opaque, 0, y, xs, px.data() + y * xs * bpp);
+    }
+    if (d->mt_run && d->mt_destroy) d->mt_destroy(run_opaque);
+  }
+  return JXL_DEC_FULL_IMAGE;
+}
+
 // Drops the current frame and moves to the one behind it; false (stage 6) when it was the last.
 bool NextFrame(JxlDecoder* d) {
   uint32_t t[3];
@@ -1033,6 +1168,12 @@ bool NextFrame(JxlDecoder* d) {
   if (t[1]) {
     d->stage = 6;
     return false;
+  }
+  if (d->frame_shown) {  // dec_frame.cc:160-168
+    d->visible_index++;
+    d->nonvisible_index = 0;
+  } else {
+    d->nonvisible_index++;
   }
   if (d->frame) jxlamd_frame_free(d->frame);
   if (d->mframe) jxlamd_modframe_free(d->mframe);
@@ -1087,8 +1228,24 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
         return 2;
       }
       d->stage = 3;
-      if (d->skip_frames > 0) {  // decode.cc:1359-1408: nothing can reference a frame accepted here, so skipping drops it whole
-        d->skip_frames--;
+      JxlAmdFramePlacement pl;
+      Placement(d, &pl);
+      d->frame_shown = pl.is_last || pl.duration > 0;  // decode.cc:1346-1350 is_last_of_still (coalescing)
+      if (NeedsCanvas(pl)) d->canvas_mode = true;
+      d->frame_skipped = false;
+      if (d->skip_frames > 0) {  // decode.cc:1359-1408
+        d->frame_skipped = true;
+        if (d->frame_shown) d->skip_frames--;
+      }
+      if (!d->frame_shown || d->frame_skipped) {
+        // no events for it; its pixels are still needed when a later frame may be blended with them
+        if (d->canvas_mode && CanBeReferenced(pl) && (d->events & JXL_DEC_FULL_IMAGE)) {
+          const JxlDecoderStatus st = DecodePixels(d, true);
+          if (st != JXL_DEC_SUCCESS) {
+            *ev = st;
+            return 2;
+          }
+        }
         if (!NextFrame(d)) return 1;
         continue;
       }
@@ -1109,7 +1266,12 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
         *ev = JXL_DEC_NEED_IMAGE_OUT_BUFFER;
         return 2;
       }
-      *ev = DecodePixels(d);
+      if (d->canvas_mode) {
+        *ev = DecodePixels(d, true);
+        if (*ev == JXL_DEC_SUCCESS) *ev = DeliverCanvas(d);
+      } else {
+        *ev = DecodePixels(d, false);
+      }
       if (*ev == JXL_DEC_FULL_IMAGE) d->stage = 5;
       return 2;
     }

@@ -748,13 +748,52 @@ static uint32_t g_orientation = 1;
 // AnimationHeader; each frame header carries `duration` ticks and `is_last`). A whole animation is the first frame's
 // stream followed by the frame parts (from jxlenc_last_header_bytes() on) of the others.
 struct AnimationState {
-  bool enabled = false;
+  bool enabled = false;  // multi-frame mode: is_last is coded from here
+  bool timed = true;     // ... with an AnimationHeader and per-frame durations (false: a layered still)
   uint32_t tps_num = 10, tps_den = 1, loops = 0, duration = 1;
   bool is_last = true;
 };
 static AnimationState g_anim;
+// jxlenc_set_layer: how the next frame sits on the canvas (frame_header.cc:303-370): crop origin, the canvas size (to
+// know whether the frame covers it), BlendingInfo of the colour channels and of the alpha channel, the slot it is kept in.
+struct LayerState {
+  bool enabled = false;
+  int32_t x0 = 0, y0 = 0;
+  uint32_t canvas_w = 0, canvas_h = 0;
+  uint32_t mode = 0, alpha_mode = 0, source = 0, alpha_source = 0, clamp = 0, save_as = 0;
+};
+static LayerState g_layer;
+// Crop + blending fields of a frame header for a frame of fw x fh pixels; returns whether a save_before_color_transform
+// bit follows the timing fields (frame_header.cc:396-408).
+static bool WriteCropAndBlending(BitWriter& bw, uint32_t fw, uint32_t fh, bool have_alpha) {
+  const LayerState& L = g_layer;
+  static const uint32_t db[4] = {8, 11, 14, 30}, dof[4] = {0, 256, 2304, 18688};
+  bool partial = false;
+  if (!L.enabled) {
+    bw.Write(1, 0);  // no custom size/origin
+  } else {
+    bw.Write(1, 1);
+    auto pack = [](int32_t v) { return v >= 0 ? uint32_t(v) * 2 : uint32_t(-(v + 1)) * 2 + 1; };
+    WriteU32Sel(bw, pack(L.x0), db, dof);
+    WriteU32Sel(bw, pack(L.y0), db, dof);
+    WriteU32Sel(bw, fw, db, dof);
+    WriteU32Sel(bw, fh, db, dof);
+    partial = L.x0 > 0 || L.y0 > 0 || int64_t(fw) + L.x0 < int64_t(L.canvas_w) || int64_t(fh) + L.y0 < int64_t(L.canvas_h);
+  }
+  auto info = [&](uint32_t mode, uint32_t source) {
+    static const uint32_t mb[4] = {0, 0, 0, 2}, mo[4] = {0, 1, 2, 3};
+    WriteU32Sel(bw, mode, mb, mo);
+    const bool alpha_modes = have_alpha && (mode == 2 || mode == 3);
+    if (alpha_modes) bw.Write(2, 0);  // alpha_channel 0
+    if (alpha_modes || mode == 4) bw.Write(1, L.clamp ? 1 : 0);
+    if (mode != 0 || partial) bw.Write(2, source);
+  };
+  info(L.enabled ? L.mode : 0, L.source);
+  if (have_alpha) info(L.enabled ? L.alpha_mode : 0, L.alpha_source);
+  return (!L.enabled || L.mode == 0) && !partial;
+}
 static size_t g_last_header_bytes = 0;  // where the frame header of the last written stream starts
-static bool ExtraFields() { return g_orientation != 1 || g_anim.enabled; }
+static bool ExtraFields() { return g_orientation != 1 || (g_anim.enabled && g_anim.timed); }
 // image_metadata.cc:283-300: extra_fields = orientation, no intrinsic size, no preview, animation (:235-250).
 static void WriteExtraFields(BitWriter& bw) {
   if (!ExtraFields()) {
@@ -764,8 +803,8 @@ static void WriteExtraFields(BitWriter& bw) {
   bw.Write(1, 1);
   bw.Write(3, g_orientation - 1);
   bw.Write(2, 0);  // no intrinsic size, no preview
-  bw.Write(1, g_anim.enabled ? 1 : 0);
-  if (g_anim.enabled) {
+  bw.Write(1, g_anim.enabled && g_anim.timed ? 1 : 0);
+  if (g_anim.enabled && g_anim.timed) {
     static const uint32_t nb[4] = {0, 0, 10, 30}, no[4] = {100, 1000, 1, 1};
     static const uint32_t db[4] = {0, 0, 8, 10}, dof[4] = {1, 1001, 1, 1};
     static const uint32_t lb[4] = {0, 3, 16, 32}, lo[4] = {0, 0, 0, 0};
@@ -781,14 +820,18 @@ static void WriteToneMapping(BitWriter& bw) {
 }
 // frame_header.cc:130-150, 372-399: the animation fields of a frame header, is_last, and (not last) save_as_reference 0.
 // A frame with a duration and no reference slot cannot be referenced: no save_before_color_transform bit follows.
-static void WriteFrameTiming(BitWriter& bw) {
-  if (g_anim.enabled) {
+static void WriteFrameTiming(BitWriter& bw, bool replace_whole_canvas = true) {
+  const bool timed = g_anim.enabled && g_anim.timed;
+  if (timed) {
     static const uint32_t b[4] = {0, 0, 8, 32}, o[4] = {0, 1, 0, 0};
     WriteU32Sel(bw, g_anim.duration, b, o);
   }
   const bool last = !g_anim.enabled || g_anim.is_last;
+  const uint32_t duration = timed ? g_anim.duration : 0, save_as = g_layer.enabled ? g_layer.save_as : 0;
   bw.Write(1, last ? 1 : 0);
-  if (!last) bw.Write(2, 0);  // save_as_reference 0
+  if (!last) bw.Write(2, save_as);  // save_as_reference
+  // CanBeReferenced (frame_header.h:373-379) and a full-canvas replace: save_before_color_transform = false
+  if (!last && (duration == 0 || save_as != 0) && replace_whole_canvas) bw.Write(1, 0);
 }
 // jxlenc_set_splines: the quantised spline dictionary the next streams carry (frame flag kSplines), flat:
 // [quantisation adjustment, number of splines, then per spline: start x, start y, number of further control points,
@@ -1322,10 +1365,8 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(2, 0);  // no downsampling brackets
     bw.Write(2, 1);  // shift of pass 0 = 1 (the last pass always has shift 0)
   }
-  bw.Write(1, 0);  // no custom size/origin
-  bw.Write(2, 0);  // blend mode: replace
-  if (have_alpha) bw.Write(2, 0);  // the extra channel's blend mode: replace
-  WriteFrameTiming(bw);
+  const bool whole = WriteCropAndBlending(bw, uint32_t(f.xs), uint32_t(f.ys), have_alpha);
+  WriteFrameTiming(bw, whole);
   bw.Write(2, 0);  // no name
   bw.Write(1, 0);  // loop filter not all_default
   bw.Write(1, f.gab ? 1 : 0);
@@ -2243,10 +2284,8 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   if (alpha) bw.Write(2, 0);
   bw.Write(2, 1);  // group_size_shift 1 (256)
   bw.Write(2, 0);  // one pass
-  bw.Write(1, 0);  // no custom size
-  bw.Write(2, 0);  // blend mode replace
-  if (alpha) bw.Write(2, 0);
-  WriteFrameTiming(bw);
+  const bool whole = WriteCropAndBlending(bw, uint32_t(xs), uint32_t(ys), alpha);
+  WriteFrameTiming(bw, whole);
   bw.Write(2, 0);  // no name
   bw.Write(1, 0);  // loop filter not all_default
   bw.Write(1, 0);  // no gaborish
@@ -2307,6 +2346,25 @@ void jxlenc_set_animation(int enabled, uint32_t tps_numerator, uint32_t tps_deno
   jxe::g_anim.loops = num_loops;
   jxe::g_anim.duration = duration;
   jxe::g_anim.is_last = is_last != 0;
+}
+// How the next frame sits on the canvas (enabled = 0: a plain full frame again): crop origin, canvas size, BlendMode of
+// colour and of alpha (0 replace, 1 add, 2 blend, 3 alpha-weighted add, 4 multiply), their reference slots, the clamp
+// flag, the slot the blended canvas is saved in. `timed` = 0 turns the multi-frame mode of jxlenc_set_animation into a
+// layered still (no animation header, no durations). Test aid, not thread-safe.
+void jxlenc_set_layer(int enabled, int32_t x0, int32_t y0, uint32_t canvas_w, uint32_t canvas_h, uint32_t mode, uint32_t alpha_mode,
+                      uint32_t source, uint32_t alpha_source, uint32_t clamp, uint32_t save_as, int timed) {
+  jxe::g_layer.enabled = enabled != 0;
+  jxe::g_layer.x0 = x0;
+  jxe::g_layer.y0 = y0;
+  jxe::g_layer.canvas_w = canvas_w;
+  jxe::g_layer.canvas_h = canvas_h;
+  jxe::g_layer.mode = mode;
+  jxe::g_layer.alpha_mode = alpha_mode;
+  jxe::g_layer.source = source;
+  jxe::g_layer.alpha_source = alpha_source;
+  jxe::g_layer.clamp = clamp;
+  jxe::g_layer.save_as = save_as;
+  jxe::g_anim.timed = timed != 0;
 }
 // Byte offset of the frame header in the stream written last (signature + image header come before it).
 size_t jxlenc_last_header_bytes(void) { return jxe::g_last_header_bytes; }

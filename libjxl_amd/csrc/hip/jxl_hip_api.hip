@@ -22,6 +22,7 @@
 #include "jxl_hip_filter_fused.h"
 #include "jxl_hip_modular.h"
 #include "jxl_hip_enc.h"
+#include "jxl_hip_canvas.h"
 
 namespace {
 #include "../host/afv_basis.inc"
@@ -2707,6 +2708,127 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
         }
       }
   }
+  return 0;
+}
+
+// ---- canvas (jxl_hip_canvas.h)
+struct JxlHipCanvas {
+  int device = 0;
+  uint32_t xs = 0, ys = 0;
+  bool has_alpha = false, premultiplied = false;
+  Buf cur, slot[4], pixels;
+  bool slot_valid[4] = {false, false, false, false};
+  hipStream_t last_stream = nullptr;  // the stream of the last blend: later work on the canvas is ordered behind it
+};
+
+int jxlhip_canvas_create(int device, uint32_t xsize, uint32_t ysize, uint32_t has_alpha, uint32_t premultiplied, JxlHipCanvas** out) {
+  if (!out || !xsize || !ysize || xsize > (1u << 18) || ysize > (1u << 18)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  JxlHipCanvas* v = new (std::nothrow) JxlHipCanvas;
+  if (!v) return JXLHIP_ERR_INVALID_ARGUMENT;
+  v->device = device;
+  v->xs = xsize;
+  v->ys = ysize;
+  v->has_alpha = has_alpha != 0;
+  v->premultiplied = premultiplied != 0;
+  int r = v->cur.Ensure(size_t(xsize) * ysize * 16);
+  if (r) {
+    delete v;
+    return r;
+  }
+  *out = v;
+  return 0;
+}
+
+void jxlhip_canvas_destroy(JxlHipCanvas* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  if (v->last_stream) (void)hipStreamSynchronize(v->last_stream);
+  v->cur.Free();
+  v->pixels.Free();
+  for (Buf& b : v->slot) b.Free();
+  delete v;
+}
+
+int jxlhip_canvas_blend(JxlHipCanvas* v, JxlHipContext* c, const JxlHipBlend* b) {
+  if (!v || !c || !b || c->device != v->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (b->mode > 4 || b->alpha_mode > 4 || b->source > 3 || b->alpha_source > 3 || b->save_slot > 3) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame && !c->mod.have) return JXLHIP_ERR_NO_FRAME;
+  if (c->out_type != 0 || c->out_nc != 4 || c->out_swap || c->out_orient) return JXLHIP_ERR_INVALID_ARGUMENT;  // f32 x 4 as coded
+  if (size_t(c->oxs) * c->oys * 16 > c->rgb.cap) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(v->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  const size_t bytes = size_t(v->xs) * v->ys * 16;
+  jxlhip::BlendParams P;
+  memset(&P, 0, sizeof(P));
+  P.out = v->cur.as<float>();
+  P.bg_color = v->slot_valid[b->source] ? v->slot[b->source].as<float>() : nullptr;
+  P.bg_alpha = v->slot_valid[b->alpha_source] ? v->slot[b->alpha_source].as<float>() : nullptr;
+  P.fg = c->rgb.as<float>();
+  P.w = v->xs;
+  P.h = v->ys;
+  P.fw = c->oxs;
+  P.fh = c->oys;
+  P.x0 = b->x0;
+  P.y0 = b->y0;
+  P.mode = b->mode;
+  P.alpha_mode = b->alpha_mode;
+  P.clamp = b->clamp;
+  P.alpha_clamp = b->alpha_clamp;
+  P.has_alpha = v->has_alpha;
+  P.premultiplied = v->premultiplied;
+  if (v->last_stream && v->last_stream != c->stream) HIP_TRY(hipStreamSynchronize(v->last_stream));
+  hipLaunchKernelGGL(jxlhip::k_canvas_blend, dim3((v->xs + 255) / 256, v->ys), dim3(256), 0, c->stream, P);
+  HIP_TRY(hipGetLastError());
+  if (b->save_slot >= 0) {
+    int r = v->slot[b->save_slot].Ensure(bytes);
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(v->slot[b->save_slot].p, v->cur.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+    v->slot_valid[b->save_slot] = true;
+  }
+  v->last_stream = c->stream;
+  return 0;
+}
+
+int jxlhip_canvas_download(JxlHipCanvas* v, uint32_t data_type, uint32_t num_channels, uint32_t bits, int big_endian, uint32_t orientation,
+                           void* dst, size_t stride) {
+  if (!v || !dst || num_channels < 1 || num_channels > 4 || orientation < 1 || orientation > 8) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (data_type != 0 && data_type != 2 && data_type != 3 && data_type != 5) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(v->device));
+  static const uint8_t kBits[9] = {0, 0, 1, 3, 2, 4, 6, 7, 5};
+  const uint32_t sample = data_type == 2 ? 1 : (data_type == 0 ? 4 : 2), full = sample * 8;
+  jxlhip::PixelOut po;
+  memset(&po, 0, sizeof(po));
+  int r = v->pixels.Ensure(size_t(v->xs) * v->ys * num_channels * sample);
+  if (r) return r;
+  po.dst = v->pixels.p;
+  po.alpha = v->has_alpha ? v->cur.as<float>() + size_t(3) * v->xs * v->ys : nullptr;
+  po.xsize = v->xs;
+  po.ysize = v->ys;
+  po.orient = kBits[orientation];
+  po.type = data_type;
+  po.nc = num_channels;
+  po.bits = (data_type == 2 || data_type == 3) ? (bits && bits < full ? bits : full) : 0;
+  po.swap = big_endian && sample > 1;
+  hipStream_t st = v->last_stream;
+  hipLaunchKernelGGL(jxlhip::k_canvas_out, dim3((v->xs + 255) / 256, v->ys), dim3(256), 0, st, static_cast<const float*>(v->cur.as<float>()), po);
+  HIP_TRY(hipGetLastError());
+  const bool transposed = (po.orient & 4) != 0;
+  const size_t row = size_t(transposed ? v->ys : v->xs) * num_channels * sample, rows = transposed ? v->xs : v->ys;
+  if (stride < row) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipMemcpy2DAsync(dst, stride, v->pixels.p, row, row, rows, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return 0;
+}
+
+int jxlhip_canvas_download_alpha(JxlHipCanvas* v, float* dst, size_t n) {
+  if (!v || !dst || n < size_t(v->xs) * v->ys) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(v->device));
+  HIP_TRY(hipMemcpyAsync(dst, v->cur.as<float>() + size_t(3) * v->xs * v->ys, size_t(v->xs) * v->ys * 4, hipMemcpyDeviceToHost, v->last_stream));
+  HIP_TRY(hipStreamSynchronize(v->last_stream));
   return 0;
 }
 

@@ -84,7 +84,7 @@ struct FramePlan {
   // single-section frames: AC data starts mid-byte inside the one section
   uint32_t first_section_bit_offset = 0;
   size_t frame_end = 0;  // byte offset just after the frame
-  size_t frame_index = 0;  // position in the codestream (every frame accepted here is a visible one: dec_frame.cc:160-168)
+  size_t frame_index = 0, nonvisible_index = 0;  // shown frames before this one, invisible ones since (dec_frame.cc:160-168)
   // Extra channels (alpha, ...): Modular-coded beside the VarDCT colour (dec_frame.cc:511-542, dec_modular.cc:209-425).
   // `extra` is the frame's global Modular image; channels no larger than a group are complete after the DC global
   // section, the others continue in every AC group section BEHIND the coefficient stream, whose end only the entropy
@@ -149,13 +149,15 @@ class FrameParser {
   }
 
   // Parses the frame that starts at byte `pos` of the buffer. Throws jxh::Error for unsupported streams.
-  // frame_index: position of the frame in the codestream. Several frames are accepted when each one shows alone
-  // (decode.cc:1346-1350: last, or an animation frame with a duration) and replaces the whole canvas (full size,
-  // BlendMode kReplace): an animation without layers, references or crops.
-  void ParseFrame(size_t pos, const ImageHeader& ih, FramePlan* plan, const ParallelFor& pfor = SerialFor, size_t frame_index = 0) {
+  // frame_index / nonvisible_index: the shown frames before this one and the invisible ones since (dec_frame.cc:160-168;
+  // they seed the noise). The plan is of the frame at its own size: where it sits on the canvas and how it blends with
+  // a reference slot (fh.x0 / y0, fh.blend) is the caller's business (the decoder API composes on a JxlHipCanvas).
+  void ParseFrame(size_t pos, const ImageHeader& ih, FramePlan* plan, const ParallelFor& pfor = SerialFor, size_t frame_index = 0,
+                  size_t nonvisible_index = 0) {
     FramePlan& P = *plan;
     P.ih = ih;
     P.frame_index = frame_index;
+    P.nonvisible_index = nonvisible_index;
     BitReader br(data_ + pos, codestream_base_ + cs_size_ - pos);
     ReadFrameHeader(br, ih, &P.fh);
     const FrameHeader& fh = P.fh;
@@ -163,9 +165,7 @@ class FrameParser {
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
     JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
     JXH_CHECK(fh.upsampling == 1 || !ih.custom_upsampling, "unsupported: custom upsampling weights");
-    JXH_CHECK(!fh.custom_size, "unsupported: cropped frames");
-    JXH_CHECK(fh.is_last || (ih.have_animation && fh.duration > 0), "unsupported: layered frames (zero duration, not last)");
-    JXH_CHECK((fh.is_last && frame_index == 0) || fh.blend_mode == 0, "unsupported: blended frames");
+    JXH_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(ih.extra.empty() || fh.upsampling == 1, "unsupported: extra channels of upsampled frames");

@@ -202,6 +202,13 @@ struct LoopFilter {
         epf_border_sad_mul = 2.0f / 3.0f, epf_sigma_for_modular = 1.0f;
 };
 
+// frame_header.cc:72-104 BlendingInfo: how a frame's channels combine with a reference slot (blending.cc, alpha.cc)
+struct BlendInfo {
+  uint32_t mode = 0;  // 0 replace, 1 add, 2 blend (alpha over), 3 alpha-weighted add, 4 multiply
+  uint32_t alpha_channel = 0, source = 0;
+  bool clamp = false;
+};
+
 struct FrameHeader {
   uint32_t frame_type = 0;  // 0 regular, 1 DC frame, 2 reference only, 3 skip progressive
   bool modular = false;
@@ -220,6 +227,8 @@ struct FrameHeader {
   uint32_t save_as_reference = 0;
   uint32_t duration = 0, timecode = 0;  // AnimationFrame (frame_header.cc:130-150), in ticks of the image's AnimationHeader
   uint32_t blend_mode = 0;              // BlendMode of the colour channels: 0 = replace
+  BlendInfo blend;                      // ... in full, and of every extra channel
+  std::vector<BlendInfo> ec_blend;
   bool save_before_color_transform = false;
   LoopFilter lf;
   static const uint64_t kNoise = 1, kPatches = 2, kSplines = 16, kUseDcFrame = 32, kSkipDcSmoothing = 128;
@@ -261,14 +270,16 @@ static inline void ReadLoopFilter(BitReader& br, bool modular, LoopFilter* lf) {
   SkipExtensions(br);
 }
 
-static inline void ReadBlendingInfo(BitReader& br, size_t num_extra, bool partial, uint32_t* mode_out) {
-  uint32_t mode = ReadU32(br, Val(0), Val(1), Val(2), BitsOffset(2, 3));
-  JXH_CHECK(mode <= 4, "invalid blend mode");
-  bool alpha_modes = num_extra > 0 && (mode == 2 || mode == 3);
-  if (alpha_modes) ReadU32(br, Val(0), Val(1), Val(2), BitsOffset(3, 3));
-  if (alpha_modes || mode == 4) br.ReadBool();
-  if (mode != 0 || partial) ReadU32(br, Val(0), Val(1), Val(2), Val(3));
-  *mode_out = mode;
+static inline void ReadBlendingInfo(BitReader& br, size_t num_extra, bool partial, BlendInfo* b) {
+  b->mode = ReadU32(br, Val(0), Val(1), Val(2), BitsOffset(2, 3));
+  JXH_CHECK(b->mode <= 4, "invalid blend mode");
+  bool alpha_modes = num_extra > 0 && (b->mode == 2 || b->mode == 3);
+  if (alpha_modes) {
+    b->alpha_channel = ReadU32(br, Val(0), Val(1), Val(2), BitsOffset(3, 3));
+    JXH_CHECK(b->alpha_channel < num_extra, "blending refers to a missing alpha channel");
+  }
+  if (alpha_modes || b->mode == 4) b->clamp = br.ReadBool();
+  if (b->mode != 0 || partial) b->source = ReadU32(br, Val(0), Val(1), Val(2), Val(3));
 }
 
 static inline void ReadFrameHeader(BitReader& br, const ImageHeader& ih, FrameHeader* f) {
@@ -334,11 +345,10 @@ static inline void ReadFrameHeader(BitReader& br, const ImageHeader& ih, FrameHe
   }
   uint32_t blend_mode = 0;
   if (f->frame_type == 0 || f->frame_type == 3) {
-    ReadBlendingInfo(br, ih.extra.size(), partial, &blend_mode);
-    for (size_t i = 0; i < ih.extra.size(); i++) {
-      uint32_t m;
-      ReadBlendingInfo(br, ih.extra.size(), partial, &m);
-    }
+    ReadBlendingInfo(br, ih.extra.size(), partial, &f->blend);
+    blend_mode = f->blend.mode;
+    f->ec_blend.resize(ih.extra.size());
+    for (size_t i = 0; i < ih.extra.size(); i++) ReadBlendingInfo(br, ih.extra.size(), partial, &f->ec_blend[i]);
     if (ih.have_animation) {
       f->duration = ReadU32(br, Val(0), Val(1), Bits(8), Bits(32));
       if (ih.have_timecodes) f->timecode = uint32_t(br.Read(32));

@@ -59,7 +59,9 @@ class ModFrameParser {
  public:
   ModFrameParser(const uint8_t* data, size_t size) : data_(data), size_(size) {}
 
-  void ParseFrame(size_t pos, const ImageHeader& ih, ModFramePlan* plan, size_t frame_index = 0) {
+  void ParseFrame(size_t pos, const ImageHeader& ih, ModFramePlan* plan, size_t frame_index = 0, size_t nonvisible_index = 0) {
+    (void)frame_index;
+    (void)nonvisible_index;  // (Modular frames carry no noise: nothing here depends on the frame's position)
     ModFramePlan& P = *plan;
     P.ih = ih;
     BitReader br(data_ + pos, size_ - pos);
@@ -67,11 +69,9 @@ class ModFrameParser {
     const FrameHeader& fh = P.fh;
     JXH_CHECK(fh.modular, "not a Modular frame");
     JXH_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
-    // (several frames: as FrameParser::ParseFrame, an animation of frames that replace the whole canvas)
-    JXH_CHECK(fh.is_last || (ih.have_animation && fh.duration > 0), "unsupported: layered frames (zero duration, not last)");
-    JXH_CHECK((fh.is_last && frame_index == 0) || fh.blend_mode == 0, "unsupported: blended frames");
+    // (where the frame sits on the canvas and how it blends: the caller's business, as for FrameParser::ParseFrame)
     JXH_CHECK(!ih.xyb_encoded && !fh.ycbcr, "unsupported: XYB or YCbCr Modular frames");
-    JXH_CHECK(fh.upsampling == 1 && !fh.custom_size && fh.num_passes == 1, "unsupported: upsampled / cropped / multi-pass Modular frames");
+    JXH_CHECK(fh.upsampling == 1 && fh.num_passes == 1, "unsupported: upsampled / multi-pass Modular frames");
     for (uint32_t u : fh.ec_upsampling) JXH_CHECK(u == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
               "unsupported: patches/noise/DC frames");

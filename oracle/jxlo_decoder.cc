@@ -36,6 +36,7 @@ struct Decoded {
   size_t out_xsize = 0, out_ysize = 0;  // the image (= frame size times the frame's upsampling factor, cropped)
   std::vector<uint8_t> rgb8;   // interleaved, out_xsize*out_ysize*out_channels
   std::vector<float> rgbf;     // planar 3 x ysize x xsize (after transfer function, before uint8)
+  std::vector<float> alphaf;   // the alpha plane as floats (images with alpha)
   // VarDCT intermediates
   std::vector<int32_t> coeffs;     // [group][c][65536], block-contiguous per varblock
   std::vector<int32_t> nzeros;     // [group][c][32*32]
@@ -58,7 +59,7 @@ struct FrameState {
   const ImageHeader* ih;
   FrameHeader fh;
   FrameDim dim;
-  size_t frame_index = 0;  // = the visible frames before this one (dec_frame.cc:160-168): every accepted frame is visible
+  size_t frame_index = 0, nonvisible_index = 0;  // visible frames before this one, invisible ones since (dec_frame.cc:160-168)
   // DC global
   DequantTables dq;
   uint32_t global_scale = 1, quant_dc = 16;
@@ -456,22 +457,21 @@ static void ReconstructGroup(FrameState* s, size_t g, const int32_t* coeffs) {
     }
 }
 
-// frame_index: position of the frame in the codestream (0 = first). A codestream with several frames is accepted when
-// each one shows alone (decode.cc:1346-1350 is_last_of_still: last, or an animation frame with a duration) and replaces
-// the whole canvas (full size, BlendMode kReplace): an animation without layers, references or crops.
-static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool want_dumps, size_t frame_index = 0) {
+// frame_index / nonvisible_index: the visible frames before this one and the invisible ones since (they seed the noise).
+// The frame is rendered at its own size; Decode() places it on the canvas (crop origin, blending with a reference slot).
+static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool want_dumps, size_t frame_index = 0,
+                        size_t nonvisible_index = 0) {
   FrameState st;
   FrameState* s = &st;
   s->out = out;
   s->ih = &ih;
   s->frame_index = frame_index;
+  s->nonvisible_index = nonvisible_index;
   ReadFrameHeader(br, ih, &s->fh);
   const FrameHeader& fh = s->fh;
   JXLO_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
   JXLO_CHECK(fh.upsampling == 1 || (!fh.modular && !ih.custom_upsampling), "unsupported: upsampled Modular frames / custom weights");
-  JXLO_CHECK(!fh.custom_size, "unsupported: cropped frames");
-  JXLO_CHECK(fh.is_last || (ih.have_animation && fh.duration > 0), "unsupported: layered frames (zero duration, not last)");
-  JXLO_CHECK((fh.is_last && frame_index == 0) || fh.blend_mode == 0, "unsupported: blended frames");
+  JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
   JXLO_CHECK(fh.modular || ih.xyb_encoded, "unsupported: non-XYB VarDCT");
   JXLO_CHECK(!(fh.modular && ih.xyb_encoded), "unsupported: XYB Modular frames");
@@ -640,7 +640,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       for (float v : s->noise_lut) any = any || std::fabs(v) > 1e-3f;
       if (any) {
         noisy = *cur;
-        AddNoise(&noisy, xs, ys, s->noise_lut, s->base_corr_x, s->base_corr_b, uint32_t(s->frame_index), 0);
+        AddNoise(&noisy, xs, ys, s->noise_lut, s->base_corr_x, s->base_corr_b, uint32_t(s->frame_index), uint32_t(s->nonvisible_index));
         cur = &noisy;
         if (want_dumps && fh.upsampling == 1) {  // (the dump then holds what the colour conversion reads)
           for (int c = 0; c < 3; c++)
@@ -689,6 +689,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     const float af = float(1.0 / double((1u << ih.extra[0].bits) - 1));
     alpha.resize(xs * ys);
     for (size_t i = 0; i < xs * ys; i++) alpha[i] = float(ch.d[i]) * af;
+    out->alphaf = alpha;
   }
 #pragma omp parallel for schedule(static)
   for (size_t y = 0; y < ys; y++)
@@ -730,11 +731,120 @@ static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dum
   BitReader br(data, size);
   br.Skip(16);
   ReadImageHeader(br, &out->ih);
-  for (size_t i = 0;; i++) {
-    DecodeFrame(br, out->ih, out, want_dumps && i == frame_index, i);
-    if (i == frame_index) break;
-    JXLO_CHECK(!out->fh.is_last, "no such frame");
-    const ImageHeader ih = out->ih;
+  // The canvas (blending.cc, render_pipeline/stage_blending.cc, dec_cache.cc:268-290): every frame is blended, in the
+  // output colour space, with the reference slot its header names -- outside the frame's rectangle the result is that
+  // slot's content (zeros when it was never written) -- and frames that can be referenced store the result in a slot.
+  // frame_index counts the frames that are shown (decode.cc:1346-1350: the last one, or one with a duration).
+  const ImageHeader ih = out->ih;
+  const size_t W = ih.xsize, H = ih.ysize;
+  const bool has_alpha = !ih.extra.empty() && ih.extra[0].type == 0;
+  struct Slot {
+    std::vector<float> p[4];
+    bool valid = false;
+  } slots[4];
+  size_t visible = 0, nonvisible = 0;
+  for (;;) {
+    DecodeFrame(br, ih, out, want_dumps && visible == frame_index, visible, nonvisible);
+    const FrameHeader fh = out->fh;
+    const bool shown = fh.is_last || fh.duration > 0;
+    bool needs_blending = fh.custom_size || fh.blend.mode != 0;
+    for (const BlendInfo& e : fh.ec_blend) needs_blending = needs_blending || e.mode != 0;
+    const bool can_ref = !fh.is_last && (fh.duration == 0 || fh.save_as_reference != 0);
+    if (needs_blending || can_ref || !shown || visible != 0 || nonvisible != 0) {
+      JXLO_CHECK(ih.extra.size() <= 1 && (ih.extra.empty() || has_alpha), "unsupported: blending with extra channels other than alpha");
+      JXLO_CHECK(!(can_ref && fh.save_before_color_transform), "unsupported: frames saved before the colour transform");
+      const size_t fw = out->out_xsize, fhh = out->out_ysize;
+      const BlendInfo cb = fh.blend, ab = has_alpha ? fh.ec_blend[0] : BlendInfo();
+      const bool premul = has_alpha && ih.extra[0].alpha_associated;
+      Slot cur;
+      for (auto& v : cur.p) v.assign(W * H, 0.0f);
+      const Slot& bgc = slots[cb.source];
+      const Slot& bga = slots[ab.source];
+      auto clamp01 = [](float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); };
+      for (size_t y = 0; y < H; y++)
+        for (size_t x = 0; x < W; x++) {
+          const size_t i = y * W + x;
+          float bg[4] = {0, 0, 0, 0};
+          if (bgc.valid)
+            for (int c = 0; c < 3; c++) bg[c] = bgc.p[c][i];
+          if (bga.valid) bg[3] = bga.p[3][i];
+          const long long fx = (long long)x - fh.x0, fy = (long long)y - fh.y0;
+          if (fx < 0 || fy < 0 || fx >= (long long)fw || fy >= (long long)fhh) {  // padding: the background shows
+            for (int c = 0; c < 4; c++) cur.p[c][i] = bg[c];
+            continue;
+          }
+          const size_t j = size_t(fy) * fw + size_t(fx);
+          float fg[4];
+          for (int c = 0; c < 3; c++) fg[c] = out->rgbf[c * fw * fhh + j];
+          fg[3] = has_alpha ? out->alphaf[j] : 1.0f;
+          float o[4];
+          // the alpha channel first, from the alpha values before blending (blending.cc:51-112; alpha.cc:44-88)
+          if (has_alpha) {
+            const float fa = ab.clamp ? clamp01(fg[3]) : fg[3];
+            switch (ab.mode) {
+              case 1: o[3] = bg[3] + fg[3]; break;
+              case 2: o[3] = 1.0f - (1.0f - fa) * (1.0f - bg[3]); break;
+              case 3: o[3] = bg[3]; break;
+              case 4: o[3] = bg[3] * fa; break;
+              default: o[3] = fg[3]; break;
+            }
+          } else {
+            o[3] = 1.0f;
+          }
+          const float fa = cb.clamp ? clamp01(fg[3]) : fg[3];
+          switch (cb.mode) {
+            case 1:
+              for (int c = 0; c < 3; c++) o[c] = bg[c] + fg[c];
+              break;
+            case 3:
+              for (int c = 0; c < 3; c++) o[c] = has_alpha ? bg[c] + fg[c] * fa : bg[c] + fg[c];
+              break;
+            case 2:
+              if (!has_alpha) {
+                for (int c = 0; c < 3; c++) o[c] = fg[c];
+              } else if (premul) {
+                for (int c = 0; c < 3; c++) o[c] = fg[c] + bg[c] * (1.0f - fa);
+                o[3] = 1.0f - (1.0f - fa) * (1.0f - bg[3]);
+              } else {
+                const float new_a = 1.0f - (1.0f - fa) * (1.0f - bg[3]);
+                const float rnew_a = new_a > 0 ? 1.0f / new_a : 0.0f;
+                for (int c = 0; c < 3; c++) o[c] = (fg[c] * fa + bg[c] * bg[3] * (1.0f - fa)) * rnew_a;
+                o[3] = new_a;
+              }
+              break;
+            case 4:
+              for (int c = 0; c < 3; c++) o[c] = bg[c] * (cb.clamp ? clamp01(fg[c]) : fg[c]);
+              break;
+            default:
+              for (int c = 0; c < 3; c++) o[c] = fg[c];
+              break;
+          }
+          for (int c = 0; c < 4; c++) cur.p[c][i] = o[c];
+        }
+      cur.valid = true;
+      if (can_ref) slots[fh.save_as_reference] = cur;
+      // the shown image is the canvas
+      out->out_xsize = W;
+      out->out_ysize = H;
+      out->rgbf.resize(3 * W * H);
+      for (int c = 0; c < 3; c++) memcpy(out->rgbf.data() + c * W * H, cur.p[c].data(), W * H * sizeof(float));
+      if (has_alpha) out->alphaf = cur.p[3];
+      const int oc = out->out_channels;
+      out->rgb8.resize(W * H * oc);
+      for (size_t y = 0; y < H; y++)
+        for (size_t x = 0; x < W; x++) {
+          for (int c = 0; c < 3; c++) out->rgb8[(y * W + x) * oc + c] = ToU8(out->rgbf[c * W * H + y * W + x], x, y, c);
+          if (has_alpha) out->rgb8[(y * W + x) * oc + 3] = ToU8(out->alphaf[y * W + x], x, y, 3);
+        }
+    }
+    if (shown) {
+      if (visible == frame_index) break;
+      visible++;
+      nonvisible = 0;
+    } else {
+      nonvisible++;
+    }
+    JXLO_CHECK(!fh.is_last, "no such frame");
     *out = Decoded();  // (frames before the wanted one are decoded and dropped: test sizes)
     out->ih = ih;
   }

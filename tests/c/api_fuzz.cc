@@ -25,6 +25,11 @@ int jxlhip_run_transform(JxlHipContext*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_set_alpha(JxlHipContext*, const float*, uint32_t, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_set_output_format(JxlHipContext*, uint32_t, uint32_t, uint32_t, int) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_set_output_orientation(JxlHipContext*, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_canvas_create(int, uint32_t, uint32_t, uint32_t, uint32_t, JxlHipCanvas**) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+void jxlhip_canvas_destroy(JxlHipCanvas*) {}
+int jxlhip_canvas_blend(JxlHipCanvas*, JxlHipContext*, const JxlHipBlend*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_canvas_download(JxlHipCanvas*, uint32_t, uint32_t, uint32_t, int, uint32_t, void*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_canvas_download_alpha(JxlHipCanvas*, float*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 }
 
 static uint64_t g_rng = 0x9E3779B97F4A7C15ull;

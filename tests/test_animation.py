@@ -1,6 +1,6 @@
 """Animations (multi-frame codestreams): a sequence of frames that each replace the whole canvas
-(decode.cc:1346-1350 is_last_of_still; full size, BlendMode kReplace, a duration). Layers, blending, crops and
-references stay refused. CPU part: oracle, host parse and the header-only event sequence; GPU part: pixels of every
+(decode.cc:1346-1350 is_last_of_still; full size, BlendMode kReplace, a duration); crops, blending and invisible layers:
+tests/test_layers.py. CPU part: oracle, host parse and the header-only event sequence; GPU part: pixels of every
 frame through the replay of the reference's call sequence."""
 import ctypes
 import struct
@@ -50,10 +50,11 @@ def test_host_parses_frame_after_frame(built):
             pos = f.end
             f.close()
         assert pos == len(data)
-    # layers are refused: a frame that is neither the last nor timed would have to be blended with the next
+    # a zero-duration frame is an invisible layer: it parses like any frame (composition: tests/test_layers.py)
     layered = J.encode_animation(fr[:2], [0, 1])
-    with pytest.raises(J.JxlAmdError, match="layered"):
-        J.Frame(layered)
+    f = J.Frame(layered)
+    assert (f.duration, f.is_last) == (0, False)
+    f.close()
 
 
 def test_decoder_api_walks_the_frames_without_pixels(built):
