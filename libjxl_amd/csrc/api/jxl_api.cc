@@ -1372,7 +1372,8 @@ JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* d, JXL_BOOL unpremu
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* d, JXL_BOOL) { return d->stage == 0 ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL) { return d->stage == 0 ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
+// Frames are always delivered coalesced (the canvas); asking for the individual layers is refused rather than ignored.
+JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL coalescing) { return d->stage == 0 && coalescing ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
 
 JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t size) {
   if (d->in) return JXL_DEC_ERROR;

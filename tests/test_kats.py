@@ -94,6 +94,12 @@ def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
     finally:
         J.set_splines(None)
     with_splines.append(open(os.path.join(ROOT, "tests", "golden", "ref_wasm_splines.jxl"), "rb").read())
+    patch = J.synth_image(80, 60, seed=2)
+    ramp = ((np.mgrid[0:60, 0:80][1] * 255) // 79).astype(np.uint8)
+    with_splines.append(J.encode_layers([dict(img=np.dstack([img, img[..., 0]]), save_as=1, duration=2),
+                                         dict(img=np.dstack([patch, ramp]), x0=-10, y0=100, mode=2, alpha_mode=2, source=1, save_as=1),
+                                         dict(img=np.dstack([patch, ramp]), x0=250, y0=-20, mode=4, alpha_mode=3, source=1, clamp=1, duration=1)],
+                                        tps=(10, 1), lossless=True))
     streams = with_splines + [J.encode_rgb8(img), J.encode_rgba8(np.dstack([img, img[..., 0]])), J.encode_random(264, 200, seed=3),
                J.encode_rgb8(img, ac_code_mode=3, num_passes=2, custom_orders=1, custom_bctx=1, noise=50), J.encode_rgb8(img, upsampling=2),
                J.encode_lossless(img, J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP),
@@ -128,9 +134,14 @@ def test_decoder_api_under_sanitizers_on_damaged_files(built, tmp_path):
     finally:
         J.set_embedded_icc(None)
     anim = J.encode_animation(frames, [1, 2, 3])
+    import numpy as np
+    patch = J.synth_image(80, 60, seed=2)
+    ramp = ((np.mgrid[0:60, 0:80][1] * 255) // 79).astype(np.uint8)
+    layered = J.encode_layers([dict(img=np.dstack([img, img[..., 0]]), save_as=1),
+                               dict(img=np.dstack([patch, ramp]), x0=-10, y0=100, mode=2, alpha_mode=2, source=1)], lossless=True)
     files = []
     for i, s in enumerate([J.encode_rgb8(img), R.container(J.encode_rgb8(img)), R.container(with_icc, pieces=3), anim,
-                           R.container(anim, pieces=4), R.container(J.encode_lossless(img), pieces=1)]):
+                           R.container(anim, pieces=4), R.container(J.encode_lossless(img), pieces=1), layered]):
         files.append(os.path.join(str(tmp_path), "f%d.jxl" % i))
         open(files[-1], "wb").write(s)
     r = subprocess.run([out, "60"] + files, capture_output=True, text=True, timeout=900)
