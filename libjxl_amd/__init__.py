@@ -505,7 +505,7 @@ def encode_animation(frames, durations, tps=(10, 1), num_loops=0, lossless=False
     return out
 
 
-def encode_layers(layers, tps=None, num_loops=0, lossless=False, **kw):
+def encode_layers(layers, tps=None, num_loops=0, lossless=False, premultiplied=False, **kw):
     """Test aid: a codestream of several frames composed on a canvas (blending.cc): layers[i] is a dict with img (HxWx3 or
     HxWx4 uint8; layers[0] covers the whole canvas at the origin and gives its size) and optionally x0, y0 (crop origin),
     mode / alpha_mode (BlendMode of colour / alpha: 0 replace, 1 add, 2 blend, 3 alpha-weighted add, 4 multiply), source /
@@ -520,6 +520,9 @@ def encode_layers(layers, tps=None, num_loops=0, lossless=False, **kw):
     E.jxlenc_last_header_bytes.restype = ctypes.c_size_t
     ch, cw = layers[0]["img"].shape[:2]
     out = b""
+    E.jxlenc_set_alpha_premultiplied.argtypes = [ctypes.c_int]
+    E.jxlenc_set_alpha_premultiplied.restype = None
+    E.jxlenc_set_alpha_premultiplied(1 if premultiplied else 0)  # (the alpha channel is declared associated; samples as given)
     try:
         for i, L in enumerate(layers):
             img = L["img"]
@@ -537,6 +540,7 @@ def encode_layers(layers, tps=None, num_loops=0, lossless=False, **kw):
     finally:
         E.jxlenc_set_layer(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1)
         E.jxlenc_set_animation(0, 10, 1, 0, 0, 1)
+        E.jxlenc_set_alpha_premultiplied(0)
     return out
 
 

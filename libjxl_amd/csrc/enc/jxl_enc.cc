@@ -763,6 +763,22 @@ struct LayerState {
   uint32_t mode = 0, alpha_mode = 0, source = 0, alpha_source = 0, clamp = 0, save_as = 0;
 };
 static LayerState g_layer;
+// jxlenc_set_alpha_premultiplied: the alpha channel is declared associated (ExtraChannelInfo.alpha_associated,
+// image_metadata.cc:158-200); the samples are written as given.
+static bool g_alpha_premultiplied = false;
+static void WriteAlphaChannelInfo(BitWriter& bw) {
+  if (!g_alpha_premultiplied) {
+    bw.Write(1, 1);  // ExtraChannelInfo all_default: 8-bit alpha
+    return;
+  }
+  bw.Write(1, 0);  // not all_default
+  bw.Write(2, 0);  // type: alpha
+  bw.Write(1, 0);  // integer samples
+  bw.Write(2, 0);  //   8 bits
+  bw.Write(2, 0);  // dim_shift 0
+  bw.Write(2, 0);  // no name
+  bw.Write(1, 1);  // alpha_associated
+}
 // Crop + blending fields of a frame header for a frame of fw x fh pixels; returns whether a save_before_color_transform
 // bit follows the timing fields (frame_header.cc:396-408).
 static bool WriteCropAndBlending(BitWriter& bw, uint32_t fw, uint32_t fh, bool have_alpha) {
@@ -1325,7 +1341,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(2, 0);  //   8 bits
     bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
     bw.Write(2, have_alpha ? 1 : 0);  // extra channels
-    if (have_alpha) bw.Write(1, 1);   //   ExtraChannelInfo all_default: 8-bit alpha
+    if (have_alpha) WriteAlphaChannelInfo(bw);
     bw.Write(1, 1);  // xyb_encoded
     if (!with_icc) {
       bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
@@ -2244,7 +2260,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(2, 0);  //   8 bits
   bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
   bw.Write(2, alpha ? 1 : 0);  // extra channels
-  if (alpha) bw.Write(1, 1);   //   all_default: 8-bit alpha
+  if (alpha) WriteAlphaChannelInfo(bw);
   bw.Write(1, 0);  // xyb_encoded = false
   const bool with_icc = !g_embedded_icc.empty() && !gray;
   if (with_icc) {
@@ -2366,6 +2382,7 @@ void jxlenc_set_layer(int enabled, int32_t x0, int32_t y0, uint32_t canvas_w, ui
   jxe::g_layer.save_as = save_as;
   jxe::g_anim.timed = timed != 0;
 }
+void jxlenc_set_alpha_premultiplied(int premultiplied) { jxe::g_alpha_premultiplied = premultiplied != 0; }
 // Byte offset of the frame header in the stream written last (signature + image header come before it).
 size_t jxlenc_last_header_bytes(void) { return jxe::g_last_header_bytes; }
 

@@ -242,7 +242,7 @@ def _oriented(img, orientation):
     return np.ascontiguousarray(img)
 
 
-@pytest.mark.parametrize("orientation", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("orientation", [3, 5, 6, 8])  # (mirror x | y, transpose, y + transpose, x + transpose: every bit, every pairing)
 def test_orientation_is_undone_by_the_pixel_writer(built, tmp_path, orientation):
     """JxlDecoderSetKeepOrientation(false) (the default, and what DecodeImageJXL asks for: jxl.cc:213): basic info,
     buffer size and frame header give the oriented size (decode.cc:985-990, 2233-2240) and the pixels and extra channel

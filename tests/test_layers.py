@@ -78,14 +78,14 @@ def _oracle_frames(data, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lossless,case", [(True, "blend"), (False, "blend"), (True, "add_mul"), (False, "outside")])
+@pytest.mark.parametrize("lossless,case", [(True, "blend"), (False, "blend"), (True, "add_mul"), (False, "outside"), (True, "premultiplied")])
 def test_layered_stills_through_the_gpu(built, tmp_path, lossless, case):
     """Only the last frame of a layered still is shown; the layers before it are decoded, blended and kept in their
     slots without any event (decode.cc:1346-1408)."""
     J = built
     base, opaque, patch, ramp = _parts(J)
     first = dict(img=np.dstack([base, opaque]), save_as=1)
-    if case == "blend":
+    if case in ("blend", "premultiplied"):
         layers = [first, dict(img=np.dstack([patch, ramp]), x0=50, y0=40, mode=2, alpha_mode=2, source=1)]
     elif case == "add_mul":
         layers = [first, dict(img=np.dstack([patch // 4, ramp]), x0=10, y0=20, mode=1, alpha_mode=0, source=1, save_as=2),
@@ -95,7 +95,7 @@ def test_layered_stills_through_the_gpu(built, tmp_path, lossless, case):
         layers = [first, dict(img=np.dstack([patch, ramp]), x0=-30, y0=-20, mode=2, alpha_mode=2, source=1, save_as=1),
                   dict(img=np.dstack([patch, ramp]), x0=W - 40, y0=H - 25, mode=2, alpha_mode=2, source=1, save_as=1),
                   dict(img=np.dstack([patch, ramp]), x0=W + 5, y0=10, mode=0, alpha_mode=0, source=1)]
-    data = J.encode_layers(layers, lossless=lossless)
+    data = J.encode_layers(layers, lossless=lossless, premultiplied=case == "premultiplied")  # (alpha.cc:22-31 for associated alpha)
     (want8, wantf), = _oracle_frames(data, 1)
     rc, events, out, px = R.run(data, tmp_path, "u8", 4)
     assert rc == 0 and [e for e in events if e in ("FRAME", "FULL_IMAGE")] == ["FRAME", "FULL_IMAGE"], out
