@@ -278,7 +278,9 @@ def lossless_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize
     """BASELINE.json configs[3]: Modular lossless decode. A step decodes `--batch` frames (every stream of every frame as one
     lane of ONE k_modular_streams launch, then the inverse transforms and the sample conversion per frame)."""
     import numpy as np
-    batch = args.batch if args.batch != 640 else 96  # (the VarDCT default would not fit: ~0.35 GB of channel buffers per frame)
+    # (the VarDCT default of 640 would not fit: ~0.35 GB of channel buffers per frame; 384 frames = 134 of the 288 GB, and
+    # the launch time is set by the longest stream, so frames per launch is what throughput follows: DESIGN.md §8.5)
+    batch = args.batch if args.batch != 640 else 384
     ndistinct = max(1, min(args.distinct, batch))
     flags = J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP
     if args.lossless_flags >= 0:  # measurement aid: other feature sets of the synthetic encoder
