@@ -368,7 +368,7 @@ def encode_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, 
     img = J.synth_image(xsize, ysize, 177)
     ctx = J.HipContext(local_rank)
     t = {}
-    data = J.encode_rgb8_gpu(img, ctx, timings=t, distance=args.distance)  # (leaves the image resident on the device)
+    data = J.encode_rgb8_gpu(img, ctx, timings=t, distance=args.distance, cfl_fit=1)  # (leaves the image resident on the device)
 
     def barrier():
         if dist is not None:
@@ -392,8 +392,8 @@ def encode_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, 
                "value": round(total_frames * px * 1e-6 / max_elapsed, 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(max_elapsed / args.steps * 1e3, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%dx%d RGB8 -> XYB, sharpening, transform selection, forward DCT 8..64, quantisation with "
-                                      "chroma-from-luma (pixel-domain half of a VarDCT encode), %d frames/step/GPU, input resident in "
+               "config": {"workload": "%dx%d RGB8 -> XYB, sharpening, transform selection, forward DCT 8..64, per-tile chroma-from-luma fit, "
+                                      "quantisation (pixel-domain half of a VarDCT encode), %d frames/step/GPU, input resident in "
                                       "HBM; entropy coding on the host is outside `value` (see e2e)" % (xsize, ysize, batch),
                           "bytes_out": len(data), "bpp": round(len(data) * 8.0 / px, 3),
                           "parallelism": "frames sharded over %d GPU(s), no data-path collective" % world},
@@ -405,7 +405,7 @@ def encode_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, 
             best = None
             for _ in range(3):
                 t1 = time.perf_counter()
-                J.encode_rgb8_gpu(img, ctx, timings=t, distance=args.distance)
+                J.encode_rgb8_gpu(img, ctx, timings=t, distance=args.distance, cfl_fit=1)
                 dt = time.perf_counter() - t1
                 if best is None or dt < best[0]:
                     best = (dt, dict(t))
@@ -414,7 +414,7 @@ def encode_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, 
                           "note": "one frame, RGB8 in host memory to codestream bytes: upload, kernels, download, host rANS coding"}
             if not args.no_cpu_baseline:
                 t1, c1 = time.perf_counter(), time.process_time()
-                J.enc_forward_model(img, None, distance=args.distance)
+                J.enc_forward_model(img, None, distance=args.distance, cfl_fit=1)
                 dt = time.perf_counter() - t1
                 cores = max(1, int(round((time.process_time() - c1) / dt)))  # the cores the OpenMP loops really got (cgroup share)
                 out["cpu_baseline"] = {"value": round(px * 1e-6 / dt, 3), "unit": "MP/s", "cores": cores, "kind": "port",

@@ -370,6 +370,12 @@ typedef struct {
   uint32_t strategy_mode; /* 0: DCT8 only, 1: activity-driven DCT 8..64 incl. rectangles */
   uint32_t global_scale, quant_dc; /* Quantizer parameters of the frame (quantizer.h:82-114) */
   float quant_ac;         /* AC quant target the quant field is built around */
+  /* 1: fit the chroma-from-luma factors of every 64x64 tile like the reference's fast path (enc_chroma_from_luma.cc:
+   * 128-151 FindBestMultiplier, 204-352 ComputeTile) and quantise X / B against them; 0: factors 0 (X), 0 (B on top of
+   * the base 1.0). Output: ytox / ytob, one int8 per tile (ceil(xb / 8) * ceil(yb / 8)), host memory, may be NULL. */
+  uint32_t cfl_fit;
+  int8_t* ytox;
+  int8_t* ytob;
   /* dequantisation tables, as JxlHipFrameDesc: kind k, channel c at dequant[dequant_offset[k] + c * dequant_size[k]] */
   const float* dequant;
   uint32_t dequant_floats;

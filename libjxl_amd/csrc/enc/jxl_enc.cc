@@ -929,6 +929,8 @@ struct Params {
                            //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
   int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS (libjxl's fastest efforts), bit 1 = LZ77
   int32_t noise;           // > 0: frame flag kNoise with the strength LUT point i = min(1023, noise + 40 * i) / 1024
+  int32_t cfl_fit;         // 1 = image mode fits the chroma-from-luma factor of every 64x64 tile the way the reference's
+                           //     fast path does (enc_chroma_from_luma.cc:128-151, 204-352): least squares over the tile's AC
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -1514,6 +1516,9 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     d.global_scale = f.global_scale;
     d.quant_dc = f.quant_dc;
     d.quant_ac = quant_ac;
+    d.cfl_fit = p.cfl_fit ? 1 : 0;
+    d.ytox = f.ytox.data();
+    d.ytob = f.ytob.data();
     const size_t nb = f.xb * f.yb, ng = DivCeil(xs, 256) * DivCeil(ys, 256);
     f.acs.assign(nb, 0);
     f.qf.assign(nb, 0);
@@ -1647,6 +1652,51 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
       int q = int(quant_ac * mul * inv_gs + 0.5f);
       f.qf[by * f.xb + bx] = std::max(1, std::min(256, q));
     }
+  if (p.cfl_fit && !p.random_cmap) {
+    // enc_chroma_from_luma.cc:204-352 ComputeTile + :128-151 FindBestMultiplier (fast): over the AC coefficients of the
+    // tile's transforms (lowest frequencies excluded), weighted by the inverse quantisation matrix of the chroma channel
+    // and q = Scale() * 128 * quant field, the least-squares factor of chroma against luma, pulled 2.6 towards zero.
+    jxh::DequantTables dqc;
+    for (int s2 = 0; s2 < 27; s2++) dqc.Matrix(s2, 0);
+    const float scale = float(f.global_scale) / 65536.0f;
+    const size_t tx_n = DivCeil(f.xb, 8), ty_n = DivCeil(f.yb, 8);
+#pragma omp parallel for schedule(dynamic)
+    for (size_t t = 0; t < tx_n * ty_n; t++) {
+      const size_t bx0 = (t % tx_n) * 8, by0 = (t / tx_n) * 8;
+      double sa2[2] = {0, 0}, sab[2] = {0, 0};
+      size_t num = 0;
+      std::vector<float> cy, cxv, cb, tmp;
+      for (size_t by = by0; by < std::min(by0 + 8, f.yb); by++)
+        for (size_t bx = bx0; bx < std::min(bx0 + 8, f.xb); bx++) {
+          const uint8_t a = f.acs[by * f.xb + bx];
+          if (!(a & 1)) continue;
+          const int st = a >> 1, cx = jxh::kCoveredX[st], cyb = jxh::kCoveredY[st], R = cyb * 8, C = cx * 8;
+          const size_t size = size_t(R) * C, cstride = size_t(std::max(cx, cyb)) * 8;
+          const size_t lrows = size_t(std::min(cx, cyb)), lcols = size_t(std::max(cx, cyb));
+          cy.resize(size); cxv.resize(size); cb.resize(size);
+          ForwardDct(xyb[1].data() + by * 8 * xp + bx * 8, xp, R, C, cy.data(), tmp);
+          ForwardDct(xyb[0].data() + by * 8 * xp + bx * 8, xp, R, C, cxv.data(), tmp);
+          ForwardDct(xyb[2].data() + by * 8 * xp + bx * 8, xp, R, C, cb.data(), tmp);
+          const float q = scale * 128.0f * float(f.qf[by * f.xb + bx]);
+          const float *mx = dqc.Matrix(st, 0), *mb = dqc.Matrix(st, 2);
+          for (size_t k = 0; k < size; k++) {
+            if (k / cstride < lrows && k % cstride < lcols) continue;
+            const float wx = q / mx[k], wb = q / mb[k];
+            const float ax = (1.0f / 84) * (cy[k] * wx), bxv = 0.0f * (cy[k] * wx) - cxv[k] * wx;
+            const float ab = (1.0f / 84) * (cy[k] * wb), bbv = 1.0f * (cy[k] * wb) - cb[k] * wb;
+            sa2[0] += double(ax) * ax; sab[0] += double(ax) * bxv;
+            sa2[1] += double(ab) * ab; sab[1] += double(ab) * bbv;
+          }
+          num += size;
+        }
+      for (int c = 0; c < 2; c++) {
+        float x = num ? float(-sab[c] / (sa2[c] + double(num) * 1e-9 * 0.5)) : 0.0f;
+        x = x >= 2.6f ? x - 2.6f : (x <= -2.6f ? x + 2.6f : 0.0f);
+        const int8_t v = int8_t(std::max(-128.0f, std::min(127.0f, std::round(x))));
+        (c == 0 ? f.ytox : f.ytob)[t] = v;
+      }
+    }
+  }
   // transform + quantise per group
   const size_t xg = DivCeil(xs, 256), yg = DivCeil(ys, 256);
   f.coeffs.assign(xg * yg, {});
@@ -2340,6 +2390,7 @@ struct JxlEncParams {
                            //     sigma parameters, and non-default DC dequantisation steps (valid streams, not tuned ones)
   int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS, bit 1 = LZ77
   int32_t noise;           // > 0: noise synthesis, see jxe::Params
+  int32_t cfl_fit;         // 1 = per-tile chroma-from-luma fit (the reference's fast FindBestMultiplier), see jxe::Params
 };
 
 // The next encoded streams embed this coded ICC profile of exactly `bits` bits (n = 0: none again). Test aid, not thread-safe.
@@ -2459,6 +2510,7 @@ int jxlenc_forward_cpu(void*, const uint8_t* rgb, size_t stride, const JxlHipEnc
   q.epf_iters = -1;
   q.gab = int32_t(d->gaborish);
   q.strategy_mode = int32_t(d->strategy_mode);
+  q.cfl_fit = int32_t(d->cfl_fit);
   q.seed = 1;
   std::vector<uint8_t> tight;
   if (stride != size_t(d->xsize) * 3) {
@@ -2475,6 +2527,8 @@ int jxlenc_forward_cpu(void*, const uint8_t* rgb, size_t stride, const JxlHipEnc
   if (f.global_scale != d->global_scale || f.quant_dc != d->quant_dc) return -3;  // the descriptor is not this distance's
   const size_t nb = f.xb * f.yb;
   memcpy(acs, f.acs.data(), nb);
+  if (d->ytox) memcpy(d->ytox, f.ytox.data(), f.ytox.size());
+  if (d->ytob) memcpy(d->ytob, f.ytob.data(), f.ytob.size());
   memcpy(qf, f.qf.data(), nb * 4);
   for (int c = 0; c < 3; c++) memcpy(dc + c * nb, f.dc[c].data(), nb * 4);
   for (size_t g = 0; g < f.coeffs.size(); g++) memcpy(coeffs + g * 3 * 65536, f.coeffs[g].data(), size_t(3) * 65536 * 4);

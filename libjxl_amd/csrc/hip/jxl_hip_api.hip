@@ -222,7 +222,7 @@ struct JxlHipContext {
   // output pixel format (jxlhip_set_output_format; JxlDataType numbering): RGB8 by default
   uint32_t out_type = 2, out_nc = 3, out_bits = 8, out_swap = 0;
   // forward (encoder) path, jxlhip_enc_forward: device buffers and the kernel time of the last call
-  Buf enc_rgb, enc_planes[3], enc_act, enc_acs, enc_qf, enc_off, enc_dc, enc_coef, enc_lut, enc_dq;
+  Buf enc_rgb, enc_planes[3], enc_act, enc_acs, enc_qf, enc_off, enc_dc, enc_coef, enc_lut, enc_dq, enc_ytox, enc_ytob;
   hipEvent_t enc_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // whole sequence; the transform kernel of its last pass
   bool enc_timed = false;
   jxlhip::EncFwd enc_last;     // the parameters of the last jxlhip_enc_forward (its input stays resident): jxlhip_enc_forward_rerun
@@ -407,7 +407,7 @@ static std::vector<Buf*> AllBufs(JxlHipContext* c) {
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes,
-                &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq};
+                &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob};
   for (auto& pb : c->pass_bufs)
     for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset, &pb.alias_packed}) all.push_back(b);
   return all;
@@ -2897,6 +2897,9 @@ int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, cons
       (r = c->enc_off.Ensure(nb * 4)) || (r = c->enc_dc.Ensure(3 * nb * 4)) || (r = c->enc_coef.Ensure(ng * 3 * 65536 * 4)) ||
       (r = c->enc_lut.Ensure(256 * 4)) || (r = c->enc_dq.Ensure(size_t(d->dequant_floats) * 4)))
     return r;
+  const size_t ntiles = size_t((P.xb + 7) / 8) * ((P.yb + 7) / 8);
+  if ((r = c->enc_ytox.Ensure(ntiles)) || (r = c->enc_ytob.Ensure(ntiles))) return r;
+  if (d->cfl_fit && getenv("JXLHIP_ENC_BLOCK_KERNEL")) return JXLHIP_ERR_UNSUPPORTED;  // (the tile kernel makes the fit)
   for (auto& b : c->enc_planes)
     if ((r = b.Ensure(3 * plane * 4))) return r;
   for (auto& ev : c->enc_ev)
@@ -2933,12 +2936,20 @@ int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, cons
   P.dc_step[1] = inv_quant_dc / 512.0f;
   P.dc_step[2] = inv_quant_dc / 256.0f;
   P.strategy_mode = d->strategy_mode;
+  P.cfl_fit = d->cfl_fit ? 1 : 0;
+  P.scale = float(d->global_scale) / 65536.0f;
+  P.ytox = c->enc_ytox.as<int8_t>();
+  P.ytob = c->enc_ytob.as<int8_t>();
+  HIP_TRY(hipMemsetAsync(c->enc_ytox.p, 0, ntiles, c->stream));
+  HIP_TRY(hipMemsetAsync(c->enc_ytob.p, 0, ntiles, c->stream));
   HIP_TRY(hipEventRecord(c->enc_ev[0], c->stream));
   if ((r = EncLaunch(c, P, d->gaborish != 0))) return r;
   c->enc_last = P;
   c->enc_last_gaborish = d->gaborish != 0;
   HIP_TRY(hipEventRecord(c->enc_ev[1], c->stream));
   c->enc_timed = true;
+  if (d->ytox) HIP_TRY(hipMemcpyAsync(d->ytox, c->enc_ytox.p, ntiles, hipMemcpyDeviceToHost, c->stream));
+  if (d->ytob) HIP_TRY(hipMemcpyAsync(d->ytob, c->enc_ytob.p, ntiles, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(acs, c->enc_acs.p, nb, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(qf, c->enc_qf.p, nb * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(dc, c->enc_dc.p, 3 * nb * 4, hipMemcpyDeviceToHost, c->stream));

@@ -31,6 +31,11 @@ struct EncFwd {
   float distance, quant_ac, inv_gs, x_dm, b_dm;
   float dc_step[3];
   uint32_t strategy_mode;
+  // chroma-from-luma fit per 64x64 tile (enc_chroma_from_luma.cc:128-151, 204-352): factors out, one int8 per tile
+  uint32_t cfl_fit;
+  float scale;  // Quantizer::Scale() = global_scale / 65536
+  int8_t* ytox;
+  int8_t* ytob;
 };
 
 // enc_xyb.cc:50-104: opsin absorbance matrix + bias, cube root, X = (L - M) / 2, Y = (L + M) / 2, B = S.
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
   float* const s_basis = s_basis_raw + 3;
   __shared__ uint32_t s_info[64], s_off[64];
   __shared__ int32_t s_qf[64];
+  __shared__ float s_red[8], s_cc;
   const uint32_t tiles_x = (P.xb + 7) / 8;
   const uint32_t bx0 = (blockIdx.x % tiles_x) * 8, by0 = (blockIdx.x / tiles_x) * 8, tid = threadIdx.x;
   const uint32_t w = min(8u, P.xb - bx0), h = min(8u, P.yb - by0);
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
   const uint32_t g = (by0 / 32) * P.xg + bx0 / 32;
   const size_t plane = size_t(P.xp) * P.yp, nb = size_t(P.xb) * P.yb;
   const float biases1 = 1.0f - 0.07005449891748593f, biases3 = 0.145f;
-  float ydeq[2][8];
+  float ydeq[2][8], ycoef[2][8];
   for (int ci = 0; ci < 3; ci++) {
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
     __syncthreads();
@@ -452,6 +458,58 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
         P.dc[2 * nb + di] = int32_t(lroundf((s - 1.0f * s_ydc[tid]) / P.dc_step[2]));
       }
     }
+    // chroma-from-luma factor of the tile for this channel: the least squares of the reference's fast FindBestMultiplier
+    // over the tile's AC coefficients (a = Y * w / 84, b = base * Y * w - chroma * w, w = Scale * 128 * qf / matrix)
+    float cc = c == 0 ? 0.0f : 1.0f;  // (the default factors: 0 on X, the base correlation 1 on B)
+    if (c == 1 || P.cfl_fit) {
+      float sa2 = 0.0f, sab = 0.0f;
+      for (uint32_t half = 0; half < 2; half++) {
+        const uint32_t cr = band * 2 + half, cell = cr * 8 + (col >> 3), info = s_info[cell];
+        if (info == 0xFFFFFFFFu) continue;
+        const uint32_t st = info >> 6, ox = info & 7, oy = (info >> 3) & 7;
+        const uint32_t cx = c_covered_x[st], cy = c_covered_y[st], R = cy * 8, C = cx * 8;
+        const uint32_t kx = col - ox * 8, ky0 = (cr - oy) * 8;
+        if (c == 1) {
+          for (uint32_t j = 0; j < 8; j++) ycoef[half][j] = s_px[(cr * 8 + j) * 64 + col];
+          continue;
+        }
+        const int kind = c_strategy_qtable[st];
+        const float* m = P.dequant + P.dq_offset[kind] + size_t(c) * P.dq_size[kind];
+        const float q = P.scale * 128.0f * float(s_qf[cell]);
+        for (uint32_t j = 0; j < 8; j++) {
+          const uint32_t ky = ky0 + j, k = R < C ? ky * C + kx : kx * R + ky;
+          if (ky < cy && kx < cx) continue;
+          const float w = q / m[k], yw = ycoef[half][j] * w;
+          const float a = (1.0f / 84) * yw, b = cc * yw - s_px[(cr * 8 + j) * 64 + col] * w;
+          sa2 += a * a;
+          sab += a * b;
+        }
+      }
+      if (c != 1) {
+        for (int d = 32; d > 0; d >>= 1) {
+          sa2 += __shfl_down(sa2, d, 64);
+          sab += __shfl_down(sab, d, 64);
+        }
+        if ((tid & 63) == 0) {
+          s_red[(tid >> 6) * 2] = sa2;
+          s_red[(tid >> 6) * 2 + 1] = sab;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const float ta2 = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]), tab = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+          uint32_t cells = 0;
+          for (int i = 0; i < 64; i++) cells += s_info[i] != 0xFFFFFFFFu;
+          const float num = float(cells * 64);
+          float x = cells ? -tab / (ta2 + num * 1e-9f * 0.5f) : 0.0f;
+          x = x >= 2.6f ? x - 2.6f : (x <= -2.6f ? x + 2.6f : 0.0f);
+          const float v = fmaxf(-128.0f, fminf(127.0f, roundf(x)));
+          (c == 0 ? P.ytox : P.ytob)[blockIdx.x] = int8_t(v);
+          s_cc = cc + v / 84.0f;
+        }
+        __syncthreads();
+        cc = s_cc;
+      }
+    }
     // quantisation of this thread's 2 x 8 coefficients
     for (uint32_t half = 0; half < 2; half++) {
       const uint32_t cr = band * 2 + half, cell = cr * 8 + (col >> 3), info = s_info[cell];
@@ -462,7 +520,6 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
       const int kind = c_strategy_qtable[st];
       const float scaled = P.inv_gs / float(s_qf[cell]);
       const float mulc = c == 0 ? scaled * P.x_dm : (c == 1 ? scaled : scaled * P.b_dm);
-      const float cc = c == 0 ? 0.0f : 1.0f;
       const float* m = P.dequant + P.dq_offset[kind] + size_t(c) * P.dq_size[kind];
       int32_t* dst = P.coeffs + (size_t(g) * 3 + c) * 65536 + s_off[cell];
       int32_t q[8];

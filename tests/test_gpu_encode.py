@@ -15,7 +15,8 @@ def _psnr(a, b):
 
 
 @pytest.mark.parametrize("size,kw", [((301, 143), {}), ((512, 512), dict(distance=2.0)), ((640, 333), dict(strategy_mode=0)),
-                                     ((257, 260), dict(gab=0, distance=0.5)), ((1000, 700), dict(distance=4.0))])
+                                     ((257, 260), dict(gab=0, distance=0.5)), ((1000, 700), dict(distance=4.0)),
+                                     ((777, 555), dict(cfl_fit=1)), ((640, 333), dict(cfl_fit=1, strategy_mode=0, distance=2.0))])
 def test_forward_path_matches_the_cpu_model(built, size, kw):
     """Same float expressions in the same order with contraction off: transform selection and quant field agree except
     where log2f / cbrtf differ in the last place, coefficients and DC except at rounding ties."""
@@ -31,15 +32,17 @@ def test_forward_path_matches_the_cpu_model(built, size, kw):
         assert (gpu["qf"] != cpu["qf"]).mean() < 0.005 and np.abs(gpu["qf"] - cpu["qf"]).max() <= 1
         assert np.abs(gpu["dc"] - cpu["dc"]).max() <= 1 and (gpu["dc"] != cpu["dc"]).mean() < 0.002
         diff = gpu["coeffs"] != cpu["coeffs"]
-        assert diff.mean() < 0.002, diff.mean()
-        if (gpu["qf"] == cpu["qf"]).all():
+        # (with the chroma-from-luma fit a tile whose least-squares factor lands on the other side of a rounding boundary,
+        # sums in another order, changes every X or B coefficient of that tile: still a small fraction)
+        assert diff.mean() < (0.01 if kw.get("cfl_fit") else 0.002), diff.mean()
+        if (gpu["qf"] == cpu["qf"]).all() and not kw.get("cfl_fit"):
             assert np.abs(gpu["coeffs"] - cpu["coeffs"]).max() <= 1
     nz = np.count_nonzero(gpu["coeffs"])
     assert 0.5 < nz / max(1, np.count_nonzero(cpu["coeffs"])) < 2.0
 
 
-@pytest.mark.parametrize("distance,floor", [(0.5, 39.0), (1.0, 37.0), (2.0, 33.5), (4.0, 30.5)])
-def test_gpu_encoded_stream_round_trips(built, distance, floor):
+@pytest.mark.parametrize("distance,floor,cfl", [(0.5, 39.0, 0), (1.0, 37.0, 0), (2.0, 33.5, 0), (4.0, 30.5, 0), (1.0, 37.3, 1)])
+def test_gpu_encoded_stream_round_trips(built, distance, floor, cfl):
     """Encode on the GPU, decode on the GPU and with the oracle: same pixels from both decoders, quality as the CPU
     writer's stream of the same image, size within a few percent of it."""
     import jxlo
@@ -47,10 +50,12 @@ def test_gpu_encoded_stream_round_trips(built, distance, floor):
     img = J.synth_image(777, 555, seed=17)
     ctx = J.HipContext()
     t = {}
-    data = J.encode_rgb8_gpu(img, ctx, timings=t, distance=distance)
+    data = J.encode_rgb8_gpu(img, ctx, timings=t, distance=distance, cfl_fit=cfl)
     ctx.close()
     assert t["kernels_ms"] > 0
-    ref = J.encode_rgb8(img, distance=distance)
+    ref = J.encode_rgb8(img, distance=distance, cfl_fit=cfl)
+    if cfl:  # the fit of enc_chroma_from_luma.cc pays: smaller than the stream with the default factors
+        assert len(data) < 0.99 * len(J.encode_rgb8(img, distance=distance))
     assert abs(len(data) - len(ref)) < 0.03 * len(ref)
     got = J.decode_rgb8(data)
     o = jxlo.Decoded(data, dumps=False)
