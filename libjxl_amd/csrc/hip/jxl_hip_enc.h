@@ -95,13 +95,26 @@ __global__ __launch_bounds__(256) void k_enc_sharpen4(const float* __restrict__ 
   const float w1 = 1.1f * 0.104699568f, w2 = 1.1f * 0.055680538f, nrm = 1.0f / (1.0f + 4 * (w1 + w2));
   float* y = s_a;
   float* t = s_b;
+  // a tile whose apron lies inside the image needs no clamping: the neighbours are the LDS neighbours
+  const bool interior = tx0 >= 0 && ty0 >= 0 && tx0 + LW <= int(xp) && ty0 + LH <= int(yp);
   for (int it = 1; it <= 4; it++) {
     for (int i = tid; i < LW * LH; i += 256) {
       const int lx = i % LW, ly = i / LW, gx = tx0 + lx, gy = ty0 + ly;  // (constant divisors)
       if (lx < it || ly < it || lx >= LW - it || ly >= LH - it) continue;
-      if (gx < 0 || gy < 0 || gx >= int(xp) || gy >= int(yp)) continue;
-      const int x0 = (gx ? gx - 1 : 0) - tx0, x1 = (gx + 1 < int(xp) ? gx + 1 : int(xp) - 1) - tx0;
-      const int y0 = ((gy ? gy - 1 : 0) - ty0) * LW, y1 = ((gy + 1 < int(yp) ? gy + 1 : int(yp) - 1) - ty0) * LW, yc = ly * LW;
+      int x0, x1, y0, y1;
+      const int yc = ly * LW;
+      if (interior) {
+        x0 = lx - 1;
+        x1 = lx + 1;
+        y0 = yc - LW;
+        y1 = yc + LW;
+      } else {
+        if (gx < 0 || gy < 0 || gx >= int(xp) || gy >= int(yp)) continue;
+        x0 = (gx ? gx - 1 : 0) - tx0;
+        x1 = (gx + 1 < int(xp) ? gx + 1 : int(xp) - 1) - tx0;
+        y0 = ((gy ? gy - 1 : 0) - ty0) * LW;
+        y1 = ((gy + 1 < int(yp) ? gy + 1 : int(yp) - 1) - ty0) * LW;
+      }
       const float side = y[yc + x0] + y[yc + x1] + y[y0 + lx] + y[y1 + lx];
       const float corner = y[y0 + x0] + y[y0 + x1] + y[y1 + x0] + y[y1 + x1];
       const float centre = y[yc + lx];
