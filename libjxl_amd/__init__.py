@@ -448,6 +448,22 @@ def set_embedded_icc(coded=None):
     E.jxlenc_set_embedded_icc(coded, len(coded), bits)
 
 
+def set_color_encoding(white_point=None, primaries=1, transfer_function=13, gamma=None, intent=1, xy=None):
+    """Test aid: the next LOSSLESS streams declare this enum colour encoding (values of jxl/color_encoding.h: white point
+    1 D65 / 2 custom / 10 E / 11 DCI; primaries 1 sRGB / 2 custom / 9 Rec.2100 / 11 P3; transfer function 1 709 / 8 linear /
+    13 sRGB / 16 PQ / 17 DCI / 18 HLG, or gamma as a float; xy = 8 custom chromaticities white, red, green, blue).
+    white_point=None: sRGB again."""
+    E = _enc_lib()
+    E.jxlenc_set_color_encoding.argtypes = [ctypes.c_int] + [ctypes.c_uint32] * 6 + [ctypes.POINTER(ctypes.c_int32)]
+    E.jxlenc_set_color_encoding.restype = None
+    if white_point is None:
+        E.jxlenc_set_color_encoding(0, 1, 1, 0, 0, 13, 1, None)
+        return
+    arr = (ctypes.c_int32 * 8)(*[int(round(v * 1e6)) for v in (xy or [0] * 8)])
+    E.jxlenc_set_color_encoding(1, white_point, primaries, 1 if gamma is not None else 0, int(round((gamma or 0) * 1e7)), transfer_function,
+                                intent, arr)
+
+
 def set_orientation(orientation=1):
     """Test aid: the synthetic encoders declare this image orientation (1..8, EXIF numbering) in the streams they write
     from now on (1: none again)."""

@@ -1506,18 +1506,36 @@ JxlDecoderStatus JxlDecoderGetColorAsEncodedProfile(const JxlDecoder* d, JxlColo
   if (EmbeddedIcc(d, target)) return JXL_DEC_ERROR;  // (decode.h:728-730: only the ICC form exists then)
   if (ce) {
     memset(ce, 0, sizeof(*ce));
-    ce->color_space = d->ih.gray ? JXL_COLOR_SPACE_GRAY : JXL_COLOR_SPACE_RGB;
-    ce->white_point = JXL_WHITE_POINT_D65;
-    ce->white_point_xy[0] = 0.3127;
-    ce->white_point_xy[1] = 0.3290;
-    ce->primaries = JXL_PRIMARIES_SRGB;
-    ce->primaries_red_xy[0] = 0.639998686; ce->primaries_red_xy[1] = 0.330010138;
-    ce->primaries_green_xy[0] = 0.300003784; ce->primaries_green_xy[1] = 0.600003357;
-    ce->primaries_blue_xy[0] = 0.150002046; ce->primaries_blue_xy[1] = 0.059997204;
+    // the fields as coded (color_encoding_internal.cc:144-200; enum xy values: color_encoding_cms.h); an XYB image is
+    // always (linear) sRGB here, anything else was refused with the headers
+    const jxh::ImageHeader& ih = d->ih;
+    ce->color_space = ih.gray ? JXL_COLOR_SPACE_GRAY : JXL_COLOR_SPACE_RGB;
+    ce->white_point = JxlWhitePoint(ih.white_point);
+    switch (ih.white_point) {
+      case 2: ce->white_point_xy[0] = ih.white_xy[0] * 1e-6; ce->white_point_xy[1] = ih.white_xy[1] * 1e-6; break;
+      case 10: ce->white_point_xy[0] = ce->white_point_xy[1] = 1.0 / 3; break;
+      case 11: ce->white_point_xy[0] = 0.314; ce->white_point_xy[1] = 0.351; break;
+      default: ce->white_point_xy[0] = 0.3127; ce->white_point_xy[1] = 0.3290; break;
+    }
+    ce->primaries = JxlPrimaries(ih.primaries);
+    static const double kSrgb[6] = {0.639998686, 0.330010138, 0.300003784, 0.600003357, 0.150002046, 0.059997204};
+    static const double k2100[6] = {0.708, 0.292, 0.170, 0.797, 0.131, 0.046};
+    static const double kP3[6] = {0.680, 0.320, 0.265, 0.690, 0.150, 0.060};
+    double xy[6];
+    for (int i = 0; i < 6; i++) xy[i] = ih.primaries == 2 ? ih.primaries_xy[i] * 1e-6 : (ih.primaries == 9 ? k2100[i] : (ih.primaries == 11 ? kP3[i] : kSrgb[i]));
+    ce->primaries_red_xy[0] = xy[0]; ce->primaries_red_xy[1] = xy[1];
+    ce->primaries_green_xy[0] = xy[2]; ce->primaries_green_xy[1] = xy[3];
+    ce->primaries_blue_xy[0] = xy[4]; ce->primaries_blue_xy[1] = xy[5];
     // the pixels (target DATA) follow JxlDecoderSetOutputColorProfile; the original profile is what the stream says
-    const bool linear = target == JXL_COLOR_PROFILE_TARGET_DATA && d->want_linear >= 0 ? d->want_linear != 0 : d->ih.linear_tf;
-    ce->transfer_function = linear ? JXL_TRANSFER_FUNCTION_LINEAR : JXL_TRANSFER_FUNCTION_SRGB;
-    ce->rendering_intent = JXL_RENDERING_INTENT_RELATIVE;
+    if (target == JXL_COLOR_PROFILE_TARGET_DATA && d->want_linear >= 0) {
+      ce->transfer_function = d->want_linear ? JXL_TRANSFER_FUNCTION_LINEAR : JXL_TRANSFER_FUNCTION_SRGB;
+    } else if (ih.have_gamma) {
+      ce->transfer_function = JXL_TRANSFER_FUNCTION_GAMMA;
+      ce->gamma = ih.gamma * 1e-7;
+    } else {
+      ce->transfer_function = JxlTransferFunction(ih.transfer_function);
+    }
+    ce->rendering_intent = JxlRenderingIntent(ih.rendering_intent);
   }
   return JXL_DEC_SUCCESS;
 }

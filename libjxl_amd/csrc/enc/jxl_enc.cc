@@ -763,6 +763,40 @@ struct LayerState {
   uint32_t mode = 0, alpha_mode = 0, source = 0, alpha_source = 0, clamp = 0, save_as = 0;
 };
 static LayerState g_layer;
+// jxlenc_set_color_encoding: the enum ColorEncoding the next LOSSLESS streams declare (color_encoding_internal.cc:144-200):
+// white point / primaries / transfer function values of color_encoding.h (2 = custom xy in millionths; have_gamma with
+// gamma in 1e-7), rendering intent. The samples are written as given: a non-XYB image's colour encoding is metadata.
+struct ColorState {
+  bool enabled = false;
+  uint32_t white_point = 1, primaries = 1, have_gamma = 0, gamma = 0, transfer_function = 13, intent = 1;
+  int32_t xy[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // white, red, green, blue
+};
+static ColorState g_color;
+static void WriteEnum(BitWriter& bw, uint32_t v) {  // U32(Val(0), Val(1), BitsOffset(4, 2), BitsOffset(6, 18))
+  static const uint32_t b[4] = {0, 0, 4, 6}, o[4] = {0, 1, 2, 18};
+  WriteU32Sel(bw, v, b, o);
+}
+static void WriteCustomXy(BitWriter& bw, const int32_t* xy) {
+  static const uint32_t b[4] = {19, 19, 20, 21}, o[4] = {0, 524288, 1048576, 2097152};
+  for (int i = 0; i < 2; i++) WriteU32Sel(bw, xy[i] >= 0 ? uint32_t(xy[i]) * 2 : uint32_t(-(xy[i] + 1)) * 2 + 1, b, o);
+}
+static void WriteColorEncodingFields(BitWriter& bw, bool gray) {
+  const ColorState& C = g_color;
+  bw.Write(1, 0);  // not all_default
+  bw.Write(1, 0);  // no ICC
+  WriteEnum(bw, gray ? 1 : 0);
+  WriteEnum(bw, C.white_point);
+  if (C.white_point == 2) WriteCustomXy(bw, C.xy);
+  if (!gray) {
+    WriteEnum(bw, C.primaries);
+    if (C.primaries == 2)
+      for (int c = 0; c < 3; c++) WriteCustomXy(bw, C.xy + 2 + 2 * c);
+  }
+  bw.Write(1, C.have_gamma ? 1 : 0);
+  if (C.have_gamma) bw.Write(24, C.gamma);
+  else WriteEnum(bw, C.transfer_function);
+  WriteEnum(bw, C.intent);
+}
 // jxlenc_set_alpha_premultiplied: the alpha channel is declared associated (ExtraChannelInfo.alpha_associated,
 // image_metadata.cc:158-200); the samples are written as given.
 static bool g_alpha_premultiplied = false;
@@ -2317,6 +2351,8 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
     bw.Write(1, 0);  // not all_default
     bw.Write(1, 1);  //   want_icc
     bw.Write(2, 0);  //   colour space RGB
+  } else if (g_color.enabled) {
+    WriteColorEncodingFields(bw, gray);
   } else if (!gray) {
     bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
   } else {
@@ -2432,6 +2468,17 @@ void jxlenc_set_layer(int enabled, int32_t x0, int32_t y0, uint32_t canvas_w, ui
   jxe::g_layer.clamp = clamp;
   jxe::g_layer.save_as = save_as;
   jxe::g_anim.timed = timed != 0;
+}
+void jxlenc_set_color_encoding(int enabled, uint32_t white_point, uint32_t primaries, uint32_t have_gamma, uint32_t gamma,
+                               uint32_t transfer_function, uint32_t intent, const int32_t* xy8) {
+  jxe::g_color.enabled = enabled != 0;
+  jxe::g_color.white_point = white_point;
+  jxe::g_color.primaries = primaries;
+  jxe::g_color.have_gamma = have_gamma;
+  jxe::g_color.gamma = gamma;
+  jxe::g_color.transfer_function = transfer_function;
+  jxe::g_color.intent = intent;
+  for (int i = 0; i < 8; i++) jxe::g_color.xy[i] = xy8 ? xy8[i] : 0;
 }
 void jxlenc_set_alpha_premultiplied(int premultiplied) { jxe::g_alpha_premultiplied = premultiplied != 0; }
 // Byte offset of the frame header in the stream written last (signature + image header come before it).

@@ -34,6 +34,10 @@ struct ImageHeader {
   std::vector<ExtraChannel> extra;
   bool xyb_encoded = true;
   bool gray = false;
+  // ColorEncoding as coded (enum values of color_encoding.h); custom xy in millionths, gamma in 1e-7
+  uint32_t white_point = 1, primaries = 1, transfer_function = 13, rendering_intent = 1, gamma = 0;
+  bool have_gamma = false;
+  int32_t white_xy[2] = {0, 0}, primaries_xy[6] = {0, 0, 0, 0, 0, 0};
   bool linear_tf = false;  // output transfer function: false = sRGB, true = linear
   bool want_icc = false;   // an ICC profile is embedded (the oracle skips it: it only checks pixels)
   bool have_animation = false, have_timecodes = false;
@@ -81,26 +85,47 @@ static inline uint32_t AspectRatioX(uint32_t ysize, uint32_t ratio) {
 
 static inline void ReadColorEncoding(BitReader& br, ImageHeader* h) {
   if (br.ReadBool()) return;  // all_default: sRGB
-  const bool want_icc = br.ReadBool();
-  h->want_icc = want_icc;
+  h->want_icc = br.ReadBool();
   uint32_t cs = ReadEnum(br);  // 0 RGB, 1 Gray, 2 XYB, 3 Unknown
-  // (an embedded ICC profile describes the original colours; the enum fields are absent then,
-  // color_encoding_internal.cc:151-158, and the coded profile follows the headers: SkipIcc)
   JXLO_CHECK(cs == 0 || cs == 1, "unsupported: colour space");
   h->gray = cs == 1;
-  if (want_icc) return;
-  uint32_t wp = ReadEnum(br);
-  JXLO_CHECK(wp == 1, "unsupported: white point");
+  // an embedded ICC profile describes the ORIGINAL colours (it follows the headers: ReadImageHeader); the enum fields are
+  // absent then (color_encoding_internal.cc:151-158). XYB images are still decoded to sRGB, the others keep their samples.
+  if (h->want_icc) return;
+  // color_encoding_internal.cc:144-200: white point, primaries (custom ones as signed millionths), transfer function or
+  // gamma, rendering intent. Kept as coded: they describe samples that pass through unchanged when the image is not XYB.
+  auto custom_xy = [&](int32_t* xy) {
+    for (int i = 0; i < 2; i++) {
+      const uint32_t u = ReadU32(br, Bits(19), BitsOffset(19, 524288), BitsOffset(20, 1048576), BitsOffset(21, 2097152));
+      xy[i] = (u & 1) ? -int32_t((u + 1) >> 1) : int32_t(u >> 1);
+    }
+  };
+  h->white_point = ReadEnum(br);
+  JXLO_CHECK(h->white_point == 1 || h->white_point == 2 || h->white_point == 10 || h->white_point == 11, "invalid white point");
+  if (h->white_point == 2) custom_xy(h->white_xy);
   if (cs == 0) {
-    uint32_t prim = ReadEnum(br);
-    JXLO_CHECK(prim == 1, "unsupported: primaries");
+    h->primaries = ReadEnum(br);
+    JXLO_CHECK(h->primaries == 1 || h->primaries == 2 || h->primaries == 9 || h->primaries == 11, "invalid primaries");
+    if (h->primaries == 2)
+      for (int c = 0; c < 3; c++) custom_xy(h->primaries_xy + 2 * c);
   }
-  bool have_gamma = br.ReadBool();
-  JXLO_CHECK(!have_gamma, "unsupported: gamma transfer function");
-  uint32_t tf = ReadEnum(br);
-  JXLO_CHECK(tf == 13 || tf == 8, "unsupported: transfer function");
-  h->linear_tf = tf == 8;
-  (void)ReadEnum(br);  // rendering intent
+  h->have_gamma = br.ReadBool();
+  if (h->have_gamma) {
+    h->gamma = uint32_t(br.Read(24));  // in units of 1e-7 (kGammaMul)
+    JXLO_CHECK(h->gamma <= 10000000 && uint64_t(h->gamma) * 8192 >= 10000000, "invalid gamma");
+  } else {
+    h->transfer_function = ReadEnum(br);
+    JXLO_CHECK(h->transfer_function == 1 || h->transfer_function == 8 || h->transfer_function == 13 || h->transfer_function == 16 ||
+            h->transfer_function == 17 || h->transfer_function == 18, "unsupported: transfer function");
+  }
+  h->rendering_intent = ReadEnum(br);
+  JXLO_CHECK(h->rendering_intent <= 3, "invalid rendering intent");
+  h->linear_tf = !h->have_gamma && h->transfer_function == 8;
+  // an XYB image is rendered by the colour stage here, which knows sRGB primaries with the sRGB curve or none
+  // (dec_xyb.cc:181-250 does the other enum spaces; no CMS here): anything else is refused rather than mis-rendered
+  if (h->xyb_encoded)
+    JXLO_CHECK(h->white_point == 1 && (cs == 1 || h->primaries == 1) && !h->have_gamma && (h->transfer_function == 13 || h->transfer_function == 8),
+            "unsupported: XYB image in a colour space other than (linear) sRGB");
 }
 
 // The coded ICC profile (lib/jxl/icc_codec.cc:306-428): an entropy-coded byte stream whose length is only known once it

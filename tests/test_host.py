@@ -420,3 +420,54 @@ def test_context_model_tables_match_the_reference_source():
         assert _c_array(path, "kCoveredX") == ref["covered_blocks_x"] and _c_array(path, "kCoveredY") == ref["covered_blocks_y"], path
         assert _c_array(path, "kStrategyQuantTable") == ref["strategy_to_quant_table"], path
     assert _c_array("libjxl_amd/csrc/hip/jxl_hip_kernels.h", "c_strategy_qtable") == ref["strategy_to_quant_table"]
+
+
+def test_enum_colour_encodings_of_lossless_images_are_reported(built):
+    """A non-XYB image's colour encoding is metadata: the samples pass through, JxlDecoderGetColorAsEncodedProfile hands the
+    coded fields out (color_encoding_internal.cc:144-200: Rec.2100 PQ; custom chromaticities with a gamma)."""
+    import ctypes
+
+    class CE(ctypes.Structure):
+        _fields_ = [("color_space", ctypes.c_int), ("white_point", ctypes.c_int), ("white_point_xy", ctypes.c_double * 2),
+                    ("primaries", ctypes.c_int), ("red", ctypes.c_double * 2), ("green", ctypes.c_double * 2), ("blue", ctypes.c_double * 2),
+                    ("transfer_function", ctypes.c_int), ("gamma", ctypes.c_double), ("rendering_intent", ctypes.c_int)]
+
+    J = built
+    L = J.lib()
+    vp = ctypes.c_void_p
+    L.JxlDecoderCreate.restype = vp
+    L.JxlDecoderCreate.argtypes = [vp]
+    for n in ("JxlDecoderDestroy", "JxlDecoderProcessInput", "JxlDecoderCloseInput"):
+        getattr(L, n).argtypes = [vp]
+    L.JxlDecoderSubscribeEvents.argtypes = [vp, ctypes.c_int]
+    L.JxlDecoderSetInput.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    L.JxlDecoderGetColorAsEncodedProfile.argtypes = [vp, ctypes.c_int, ctypes.POINTER(CE)]
+    img = J.synth_image(64, 48, seed=2)
+
+    def encoded_profile(**kw):
+        J.set_color_encoding(**kw)
+        try:
+            data = J.encode_lossless(img)
+        finally:
+            J.set_color_encoding(None)
+        J.ModFrame(data).close()  # the front-end plans it like any lossless frame
+        dec = L.JxlDecoderCreate(None)
+        L.JxlDecoderSubscribeEvents(dec, 0x100)
+        L.JxlDecoderSetInput(dec, data, len(data))
+        L.JxlDecoderCloseInput(dec)
+        assert L.JxlDecoderProcessInput(dec) == 0x100
+        ce = CE()
+        assert L.JxlDecoderGetColorAsEncodedProfile(dec, 0, ctypes.byref(ce)) == 0
+        L.JxlDecoderDestroy(dec)
+        return ce
+
+    ce = encoded_profile(white_point=1, primaries=9, transfer_function=16, intent=0)
+    assert (ce.color_space, ce.white_point, ce.primaries, ce.transfer_function, ce.rendering_intent) == (0, 1, 9, 16, 0)
+    assert tuple(ce.red) == (0.708, 0.292) and tuple(ce.blue) == (0.131, 0.046)
+    xy = [0.31, 0.33, 0.64, 0.33, 0.3, 0.6, 0.15, 0.06]
+    ce = encoded_profile(white_point=2, primaries=2, gamma=0.45455, xy=xy)
+    assert (ce.white_point, ce.primaries, ce.transfer_function) == (2, 2, 65535) and abs(ce.gamma - 0.45455) < 1e-7
+    got = list(ce.white_point_xy) + list(ce.red) + list(ce.green) + list(ce.blue)
+    assert max(abs(a - b) for a, b in zip(got, xy)) < 1e-6
+    ce = encoded_profile(white_point=11, primaries=11, transfer_function=17)  # DCI white, P3, DCI transfer function
+    assert abs(ce.white_point_xy[0] - 0.314) < 1e-9 and tuple(ce.green) == (0.265, 0.690) and ce.transfer_function == 17
