@@ -1386,8 +1386,10 @@ JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t s
 size_t JxlDecoderReleaseInput(JxlDecoder* d) {
   if (!d->in) return 0;
   size_t remaining = d->in_size - d->in_pos;
-  if (d->container == 0 && (d->frame || d->mframe) && d->stage >= 5) {
-    // bare codestream: bytes behind the last frame were copied along but are not part of it
+  if (d->container == 0 && (d->frame || d->mframe) && d->stage >= 5 &&
+      (d->frame ? d->frame->plan.fh.is_last : d->mframe->plan.fh.is_last)) {
+    // bare codestream: bytes behind the LAST frame were copied along but are not part of it (behind any other frame
+    // the next frame follows: those bytes are consumed)
     const uint64_t cs_end = d->frame ? d->frame->plan.frame_end : d->mframe->plan.frame_end;
     const uint64_t given = d->file_pos + d->in_pos;
     if (given > cs_end) remaining = size_t(std::min<uint64_t>(d->in_size, given - cs_end));

@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[3], "u16")) format.data_type = JXL_TYPE_UINT16;
   if (!strcmp(argv[3], "f16")) format.data_type = JXL_TYPE_FLOAT16;
   if (!strcmp(argv[3], "f32")) format.data_type = JXL_TYPE_FLOAT;
-  int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0, multi = 0, frames_done = 0;
+  int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0, multi = 0, frames_done = 0, swap = 0;
   size_t skip = 0;
   uint8_t* ec_pixels[4] = {NULL, NULL, NULL, NULL};
   size_t ec_sizes[4] = {0, 0, 0, 0};
@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "callback")) use_callback = 1;
     if (!strcmp(argv[i], "mt")) use_mt = 1;
     if (!strcmp(argv[i], "linear")) linear = 1;
+    if (!strcmp(argv[i], "swap")) swap = 1; /* hand the input back and in again after every frame (decode.h: JxlDecoderReleaseInput) */
     if (!strcmp(argv[i], "frames")) multi = 1; /* animation: every frame's pixels are appended to the output file */
     if (!strncmp(argv[i], "skip=", 5)) skip = (size_t)atol(argv[i] + 5); /* JxlDecoderSkipFrames before decoding */
     if (!strcmp(argv[i], "keep")) keep = 1; /* the pixels as coded, the orientation left to the caller */
@@ -215,6 +216,16 @@ int main(int argc, char** argv) {
         fwrite(g_pixels, 1, g_stride * info.ysize, o);
         fclose(o);
         frames_done++;
+      }
+      if (swap) {
+        size_t left = JxlDecoderReleaseInput(dec);
+        consumed += given - left;
+        given = size - consumed;
+        printf("swap consumed=%zu\n", consumed);
+        if (given) {
+          if (JxlDecoderSetInput(dec, bytes + consumed, given) != JXL_DEC_SUCCESS) return 2;
+          JxlDecoderCloseInput(dec);
+        }
       }
     } else if (st == JXL_DEC_SUCCESS) {
       printf("event SUCCESS\n");

@@ -141,7 +141,8 @@ def test_every_frame_of_an_animation_through_the_gpu(built, tmp_path, lossless):
         want.append(o.rgb8.copy())
         o.close()
     tol = 0 if lossless else 1
-    for stream, extra in ((data, ()), (R.container(data), ("chunk=3000",))):
+    # (whole; in a container in pieces; the input handed back and in again after every frame)
+    for stream, extra in ((data, ()), (R.container(data), ("chunk=3000",)), (data, ("swap",))):
         rc, events, out, px = R.run(stream, tmp_path, "u8", 4, "frames", *extra)
         assert rc == 0, out
         assert [e for e in events if e in ("FRAME", "NEED_IMAGE_OUT_BUFFER", "FULL_IMAGE")] == ["FRAME", "NEED_IMAGE_OUT_BUFFER", "FULL_IMAGE"] * 3, out
