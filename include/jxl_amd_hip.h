@@ -356,6 +356,11 @@ int jxlhip_canvas_download(JxlHipCanvas* canvas, uint32_t data_type, uint32_t nu
 /* The canvas alpha plane as floats (xsize * ysize, not oriented). Synchronous. */
 int jxlhip_canvas_download_alpha(JxlHipCanvas* canvas, float* dst, size_t n);
 
+/* Test entry: the blend kernel alone on `n` caller-supplied samples: bg planar [4][n] (R, G, B, alpha), fg interleaved
+ * [n][4], out planar [4][n]; for the reference's own blending vectors (lib/jxl/alpha_test.cc) against the kernel itself. */
+int jxlhip_debug_blend(int device, const float* bg, const float* fg, size_t n, const JxlHipBlend* blend, uint32_t has_alpha,
+                       uint32_t alpha_premultiplied, float* out);
+
 /* ---- Forward path (first slice): the pixel-domain half of a VarDCT encode on the device.
  * Replaces, behind lib/jxl/enc_frame.cc:1135-1166's per-group loop: SRGBToXYB (enc_xyb.cc:152-174), the Gaborish
  * sharpening (enc_gaborish.cc:21-70) and ComputeCoefficients (enc_group.cc:380-533: forward transform, DC from the

@@ -2793,6 +2793,45 @@ int jxlhip_canvas_blend(JxlHipCanvas* v, JxlHipContext* c, const JxlHipBlend* b)
   return 0;
 }
 
+int jxlhip_debug_blend(int device, const float* bg, const float* fg, size_t n, const JxlHipBlend* b, uint32_t has_alpha, uint32_t premultiplied,
+                       float* out) {
+  if (!bg || !fg || !b || !out || !n || n > (1u << 20) || b->mode > 4 || b->alpha_mode > 4) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(device));
+  Buf dbg, dfg, dout;
+  int r;
+  if ((r = dbg.Ensure(n * 16)) || (r = dfg.Ensure(n * 16)) || (r = dout.Ensure(n * 16))) {
+    dbg.Free();
+    dfg.Free();
+    dout.Free();
+    return r;
+  }
+  hipError_t e = hipMemcpy(dbg.p, bg, n * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dfg.p, fg, n * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    jxlhip::BlendParams P;
+    memset(&P, 0, sizeof(P));
+    P.out = dout.as<float>();
+    P.bg_color = dbg.as<float>();
+    P.bg_alpha = dbg.as<float>();
+    P.fg = dfg.as<float>();
+    P.w = P.fw = uint32_t(n);
+    P.h = P.fh = 1;
+    P.mode = b->mode;
+    P.alpha_mode = b->alpha_mode;
+    P.clamp = b->clamp;
+    P.alpha_clamp = b->alpha_clamp;
+    P.has_alpha = has_alpha;
+    P.premultiplied = premultiplied;
+    hipLaunchKernelGGL(jxlhip::k_canvas_blend, dim3((uint32_t(n) + 255) / 256, 1), dim3(256), 0, nullptr, P);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, dout.p, n * 16, hipMemcpyDeviceToHost);
+  }
+  dbg.Free();
+  dfg.Free();
+  dout.Free();
+  return e == hipSuccess ? 0 : -int(e);
+}
+
 int jxlhip_canvas_download(JxlHipCanvas* v, uint32_t data_type, uint32_t num_channels, uint32_t bits, int big_endian, uint32_t orientation,
                            void* dst, size_t stride) {
   if (!v || !dst || num_channels < 1 || num_channels > 4 || orientation < 1 || orientation > 8) return JXLHIP_ERR_INVALID_ARGUMENT;

@@ -126,3 +126,42 @@ def test_animation_of_deltas_over_the_previous_canvas(built, tmp_path):
     rc, events, out, px = R.run(R.container(data), tmp_path, "u8", 4, "frames", "skip=2", "chunk=5000")
     assert rc == 0 and events.count("FULL_IMAGE") == 1, out
     assert np.array_equal(np.frombuffer(px, np.uint8).reshape(H, W, 4), want[2][0])
+
+
+@pytest.mark.gpu
+def test_reference_alpha_blending_vectors_on_the_kernel(built):
+    """lib/jxl/alpha_test.cc:25-86 (BlendingWithNonPremultiplied, BlendingWithPremultiplied, Mul): the reference's own
+    known answers for PerformAlphaBlending / PerformMulBlending, through k_canvas_blend itself (jxlhip_debug_blend)."""
+    import ctypes
+    J = built
+    L = J.lib()
+
+    class Blend(ctypes.Structure):
+        _fields_ = [("x0", ctypes.c_int32), ("y0", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in (
+            "mode", "alpha_mode", "source", "alpha_source", "clamp", "alpha_clamp")] + [("save_slot", ctypes.c_int32)]
+
+    L.jxlhip_debug_blend.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(Blend), ctypes.c_uint32,
+                                     ctypes.c_uint32, ctypes.c_void_p]
+
+    def blend(bg, fg, mode, alpha_mode, premultiplied, clamp):
+        bgp = np.ascontiguousarray(np.array(bg, np.float32).reshape(4, 1))
+        fgp = np.ascontiguousarray(np.array(fg, np.float32).reshape(1, 4))
+        out = np.zeros((4, 1), np.float32)
+        b = Blend(0, 0, mode, alpha_mode, 0, 0, clamp, clamp, -1)
+        assert L.jxlhip_debug_blend(0, bgp.ctypes.data, fgp.ctypes.data, 1, ctypes.byref(b), 1, premultiplied, out.ctypes.data) == 0
+        return out[:, 0]
+
+    bg = [100, 110, 120, 180.0 / 255]
+    fg, fg2 = [25, 21, 23, 15420.0 / 65535], [25, 21, 23, 2.0]
+    o = blend(bg, fg, 2, 2, 0, 0)
+    assert np.abs(o[:3] - [77.2, 83.0, 90.6]).max() < 0.05 and abs(o[3] - 3174.0 / 4095) < 1e-5
+    o = blend(bg, fg2, 2, 2, 0, 1)
+    assert np.abs(o[:3] - fg2[:3]).max() < 0.05 and abs(o[3] - 1.0) < 1e-5
+    o = blend(bg, fg, 2, 2, 1, 0)
+    assert np.abs(o[:3] - [101.5, 105.1, 114.8]).max() < 0.05 and abs(o[3] - 3174.0 / 4095) < 1e-5
+    o = blend(bg, fg2, 2, 2, 1, 1)
+    assert np.abs(o[:3] - fg2[:3]).max() < 0.05 and abs(o[3] - 1.0) < 1e-5
+    o = blend([100, 100, 100, 1], [25, 25, 25, 1], 4, 0, 0, 0)
+    assert np.abs(o[:3] - 2500).max() < 0.05
+    o = blend([100, 100, 100, 1], [25, 25, 25, 1], 4, 0, 0, 1)
+    assert np.abs(o[:3] - 100).max() < 0.05
