@@ -9,7 +9,10 @@
 //            transforms, to exactly the raw interleaved 8-bit samples it was made from.
 //   icc ENC ICC   (product only) the reference's own ICC codec vector (icc_codec_test.cc:52-211): the coded stream ENC must
 //            decode to the profile ICC byte for byte, and damaged copies of it must be rejected, not crash.
-// usage: host_kats {alias|hybrid|lehmer|fjxl ...|icc ...};  exit code 0 = pass, message on stderr otherwise.
+//   fastmath the error bars of the reference's own fast_math_test.cc:46-111 on this front-end's FastLog2f / FastPow2f /
+//            FastPowf (they shape the dequantisation tables, quant_weights.cc) and the splines' FastCosf, over the ranges
+//            the reference samples (2^20 draws each).
+// usage: host_kats {alias|hybrid|lehmer|fastmath|fjxl ...|icc ...};  exit code 0 = pass, message on stderr otherwise.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,12 +24,16 @@
 #include "../../oracle/jxlo_entropy.h"
 #include "../../oracle/jxlo_headers.h"
 #include "../../oracle/jxlo_modular.h"
+#include "../../oracle/jxlo_splines.h"
+#include "../../oracle/jxlo_vardct.h"
 namespace H = jxlo;
 #else
 #include "../../libjxl_amd/csrc/host/jxh_bits.h"
 #include "../../libjxl_amd/csrc/host/jxh_entropy.h"
 #include "../../libjxl_amd/csrc/host/jxh_headers.h"
 #include "../../libjxl_amd/csrc/host/jxh_modular.h"
+#include "../../libjxl_amd/csrc/host/jxh_splines.h"
+#include "../../libjxl_amd/csrc/host/jxh_vardct.h"
 namespace H = jxh;
 #endif
 
@@ -340,12 +347,32 @@ static int TestIcc(const char* enc_path, const char* icc_path) {
 }
 #endif
 
+static float Uniform(float lo, float hi) { return lo + (hi - lo) * float(Rnd(1u << 24)) / float(1u << 24); }
+static int FastMathKat() {
+  for (int i = 0; i < (1 << 20); i++) {
+    const float f = Uniform(1e-7f, 1e3f);
+    REQUIRE(std::fabs(std::log2(f) - H::FastLog2f(f)) < 3.1e-6f, "FastLog2f(%g)", f);
+    const float g = Uniform(-100.0f, 100.0f), e2 = std::pow(2.0f, g);
+    REQUIRE(std::fabs(e2 - H::FastPow2f(g)) / e2 < 3.1e-6f, "FastPow2f(%g)", g);
+    const float b = Uniform(1e-3f, 1e3f), e = Uniform(-10.0f, 10.0f), ex = std::pow(b, e);
+    REQUIRE(std::fabs(ex - H::FastPowf(b, e)) / ex < 3e-5f, "FastPowf(%g, %g)", b, e);
+    const float c = Uniform(-1e3f, 1e3f);
+    REQUIRE(std::fabs(std::cos(c) - H::SplineFastCos(c)) < 7e-5f, "FastCosf(%g)", c);
+#ifdef KAT_ORACLE  // (the product draws splines on the device: its FastErff is compared with this one to 1e-6 by the GPU tests)
+    const float r = Uniform(-5.0f, 5.0f);
+    REQUIRE(std::fabs(std::erf(r) - H::SplineFastErf(r)) < 7e-4f, "FastErff(%g)", r);
+#endif
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string t = argv[1];
   if (t == "alias") return TestAlias();
   if (t == "hybrid") return TestHybrid();
   if (t == "lehmer") return TestLehmer();
+  if (t == "fastmath") return FastMathKat();
 #ifndef KAT_ORACLE
   if (t == "icc" && argc == 4) return TestIcc(argv[2], argv[3]);
 #endif

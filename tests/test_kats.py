@@ -32,7 +32,7 @@ def _binary(which):
 
 
 @pytest.mark.parametrize("which", ["product", "oracle"])
-@pytest.mark.parametrize("kat", ["alias", "hybrid", "lehmer"])
+@pytest.mark.parametrize("kat", ["alias", "hybrid", "lehmer", "fastmath"])
 def test_reference_closed_form_kats(which, kat):
     r = subprocess.run([_binary(which), kat], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
