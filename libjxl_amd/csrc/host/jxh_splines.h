@@ -172,6 +172,9 @@ static inline void InitSplineDrawCache(Splines* s, size_t xsize, size_t ysize, f
     }
     total_area += width_estimate * manhattan;
     JXH_CHECK(total_area <= area_limit, "splines cover too large an area");
+    // The reference only warns beyond this (splines.cc:688-698) and fails in its fuzzing build: a few bytes of stream can
+    // otherwise ask for gigabytes of segments. Here it is a refusal.
+    JXH_CHECK(total_area <= std::min<uint64_t>(8 * image_size + (uint64_t(1) << 25), uint64_t(1) << 30), "splines cover too large an area");
     for (size_t i = 0; i + 1 < cp.size(); i++) JXH_CHECK(cp[i].x != cp[i + 1].x || cp[i].y != cp[i + 1].y, "identical successive control points");
     // centripetal Catmull-Rom through the control points, 16 samples per span (splines.cc:326-367)
     std::vector<SplinePoint> inter;
@@ -229,6 +232,7 @@ static inline void InitSplineDrawCache(Splines* s, size_t xsize, size_t ysize, f
           if (from_previous + to_next >= 1.0f) {
             const float f = (1.0f - from_previous) / to_next;
             current = {previous->x + f * dxn, previous->y + f * dyn};
+            JXH_CHECK(draw.size() < (size_t(1) << 22), "spline too long");
             draw.push_back({current, 1.0f});
             break;
           }
@@ -259,6 +263,7 @@ static inline void InitSplineDrawCache(Splines* s, size_t xsize, size_t ysize, f
       long long y1 = std::llround(pd.first.y + maxd) + 1;
       y1 = std::min<long long>(y1, (long long)ysize);
       if (y1 <= y0) continue;
+      JXH_CHECK(s->segments.size() < size_t(8) << 22, "too many spline segments");
       const float seg[8] = {pd.first.x, pd.first.y, maxd, 1.0f / sigma, 0.25f * sigma * intensity, colr[0], colr[1], colr[2]};
       s->segments.insert(s->segments.end(), seg, seg + 8);
       spans.push_back({size_t(y0), size_t(y1)});
@@ -266,10 +271,13 @@ static inline void InitSplineDrawCache(Splines* s, size_t xsize, size_t ysize, f
   }
   // per-row lists in segment order (splines.cc:730-766)
   s->row_start.assign(ysize + 1, 0);
+  uint64_t total_rows = 0;
+  for (const auto& sp : spans) total_rows += sp.second - sp.first;
+  JXH_CHECK(total_rows < (uint64_t(1) << 26), "splines cover too large an area");
   for (const auto& sp : spans)
     for (size_t y = sp.first; y < sp.second; y++) s->row_start[y + 1]++;
   for (size_t y = 0; y < ysize; y++) s->row_start[y + 1] += s->row_start[y];
-  JXH_CHECK(s->row_start[ysize] < (1u << 30), "splines cover too large an area");
+  JXH_CHECK(s->row_start[ysize] < (1u << 26), "splines cover too large an area");
   s->row_segments.assign(s->row_start[ysize], 0);
   std::vector<uint32_t> fill(s->row_start.begin(), s->row_start.end() - 1);
   for (size_t i = 0; i < spans.size(); i++)
