@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <queue>
 #include <stdexcept>
 #include <string>
@@ -733,6 +735,9 @@ struct FrameModel {
   std::vector<int32_t> dc[3];      // quantised DC ints per block, stored X, Y, B
   // quantised AC, per group: [c][65536] block-contiguous
   std::vector<std::vector<int32_t>> coeffs;
+  // ... or, when the forward path delivered them in one block: [group][3][65536] (then `coeffs` stays empty)
+  std::unique_ptr<int32_t[]> flat_coeffs;
+  const int32_t* GroupCoeffs(size_t g) const { return flat_coeffs ? flat_coeffs.get() + g * 3 * 65536 : coeffs[g].data(); }
   uint32_t global_scale, quant_dc;
   int epf_iters, gab;
   uint64_t flags;
@@ -1185,7 +1190,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
         static const int kOrder[3] = {1, 0, 2};
         for (int ci = 0; ci < 3; ci++) {
           const int c = kOrder[ci];
-          const int32_t* q = f.coeffs[g].data() + size_t(c) * 65536 + offset;
+          const int32_t* q = f.GroupCoeffs(g) + size_t(c) * 65536 + offset;
           int32_t* nzc = nzmap.data() + c * 1024;
           const int32_t* top = by ? nzc + (by - 1) * 32 : nullptr;
           int32_t* cur = nzc + by * 32;
@@ -1525,21 +1530,25 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     f.sharp.assign(f.xb * f.yb, 4);
     f.ytox.assign(DivCeil(f.xb, 8) * DivCeil(f.yb, 8), 0);
     f.ytob.assign(f.ytox.size(), 0);
-    jxh::DequantTables dq;
+    // the default dequantisation tables, flat, built once (they do not depend on the image)
+    static std::vector<float> flat;
+    static uint32_t flat_offset[17], flat_size[17];
+    static std::once_flag flat_once;
+    std::call_once(flat_once, [] {
+      jxh::DequantTables dq;
+      for (int k = 0; k < 17; k++) {
+        flat_offset[k] = flat_size[k] = 0;
+        if (k >= 13) continue;  // 128 / 256 point tables: never selected here, not built
+        dq.Compute(k);
+        flat_offset[k] = uint32_t(flat.size());
+        flat_size[k] = uint32_t(dq.table[k].size() / 3);
+        flat.insert(flat.end(), dq.table[k].begin(), dq.table[k].end());
+      }
+    });
     JxlHipEncDesc d;
     memset(&d, 0, sizeof(d));
-    std::vector<float> flat;
-    for (int k = 0; k < 17; k++) {
-      if (k == 13 || k == 14 || k == 15 || k == 16) {  // 128 / 256 point tables: never selected here, not built
-        d.dequant_offset[k] = 0;
-        d.dequant_size[k] = 0;
-        continue;
-      }
-      dq.Compute(k);
-      d.dequant_offset[k] = uint32_t(flat.size());
-      d.dequant_size[k] = uint32_t(dq.table[k].size() / 3);
-      flat.insert(flat.end(), dq.table[k].begin(), dq.table[k].end());
-    }
+    memcpy(d.dequant_offset, flat_offset, sizeof(flat_offset));
+    memcpy(d.dequant_size, flat_size, sizeof(flat_size));
     d.dequant = flat.data();
     d.dequant_floats = uint32_t(flat.size());
     d.xsize = uint32_t(xs);
@@ -1556,19 +1565,20 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     const size_t nb = f.xb * f.yb, ng = DivCeil(xs, 256) * DivCeil(ys, 256);
     f.acs.assign(nb, 0);
     f.qf.assign(nb, 0);
-    std::vector<int32_t> dc(3 * nb), co(ng * 3 * 65536);
-    const int r = hook->fn(hook->ctx, rgb, xs * 3, &d, f.acs.data(), f.qf.data(), dc.data(), co.data());
+    // (no zero fill and no second copy of the coefficients: 100 MB at 4K)
+    std::vector<int32_t> dc(3 * nb);
+    f.flat_coeffs.reset(new int32_t[ng * 3 * 65536]);
+    int32_t* const co = f.flat_coeffs.get();
+    const int r = hook->fn(hook->ctx, rgb, xs * 3, &d, f.acs.data(), f.qf.data(), dc.data(), co);
     if (r) throw std::runtime_error("forward hook failed (" + std::to_string(r) + ")");
     if (hook->cap_acs) {
       memcpy(hook->cap_acs, f.acs.data(), nb);
       memcpy(hook->cap_qf, f.qf.data(), nb * 4);
       memcpy(hook->cap_dc, dc.data(), dc.size() * 4);
-      memcpy(hook->cap_coeffs, co.data(), co.size() * 4);
+      memcpy(hook->cap_coeffs, co, ng * 3 * 65536 * 4);
       return;
     }
     for (int c = 0; c < 3; c++) f.dc[c].assign(dc.begin() + c * nb, dc.begin() + (c + 1) * nb);
-    f.coeffs.resize(ng);
-    for (size_t g = 0; g < ng; g++) f.coeffs[g].assign(co.begin() + g * 3 * 65536, co.begin() + (g + 1) * 3 * 65536);
     const double t1 = NowSeconds();
     Assemble(f, p, out);
     hook->seconds[0] = t1 - t0;
