@@ -319,6 +319,14 @@ typedef struct JxlHipModFrameDesc {
   uint32_t num_color, has_alpha, bits, alpha_bits;
   /* splines over the three colour channels (as floats, before the sample conversion); colour images only */
   JxlHipSplines splines;
+  /* XYB Modular frames (dec_modular.cc:583-631): the colour buffers hold Y, X, B - Y as integers in units of
+   * xyb_factor[] = the DC quantisation steps of X, Y, B; the colour stage (opsin_inv scaled by 255 / intensity_target,
+   * opsin_bias, linear_output as in JxlHipFrameDesc) makes the samples. */
+  uint32_t xyb;
+  float xyb_factor[3];
+  float opsin_inv[9];
+  float opsin_bias[3];
+  int32_t linear_output;
 } JxlHipModFrameDesc;
 /* Copies a Modular frame's tables and sections to the device (the arrays may be released afterwards). */
 int jxlhip_modular_upload(JxlHipContext* ctx, const JxlHipModFrameDesc* desc);

@@ -644,6 +644,7 @@ def encode_rgba8(img, **kw):
 
 
 LOSSLESS_PREFIX, LOSSLESS_LZ77, LOSSLESS_WP, LOSSLESS_SQUEEZE, LOSSLESS_RCT, LOSSLESS_ALL_PREDICTORS, LOSSLESS_PREV_CHANNEL = 1, 2, 4, 8, 16, 32, 64
+MODULAR_XYB = 128  # the frame codes XYB integers (Y, X, B - Y): "lossy Modular", not lossless any more
 
 
 def encode_lossless(img, flags=LOSSLESS_RCT, seed=0):

@@ -510,6 +510,13 @@ int jxlamd_modframe_upload(const JxlAmdModFrame* f, JxlHipContext* ctx) {
   d.bits = P.ih.bits;
   d.alpha_bits = P.alpha_bits;
   FillSplines(P.has_splines, P.splines, &d.splines);
+  d.xyb = P.xyb ? 1 : 0;
+  for (int c = 0; c < 3; c++) {
+    d.xyb_factor[c] = P.dc_quant[c];
+    d.opsin_bias[c] = P.ih.opsin_bias[c];
+  }
+  for (int i = 0; i < 9; i++) d.opsin_inv[i] = P.ih.inv_opsin[i] * (255.0f / P.ih.intensity_target);
+  d.linear_output = P.ih.linear_tf ? 1 : 0;
   const int r = jxlhip_modular_upload(ctx, &d);
   if (r) g_last_error = "jxlhip_modular_upload failed (" + std::to_string(r) + ")";
   return r;

@@ -2016,7 +2016,24 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
     ch[c].d.resize(xs * ys);
     for (size_t i = 0; i < xs * ys; i++) ch[c].d[i] = px[i * nc + c];
   }
-  const bool rct = (flags & 16) && !gray;
+  // flag 128: an XYB Modular frame ("lossy Modular": dec_modular.cc:583-631): the colour is converted to XYB and coded as
+  // the integers Y, X, B - Y in units of the default DC quantisation steps (1/512, 1/4096, 1/256); the decoder's colour
+  // stage brings it back. Colour images only; the alpha channel stays as it is.
+  const bool xyb = (flags & 128) && !gray;
+  if (xyb) {
+    std::vector<float> planes[3];
+    std::vector<uint8_t> rgb(xs * ys * 3);
+    for (size_t i = 0; i < xs * ys; i++)
+      for (int c = 0; c < 3; c++) rgb[i * 3 + c] = px[i * nc + c];
+    RgbToXyb(rgb.data(), xs, ys, xs, ys, planes);
+    for (size_t i = 0; i < xs * ys; i++) {
+      const int32_t Y = int32_t(std::lround(planes[1][i] * 512.0f));
+      ch[0].d[i] = Y;
+      ch[1].d[i] = int32_t(std::lround(planes[0][i] * 4096.0f));
+      ch[2].d[i] = int32_t(std::lround(planes[2][i] * 256.0f)) - Y;
+    }
+  }
+  const bool rct = (flags & 16) && !gray && !xyb;
   if (rct)  // forward YCoCg (rct.cc, type 6): the decoder computes tmp = Y - (Cg >> 1), G = Cg + tmp, B = tmp - (Co >> 1), R = B + Co
     for (size_t i = 0; i < xs * ys; i++) {
       const int32_t R = ch[0].d[i], G = ch[1].d[i], B = ch[2].d[i];
@@ -2355,7 +2372,8 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
   bw.Write(2, alpha ? 1 : 0);  // extra channels
   if (alpha) WriteAlphaChannelInfo(bw);
-  bw.Write(1, 0);  // xyb_encoded = false
+  const bool xyb_frame = (o.flags & 128) && !gray;
+  bw.Write(1, xyb_frame ? 1 : 0);  // xyb_encoded
   const bool with_icc = !g_embedded_icc.empty() && !gray;
   if (with_icc) {
     bw.Write(1, 0);  // not all_default
@@ -2391,7 +2409,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
     bw.Write(2, 1);  // flags = kSplines (16): U64 selector 1, 1 + 4 bits
     bw.Write(4, 15);
   }
-  bw.Write(1, 0);  // (not XYB:) no YCbCr
+  if (!xyb_frame) bw.Write(1, 0);  // (not XYB:) no YCbCr
   bw.Write(2, 0);  // upsampling 1
   if (alpha) bw.Write(2, 0);
   bw.Write(2, 1);  // group_size_shift 1 (256)

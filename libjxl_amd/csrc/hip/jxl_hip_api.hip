@@ -187,6 +187,9 @@ struct JxlHipContext {
     std::vector<uint32_t> stream_samples;
     uint32_t out_buffer[4] = {0, 0, 0, 0};
     uint32_t num_color = 3, has_alpha = 0, bits = 8, alpha_bits = 8, xs = 0, ys = 0, nstreams = 0;
+    bool xyb = false;  // XYB Modular frame: integer Y, X, B - Y channels, the colour stage's parameters in `xyb_color`
+    float xyb_factor[3] = {0, 0, 0};
+    jxlhip::FilterParams xyb_color;
     std::vector<const JxlHipContext*> batch_ctxs;
     std::vector<uint64_t> batch_gens;
     uint32_t batch_n = 0, batch_tree_cap = 0, batch_table_cap = 0;
@@ -1989,6 +1992,18 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
   HIP_TRY(hipStreamSynchronize(c->stream));  // the staging vectors are locals
   if (d->splines.num_segments && d->num_color != 3) return JXLHIP_ERR_UNSUPPORTED;
+  M.xyb = d->xyb != 0;
+  if (M.xyb) {
+    if (d->num_color != 3) return JXLHIP_ERR_UNSUPPORTED;
+    memset(&M.xyb_color, 0, sizeof(M.xyb_color));
+    for (int ch = 0; ch < 3; ch++) {
+      M.xyb_factor[ch] = d->xyb_factor[ch];
+      M.xyb_color.opsin_bias[ch] = d->opsin_bias[ch];
+      M.xyb_color.opsin_bias_cbrt[ch] = cbrtf(d->opsin_bias[ch]);
+    }
+    memcpy(M.xyb_color.opsin_inv, d->opsin_inv, sizeof(M.xyb_color.opsin_inv));
+    M.xyb_color.linear_output = d->linear_output;
+  }
   if ((r = UploadSplines(c, d->splines, d->ysize))) return r;
   if (c->spl_segments && (r = c->spl_planes.Ensure(size_t(d->xsize) * d->ysize * 3 * 4))) return r;
   M.have = true;
@@ -2102,6 +2117,8 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
         o.h = M.ys;
         o.fplanes = c->spl_planes.as<float>();
         o.fmode = 1;
+        o.xyb = M.xyb ? 1 : 0;  // (the planes then hold XYB; the final pass converts what it reads back)
+        memcpy(o.xyb_factor, M.xyb_factor, sizeof(o.xyb_factor));
         append(&o, sizeof(o));
         S.gx = std::max(S.gx, (M.xs + 255) / 256);
       } else {
@@ -2136,6 +2153,9 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
       o.fplanes = c->spl_planes.as<float>();
       o.fmode = 2;
     }
+    o.xyb = M.xyb ? 1 : 0;
+    memcpy(o.xyb_factor, M.xyb_factor, sizeof(o.xyb_factor));
+    o.color = M.xyb_color;
     for (uint32_t j = 0; j < M.num_color + (M.has_alpha ? 1 : 0); j++) {
       o.ch[j] = pool + M.buf_off[M.out_buffer[j]];
       o.stride[j] = M.xs;

@@ -793,6 +793,10 @@ struct ModOutput {
   // drawn over them), fmode 2 = take the colour from fplanes instead of the integer channels; 0 = neither
   float* fplanes;
   uint32_t fmode;
+  // XYB Modular frames: ch[0..2] = Y, X, B - Y in units of xyb_factor (X, Y, B); color = the colour stage's parameters
+  uint32_t xyb;
+  float xyb_factor[3];
+  FilterParams color;
 };
 __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   const ModOutput& P = ops[blockIdx.z];
@@ -802,12 +806,19 @@ __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   const float mul = 1.0f / float((uint64_t(1) << P.bits) - 1);
   float v[4];
   for (uint32_t c = 0; c < P.num_color; c++) v[c] = float(P.ch[c][size_t(y) * P.stride[c] + x]) * mul;
+  if (P.xyb) {  // dec_modular.cc:583-631 (MultiplySum for B)
+    const int32_t iy = P.ch[0][size_t(y) * P.stride[0] + x], ix = P.ch[1][size_t(y) * P.stride[1] + x], ib = P.ch[2][size_t(y) * P.stride[2] + x];
+    v[0] = float(ix) * P.xyb_factor[0];
+    v[1] = float(iy) * P.xyb_factor[1];
+    v[2] = float(ib + iy) * P.xyb_factor[2];
+  }
   if (P.fmode == 1) {
     for (uint32_t c = 0; c < 3; c++) P.fplanes[(size_t(c) * P.h + y) * P.w + x] = v[c];
     continue;
   }
   if (P.fmode == 2)
     for (uint32_t c = 0; c < 3; c++) v[c] = P.fplanes[(size_t(c) * P.h + y) * P.w + x];
+  if (P.xyb) XybToRgb(P.color, v[0], v[1], v[2], &v[0], &v[1], &v[2]);  // (after the splines, like every XYB frame)
   const float a = P.has_alpha ? float(P.ch[P.num_color][size_t(y) * P.stride[P.num_color] + x]) * (1.0f / float((uint64_t(1) << P.alpha_bits) - 1)) : 1.0f;
   const uint32_t nc = P.po.nc, ncol = nc < 3 ? 1u : 3u;
   float s[4];

@@ -51,6 +51,8 @@ struct ModFramePlan {
   uint32_t num_color = 3, has_alpha = 0, alpha_bits = 8;
   std::vector<uint32_t> extra_buffer;    // per extra channel: the buffer that holds it after the inverse transforms
   size_t frame_end = 0;
+  bool xyb = false;  // the colour channels are XYB integers (Y, X, B - Y): converted by the colour stage on the device
+  float dc_quant[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
   Splines splines;  // frame flag kSplines: drawn over the colour channels before the sample conversion
   bool has_splines = false;
 };
@@ -70,7 +72,8 @@ class ModFrameParser {
     JXH_CHECK(fh.modular, "not a Modular frame");
     JXH_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
     // (where the frame sits on the canvas and how it blends: the caller's business, as for FrameParser::ParseFrame)
-    JXH_CHECK(!ih.xyb_encoded && !fh.ycbcr, "unsupported: XYB or YCbCr Modular frames");
+    JXH_CHECK(!fh.ycbcr, "unsupported: YCbCr Modular frames");
+    JXH_CHECK(!(ih.xyb_encoded && ih.gray), "unsupported: grey XYB Modular frames");
     JXH_CHECK(fh.upsampling == 1 && fh.num_passes == 1, "unsupported: upsampled / multi-pass Modular frames");
     for (uint32_t u : fh.ec_upsampling) JXH_CHECK(u == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
@@ -99,8 +102,13 @@ class ModFrameParser {
       InitSplineDrawCache(&P.splines, d.xsize, d.ysize, 0.0f, 1.0f);
       P.has_splines = true;
     }
+    // dec_modular.cc:583-631: an XYB Modular frame codes Y, X, B - Y in units of the DC quantisation steps read here
+    P.xyb = ih.xyb_encoded;
     if (!g.ReadBool())
-      for (int c = 0; c < 3; c++) ReadF16(g);
+      for (int c = 0; c < 3; c++) {
+        P.dc_quant[c] = ReadF16(g) * (1.0f / 128.0f);
+        JXH_CHECK(P.dc_quant[c] >= 1e-8f, "invalid DC quant");
+      }
     bool have_global = false;
     if (g.ReadBool()) {
       const size_t nb = (ih.gray ? 1 : 3) + ih.extra.size();

@@ -474,7 +474,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
   JXLO_CHECK(fh.modular || ih.xyb_encoded, "unsupported: non-XYB VarDCT");
-  JXLO_CHECK(!(fh.modular && ih.xyb_encoded), "unsupported: XYB Modular frames");
+  JXLO_CHECK(!(fh.modular && ih.xyb_encoded && ih.gray), "unsupported: grey XYB Modular frames");
   s->dim = MakeFrameDim(fh);
   const FrameDim& d = s->dim;
   out->fh = fh;
@@ -667,13 +667,40 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   } else {
     const float factor = float(1.0 / double((1u << s->full.bitdepth) - 1));
     const size_t ncol = s->modular_color_channels;
-    for (int c = 0; c < 3; c++) {
-      const MChannel& ch = s->full.ch[ncol == 1 ? 0 : c];
-      for (size_t i = 0; i < xs * ys; i++) out->rgbf[c * xs * ys + i] = float(ch.d[i]) * factor;
+    if (ih.xyb_encoded) {
+      // dec_modular.cc:583-631: an XYB Modular frame codes Y, X, B - Y as integers in units of the DC quantisation steps
+      const int32_t* cy = s->full.ch[0].d.data();
+      const int32_t* cx = s->full.ch[1].d.data();
+      const int32_t* cb = s->full.ch[2].d.data();
+      for (size_t i = 0; i < xs * ys; i++) {
+        out->rgbf[i] = float(cx[i]) * s->dq.dc_quant[0];
+        out->rgbf[xs * ys + i] = float(cy[i]) * s->dq.dc_quant[1];
+        out->rgbf[2 * xs * ys + i] = float(cb[i] + cy[i]) * s->dq.dc_quant[2];
+      }
+    } else {
+      for (int c = 0; c < 3; c++) {
+        const MChannel& ch = s->full.ch[ncol == 1 ? 0 : c];
+        for (size_t i = 0; i < xs * ys; i++) out->rgbf[c * xs * ys + i] = float(ch.d[i]) * factor;
+      }
     }
     if (s->has_splines) {  // the same stage on the three colour channels of a Modular frame (default colour correlation: 0, 1)
       InitSplineDrawCache(&s->splines, xs, ys, s->base_corr_x, s->base_corr_b);
       DrawSplines(s->splines, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs, xs, ys);
+    }
+    if (ih.xyb_encoded) {  // then the colour stage of every XYB frame
+      OpsinParams op = MakeOpsinParams(ih);
+      for (size_t i = 0; i < xs * ys; i++) {
+        float r, g, bb;
+        XybToRgb(op, out->rgbf[i], out->rgbf[xs * ys + i], out->rgbf[2 * xs * ys + i], &r, &g, &bb);
+        if (!ih.linear_tf) {
+          r = LinearToSrgb(r);
+          g = LinearToSrgb(g);
+          bb = LinearToSrgb(bb);
+        }
+        out->rgbf[i] = r;
+        out->rgbf[xs * ys + i] = g;
+        out->rgbf[2 * xs * ys + i] = bb;
+      }
     }
     if (want_dumps) {
       out->modular.resize(s->full.ch.size() * xs * ys);

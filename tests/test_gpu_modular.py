@@ -198,3 +198,40 @@ def test_reference_wasm_cross_stream_on_gpu(built, tmp_path):
     rc, events, out, px = R.run(data, tmp_path, "u16", 3)
     assert rc == 0, out
     assert np.array_equal(np.frombuffer(px, np.uint16).reshape(20, 20, 3), want.astype(np.uint16) * 257)
+
+
+@pytest.mark.parametrize("case", ["plain", "alpha_squeeze_wp", "splines"])
+def test_xyb_modular_frames_go_through_the_colour_stage(built, tmp_path, case):
+    """An XYB Modular frame ("lossy Modular", dec_modular.cc:583-631): the stream kernel decodes the integers Y, X, B - Y,
+    the output kernel scales them by the DC quantisation steps and runs the colour stage of every XYB frame (after the
+    splines, where there are any)."""
+    import jxlo
+    import replay_util as R
+    J = built
+    img = J.synth_image(300, 200, seed=5)
+    flags = J.MODULAR_XYB
+    src = img
+    if case == "alpha_squeeze_wp":
+        flags |= J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP
+        src = np.dstack([img, img[..., 0]])
+    if case == "splines":
+        J.set_splines([dict(points=[(20, 30), (120, 90), (220, 40)], color=[[40] + [0] * 31, [300, 10] + [0] * 30, [0] * 32], sigma=[12] + [0] * 31)])
+    try:
+        data = J.encode_lossless(src, flags)
+    finally:
+        J.set_splines(None)
+    o = jxlo.Decoded(data)
+    want8, wantf = o.rgb8.copy(), o.planes("rgbf").transpose(1, 2, 0).copy()
+    o.close()
+    nc = src.shape[2]
+    if case != "splines":  # (quantised to the DC steps: 45 dB; the test spline is a bright stroke over it)
+        assert 10 * np.log10(255.0 ** 2 / np.mean((want8[..., :3].astype(float) - img) ** 2)) > 44
+    rc, events, out, px = R.run(data, tmp_path, "u8", nc)
+    assert rc == 0, out
+    got = np.frombuffer(px, np.uint8).reshape(200, 300, nc)
+    assert np.abs(got.astype(int) - want8.astype(int)).max() <= 1
+    if nc == 4:
+        assert np.array_equal(got[..., 3], img[..., 0])
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.float32).reshape(200, 300, 3) - wantf).max() < 5e-5

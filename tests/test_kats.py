@@ -94,6 +94,7 @@ def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
     finally:
         J.set_splines(None)
     with_splines.append(open(os.path.join(ROOT, "tests", "golden", "ref_wasm_splines.jxl"), "rb").read())
+    with_splines.append(J.encode_lossless(img, J.MODULAR_XYB | J.LOSSLESS_SQUEEZE))
     patch = J.synth_image(80, 60, seed=2)
     ramp = ((np.mgrid[0:60, 0:80][1] * 255) // 79).astype(np.uint8)
     with_splines.append(J.encode_layers([dict(img=np.dstack([img, img[..., 0]]), save_as=1, duration=2),
