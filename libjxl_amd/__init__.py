@@ -464,6 +464,14 @@ def set_color_encoding(white_point=None, primaries=1, transfer_function=13, gamm
                                 intent, arr)
 
 
+def set_frame_name(name=""):
+    """Test aid: the frames written from now on carry this name (empty: none again)."""
+    E = _enc_lib()
+    E.jxlenc_set_frame_name.argtypes = [ctypes.c_char_p]
+    E.jxlenc_set_frame_name.restype = None
+    E.jxlenc_set_frame_name(name.encode())
+
+
 def set_orientation(orientation=1):
     """Test aid: the synthetic encoders declare this image orientation (1..8, EXIF numbering) in the streams they write
     from now on (1: none again)."""

@@ -1584,6 +1584,7 @@ JxlDecoderStatus JxlDecoderSetOutputColorProfile(JxlDecoder* d, const JxlColorEn
   else return JXL_DEC_ERROR;
   return JXL_DEC_SUCCESS;
 }
+static const std::string& FrameName(const JxlDecoder* d) { return d->frame ? d->frame->plan.fh.name : d->mframe->plan.fh.name; }
 JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h) {
   if (!d->frame && !d->mframe) return JXL_DEC_ERROR;
   if (h) {
@@ -1594,15 +1595,19 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
     h->duration = t[0];  // decode.cc:2700-2712
     h->is_last = t[1] ? JXL_TRUE : JXL_FALSE;
     h->timecode = t[2];
+    h->name_length = uint32_t(FrameName(d).size());
     h->layer_info.xsize = uint32_t(OrientedXsize(d));  // decode.cc:2714-2722
     h->layer_info.ysize = uint32_t(OrientedYsize(d));
     h->layer_info.blend_info.blendmode = JXL_BLEND_REPLACE;
   }
   return JXL_DEC_SUCCESS;
 }
+// decode.cc:2778-2792: the name with its terminating zero; the buffer must hold name_length + 1 bytes.
 JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* d, char* name, size_t size) {
-  if ((!d->frame && !d->mframe) || !name || !size) return JXL_DEC_ERROR;
-  name[0] = 0;
+  if ((!d->frame && !d->mframe) || !name) return JXL_DEC_ERROR;
+  const std::string& n = FrameName(d);
+  if (size < n.size() + 1) return JXL_DEC_ERROR;
+  memcpy(name, n.c_str(), n.size() + 1);
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderPreviewOutBufferSize(const JxlDecoder*, const JxlPixelFormat*, size_t*) { return JXL_DEC_ERROR; }

@@ -768,6 +768,13 @@ struct LayerState {
   uint32_t mode = 0, alpha_mode = 0, source = 0, alpha_source = 0, clamp = 0, save_as = 0;
 };
 static LayerState g_layer;
+// jxlenc_set_frame_name: the name the next frames carry (frame_header.cc:431 VisitNameString: U32 length, bytes)
+static std::string g_frame_name;
+static void WriteFrameName(BitWriter& bw) {
+  static const uint32_t b[4] = {0, 4, 5, 10}, o[4] = {0, 0, 16, 48};
+  WriteU32Sel(bw, uint32_t(g_frame_name.size()), b, o);
+  for (unsigned char ch : g_frame_name) bw.Write(8, ch);
+}
 // jxlenc_set_color_encoding: the enum ColorEncoding the next LOSSLESS streams declare (color_encoding_internal.cc:144-200):
 // white point / primaries / transfer function values of color_encoding.h (2 = custom xy in millionths; have_gamma with
 // gamma in 1e-7), rendering intent. The samples are written as given: a non-XYB image's colour encoding is metadata.
@@ -1424,7 +1431,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   const bool whole = WriteCropAndBlending(bw, uint32_t(f.xs), uint32_t(f.ys), have_alpha);
   WriteFrameTiming(bw, whole);
-  bw.Write(2, 0);  // no name
+  WriteFrameName(bw);
   bw.Write(1, 0);  // loop filter not all_default
   bw.Write(1, f.gab ? 1 : 0);
   if (f.gab) {
@@ -2416,7 +2423,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(2, 0);  // one pass
   const bool whole = WriteCropAndBlending(bw, uint32_t(xs), uint32_t(ys), alpha);
   WriteFrameTiming(bw, whole);
-  bw.Write(2, 0);  // no name
+  WriteFrameName(bw);
   bw.Write(1, 0);  // loop filter not all_default
   bw.Write(1, 0);  // no gaborish
   bw.Write(2, 0);  // no EPF
@@ -2508,6 +2515,7 @@ void jxlenc_set_color_encoding(int enabled, uint32_t white_point, uint32_t prima
   jxe::g_color.intent = intent;
   for (int i = 0; i < 8; i++) jxe::g_color.xy[i] = xy8 ? xy8[i] : 0;
 }
+void jxlenc_set_frame_name(const char* name) { jxe::g_frame_name = name ? name : ""; }
 void jxlenc_set_alpha_premultiplied(int premultiplied) { jxe::g_alpha_premultiplied = premultiplied != 0; }
 // Byte offset of the frame header in the stream written last (signature + image header come before it).
 size_t jxlenc_last_header_bytes(void) { return jxe::g_last_header_bytes; }

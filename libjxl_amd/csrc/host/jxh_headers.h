@@ -253,6 +253,7 @@ struct FrameHeader {
   uint32_t save_as_reference = 0;
   uint32_t duration = 0, timecode = 0;  // AnimationFrame (frame_header.cc:130-150), in ticks of the image's AnimationHeader
   uint32_t blend_mode = 0;              // BlendMode of the colour channels: 0 = replace
+  std::string name;                     // frame_header.cc:431 (UTF-8, up to 1071 bytes)
   BlendInfo blend;                      // ... in full, and of every extra channel
   std::vector<BlendInfo> ec_blend;
   bool save_before_color_transform = false;
@@ -394,7 +395,7 @@ static inline void ReadFrameHeader(BitReader& br, const ImageHeader& ih, FrameHe
       f->save_before_color_transform = br.ReadBool();
     }
   }
-  ReadName(br);
+  f->name = ReadName(br);
   ReadLoopFilter(br, f->modular, &f->lf);
   SkipExtensions(br);
 }

@@ -174,3 +174,39 @@ def test_noise_of_later_frames_uses_the_frame_index(built, tmp_path):
         ref = o.planes("rgbf").transpose(1, 2, 0).copy()
         o.close()
         assert np.abs(got[k] - ref).max() < 1e-4, k
+
+
+def test_frame_names_come_out_of_the_frame_header(built):
+    """frame_header.cc:431: JxlFrameHeader.name_length and JxlDecoderGetFrameName (decode.cc:2778-2792: the buffer holds
+    the name and its terminating zero)."""
+    J = built
+    L = J.lib()
+    vp = ctypes.c_void_p
+    L.JxlDecoderCreate.restype = vp
+    L.JxlDecoderCreate.argtypes = [vp]
+    for n in ("JxlDecoderDestroy", "JxlDecoderProcessInput", "JxlDecoderCloseInput"):
+        getattr(L, n).argtypes = [vp]
+    L.JxlDecoderSubscribeEvents.argtypes = [vp, ctypes.c_int]
+    L.JxlDecoderSetInput.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    L.JxlDecoderGetFrameHeader.argtypes = [vp, vp]
+    L.JxlDecoderGetFrameName.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    name = "layer é with a longer name than sixteen bytes"
+    J.set_frame_name(name)
+    try:
+        streams = [J.encode_rgb8(J.synth_image(64, 48, seed=1)), J.encode_lossless(J.synth_image(64, 48, seed=1))]
+    finally:
+        J.set_frame_name("")
+    for data in streams:
+        dec = L.JxlDecoderCreate(None)
+        L.JxlDecoderSubscribeEvents(dec, 0x400)
+        L.JxlDecoderSetInput(dec, data, len(data))
+        L.JxlDecoderCloseInput(dec)
+        assert L.JxlDecoderProcessInput(dec) == 0x400
+        fh = (ctypes.c_uint8 * 256)()
+        assert L.JxlDecoderGetFrameHeader(dec, fh) == 0
+        n = struct.unpack_from("<4I", bytes(fh), 0)[2]
+        assert n == len(name.encode())
+        buf = ctypes.create_string_buffer(n + 1)
+        assert L.JxlDecoderGetFrameName(dec, buf, n + 1) == 0 and buf.value.decode() == name
+        assert L.JxlDecoderGetFrameName(dec, buf, n) == 1  # too small
+        L.JxlDecoderDestroy(dec)
