@@ -1499,7 +1499,16 @@ JxlDecoderStatus JxlDecoderGetExtraChannelName(const JxlDecoder* d, size_t index
 }
 JxlDecoderStatus JxlDecoderGetExtraChannelBlendInfo(const JxlDecoder* d, size_t index, JxlBlendInfo* info) {
   if ((!d->frame && !d->mframe) || index >= d->ih.extra.size()) return JXL_DEC_ERROR;
-  if (info) memset(info, 0, sizeof(*info));
+  if (info) {  // decode.cc:2796-2812: the frame header's BlendingInfo of that channel
+    memset(info, 0, sizeof(*info));
+    const jxh::FrameHeader& fh = d->frame ? d->frame->plan.fh : d->mframe->plan.fh;
+    if (index < fh.ec_blend.size()) {
+      info->blendmode = JxlBlendMode(fh.ec_blend[index].mode);
+      info->source = fh.ec_blend[index].source;
+      info->alpha = fh.ec_blend[index].alpha_channel;
+      info->clamp = fh.ec_blend[index].clamp ? JXL_TRUE : JXL_FALSE;
+    }
+  }
   return JXL_DEC_SUCCESS;
 }
 // The embedded ICC profile (ImageMetadata.color_encoding.want_icc, decoded by the host front-end: jxh_icc.h) answers for

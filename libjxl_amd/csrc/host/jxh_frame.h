@@ -161,7 +161,7 @@ class FrameParser {
     BitReader br(data_ + pos, codestream_base_ + cs_size_ - pos);
     ReadFrameHeader(br, ih, &P.fh);
     const FrameHeader& fh = P.fh;
-    JXH_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
+    JXH_CHECK(fh.frame_type == 0 || fh.frame_type == 3, "unsupported: reference-only / DC frames");  // (3 = kSkipProgressive: a regular frame)
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
     JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
     JXH_CHECK(fh.upsampling == 1 || !ih.custom_upsampling, "unsupported: custom upsampling weights");

@@ -469,7 +469,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   s->nonvisible_index = nonvisible_index;
   ReadFrameHeader(br, ih, &s->fh);
   const FrameHeader& fh = s->fh;
-  JXLO_CHECK(fh.frame_type == 0, "unsupported: non-regular frame");
+  JXLO_CHECK(fh.frame_type == 0 || fh.frame_type == 3, "unsupported: reference-only / DC frames");  // (3 = kSkipProgressive: a regular frame)
   JXLO_CHECK(fh.upsampling == 1 || (!fh.modular && !ih.custom_upsampling), "unsupported: upsampled Modular frames / custom weights");
   JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
