@@ -568,6 +568,41 @@ def encode_layers(layers, tps=None, num_loops=0, lossless=False, premultiplied=F
     return out
 
 
+def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=False, **kw):
+    """Test aid: a reference-only frame holding `atlas` (HxWx3 uint8; coded as an XYB Modular frame like libjxl's patch
+    frames, or as a VarDCT frame) kept in `slot`, then `img` coded with a patch dictionary. patches: list of dicts with
+    x0, y0, xsize, ysize (rectangle in the atlas) and positions: list of (x, y, mode, clamp) with PatchBlendMode 0 none,
+    1 replace, 2 add, 3 multiply. The patches are drawn over the decoded frame; nothing is subtracted when encoding."""
+    E = _enc_lib()
+    E.jxlenc_set_reference_frame.argtypes = [ctypes.c_int]
+    E.jxlenc_set_reference_frame.restype = None
+    E.jxlenc_set_image_size.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    E.jxlenc_set_image_size.restype = None
+    E.jxlenc_set_patches.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.c_size_t]
+    E.jxlenc_set_patches.restype = None
+    E.jxlenc_set_animation.argtypes = [ctypes.c_int] + [ctypes.c_uint32] * 4 + [ctypes.c_int]
+    E.jxlenc_set_animation.restype = None
+    E.jxlenc_last_header_bytes.restype = ctypes.c_size_t
+    flat = [len(patches)]
+    for p in patches:
+        flat += [slot, p["x0"], p["y0"], p["xsize"], p["ysize"], len(p["positions"])]
+        for (x, y, mode, clamp) in p["positions"]:
+            flat += [x, y, mode, clamp]
+    try:
+        E.jxlenc_set_image_size(img.shape[1], img.shape[0])
+        E.jxlenc_set_reference_frame(slot)
+        first = encode_rgb8(atlas, **kw) if atlas_vardct else encode_lossless(atlas, MODULAR_XYB)
+        E.jxlenc_set_reference_frame(-1)
+        arr = (ctypes.c_int32 * len(flat))(*flat)
+        E.jxlenc_set_patches(arr, len(flat))
+        second = encode_lossless(img, MODULAR_XYB) if lossless else (encode_rgba8(img, **kw) if img.shape[2] == 4 else encode_rgb8(img, **kw))
+        return first + second[E.jxlenc_last_header_bytes():]
+    finally:
+        E.jxlenc_set_reference_frame(-1)
+        E.jxlenc_set_patches(None, 0)
+        E.jxlenc_set_image_size(0, 0)
+
+
 def synth_image(xsize, ysize, seed=177):
     """Deterministic synthetic RGB8 test image (gradient background, rectangles, discs, texture, noise)."""
     a = np.zeros((ysize, xsize, 3), np.uint8)

@@ -768,6 +768,15 @@ struct LayerState {
   uint32_t mode = 0, alpha_mode = 0, source = 0, alpha_source = 0, clamp = 0, save_as = 0;
 };
 static LayerState g_layer;
+// jxlenc_set_reference_frame: the next frame is a kReferenceOnly frame (frame_header.cc:215-240, 372-411): never shown,
+// kept before its colour transform in slot `save_as` for the patches of later frames; coded with its own size.
+// jxlenc_set_image_size: the image size the next stream's headers declare (a reference frame that comes first is smaller
+// or larger than the image). jxlenc_set_patches: the patch dictionary of the next frames (flat: number of references, per
+// reference: slot, x0, y0, xsize, ysize, count, then per position: x, y, colour blend mode 0..3, clamp), written the way
+// PatchDictionary::Decode reads it (dec_patch_dictionary.cc:32-175; extra channels are left alone: mode kNone).
+static int g_reference_slot = -1;
+static uint32_t g_image_w = 0, g_image_h = 0;
+static std::vector<int32_t> g_patches;
 // jxlenc_set_frame_name: the name the next frames carry (frame_header.cc:431 VisitNameString: U32 length, bytes)
 static std::string g_frame_name;
 static void WriteFrameName(BitWriter& bw) {
@@ -830,6 +839,12 @@ static void WriteAlphaChannelInfo(BitWriter& bw) {
 static bool WriteCropAndBlending(BitWriter& bw, uint32_t fw, uint32_t fh, bool have_alpha) {
   const LayerState& L = g_layer;
   static const uint32_t db[4] = {8, 11, 14, 30}, dof[4] = {0, 256, 2304, 18688};
+  if (g_reference_slot >= 0) {  // kReferenceOnly: its own size, no origin, no blending info
+    bw.Write(1, 1);
+    WriteU32Sel(bw, fw, db, dof);
+    WriteU32Sel(bw, fh, db, dof);
+    return false;
+  }
   bool partial = false;
   if (!L.enabled) {
     bw.Write(1, 0);  // no custom size/origin
@@ -883,6 +898,11 @@ static void WriteToneMapping(BitWriter& bw) {
 // frame_header.cc:130-150, 372-399: the animation fields of a frame header, is_last, and (not last) save_as_reference 0.
 // A frame with a duration and no reference slot cannot be referenced: no save_before_color_transform bit follows.
 static void WriteFrameTiming(BitWriter& bw, bool replace_whole_canvas = true) {
+  if (g_reference_slot >= 0) {  // no duration, no is_last (= false); save_as_reference, then save_before_color_transform
+    bw.Write(2, uint32_t(g_reference_slot));
+    bw.Write(1, 1);
+    return;
+  }
   const bool timed = g_anim.enabled && g_anim.timed;
   if (timed) {
     static const uint32_t b[4] = {0, 0, 8, 32}, o[4] = {0, 1, 0, 0};
@@ -901,6 +921,44 @@ static void WriteFrameTiming(BitWriter& bw, bool replace_whole_canvas = true) {
 // Splines::Decode reads it (splines.cc:596-648): 6 contexts, starting points as deltas of each other, ANS coded.
 static std::vector<int32_t> g_splines;
 static void WriteCodeHeader(BitWriter& bw, const EncCode& code);
+static void WritePatches(BitWriter& bw, size_t num_extra) {
+  const int32_t* d = g_patches.data();
+  const size_t nref = size_t(*d++);
+  std::vector<Token> tk;
+  tk.push_back({0, uint32_t(nref)});
+  auto pack = [](int64_t v) { return v >= 0 ? uint32_t(v) * 2 : uint32_t(-(v + 1)) * 2 + 1; };
+  for (size_t r = 0; r < nref; r++) {
+    tk.push_back({1, uint32_t(d[0])});
+    tk.push_back({3, uint32_t(d[1])});
+    tk.push_back({3, uint32_t(d[2])});
+    tk.push_back({2, uint32_t(d[3] - 1)});
+    tk.push_back({2, uint32_t(d[4] - 1)});
+    const size_t count = size_t(d[5]);
+    tk.push_back({7, uint32_t(count - 1)});
+    d += 6;
+    int64_t px = 0, py = 0;
+    for (size_t i = 0; i < count; i++, d += 4) {
+      if (i == 0) {
+        tk.push_back({4, uint32_t(d[0])});
+        tk.push_back({4, uint32_t(d[1])});
+      } else {
+        tk.push_back({6, pack(int64_t(d[0]) - px)});
+        tk.push_back({6, pack(int64_t(d[1]) - py)});
+      }
+      px = d[0];
+      py = d[1];
+      tk.push_back({5, uint32_t(d[2])});
+      if (d[2] == 3) tk.push_back({9, uint32_t(d[3] ? 1 : 0)});
+      for (size_t e = 0; e < num_extra; e++) tk.push_back({5, 0});  // extra channels: kNone
+    }
+  }
+  jxh::HybridCfg cfg;
+  cfg.split_exp = 4; cfg.split_token = 16; cfg.msb = 2; cfg.lsb = 0;
+  EncCode code;
+  BuildCode({&tk}, 10, 10, cfg, &code);
+  WriteCodeHeader(bw, code);
+  WriteTokens(bw, tk.data(), tk.size(), code);
+}
 static void WriteSplines(BitWriter& bw) {
   const int32_t* d = g_splines.data();
   const int32_t adjust = *d++;
@@ -1234,7 +1292,8 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   // ---- sections
   auto write_dc_global = [&](BitWriter& bw) {
-    if (!g_splines.empty()) WriteSplines(bw);  // (dec_frame.cc:289-296: splines, then noise)
+    if (!g_patches.empty()) WritePatches(bw, have_alpha ? 1 : 0);  // (dec_frame.cc:271-296: patches, splines, noise)
+    if (!g_splines.empty()) WriteSplines(bw);
     if (p.noise > 0)  // NoiseParams: eight 10-bit LUT points (dec_noise.cc:154-164)
       for (int i = 0; i < 8; i++) bw.Write(10, uint32_t(std::min(1023, p.noise + 40 * i)));
     if (!p.custom_lf) {
@@ -1376,9 +1435,9 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   const uint32_t ups = (p.upsampling == 2 || p.upsampling == 4 || p.upsampling == 8) ? uint32_t(p.upsampling) : 1;
   // the image is the frame times the upsampling factor (the frame is ceil(image / factor): any image size in
   // (factor * (frame - 1), factor * frame] is valid; img_xs / img_ys pick one)
-  WriteSizeDim(bw, uint32_t(ups == 1 ? f.ys : f.img_ys));
+  WriteSizeDim(bw, g_image_h ? g_image_h : uint32_t(ups == 1 ? f.ys : f.img_ys));
   bw.Write(3, 0);  // no aspect-ratio shortcut
-  WriteSizeDim(bw, uint32_t(ups == 1 ? f.xs : f.img_xs));
+  WriteSizeDim(bw, g_image_w ? g_image_w : uint32_t(ups == 1 ? f.xs : f.img_xs));
   const bool with_icc = !g_embedded_icc.empty();
   if (!have_alpha && !with_icc && !ExtraFields()) {
     bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
@@ -1407,7 +1466,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   g_last_header_bytes = bw.bytes().size();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
-  bw.Write(2, 0);  // regular frame
+  bw.Write(2, g_reference_slot >= 0 ? 2 : 0);  // regular frame, or kReferenceOnly
   bw.Write(1, 0);  // VarDCT
   if (f.flags == 0) {
     bw.Write(2, 0);
@@ -1422,7 +1481,9 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   if (have_alpha) bw.Write(2, 0);  // extra channel upsampling 1
   bw.Write(3, p.custom_cmap ? 2 : 3);  // x_qm_scale
   bw.Write(3, p.custom_cmap ? 4 : 2);  // b_qm_scale
-  if (num_passes == 1) {
+  if (g_reference_slot >= 0) {
+    // (frame_header.cc:303: a kReferenceOnly frame has no Passes bundle)
+  } else if (num_passes == 1) {
     bw.Write(2, 0);  // one pass
   } else {
     bw.Write(2, 1);  // two passes
@@ -1533,7 +1594,7 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     if (p.strategy_mode > 1 || p.random_cmap || p.custom_cmap) throw std::runtime_error("forward hook: unsupported parameters");
     const double t0 = NowSeconds();
     f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
-    f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16);
+    f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16) | (g_patches.empty() ? 0 : 2);
     f.sharp.assign(f.xb * f.yb, 4);
     f.ytox.assign(DivCeil(f.xb, 8) * DivCeil(f.yb, 8), 0);
     f.ytob.assign(f.ytox.size(), 0);
@@ -1617,7 +1678,7 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     }
   }
   f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
-  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16);
+  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16) | (g_patches.empty() ? 0 : 2);
   f.acs.assign(f.xb * f.yb, 0xFF);
   f.qf.assign(f.xb * f.yb, 0);
   f.sharp.assign(f.xb * f.yb, 4);
@@ -1857,7 +1918,7 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
   f.quant_dc = 8 + rng.Below(16);
   f.gab = p.gab < 0 ? 1 : p.gab;
   f.epf_iters = p.epf_iters < 0 ? 1 : p.epf_iters;
-  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16);
+  f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16) | (g_patches.empty() ? 0 : 2);
   f.acs.assign(f.xb * f.yb, 0xFF);
   f.qf.assign(f.xb * f.yb, 0);
   f.sharp.assign(f.xb * f.yb, 0);
@@ -2323,6 +2384,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   };
   std::vector<std::vector<uint8_t>> sections;
   auto dc_global = [&](BitWriter& bw) {
+    if (!g_patches.empty()) WritePatches(bw, alpha ? 1 : 0);
     if (!g_splines.empty()) WriteSplines(bw);
     bw.Write(1, 1);  // default DC dequantisation
     bw.Write(1, 1);  // global tree present
@@ -2369,9 +2431,9 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   BitWriter bw;
   bw.Write(16, 0x0AFF);
   bw.Write(1, 0);  // not "small"
-  WriteSizeDim(bw, uint32_t(ys));
+  WriteSizeDim(bw, g_image_h ? g_image_h : uint32_t(ys));
   bw.Write(3, 0);
-  WriteSizeDim(bw, uint32_t(xs));
+  WriteSizeDim(bw, g_image_w ? g_image_w : uint32_t(xs));
   bw.Write(1, 0);  // ImageMetadata not all_default
   WriteExtraFields(bw);
   bw.Write(1, 0);  // integer samples
@@ -2408,19 +2470,23 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   g_last_header_bytes = bw.bytes().size();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
-  bw.Write(2, 0);  // regular frame
+  bw.Write(2, g_reference_slot >= 0 ? 2 : 0);  // regular frame, or kReferenceOnly
   bw.Write(1, 1);  // Modular
-  if (g_splines.empty()) {
-    bw.Write(2, 0);  // flags 0
-  } else {
-    bw.Write(2, 1);  // flags = kSplines (16): U64 selector 1, 1 + 4 bits
-    bw.Write(4, 15);
+  {
+    const uint32_t mflags = (g_splines.empty() ? 0 : 16) | (g_patches.empty() ? 0 : 2);
+    if (mflags == 0) {
+      bw.Write(2, 0);
+    } else {  // U64 selector 1: 1 + 4 bits (<= 16), selector 2: 17 + 8 bits
+      bw.Write(2, mflags <= 16 ? 1 : 2);
+      if (mflags <= 16) bw.Write(4, mflags - 1);
+      else bw.Write(8, mflags - 17);
+    }
   }
   if (!xyb_frame) bw.Write(1, 0);  // (not XYB:) no YCbCr
   bw.Write(2, 0);  // upsampling 1
   if (alpha) bw.Write(2, 0);
   bw.Write(2, 1);  // group_size_shift 1 (256)
-  bw.Write(2, 0);  // one pass
+  if (g_reference_slot < 0) bw.Write(2, 0);  // one pass (a kReferenceOnly frame has no Passes bundle: frame_header.cc:303)
   const bool whole = WriteCropAndBlending(bw, uint32_t(xs), uint32_t(ys), alpha);
   WriteFrameTiming(bw, whole);
   WriteFrameName(bw);
@@ -2515,6 +2581,12 @@ void jxlenc_set_color_encoding(int enabled, uint32_t white_point, uint32_t prima
   jxe::g_color.intent = intent;
   for (int i = 0; i < 8; i++) jxe::g_color.xy[i] = xy8 ? xy8[i] : 0;
 }
+void jxlenc_set_reference_frame(int slot) { jxe::g_reference_slot = slot; }
+void jxlenc_set_image_size(uint32_t w, uint32_t h) {
+  jxe::g_image_w = w;
+  jxe::g_image_h = h;
+}
+void jxlenc_set_patches(const int32_t* data, size_t n) { jxe::g_patches.assign(data, data + n); }
 void jxlenc_set_frame_name(const char* name) { jxe::g_frame_name = name ? name : ""; }
 void jxlenc_set_alpha_premultiplied(int premultiplied) { jxe::g_alpha_premultiplied = premultiplied != 0; }
 // Byte offset of the frame header in the stream written last (signature + image header come before it).

@@ -22,6 +22,7 @@
 #include "jxlo_entropy.h"
 #include "jxlo_headers.h"
 #include "jxlo_modular.h"
+#include "jxlo_patches.h"
 #include "jxlo_render.h"
 #include "jxlo_splines.h"
 #include "jxlo_vardct.h"
@@ -37,6 +38,7 @@ struct Decoded {
   std::vector<uint8_t> rgb8;   // interleaved, out_xsize*out_ysize*out_channels
   std::vector<float> rgbf;     // planar 3 x ysize x xsize (after transfer function, before uint8)
   std::vector<float> alphaf;   // the alpha plane as floats (images with alpha)
+  std::vector<float> xyb_save; // frames kept before the colour transform: 3 x out_ysize x out_xsize (dec_cache.cc:225-230)
   // VarDCT intermediates
   std::vector<int32_t> coeffs;     // [group][c][65536], block-contiguous per varblock
   std::vector<int32_t> nzeros;     // [group][c][32*32]
@@ -69,6 +71,9 @@ struct FrameState {
   int32_t ytox_dc = 0, ytob_dc = 0;
   Splines splines;
   bool has_splines = false;
+  Patches patches;
+  bool has_patches = false;
+  const XybSlot* xyb_slots = nullptr;  // the reference frames kept before their colour transform
   float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool has_noise = false;
   MGlobal mglobal;
@@ -85,7 +90,11 @@ struct FrameState {
 
 static void DecodeDcGlobal(BitReader& br, FrameState* s) {
   const FrameHeader& fh = s->fh;
-  JXLO_CHECK(!(fh.flags & FrameHeader::kPatches), "unsupported: patches");
+  if (fh.flags & FrameHeader::kPatches) {  // dec_frame.cc:271-285
+    JXLO_CHECK(fh.upsampling == 1 && s->xyb_slots, "unsupported: patches on upsampled frames");
+    DecodePatches(br, s->dim.xsize_padded, s->dim.ysize_padded, s->ih->extra.size(), s->xyb_slots, &s->patches);
+    s->has_patches = true;
+  }
   if (fh.flags & FrameHeader::kSplines) {  // dec_frame.cc:289-293
     JXLO_CHECK(fh.upsampling == 1, "unsupported: splines on upsampled frames");
     DecodeSplines(br, s->dim.xsize * s->dim.ysize, &s->splines);
@@ -460,16 +469,17 @@ static void ReconstructGroup(FrameState* s, size_t g, const int32_t* coeffs) {
 // frame_index / nonvisible_index: the visible frames before this one and the invisible ones since (they seed the noise).
 // The frame is rendered at its own size; Decode() places it on the canvas (crop origin, blending with a reference slot).
 static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool want_dumps, size_t frame_index = 0,
-                        size_t nonvisible_index = 0) {
+                        size_t nonvisible_index = 0, const XybSlot* xyb_slots = nullptr) {
   FrameState st;
   FrameState* s = &st;
   s->out = out;
   s->ih = &ih;
   s->frame_index = frame_index;
   s->nonvisible_index = nonvisible_index;
+  s->xyb_slots = xyb_slots;
   ReadFrameHeader(br, ih, &s->fh);
   const FrameHeader& fh = s->fh;
-  JXLO_CHECK(fh.frame_type == 0 || fh.frame_type == 3, "unsupported: reference-only / DC frames");  // (3 = kSkipProgressive: a regular frame)
+  JXLO_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
   JXLO_CHECK(fh.upsampling == 1 || (!fh.modular && !ih.custom_upsampling), "unsupported: upsampled Modular frames / custom weights");
   JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
@@ -616,6 +626,15 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       for (int c = 0; c < 3; c++)
         memcpy(out->xyb_filtered.data() + c * d.xsize_padded * d.ysize, cur->p[c].data(), d.xsize_padded * d.ysize * sizeof(float));
     }
+    Planes3 patched;
+    if (s->has_patches) {  // dec_cache.cc:193-197: patches, then splines
+      patched = *cur;
+      ApplyPatches(s->patches, s->xyb_slots, patched.p[0].data(), patched.p[1].data(), patched.p[2].data(), patched.stride);
+      cur = &patched;
+      if (want_dumps)
+        for (int c = 0; c < 3; c++)
+          memcpy(out->xyb_filtered.data() + c * d.xsize_padded * d.ysize, cur->p[c].data(), d.xsize_padded * d.ysize * sizeof(float));
+    }
     Planes3 splined;
     if (s->has_splines) {  // dec_cache.cc:198-201: after the filters, before upsampling and noise
       InitSplineDrawCache(&s->splines, d.xsize, d.ysize, s->base_corr_x, s->base_corr_b);  // dec_frame.cc:303-308
@@ -647,6 +666,11 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
             memcpy(out->xyb_filtered.data() + c * d.xsize_padded * d.ysize, cur->p[c].data(), d.xsize_padded * d.ysize * sizeof(float));
         }
       }
+    }
+    if (fh.frame_type == 2 || fh.save_before_color_transform) {  // what a later frame's patches read
+      out->xyb_save.resize(3 * xs * ys);
+      for (int c = 0; c < 3; c++)
+        for (size_t y = 0; y < ys; y++) memcpy(out->xyb_save.data() + (c * ys + y) * xs, cur->p[c].data() + y * cur->stride, xs * sizeof(float));
     }
     OpsinParams op = MakeOpsinParams(ih);
 #pragma omp parallel for schedule(static)
@@ -683,10 +707,12 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
         for (size_t i = 0; i < xs * ys; i++) out->rgbf[c * xs * ys + i] = float(ch.d[i]) * factor;
       }
     }
+    if (s->has_patches) ApplyPatches(s->patches, s->xyb_slots, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs);
     if (s->has_splines) {  // the same stage on the three colour channels of a Modular frame (default colour correlation: 0, 1)
       InitSplineDrawCache(&s->splines, xs, ys, s->base_corr_x, s->base_corr_b);
       DrawSplines(s->splines, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs, xs, ys);
     }
+    if (fh.frame_type == 2 || fh.save_before_color_transform) out->xyb_save = out->rgbf;
     if (ih.xyb_encoded) {  // then the colour stage of every XYB frame
       OpsinParams op = MakeOpsinParams(ih);
       for (size_t i = 0; i < xs * ys; i++) {
@@ -769,10 +795,23 @@ static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dum
     std::vector<float> p[4];
     bool valid = false;
   } slots[4];
+  XybSlot xyb_slots[4];
   size_t visible = 0, nonvisible = 0;
   for (;;) {
-    DecodeFrame(br, ih, out, want_dumps && visible == frame_index, visible, nonvisible);
+    DecodeFrame(br, ih, out, want_dumps && visible == frame_index, visible, nonvisible, xyb_slots);
     const FrameHeader fh = out->fh;
+    if (fh.frame_type == 2 || (!fh.is_last && fh.save_before_color_transform)) {  // dec_frame.cc FinalizeFrame: kept in XYB
+      XybSlot& slot = xyb_slots[fh.save_as_reference];
+      slot.w = out->out_xsize;
+      slot.h = out->out_ysize;
+      for (int c = 0; c < 3; c++) slot.p[c].assign(out->xyb_save.begin() + c * slot.w * slot.h, out->xyb_save.begin() + (c + 1) * slot.w * slot.h);
+    }
+    if (fh.frame_type == 2) {  // never shown, never blended
+      nonvisible++;
+      *out = Decoded();
+      out->ih = ih;
+      continue;
+    }
     const bool shown = fh.is_last || fh.duration > 0;
     bool needs_blending = fh.custom_size || fh.blend.mode != 0;
     for (const BlendInfo& e : fh.ec_blend) needs_blending = needs_blending || e.mode != 0;
