@@ -32,13 +32,17 @@ size_t jxlamd_frame_end(const JxlAmdFrame* frame, uint32_t* duration_last_timeco
 typedef struct {
   int32_t x0, y0;
   uint32_t xsize, ysize;
-  uint32_t custom_size;
+  uint32_t custom_size, frame_type; /* frame_type: 0 regular, 2 reference only (kept in XYB for patches), 3 skip-progressive */
   uint32_t mode, alpha_mode, source, alpha_source, clamp, alpha_clamp;
   uint32_t duration, is_last, save_as_reference, save_before_color_transform;
 } JxlAmdFramePlacement;
 void jxlamd_frame_placement(const JxlAmdFrame* frame, JxlAmdFramePlacement* placement);
 /* The frame's position among the shown / invisible frames (seeds its noise: dec_frame.cc:160-168); before upload. */
 void jxlamd_frame_set_indices(JxlAmdFrame* frame, uint32_t visible_index, uint32_t nonvisible_index);
+/* The reference frames a frame's patches read (device XYB planes of the four slots, jxlhip_canvas_xyb_source); checks every
+ * patch rectangle against them. Before upload; returns non-zero (see jxlamd_last_error) when a patch refers to an empty
+ * slot or reaches outside its reference frame. */
+int jxlamd_frame_set_patch_sources(JxlAmdFrame* frame, const float* const* planes, const uint32_t* xsize, const uint32_t* ysize);
 void jxlamd_frame_free(JxlAmdFrame* frame);
 /* info[0..15]: xsize, ysize, xsize_blocks, ysize_blocks, num_groups, num_dc_groups, num_passes, used_acs mask,
  * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes, then of pass 0: log2 alphabet size,

@@ -84,6 +84,19 @@ typedef struct JxlHipSplines {
   const uint32_t* row_segments;
 } JxlHipSplines;
 
+/* The patches of a frame (lib/jxl/dec_patch_dictionary.cc): 8 u32 per position {x, y, xsize, ysize, x0 and y0 in the
+ * reference frame, reference slot, PatchBlendMode of the colour channels (0 none, 1 replace, 2 add, 3 multiply) | clamp
+ * << 8}; row y applies positions row_list[row_start[y] .. row_start[y + 1]) in that order. The reference frames are XYB
+ * planes on the device ([3][slot_h][slot_w], from jxlhip_canvas_xyb_source). num_positions = 0: no patches. */
+typedef struct JxlHipPatches {
+  uint32_t num_positions, num_row_entries;
+  const uint32_t* records;
+  const uint32_t* row_start; /* ysize + 1 entries */
+  const uint32_t* row_list;
+  const float* slot_planes[4];
+  uint32_t slot_w[4], slot_h[4];
+} JxlHipPatches;
+
 typedef struct JxlHipFrameDesc {
   uint32_t xsize, ysize;
   uint32_t xsize_blocks, ysize_blocks;
@@ -149,6 +162,8 @@ typedef struct JxlHipFrameDesc {
   /* Splines (render_pipeline/stage_splines.cc; the draw cache of lib/jxl/splines.cc:661-768, built by the host): drawn
    * over the filtered planes before noise and colour conversion. Only for frames that are not upsampled. */
   JxlHipSplines splines;
+  /* Patches: drawn over the filtered planes before the splines (dec_cache.cc:193-201). Not for upsampled frames. */
+  JxlHipPatches patches;
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);
@@ -355,6 +370,12 @@ typedef struct JxlHipBlend {
   uint32_t clamp, alpha_clamp;
   int32_t save_slot;          /* 0..3: the blended canvas is also kept in this slot; -1: not kept */
 } JxlHipBlend;
+/* Reference frames kept BEFORE the colour transform (kReferenceOnly frames, the sources of patches): copies the XYB
+ * planes `frame` holds after its last run (VarDCT: the filtered planes; Modular: needs jxlhip_set_option(frame,
+ * "keep_xyb_planes", 1) before the upload) into XYB slot 0..3; jxlhip_canvas_xyb_source hands the device planes out
+ * ([3][h][w]; NULL / 0 while the slot is empty). */
+int jxlhip_canvas_save_xyb(JxlHipCanvas* canvas, JxlHipContext* frame, uint32_t slot);
+int jxlhip_canvas_xyb_source(JxlHipCanvas* canvas, uint32_t slot, const float** planes, uint32_t* xsize, uint32_t* ysize);
 /* Blends the pixels `frame` holds (its last run, f32 x 4) into the canvas. */
 int jxlhip_canvas_blend(JxlHipCanvas* canvas, JxlHipContext* frame, const JxlHipBlend* blend);
 /* The canvas in a sample format (as jxlhip_set_output_format) and orientation (as jxlhip_set_output_orientation), into

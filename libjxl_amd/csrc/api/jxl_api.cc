@@ -107,6 +107,7 @@ static void FillPlacement(const jxh::ImageHeader& ih, const jxh::FrameHeader& fh
   p->xsize = uint32_t(xs);
   p->ysize = uint32_t(ys);
   p->custom_size = fh.custom_size;
+  p->frame_type = fh.frame_type;
   p->mode = fh.blend.mode;
   p->source = fh.blend.source;
   p->clamp = fh.blend.clamp;
@@ -126,6 +127,26 @@ void jxlamd_frame_placement(const JxlAmdFrame* f, JxlAmdFramePlacement* p) {
     p->xsize = uint32_t(f->plan.ih.xsize);
     p->ysize = uint32_t(f->plan.ih.ysize);
   }
+}
+int jxlamd_frame_set_patch_sources(JxlAmdFrame* f, const float* const* planes, const uint32_t* xs, const uint32_t* ys) {
+  g_last_error.clear();
+  jxh::FramePlan& P = f->plan;
+  for (int i = 0; i < 4; i++) {
+    P.patch_src[i] = planes[i];
+    P.patch_src_w[i] = planes[i] ? xs[i] : 0;
+    P.patch_src_h[i] = planes[i] ? ys[i] : 0;
+  }
+  for (const jxh::PatchRef& r : P.patches.refs) {  // dec_patch_dictionary.cc:63-83
+    if (!P.patch_src[r.slot]) {
+      g_last_error = "patches: the reference frame is missing";
+      return 2;
+    }
+    if (uint64_t(r.x0) + r.xsize > P.patch_src_w[r.slot] || uint64_t(r.y0) + r.ysize > P.patch_src_h[r.slot]) {
+      g_last_error = "patches: rectangle outside the reference frame";
+      return 2;
+    }
+  }
+  return 0;
 }
 void jxlamd_frame_set_indices(JxlAmdFrame* f, uint32_t visible_index, uint32_t nonvisible_index) {
   f->plan.frame_index = visible_index;
@@ -289,6 +310,19 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.band_group_row_end = group_row_end;
   d.has_noise = P.has_noise ? 1 : 0;
   FillSplines(P.has_splines, P.splines, &d.splines);
+  memset(&d.patches, 0, sizeof(d.patches));
+  if (P.has_patches && !P.patches.pos.empty()) {
+    d.patches.num_positions = uint32_t(P.patches.pos.size());
+    d.patches.num_row_entries = uint32_t(P.patch_row_list.size());
+    d.patches.records = P.patch_records.data();
+    d.patches.row_start = P.patch_row_start.data();
+    d.patches.row_list = P.patch_row_list.data();
+    for (int i = 0; i < 4; i++) {
+      d.patches.slot_planes[i] = P.patch_src[i];
+      d.patches.slot_w[i] = P.patch_src_w[i];
+      d.patches.slot_h[i] = P.patch_src_h[i];
+    }
+  }
   memcpy(d.noise_lut, P.noise_lut, sizeof(d.noise_lut));
   // dec_frame.cc:160-168: the number of visible frames before this one, and of invisible ones since (none are accepted)
   d.noise_frame_index[0] = uint32_t(P.frame_index);
@@ -986,6 +1020,11 @@ JxlDecoderStatus DecodeModularPixels(JxlDecoder* d, bool to_canvas) {
       if (e.type == 0 && e.alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
   if (!r) r = jxlhip_set_output_orientation(d->ctx, to_canvas ? 1 : UndoOrientation(d));
+  {
+    JxlAmdFramePlacement pl;
+    jxlamd_modframe_placement(d->mframe, &pl);
+    if (!r) r = jxlhip_set_option(d->ctx, "keep_xyb_planes", pl.frame_type == 2 ? 1 : 0);
+  }
   if (!r) r = jxlamd_modframe_upload(d->mframe, d->ctx);
   if (!r) r = jxlhip_modular_run(d->ctx);
   uint32_t info[16];
@@ -1037,6 +1076,12 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
   if (!r) r = jxlhip_set_output_orientation(d->ctx, orientation);
   if (!r) r = jxlhip_set_alpha(d->ctx, nullptr, 0, 0);
+  if (!r && P.has_patches) {  // the reference frames the patches read: the XYB slots of the canvas
+    const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t pw[4] = {0, 0, 0, 0}, ph[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < 4 && d->canvas; i++) jxlhip_canvas_xyb_source(d->canvas, i, &planes[i], &pw[i], &ph[i]);
+    if (jxlamd_frame_set_patch_sources(d->frame, planes, pw, ph)) return Fail(d, g_last_error);
+  }
   if (!r) r = jxlamd_frame_upload(d->frame, d->ctx);
   if (!r) r = jxlhip_run_entropy(d->ctx);
   std::vector<uint32_t> flags(P.dim.num_groups);
@@ -1099,13 +1144,18 @@ JxlDecoderStatus BlendIntoCanvas(JxlDecoder* d) {
   Placement(d, &p);
   const bool has_alpha = !d->ih.extra.empty() && d->ih.extra[0].type == 0;
   if (d->ih.extra.size() > 1 || (!d->ih.extra.empty() && !has_alpha)) return Fail(d, "unsupported: blending with extra channels other than alpha");
-  if (CanBeReferenced(p) && p.save_before_color_transform) return Fail(d, "unsupported: frames saved before the colour transform");
+  if (p.frame_type != 2 && CanBeReferenced(p) && p.save_before_color_transform) return Fail(d, "unsupported: regular frames saved before the colour transform");
   int r = 0;
   if (!d->canvas) {
     const char* dev = getenv("JXLHIP_DEVICE");
     r = jxlhip_canvas_create(dev ? atoi(dev) : 0, uint32_t(d->ih.xsize), uint32_t(d->ih.ysize), has_alpha ? 1 : 0,
                              has_alpha && d->ih.extra[0].alpha_associated ? 1 : 0, &d->canvas);
     if (r) return Fail(d, "jxlhip_canvas_create failed (" + std::to_string(r) + ")");
+  }
+  if (p.frame_type == 2) {  // kReferenceOnly: kept before the colour transform for the patches of later frames, never blended
+    r = jxlhip_canvas_save_xyb(d->canvas, d->ctx, p.save_as_reference);
+    if (r) return Fail(d, "jxlhip_canvas_save_xyb failed (" + std::to_string(r) + ")");
+    return JXL_DEC_SUCCESS;
   }
   JxlHipBlend b;
   memset(&b, 0, sizeof(b));

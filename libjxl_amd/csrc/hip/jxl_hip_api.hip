@@ -234,6 +234,12 @@ struct JxlHipContext {
   // splines (JxlHipSplines): the draw cache on the device; for a Modular frame also the float planes they are drawn over
   Buf spl_seg, spl_row_start, spl_row_seg, spl_planes;
   uint32_t spl_segments = 0;
+  // patches (JxlHipPatches): records and row lists on the device, the reference planes they read
+  Buf pat_rec, pat_row_start, pat_row_list;
+  uint32_t pat_positions = 0;
+  const float* pat_src[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint32_t pat_src_w[4] = {0, 0, 0, 0}, pat_src_h[4] = {0, 0, 0, 0};
+  bool keep_xyb = false;  // option "keep_xyb_planes": a Modular frame also leaves its colour as float planes (spl_planes)
   // noise synthesis (JxlHipFrameDesc::has_noise): raw random planes [3][ys][xs], LUT, seeds, base colour correlation
   Buf noise;
   bool has_noise = false;
@@ -409,7 +415,7 @@ static std::vector<Buf*> AllBufs(JxlHipContext* c) {
   std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
-                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes,
+                &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
                 &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob};
   for (auto& pb : c->pass_bufs)
     for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset, &pb.alias_packed}) all.push_back(b);
@@ -683,6 +689,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     add(size_t(d->num_passes) * sizeof(jxlhip::PassDev)); add(64 * 25 * 4); add((size_t(d->num_blocks) + 1) * 4);
     add((size_t(d->num_blocks) + 16) * 4); add(sizeof(jxlhip::EntropyParams)); add(size_t(d->dequant_floats) * 4);
     add(size_t(d->splines.num_segments) * 32); add((size_t(d->ysize) + 1) * 4); add(size_t(d->splines.num_row_segments) * 4 + 16);
+    add(size_t(d->patches.num_positions) * 32); add((size_t(d->ysize) + 1) * 4); add(size_t(d->patches.num_row_entries) * 4 + 16);
     if ((r = BlobBegin(c, bound))) return r;
   }
   struct BlobGuard {  // whatever the outcome, later uploads of other kinds see the plain mode
@@ -838,6 +845,39 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     c->color_out = true;
   }
   if ((r = UploadSplines(c, d->splines, c->ys))) return r;
+  // patches: validated like every table a kernel indexes with (rectangles inside the frame and inside their reference)
+  c->pat_positions = 0;
+  if (d->patches.num_positions) {
+    const JxlHipPatches& pt = d->patches;
+    if (c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
+    if (!pt.records || !pt.row_start || !pt.row_list || pt.num_positions > (1u << 24) || pt.num_row_entries > (1u << 26)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (pt.row_start[0] != 0 || pt.row_start[c->ys] != pt.num_row_entries) return JXLHIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t y = 0; y < c->ys; y++)
+      if (pt.row_start[y] > pt.row_start[y + 1]) return JXLHIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t i = 0; i < pt.num_positions; i++) {
+      const uint32_t* q = pt.records + size_t(i) * 8;
+      const uint32_t slot = q[6];
+      if (slot > 3 || !pt.slot_planes[slot] || (q[7] & 255) > 3 || !q[2] || !q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (uint64_t(q[4]) + q[2] > pt.slot_w[slot] || uint64_t(q[5]) + q[3] > pt.slot_h[slot]) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (uint64_t(q[0]) + q[2] > c->xp || uint64_t(q[1]) + q[3] > c->yp) return JXLHIP_ERR_INVALID_ARGUMENT;
+    }
+    for (uint32_t y = 0; y < c->ys; y++)
+      for (uint32_t i = pt.row_start[y]; i < pt.row_start[y + 1]; i++) {
+        if (pt.row_list[i] >= pt.num_positions) return JXLHIP_ERR_INVALID_ARGUMENT;
+        const uint32_t* q = pt.records + size_t(pt.row_list[i]) * 8;
+        if (y < q[1] || y >= q[1] + q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the row is one of the patch's rows)
+      }
+    c->color_out = true;
+    if ((r = Upload(c, c->pat_rec, pt.records, size_t(pt.num_positions) * 32))) return r;
+    if ((r = Upload(c, c->pat_row_start, pt.row_start, (size_t(c->ys) + 1) * 4))) return r;
+    if ((r = Upload(c, c->pat_row_list, pt.row_list, std::max<size_t>(4, size_t(pt.num_row_entries) * 4)))) return r;
+    for (int i = 0; i < 4; i++) {
+      c->pat_src[i] = pt.slot_planes[i];
+      c->pat_src_w[i] = pt.slot_w[i];
+      c->pat_src_h[i] = pt.slot_h[i];
+    }
+    c->pat_positions = pt.num_positions;
+  }
   if (c->have_alpha && c->alpha.cap < size_t(c->oxs) * c->oys * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
   if ((c->keep_filtered || c->ups != 1 || c->color_out) && (r = c->plane[1].Ensure(plane_bytes))) return r;
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
@@ -1067,6 +1107,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   lap("rest");
   if (prof) fprintf(stderr, "[upload] %s\n", prof_line.c_str());
   c->have_frame = true;
+  c->mod.have = false;  // (the context now holds a VarDCT frame, not the Modular one it may have held before)
   return 0;
 }
 
@@ -2005,7 +2046,8 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
     M.xyb_color.linear_output = d->linear_output;
   }
   if ((r = UploadSplines(c, d->splines, d->ysize))) return r;
-  if (c->spl_segments && (r = c->spl_planes.Ensure(size_t(d->xsize) * d->ysize * 3 * 4))) return r;
+  if ((c->spl_segments || c->keep_xyb) && d->num_color != 3) return JXLHIP_ERR_UNSUPPORTED;
+  if ((c->spl_segments || c->keep_xyb) && (r = c->spl_planes.Ensure(size_t(d->xsize) * d->ysize * 3 * 4))) return r;
   M.have = true;
   M.batch_ctxs.clear();
   c->generation++;
@@ -2103,7 +2145,7 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
     for (size_t i = 0; i < n; i++) {
       const JxlHipContext* c = ctxs[i];
       const JxlHipContext::Modular& M = c->mod;
-      if (!c->spl_segments) continue;
+      if (pass == 4 ? !(c->spl_segments || c->keep_xyb) : !c->spl_segments) continue;
       if (pass == 4) {
         jxlhip::ModOutput o;
         memset(&o, 0, sizeof(o));
@@ -2149,7 +2191,7 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
     int32_t* pool = M.pool.as<int32_t>();
     jxlhip::ModOutput o;
     memset(&o, 0, sizeof(o));
-    if (c->spl_segments) {
+    if (c->spl_segments || c->keep_xyb) {
       o.fplanes = c->spl_planes.as<float>();
       o.fmode = 2;
     }
@@ -2366,6 +2408,28 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
   }
   for (size_t i = 0; i < n; i++) {
     const JxlHipContext* c = ctxs[i];
+    if (!c->pat_positions) continue;
+    jxlhip::PatchParams pp;
+    memset(&pp, 0, sizeof(pp));
+    pp.planes = c->plane[1].as<float>();
+    pp.records = c->pat_rec.as<uint32_t>();
+    pp.row_start = c->pat_row_start.as<uint32_t>();
+    pp.row_list = c->pat_row_list.as<uint32_t>();
+    for (int k = 0; k < 4; k++) {
+      pp.slot_planes[k] = c->pat_src[k];
+      pp.slot_w[k] = c->pat_src_w[k];
+      pp.slot_h[k] = c->pat_src_h[k];
+    }
+    pp.stride = c->xp;
+    pp.plane_stride = size_t(c->xp) * c->yp;
+    pp.xsize = c->xs;
+    pp.y_begin = c->band_y0;
+    pp.y_end = c->band_y1;
+    hipLaunchKernelGGL(jxlhip::k_patches_add, dim3(c->band_y1 - c->band_y0), dim3(256), 0, ls, pp);
+    HIP_TRY(hipGetLastError());
+  }
+  for (size_t i = 0; i < n; i++) {
+    const JxlHipContext* c = ctxs[i];
     if (!c->spl_segments) continue;
     jxlhip::SplineParams sp;
     memset(&sp, 0, sizeof(sp));
@@ -2474,6 +2538,11 @@ int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
   }
   if (std::string(name) == "filter_async") {
     c->filter_async = value != 0;
+    return 0;
+  }
+  if (std::string(name) == "keep_xyb_planes") {  // (takes effect at the next Modular upload)
+    c->keep_xyb = value != 0;
+    c->generation++;
     return 0;
   }
   if (std::string(name) == "blocking_sync") {
@@ -2738,6 +2807,8 @@ struct JxlHipCanvas {
   bool has_alpha = false, premultiplied = false;
   Buf cur, slot[4], pixels;
   bool slot_valid[4] = {false, false, false, false};
+  Buf xyb[4];  // reference frames kept before the colour transform: [3][xyb_h][xyb_w]
+  uint32_t xyb_w[4] = {0, 0, 0, 0}, xyb_h[4] = {0, 0, 0, 0};
   hipStream_t last_stream = nullptr;  // the stream of the last blend: later work on the canvas is ordered behind it
 };
 
@@ -2767,7 +2838,56 @@ void jxlhip_canvas_destroy(JxlHipCanvas* v) {
   v->cur.Free();
   v->pixels.Free();
   for (Buf& b : v->slot) b.Free();
+  for (Buf& b : v->xyb) b.Free();
   delete v;
+}
+
+int jxlhip_canvas_save_xyb(JxlHipCanvas* v, JxlHipContext* c, uint32_t slot) {
+  if (!v || !c || slot > 3 || c->device != v->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(v->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  const float* src;
+  size_t src_stride, src_plane;
+  uint32_t w, h;
+  if (c->mod.have) {  // a Modular frame (a later VarDCT upload clears the flag): the float planes of the "keep_xyb_planes" pass
+    if (!c->keep_xyb || !c->spl_planes.p) return JXLHIP_ERR_INVALID_ARGUMENT;
+    w = c->mod.xs;
+    h = c->mod.ys;
+    src = c->spl_planes.as<float>();
+    src_stride = w;
+    src_plane = size_t(w) * h;
+  } else if (c->have_frame) {  // a VarDCT frame: the filtered planes (patches, splines, noise already on them)
+    if (c->ups != 1 || !c->color_out || !c->plane[1].p) return JXLHIP_ERR_UNSUPPORTED;
+    w = c->xs;
+    h = c->ys;
+    src = c->plane[1].as<float>();
+    src_stride = c->xp;
+    src_plane = size_t(c->xp) * c->yp;
+  } else {
+    return JXLHIP_ERR_NO_FRAME;
+  }
+  int r = v->xyb[slot].Ensure(size_t(w) * h * 12);
+  if (r) return r;
+  if (v->last_stream && v->last_stream != c->stream) HIP_TRY(hipStreamSynchronize(v->last_stream));
+  hipLaunchKernelGGL(jxlhip::k_copy_planes, dim3((w + 255) / 256, h, 3), dim3(256), 0, c->stream, src, src_stride, src_plane,
+                     v->xyb[slot].as<float>(), w, h);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (later frames read the slot from other streams of other contexts)
+  v->xyb_w[slot] = w;
+  v->xyb_h[slot] = h;
+  v->last_stream = c->stream;
+  return 0;
+}
+
+int jxlhip_canvas_xyb_source(JxlHipCanvas* v, uint32_t slot, const float** planes, uint32_t* xsize, uint32_t* ysize) {
+  if (!v || slot > 3 || !planes || !xsize || !ysize) return JXLHIP_ERR_INVALID_ARGUMENT;
+  *planes = v->xyb_w[slot] ? v->xyb[slot].as<float>() : nullptr;
+  *xsize = v->xyb_w[slot];
+  *ysize = v->xyb_h[slot];
+  return 0;
 }
 
 int jxlhip_canvas_blend(JxlHipCanvas* v, JxlHipContext* c, const JxlHipBlend* b) {

@@ -79,6 +79,13 @@ __global__ __launch_bounds__(256) void k_canvas_blend(BlendParams P) {
   for (int c = 0; c < 4; c++) P.out[c * plane + i] = o[c];
 }
 
+// Three planes of w x h samples out of planes with a row stride (a frame's XYB planes into a reference slot).
+__global__ __launch_bounds__(256) void k_copy_planes(const float* __restrict__ src, size_t src_stride, size_t src_plane, float* __restrict__ dst,
+                                                     uint32_t w, uint32_t h) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, c = blockIdx.z;
+  if (x < w) dst[(size_t(c) * h + y) * w + x] = src[c * src_plane + size_t(y) * src_stride + x];
+}
+
 // The canvas in the caller's sample format and orientation (StorePixel: stage_write.cc's conversions and dither).
 __global__ __launch_bounds__(256) void k_canvas_out(const float* __restrict__ canvas, PixelOut po) {
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;

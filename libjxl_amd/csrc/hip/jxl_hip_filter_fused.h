@@ -1024,5 +1024,40 @@ __global__ __launch_bounds__(256) void k_splines_add_batch(const SplineParams* o
   if (y < P.y_end) SplinesAddRow(P, y);
 }
 
+// ---- patches (lib/jxl/dec_patch_dictionary.cc:317-356 AddOneRow + blending.cc PerformBlending for the alpha-free colour
+// modes): like the splines, one workgroup per row walks the row's positions in dictionary order and a thread owns the
+// samples x = tid (mod 256), so that overlapping patches combine in the order the dictionary gives.
+struct PatchParams {
+  float* planes;  // [3] planes `plane_stride` floats apart, rows of `stride` floats
+  const uint32_t* records;
+  const uint32_t* row_start;
+  const uint32_t* row_list;
+  const float* slot_planes[4];
+  uint32_t slot_w[4], slot_h[4];
+  size_t stride, plane_stride;
+  uint32_t xsize, y_begin, y_end;
+};
+__global__ __launch_bounds__(256) void k_patches_add(PatchParams P) {
+  const uint32_t y = P.y_begin + blockIdx.x, tid = threadIdx.x;
+  if (y >= P.y_end) return;
+  for (uint32_t i = P.row_start[y]; i < P.row_start[y + 1]; i++) {
+    const uint32_t* r = P.records + size_t(P.row_list[i]) * 8;
+    const uint32_t px = r[0], py = r[1], w = r[2], rx0 = r[4], ry0 = r[5], slot = r[6], mode = r[7] & 255, clamp = r[7] >> 8;
+    if (mode == 0) continue;
+    const float* src = P.slot_planes[slot];
+    const size_t sw = P.slot_w[slot], splane = sw * P.slot_h[slot];
+    const uint32_t x1 = min(px + w, P.xsize);
+    for (uint32_t x = (px & ~255u) + tid; x < x1; x += 256) {
+      if (x < px) continue;
+      const size_t si = size_t(ry0 + (y - py)) * sw + rx0 + (x - px);
+      float* p = P.planes + size_t(y) * P.stride + x;
+      for (int c = 0; c < 3; c++) {
+        const float fg = src[c * splane + si], bg = p[c * P.plane_stride];
+        p[c * P.plane_stride] = mode == 1 ? fg : (mode == 2 ? bg + fg : bg * (clamp ? __builtin_amdgcn_fmed3f(fg, 0.0f, 1.0f) : fg));
+      }
+    }
+  }
+}
+
 }  // namespace jxlhip
 #endif  // JXL_HIP_FILTER_FUSED_H_

@@ -18,6 +18,7 @@
 #include "jxh_entropy.h"
 #include "jxh_headers.h"
 #include "jxh_modular.h"
+#include "jxh_patches.h"
 #include "jxh_splines.h"
 #include "jxh_vardct.h"
 
@@ -77,6 +78,11 @@ struct FramePlan {
   // AC sections: for pass p, group g: index p * num_groups + g
   float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // noise synthesis (frame flag kNoise): strength LUT
   bool has_noise = false;
+  Patches patches;  // frame flag kPatches: dictionary (jxh_patches.h) and its device layout
+  bool has_patches = false;
+  std::vector<uint32_t> patch_records, patch_row_start, patch_row_list;
+  const float* patch_src[4] = {nullptr, nullptr, nullptr, nullptr};  // device planes of the reference slots (set_patch_sources)
+  uint32_t patch_src_w[4] = {0, 0, 0, 0}, patch_src_h[4] = {0, 0, 0, 0};
   Splines splines;  // frame flag kSplines: dictionary + draw cache (jxh_splines.h)
   bool has_splines = false;
   std::vector<uint64_t> section_offset;  // byte offset inside the codestream buffer handed to ParseFrame
@@ -161,7 +167,7 @@ class FrameParser {
     BitReader br(data_ + pos, codestream_base_ + cs_size_ - pos);
     ReadFrameHeader(br, ih, &P.fh);
     const FrameHeader& fh = P.fh;
-    JXH_CHECK(fh.frame_type == 0 || fh.frame_type == 3, "unsupported: reference-only / DC frames");  // (3 = kSkipProgressive: a regular frame)
+    JXH_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
     JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
     JXH_CHECK(fh.upsampling == 1 || !ih.custom_upsampling, "unsupported: custom upsampling weights");
@@ -169,7 +175,8 @@ class FrameParser {
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(ih.extra.empty() || fh.upsampling == 1, "unsupported: extra channels of upsampled frames");
-    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kUseDcFrame)), "unsupported: patches/DC frames");
+    JXH_CHECK(!(fh.flags & FrameHeader::kUseDcFrame), "unsupported: DC frames");
+    JXH_CHECK(!(fh.flags & FrameHeader::kPatches) || fh.upsampling == 1, "unsupported: patches on upsampled frames");
     JXH_CHECK(!(fh.flags & FrameHeader::kSplines) || fh.upsampling == 1, "unsupported: splines on upsampled frames");
     JXH_CHECK(!(fh.flags & FrameHeader::kNoise) || fh.upsampling == 1, "unsupported: noise on upsampled frames");
     P.dim = MakeFrameDim(fh);
@@ -259,6 +266,11 @@ class FrameParser {
 
  private:
   void DcGlobal(BitReader& br, FramePlan* P) {
+    if (P->fh.flags & FrameHeader::kPatches) {  // dec_frame.cc:271-285
+      DecodePatches(br, P->dim.xsize_padded, P->dim.ysize_padded, P->ih.extra.size(), &P->patches);
+      BuildPatchRows(P->patches, P->dim.ysize, &P->patch_records, &P->patch_row_start, &P->patch_row_list);
+      P->has_patches = true;
+    }
     if (P->fh.flags & FrameHeader::kSplines) {  // dec_frame.cc:289-293
       DecodeSplines(br, P->dim.xsize * P->dim.ysize, &P->splines);
       P->has_splines = true;

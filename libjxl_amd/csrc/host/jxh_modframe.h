@@ -70,7 +70,7 @@ class ModFrameParser {
     ReadFrameHeader(br, ih, &P.fh);
     const FrameHeader& fh = P.fh;
     JXH_CHECK(fh.modular, "not a Modular frame");
-    JXH_CHECK(fh.frame_type == 0 || fh.frame_type == 3, "unsupported: reference-only / DC frames");  // (3 = kSkipProgressive: a regular frame)
+    JXH_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
     // (where the frame sits on the canvas and how it blends: the caller's business, as for FrameParser::ParseFrame)
     JXH_CHECK(!fh.ycbcr, "unsupported: YCbCr Modular frames");
     JXH_CHECK(!(ih.xyb_encoded && ih.gray), "unsupported: grey XYB Modular frames");

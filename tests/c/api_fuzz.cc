@@ -30,6 +30,9 @@ void jxlhip_canvas_destroy(JxlHipCanvas*) {}
 int jxlhip_canvas_blend(JxlHipCanvas*, JxlHipContext*, const JxlHipBlend*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_canvas_download(JxlHipCanvas*, uint32_t, uint32_t, uint32_t, int, uint32_t, void*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_canvas_download_alpha(JxlHipCanvas*, float*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_canvas_save_xyb(JxlHipCanvas*, JxlHipContext*, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_canvas_xyb_source(JxlHipCanvas*, uint32_t, const float**, uint32_t*, uint32_t*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_set_option(JxlHipContext*, const char*, int) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 }
 
 static uint64_t g_rng = 0x9E3779B97F4A7C15ull;

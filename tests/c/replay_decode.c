@@ -101,6 +101,7 @@ int main(int argc, char** argv) {
     JxlDecoderStatus st = JxlDecoderProcessInput(dec);
     if (st == JXL_DEC_ERROR) {
       printf("event ERROR\n");
+      { extern const char* jxlamd_last_error(void); printf("last error: %s\n", jxlamd_last_error()); }
       rc = JxlDecoderGetFrameHeader(dec, &fh) == JXL_DEC_SUCCESS && g_pixels ? 3 : 1;
       break;
     } else if (st == JXL_DEC_NEED_MORE_INPUT) {

@@ -95,6 +95,8 @@ def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
         J.set_splines(None)
     with_splines.append(open(os.path.join(ROOT, "tests", "golden", "ref_wasm_splines.jxl"), "rb").read())
     with_splines.append(J.encode_lossless(img, J.MODULAR_XYB | J.LOSSLESS_SQUEEZE))
+    with_splines.append(J.encode_patched(img, J.synth_image(64, 48, seed=9), [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(10, 10, 2, 0), (250, 170, 1, 0)]),
+                                                                            dict(x0=30, y0=0, xsize=30, ysize=40, positions=[(60, 120, 3, 1)])]))
     patch = J.synth_image(80, 60, seed=2)
     ramp = ((np.mgrid[0:60, 0:80][1] * 255) // 79).astype(np.uint8)
     with_splines.append(J.encode_layers([dict(img=np.dstack([img, img[..., 0]]), save_as=1, duration=2),

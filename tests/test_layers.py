@@ -50,7 +50,7 @@ def test_host_reports_the_placement_of_every_frame(built):
 
     class Placement(ctypes.Structure):
         _fields_ = [("x0", ctypes.c_int32), ("y0", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in (
-            "xsize", "ysize", "custom_size", "mode", "alpha_mode", "source", "alpha_source", "clamp", "alpha_clamp", "duration",
+            "xsize", "ysize", "custom_size", "frame_type", "mode", "alpha_mode", "source", "alpha_source", "clamp", "alpha_clamp", "duration",
             "is_last", "save_as_reference", "save_before_color_transform")]
 
     L.jxlamd_modframe_placement.argtypes = [ctypes.c_void_p, ctypes.POINTER(Placement)]

@@ -1,0 +1,71 @@
+"""Patches (lib/jxl/dec_patch_dictionary.cc, render_pipeline/stage_patches.cc): a reference-only frame
+kept before its colour transform (what libjxl codes its patch atlas as: an XYB Modular frame), and a frame whose
+dictionary draws rectangles of it over the decoded XYB planes, before the splines. CPU part: the oracle's placement
+against the atlas decoded on its own, the host's parse; GPU part: k_patches_add behind the decoder API against the oracle."""
+import numpy as np
+import pytest
+
+import replay_util as R
+
+
+def _case(J):
+    img = J.synth_image(300, 200, seed=5)
+    atlas = J.synth_image(64, 48, seed=9)
+    patches = [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(10, 10, 2, 0), (100, 50, 2, 0), (250, 170, 1, 0), (255, 175, 2, 0)]),
+               dict(x0=30, y0=0, xsize=30, ysize=40, positions=[(60, 120, 3, 1), (200, 20, 2, 0), (270, 160, 0, 0)])]
+    return img, atlas, patches
+
+
+def test_oracle_places_replaced_patches_exactly(built):
+    """PatchBlendMode kReplace copies the reference's XYB samples: inside such a rectangle (where nothing else is drawn) the
+    picture is the atlas decoded as a still of its own, pixel for pixel; outside every rectangle it is the frame without
+    patches."""
+    import jxlo
+    J = built
+    img, atlas, _ = _case(J)
+    patches = [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(250, 170, 1, 0), (16, 8, 1, 0)])]
+    data = J.encode_patched(img, atlas, patches, lossless=True)
+    got = jxlo.Decoded(data, dumps=False).rgb8
+    plain = jxlo.Decoded(J.encode_lossless(img, J.MODULAR_XYB), dumps=False).rgb8
+    alone = jxlo.Decoded(J.encode_lossless(atlas, J.MODULAR_XYB), dumps=False).rgb8
+    # (the 8-bit conversion dithers by position: compare within 1 level)
+    for (x, y) in ((250, 170), (16, 8)):
+        assert np.abs(got[y:y + 16, x:x + 20].astype(int) - alone[6:22, 4:24].astype(int)).max() <= 1
+    mask = np.ones(got.shape[:2], bool)
+    mask[170:186, 250:270] = False
+    mask[8:24, 16:36] = False
+    assert np.array_equal(got[mask], plain[mask])
+
+
+def test_host_parses_reference_frames_and_dictionaries(built):
+    J = built
+    img, atlas, patches = _case(J)
+    for kw in (dict(), dict(atlas_vardct=True)):
+        data = J.encode_patched(img, atlas, patches, **kw)
+        first = (J.Frame if kw else J.ModFrame)(data)
+        assert (first.info["xsize"], first.info["ysize"]) == (64, 48) and not first.is_last
+        second = J.Frame(data, frame_pos=first.end, frame_index=1)
+        assert (second.info["xsize"], second.info["ysize"]) == (300, 200) and second.is_last and second.end == len(data)
+        first.close()
+        second.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(atlas_vardct=True), dict(epf_iters=2, noise=40)])
+def test_patches_through_the_gpu(built, tmp_path, kw):
+    """Reference frame (XYB Modular like libjxl's, or VarDCT) -> XYB slot on the device canvas; VarDCT frame with add /
+    replace / multiply / none patches, overlapping ones in dictionary order; with EPF2 + noise behind them."""
+    import jxlo
+    J = built
+    img, atlas, patches = _case(J)
+    data = J.encode_patched(img, atlas, patches, **kw)
+    o = jxlo.Decoded(data)
+    want8, wantf = o.rgb8.copy(), o.planes("rgbf").transpose(1, 2, 0).copy()
+    o.close()
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+    assert rc == 0 and [e for e in events if e in ("FRAME", "FULL_IMAGE")] == ["FRAME", "FULL_IMAGE"], out
+    got = np.frombuffer(px, np.float32).reshape(200, 300, 3)
+    assert np.abs(got - wantf).max() < 1e-4
+    rc, events, out, px = R.run(R.container(data), tmp_path, "u8", 3, "chunk=4000")
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.uint8).reshape(200, 300, 3).astype(int) - want8.astype(int)).max() <= 1
