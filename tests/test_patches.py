@@ -69,3 +69,31 @@ def test_patches_through_the_gpu(built, tmp_path, kw):
     rc, events, out, px = R.run(R.container(data), tmp_path, "u8", 3, "chunk=4000")
     assert rc == 0, out
     assert np.abs(np.frombuffer(px, np.uint8).reshape(200, 300, 3).astype(int) - want8.astype(int)).max() <= 1
+
+
+def test_patch_rectangles_are_checked_against_the_reference_frames(built):
+    """jxlamd_frame_set_patch_sources (dec_patch_dictionary.cc:63-83): a patch that names an empty slot, or reaches outside
+    the reference frame it names, is refused before anything is uploaded (the pointers are only carried, never read here)."""
+    import ctypes
+    J = built
+    L = J.lib()
+    img, atlas, patches = _case(J)
+    data = J.encode_patched(img, atlas, patches)  # slot 1, rectangles up to x = 60, y = 40 of the 64 x 48 atlas
+    first = J.ModFrame(data)
+    f = J.Frame(data, frame_pos=first.end, frame_index=1)
+    first.close()
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.jxlamd_frame_set_patch_sources.argtypes = [ctypes.c_void_p, ctypes.POINTER(fp), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+    L.jxlamd_last_error.restype = ctypes.c_char_p
+    dummy = (ctypes.c_float * 4)()
+    some = ctypes.cast(dummy, fp)
+
+    def check(slots, w, h):
+        planes = (fp * 4)(*[some if s else fp() for s in slots])
+        return L.jxlamd_frame_set_patch_sources(f._h, planes, (ctypes.c_uint32 * 4)(*w), (ctypes.c_uint32 * 4)(*h))
+
+    assert check([0, 1, 0, 0], [0, 64, 0, 0], [0, 48, 0, 0]) == 0
+    assert check([1, 0, 1, 1], [64, 0, 64, 64], [48, 0, 48, 48]) != 0 and b"missing" in L.jxlamd_last_error()
+    assert check([0, 1, 0, 0], [0, 59, 0, 0], [0, 48, 0, 0]) != 0 and b"outside" in L.jxlamd_last_error()
+    assert check([0, 1, 0, 0], [0, 64, 0, 0], [0, 39, 0, 0]) != 0 and b"outside" in L.jxlamd_last_error()
+    f.close()
