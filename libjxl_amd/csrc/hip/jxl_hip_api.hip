@@ -767,8 +767,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     if ((r = Upload(c, pb.alias, s.alias, alias_bytes))) return r;
     {
       // alias entry {cutoff u8, right u8, freq0 u16 | offsets1 u16, freq1 u16} -> the lane kernel's form
-      //   x = (freq0 - 1) & 0xFFF | cutoff << 24                    taken when pos <  cutoff: symbol = slot, offset = pos
-      //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24    taken when pos >= cutoff
+      //   x = (freq0 - 1) & 0xFFF | uint config << 12 | cutoff << 24   taken when pos <  cutoff: symbol = slot, offset = pos
+      //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24        taken when pos >= cutoff
+      // (uint config of the entry's cluster: split_exponent | msb_in_token << 4 | lsb_in_token << 8, validated below)
       void* st = nullptr;
       if ((r = StageAlloc(c, alias_bytes ? alias_bytes : 16, &st))) return r;
       const uint32_t* src = reinterpret_cast<const uint32_t*>(s.alias);
@@ -776,7 +777,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       for (size_t i = 0; i < alias_bytes / 8; i++) {
         const uint32_t ex = src[2 * i], ey = src[2 * i + 1];
         const uint32_t cutoff = ex & 0xFF, right = (ex >> 8) & 0xFF, freq0 = ex >> 16, offs1 = ey & 0xFFFF, freq1 = ey >> 16;
-        dst[2 * i] = ((freq0 - 1) & 0xFFFu) | (cutoff << 24);
+        const uint32_t uc = s.uint_cfg[i >> s.log_alpha];
+        const uint32_t cfg12 = (uc & 15u) | (((uc >> 8) & 15u) << 4) | (((uc >> 16) & 15u) << 8);
+        dst[2 * i] = ((freq0 - 1) & 0xFFFu) | (cfg12 << 12) | (cutoff << 24);
         dst[2 * i + 1] = ((freq1 - 1) & 0xFFFu) | ((offs1 & 0xFFFu) << 12) | (right << 24);
       }
       if ((r = UploadStaged(c, pb.alias_packed, st, alias_bytes))) return r;
@@ -1492,17 +1495,24 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
     HIP_TRY(hipStreamSynchronize(c0->stream));
     HIP_TRY(hipMemcpy(h.data(), b.prof, nwaves * 64, hipMemcpyDeviceToHost));
     (void)hipFree(b.prof);
-    unsigned long long mx[7] = {0, 0, 0, 0, 0, 0, 0};
-    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    // per wave: {cycles total, cycles in service, service calls, hot trips, lane-trips taken, service: waiting for the
+    // previous phase's DMA / flush + DMA requests / transitions}; one JSON line: the longest wave and the mean over waves
+    unsigned long long mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t used = 0;
     for (size_t w = 0; w < nwaves; w++) {
       if (!h[w * 8 + 3] && !h[w * 8 + 2]) continue;
       used++;
-      if (h[w * 8] > mx[0]) for (int j = 0; j < 7; j++) mx[j] = h[w * 8 + j];
-      for (int j = 0; j < 7; j++) sum[j] += double(h[w * 8 + j]);
+      if (h[w * 8] > mx[0]) for (int j = 0; j < 8; j++) mx[j] = h[w * 8 + j];
+      for (int j = 0; j < 8; j++) sum[j] += double(h[w * 8 + j]);
     }
-    fprintf(stderr, "[lanes prof] waves %zu  longest: cycles %llu service %llu (%llu calls) trips %llu hot0 %llu hot1 %llu | mean: cycles %.0f service %.0f calls %.0f trips %.0f hot0 %.0f hot1 %.0f landing %.0f\n",
-            used, mx[0], mx[1], mx[2], mx[3], mx[4], mx[5], sum[0] / used, sum[1] / used, sum[2] / used, sum[3] / used, sum[4] / used, sum[5] / used, sum[6] / used);
+    const char* names[8] = {"cycles", "refill_cycles", "passes", "trips", "lane_trips", "trip_cycles", "pass_lanes_served", "pass_cycles"};
+    std::string line = "{\"waves\": " + std::to_string(used) + ", \"longest\": {";
+    for (int j = 0; j < 8; j++) line += std::string(j ? ", " : "") + "\"" + names[j] + "\": " + std::to_string(mx[j]);
+    line += "}, \"mean\": {";
+    for (int j = 0; j < 8; j++) line += std::string(j ? ", " : "") + "\"" + names[j] + "\": " + std::to_string((unsigned long long)(sum[j] / (used ? used : 1)));
+    line += "}}";
+    fprintf(stderr, "[lanes prof] %s\n", line.c_str());
   }
   return 0;
 }
@@ -1603,7 +1613,37 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
         u.lanes = want > u.count ? u.count : (want < u.min_lanes ? u.min_lanes : want);
       }
     }
+    // Dense regime: a frame's few largest sections decide how long its launch lasts (the lane that decodes one of them
+    // runs one token per trip whatever the other lanes do, and every transition pass of the wave delays it), so they get a
+    // wave of their own with few lanes (few transitions to serve) beside the wave for all the other sections; the two
+    // share one set of LDS rows (EntropyLaneBatch::wave_log_ls).
+    const uint32_t split = (wpg == 1 && lanes_per_wave == 64) ? uint32_t(EnvInt("JXLHIP_SPLIT", 0)) : 0u;  // (0: measured slower on the benchmark frames)
+    std::vector<uint8_t> wg_shared;  // per workgroup: its waves share one row set
+    if (split && split < 64) {
+      wpg = 2;
+      c0->batch_wpg = 2;
+    }
     for (const Unit& u : units) {
+      if (split && split < 64) {
+        const uint32_t heavy = u.count >= 64 ? split : 0u;  // (a small unit: one wave)
+        const uint32_t first_index = uint32_t(unit_desc.size() / 4);
+        const uint32_t parts[2][2] = {{u.begin, heavy}, {u.begin + heavy, u.count - heavy}};
+        for (int part = 0; part < 2; part++) {
+          unit_desc.push_back(u.frame | u.sel << 16);
+          unit_desc.push_back(parts[part][0]);
+          unit_desc.push_back(parts[part][1]);
+          unit_desc.push_back(u.pass);
+        }
+        const uint32_t light_lanes = std::min<uint32_t>(64 - heavy, u.count - heavy);
+        map.push_back(first_index);
+        map.push_back(first_index + 1);
+        wave_lanes.push_back(uint8_t(heavy));
+        wave_lanes.push_back(uint8_t(light_lanes));
+        wave_ls.push_back(uint8_t(0x80 | (64 - heavy) % 64));  // the heavy wave's lanes use the top columns
+        wave_ls.push_back(uint8_t(0x80));
+        wg_shared.push_back(1);
+        continue;
+      }
       const uint32_t per_wg = lanes_per_wave * wpg;
       const uint32_t wgs = (u.lanes + per_wg - 1) / per_wg;
       const uint32_t waves = wgs * wpg;
@@ -1612,12 +1652,11 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
       unit_desc.push_back(u.begin);
       unit_desc.push_back(u.count);
       unit_desc.push_back(u.pass);
-      for (uint32_t j = 0; j < wgs; j++) map.push_back(unit_index);
+      for (uint32_t j = 0; j < wgs; j++) wg_shared.push_back(0);
       for (uint32_t w = 0; w < waves; w++) {  // even split of the unit's lanes over its waves
         const uint32_t cnt = u.lanes / waves + (w < u.lanes % waves ? 1u : 0u);
-        uint32_t l2 = 0;
-        while ((1u << l2) < cnt) l2++;
-        wave_ls.push_back(uint8_t(l2));
+        map.push_back(unit_index);
+        wave_ls.push_back(uint8_t(0));  // (rows of its own, 64 lanes wide: jxl_hip_entropy_lanes.h)
         wave_lanes.push_back(uint8_t(cnt));
       }
     }
@@ -1626,19 +1665,20 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     // 64 KB), the tables stay in global memory instead: a cached global round trip on every token's serial chain, but
     // every frame resident (JXLHIP_GALIAS = 0 / 1 forces either form: measurement aid)
     size_t lds_by_form[2] = {0, 0};
+    const size_t num_wgs = map.size() / wpg;  // (`map` holds one unit per wave)
     for (int form = 0; form < 2; form++)
-      for (size_t wg = 0; wg < map.size(); wg++) {
-        const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg]) * 4] & 0xFFFF];
-        const uint32_t up = unit_desc[size_t(map[wg]) * 4 + 3];  // the unit's pass
+      for (size_t wg = 0; wg < num_wgs; wg++) {
+        const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg * wpg]) * 4] & 0xFFFF];
+        const uint32_t up = unit_desc[size_t(map[wg * wpg]) * 4 + 3];  // the unit's pass
         size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[up], c->pass_log_alpha[up], 0, 0, form == 0 && !c0->lane_prefix,
                                           c0->lane_prefix).wave0;
-        for (uint32_t w = 0; w < wpg; w++) l += size_t(jxlhip::kLanesPerLaneBytes) << wave_ls[wg * wpg + w];
+        l += size_t(jxlhip::kLanesPerLaneBytes) * 64 * (wg_shared[wg] ? 1 : wpg);
         lds_by_form[form] = l > lds_by_form[form] ? l : lds_by_form[form];
       }
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, c0->device);
-    const size_t resident = lds_by_form[0] ? size_t(dev_cus) * ((160 * 1024) / lds_by_form[0]) : map.size();
-    bool galias = lds_by_form[0] > kLdsBudget || resident < map.size();
+    const size_t resident = lds_by_form[0] ? size_t(dev_cus) * ((160 * 1024) / lds_by_form[0]) : num_wgs;
+    bool galias = lds_by_form[0] > kLdsBudget || resident < num_wgs;
     const int forced_form = EnvInt("JXLHIP_GALIAS", -1);
     if (forced_form == 0 && lds_by_form[0] <= kLdsBudget) galias = false;
     if (forced_form == 1) galias = true;
@@ -1648,7 +1688,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     lds = lds_by_form[galias ? 1 : 0];
     if (EnvInt("JXLHIP_PACK_DEBUG", 0))
       fprintf(stderr, "[pack] units %zu sections %zu lanes(min) %zu lanes/wave %u waves/wg %u workgroups %zu lds %zu\n", units.size(),
-              total_sections, min_total, lanes_per_wave, wpg, map.size(), lds);
+              total_sections, min_total, lanes_per_wave, wpg, map.size() / wpg, lds);
   } else {
     for (size_t i = 0; i < n; i++) {
       const uint32_t wgs = (ctxs[i]->ng + kEntropyWPG - 1) / kEntropyWPG;
@@ -1687,7 +1727,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
   c0->batch_ctxs.assign(ctxs, ctxs + n);
   c0->batch_gens.resize(n);
   for (size_t i = 0; i < n; i++) c0->batch_gens[i] = ctxs[i]->generation;
-  c0->batch_wgs = uint32_t(map.size());
+  c0->batch_wgs = uint32_t(kernel == 2 ? map.size() / c0->batch_wpg : map.size());
   c0->batch_lds = lds;
   c0->batch_kernel = kernel;
   return 0;

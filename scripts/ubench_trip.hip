@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t SymbolM(uint32_t cluster, uint32_t& state, u
   return take ? big : tok;
 }
 
-template <int CH, int WPG, int MODE>
+template <int CH, int WPG, int MODE, int UNROLL = 1>
 __global__ __launch_bounds__(64 * WPG) void k_trip(const uint32_t* tables, uint16_t* out, uint32_t iters, unsigned long long* cycles) {
   extern __shared__ __align__(16) uint8_t lds_raw[];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,6 +94,7 @@ __global__ __launch_bounds__(64 * WPG) void k_trip(const uint32_t* tables, uint1
     ring[c] = ring_base + c * 18 * 64 + lane;
   }
   const unsigned long long t0 = __builtin_readcyclecounter();
+#pragma unroll UNROLL
   for (uint32_t it = 0; it < iters; it++) {
 #pragma unroll
     for (int c = 0; c < CH; c++) {
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(64 * WPG) void k_trip(const uint32_t* tables, uint1
   if (state[0] == 0x12345u) out[0] = uint16_t(bitpos[CH - 1]);
 }
 
-template <int CH, int WPG, int MODE = 0>
+template <int CH, int WPG, int MODE = 0, int UNROLL = 1>
 static void Run(int wgs_per_cu, uint32_t iters, const uint32_t* d_tables, uint16_t* d_out, unsigned long long* d_cyc) {
   const size_t lds_min = kTables + size_t(WPG) * CH * 18 * 64 * 4;
   size_t lds = (160 * 1024 / wgs_per_cu) & ~size_t(255);  // a CU takes floor(160 KiB / lds) workgroups
@@ -134,7 +135,7 @@ static void Run(int wgs_per_cu, uint32_t iters, const uint32_t* d_tables, uint16
     printf("CH=%d WPG=%d wgs/CU=%d: needs %zu B of LDS per workgroup, only %zu available: skipped\n", CH, WPG, wgs_per_cu, lds_min, lds);
     return;
   }
-  auto kern = k_trip<CH, WPG, MODE>;
+  auto kern = k_trip<CH, WPG, MODE, UNROLL>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
   const int grid = 256 * wgs_per_cu, waves = grid * WPG;
   hipEvent_t e0, e1;
@@ -154,7 +155,7 @@ static void Run(int wgs_per_cu, uint32_t iters, const uint32_t* d_tables, uint16
   for (auto v : cyc) mean += double(v);
   mean /= waves;
   const double tokens = double(waves) * 64 * CH * iters;
-  printf("MODE=%d CH=%d WPG=%d wgs/CU=%d (%.2f waves/SIMD) lds/wg=%zu: %.3f ms, %.0f cycles/iteration/wave (%.0f per token-trip), %.1f Gtokens/s, err=%s\n", MODE, CH, WPG,
+  printf("UNROLL=%d MODE=%d CH=%d WPG=%d wgs/CU=%d (%.2f waves/SIMD) lds/wg=%zu: %.3f ms, %.0f cycles/iteration/wave (%.0f per token-trip), %.1f Gtokens/s, err=%s\n", UNROLL, MODE, CH, WPG,
          wgs_per_cu, wgs_per_cu * WPG / 4.0, lds, ms, mean / iters, mean / iters / CH, tokens / ms * 1e-6, hipGetErrorString(hipGetLastError()));
 }
 
@@ -179,7 +180,14 @@ int main(int argc, char** argv) {
   hipMalloc(reinterpret_cast<void**>(&d_out), size_t(4096) * 64 * 4096 * 4 * 2 + 4096);
   hipMalloc(reinterpret_cast<void**>(&d_cyc), 65536 * 8);
   const int which = argc > 2 ? atoi(argv[2]) : 0;
-  if (which == 0) {
+  if (which == 2) {  // code footprint: the same trip unrolled 1 / 4 / 16 / 64 times (no stores)
+    Run<1, 1, 1, 1>(4, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 1, 4>(4, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 1, 16>(4, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 1, 64>(4, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 1, 64>(2, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 1, 64>(1, iters, d_tables, d_out, d_cyc);
+  } else if (which == 0) {
     // one wave per workgroup (a frame's tables per wave, as shipped): 4 per CU = one wave per SIMD
     Run<1, 1>(4, iters, d_tables, d_out, d_cyc);
     Run<2, 1>(4, iters, d_tables, d_out, d_cyc);

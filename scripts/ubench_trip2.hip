@@ -1,0 +1,154 @@
+// Measurement aid (not product code): the round-3 hot trip of k_entropy_lanes (select-based, one basic block) on random
+// tables, every lane active. VAR bit 0: real `act` mask from a lane pattern (half the lanes idle); bit 1: no extra-bits
+// code; bit 2: no next-context speculation reads; bit 3: commit without selects (act assumed).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude scripts/ubench_trip2.hip -o /tmp/ubench_trip2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../libjxl_amd/csrc/hip/jxl_hip_kernels.h"
+#include "../libjxl_amd/csrc/hip/jxl_hip_entropy_lanes.h"
+using namespace jxlhip;
+constexpr uint32_t kAliasBytes = 64 * 32 * 8, kCtxBytes = 7424 + 16, kTables = kAliasBytes + kCtxBytes + 128 + 512;
+
+template <int VAR>
+__global__ __launch_bounds__(64) void k_trip2(const uint32_t* tables, uint32_t* out, uint32_t iters, unsigned long long* cycles, uint32_t log_alpha_, uint32_t shift_) {
+  extern __shared__ __align__(16) uint8_t lds_raw[];
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t i = threadIdx.x; i < kTables / 4; i += 64) reinterpret_cast<uint32_t*>(lds_raw)[i] = tables[i];
+  uint32_t* ring_base = reinterpret_cast<uint32_t*>(lds_raw + kTables);
+  for (uint32_t i = lane; i < 18 * 64; i += 64) ring_base[i] = tables[(i * 7 + blockIdx.x) % (kTables / 4)] * 2654435761u;
+  __syncthreads();
+  LdsU8* const lds = (LdsU8*)lds_raw;
+  LdsU8* const l_ctx = lds + kAliasBytes;
+  LdsU16* const l_nnz2 = (LdsU16*)(lds + kAliasBytes + kCtxBytes);
+  LdsU32* const ring = (LdsU32*)(lds + kTables) + lane;
+  const uint32_t log_alpha = log_alpha_, log_entry = 12 - log_alpha, entry_mask = (1u << log_entry) - 1, cl_shift = 3 + log_alpha, shift = shift_;
+  uint32_t state = 0x130000u + lane * 977, bitpos = lane & 31, ctxe = lane & 63, addr_a = 37 * 15 + 62, nnz_b = 62, nzeros = 20 + (lane & 7), k = 1;
+  uint32_t acc_lo = 0, acc_hi = 0, dst = lane * 4096, cbase = 37 * 15, log2c = 0, covm1 = 0, size = 64, mode = 1;
+  const void* coef_base = out;
+  bool act = (VAR & 1) ? (lane % 3 != 0) : true;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (uint32_t it = 0; it < iters; it++) {
+    const uint32_t slotw = (bitpos >> 5) & 15;
+    LdsU32* const rp = ring + slotw * 64;
+    const uint32_t w0 = rp[0], w1 = rp[64], w2 = rp[128];
+    const uint32_t kn = k + 1;
+    const uint32_t b = kn >> log2c;
+    const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
+    const uint32_t addr_b = cbase + 1 + nnz_b;
+    uint32_t e_zero = 3, e_nonzero = 5, nnz_c = 62;
+    if (!(VAR & 4)) {
+      e_zero = l_ctx[(addr_a + f2) & 0x1FFF];
+      e_nonzero = l_ctx[(addr_b + f2) & 0x1FFF];
+      nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
+    }
+    uint32_t tok, cfg, adv, nstate;
+    {
+      const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & entry_mask;
+      LanesU32x2 e = *(LdsU32x2*)(lds + (((ctxe & 63) << cl_shift) + slot * 8));
+      const bool gt = pos >= (e.x >> 24);
+      const uint32_t x = gt ? e.y : e.x;
+      tok = gt ? (e.y >> 24) : slot;
+      const uint32_t hi = state >> 12;
+      nstate = (x & 0xFFFu) * hi + hi + (gt ? ((e.y >> 12) & 0xFFFu) : 0u) + pos;
+      const bool need = nstate < (1u << 16);
+      const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
+      nstate = need ? ((nstate << 16) | (win & 0xFFFFu)) : nstate;
+      adv = need ? 16u : 0u;
+      cfg = 4 | (2 << 4);
+    }
+    if (!(VAR & 2)) {
+      const bool take = act && tok >= (1u << (cfg & 15));
+      if (__ballot(take)) {
+        uint32_t nbits;
+        const uint32_t big = LaneHybrid(tok, cfg, w0, w1, w2, (bitpos & 31) + adv, nbits);
+        tok = take ? big : tok;
+        adv += take ? nbits : 0u;
+      }
+    }
+    const uint32_t sgn = uint32_t(-int32_t(tok & 1));
+    const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
+    const uint32_t n_lo = __builtin_amdgcn_alignbit(acc_hi, acc_lo, 16);
+    const uint32_t n_hi = (acc_hi >> 16) | (uint32_t(coeff) << 16);
+    const bool nz = tok != 0;
+    const uint32_t n_nzeros = nzeros - (nz ? 1u : 0u);
+    const bool full = act && (kn & 3) == 0 && coeff == 0x7FFFFFF;  // (never true: no stores in this probe)
+    if (full) LaneStore64(coef_base, dst, n_lo, n_hi);
+    const bool done = n_nzeros == 0 || kn >= size;
+    if (VAR & 8) {
+      state = nstate | 0x10000u; bitpos += adv; acc_lo = n_lo; acc_hi = n_hi; dst += full ? 8u : 0u; k = kn & 63; nzeros = n_nzeros < 3 ? 40u : n_nzeros;
+      ctxe = nz ? e_nonzero : e_zero; addr_a = nz ? addr_b - 1 : addr_a; nnz_b = nz ? nnz_c : nnz_b; mode = done ? 1u : mode;
+    } else {
+      state = act ? (nstate | 0x10000u) : state;
+      bitpos += act ? adv : 0u;
+      acc_lo = act ? n_lo : acc_lo;
+      acc_hi = act ? n_hi : acc_hi;
+      dst += full ? 8u : 0u;
+      k = act ? (kn & 63) : k;
+      nzeros = act ? (n_nzeros < 3 ? 40u : n_nzeros) : nzeros;
+      ctxe = act ? (nz ? e_nonzero : e_zero) : ctxe;
+      addr_a = (act && nz) ? addr_b - 1 : addr_a;
+      nnz_b = (act && nz) ? nnz_c : nnz_b;
+      mode = (act && done) ? 1u : mode;
+      act = act && (mode != 7);
+    }
+    addr_a = addr_a > 400 ? 37 * 15 + 62 : addr_a;
+    state &= 0x7FFFFFFFu;
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (lane == 0) cycles[blockIdx.x] = t1 - t0;
+  if (state == 0x12345u) out[0] = bitpos + acc_lo + acc_hi + dst + mode + k;
+}
+
+template <int VAR>
+static void Run(int wgs_per_cu, uint32_t iters, const uint32_t* d_tables, uint32_t* d_out, unsigned long long* d_cyc) {
+  size_t lds = (160 * 1024 / wgs_per_cu) & ~size_t(255);
+  auto kern = k_trip2<VAR>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+  const int grid = 256 * wgs_per_cu;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, 0, d_tables, d_out, 64u, d_cyc, 5u, 0u);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, 0, d_tables, d_out, iters, d_cyc, 5u, 0u);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> cyc(grid);
+  hipMemcpy(cyc.data(), d_cyc, grid * 8, hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (auto v : cyc) mean += double(v);
+  mean /= grid;
+  printf("VAR=%d wgs/CU=%d: %.3f ms, %.0f ticks/trip, %.1f ns/trip, err=%s\n", VAR, wgs_per_cu, ms, mean / iters, ms * 1e6 / iters, hipGetErrorString(hipGetLastError()));
+}
+
+int main(int argc, char** argv) {
+  const uint32_t iters = argc > 1 ? uint32_t(atoi(argv[1])) : 20000;
+  std::vector<uint32_t> t(kTables / 4);
+  uint32_t s = 12345;
+  for (auto& v : t) {
+    s = s * 1664525u + 1013904223u;
+    v = s;
+  }
+  uint8_t* bytes = reinterpret_cast<uint8_t*>(t.data());
+  for (uint32_t i = 0; i < kCtxBytes; i++) bytes[kAliasBytes + i] &= 63;
+  for (uint32_t i = 0; i < 64; i++) reinterpret_cast<uint16_t*>(bytes + kAliasBytes + kCtxBytes)[i] = uint16_t((i * 31 / 10) & ~1u);
+  uint32_t *d_tables, *d_out;
+  unsigned long long* d_cyc;
+  hipMalloc(reinterpret_cast<void**>(&d_tables), kTables);
+  hipMemcpy(d_tables, t.data(), kTables, hipMemcpyHostToDevice);
+  hipMalloc(reinterpret_cast<void**>(&d_out), 1 << 26);
+  hipMalloc(reinterpret_cast<void**>(&d_cyc), 65536 * 8);
+  Run<0>(4, iters, d_tables, d_out, d_cyc);
+  Run<0>(1, iters, d_tables, d_out, d_cyc);
+  Run<1>(4, iters, d_tables, d_out, d_cyc);
+  Run<2>(4, iters, d_tables, d_out, d_cyc);
+  Run<4>(4, iters, d_tables, d_out, d_cyc);
+  Run<8>(4, iters, d_tables, d_out, d_cyc);
+  Run<14>(4, iters, d_tables, d_out, d_cyc);
+  return 0;
+}
