@@ -227,6 +227,61 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
                     "stage_busy_ms_per_frame = wall time of each pipeline thread (gpu_stages: summed over its two threads)" % chunk}
 
 
+def single_image_api(J, data, xsize, ysize, reps=10):
+    """One image through the drop-in boundary, the way djxl times it (tools/djxl_main.cc:415-422: wall clock around the whole
+    DecodeImageJXL call sequence, compressed bytes in memory -> RGB8 in the caller's buffer; tools/speed_stats.cc:23-69: with
+    three or more repetitions the geometric mean without the first)."""
+    import ctypes
+    import math
+    L = J.lib()
+    vp = ctypes.c_void_p
+    L.JxlDecoderCreate.restype = vp
+    L.JxlDecoderCreate.argtypes = [vp]
+    L.JxlThreadParallelRunnerCreate.restype = vp
+    L.JxlThreadParallelRunnerCreate.argtypes = [vp, ctypes.c_size_t]
+    L.JxlThreadParallelRunnerDestroy.argtypes = [vp]
+    for fn, args in (("JxlDecoderDestroy", [vp]), ("JxlDecoderSubscribeEvents", [vp, ctypes.c_int]),
+                     ("JxlDecoderSetInput", [vp, ctypes.c_char_p, ctypes.c_size_t]), ("JxlDecoderCloseInput", [vp]),
+                     ("JxlDecoderProcessInput", [vp]), ("JxlDecoderSetParallelRunner", [vp, vp, vp]),
+                     ("JxlDecoderSetImageOutBuffer", [vp, vp, vp, ctypes.c_size_t])):
+        getattr(L, fn).argtypes = args
+
+    class Fmt(ctypes.Structure):
+        _fields_ = [("num_channels", ctypes.c_uint32), ("data_type", ctypes.c_int), ("endianness", ctypes.c_int), ("align", ctypes.c_size_t)]
+    fmt = Fmt(3, 2, 0, 0)  # RGB, JXL_TYPE_UINT8, native endian
+    out = ctypes.create_string_buffer(xsize * ysize * 3)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 32))
+    pool = L.JxlThreadParallelRunnerCreate(None, threads)
+    runner = ctypes.cast(L.JxlThreadParallelRunner, vp)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dec = L.JxlDecoderCreate(None)
+        L.JxlDecoderSetParallelRunner(dec, runner, pool)
+        L.JxlDecoderSubscribeEvents(dec, 0x1000)  # JXL_DEC_FULL_IMAGE
+        L.JxlDecoderSetInput(dec, data, len(data))
+        L.JxlDecoderCloseInput(dec)
+        status = L.JxlDecoderProcessInput(dec)
+        if status == 5:  # JXL_DEC_NEED_IMAGE_OUT_BUFFER
+            L.JxlDecoderSetImageOutBuffer(dec, ctypes.byref(fmt), out, len(out))
+            status = L.JxlDecoderProcessInput(dec)
+        L.JxlDecoderDestroy(dec)
+        times.append(time.perf_counter() - t0)
+        if status != 0x1000:
+            L.JxlThreadParallelRunnerDestroy(pool)
+            return {"error": "JxlDecoderProcessInput returned %d" % status}
+    L.JxlThreadParallelRunnerDestroy(pool)
+    tail = times[1:] if len(times) >= 3 else times[-1:]
+    gm = math.exp(sum(math.log(t) for t in tail) / len(tail))
+    return {"value": round(xsize * ysize * 1e-6 / gm, 1), "unit": "MP/s", "seconds": round(gm, 5), "reps": reps, "runner_threads": threads,
+            "span": "JxlDecoderCreate .. JXL_DEC_FULL_IMAGE of ONE %dx%d frame through the JxlDecoder C API with JxlThreadParallelRunner "
+                    "(tools/djxl_main.cc:415-422), geometric mean without the first repetition (tools/speed_stats.cc:23-69)" % (xsize, ysize)}
+
+
 def system_libjxl_baseline(data, xsize, ysize, threads):
     """If the box has a libjxl of its own (probe, never assume), times it on the same stream through the
     same JxlDecoder C API with its thread pool and returns a cpu_baseline dict (kind "reference"), else None."""
@@ -661,13 +716,17 @@ def main():
         frames_per_launch = args.batch if dom == 0 else 1
         # HBM traffic of the dominant kernel: PMC counters from separate rocprofv3 passes of this command (committed
         # summary; 2 x FETCH_SIZE + WRITE_SIZE per dispatch), only quoted when taken at the same frames per launch
-        traffic = None
+        traffic, traffic_source = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pmc_name = "r03_pmc_traffic.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             key = ["k_entropy_lanes", "k_idct_fast<short, 4, 4>", "k_filter_rows2"][dom]
             for name, v in pmc.items():
                 if key in name and pmc.get("_frames_per_launch") == args.batch:
                     traffic = int(v["hbm_kib_per_dispatch"] * 1024)  # FETCH_SIZE doubled (gfx950: the guide's correction) + WRITE_SIZE
+                    # (PMC counters cannot be collected inside this run: the figure is the committed profile's, named with the
+                    # commit it was taken at, for a launch of the same frames per launch)
+                    traffic_source = "profiles/%s (separate rocprofv3 --pmc passes of this command at commit %s)" % (pmc_name, pmc.get("_commit", "unknown"))
         except (OSError, ValueError, KeyError, TypeError):
             pass
         out = {
@@ -684,14 +743,20 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%dx%d RGB8 VarDCT d%.1f decode (gab+EPF1, 1 pass), %d frames/step/GPU, inputs resident in HBM" % (
-                xsize, ysize, args.distance, args.batch), "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
+                xsize, ysize, args.distance, args.batch),
+                "timed_region": "the GPU stages of the frame decode: AC entropy decode of every 256x256 group, dequantisation + chroma "
+                                "from luma + inverse transforms, Gaborish + EPF + XYB->sRGB + RGB8 store; the compressed sections and "
+                                "the per-frame tables (headers, TOC, DC image, quant field, histograms: host front-end) are resident in "
+                                "HBM before it starts, the pixels stay in HBM. The rate from compressed bytes in host memory to pixels "
+                                "in host memory (host parse, PCIe both ways: the reference's own metric) is `e2e`, never `value`",
+                "bpp": round(bpp, 3), "groups_per_frame": info["num_groups"],
                 "frames_per_step_per_gpu": args.batch, "distinct_frames": ndistinct, "entropy_tables": tables, "pipeline": ("%d frame sets, each on its own stream (entropy -> transform -> filter+colour every step), free-running" % nsets) if free_running else ("2 frame sets, 3 concurrent launches: entropy(A) | transform(B) | filter+colour(A, previous step)" if three else
                              "2 frame sets: entropy(set A) overlaps transform+filter(set B)") if nsets == 2 else
                 ("1 frame set: entropy and transform back to back, filter+colour of step k on a second stream under the entropy launch of step k+1" if chain else "none"),
                 "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes and not three and not free_running else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
                 ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "frames_per_launch": frames_per_launch, "launch_ms": round(stage_ms[dom] * frames_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(alg[names[dom]] * frames_per_launch),
                          "note": "entropy decode is serial per 256x256 group (latency-bound, not HBM-bound); amortised over the frames of one launch" if dom == 0 else ""},
@@ -706,6 +771,7 @@ def main():
         # (the end-to-end and the CPU legs: one-GPU runs only, so that the ranks of a scaling run end together)
         if args.e2e_frames > 0 and args.shard == "frames" and world == 1:
             out["e2e"] = end_to_end(J, datas, args.e2e_frames, local_rank, xsize, ysize)
+            out["e2e"]["single_image"] = single_image_api(J, data, xsize, ysize)
         if not args.no_cpu_baseline and world == 1:
             ref = system_libjxl_baseline(data, xsize, ysize, os.cpu_count() or 1)
             out["cpu_baseline"] = ref if ref else cpu_baseline(data, xsize, ysize)

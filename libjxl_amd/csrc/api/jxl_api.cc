@@ -1403,7 +1403,26 @@ void JxlDecoderRewind(JxlDecoder* d) {
   d->decompress_boxes = db;
 }
 void JxlDecoderSkipFrames(JxlDecoder* d, size_t amount) { d->skip_frames += amount; }
-JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* d) { return d->stage >= 3 && d->stage < 5 ? (d->stage = 6, JXL_DEC_SUCCESS) : JXL_DEC_ERROR; }
+// decode.cc:904-915: only the current frame is dropped (its bytes are stepped over and the decoder is back before the
+// next frame header); a frame that later ones may be blended with still reaches the canvas / its reference slot, like the
+// frames StepCodestream skips without events.
+JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* d) {
+  if (!(d->stage >= 3 && d->stage < 5)) return JXL_DEC_ERROR;
+  JxlAmdFramePlacement pl;
+  Placement(d, &pl);
+  if (d->canvas_mode && CanBeReferenced(pl) && (d->events & JXL_DEC_FULL_IMAGE)) {
+    if (DecodePixels(d, true) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
+  }
+  if (d->frame_shown) {  // (is_last_of_still: the output buffers belonged to this frame)
+    d->have_out = false;
+    d->out_buf = nullptr;
+    d->callback = nullptr;
+    d->mt_run = nullptr;
+    d->extra_out.clear();
+  }
+  NextFrame(d);  // stage 2 (the next frame's header) or 6 (this was the last frame)
+  return JXL_DEC_SUCCESS;
+}
 
 JxlDecoderStatus JxlDecoderSetParallelRunner(JxlDecoder* d, JxlParallelRunner runner, void* opaque) {
   if (d->stage != 0) return JXL_DEC_ERROR;

@@ -1876,6 +1876,8 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
     pool += (size_t(d->buffers[i].w) * d->buffers[i].h + 3) & ~size_t(3);
   }
   if ((r = M.pool.Ensure((pool + 4) * 4))) return r;
+  // (a channel buffer that no stream covers must read as zeros, not as the previous frame's samples)
+  HIP_TRY(hipMemsetAsync(M.pool.p, 0, (pool + 4) * 4, c->stream));
   // ---- sections, 4-byte aligned, zero padded
   std::vector<size_t> sec_off(d->num_sections);
   size_t total = 0;
@@ -1902,7 +1904,10 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
     for (uint32_t k = 0; k < d->tree_size[i]; k++) {  // every index the walk can follow must exist
       const JxlHipModTreeNode& nd = d->trees[i][k];
       if (nd.property >= int32_t(jxlhip::kModMaxProps)) return JXLHIP_ERR_UNSUPPORTED;
-      if (nd.property >= 0 && (nd.lchild >= d->tree_size[i] || nd.rchild >= d->tree_size[i])) return JXLHIP_ERR_INVALID_ARGUMENT;
+      // children behind their parent (the breadth-first order dec_ma.cc:107-159 produces): a back edge would make the
+      // kernel's tree walk spin forever
+      if (nd.property >= 0 && (nd.lchild >= d->tree_size[i] || nd.rchild >= d->tree_size[i] || nd.lchild <= k || nd.rchild <= k))
+        return JXLHIP_ERR_INVALID_ARGUMENT;
       if (nd.property < 0 && (nd.predictor > 13 || nd.lchild >= d->codes[i].ctx_map_size || !d->codes[i].ctx_map)) return JXLHIP_ERR_INVALID_ARGUMENT;
       jxlhip::ModTreeNode& o = packed_tree[k];
       if (nd.property >= 0) {
@@ -2918,6 +2923,7 @@ int jxlhip_canvas_save_xyb(JxlHipCanvas* v, JxlHipContext* c, uint32_t slot) {
   HIP_TRY(hipStreamSynchronize(c->stream));  // (later frames read the slot from other streams of other contexts)
   v->xyb_w[slot] = w;
   v->xyb_h[slot] = h;
+  v->slot_valid[slot] = false;  // (the slot now holds a frame saved BEFORE the colour transform: not a blending source)
   v->last_stream = c->stream;
   return 0;
 }
@@ -2968,6 +2974,8 @@ int jxlhip_canvas_blend(JxlHipCanvas* v, JxlHipContext* c, const JxlHipBlend* b)
     if (r) return r;
     HIP_TRY(hipMemcpyAsync(v->slot[b->save_slot].p, v->cur.p, bytes, hipMemcpyDeviceToDevice, c->stream));
     v->slot_valid[b->save_slot] = true;
+    // the slot now holds a frame saved AFTER the colour transform: patches cannot take it (dec_patch_dictionary.cc:66-73)
+    v->xyb_w[b->save_slot] = v->xyb_h[b->save_slot] = 0;
   }
   v->last_stream = c->stream;
   return 0;

@@ -5,7 +5,7 @@
 # from where they are copied into profiles/.
 # usage: bash scripts/profile_round.sh OUTDIR TAG [bench args]
 OUT=${1:-gpurun_out/prof}
-TAG=${2:-r02}
+TAG=${2:-r03}
 shift 2 || true
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/$OUT
@@ -20,7 +20,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/iso -o s -- $BENCH 
 cp $(find $RAW/iso -name "*kernel_stats.csv" | head -1) $R/$OUT/${TAG}_kernel_stats_isolated.csv
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $RAW/f -o f -- $BENCH > /dev/null 2> $RAW/f.log
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $RAW/w -o w -- $BENCH > /dev/null 2> $RAW/w.log
-python3 $R/scripts/pmc_summary.py $(find $RAW/f -name "*counter_collection.csv" | head -1) $(find $RAW/w -name "*counter_collection.csv" | head -1) $R/$OUT/${TAG}_pmc_traffic.json 640
+# frames per launch: what the bench line of this very run says (not a literal: --batch may be among the arguments)
+FRAMES=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['config']['frames_per_step_per_gpu'])" $R/$OUT/${TAG}_bench.json)
+python3 $R/scripts/pmc_summary.py $(find $RAW/f -name "*counter_collection.csv" | head -1) $(find $RAW/w -name "*counter_collection.csv" | head -1) $R/$OUT/${TAG}_pmc_traffic.json $FRAMES
 tail -1 $R/$OUT/${TAG}_bench.json | cut -c1-300
 head -8 $R/$OUT/${TAG}_kernel_stats.csv | cut -c1-200
 rm -rf $RAW

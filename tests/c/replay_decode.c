@@ -60,6 +60,8 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[3], "f32")) format.data_type = JXL_TYPE_FLOAT;
   int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0, multi = 0, frames_done = 0, swap = 0;
   size_t skip = 0;
+  long skipcur = -1; /* skipcur=K: JxlDecoderSkipCurrentFrame at the FRAME event of the K-th frame that has one */
+  long frame_events = 0;
   uint8_t* ec_pixels[4] = {NULL, NULL, NULL, NULL};
   size_t ec_sizes[4] = {0, 0, 0, 0};
   size_t chunk = 0;
@@ -70,6 +72,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "swap")) swap = 1; /* hand the input back and in again after every frame (decode.h: JxlDecoderReleaseInput) */
     if (!strcmp(argv[i], "frames")) multi = 1; /* animation: every frame's pixels are appended to the output file */
     if (!strncmp(argv[i], "skip=", 5)) skip = (size_t)atol(argv[i] + 5); /* JxlDecoderSkipFrames before decoding */
+    if (!strncmp(argv[i], "skipcur=", 8)) skipcur = atol(argv[i] + 8);
     if (!strcmp(argv[i], "keep")) keep = 1; /* the pixels as coded, the orientation left to the caller */
     if (!strcmp(argv[i], "ec")) want_ec = 1; /* also fetch every extra channel into its own buffer (jxl.cc:571-590) */
     if (!strncmp(argv[i], "chunk=", 6)) chunk = (size_t)atol(argv[i] + 6);
@@ -182,6 +185,10 @@ int main(int argc, char** argv) {
       if (info.have_animation)
         printf("animation tps=%u/%u loops=%u duration=%u timecode=%u\n", info.animation.tps_numerator, info.animation.tps_denominator,
                info.animation.num_loops, fh.duration, fh.timecode);
+      if (frame_events++ == skipcur) {
+        if (JxlDecoderSkipCurrentFrame(dec) != JXL_DEC_SUCCESS) return 2;
+        printf("skipped current frame\n");
+      }
     } else if (st == JXL_DEC_NEED_IMAGE_OUT_BUFFER) {
       size_t buffer_size = 0;
       if (JxlDecoderImageOutBufferSize(dec, &format, &buffer_size) != JXL_DEC_SUCCESS) return 2;

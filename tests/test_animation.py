@@ -210,3 +210,43 @@ def test_frame_names_come_out_of_the_frame_header(built):
         assert L.JxlDecoderGetFrameName(dec, buf, n + 1) == 0 and buf.value.decode() == name
         assert L.JxlDecoderGetFrameName(dec, buf, n) == 1  # too small
         L.JxlDecoderDestroy(dec)
+
+
+@pytest.mark.gpu
+def test_skip_current_frame_only_drops_that_frame(built, tmp_path):
+    """JxlDecoderSkipCurrentFrame (decode.cc:904-915) steps over ONE frame: the frames behind it still come with their
+    FRAME / FULL_IMAGE events and pixels; a skipped frame that later frames are blended with still reaches its reference
+    slot, so the canvas the caller gets afterwards is the one it would have got without the skip."""
+    import jxlo
+    J = built
+    fr = _frames(J, 3, size=(300, 200))
+    data = J.encode_animation(fr, [4, 2, 9])
+    want = []
+    for k in range(3):
+        o = jxlo.Decoded(data, dumps=False, frame=k)
+        want.append(o.rgb8.copy())
+        o.close()
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3, "frames", "skipcur=0")
+    assert rc == 0 and "skipped current frame" in out, out
+    assert [e for e in events if e in ("FRAME", "NEED_IMAGE_OUT_BUFFER", "FULL_IMAGE")] == ["FRAME"] + ["FRAME", "NEED_IMAGE_OUT_BUFFER", "FULL_IMAGE"] * 2, out
+    got = np.frombuffer(px, np.uint8).reshape(2, 200, 300, 3)
+    for k in range(2):
+        assert np.abs(got[k].astype(int) - want[k + 1].astype(int)).max() <= 1, k
+    # skipping the LAST frame ends the decode cleanly
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3, "frames", "skipcur=2")
+    assert rc == 0 and events.count("FULL_IMAGE") == 2, out
+    # a delta animation: frame 1 is a patch blended over frame 0 (kept in slot 1); skipping frame 0 must not lose it
+    base = J.synth_image(200, 150, seed=1)
+    opaque = np.full((150, 200), 255, np.uint8)
+    patch = J.synth_image(80, 60, seed=2)
+    ramp = ((np.mgrid[0:60, 0:80][1] * 255) // 79).astype(np.uint8)
+    layered = J.encode_layers([dict(img=np.dstack([base, opaque]), save_as=1, duration=2),
+                               dict(img=np.dstack([patch, ramp]), x0=50, y0=40, mode=2, alpha_mode=2, source=1, duration=3)],
+                              tps=(10, 1), lossless=True)
+    o = jxlo.Decoded(layered, dumps=False, frame=1)
+    ref = o.rgb8.copy()
+    o.close()
+    rc, events, out, px = R.run(layered, tmp_path, "u8", 4, "frames", "skipcur=0")
+    assert rc == 0 and events.count("FULL_IMAGE") == 1, out
+    got = np.frombuffer(px, np.uint8).reshape(150, 200, 4)
+    assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1
