@@ -21,7 +21,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")  # one HIP stream per frame in flight: the default of 4 hardware queues serialises them
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # the few streams in use (two frame sets x two, the copy stream, the shared pool) each on a hardware queue of their own
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -272,6 +272,7 @@ struct JxlHipContext {
   // the launch's end event; waited for by whatever touches the planes or the pixels next (transform, download, sync,
   // upload), never by an entropy launch.
   bool filter_async = false;
+  bool owns_stream = false;   // `stream` is this context's own (it heads batched launches), not one of the shared pool
   hipStream_t stream2 = nullptr;
   hipStream_t fstream = nullptr;  // stream of the filter launch in progress (set by BeginDownstreamBatch)
   hipEvent_t fork_event = nullptr, filter_done = nullptr, filter_wait = nullptr;
@@ -355,6 +356,35 @@ int jxlhip_device_count(void) {
   return n;
 }
 
+// Streams. A context does NOT get a HIP stream of its own: with more than ~16 streams alive in a process (used or not) the
+// runtime time-slices its hardware queues, and a long kernel is then preempted and resumed several times over (rocprofv3
+// counts each resumption as a wave: SQ_WAVES 251 for a 32-wave launch); scripts/r03_streams_probe2.py: the same 8-frame
+// entropy launch takes 79 ms with up to 16 streams in the process, 114 ms with 32, 125 ms with 64. Contexts share a small
+// pool per device (JXLHIP_STREAMS, default 4); a context that heads batched launches over several contexts gets a
+// dedicated stream the first time it does (EnsureOwnStream), so that the batched stages of different frame sets overlap.
+static hipStream_t PoolStream(int device) {
+  static std::mutex mu;
+  static std::vector<hipStream_t> pool[64];
+  static size_t next[64] = {};
+  std::lock_guard<std::mutex> lock(mu);
+  if (device < 0 || device >= 64) return nullptr;
+  if (pool[device].empty()) {
+    int n = 4;
+    if (const char* e = getenv("JXLHIP_STREAMS")) n = atoi(e);
+    n = n < 1 ? 1 : (n > 16 ? 16 : n);
+    for (int i = 0; i < n; i++) {
+      hipStream_t st = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) break;
+      pool[device].push_back(st);
+    }
+    if (pool[device].empty()) return nullptr;
+  }
+  return pool[device][next[device]++ % pool[device].size()];
+}
+
+// The head context of a batched launch runs the batch on a stream of its own (created on first use).
+static int EnsureOwnStream(JxlHipContext* c);
+
 int jxlhip_ctx_create(int device, JxlHipContext** out) {
   if (!out) return JXLHIP_ERR_INVALID_ARGUMENT;
   *out = nullptr;
@@ -362,10 +392,11 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
   JxlHipContext* c = new (std::nothrow) JxlHipContext;
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   c->device = device;
-  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
+  hipError_t e = hipSuccess;
+  c->stream = PoolStream(device);
+  if (!c->stream) {
     delete c;
-    return -int(e);
+    return JXLHIP_ERR_INVALID_ARGUMENT;
   }
   for (auto& ev : c->ev) {
     e = hipEventCreate(&ev);
@@ -440,7 +471,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->filter_done) (void)hipEventDestroy(c->filter_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -1372,6 +1403,17 @@ static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup&
 }
 
 // Validates a set for a batched downstream call and orders the launch stream after everything its frames wait for.
+static int EnsureOwnStream(JxlHipContext* c) {
+  if (c->owns_stream) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (what the context queued on the shared stream so far)
+  hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  c->stream = st;
+  c->owns_stream = true;
+  return 0;
+}
+
 static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_stage = false) {
   if (!ctxs || !n) return JXLHIP_ERR_INVALID_ARGUMENT;
   JxlHipContext* c0 = ctxs[0];
@@ -1381,6 +1423,10 @@ static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filte
     if (ctxs[i]->device != c0->device || ctxs[i]->coef_bits != c0->coef_bits) return JXLHIP_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(hipSetDevice(c0->device));
+  if (n > 1) {
+    const int r = EnsureOwnStream(c0);
+    if (r) return r;
+  }
   hipStream_t ls = c0->stream;  // launch stream
   if (filter_stage && c0->filter_async) {
     if (!c0->stream2) {
@@ -1513,6 +1559,12 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
     for (int j = 0; j < 8; j++) line += std::string(j ? ", " : "") + "\"" + names[j] + "\": " + std::to_string((unsigned long long)(sum[j] / (used ? used : 1)));
     line += "}}";
     fprintf(stderr, "[lanes prof] %s\n", line.c_str());
+    if (b.debug & 16)  // (measurement aid: per wave: cycles, trips, HW_ID fields wave / simd / cu / sh / se, XCC)
+      for (size_t w = 0; w < nwaves && w < 64; w++) {
+        const unsigned long long hw = h[w * 8 + 6];
+        fprintf(stderr, "[lanes wave] %zu cycles %llu trips %llu trip_cycles %llu pass_cycles %llu passes %llu refill_cycles %llu simd %llu cu %llu sh %llu se %llu xcc %llu\n", w, h[w * 8], h[w * 8 + 3], h[w * 8 + 5], h[w * 8 + 7], h[w * 8 + 2], h[w * 8 + 1], (hw >> 4) & 3,
+                (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, (hw >> 32) & 15);
+      }
   }
   return 0;
 }
@@ -1758,6 +1810,10 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   }
   const int kernel = all_scan ? 2 : 1;
   HIP_TRY(hipSetDevice(c0->device));
+  if (n > 1) {
+    const int r = EnsureOwnStream(c0);
+    if (r) return r;
+  }
   // measurement aid: JXLHIP_BATCH_PROF=1 prints the host time of the phases of this call (microseconds)
   const bool prof = EnvInt("JXLHIP_BATCH_PROF", 0) != 0;
   std::chrono::steady_clock::time_point tp0 = std::chrono::steady_clock::now();
@@ -2298,6 +2354,10 @@ extern "C" int jxlhip_modular_run_batch(JxlHipContext* const* ctxs, size_t n) {
     if (size_t(ctxs[i]->oxs) * ctxs[i]->oys * OutPixelBytes(ctxs[i]) > ctxs[i]->rgb.cap) return JXLHIP_ERR_INVALID_ARGUMENT;
   }
   HIP_TRY(hipSetDevice(c0->device));
+  if (n > 1) {
+    const int r = EnsureOwnStream(c0);
+    if (r) return r;
+  }
   JxlHipContext::Modular& M0 = c0->mod;
   bool same = M0.batch_ctxs.size() == n;
   for (size_t i = 0; same && i < n; i++) same = M0.batch_ctxs[i] == ctxs[i] && M0.batch_gens[i] == ctxs[i]->generation;

@@ -634,6 +634,12 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
     o[5] = t_wait;
     o[6] = t_dma;
     o[7] = t_trans;
+    if (B.debug & 16) {  // (measurement aid: where the wave ran: HW_ID | XCC_ID << 32 instead of the lanes served)
+      uint32_t hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[6] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
   }
   if (B.prof) {  // lane-trips of the wave (how full its trips were)
     unsigned long long total = n_lane_trips;

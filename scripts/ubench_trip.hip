@@ -93,6 +93,10 @@ __global__ __launch_bounds__(64 * WPG) void k_trip(const uint32_t* tables, uint1
     dptr[c] = ((blockIdx.x * WPG + wave) * 64 + lane) * 4096 * CH + c * 4096;
     ring[c] = ring_base + c * 18 * 64 + lane;
   }
+  if (MODE & 16) {  // desynchronise the waves of a CU: a different delay per workgroup before the loop
+    const uint32_t spin = (blockIdx.x * 2654435761u >> 20) & 4095;
+    for (uint32_t i = 0; i < spin; i++) __builtin_amdgcn_s_sleep(1);
+  }
   const unsigned long long t0 = __builtin_readcyclecounter();
 #pragma unroll UNROLL
   for (uint32_t it = 0; it < iters; it++) {
@@ -187,6 +191,12 @@ int main(int argc, char** argv) {
     Run<1, 1, 1, 64>(4, iters, d_tables, d_out, d_cyc);
     Run<1, 1, 1, 64>(2, iters, d_tables, d_out, d_cyc);
     Run<1, 1, 1, 64>(1, iters, d_tables, d_out, d_cyc);
+    // the same with the waves of a CU at different places of the loop (MODE bit 4)
+    Run<1, 1, 17, 1>(4, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 17, 16>(4, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 17, 64>(4, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 17, 64>(3, iters, d_tables, d_out, d_cyc);
+    Run<1, 1, 17, 64>(1, iters, d_tables, d_out, d_cyc);
   } else if (which == 0) {
     // one wave per workgroup (a frame's tables per wave, as shipped): 4 per CU = one wave per SIMD
     Run<1, 1>(4, iters, d_tables, d_out, d_cyc);

@@ -102,11 +102,11 @@ __global__ __launch_bounds__(64) void k_trip2(const uint32_t* tables, uint32_t* 
 }
 
 template <int VAR>
-static void Run(int wgs_per_cu, uint32_t iters, const uint32_t* d_tables, uint32_t* d_out, unsigned long long* d_cyc) {
+static void Run(int wgs_per_cu, uint32_t iters, const uint32_t* d_tables, uint32_t* d_out, unsigned long long* d_cyc, int grid_override = 0) {
   size_t lds = (160 * 1024 / wgs_per_cu) & ~size_t(255);
   auto kern = k_trip2<VAR>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-  const int grid = 256 * wgs_per_cu;
+  const int grid = grid_override ? grid_override : 256 * wgs_per_cu;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
@@ -123,7 +123,7 @@ static void Run(int wgs_per_cu, uint32_t iters, const uint32_t* d_tables, uint32
   double mean = 0;
   for (auto v : cyc) mean += double(v);
   mean /= grid;
-  printf("VAR=%d wgs/CU=%d: %.3f ms, %.0f ticks/trip, %.1f ns/trip, err=%s\n", VAR, wgs_per_cu, ms, mean / iters, ms * 1e6 / iters, hipGetErrorString(hipGetLastError()));
+  printf("VAR=%d grid=%d wgs/CU=%d: %.3f ms, %.0f ticks/trip, %.1f ns/trip, err=%s\n", VAR, wgs_per_cu, ms, mean / iters, ms * 1e6 / iters, hipGetErrorString(hipGetLastError()));
 }
 
 int main(int argc, char** argv) {
@@ -143,6 +143,7 @@ int main(int argc, char** argv) {
   hipMemcpy(d_tables, t.data(), kTables, hipMemcpyHostToDevice);
   hipMalloc(reinterpret_cast<void**>(&d_out), 1 << 26);
   hipMalloc(reinterpret_cast<void**>(&d_cyc), 65536 * 8);
+  for (int g : {1, 8, 16, 32, 64, 128, 256, 512, 1024}) Run<0>(3, iters, d_tables, d_out, d_cyc, g);
   Run<0>(4, iters, d_tables, d_out, d_cyc);
   Run<0>(1, iters, d_tables, d_out, d_cyc);
   Run<1>(4, iters, d_tables, d_out, d_cyc);
