@@ -12,7 +12,16 @@
 //   fastmath the error bars of the reference's own fast_math_test.cc:46-111 on this front-end's FastLog2f / FastPow2f /
 //            FastPowf (they shape the dequantisation tables, quant_weights.cc) and the splines' FastCosf, over the ranges
 //            the reference samples (2^20 draws each).
-// usage: host_kats {alias|hybrid|lehmer|fastmath|fjxl ...|icc ...};  exit code 0 = pass, message on stderr otherwise.
+//   bits     bit_reader_test.cc:28-50,152-255: the byte-order known answers of TestOrder (bytes 1F FC, F8 3F, 3F F8, BD 8D
+//            and the fields they were written from), zero extension past the end, the consumed-bit counter.
+//   fields   fields_test.cc:57-209: every U32 / U64 value the reference tests, written here by an independent writer of
+//            the wire format (fields.cc:444-452, 494-521), must read back AND consume exactly the number of bits the
+//            reference's test states; the F16 values it lists decode exactly (fields.cc:550-575).
+//   quant    quant_weights_test.cc:185-271 (DCTUniform): with every table coded as DCT bands {1/4, 0} the table builder
+//            must produce 4.0 in every entry of every one of the 17 tables (the reference asserts the transforms agree
+//            with a uniformly quantised slow DCT to 1e-4 and that every matrix starts with 4: 1e-6).
+// usage: host_kats {alias|hybrid|lehmer|fastmath|bits|fields|quant|fjxl ...|icc ...};  exit code 0 = pass, message on stderr otherwise.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -366,6 +375,213 @@ static int FastMathKat() {
   return 0;
 }
 
+// LSB-first bit writer of the KATs' own (fields.cc / enc_bit_writer.cc wire format: bits fill a byte from its low end)
+struct KatBitWriter {
+  std::vector<uint8_t> buf;
+  size_t pos = 0;
+  void Write(unsigned nbits, uint64_t v) {
+    for (unsigned i = 0; i < nbits; i++, pos++) {
+      if ((pos & 7) == 0) buf.push_back(0);
+      buf.back() |= uint8_t(((v >> i) & 1) << (pos & 7));
+    }
+  }
+  void ZeroPad() { pos = (pos + 7) & ~size_t(7); }
+  size_t BitPos() const { return pos; }
+  std::vector<uint8_t>& bytes() { return buf; }
+};
+
+static int TestBits() {
+  {  // TestOrder: LSB-first within a byte, bytes in stream order, multi-byte fields little-endian
+    const uint8_t a[2] = {0x1F, 0xFC};
+    H::BitReader r(a, 2);
+    for (int i = 0; i < 5; i++) REQUIRE(r.Read(1) == 1, "order a");
+    for (int i = 0; i < 5; i++) REQUIRE(r.Read(1) == 0, "order a");
+    for (int i = 0; i < 6; i++) REQUIRE(r.Read(1) == 1, "order a");
+    const uint8_t b[2] = {0x3F, 0xF8};
+    H::BitReader rb(b, 2);
+    REQUIRE(rb.Read(16) == 0xF83F, "u16 is little-endian");
+    const uint8_t c[2] = {0xBD, 0x8D};
+    H::BitReader rc(c, 2);
+    REQUIRE(rc.Read(1) == 1 && rc.Read(3) == 6 && rc.Read(8) == 0xDB && rc.Read(4) == 8, "mixed sizes");
+    REQUIRE(rc.BitPos() == 16 && !rc.Overread(), "consumed");
+  }
+  for (size_t size = 4; size < 32; size++) {  // ExtendsWithZeroes
+    std::vector<uint8_t> data(size, 0xFF);
+    for (size_t n = 0; n < size; n++) {
+      H::BitReader r(data.data(), n);
+      for (size_t i = 0; i < n * 8; i++) REQUIRE(r.Read(1) == 1, "n=%zu i=%zu", n, i);
+      for (unsigned i = 0; i <= 56; i++) REQUIRE(r.Peek(i) == 0, "bits past the end are zero (n=%zu, %u bits)", n, i);
+      REQUIRE(!r.Overread(), "peeking does not consume");
+    }
+  }
+  {  // TotalCountersTest
+    const uint8_t buf[8] = {1, 2, 3, 4};
+    H::BitReader r(buf, 8);
+    REQUIRE(r.BitPos() == 0, "counter");
+    r.Read(1);
+    REQUIRE(r.BitPos() == 1, "counter");
+    r.Read(10);
+    REQUIRE(r.BitPos() == 11, "counter");
+    r.Read(4);
+    r.Read(1);
+    REQUIRE(r.BitPos() == 16, "counter");
+    REQUIRE(r.Read(16) == 0x0403 && r.BitPos() == 32, "counter");
+  }
+  for (size_t skip = 0; skip < 128; skip++) {  // TestSkip: skipping equals reading
+    for (size_t ones = 0; ones < 96; ones += 7) {
+      KatBitWriter w;
+      for (size_t i = 0; i < ones; i++) w.Write(1, 1);
+      for (size_t i = 0; i < skip; i++) w.Write(1, 0);
+      w.Write(3, 5);
+      w.ZeroPad();
+      H::BitReader r(w.bytes().data(), w.bytes().size());
+      for (size_t i = 0; i < ones; i++) REQUIRE(r.Read(1) == 1, "skip");
+      r.Skip(skip);
+      REQUIRE(r.Read(3) == 5 && r.BitPos() == ones + skip + 3, "skip=%zu", skip);
+    }
+  }
+  return 0;
+}
+
+// An independent writer of the U64 wire format (fields.cc:494-521), for the KAT only.
+static void KatWriteU64(KatBitWriter& w, uint64_t v) {
+  if (v == 0) {
+    w.Write(2, 0);
+  } else if (v <= 16) {
+    w.Write(2, 1);
+    w.Write(4, v - 1);
+  } else if (v <= 272) {
+    w.Write(2, 2);
+    w.Write(8, v - 17);
+  } else {
+    w.Write(2, 3);
+    w.Write(12, v & 4095);
+    v >>= 12;
+    int shift = 12;
+    while (v > 0 && shift < 60) {
+      w.Write(1, 1);
+      w.Write(8, v & 255);
+      v >>= 8;
+      shift += 8;
+    }
+    if (v > 0) {
+      w.Write(1, 1);
+      w.Write(4, v & 15);
+    } else {
+      w.Write(1, 0);
+    }
+  }
+}
+
+static int TestFields() {
+  {  // U32CoderTest: enc = Val(0), Bits(4), Val(0x7FFFFFFF), Bits(32); {value, bits, selector}
+    const struct {
+      uint32_t value, bits, sel;
+    } cases[] = {{0, 2, 0}, {1, 6, 1}, {15, 6, 1}, {0x7FFFFFFF, 2, 2}, {128, 34, 3}, {0x7FFFFFFEu, 34, 3}, {0x80000000u, 34, 3}, {0xFFFFFFFFu, 34, 3}};
+    for (const auto& t : cases) {
+      KatBitWriter w;
+      w.Write(2, t.sel);
+      if (t.sel == 1) w.Write(4, t.value);
+      if (t.sel == 3) w.Write(32, t.value);
+      REQUIRE(w.BitPos() == t.bits, "U32 %u: the writer used %zu bits, the reference's test says %u", t.value, w.BitPos(), t.bits);
+      w.ZeroPad();
+      H::BitReader r(w.bytes().data(), w.bytes().size());
+      const uint32_t got = H::ReadU32(r, H::Val(0), H::Bits(4), H::Val(0x7FFFFFFF), H::Bits(32));
+      REQUIRE(got == t.value && r.BitPos() == t.bits, "U32 %u: read %u in %zu bits (expected %u bits)", t.value, got, r.BitPos(), t.bits);
+    }
+  }
+  {  // U64CoderTest
+    const struct {
+      uint64_t value;
+      unsigned bits;
+    } cases[] = {{0, 2}, {1, 6}, {2, 6}, {8, 6}, {15, 6}, {16, 6}, {17, 10}, {18, 10}, {100, 10}, {271, 10}, {272, 10}, {273, 15}, {274, 15}, {1000, 15},
+                 {4094, 15}, {4095, 15}, {4096, 24}, {4097, 24}, {10000, 24}, {1048574, 24}, {1048575, 24}, {1048576, 33}, {1048577, 33},
+                 {10000000, 33}, {268435454, 33}, {268435455, 33}, {268435456ull, 42}, {268435457ull, 42}, {1000000000ull, 42},
+                 {68719476734ull, 42}, {68719476735ull, 42}, {68719476736ull, 51}, {68719476737ull, 51}, {1000000000000ull, 51},
+                 {17592186044414ull, 51}, {17592186044415ull, 51}, {17592186044416ull, 60}, {17592186044417ull, 60},
+                 {100000000000000ull, 60}, {4503599627370494ull, 60}, {4503599627370495ull, 60}, {4503599627370496ull, 69},
+                 {4503599627370497ull, 69}, {10000000000000000ull, 69}, {1152921504606846974ull, 69}, {1152921504606846975ull, 69},
+                 {1152921504606846976ull, 73}, {1152921504606846977ull, 73}, {10000000000000000000ull, 73},
+                 {18446744073709551614ull, 73}, {18446744073709551615ull, 73}};
+    for (const auto& t : cases) {
+      KatBitWriter w;
+      KatWriteU64(w, t.value);
+      REQUIRE(w.BitPos() == t.bits, "U64 %llu: the writer used %zu bits, the reference's test says %u", (unsigned long long)t.value, w.BitPos(), t.bits);
+      w.ZeroPad();
+      H::BitReader r(w.bytes().data(), w.bytes().size());
+      const uint64_t got = H::ReadU64(r);
+      REQUIRE(got == t.value && r.BitPos() == t.bits, "U64 %llu: read %llu in %zu bits", (unsigned long long)t.value, (unsigned long long)got, r.BitPos());
+    }
+  }
+  {  // F16CoderTest: IEEE binary16 bit patterns of the values the reference lists (all exactly representable)
+    const struct {
+      float value;
+      uint16_t bits;
+    } cases[] = {{0.0f, 0x0000}, {0.5f, 0x3800}, {1.0f, 0x3C00}, {2.0f, 0x4000}, {2.5f, 0x4100}, {16.015625f, 0x4C01},
+                 {1.0f / 4096, 0x0C00}, {1.0f / 16384, 0x0400}, {65504.0f, 0x7BFF}};
+    for (int sign = 0; sign < 2; sign++)
+      for (const auto& t : cases) {
+        KatBitWriter w;
+        w.Write(16, t.bits | (sign << 15));
+        H::BitReader r(w.bytes().data(), w.bytes().size());
+        const float got = H::ReadF16(r);
+        REQUIRE(got == (sign ? -t.value : t.value) && r.BitPos() == 16, "F16 %g: read %g", t.value, got);
+      }
+    // subnormals (fields.cc:565-569): 2^-24 * mantissa
+    KatBitWriter w;
+    w.Write(16, 0x0001);
+    w.Write(16, 0x83FF);
+    H::BitReader r(w.bytes().data(), w.bytes().size());
+    REQUIRE(H::ReadF16(r) == 1.0f / 16777216 && H::ReadF16(r) == -1023.0f / 16777216, "F16 subnormals");
+  }
+  return 0;
+}
+
+static int TestQuantUniform() {
+  H::DequantTables t;
+  for (int k = 0; k < 17; k++) {
+    H::QuantEncoding e;
+    e.mode = 6;  // QuantEncoding::DCT(dct_params) for EVERY table, like the reference's test
+    e.nb = 2;
+    for (int c = 0; c < 3; c++) {
+      e.bands[c][0] = 1.0f / 4;
+      e.bands[c][1] = 0.0f;
+    }
+    t.enc[k] = e;
+  }
+  for (int strategy = 0; strategy < 27; strategy++)
+    for (int c = 0; c < 3; c++) {
+      const float* m = t.Matrix(strategy, c);
+      const size_t n = t.table[H::kStrategyQuantTable[strategy]].size() / 3;
+      REQUIRE(n == size_t(64) * H::kQTReqX[H::kStrategyQuantTable[strategy]] * H::kQTReqY[H::kStrategyQuantTable[strategy]], "table size");
+      // the first entry exactly like the reference asserts it (1e-6); the others pass through FastPowf(1, t), whose own
+      // error bar is 3e-5 relative (fast_math_test.cc) and which the round-trip part of the reference's test holds to 1e-4
+      REQUIRE(std::fabs(m[0] - 4.0f) < 1e-6f, "strategy %d channel %d: first entry %.9g, expected 4", strategy, c, m[0]);
+      for (size_t i = 0; i < n; i++) REQUIRE(std::fabs(m[i] - 4.0f) < 4.0f * 3e-5f, "strategy %d channel %d entry %zu = %.9g, expected 4", strategy, c, i, m[i]);
+    }
+  // a second, non-trivial closed form of the band interpolation (quant_weights.cc:37-90 GetQuantWeights): bands {1, -1}
+  // halve from distance 0 to the far corner, weight(d) = 1 * (1/2)^(d / dmax) along the scaled distance, so the
+  // table (1 / weight) grows from 1 to 2 monotonically with the distance of (x, y) from the origin
+  for (int k : {0, 4, 5}) {
+    H::DequantTables u;
+    H::QuantEncoding e;
+    e.mode = 6;
+    e.nb = 2;
+    for (int c = 0; c < 3; c++) {
+      e.bands[c][0] = 1.0f;
+      e.bands[c][1] = -1.0f;
+    }
+    u.enc[k] = e;
+    u.Compute(k);
+    const size_t rows = 8 * H::kQTReqX[k], cols = 8 * H::kQTReqY[k];
+    const float* m = u.table[k].data();
+    REQUIRE(std::fabs(m[0] - 1.0f) < 1e-5f && std::fabs(m[rows * cols - 1] - 2.0f) < 2e-4f, "band ends: %g %g", m[0], m[rows * cols - 1]);
+    for (size_t y = 0; y < rows; y++)
+      for (size_t x = 0; x + 1 < cols; x++) REQUIRE(m[y * cols + x + 1] >= m[y * cols + x] - 1e-6f, "monotone along a row (%zu, %zu)", y, x);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string t = argv[1];
@@ -373,6 +589,9 @@ int main(int argc, char** argv) {
   if (t == "hybrid") return TestHybrid();
   if (t == "lehmer") return TestLehmer();
   if (t == "fastmath") return FastMathKat();
+  if (t == "bits") return TestBits();
+  if (t == "fields") return TestFields();
+  if (t == "quant") return TestQuantUniform();
 #ifndef KAT_ORACLE
   if (t == "icc" && argc == 4) return TestIcc(argv[2], argv[3]);
 #endif

@@ -657,3 +657,35 @@ def test_16k_frame_whole_and_in_8_bands(built):
     finally:
         c.close()
         f.close()
+
+
+@pytest.mark.parametrize("kw", [dict(gab=1, epf_iters=1), dict(gab=0, epf_iters=3), dict(gab=1, epf_iters=2), dict(gab=1, epf_iters=0),
+                                dict(gab=1, epf_iters=3, distance=3.0)])
+def test_filter_kernels_against_a_float64_third_reading(built, kw):
+    """The HIP filter kernels (k_filter_rows2 for Gaborish + EPF1, k_filter_fused for the other combinations) against
+    tests/filters_f64.py, the float64 NumPy restatement of stage_gaborish.cc / stage_epf.cc that neither the oracle nor the
+    kernels share code with: the kernels' own inverse-transform output and their own 1 / sigma go in, their filtered
+    planes must match to 2e-5 (the bar of the oracle comparison; observed ~1e-6)."""
+    import filters_f64 as F
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(331, 245, seed=11), **kw)
+    f = J.Frame(data, threads=2)
+    o = jxlo.Decoded(data)
+    i = o.info
+    sig = o.buffer("inv_sigma")
+    sig = (np.zeros(i["xsize_blocks"] * i["ysize_blocks"], np.float32) if sig is None else sig).reshape(i["ysize_blocks"], -1)[:, :i["xsize_blocks"]]
+    o.close()
+    c = J.HipContext()
+    try:
+        c.set_option("keep_filtered", 1)
+        c.upload(f)
+        c.run_all()
+        c.sync()
+        idct = c.download("xyb_idct")
+        got = c.download("xyb_filtered")[:, :i["ysize"], :i["xsize"]]
+    finally:
+        c.close()
+        f.close()
+    want = F.loop_filters(idct, sig, i["xsize"], i["ysize"], i["gab"], i["epf_iters"])
+    assert np.abs(got - want).max() < 2e-5

@@ -3,6 +3,9 @@
 so that neither is only ever compared with its twin:
   * alias-table invariants (lib/jxl/ans_common_test.cc:26-44), hybrid-uint worked examples and round trip
     (lib/jxl/dec_ans.h:47-67, entropy_coder_test.cc:20-59), Lehmer codes (lehmer_code_test.cc);
+  * the bit reader's byte-order known answers (bit_reader_test.cc:28-255), the U32 / U64 / F16 field coders with the bit
+    counts the reference's test states (fields_test.cc:57-209), and the dequantisation-table builder on the reference's
+    DCTUniform vector (quant_weights_test.cc:185-271: every entry of every table is 4);
   * the fjxl fixtures (output of the reference's enc_fast_lossless.cc): bit reader, field coders, headers, TOC, prefix
     codes, LZ77, hybrid uint, context maps, MA-tree Modular decode, RCT and Palette of each front-end must reproduce the
     encoder's input image exactly.
@@ -32,7 +35,7 @@ def _binary(which):
 
 
 @pytest.mark.parametrize("which", ["product", "oracle"])
-@pytest.mark.parametrize("kat", ["alias", "hybrid", "lehmer", "fastmath"])
+@pytest.mark.parametrize("kat", ["alias", "hybrid", "lehmer", "fastmath", "bits", "fields", "quant"])
 def test_reference_closed_form_kats(which, kat):
     r = subprocess.run([_binary(which), kat], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr

@@ -274,3 +274,25 @@ def test_colour_stage_closed_forms_oracle(built):
         L.jxlo_color_kat(xyb.ctypes.data, xyb.shape[1], 1 if linear else 0, out.ctypes.data)
         return out
     color_kat.check(convert)
+
+
+@pytest.mark.parametrize("kw", [dict(gab=1, epf_iters=1), dict(gab=0, epf_iters=3), dict(gab=1, epf_iters=2), dict(gab=1, epf_iters=0),
+                                dict(gab=1, epf_iters=3, distance=3.0)])
+def test_loop_filters_against_a_float64_third_reading(built, kw):
+    """tests/filters_f64.py restates Gaborish and the three EPF stages in float64 NumPy straight from stage_gaborish.cc /
+    stage_epf.cc / loop_filter.cc; the oracle's filtered planes must agree with it on decoded frames (ragged size, every
+    filter combination). No reference-decoded pixels exist here, so a reading that neither the oracle's nor
+    the kernels' author-shared code takes part in is what stands in for them."""
+    import filters_f64 as F
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(203, 117, seed=7), **kw)
+    o = jxlo.Decoded(data)
+    i = o.info
+    assert (i["gab"], i["epf_iters"]) == (kw["gab"], kw["epf_iters"])
+    sig = o.buffer("inv_sigma")
+    sig = (np.zeros(i["xsize_blocks"] * i["ysize_blocks"], np.float32) if sig is None else sig).reshape(i["ysize_blocks"], -1)[:, :i["xsize_blocks"]]
+    want = F.loop_filters(o.planes("xyb_idct"), sig, i["xsize"], i["ysize"], i["gab"], i["epf_iters"])
+    got = o.planes("xyb_filtered")[:, :i["ysize"], :i["xsize"]]
+    o.close()
+    assert np.abs(got - want).max() < 2e-6
