@@ -494,6 +494,10 @@ def main():
     ap.add_argument("--shard", choices=("frames", "bands"), default="frames",
                     help="multi-GPU split: whole frames per rank (weak scaling) or, for very large frames, one band of rows "
                          "of 256x256 groups of every frame per rank (strong scaling, no exchange between ranks)")
+    ap.add_argument("--halo", action="store_true",
+                    help="--shard bands: every rank decodes ONLY its own rows of groups and the few rows its filters read beyond "
+                         "them are exchanged with the neighbouring ranks after the transform stage (RCCL send / recv of dense "
+                         "device blocks; jxlhip_halo_*), instead of decoding one group row of overlap either side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one frame set: entropy, then transform+filter, in sequence")
     ap.add_argument("--two-set", action="store_true",
@@ -619,8 +623,34 @@ def main():
     nth = 0
     for cs in sets:
         for c in cs:
+            if band is not None and args.halo:
+                c.set_option("band_halo", 1)
             c.upload(frames[nth % ndistinct], band=band)
             nth += 1
+
+    def exchange_halos(cs):
+        # after the transform stage of a band set: this rank's boundary rows to its neighbours, theirs beside its band; one
+        # block per frame and side, all frames of the set in one tensor per message
+        if band is None or not args.halo or world == 1:
+            return
+        n = cs[0].halo_floats()
+
+        def pack(side):
+            t = torch.empty(len(cs) * n, dtype=torch.float32, device="cuda")
+            for i, c in enumerate(cs):
+                c.halo_pack(side, t.data_ptr() + i * n * 4, n * 4)
+            return t
+
+        def unpack(side, t):
+            for i, c in enumerate(cs):
+                c.halo_unpack(side, t.data_ptr() + i * n * 4, n * 4)
+
+        def recv(peer):
+            t = torch.empty(len(cs) * n, dtype=torch.float32, device="cuda")
+            dist.recv(t, peer)
+            return t
+
+        sharding.exchange_halos(rank, world, pack, unpack, lambda t, peer: dist.send(t, peer), recv)
     for cs in sets:  # prime: every set holds decoded coefficients before the first (warmup) step
         J.run_entropy_batch(cs)
     for cs in sets:
@@ -648,9 +678,11 @@ def main():
             J.run_filter_color_batch(ent)
             J.run_entropy_batch(ent)
             J.run_transform_batch(down)
+            exchange_halos(down)
             return ent
         J.run_entropy_batch(ent)  # one launch: the per-section decoders of all frames of the set share the GPU
         J.run_transform_batch(down)      # one launch per transform kernel for the whole set
+        exchange_halos(down)
         J.run_filter_color_batch(down)   # one fused filter + colour launch
         # No host synchronisation inside a step: all work of a set is ordered on that set's first stream (entropy ->
         # transform -> filter -> next entropy ...), the two sets' streams overlap on the device, and the host only
@@ -754,7 +786,8 @@ def main():
                              "2 frame sets: entropy(set A) overlaps transform+filter(set B)") if nsets == 2 else
                 ("1 frame set: entropy and transform back to back, filter+colour of step k on a second stream under the entropy launch of step k+1" if chain else "none"),
                 "xyb_planes": "shared by the two sets" if nsets == 2 and not args.no_share_planes and not three and not free_running else "per frame", "parallelism": ("frames sharded over %d GPU(s), no data-path collective" % world) if args.shard == "frames" else
-                ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world)},
+                (("every frame split into %d bands of group rows, one per GPU; the rows a band's filters read beyond it are exchanged after the transform stage (RCCL send / recv)" % world) if args.halo else
+                 ("every frame split into %d bands of group rows, one per GPU; each GPU also decodes the group row above and below its band, no exchange" % world))},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "frames_per_launch": frames_per_launch, "launch_ms": round(stage_ms[dom] * frames_per_launch, 4),

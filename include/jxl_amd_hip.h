@@ -248,6 +248,19 @@ int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_
  * spinning; for servers that pipeline frames over more host threads than they have CPUs to spare. */
 int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
 
+/* ---- Bands of one frame on several devices (multi-GPU split of very large frames; replaces nothing in the reference,
+ * whose LowMemoryRenderPipeline keeps the rows between groups in one address space: low_memory_render_pipeline.cc:475-517).
+ * jxlhip_set_option(ctx, "band_halo", 1) before the upload of a band: the context entropy-decodes and transforms ONLY the
+ * band's own rows of groups; the rows of the neighbouring bands that its filters read (jxlhip_halo_rows: Gaborish 1,
+ * EPF 2 / 3 / 6 more) are exchanged after the transform stage: the neighbour packs them (side 0 = its first rows,
+ * side 1 = its last rows) into a dense [3][rows][padded xsize] f32 block of DEVICE memory, any device-to-device transport
+ * (hipMemcpyPeerAsync, an RCCL send / recv) moves the block, and jxlhip_halo_unpack writes it beside the band (side 0 =
+ * above it, side 1 = below it). Both calls run behind the context's transform stage and are complete when they return;
+ * the filter stage follows them. */
+int jxlhip_halo_rows(JxlHipContext* ctx, uint32_t* rows);
+int jxlhip_halo_pack(JxlHipContext* ctx, int side, void* dst_device, size_t dst_bytes);
+int jxlhip_halo_unpack(JxlHipContext* ctx, int side, const void* src_device, size_t src_bytes);
+
 /* Test entry: runs the colour stage alone (XYB -> linear RGB -> sRGB transfer function unless linear_output) on n
  * XYB triples, planar [3][n], with the opsin parameters of the frame the context last uploaded; interleaved f32 RGB out.
  * For the reference's closed-form colour tests (lib/jxl/opsin_image_test.cc) against the kernel itself. */

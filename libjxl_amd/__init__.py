@@ -223,6 +223,31 @@ class HipContext:
         _check(lib().jxlamd_frame_upload_band(frame._h, self._h, b0, b1), "jxlamd_frame_upload_band")
         self.frame_info = dict(frame.info)
 
+    def halo_rows(self):
+        """Rows of the neighbouring bands the filters of this band read (after an upload)."""
+        L = lib()
+        L.jxlhip_halo_rows.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+        n = ctypes.c_uint32()
+        _check(L.jxlhip_halo_rows(self._h, ctypes.byref(n)), "jxlhip_halo_rows")
+        return int(n.value)
+
+    def halo_floats(self):
+        """Floats of one halo block ([3][rows][padded xsize])."""
+        xp = ((self.frame_info["xsize"] + 7) // 8) * 8
+        return 3 * self.halo_rows() * xp
+
+    def halo_pack(self, side, device_ptr, nbytes):
+        """side 0: this band's first rows (for the band above), 1: its last rows (for the band below) -> device memory."""
+        L = lib()
+        L.jxlhip_halo_pack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+        _check(L.jxlhip_halo_pack(self._h, side, device_ptr, nbytes), "jxlhip_halo_pack")
+
+    def halo_unpack(self, side, device_ptr, nbytes):
+        """side 0: the rows just above this band, 1: just below it <- device memory (what the neighbour packed)."""
+        L = lib()
+        L.jxlhip_halo_unpack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
+        _check(L.jxlhip_halo_unpack(self._h, side, device_ptr, nbytes), "jxlhip_halo_unpack")
+
     def set_output_format(self, data_type=2, num_channels=3, bits=0, big_endian=False):
         """JxlDataType numbering: 0 f32, 2 u8, 3 u16, 5 f16; call before upload."""
         _check(lib().jxlhip_set_output_format(self._h, data_type, num_channels, bits, 1 if big_endian else 0), "jxlhip_set_output_format")

@@ -222,6 +222,8 @@ struct JxlHipContext {
   bool lanes = false, lane_multi = false;
   uint32_t nblocks = 0;
   bool keep_filtered = false;  // jxlhip_set_option("keep_filtered"): also write the filtered XYB planes (tests)
+  bool band_halo = false;      // jxlhip_set_option("band_halo"): a band decodes ONLY its own group rows; the rows of the
+                               // neighbouring bands that its filters read arrive through jxlhip_halo_unpack
   // output pixel format (jxlhip_set_output_format; JxlDataType numbering): RGB8 by default
   uint32_t out_type = 2, out_nc = 3, out_bits = 8, out_swap = 0;
   // forward (encoder) path, jxlhip_enc_forward: device buffers and the kernel time of the last call
@@ -658,8 +660,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     uint32_t rb = d->band_group_row_begin, re = d->band_group_row_end;
     if (rb == 0 && re == 0) re = yg;
     if (rb >= re || re > yg) return JXLHIP_ERR_INVALID_ARGUMENT;
-    ext_row0 = rb ? rb - 1 : 0;
-    ext_row1 = re < yg ? re + 1 : yg;
+    ext_row0 = (rb && !c->band_halo) ? rb - 1 : rb;
+    ext_row1 = (re < yg && !c->band_halo) ? re + 1 : re;
     c->band_y0 = rb * 256;
     c->band_y1 = re * 256 < d->ysize ? re * 256 : d->ysize;
     c->group_list.clear();
@@ -2635,10 +2637,63 @@ int jxlhip_share_planes(JxlHipContext* c, JxlHipContext* lender) {
   return 0;
 }
 
+// ---- halo exchange between the bands of one frame: the filters of a band read up to `rows` rows of the
+// inverse-transform output above and below it; with "band_halo" those rows are not decoded a second time but copied from
+// the neighbouring band's planes (another context: another GPU's, through any device-to-device transport).
+int jxlhip_halo_rows(JxlHipContext* c, uint32_t* rows) {
+  if (!c || !rows) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  *rows = uint32_t(jxlhip::FusedHalo(c->gab != 0, int(c->epf_iters)));
+  return 0;
+}
+namespace {
+// rows [y0, y0 + rows) of the three planes <-> a dense [3][rows][xp] f32 block
+int HaloCopy(JxlHipContext* c, uint32_t y0, uint32_t rows, void* block, bool to_block) {
+  const size_t row_bytes = size_t(c->xp) * 4, plane = size_t(c->xp) * c->yp;
+  float* planes = PlaneHolder(c)->plane[0].as<float>();
+  int r = ApplyPendingWait(c);  // (behind the batched transform launch that produced the planes)
+  if (r) return r;
+  for (int ch = 0; ch < 3; ch++) {
+    float* in_plane = planes + ch * plane + size_t(y0) * c->xp;
+    float* in_block = static_cast<float*>(block) + size_t(ch) * rows * c->xp;
+    HIP_TRY(hipMemcpyAsync(to_block ? in_block : in_plane, to_block ? in_plane : in_block, row_bytes * rows, hipMemcpyDeviceToDevice, c->stream));
+  }
+  // the block is handed to a transport / the planes to a filter launch on another stream: complete before returning
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+}  // namespace
+// side 0: the first rows of this band (what the band ABOVE needs), side 1: its last rows (what the band BELOW needs);
+// `dst` = device memory of at least 3 * rows * xp floats. Runs behind the context's transform; complete on return.
+int jxlhip_halo_pack(JxlHipContext* c, int side, void* dst, size_t dst_bytes) {
+  uint32_t rows = 0;
+  int r = jxlhip_halo_rows(c, &rows);
+  if (r) return r;
+  if (!dst || (side != 0 && side != 1) || dst_bytes < size_t(3) * rows * c->xp * 4 || c->band_y1 - c->band_y0 < rows) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!rows) return 0;
+  return HaloCopy(c, side == 0 ? c->band_y0 : c->band_y1 - rows, rows, dst, true);
+}
+// side 0: the rows just above this band (the band above packed them with side 1), side 1: the rows just below it.
+int jxlhip_halo_unpack(JxlHipContext* c, int side, const void* src, size_t src_bytes) {
+  uint32_t rows = 0;
+  int r = jxlhip_halo_rows(c, &rows);
+  if (r) return r;
+  if (!src || (side != 0 && side != 1) || src_bytes < size_t(3) * rows * c->xp * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (side == 0 ? c->band_y0 < rows : c->band_y1 + rows > c->ys) return JXLHIP_ERR_INVALID_ARGUMENT;  // (no band on that side)
+  HIP_TRY(hipSetDevice(c->device));
+  if (!rows) return 0;
+  return HaloCopy(c, side == 0 ? c->band_y0 - rows : c->band_y1, rows, const_cast<void*>(src), false);
+}
+
 int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
   if (!c || !name) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (std::string(name) == "keep_filtered") {
     c->keep_filtered = value != 0;
+    return 0;
+  }
+  if (std::string(name) == "band_halo") {  // (takes effect at the next upload of a band)
+    c->band_halo = value != 0;
     return 0;
   }
   if (std::string(name) == "filter_async") {

@@ -689,3 +689,79 @@ def test_filter_kernels_against_a_float64_third_reading(built, kw):
         f.close()
     want = F.loop_filters(idct, sig, i["xsize"], i["ysize"], i["gab"], i["epf_iters"])
     assert np.abs(got - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(epf_iters=3), dict(gab=0, epf_iters=2)])
+def test_bands_with_halo_exchange_match_the_whole_frame(built, kw):
+    """The multi-GPU band split without redundant decoding (option "band_halo", jxlhip_halo_*): three bands of
+    a 700x1500 frame (6 rows of groups), each in a context of its own that entropy-decodes and transforms ONLY its own
+    rows of groups; after the transform stage the boundary rows (Gaborish 1 + EPF up to 6) move between the contexts as
+    dense device blocks through sharding.exchange_halos (here device-to-device inside one process; between GPUs the same
+    blocks go through RCCL send / recv), then each band is filtered. The stitched bands are bit-identical to the
+    whole-frame decode, for every filter depth."""
+    import ctypes
+    from libjxl_amd import sharding
+    J = built
+    hip = ctypes.CDLL("libamdhip64.so")
+    blocks = []
+
+    def device_block(nbytes):  # plain device memory for a halo block (what an RCCL send / recv would move between GPUs)
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(nbytes)) == 0
+        blocks.append(p)
+        return p
+
+    data = J.encode_rgb8(J.synth_image(700, 1500, seed=33), **kw)
+    f = J.Frame(data, threads=4)
+    c = J.HipContext()
+    c.upload(f)
+    c.run_all()
+    whole = c.rgb8()
+    c.close()
+    world = 3
+    bands = [sharding.band_of(6, r, world) for r in range(world)]
+    ctxs = []
+    for r in range(world):
+        b = J.HipContext()
+        b.set_option("band_halo", 1)
+        b.upload(f, band=bands[r])
+        b.run_entropy()
+        b.run_transform()
+        ctxs.append(b)
+    rows = ctxs[0].halo_rows()
+    assert rows == 1 * (kw.get("gab", 1) != 0) + {0: 0, 1: 2, 2: 3, 3: 6}[kw.get("epf_iters", 1)]
+    n = ctxs[0].halo_floats()
+    mailbox = {}
+
+    def run_rank(r):
+        # (one process plays every rank in turn: `send` leaves the block in a mailbox, `recv` of the peer picks it up; the
+        # two passes below stand for the two sides of each blocking send / recv pair)
+        def pack(side):
+            t = device_block(n * 4)
+            ctxs[r].halo_pack(side, t, n * 4)
+            return t
+
+        def unpack(side, block):
+            ctxs[r].halo_unpack(side, block, n * 4)
+
+        return pack, unpack
+
+    for r in range(world):  # every rank posts what its neighbours need ...
+        pack, _ = run_rank(r)
+        if r > 0:
+            mailbox[(r, r - 1)] = pack(0)
+        if r + 1 < world:
+            mailbox[(r, r + 1)] = pack(1)
+    for r in range(world):  # ... and takes what they posted, in the order exchange_halos prescribes
+        pack, unpack = run_rank(r)
+        sharding.exchange_halos(r, world, lambda side: None, unpack, lambda block, peer: None, lambda peer, r=r: mailbox[(peer, r)])
+    for r in range(world):
+        ctxs[r].run_filter_color()
+        ctxs[r].sync()
+        b0, b1 = bands[r]
+        got = ctxs[r].rgb8_rows(b0 * 256, min(b1 * 256, 1500))
+        assert np.array_equal(got, whole[b0 * 256:min(b1 * 256, 1500)]), "band %d differs from the whole-frame decode" % r
+        ctxs[r].close()
+    f.close()
+    for p in blocks:
+        hip.hipFree(p)

@@ -471,3 +471,56 @@ def test_enum_colour_encodings_of_lossless_images_are_reported(built):
     assert max(abs(a - b) for a, b in zip(got, xy)) < 1e-6
     ce = encoded_profile(white_point=11, primaries=11, transfer_function=17)  # DCI white, P3, DCI transfer function
     assert abs(ce.white_point_xy[0] - 0.314) < 1e-9 and tuple(ce.green) == (0.265, 0.690) and ce.transfer_function == 17
+
+
+_HALO_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from libjxl_amd import sharding
+world = %(world)d
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=world)
+rank = dist.get_rank()
+# a frame of `world` bands of 4 rows x 6 columns; row y holds the value y everywhere; each rank owns rows [4r, 4r + 4)
+# and has room for 2 halo rows either side
+H, W, HALO = 4, 6, 2
+plane = torch.full((H * world, W), -1.0)
+plane[H * rank:H * (rank + 1)] = torch.arange(H * rank, H * (rank + 1), dtype=torch.float32)[:, None]
+def pack(side):
+    y0 = H * rank if side == 0 else H * (rank + 1) - HALO
+    return plane[y0:y0 + HALO].clone()
+def unpack(side, block):
+    y0 = H * rank - HALO if side == 0 else H * (rank + 1)
+    plane[y0:y0 + HALO] = block
+def send(block, peer):
+    dist.send(block, peer)
+def recv(peer):
+    t = torch.empty((HALO, W))
+    dist.recv(t, peer)
+    return t
+sharding.exchange_halos(rank, world, pack, unpack, send, recv)
+lo, hi = max(0, H * rank - HALO), min(H * world, H * (rank + 1) + HALO)
+want = torch.arange(lo, hi, dtype=torch.float32)[:, None].expand(hi - lo, W)
+ok = bool(torch.equal(plane[lo:hi], want)) and bool((plane[:lo] == -1).all()) and bool((plane[hi:] == -1).all())
+print("HALO", rank, ok)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_schedule_gloo(built, tmp_path, world):
+    """sharding.exchange_halos over blocking point-to-point sends (gloo here, RCCL between GPUs): every rank ends up with
+    exactly its neighbours' boundary rows beside its band, nothing else moves, and the even / odd ordering does not
+    deadlock (2 and 3 ranks: an end rank, a middle rank)."""
+    pytest.importorskip("torch")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "h.py"
+    script.write_text(_HALO_WORKER % {"root": ROOT, "port": port, "world": world})
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for r in range(world):
+        assert "HALO %d True" % r in outs[r], outs[r]
