@@ -1267,9 +1267,11 @@ static int LaunchTransforms(JxlHipContext* c0) {
       case 9: e = LaunchIdctCols<CoefT, 4, 1>(c0, s); break;
       case 10: e = LaunchIdctCols<CoefT, 2, 4>(c0, s); break;
       case 11: e = LaunchIdctCols<CoefT, 4, 2>(c0, s); break;
-      case 18: e = LaunchDct<CoefT, 8, 8>(c0, s); break;
-      case 19: e = LaunchDct<CoefT, 4, 8>(c0, s); break;
-      case 20: e = LaunchDct<CoefT, 8, 4>(c0, s); break;
+      // the 64-class: the fast (recursive even / odd) form too, one varblock per wave; JXLHIP_IDCT_MATRIX keeps the
+      // matrix-form kernel (the plain statement of the transform) reachable
+      case 18: e = IdctMatrixForm() ? LaunchDct<CoefT, 8, 8>(c0, s) : LaunchIdctFast<CoefT, 8, 8>(c0, s); break;
+      case 19: e = IdctMatrixForm() ? LaunchDct<CoefT, 4, 8>(c0, s) : LaunchIdctFast<CoefT, 4, 8>(c0, s); break;
+      case 20: e = IdctMatrixForm() ? LaunchDct<CoefT, 8, 4>(c0, s) : LaunchIdctFast<CoefT, 8, 4>(c0, s); break;
       default:
         hipLaunchKernelGGL((jxlhip::k_special<CoefT>), dim3(c0->desc_count[s]), dim3(256), 0, c0->stream,
                            c0->tb_params.as<jxlhip::TransformParams>(), c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));

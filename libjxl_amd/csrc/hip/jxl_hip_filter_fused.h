@@ -504,6 +504,19 @@ __device__ __forceinline__ f2 LinearToSrgb2(f2 v) {
   return f2{copysignf(a.x > 0.0031308f ? hi.x : lo.x, v.x), copysignf(a.y > 0.0031308f ? hi.y : lo.y, v.y)};
 }
 
+// The sRGB transfer function for samples that are about to become 8-bit integers: the curve itself,
+// 1.055 * v^(1/2.4) - 0.055 through the hardware's base-2 logarithm and exponential (two transcendental and four plain
+// instructions per value instead of two and about thirteen). It differs from the reference's rational polynomial
+// (stage_from_linear.cc:114-144 via transfer_functions-inl.h:245-268, itself an approximation of this curve to ~5e-7) by
+// about 1e-6, far below half an 8-bit level; float output keeps the polynomial (LinearToSrgb2).
+__device__ __forceinline__ f2 LinearToSrgb2ForU8(f2 v) {
+  const f2 a = Abs2(v);
+  const f2 p = f2{__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a.x) * (1.0f / 2.4f)), __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a.y) * (1.0f / 2.4f))};
+  const f2 hi = p * 1.055f - 0.055f;
+  const f2 lo = a * 12.92f;
+  return f2{copysignf(a.x > 0.0031308f ? hi.x : lo.x, v.x), copysignf(a.y > 0.0031308f ? hi.y : lo.y, v.y)};
+}
+
 __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFilterParams* params) {
   FusedFilterParams P;
   LoadParams(P, params + blockIdx.z);
@@ -659,9 +672,15 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
           f2 cg = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
           f2 cb = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
           if (!P.f.linear_output) {
-            cr = LinearToSrgb2(cr);
-            cg = LinearToSrgb2(cg);
-            cb = LinearToSrgb2(cb);
+            if (rgbf) {
+              cr = LinearToSrgb2(cr);
+              cg = LinearToSrgb2(cg);
+              cb = LinearToSrgb2(cb);
+            } else {
+              cr = LinearToSrgb2ForU8(cr);
+              cg = LinearToSrgb2ForU8(cg);
+              cb = LinearToSrgb2ForU8(cb);
+            }
           }
           const size_t off = (size_t(r) * xs + x) * 3;
           if (rgbf) {  // float output (stage_write.cc:334-370): the samples as they are

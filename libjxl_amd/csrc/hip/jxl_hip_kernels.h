@@ -1218,6 +1218,11 @@ struct WcTable<32> {
   static constexpr float v[16] = {5.006029982e-01f, 5.054709599e-01f, 5.154473099e-01f, 5.310425911e-01f, 5.531038960e-01f, 5.829349682e-01f, 6.225041230e-01f, 6.748083415e-01f, 7.445362710e-01f, 8.393496454e-01f, 9.725682379e-01f, 1.169439933e+00f, 1.484164616e+00f, 2.057781010e+00f, 3.407608418e+00f, 1.019000812e+01f};
 };
 
+template <>
+struct WcTable<64> {  // 1 / (2 cos((n + 1/2) pi / 64)), n = 0..31 (dct_scales.h:234-236 WcMultipliers<64>)
+  static constexpr float v[32] = {5.001506360e-01f, 5.013584524e-01f, 5.037887257e-01f, 5.074711721e-01f, 5.124514794e-01f, 5.187927131e-01f, 5.265773152e-01f, 5.359098169e-01f, 5.469204380e-01f, 5.597698129e-01f, 5.746551840e-01f, 5.918185359e-01f, 6.115573479e-01f, 6.342389367e-01f, 6.603198078e-01f, 6.903721282e-01f, 7.251205224e-01f, 7.654941650e-01f, 8.127020908e-01f, 8.683447152e-01f, 9.345835970e-01f, 1.014408265e+00f, 1.112071621e+00f, 1.233832738e+00f, 1.389293959e+00f, 1.593972283e+00f, 1.874675980e+00f, 2.282050068e+00f, 2.924628428e+00f, 4.084611078e+00f, 6.796750712e+00f, 2.037387817e+01f};
+};
+
 template <int N>
 __device__ __forceinline__ void FastIdct(float (&v)[N]) {
   if constexpr (N == 2) {
@@ -1250,10 +1255,12 @@ __device__ __forceinline__ void FastIdct(float (&v)[N]) {
 __host__ __device__ constexpr int IdctFastThreads(int cx, int cy) { return (void(cx), void(cy), 64); }
 
 template <typename CoefT, int CX, int CY>
-__global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
+// (the 32-point instantiations need ~150 registers for a column of Y output plus the transform's temporaries: at four
+// waves per SIMD they spilled 8-21 of them to scratch; the 64-point ones, one varblock per wave, take two waves' share)
+__global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_waves_per_eu((CX == 8 || CY == 8) ? 2 : ((CX == 4 || CY == 4) ? 3 : 4), 8))) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
   JXL_TRANSFORM_PREAMBLE();
   constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, TB = R > C ? R : C, S = C + 1, TILE = R * S;
-  constexpr int LOGC = CX == 1 ? 3 : (CX == 2 ? 4 : 5);
+  constexpr int LOGC = CX == 1 ? 3 : (CX == 2 ? 4 : (CX == 4 ? 5 : 6));
   extern __shared__ __align__(16) float lds_f[];
   const int grp = threadIdx.x / TB, t = threadIdx.x % TB;
   float* l = lds_f + grp * TILE;
