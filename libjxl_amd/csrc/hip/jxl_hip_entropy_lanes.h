@@ -300,43 +300,41 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         unsigned long long th = 0;
         if (B.prof) th = __builtin_readcyclecounter();
         if (AIDS) n_trips += kLanesTrips;
+        // Software pipeline (the LDS-alias rANS form): what a trip reads from LDS is requested by the trip BEFORE it, as soon
+        // as that trip knows its new state, bit position and context, ahead of its own bookkeeping (coefficient chunk,
+        // store, end-of-channel test): a lone wave has nothing else to cover the LDS round trip with. The group's first trip
+        // requests its own reads here.
+        constexpr bool kPipe = !GALIAS && !PREFIX;
+        uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pe_zero = 0, pe_nonzero = 0, pnnz_c = 0;
+        LanesU32x2 pe = {0, 0};
+        auto request = [&]() {
+          LdsU32* const rp = ring + ((bitpos >> 5) & (kLanesRingWords - 1)) * 64;
+          pe = *(LdsU32x2*)(lds + ((ctxe << cl_shift) + (((state & 0xFFFu) >> log_entry) << 3)));
+          pw0 = rp[0];
+          pw1 = rp[64];
+          pw2 = rp[128];
+          __builtin_amdgcn_sched_barrier(0);  // (the reads on the serial chain leave first; the address arithmetic below covers them)
+          // the context entries of coefficient k + 1 for both outcomes of coefficient k (off the serial chain);
+          // kCoeffFreqContext(b) for b = (k + 1) / covered in 1..63 is min(b - 1, 7 + b / 2, 15 + b / 4)
+          const uint32_t b = (k + 1) >> log2c;
+          const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
+          pe_zero = l_ctx[addr_a + f2];
+          pe_nonzero = l_ctx[cbase + 1 + nnz_b + f2];
+          // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays)
+          pnnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
+        };
+        if (kPipe) request();
 #pragma unroll
         for (int rep = 0; rep < kLanesTrips; rep++) {
           if (AIDS && B.prof) n_lane_trips += act ? 1u : 0u;
-          // ---- everything the trip reads from LDS, up front (one round trip): the stream window, the alias entry, and
-          // the context entries of coefficient k + 1 for both outcomes of this one (off the serial chain);
-          // kCoeffFreqContext(b) for b = (k + 1) / covered in 1..63 is min(b - 1, 7 + b / 2, 15 + b / 4)
-          const uint32_t slotw = (bitpos >> 5) & (kLanesRingWords - 1);
-          LdsU32* const rp = ring + slotw * 64;
-          const uint32_t w0 = rp[0], w1 = rp[64], w2 = rp[128];
+          uint32_t w0, w1, w2, e_zero, e_nonzero, nnz_c;
           const uint32_t kn = k + 1;
-          const uint32_t b = kn >> log2c;
-          const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
           const uint32_t addr_b = cbase + 1 + nnz_b;
-          const uint32_t e_zero = l_ctx[(addr_a + f2) & 0x1FFF];
-          const uint32_t e_nonzero = l_ctx[(addr_b + f2) & 0x1FFF];
-          // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays)
-          const uint32_t nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
           uint32_t tok, cfg, adv, nstate = state;
-          if (PREFIX) {
-            const uint32_t po = l_poff[ctxe & 255];
-            const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
-            uint32_t e = 0;
-            if (act) e = PrefixLookup(ptable + (po & 0xFFFFFFu), po >> 24, win);  // (global table: only from valid state)
-            tok = e >> 8;
-            adv = e & 0xFFu;
-            cfg = l_cfg[ctxe & 255];
-          } else {
+          if (kPipe) {
+            w0 = pw0, w1 = pw1, w2 = pw2, e_zero = pe_zero, e_nonzero = pe_nonzero, nnz_c = pnnz_c;
+            const LanesU32x2 e = pe;
             const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & entry_mask;
-            LanesU32x2 e = {0, 0};
-            if (GALIAS) {
-              if (act) {
-                const uint2 ge = galias[(ctxe << log_alpha) + slot];
-                e = LanesU32x2{ge.x, ge.y};
-              }
-            } else {
-              e = *(LdsU32x2*)(lds + (((ctxe & 255) << cl_shift) + slot * 8));
-            }
             const bool gt = pos >= (e.x >> 24);
             const uint32_t x = gt ? e.y : e.x;
             tok = gt ? (e.y >> 24) : slot;
@@ -347,6 +345,43 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             nstate = need ? ((nstate << 16) | (win & 0xFFFFu)) : nstate;
             adv = need ? 16u : 0u;
             cfg = e.x >> 12;
+          } else {
+            // ---- everything the trip reads from LDS, up front (one round trip): the stream window, the alias entry, and
+            // the context entries of coefficient k + 1 for both outcomes of this one
+            const uint32_t slotw = (bitpos >> 5) & (kLanesRingWords - 1);
+            LdsU32* const rp = ring + slotw * 64;
+            w0 = rp[0], w1 = rp[64], w2 = rp[128];
+            const uint32_t b = kn >> log2c;
+            const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
+            e_zero = l_ctx[(addr_a + f2) & 0x1FFF];
+            e_nonzero = l_ctx[(addr_b + f2) & 0x1FFF];
+            nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
+            if (PREFIX) {
+              const uint32_t po = l_poff[ctxe & 255];
+              const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
+              uint32_t e = 0;
+              if (act) e = PrefixLookup(ptable + (po & 0xFFFFFFu), po >> 24, win);  // (global table: only from valid state)
+              tok = e >> 8;
+              adv = e & 0xFFu;
+              cfg = l_cfg[ctxe & 255];
+            } else {
+              const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & entry_mask;
+              LanesU32x2 e = {0, 0};
+              if (act) {
+                const uint2 ge = galias[(ctxe << log_alpha) + slot];
+                e = LanesU32x2{ge.x, ge.y};
+              }
+              const bool gt = pos >= (e.x >> 24);
+              const uint32_t x = gt ? e.y : e.x;
+              tok = gt ? (e.y >> 24) : slot;
+              const uint32_t hi = state >> 12;
+              nstate = (x & 0xFFFu) * hi + hi + (gt ? ((e.y >> 12) & 0xFFFu) : 0u) + pos;
+              const bool need = nstate < (1u << 16);
+              const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
+              nstate = need ? ((nstate << 16) | (win & 0xFFFFu)) : nstate;
+              adv = need ? 16u : 0u;
+              cfg = e.x >> 12;
+            }
           }
           // Tokens with extra bits are rare (|coefficient| >= 8 at the usual split of 16): their ~25 instructions are
           // skipped when no lane of the trip has one (a wave-uniform branch).
@@ -357,6 +392,21 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             tok = take ? big : tok;
             adv += take ? nbits : 0u;
           }
+          const bool nz = tok != 0;
+          const uint32_t n_nzeros = nzeros - (nz ? 1u : 0u);
+          const bool done = n_nzeros == 0 || kn >= size;
+          const bool full = act && (kn & (kPerChunk - 1)) == 0;
+          // ---- commit what the next trip's reads depend on (lanes outside the trip keep everything), then request them
+          const uint32_t acc_lo0 = acc_lo, acc_hi0 = acc_hi, dst0 = dst;
+          state = act ? nstate : state;
+          bitpos += act ? adv : 0u;
+          k = act ? kn : k;
+          nzeros = act ? n_nzeros : nzeros;
+          ctxe = act ? (nz ? e_nonzero : e_zero) : ctxe;
+          addr_a = (act && nz) ? addr_b - 1 : addr_a;
+          nnz_b = (act && nz) ? nnz_c : nnz_b;
+          if (kPipe && rep + 1 < kLanesTrips) request();
+          // ---- the trip's own bookkeeping, under the round trip of those reads
           const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
           const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
           // Coefficients leave in aligned 8-byte chunks (4 x int16 / 2 x int32), shifted into a register pair from the top:
@@ -366,29 +416,17 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           // are unspecified (the transforms never read them).
           uint32_t n_lo, n_hi;
           if (sizeof(CoefT) == 2) {
-            n_lo = __builtin_amdgcn_alignbit(acc_hi, acc_lo, 16);
-            n_hi = (acc_hi >> 16) | (uint32_t(coeff) << 16);
+            n_lo = __builtin_amdgcn_alignbit(acc_hi0, acc_lo0, 16);
+            n_hi = (acc_hi0 >> 16) | (uint32_t(coeff) << 16);
           } else {
-            n_lo = acc_hi;
+            n_lo = acc_hi0;
             n_hi = uint32_t(coeff);
           }
-          const bool nz = tok != 0;
-          const uint32_t n_nzeros = nzeros - (nz ? 1u : 0u);
-          const bool full = act && (kn & (kPerChunk - 1)) == 0;
-          if ((B.debug & 1) == 0 && full) LaneStore64(coef_base, dst, n_lo, n_hi);
-          const bool done = n_nzeros == 0 || kn >= size;
-          // ---- commit (lanes outside the trip keep everything)
+          if ((B.debug & 1) == 0 && full) LaneStore64(coef_base, dst0, n_lo, n_hi);
           if (AIDS && (B.debug & 2)) ntok += act ? 1u : 0u;
-          state = act ? nstate : state;
-          bitpos += act ? adv : 0u;
-          acc_lo = act ? n_lo : acc_lo;
-          acc_hi = act ? n_hi : acc_hi;
-          dst += full ? 8u : 0u;
-          k = act ? kn : k;
-          nzeros = act ? n_nzeros : nzeros;
-          ctxe = act ? (nz ? e_nonzero : e_zero) : ctxe;
-          addr_a = (act && nz) ? addr_b - 1 : addr_a;
-          nnz_b = (act && nz) ? nnz_c : nnz_b;
+          acc_lo = act ? n_lo : acc_lo0;
+          acc_hi = act ? n_hi : acc_hi0;
+          dst = dst0 + (full ? 8u : 0u);
           mode = (act && done) ? uint32_t(kFlush) : mode;
           act = act && !done;
         }
