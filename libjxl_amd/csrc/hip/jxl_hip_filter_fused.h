@@ -701,22 +701,28 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
               }
             }
           } else {
-          const uint32_t b0 = ToU8D(cr.x, di[0].x), b1 = ToU8D(cg.x, di[1].x), b2 = ToU8D(cb.x, di[2].x);
-          const uint32_t b3 = ToU8D(cr.y, di[0].y), b4 = ToU8D(cg.y, di[1].y), b5 = ToU8D(cb.y, di[2].y);
+          // v_cvt_pk_u8_f32 rounds to nearest even, saturates to 0..255 and drops the byte into place
+          // (scripts/cvt_probe.hip): one instruction per sample for clamp + round + pack
+          uint32_t w01 = __builtin_amdgcn_cvt_pk_u8_f32(cr.x * 255.0f + di[0].x, 0, 0u);
+          w01 = __builtin_amdgcn_cvt_pk_u8_f32(cg.x * 255.0f + di[1].x, 1, w01);
+          w01 = __builtin_amdgcn_cvt_pk_u8_f32(cb.x * 255.0f + di[2].x, 2, w01);
+          w01 = __builtin_amdgcn_cvt_pk_u8_f32(cr.y * 255.0f + di[0].y, 3, w01);
+          uint32_t w2 = __builtin_amdgcn_cvt_pk_u8_f32(cg.y * 255.0f + di[1].y, 0, 0u);
+          w2 = __builtin_amdgcn_cvt_pk_u8_f32(cb.y * 255.0f + di[2].y, 1, w2);
           const GU8W dst = rgb + off;
           if (emit1 && (off & 1) == 0) {  // six bytes from an even offset: three 16-bit stores
             const GU16W d16 = (GU16W)dst;
-            d16[0] = uint16_t(b0 | b1 << 8);
-            d16[1] = uint16_t(b2 | b3 << 8);
-            d16[2] = uint16_t(b4 | b5 << 8);
+            d16[0] = uint16_t(w01);
+            d16[1] = uint16_t(w01 >> 16);
+            d16[2] = uint16_t(w2);
           } else {
-            dst[0] = uint8_t(b0);
-            dst[1] = uint8_t(b1);
-            dst[2] = uint8_t(b2);
+            dst[0] = uint8_t(w01);
+            dst[1] = uint8_t(w01 >> 8);
+            dst[2] = uint8_t(w01 >> 16);
             if (emit1) {
-              dst[3] = uint8_t(b3);
-              dst[4] = uint8_t(b4);
-              dst[5] = uint8_t(b5);
+              dst[3] = uint8_t(w01 >> 24);
+              dst[4] = uint8_t(w2);
+              dst[5] = uint8_t(w2 >> 8);
             }
           }
           }
