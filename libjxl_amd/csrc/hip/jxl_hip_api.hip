@@ -285,6 +285,7 @@ struct JxlHipContext {
   struct FilterGroup {
     int key;  // gaborish * 4 + epf iterations
     uint32_t first, count, tiles_x, tiles_y;
+    bool u8srgb;  // every frame of the group writes 8-bit sRGB only (k_filter_rows2<true>)
   };
   Buf tb_params, tb_desc, fb_params;
   std::vector<const JxlHipContext*> db_ctxs;
@@ -1351,9 +1352,10 @@ static int PrepareDownstream(JxlHipContext* c0, JxlHipContext* const* ctxs, size
     const int key = FilterKey(c);
     const uint32_t tx = (c->xs + jxlhip::kFusedTW - 1) / jxlhip::kFusedTW;
     const uint32_t ty = (c->band_y1 - c->band_y0 + jxlhip::kFusedTH - 1) / jxlhip::kFusedTH;
-    if (c0->fgroups.empty() || c0->fgroups.back().key != key) c0->fgroups.push_back({key, uint32_t(j), 0, 0, 0});
+    if (c0->fgroups.empty() || c0->fgroups.back().key != key) c0->fgroups.push_back({key, uint32_t(j), 0, 0, 0, true});
     JxlHipContext::FilterGroup& g = c0->fgroups.back();
     g.count++;
+    g.u8srgb = g.u8srgb && fparams[j].f.rgb && !fparams[j].f.rgbf && !fparams[j].filtered && !fparams[j].f.linear_output;
     g.tiles_x = tx > g.tiles_x ? tx : g.tiles_x;
     g.tiles_y = ty > g.tiles_y ? ty : g.tiles_y;
   }
@@ -1399,7 +1401,7 @@ static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup&
   const uint32_t gy = (rows + jxlhip::kRowsStrip - 1) / jxlhip::kRowsStrip;
   for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
     const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
-    hipLaunchKernelGGL(one_px ? jxlhip::k_filter_rows : jxlhip::k_filter_rows2, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0,
+    hipLaunchKernelGGL(one_px ? jxlhip::k_filter_rows : (g.u8srgb ? jxlhip::k_filter_rows2<true> : jxlhip::k_filter_rows2<false>), dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0,
                        c0->fstream, c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
   }
   HIP_TRY(hipGetLastError());

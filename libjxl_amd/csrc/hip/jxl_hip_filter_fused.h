@@ -510,13 +510,63 @@ __device__ __forceinline__ f2 LinearToSrgb2(f2 v) {
 // (stage_from_linear.cc:114-144 via transfer_functions-inl.h:245-268, itself an approximation of this curve to ~5e-7) by
 // about 1e-6, far below half an 8-bit level; float output keeps the polynomial (LinearToSrgb2).
 __device__ __forceinline__ f2 LinearToSrgb2ForU8(f2 v) {
-  const f2 a = Abs2(v);
-  const f2 p = f2{__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a.x) * (1.0f / 2.4f)), __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a.y) * (1.0f / 2.4f))};
+  // no absolute value / sign restoration: a negative sample takes the linear branch, stays negative, and the 8-bit
+  // conversion saturates it to 0 exactly as it does the reference's -f(|v|)
+  const f2 p = f2{__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v.x) * (1.0f / 2.4f)), __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v.y) * (1.0f / 2.4f))};
   const f2 hi = p * 1.055f - 0.055f;
-  const f2 lo = a * 12.92f;
-  return f2{copysignf(a.x > 0.0031308f ? hi.x : lo.x, v.x), copysignf(a.y > 0.0031308f ? hi.y : lo.y, v.y)};
+  const f2 lo = v * 12.92f;
+  return f2{v.x > 0.0031308f ? hi.x : lo.x, v.y > 0.0031308f ? hi.y : lo.y};
 }
 
+// U8SRGB: the launch's frames all write 8-bit sRGB and nothing else (no float output, no filtered planes, no linear
+// output): the common case, compiled without the other writers so that its scalars fit the SGPR file (the general form
+// spills 32 of them to VGPR lanes and pays a v_readlane per use).
+//
+// The kernel is bound by instruction issue (a packed f32 instruction occupies the SIMD for 8 cycles, any other vector
+// instruction for 4; one step of one wave measured 1430 cycles = 84 packed + 190 other instructions), so the step is
+// written to the instruction: whatever involves a neighbouring lane is spelled per element, so that the DPP shift folds
+// into the consuming add / multiply-add (a pair built from a shifted element costs two moves before a packed
+// instruction can use it), absolute values ride on source modifiers of unpacked instructions (packed ones have none),
+// every address is a scalar base plus a loop-invariant 32-bit lane offset (the saddr form of the global instructions:
+// no vector address arithmetic in the loop), the mirrored input row is a two-scalar state machine instead of a
+// reflection loop, and every load of the next step is unconditional (clamped rows), which leaves no phi copies.
+// Two adjacent pixels as two plain floats (see k_filter_rows2: packed f32 instructions buy no issue time on this chip
+// and want their scalar operands duplicated into aligned SGPR pairs).
+struct P2 {
+  float x, y;
+};
+__device__ __forceinline__ P2 operator+(P2 a, P2 b) { return P2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ P2 operator-(P2 a, P2 b) { return P2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ P2 operator*(P2 a, P2 b) { return P2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ P2 operator+(P2 a, float b) { return P2{a.x + b, a.y + b}; }
+__device__ __forceinline__ P2 operator-(P2 a, float b) { return P2{a.x - b, a.y - b}; }
+__device__ __forceinline__ P2 operator*(P2 a, float b) { return P2{a.x * b, a.y * b}; }
+__device__ __forceinline__ P2 operator*(float b, P2 a) { return P2{b * a.x, b * a.y}; }
+__device__ __forceinline__ P2 Max0(P2 a) { return P2{__builtin_fmaxf(a.x, 0.0f), __builtin_fmaxf(a.y, 0.0f)}; }
+__device__ __forceinline__ P2 Srgb2(P2 v) {
+  const f2 r = LinearToSrgb2(f2{v.x, v.y});
+  return P2{r.x, r.y};
+}
+__device__ __forceinline__ P2 Srgb2ForU8(P2 v) {
+  const f2 r = LinearToSrgb2ForU8(f2{v.x, v.y});
+  return P2{r.x, r.y};
+}
+// gfx9 raw buffer resource over "everything from p on": base + scalar offset + 32-bit lane offset addressing with no
+// vector address arithmetic (the offsets the kernel forms are inside the allocation by construction)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t RawBuffer(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ float BufF32(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ P2 BufP2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  const f2 f = __builtin_bit_cast(f2, v);  // (the whole vector: __builtin_bit_cast of one element reads element 0 with this clang)
+  return P2{f.x, f.y};
+}
+
+template <bool U8SRGB>
 __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFilterParams* params) {
   FusedFilterParams P;
   LoadParams(P, params + blockIdx.z);
@@ -532,30 +582,30 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
   const bool emit0 = emit_lane && x < xs, emit1 = emit_lane && x + 1 < xs;
   const bool xb0 = ((mx0 & 7) == 0) || ((mx0 & 7) == 7), xb1 = ((mx1 & 7) == 0) || ((mx1 & 7) == 7);
   const size_t gplane = size_t(P.f.xp) * P.f.yp;
-  typedef const float __attribute__((address_space(1)))* GF32;
-  typedef const f2 __attribute__((address_space(1)))* GF32x2;
   typedef float __attribute__((address_space(1)))* GF32W;
-  typedef uint8_t __attribute__((address_space(1)))* GU8W;
-  typedef uint16_t __attribute__((address_space(1)))* GU16W;
-  const GF32 in0 = (GF32)(uintptr_t)P.f.in + mx0, in1 = (GF32)(uintptr_t)P.f.in + mx1;
+  typedef f2 __attribute__((address_space(1)))* GF32x2W;
   // whole wave inside the frame: one 8-byte load per lane and plane (x is even, rows are 8-byte aligned); waves at the
   // left / right frame edge load the two mirrored columns separately
   const bool paired = __all(x >= 0 && x + 1 < xs) && (P.f.xp & 1) == 0;
-  const GF32 sig = (GF32)(uintptr_t)P.f.inv_sigma + (mx0 >> 3);  // x is even: the pair shares its 8x8 block
-  const GF32 dither = (GF32)(uintptr_t)c_dither;
-  const GF32W filtered = (GF32W)(uintptr_t)P.filtered;
-  const GU8W rgb = (GU8W)(uintptr_t)P.f.rgb;
-  const GF32W rgbf = (GF32W)(uintptr_t)P.f.rgbf;
-  int dcol[2][3];
-#pragma unroll
-  for (int e = 0; e < 2; e++)
-#pragma unroll
-    for (int c = 0; c < 3; c++) dcol[e][c] = (x + e + 23 * c) & 31;
-  const f2 zero2 = f2{0.0f, 0.0f};
+  // loop-invariant lane offsets in bytes; the per-step part of every address is a scalar
+  const uint32_t vo0 = uint32_t(mx0) * 4u, vo1 = uint32_t(mx1) * 4u;  // input columns
+  const uint32_t vsig = uint32_t(mx0 >> 3) * 4u;                      // x is even: the pair shares its 8x8 block
+  const uint32_t vout = uint32_t(x) * 3u;                             // interleaved RGB column (lanes with x < 0 never store)
+  const uint32_t vd0 = uint32_t(x & 31) * 4u;                         // dither columns: channel 0 (even: pair contiguous)
+  const uint32_t vd1a = uint32_t((x + 23) & 31) * 4u, vd1b = uint32_t((x + 24) & 31) * 4u;  // channel 1 (odd: may wrap)
+  const uint32_t vd2 = uint32_t((x + 46) & 31) * 4u;                  // channel 2 (even)
+  const __amdgpu_buffer_rsrc_t in_buf = RawBuffer(P.f.in), sig_buf = RawBuffer(P.f.inv_sigma);
+  const __amdgpu_buffer_rsrc_t dither_buf = RawBuffer(c_dither), rgb_buf = RawBuffer(P.f.rgb);
+  const uint32_t plane_bytes = uint32_t(gplane * 4);  // (three planes of at most 1 GiB: offsets fit 32 bits)
+  const GF32W filtered = U8SRGB ? nullptr : (GF32W)(uintptr_t)P.filtered;
+  const bool has_rgb = U8SRGB || P.f.rgb != nullptr;
+  const GF32W rgbf = U8SRGB ? nullptr : (GF32W)(uintptr_t)P.f.rgbf;
+  const bool linear_output = U8SRGB ? false : P.f.linear_output != 0;
+  const P2 zero2 = P2{0.0f, 0.0f};
   // sliding windows as rings of 4 rows indexed with the step's phase (the row loop is unrolled by 4): a window shift is a
   // renaming, not register moves
-  f2 p[3][4], h1[3][4], g[3][4], dh[4], dv[4];
-  f2 pv_prev = zero2, dh_new = zero2;
+  P2 p[3][4], h1[3][4], g[3][4], dh[4], dv[4];
+  P2 pv_prev = zero2, dh_new = zero2;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
 #pragma unroll
@@ -564,99 +614,126 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
 #pragma unroll
   for (int k = 0; k < 4; k++) dh[k] = dv[k] = zero2;
   const int steps = (y1 - y0 + 2 * kRowsHalo + 3) / 4 * 4;  // whole groups of 4 steps (the extra steps emit nothing)
-  auto load_row = [&](int y, f2 (&dst)[3]) {
-    const size_t row = size_t(MirrorI(y, ys)) * P.f.xp;
+  // the mirrored input row as a state machine: image_ops.h:184-196 maps ..., -2, -1, 0, 1, ... to ..., 1, 0, 0, 1, ...
+  // (and likewise at the far end), a triangle wave whose turning samples repeat; (ym, ydir) walks it one row per step
+  int ym = MirrorI(y0 - kRowsHalo, ys), ydir;
+  {
+    const int ym_next = MirrorI(y0 - kRowsHalo + 1, ys);
+    ydir = ym_next > ym ? 1 : (ym_next < ym ? -1 : (ym == 0 ? -1 : 1));
+  }
+  auto load_row = [&](P2 (&dst)[3]) {  // row ym, then advance the state machine
+    const uint32_t row = uint32_t(ym) * uint32_t(P.f.xp) * 4u;
     if (paired) {
 #pragma unroll
-      for (int c = 0; c < 3; c++) dst[c] = *(GF32x2)(in0 + c * gplane + row);
+      for (int c = 0; c < 3; c++) dst[c] = BufP2(in_buf, vo0, row + c * plane_bytes);
     } else {
 #pragma unroll
-      for (int c = 0; c < 3; c++) dst[c] = f2{in0[c * gplane + row], in1[c * gplane + row]};
+      for (int c = 0; c < 3; c++) dst[c] = P2{BufF32(in_buf, vo0, row + c * plane_bytes), BufF32(in_buf, vo1, row + c * plane_bytes)};
     }
+    int nxt = ym + ydir;
+    if (nxt < 0) {
+      nxt = 0;
+      ydir = 1;
+    } else if (nxt >= ys) {
+      nxt = ys - 1;
+      ydir = -1;
+    }
+    ym = nxt;
   };
-  // everything a step reads from memory is loaded one step ahead (see k_filter_rows)
-  f2 nx[3], ndi[3] = {zero2, zero2, zero2};
+  // everything a step reads from memory is loaded one step ahead (see k_filter_rows), unconditionally: rows outside the
+  // strip's output range are clamped into the frame and their values never used
+  auto load_aux = [&](int r, float& is, P2 (&di)[3]) {
+    const int rc = r < 0 ? 0 : (r >= ys ? ys - 1 : r);
+    is = BufF32(sig_buf, vsig, uint32_t(rc >> 3) * uint32_t(P.f.xb) * 4u);
+    if (!has_rgb) return;
+    di[0] = BufP2(dither_buf, vd0, uint32_t(r & 31) * 128u);
+    di[1] = P2{BufF32(dither_buf, vd1a, uint32_t((r + 13) & 31) * 128u), BufF32(dither_buf, vd1b, uint32_t((r + 13) & 31) * 128u)};
+    di[2] = BufP2(dither_buf, vd2, uint32_t((r + 26) & 31) * 128u);
+  };
+  P2 nx[3], ndi[3] = {zero2, zero2, zero2};
   float nis = 0.0f;
-  load_row(y0 - kRowsHalo, nx);
+  load_row(nx);
+  load_aux(y0 - 2 * kRowsHalo, nis, ndi);
   auto step = [&](auto phase, int j) {
     constexpr int PH = decltype(phase)::value;
     // ring slots: N = newest (written in this step), M1 / M2 / M3 = one / two / three rows older
     constexpr int N = PH % 4, M1 = (PH + 3) % 4, M2 = (PH + 2) % 4, M3 = (PH + 1) % 4;
-    const int yi = y0 - kRowsHalo + j;
-    const f2 cur[3] = {nx[0], nx[1], nx[2]};
+    const P2 cur[3] = {nx[0], nx[1], nx[2]};
     const float is = nis;
-    const f2 di[3] = {ndi[0], ndi[1], ndi[2]};
-    const int r = yi - kRowsHalo;  // output row of this step, valid from step 6
-    const int my = MirrorI(r, ys);
-    if (j + 1 < steps) {
-      load_row(yi + 1, nx);
-      if (j + 1 >= 2 * kRowsHalo && r + 1 < y1) {  // r + 1 is an output row (the padding steps of the last group of 4 are not)
-        nis = sig[size_t((r + 1) >> 3) * P.f.xb];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-          const int drow = ((r + 1 + 13 * c) & 31) * 32;
-          ndi[c] = f2{dither[drow + dcol[0][c]], dither[drow + dcol[1][c]]};
-        }
-      }
-    }
+    const P2 di[3] = {ndi[0], ndi[1], ndi[2]};
+    const int r = y0 - 2 * kRowsHalo + j;  // output row of this step, valid from step 6 (inside the frame then: r == its mirror)
+    load_row(nx);
+    load_aux(r + 1, nis, ndi);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       p[c][N] = cur[c];
-      h1[c][N] = LeftOf(cur[c]) + RightOf(cur[c]);
+      h1[c][N] = P2{FromLeft(cur[c].y) + cur[c].y, cur[c].x + FromRight(cur[c].x)};  // columns x - 1 and x + 1 of each element
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const f2 m = p[c][M1];
-      const f2 s1 = h1[c][M1] + (p[c][M2] + p[c][N]);
-      const f2 s2 = h1[c][M2] + h1[c][N];
+      const P2 m = p[c][M1];
+      const P2 s1 = h1[c][M1] + (p[c][M2] + p[c][N]);
+      const P2 s2 = h1[c][M2] + h1[c][N];
       g[c][N] = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
     }
     dh[N] = dh_new;
     {
-      f2 a = zero2, b = zero2;
+      P2 a = zero2, b = zero2;
 #pragma unroll
       for (int c = 0; c < 3; c++) {
-        a = Abs2(g[c][N] - RightOf(g[c][N])) * P.f.ch_scale[c] + a;
-        b = Abs2(g[c][M1] - g[c][N]) * P.f.ch_scale[c] + b;
+        const P2 gn = g[c][N], gm = g[c][M1];
+        a.x = __builtin_fabsf(gn.x - gn.y) * P.f.ch_scale[c] + a.x;  // |G(x) - G(x + 1)|: the pair's other element ...
+        a.y = __builtin_fabsf(gn.y - FromRight(gn.x)) * P.f.ch_scale[c] + a.y;  // ... and the next lane's first
+        b.x = __builtin_fabsf(gm.x - gn.x) * P.f.ch_scale[c] + b.x;
+        b.y = __builtin_fabsf(gm.y - gn.y) * P.f.ch_scale[c] + b.y;
       }
       dh_new = a;
       dv[N] = b;
     }
-    const f2 pv = (dv[M1] + dv[M2]) + (LeftOf(dv[M1]) + dv[N]) + RightOf(dv[M1]);
-    const f2 ph = (dh[M1] + dh[M2]) + (LeftOf(dh[M1]) + dh[N]) + RightOf(dh[M1]);
-    const f2 ph_left = LeftOf(ph);
+    // (D(M1) + D(M2)) + (left of D(M1) + D(N)) + right of D(M1), the neighbour terms per element
+    auto plus_sum = [&](const P2 (&d)[4]) {
+      const P2 t = d[M1] + d[M2];
+      const P2 u = P2{FromLeft(d[M1].y) + d[N].x, d[M1].x + d[N].y};
+      const P2 w = t + u;
+      return P2{w.x + d[M1].y, w.y + FromRight(d[M1].x)};
+    };
+    const P2 pv = plus_sum(dv);
+    const P2 ph = plus_sum(dh);
     if (j >= 2 * kRowsHalo && r < y1) {
-      f2 o[3] = {g[0][M2], g[1][M2], g[2][M2]};
-      f2 nl[3], nr[3];
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        nl[c] = LeftOf(o[c]);
-        nr[c] = RightOf(o[c]);
-      }
-      if (!(is < -3.90524291751269967465540850526868f)) {  // else sigma too small: pixels unchanged (the pair shares a block)
-        const bool yb = ((my & 7) == 0) || ((my & 7) == 7);
-        const f2 inv_sig = f2{is * ((xb0 || yb) ? P.bsm[1] : P.sm[1]), is * ((xb1 || yb) ? P.bsm[1] : P.sm[1])};
-        const f2 sad[4] = {pv_prev, ph_left, ph, pv};  // neighbours in the reference's order: up, left, right, down
-        f2 wsum = f2{1.0f, 1.0f}, a0 = o[0], a1 = o[1], a2 = o[2];
+      P2 o[3] = {g[0][M2], g[1][M2], g[2][M2]};
+      {
+        // no branch on the lane's sigma here: the DPP reads below must see their neighbours whatever the neighbours' own
+        // sigma is (a lane switched off by a divergent branch reads as 0); the unfiltered pixels are selected at the end
+        const bool keep = is < -3.90524291751269967465540850526868f;  // sigma too small: pixels unchanged (the pair shares a block)
+        const bool yb = ((r & 7) == 0) || ((r & 7) == 7);
+        const P2 inv_sig = P2{is * ((xb0 || yb) ? P.bsm[1] : P.sm[1]), is * ((xb1 || yb) ? P.bsm[1] : P.sm[1])};
+        // neighbours in the reference's order: up, left, right, down (SADs pv_prev, ph of column x - 1, ph, pv)
+        P2 wk[4];
+        wk[0] = pv_prev * inv_sig + 1.0f;
+        wk[1] = P2{FromLeft(ph.y) * inv_sig.x + 1.0f, ph.x * inv_sig.y + 1.0f};
+        wk[2] = ph * inv_sig + 1.0f;
+        wk[3] = pv * inv_sig + 1.0f;
+        P2 wsum = P2{1.0f, 1.0f};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          f2 weight = sad[k] * inv_sig + 1.0f;
-          weight = __builtin_elementwise_max(weight, zero2);
-          wsum += weight;
-          const f2 n0 = k == 0 ? g[0][M3] : (k == 1 ? nl[0] : (k == 2 ? nr[0] : g[0][M1]));
-          const f2 n1 = k == 0 ? g[1][M3] : (k == 1 ? nl[1] : (k == 2 ? nr[1] : g[1][M1]));
-          const f2 n2 = k == 0 ? g[2][M3] : (k == 1 ? nl[2] : (k == 2 ? nr[2] : g[2][M1]));
-          a0 = weight * n0 + a0;
-          a1 = weight * n1 + a1;
-          a2 = weight * n2 + a2;
+          wk[k] = Max0(wk[k]);
+          wsum = wsum + wk[k];
         }
-        const f2 inv_w = f2{__builtin_amdgcn_rcpf(wsum.x), __builtin_amdgcn_rcpf(wsum.y)};  // 1 ulp; wsum >= 1
-        o[0] = a0 * inv_w;
-        o[1] = a1 * inv_w;
-        o[2] = a2 * inv_w;
+        const P2 inv_w = P2{__builtin_amdgcn_rcpf(wsum.x), __builtin_amdgcn_rcpf(wsum.y)};  // 1 ulp; wsum >= 1
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const P2 oc = o[c];
+          P2 a = wk[0] * g[c][M3] + oc;
+          a.x = wk[1].x * FromLeft(oc.y) + a.x;
+          a.y = wk[1].y * oc.x + a.y;
+          a.x = wk[2].x * oc.y + a.x;
+          a.y = wk[2].y * FromRight(oc.x) + a.y;
+          a = wk[3] * g[c][M1] + a;
+          o[c] = P2{keep ? oc.x : a.x * inv_w.x, keep ? oc.y : a.y * inv_w.y};
+        }
       }
       if (emit0) {
-        if (filtered) {
+        if (!U8SRGB && filtered) {
           const size_t gi = size_t(r) * P.f.xp + x;
 #pragma unroll
           for (int c = 0; c < 3; c++) {
@@ -664,29 +741,22 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
             if (emit1) filtered[c * gplane + gi + 1] = o[c].y;
           }
         }
-        if (rgb || rgbf) {
-          const f2 X = o[0], Y = o[1], Bc = o[2];
-          const f2 gr = (Y + X) - P.f.opsin_bias_cbrt[0], gg = (Y - X) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
-          const f2 mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
-          f2 cr = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);
-          f2 cg = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
-          f2 cb = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
-          if (!P.f.linear_output) {
-            if (rgbf) {
-              cr = LinearToSrgb2(cr);
-              cg = LinearToSrgb2(cg);
-              cb = LinearToSrgb2(cb);
-            } else {
-              cr = LinearToSrgb2ForU8(cr);
-              cg = LinearToSrgb2ForU8(cg);
-              cb = LinearToSrgb2ForU8(cb);
+        if (has_rgb || rgbf) {
+          const P2 X = o[0], Y = o[1], Bc = o[2];
+          const P2 gr = (Y + X) - P.f.opsin_bias_cbrt[0], gg = (Y - X) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
+          const P2 mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
+          P2 cr = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);
+          P2 cg = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
+          P2 cb = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
+          const bool even = ((r & xs) & 1) == 0;  // (r * xs + x) * 3 with x even: the row's parity decides the alignment
+          if (!U8SRGB && rgbf) {  // float output (stage_write.cc:334-370): the samples as they are
+            if (!linear_output) {
+              cr = Srgb2(cr);
+              cg = Srgb2(cg);
+              cb = Srgb2(cb);
             }
-          }
-          const size_t off = (size_t(r) * xs + x) * 3;
-          if (rgbf) {  // float output (stage_write.cc:334-370): the samples as they are
-            const GF32W d = rgbf + off;
-            if (emit1 && (off & 1) == 0) {  // six floats from an 8-byte aligned offset
-              typedef f2 __attribute__((address_space(1)))* GF32x2W;
+            const GF32W d = rgbf + (size_t(r) * xs + x) * 3;
+            if (emit1 && even) {  // six floats from an 8-byte aligned offset
               *(GF32x2W)(d) = f2{cr.x, cg.x};
               *(GF32x2W)(d + 2) = f2{cb.x, cr.y};
               *(GF32x2W)(d + 4) = f2{cg.y, cb.y};
@@ -701,30 +771,38 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
               }
             }
           } else {
-          // v_cvt_pk_u8_f32 rounds to nearest even, saturates to 0..255 and drops the byte into place
-          // (scripts/cvt_probe.hip): one instruction per sample for clamp + round + pack
-          uint32_t w01 = __builtin_amdgcn_cvt_pk_u8_f32(cr.x * 255.0f + di[0].x, 0, 0u);
-          w01 = __builtin_amdgcn_cvt_pk_u8_f32(cg.x * 255.0f + di[1].x, 1, w01);
-          w01 = __builtin_amdgcn_cvt_pk_u8_f32(cb.x * 255.0f + di[2].x, 2, w01);
-          w01 = __builtin_amdgcn_cvt_pk_u8_f32(cr.y * 255.0f + di[0].y, 3, w01);
-          uint32_t w2 = __builtin_amdgcn_cvt_pk_u8_f32(cg.y * 255.0f + di[1].y, 0, 0u);
-          w2 = __builtin_amdgcn_cvt_pk_u8_f32(cb.y * 255.0f + di[2].y, 1, w2);
-          const GU8W dst = rgb + off;
-          if (emit1 && (off & 1) == 0) {  // six bytes from an even offset: three 16-bit stores
-            const GU16W d16 = (GU16W)dst;
-            d16[0] = uint16_t(w01);
-            d16[1] = uint16_t(w01 >> 16);
-            d16[2] = uint16_t(w2);
-          } else {
-            dst[0] = uint8_t(w01);
-            dst[1] = uint8_t(w01 >> 8);
-            dst[2] = uint8_t(w01 >> 16);
-            if (emit1) {
-              dst[3] = uint8_t(w01 >> 24);
-              dst[4] = uint8_t(w2);
-              dst[5] = uint8_t(w2 >> 8);
+            if (!linear_output) {
+              cr = Srgb2ForU8(cr);
+              cg = Srgb2ForU8(cg);
+              cb = Srgb2ForU8(cb);
             }
-          }
+            // v_cvt_pk_u8_f32 rounds to nearest even, saturates to 0..255 and drops the byte into place
+            // (scripts/cvt_probe.hip): one instruction per sample for clamp + round + pack
+            uint32_t w01 = __builtin_amdgcn_cvt_pk_u8_f32(cr.x * 255.0f + di[0].x, 0, 0u);
+            w01 = __builtin_amdgcn_cvt_pk_u8_f32(cg.x * 255.0f + di[1].x, 1, w01);
+            w01 = __builtin_amdgcn_cvt_pk_u8_f32(cb.x * 255.0f + di[2].x, 2, w01);
+            w01 = __builtin_amdgcn_cvt_pk_u8_f32(cr.y * 255.0f + di[0].y, 3, w01);
+            uint32_t w2 = __builtin_amdgcn_cvt_pk_u8_f32(cg.y * 255.0f + di[1].y, 0, 0u);
+            w2 = __builtin_amdgcn_cvt_pk_u8_f32(cb.y * 255.0f + di[2].y, 1, w2);
+            const uint32_t orow = uint32_t(r) * uint32_t(xs) * 3u;  // (at most 16K x 16K x 3 bytes)
+            if (even) {  // six bytes from an even offset: 16-bit stores
+              __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01), rgb_buf, vout, orow, 0);
+              if (emit1) {
+                __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01 >> 16), rgb_buf, vout + 2, orow, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w2), rgb_buf, vout + 4, orow, 0);
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w01 >> 16), rgb_buf, vout + 2, orow, 0);
+              }
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w01), rgb_buf, vout, orow, 0);
+              __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w01 >> 8), rgb_buf, vout + 1, orow, 0);
+              __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w01 >> 16), rgb_buf, vout + 2, orow, 0);
+              if (emit1) {
+                __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w01 >> 24), rgb_buf, vout + 3, orow, 0);
+                __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w2), rgb_buf, vout + 4, orow, 0);
+                __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w2 >> 8), rgb_buf, vout + 5, orow, 0);
+              }
+            }
           }
         }
       }
