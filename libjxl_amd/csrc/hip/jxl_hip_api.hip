@@ -1398,11 +1398,26 @@ static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup&
   const bool one_px = EnvInt("JXLHIP_FILTER_ROWS1", 0) != 0;  // measurement aid: the one-column-per-lane form
   const uint32_t per_wave = one_px ? jxlhip::kRowsLanes : jxlhip::kRows2Cols;
   const uint32_t gx = ((cols + per_wave - 1) / per_wave + jxlhip::kRowsWaves - 1) / jxlhip::kRowsWaves;
-  const uint32_t gy = (rows + jxlhip::kRowsStrip - 1) / jxlhip::kRowsStrip;
+  // strip height: every strip re-reads and re-filters 6 halo rows, so the taller the better as long as the launch still
+  // has several waves for each of the chip's 1024 SIMDs
+  uint32_t strip = jxlhip::kRowsStrip;
+  if (!one_px) {
+    const uint32_t want = uint32_t(EnvInt("JXLHIP_FILTER_STRIP", 0));
+    for (uint32_t s2 = want ? 256 : 128; s2 > strip; s2 >>= 1)  // (256 measured no better than 64: 0.0374 / 0.0361 / 0.0374 ms per 4K frame)
+      if (want ? s2 == want : uint64_t(gx) * jxlhip::kRowsWaves * ((rows + s2 - 1) / s2) * g.count >= 6 * 1024) {
+        strip = s2;
+        break;
+      }
+  }
+  const uint32_t gy = (rows + strip - 1) / strip;
   for (uint32_t z = 0; z < g.count; z += 65535) {  // grid z limit
     const uint32_t zn = g.count - z < 65535 ? g.count - z : 65535;
-    hipLaunchKernelGGL(one_px ? jxlhip::k_filter_rows : (g.u8srgb ? jxlhip::k_filter_rows2<true> : jxlhip::k_filter_rows2<false>), dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0,
-                       c0->fstream, c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z);
+    const jxlhip::FusedFilterParams* fp = c0->fb_params.as<jxlhip::FusedFilterParams>() + g.first + z;
+    if (one_px)
+      hipLaunchKernelGGL(jxlhip::k_filter_rows, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0, c0->fstream, fp);
+    else
+      hipLaunchKernelGGL(g.u8srgb ? jxlhip::k_filter_rows2<true> : jxlhip::k_filter_rows2<false>, dim3(gx, gy, zn),
+                         dim3(64 * jxlhip::kRowsWaves), 0, c0->fstream, fp, int(strip));
   }
   HIP_TRY(hipGetLastError());
   return 0;

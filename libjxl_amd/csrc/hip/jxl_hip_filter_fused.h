@@ -567,14 +567,15 @@ __device__ __forceinline__ P2 BufP2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uin
 }
 
 template <bool U8SRGB>
-__global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFilterParams* params) {
+__global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFilterParams* params, int strip_rows) {
   FusedFilterParams P;
   LoadParams(P, params + blockIdx.z);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int xs = int(P.f.xs), ys = int(P.f.ys);
   const int xw0 = (int(blockIdx.x) * kRowsWaves + wave) * kRows2Cols;  // first output column of the wave (even)
-  const int y0 = int(P.f.y_begin) + int(blockIdx.y) * kRowsStrip;
-  const int y1 = y0 + kRowsStrip < int(P.f.y_end) ? y0 + kRowsStrip : int(P.f.y_end);
+  // output rows per wave: the host picks the tallest strip that still fills the chip (6 halo steps per strip are overhead)
+  const int y0 = int(P.f.y_begin) + int(blockIdx.y) * strip_rows;
+  const int y1 = y0 + strip_rows < int(P.f.y_end) ? y0 + strip_rows : int(P.f.y_end);
   if (xw0 >= xs || y0 >= y1) return;  // the grid covers the largest frame (band) of the launch
   const int x = xw0 - 4 + 2 * lane;   // the pair's first column
   const int mx0 = MirrorI(x, xs), mx1 = MirrorI(x + 1, xs);
