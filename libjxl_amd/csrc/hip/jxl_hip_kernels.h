@@ -912,6 +912,16 @@ __device__ __forceinline__ float QuantBias(int c, int q, BiasPtr b) {
   return qf - b[3] * (1.0f / qf);
 }
 
+// The same for q != 0 as selects, with the hardware reciprocal (1 ulp; the result is a dequantised coefficient compared at
+// 2e-5 absolute after the transform). q == 0 gives an unspecified value: the caller does not store it.
+template <typename BiasPtr>
+__device__ __forceinline__ float QuantBiasNoBranch(int c, int q, BiasPtr b) {
+  const float qf = float(q);
+  const float big = qf - b[3] * __builtin_amdgcn_rcpf(qf);
+  const float one = __builtin_copysignf(b[c], qf);
+  return (q == 1 || q == -1) ? one : big;
+}
+
 // Stages the dequantised coefficients of channel c of one varblock into LDS/scratch `l` at their natural positions
 // (lib/jxl/dec_group.cc:115-181: dequantisation with AdjustQuantBias, then chroma-from-luma for X and B from the
 // already staged dequantised Y in `l_y`). `gq` = the block's coefficients of channel c, `m` = channel c's dequant
@@ -1322,11 +1332,13 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
           for (int j = 0; j < 4; j++) {
             const uint32_t k = k4 + j;
             const int q = int(q4.v[j]);
-            if (k >= uint32_t(CX * CY) && k < k1 && q) {  // (entries below the lowest-frequency corner / beyond kend are unspecified)
-              const uint32_t pos = pos4[j];
-              const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
-              l[(idx >> LOGC) * S + (idx & (C - 1))] += QuantBias(c, q, P.biases) * (wv[j] * mul);
-            }
+            // value and address for every entry, without branches; only the store is conditional (a plain store: the tile
+            // was zeroed and every position has one coefficient; entries below the lowest-frequency corner / beyond kend
+            // are unspecified and skipped)
+            const uint32_t pos = pos4[j];
+            const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
+            const float val = QuantBiasNoBranch(c, q, P.biases) * (wv[j] * mul);
+            if (k >= uint32_t(CX * CY) && k < k1 && q) l[(idx >> LOGC) * S + (idx & (C - 1))] = val;
           }
         }
       } else {
@@ -1334,7 +1346,7 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
           const int q = int(gqc[k]);
           if (q) {
             const uint32_t idx = R < C ? k : (k % R) * C + k / R;
-            l[(idx >> LOGC) * S + (idx & (C - 1))] += QuantBias(c, q, P.biases) * (mc[k] * mul);
+            l[(idx >> LOGC) * S + (idx & (C - 1))] = QuantBias(c, q, P.biases) * (mc[k] * mul);
           }
         }
       }
