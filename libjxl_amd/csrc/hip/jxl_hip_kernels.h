@@ -1260,6 +1260,17 @@ __device__ __forceinline__ void FastIdct(float (&v)[N]) {
   }
 }
 
+// Tile hand-over inside a ONE-WAVE workgroup: the LDS operations of a wave execute in order, so a later read sees an
+// earlier write of any lane without a wait; only the compiler must not reorder them. __syncthreads() here would be a
+// workgroup-scope fence over global memory too: s_waitcnt vmcnt(0), i.e. every channel would wait for the previous
+// channel's row stores to be acknowledged before it may start (the transform kernels sat in such waits for 82 % of their
+// wave cycles, profiles/r02_sq_counters_isolated.txt).
+__device__ __forceinline__ void WaveLdsSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // threads per workgroup: one wave (e.g. two 32x32 varblocks, 8.4 KB of LDS; eight 8x8 ones), so that a workgroup fits into
 // the LDS the resident entropy workgroups leave free and a barrier stalls one wave only
 __host__ __device__ constexpr int IdctFastThreads(int cx, int cy) { return (void(cx), void(cy), 64); }
@@ -1269,6 +1280,7 @@ template <typename CoefT, int CX, int CY>
 // waves per SIMD they spilled 8-21 of them to scratch; the 64-point ones, one varblock per wave, take two waves' share)
 __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_waves_per_eu((CX == 8 || CY == 8) ? 2 : ((CX == 4 || CY == 4) ? 3 : 4), 8))) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
   JXL_TRANSFORM_PREAMBLE();
+  static_assert(IdctFastThreads(CX, CY) == 64, "WaveLdsSync: the workgroup is one wave");
   constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, TB = R > C ? R : C, S = C + 1, TILE = R * S;
   constexpr int LOGC = CX == 1 ? 3 : (CX == 2 ? 4 : (CX == 4 ? 5 : 6));
   extern __shared__ __align__(16) float lds_f[];
@@ -1305,7 +1317,7 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
     const float cc = c == 1 ? 0.0f : (c == 0 ? x_cc : b_cc);
     if (active)
       for (int i = t * 4; i < TILE; i += TB * 4) *reinterpret_cast<float4*>(l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
+    WaveLdsSync();
     if (active) {
       const float mul = c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm);
       const CoefT* gqc = gq + size_t(c) * 65536;
@@ -1359,7 +1371,7 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
         l[ky * S + kx] = v;
       }
     }
-    __syncthreads();
+    WaveLdsSync();
     if (active && t < R) {  // pass 1: row ky = t
       float v[C];
 #pragma unroll
@@ -1368,7 +1380,7 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
 #pragma unroll
       for (int x = 0; x < C; x++) l[t * S + x] = v[x];
     }
-    __syncthreads();
+    WaveLdsSync();
     if (active && t < C) {  // pass 2: column x = t
       float v[R];
 #pragma unroll
@@ -1383,7 +1395,7 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
         out[size_t(y) * P.xp] = r;
       }
     }
-    __syncthreads();
+    WaveLdsSync();
   }
 }
 
