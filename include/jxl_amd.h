@@ -25,6 +25,14 @@ int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runne
  * referenced is refused. */
 int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
                           void* runner_opaque, JxlAmdFrame** frame);
+/* The same from a PREFIX of the frame's bytes (what JxlDecoderFlushImage draws from; lib/jxl/dec_frame.cc:735-795 Flush,
+ * decode.cc:2458-2475): succeeds once the frame header, the TOC, the DC image (DC global + DC groups) and the AC global
+ * section are whole. AC groups with a missing section are marked absent and rendered from the DC image alone;
+ * *groups_present = the number of groups whose AC data is there. Fails ("truncated frame") for frames coded as a single
+ * section and for frames with extra channels. jxlamd_frame_is_partial() tells such a frame from a whole one. */
+int jxlamd_frame_parse_partial_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
+                                  void* runner_opaque, JxlAmdFrame** frame, uint32_t* groups_present);
+int jxlamd_frame_is_partial(const JxlAmdFrame* frame);
 /* Byte offset just behind the frame, and its animation fields {duration in ticks, is_last, timecode}. */
 size_t jxlamd_frame_end(const JxlAmdFrame* frame, uint32_t* duration_last_timecode);
 /* Where a frame sits on the canvas and how it combines with the reference slots (frame_header.h: FrameOrigin,

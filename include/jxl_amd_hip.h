@@ -164,6 +164,10 @@ typedef struct JxlHipFrameDesc {
   JxlHipSplines splines;
   /* Patches: drawn over the filtered planes before the splines (dec_cache.cc:193-201). Not for upsampled frames. */
   JxlHipPatches patches;
+  /* A frame whose bytes are not all there yet (JxlDecoderFlushImage; lib/jxl/dec_frame.cc:735-795 Flush): NULL, or one byte
+   * per group, non-zero = the group's AC sections are missing. Such a group is not entropy-decoded (its section sizes must
+   * be 0); its blocks are rendered from the DC image alone, as the reference draws them with zero passes. */
+  const uint8_t* group_absent;
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);

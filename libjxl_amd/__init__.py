@@ -593,6 +593,34 @@ def encode_layers(layers, tps=None, num_loops=0, lossless=False, premultiplied=F
     return out
 
 
+def encode_with_preview(img, preview, **kw):
+    """Test aid: `img` (HxWx3 uint8, VarDCT) with a VarDCT preview frame (hxwx3 uint8):
+    the image header announces the preview's size (headers.cc:155-183) and the preview is the codestream's first frame, a
+    regular frame that is not the last (decode.cc:1266-1268)."""
+    E = _enc_lib()
+    E.jxlenc_set_animation.argtypes = [ctypes.c_int] + [ctypes.c_uint32] * 4 + [ctypes.c_int]
+    E.jxlenc_set_animation.restype = None
+    E.jxlenc_set_preview.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32]
+    E.jxlenc_set_preview.restype = None
+    E.jxlenc_last_header_bytes.restype = ctypes.c_size_t
+    E.jxlenc_set_layer.argtypes = [ctypes.c_int, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_uint32] * 8 + [ctypes.c_int]
+    E.jxlenc_set_layer.restype = None
+    try:
+        E.jxlenc_set_animation(1, 10, 1, 0, 0, 0)  # (multi-frame ...
+        E.jxlenc_set_layer(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)  # ... untimed: a frame header with is_last = false, no duration)
+        p = encode_rgb8(preview)
+        pframe = p[E.jxlenc_last_header_bytes():]
+        E.jxlenc_set_animation(0, 10, 1, 0, 0, 1)
+        E.jxlenc_set_preview(1, preview.shape[1], preview.shape[0])
+        m = encode_rgb8(img, **kw)
+        h = E.jxlenc_last_header_bytes()
+    finally:
+        E.jxlenc_set_animation(0, 10, 1, 0, 0, 1)
+        E.jxlenc_set_layer(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1)
+        E.jxlenc_set_preview(0, 0, 0)
+    return m[:h] + pframe + m[h:]
+
+
 def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=False, **kw):
     """Test aid: a reference-only frame holding `atlas` (HxWx3 uint8; coded as an XYB Modular frame like libjxl's patch
     frames, or as a VarDCT frame) kept in `slot`, then `img` coded with a patch dictionary. patches: list of dicts with

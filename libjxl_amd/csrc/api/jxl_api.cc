@@ -68,8 +68,26 @@ int jxlamd_frame_parse(const uint8_t* data, size_t size, JxlParallelRunner runne
   return jxlamd_frame_parse_at(data, size, 0, 0, runner, runner_opaque, out);
 }
 
+static int ParseFrameAt(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
+                        void* runner_opaque, bool allow_partial, JxlAmdFrame** out);
 int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
                           void* runner_opaque, JxlAmdFrame** out) {
+  return ParseFrameAt(data, size, frame_pos, frame_index, runner, runner_opaque, false, out);
+}
+int jxlamd_frame_parse_partial_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
+                                  void* runner_opaque, JxlAmdFrame** out, uint32_t* groups_present) {
+  const int r = ParseFrameAt(data, size, frame_pos, frame_index, runner, runner_opaque, true, out);
+  if (!r && groups_present) {
+    const std::vector<uint8_t>& a = (*out)->plan.group_absent;
+    uint32_t n = uint32_t((*out)->plan.dim.num_groups);
+    for (uint8_t v : a) n -= v ? 1 : 0;
+    *groups_present = n;
+  }
+  return r;
+}
+int jxlamd_frame_is_partial(const JxlAmdFrame* f) { return f && !f->plan.group_absent.empty() ? 1 : 0; }
+static int ParseFrameAt(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
+                        void* runner_opaque, bool allow_partial, JxlAmdFrame** out) {
   g_last_error.clear();
   if (!data || !out) {
     g_last_error = "invalid argument";
@@ -81,11 +99,18 @@ int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, si
     jxh::FrameParser parser(data, size);
     jxh::ImageHeader ih;
     size_t pos = parser.ParseImageHeader(&ih);
+    const bool first = !frame_pos || frame_pos == pos;
     if (frame_pos) {
       if (frame_pos < pos || frame_pos >= size) throw std::runtime_error("truncated frame");
       pos = frame_pos;
     }
-    parser.ParseFrame(pos, ih, &f->plan, MakeParallelFor(runner, runner_opaque), frame_index);
+    if (first && ih.have_preview) {  // decode.cc:1266-1268: the first frame is the preview, its default size the preview's
+      ih.xsize = ih.preview_xsize;   // (frame_header.h:450-463)
+      ih.ysize = ih.preview_ysize;
+    }
+    parser.ParseFrame(pos, ih, &f->plan, MakeParallelFor(runner, runner_opaque), frame_index, 0, allow_partial);
+    if (first && ih.have_preview && (f->plan.fh.frame_type != 0 || f->plan.fh.custom_size || f->plan.fh.blend.mode != 0))
+      throw std::runtime_error("invalid preview frame");  // frame_header.cc:224-227, 372-376
   } catch (const std::exception& e) {
     g_last_error = e.what();
     return 2;
@@ -240,6 +265,7 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.codestream = f->data;
   d.section_offset = P.section_offset.data();
   d.section_size = P.section_size.data();
+  d.group_absent = P.group_absent.empty() ? nullptr : P.group_absent.data();
   d.first_section_bit_offset = P.first_section_bit_offset;
   std::vector<JxlHipPassDesc> pd(P.passes.size());
   for (size_t p = 0; p < P.passes.size(); p++) {
@@ -383,12 +409,19 @@ int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos,
     jxh::FrameParser head(data, size);  // (signature / container + image header)
     jxh::ImageHeader ih;
     size_t pos = head.ParseImageHeader(&ih);
+    const bool first = !frame_pos || frame_pos == pos;
     if (frame_pos) {
       if (frame_pos < pos || frame_pos >= size) throw std::runtime_error("truncated frame");
       pos = frame_pos;
     }
+    if (first && ih.have_preview) {  // (the preview frame: see jxlamd_frame_parse_at)
+      ih.xsize = ih.preview_xsize;
+      ih.ysize = ih.preview_ysize;
+    }
     jxh::ModFrameParser parser(data, size);
     parser.ParseFrame(pos, ih, &f->plan, frame_index);
+    if (first && ih.have_preview && (f->plan.fh.frame_type != 0 || f->plan.fh.custom_size || f->plan.fh.blend.mode != 0))
+      throw std::runtime_error("invalid preview frame");
   } catch (const std::exception& e) {
     g_last_error = e.what();
     return 2;
@@ -657,6 +690,10 @@ struct JxlDecoderStruct {
   JxlHipContext* ctx = nullptr;
   // ---- settings
   bool keep_orientation = false, unpremul = false;
+  bool preview_frame = false;  // the current frame is the image's preview (decode.cc:1266-1268): its own events and buffer
+  bool got_preview = false;
+  bool frame_partial = false;  // d->frame was parsed from a prefix of its bytes (events only; see JxlDecoderFlushImage)
+  bool coalescing = true;  // JxlDecoderSetCoalescing: false = every regular frame is delivered by itself, unblended
   int want_linear = -1;  // JxlDecoderSetOutputColorProfile: -1 = as coded
   JxlCmsInterface cms{};
   bool have_cms = false;
@@ -733,6 +770,8 @@ void ResetState(JxlDecoder* d) {
   d->canvas_mode = false;
   d->frame_shown = true;
   d->frame_skipped = false;
+  d->frame_partial = false;
+  d->preview_frame = d->got_preview = false;
   d->visible_index = d->nonvisible_index = 0;
   d->error = false;
   d->have_ih = false;
@@ -742,6 +781,7 @@ void ResetState(JxlDecoder* d) {
   d->mt_run = nullptr;
   d->extra_out.clear();
   d->want_linear = -1;
+  d->coalescing = true;  // decode.cc:834
   d->bit_depth = JxlBitDepth{JXL_BIT_DEPTH_FROM_PIXEL_FORMAT, 0, 0};
 }
 JxlDecoderStatus Fail(JxlDecoder* d, const std::string& why) {
@@ -967,6 +1007,19 @@ void StoreExtraRow(const int32_t* src, size_t xs, uint32_t ch_bits, const JxlPix
 uint32_t UndoOrientation(const JxlDecoder* d) { return d->keep_orientation ? 1u : d->ih.orientation; }
 size_t OrientedXsize(const JxlDecoder* d) { return UndoOrientation(d) > 4 ? d->ih.ysize : d->ih.xsize; }
 size_t OrientedYsize(const JxlDecoder* d) { return UndoOrientation(d) > 4 ? d->ih.xsize : d->ih.ysize; }
+void Placement(const JxlDecoder* d, JxlAmdFramePlacement* p);
+// decode.cc:980-1001 GetCurrentDimensions: the image, or (coalescing off) the current frame's own upsampled size.
+void CurrentDimensions(const JxlDecoder* d, size_t* xs, size_t* ys) {
+  *xs = OrientedXsize(d);
+  *ys = OrientedYsize(d);
+  if ((!d->coalescing || d->preview_frame) && (d->frame || d->mframe)) {
+    JxlAmdFramePlacement p;
+    Placement(d, &p);
+    *xs = p.xsize;
+    *ys = p.ysize;
+    if (UndoOrientation(d) > 4) std::swap(*xs, *ys);
+  }
+}
 
 // Extra-channel planes take the same flips and transpose as the colour pixels (stage_write.cc:441-458, 664-699); the
 // colour writer does them on the device, these small integer planes are permuted while they are stored.
@@ -1236,6 +1289,7 @@ bool NextFrame(JxlDecoder* d) {
   if (d->mframe) jxlamd_modframe_free(d->mframe);
   d->frame = nullptr;
   d->mframe = nullptr;
+  d->frame_partial = false;
   d->frame_pos = end;
   d->frame_index++;
   d->stage = 2;
@@ -1271,7 +1325,8 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
   }
   for (;;) {
     if (d->stage == 2) {
-      if (!(d->events & (JXL_DEC_FRAME | JXL_DEC_FULL_IMAGE))) {
+      const bool is_preview = d->ih.have_preview && !d->got_preview;  // decode.cc:1266-1268: the codestream's first frame
+      if (!(d->events & (JXL_DEC_FRAME | JXL_DEC_FULL_IMAGE | (is_preview ? JXL_DEC_PREVIEW_IMAGE : 0)))) {
         d->stage = 6;
         return 1;
       }
@@ -1280,15 +1335,45 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
         r = jxlamd_modframe_parse_at(d->cs.p, d->cs.size, d->frame_pos, d->frame_index, &d->mframe);
       if (r) {
         const std::string w = g_last_error;
-        if (!d->cs_complete && w.find("truncated") != std::string::npos) return 0;
-        *ev = Fail(d, w);
-        return 2;
+        if (!d->cs_complete && w.find("truncated") != std::string::npos) {
+          // Not all of the frame is here. Once its DC image is (decode.cc:1431-1530 reaches FrameStage::kFull with a part
+          // of the sections), the frame is announced from that prefix: the caller may then ask for what there is with
+          // JxlDecoderFlushImage. Frames nobody is shown (layers, skipped frames) wait for all their bytes.
+          uint32_t present = 0;
+          if (is_preview || !(d->events & JXL_DEC_FULL_IMAGE) || d->skip_frames > 0 ||
+              jxlamd_frame_parse_partial_at(d->cs.p, d->cs.size, d->frame_pos, d->frame_index, d->runner, d->runner_opaque, &d->frame, &present))
+            return 0;
+          JxlAmdFramePlacement pp;
+          jxlamd_frame_placement(d->frame, &pp);
+          if (!(pp.is_last || pp.duration > 0 || (!d->coalescing && pp.frame_type == 0)) || (d->coalescing && (d->canvas_mode || NeedsCanvas(pp)))) {
+            jxlamd_frame_free(d->frame);
+            d->frame = nullptr;
+            return 0;
+          }
+          d->frame_partial = true;
+        } else {
+          *ev = Fail(d, w);
+          return 2;
+        }
+      }
+      if (is_preview) {  // decode.cc:1334-1343, 1448-1450, 1554-1559: no FRAME event; its own buffer request and event
+        d->frame_shown = false;  // (counted with the frames that are not shown: dec_frame.cc:160-168)
+        d->frame_skipped = false;
+        if (!(d->events & JXL_DEC_PREVIEW_IMAGE)) {
+          d->got_preview = true;
+          if (!NextFrame(d)) return 1;
+          continue;
+        }
+        d->preview_frame = true;
+        d->stage = 4;
+        continue;
       }
       d->stage = 3;
       JxlAmdFramePlacement pl;
       Placement(d, &pl);
-      d->frame_shown = pl.is_last || pl.duration > 0;  // decode.cc:1346-1350 is_last_of_still (coalescing)
-      if (NeedsCanvas(pl)) d->canvas_mode = true;
+      // decode.cc:1346-1354 is_last_of_still: ... or any regular frame when the caller wants the layers themselves
+      d->frame_shown = pl.is_last || pl.duration > 0 || (!d->coalescing && pl.frame_type == 0);
+      if (d->coalescing && NeedsCanvas(pl)) d->canvas_mode = true;
       d->frame_skipped = false;
       if (d->skip_frames > 0) {  // decode.cc:1359-1408
         d->frame_skipped = true;
@@ -1296,7 +1381,8 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
       }
       if (!d->frame_shown || d->frame_skipped) {
         // no events for it; its pixels are still needed when a later frame may be blended with them
-        if (d->canvas_mode && CanBeReferenced(pl) && (d->events & JXL_DEC_FULL_IMAGE)) {
+        // (coalescing off: nothing is blended, but the patches of later frames still read the reference-only frames)
+        if ((d->coalescing ? d->canvas_mode : pl.frame_type == 2) && CanBeReferenced(pl) && (d->events & JXL_DEC_FULL_IMAGE)) {
           const JxlDecoderStatus st = DecodePixels(d, true);
           if (st != JXL_DEC_SUCCESS) {
             *ev = st;
@@ -1320,8 +1406,37 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
     }
     if (d->stage == 4) {
       if (!d->have_out) {
-        *ev = JXL_DEC_NEED_IMAGE_OUT_BUFFER;
+        *ev = d->preview_frame ? JXL_DEC_NEED_PREVIEW_OUT_BUFFER : JXL_DEC_NEED_IMAGE_OUT_BUFFER;
         return 2;
+      }
+      if (d->preview_frame) {
+        *ev = DecodePixels(d, false);
+        if (*ev == JXL_DEC_FULL_IMAGE) {
+          *ev = JXL_DEC_PREVIEW_IMAGE;
+          d->got_preview = true;
+          d->preview_frame = false;
+          d->events &= ~JXL_DEC_PREVIEW_IMAGE;
+          d->have_out = false;
+          d->out_buf = nullptr;
+          d->callback = nullptr;
+          d->mt_run = nullptr;
+          if (!NextFrame(d)) d->stage = 6;
+        }
+        return 2;
+      }
+      if (d->frame_partial) {  // the frame was announced from a prefix: the pixels need all of it
+        uint32_t t[3];
+        if (d->cs.size < jxlamd_frame_end(d->frame, t) && !d->cs_complete) return 0;
+        JxlAmdFrame* whole = nullptr;
+        if (jxlamd_frame_parse_at(d->cs.p, d->cs.size, d->frame_pos, d->frame_index, d->runner, d->runner_opaque, &whole)) {
+          const std::string w = g_last_error;
+          if (!d->cs_complete && w.find("truncated") != std::string::npos) return 0;
+          *ev = Fail(d, w);
+          return 2;
+        }
+        jxlamd_frame_free(d->frame);
+        d->frame = whole;
+        d->frame_partial = false;
       }
       if (d->canvas_mode) {
         *ev = DecodePixels(d, true);
@@ -1393,8 +1508,9 @@ void JxlDecoderRewind(JxlDecoder* d) {
   const int ev = d->events;
   const JxlParallelRunner r = d->runner;
   void* ro = d->runner_opaque;
-  const bool ko = d->keep_orientation, up = d->unpremul, db = d->decompress_boxes;
+  const bool ko = d->keep_orientation, up = d->unpremul, db = d->decompress_boxes, co = d->coalescing;
   ResetState(d);
+  d->coalescing = co;
   d->events = ev;
   d->runner = r;
   d->runner_opaque = ro;
@@ -1410,7 +1526,7 @@ JxlDecoderStatus JxlDecoderSkipCurrentFrame(JxlDecoder* d) {
   if (!(d->stage >= 3 && d->stage < 5)) return JXL_DEC_ERROR;
   JxlAmdFramePlacement pl;
   Placement(d, &pl);
-  if (d->canvas_mode && CanBeReferenced(pl) && (d->events & JXL_DEC_FULL_IMAGE)) {
+  if ((d->coalescing ? d->canvas_mode : pl.frame_type == 2) && CanBeReferenced(pl) && (d->events & JXL_DEC_FULL_IMAGE)) {
     if (DecodePixels(d, true) != JXL_DEC_SUCCESS) return JXL_DEC_ERROR;
   }
   if (d->frame_shown) {  // (is_last_of_still: the output buffers belonged to this frame)
@@ -1448,8 +1564,14 @@ JxlDecoderStatus JxlDecoderSetUnpremultiplyAlpha(JxlDecoder* d, JXL_BOOL unpremu
   return JXL_DEC_SUCCESS;
 }
 JxlDecoderStatus JxlDecoderSetRenderSpotcolors(JxlDecoder* d, JXL_BOOL) { return d->stage == 0 ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
-// Frames are always delivered coalesced (the canvas); asking for the individual layers is refused rather than ignored.
-JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL coalescing) { return d->stage == 0 && coalescing ? JXL_DEC_SUCCESS : JXL_DEC_ERROR; }
+// decode.cc:973-979. Off: every regular frame is its own still (FRAME / NEED_IMAGE_OUT_BUFFER / FULL_IMAGE), delivered at
+// its own size without blending; JxlDecoderGetFrameHeader then reports its crop, blend mode and reference slot so that
+// the caller can compose (decode.cc:2725-2768).
+JxlDecoderStatus JxlDecoderSetCoalescing(JxlDecoder* d, JXL_BOOL coalescing) {
+  if (d->stage != 0) return JXL_DEC_ERROR;
+  d->coalescing = coalescing != 0;
+  return JXL_DEC_SUCCESS;
+}
 
 JxlDecoderStatus JxlDecoderSetInput(JxlDecoder* d, const uint8_t* data, size_t size) {
   if (d->in) return JXL_DEC_ERROR;
@@ -1517,6 +1639,11 @@ JxlDecoderStatus JxlDecoderGetBasicInfo(const JxlDecoder* d, JxlBasicInfo* info)
   if (info) {
     memset(info, 0, sizeof(*info));
     info->have_container = d->container == 1;
+    if (d->ih.have_preview) {  // decode.cc:2231, 2267-2269
+      info->have_preview = JXL_TRUE;
+      info->preview.xsize = d->ih.preview_xsize;
+      info->preview.ysize = d->ih.preview_ysize;
+    }
     info->xsize = uint32_t(OrientedXsize(d));
     info->ysize = uint32_t(OrientedYsize(d));
     info->bits_per_sample = d->ih.bits;
@@ -1674,9 +1801,34 @@ JxlDecoderStatus JxlDecoderGetFrameHeader(const JxlDecoder* d, JxlFrameHeader* h
     h->is_last = t[1] ? JXL_TRUE : JXL_FALSE;
     h->timecode = t[2];
     h->name_length = uint32_t(FrameName(d).size());
-    h->layer_info.xsize = uint32_t(OrientedXsize(d));  // decode.cc:2714-2722
-    h->layer_info.ysize = uint32_t(OrientedYsize(d));
+    size_t xs, ys;
+    CurrentDimensions(d, &xs, &ys);  // decode.cc:2714-2722
+    h->layer_info.xsize = uint32_t(xs);
+    h->layer_info.ysize = uint32_t(ys);
     h->layer_info.blend_info.blendmode = JXL_BLEND_REPLACE;
+    if (!d->coalescing) {  // decode.cc:2725-2768: the layer as coded
+      JxlAmdFramePlacement p;
+      Placement(d, &p);
+      if (p.custom_size) {
+        int64_t cx = p.x0, cy = p.y0;
+        const uint32_t orientation = UndoOrientation(d);
+        if (orientation != 1) {  // the crop offset in the oriented image
+          const int64_t W = int64_t(OrientedXsize(d)), H = int64_t(OrientedYsize(d));
+          if (orientation > 4) std::swap(cx, cy);
+          const uint32_t o = (orientation - 1) & 3;
+          if (o > 0 && o < 3) cx = W - int64_t(xs) - cx;
+          if (o > 1) cy = H - int64_t(ys) - cy;
+        }
+        h->layer_info.have_crop = JXL_TRUE;
+        h->layer_info.crop_x0 = int32_t(cx);
+        h->layer_info.crop_y0 = int32_t(cy);
+      }
+      h->layer_info.blend_info.blendmode = JxlBlendMode(p.mode);
+      h->layer_info.blend_info.source = p.source;
+      h->layer_info.blend_info.alpha = (d->frame ? d->frame->plan.fh : d->mframe->plan.fh).blend.alpha_channel;
+      h->layer_info.blend_info.clamp = p.clamp ? JXL_TRUE : JXL_FALSE;
+      h->layer_info.save_as_reference = p.save_as_reference;
+    }
   }
   return JXL_DEC_SUCCESS;
 }
@@ -1688,8 +1840,27 @@ JxlDecoderStatus JxlDecoderGetFrameName(const JxlDecoder* d, char* name, size_t 
   memcpy(name, n.c_str(), n.size() + 1);
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderPreviewOutBufferSize(const JxlDecoder*, const JxlPixelFormat*, size_t*) { return JXL_DEC_ERROR; }
-JxlDecoderStatus JxlDecoderSetPreviewOutBuffer(JxlDecoder*, const JxlPixelFormat*, void*, size_t) { return JXL_DEC_ERROR; }
+static JxlDecoderStatus CheckFormat(const JxlDecoder* d, const JxlPixelFormat* f);
+// decode.cc:2522-2562: the preview frame's own buffer, asked for with JXL_DEC_NEED_PREVIEW_OUT_BUFFER.
+JxlDecoderStatus JxlDecoderPreviewOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* f, size_t* size) {
+  if (CheckFormat(d, f) != JXL_DEC_SUCCESS || !size || !d->ih.have_preview) return JXL_DEC_ERROR;
+  size_t xs = d->ih.preview_xsize, ys = d->ih.preview_ysize;
+  if (UndoOrientation(d) > 4) std::swap(xs, ys);
+  *size = RowStride(*f, xs) * (ys - 1) + xs * f->num_channels * SampleBytes(f->data_type);
+  return JXL_DEC_SUCCESS;
+}
+JxlDecoderStatus JxlDecoderSetPreviewOutBuffer(JxlDecoder* d, const JxlPixelFormat* f, void* buffer, size_t size) {
+  size_t need = 0;
+  if (!d->preview_frame || d->got_preview) return JXL_DEC_ERROR;  // "No preview out buffer needed at this time"
+  if (JxlDecoderPreviewOutBufferSize(d, f, &need) != JXL_DEC_SUCCESS || !buffer || size < need) return JXL_DEC_ERROR;
+  d->fmt = *f;
+  d->out_buf = buffer;
+  d->out_size = size;
+  d->callback = nullptr;
+  d->mt_run = nullptr;
+  d->have_out = true;
+  return JXL_DEC_SUCCESS;
+}
 
 static JxlDecoderStatus CheckFormat(const JxlDecoder* d, const JxlPixelFormat* f) {
   if (!d->have_ih || !f) return JXL_DEC_ERROR;
@@ -1700,7 +1871,9 @@ static JxlDecoderStatus CheckFormat(const JxlDecoder* d, const JxlPixelFormat* f
 }
 JxlDecoderStatus JxlDecoderImageOutBufferSize(const JxlDecoder* d, const JxlPixelFormat* f, size_t* size) {
   if (CheckFormat(d, f) != JXL_DEC_SUCCESS || !size) return JXL_DEC_ERROR;
-  const size_t xs = OrientedXsize(d), ys = OrientedYsize(d);
+  if (!d->coalescing && (d->stage < 3 || d->stage > 4)) return JXL_DEC_ERROR;  // decode.cc:2438-2441: frame dimensions unknown
+  size_t xs, ys;
+  CurrentDimensions(d, &xs, &ys);
   *size = RowStride(*f, xs) * (ys - 1) + xs * f->num_channels * SampleBytes(f->data_type);
   return JXL_DEC_SUCCESS;
 }
@@ -1744,7 +1917,8 @@ JxlDecoderStatus JxlDecoderExtraChannelBufferSize(const JxlDecoder* d, const Jxl
   if (!d->have_ih || !f || !size || index >= d->ih.extra.size() || !KnownType(f->data_type)) return JXL_DEC_ERROR;
   JxlPixelFormat one = *f;
   one.num_channels = 1;  // decode.cc:2608-2625: the channel count of the format is ignored
-  const size_t xs = OrientedXsize(d), ys = OrientedYsize(d);
+  size_t xs, ys;
+  CurrentDimensions(d, &xs, &ys);
   *size = RowStride(one, xs) * (ys - 1) + xs * SampleBytes(f->data_type);
   return JXL_DEC_SUCCESS;
 }
@@ -1767,7 +1941,25 @@ JxlDecoderStatus JxlDecoderSetDecompressBoxes(JxlDecoder* d, JXL_BOOL decompress
 }
 JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder*, JxlProgressiveDetail) { return JXL_DEC_SUCCESS; }
 size_t JxlDecoderGetIntendedDownsamplingRatio(JxlDecoder*) { return 1; }
-JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder*) { return JXL_DEC_ERROR; }  // nothing is rendered before a frame is complete
+// decode.cc:2458-2475 / dec_frame.cc:735-795: what has arrived of the current frame, drawn into the caller's buffer. The
+// groups whose AC sections are whole are decoded; the others come from the DC image alone (the reference draws them with
+// zero passes: every AC coefficient 0). Possible between the frame's NEED_IMAGE_OUT_BUFFER and its FULL_IMAGE, once the
+// DC image is there (which is also when the frame is announced); JXL_DEC_ERROR = nothing was drawn, and is not fatal.
+JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* d) {
+  if (!d->have_out || d->stage != 4 || !d->frame || !d->frame_partial || d->canvas_mode || d->error) return JXL_DEC_ERROR;
+  JxlAmdFrame* now = nullptr;
+  uint32_t present = 0;
+  if (jxlamd_frame_parse_partial_at(d->cs.p, d->cs.size, d->frame_pos, d->frame_index, d->runner, d->runner_opaque, &now, &present))
+    return JXL_DEC_ERROR;
+  jxlamd_frame_free(d->frame);  // (the earlier prefix: its section pointers may refer to a buffer that has since grown)
+  d->frame = now;
+  const JxlDecoderStatus st = DecodePixels(d, false);
+  if (st != JXL_DEC_FULL_IMAGE) {
+    d->error = false;
+    return JXL_DEC_ERROR;
+  }
+  return JXL_DEC_SUCCESS;
+}
 JxlDecoderStatus JxlDecoderSetImageOutBitDepth(JxlDecoder* d, const JxlBitDepth* bd) {
   if (!bd || !d->have_out) return JXL_DEC_ERROR;
   const uint32_t max_bits = d->fmt.data_type == JXL_TYPE_UINT8 ? 8 : 16;

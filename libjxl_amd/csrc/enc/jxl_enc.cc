@@ -870,7 +870,11 @@ static bool WriteCropAndBlending(BitWriter& bw, uint32_t fw, uint32_t fh, bool h
   return (!L.enabled || L.mode == 0) && !partial;
 }
 static size_t g_last_header_bytes = 0;  // where the frame header of the last written stream starts
-static bool ExtraFields() { return g_orientation != 1 || (g_anim.enabled && g_anim.timed); }
+static struct {
+  bool enabled = false;
+  uint32_t xs = 0, ys = 0;
+} g_preview;  // jxlenc_set_preview: the image header announces a preview frame of this size (headers.cc:155-183 PreviewHeader)
+static bool ExtraFields() { return g_orientation != 1 || (g_anim.enabled && g_anim.timed) || g_preview.enabled; }
 // image_metadata.cc:283-300: extra_fields = orientation, no intrinsic size, no preview, animation (:235-250).
 static void WriteExtraFields(BitWriter& bw) {
   if (!ExtraFields()) {
@@ -879,7 +883,17 @@ static void WriteExtraFields(BitWriter& bw) {
   }
   bw.Write(1, 1);
   bw.Write(3, g_orientation - 1);
-  bw.Write(2, 0);  // no intrinsic size, no preview
+  bw.Write(1, 0);  // no intrinsic size
+  bw.Write(1, g_preview.enabled ? 1 : 0);
+  if (g_preview.enabled) {  // headers.cc:155-183, ratio 0 (both sides coded)
+    const bool div8 = g_preview.xs % 8 == 0 && g_preview.ys % 8 == 0;
+    static const uint32_t b8[4] = {0, 0, 5, 9}, o8[4] = {16, 32, 1, 33};
+    static const uint32_t b1[4] = {6, 8, 10, 12}, o1[4] = {1, 65, 321, 1345};
+    bw.Write(1, div8 ? 1 : 0);
+    WriteU32Sel(bw, div8 ? g_preview.ys / 8 : g_preview.ys, div8 ? b8 : b1, div8 ? o8 : o1);
+    bw.Write(3, 0);
+    WriteU32Sel(bw, div8 ? g_preview.xs / 8 : g_preview.xs, div8 ? b8 : b1, div8 ? o8 : o1);
+  }
   bw.Write(1, g_anim.enabled && g_anim.timed ? 1 : 0);
   if (g_anim.enabled && g_anim.timed) {
     static const uint32_t nb[4] = {0, 0, 10, 30}, no[4] = {100, 1000, 1, 1};
@@ -2537,6 +2551,12 @@ void jxlenc_set_embedded_icc(const uint8_t* coded, size_t n, size_t bits) {
 }
 
 // The next encoded streams declare this orientation (1..8, codestream_header.h:45-54; 1 = identity). Test aid, not thread-safe.
+// The next streams' image header announces a preview frame of xs x ys (enabled = 0: none again). Test aid, not thread-safe.
+void jxlenc_set_preview(int enabled, uint32_t xs, uint32_t ys) {
+  jxe::g_preview.enabled = enabled != 0;
+  jxe::g_preview.xs = xs;
+  jxe::g_preview.ys = ys;
+}
 void jxlenc_set_orientation(uint32_t orientation) { jxe::g_orientation = orientation >= 1 && orientation <= 8 ? orientation : 1; }
 
 // Spline dictionary of the next streams (n = 0: none again); layout at jxe::g_splines. Test aid, not thread-safe.

@@ -211,6 +211,8 @@ struct JxlHipContext {
   // Coefficient layout of this frame (see TransformParams::scan_order); scan order is produced by k_entropy_lanes.
   // band decode: groups this context decodes (band + one group row either side), pixel rows it produces
   std::vector<uint32_t> group_list;
+  std::vector<uint32_t> absent_groups;  // JxlHipFrameDesc::group_absent: drawn from the DC image alone
+  std::vector<uint32_t> absent_blocks;  // per absent group: first block, block count
   uint32_t band_y0 = 0, band_y1 = 0;
   // upsampled frames: factor (1 = none), image size, kernels
   uint32_t ups = 1, oxs = 0, oys = 0;
@@ -666,7 +668,16 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     c->band_y0 = rb * 256;
     c->band_y1 = re * 256 < d->ysize ? re * 256 : d->ysize;
     c->group_list.clear();
-    for (uint32_t g = ext_row0 * d->xsize_groups; g < ext_row1 * d->xsize_groups; g++) c->group_list.push_back(g);
+    c->absent_groups.clear();
+    for (uint32_t g = ext_row0 * d->xsize_groups; g < ext_row1 * d->xsize_groups; g++) {
+      if (d->group_absent && d->group_absent[g]) {
+        for (uint32_t p = 0; p < d->num_passes; p++)
+          if (d->section_size[size_t(p) * d->num_groups + g]) return JXLHIP_ERR_INVALID_ARGUMENT;
+        c->absent_groups.push_back(g);
+      } else {
+        c->group_list.push_back(g);
+      }
+    }
   }
   c->coef_bits = d->coef_bits;
   c->gab = d->gab; c->epf_iters = d->epf_iters;
@@ -994,6 +1005,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   for (uint32_t p = 0; c->lanes && p < d->num_passes; p++)  // (alias tables that do not fit LDS are read in place)
     c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64, false, c->lane_prefix).total <= kLdsBudget;
   if (!c->lanes) c->lane_prefix = false;
+  if (!c->absent_groups.empty() && !c->lanes) return JXLHIP_ERR_INVALID_ARGUMENT;  // (only the lane kernel takes a list of groups)
   c->scan_order = c->lanes && d->num_passes == 1;
   c->lane_multi = c->lanes && d->num_passes > 1;
   const size_t kend_per_pass = size_t(d->num_blocks ? d->num_blocks : 1) * 3;
@@ -1041,6 +1053,11 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     ep.block_recs = c->block_recs.as<uint32_t>();
   }
   lap("records");
+  c->absent_blocks.clear();
+  for (uint32_t g : c->absent_groups) {
+    c->absent_blocks.push_back(d->group_block_begin[g]);
+    c->absent_blocks.push_back(d->group_block_begin[g + 1] - d->group_block_begin[g]);
+  }
   if (c->scan_order) {
     c->blocks_host.assign(d->blocks, d->blocks + d->num_blocks);
     c->gbb_host.assign(d->group_block_begin, d->group_block_begin + d->num_groups + 1);
@@ -1817,6 +1834,7 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
     if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
     if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
     if (c->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (n > 1 && !c->absent_groups.empty()) return JXLHIP_ERR_INVALID_ARGUMENT;  // (partial frames go one at a time: jxlhip_run_entropy)
     if (!c->lanes || c->coef_bits != c0->coef_bits || c->lane_prefix != c0->lane_prefix) all_scan = false;
     if (c->lanes || c->generic_codec || !c->alias_lds || c->ep.num_hist != 1 || c->np != 1 || c->coef_bits != c0->coef_bits ||
         c->ng > 0xFFFF * kEntropyWPG || EntropyKernelChoice() == 0)
@@ -1900,9 +1918,30 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   return 0;
 }
 
+// Groups whose AC sections have not arrived (JxlHipFrameDesc::group_absent): no coefficients at all, so that the transform
+// stage draws their blocks from the lowest frequencies (the DC image) alone. Queued in front of the entropy launch.
+static int ZeroAbsentGroups(JxlHipContext* c) {
+  if (c->absent_groups.empty()) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t coef_group_bytes = size_t(3) * 65536 * (c->coef_bits / 8);
+  for (size_t i = 0; i < c->absent_groups.size(); i++) {
+    const uint32_t g = c->absent_groups[i], b0 = c->absent_blocks[2 * i], nb = c->absent_blocks[2 * i + 1];
+    HIP_TRY(hipMemsetAsync(c->coeffs.as<uint8_t>() + size_t(g) * coef_group_bytes, 0, coef_group_bytes, c->stream));
+    for (uint32_t p = 0; p < c->np && nb; p++)
+      HIP_TRY(hipMemsetAsync(c->kend.as<uint32_t>() + size_t(p) * c->ep.kend_pass_stride + size_t(b0) * 3, 0, size_t(nb) * 12, c->stream));
+  }
+  return 0;
+}
+
 extern "C" int jxlhip_run_entropy(JxlHipContext* c) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!c->have_frame) return JXLHIP_ERR_NO_FRAME;
+  const int r = ZeroAbsentGroups(c);
+  if (r) return r;
+  if (c->group_list.empty()) {  // (nothing but the DC image has arrived)
+    HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(c->ng) * 4, c->stream));
+    return 0;
+  }
   return c->lanes ? jxlhip_run_entropy_batch(&c, 1) : RunEntropySingle(c);
 }
 

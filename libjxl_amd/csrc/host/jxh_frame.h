@@ -90,6 +90,9 @@ struct FramePlan {
   // single-section frames: AC data starts mid-byte inside the one section
   uint32_t first_section_bit_offset = 0;
   size_t frame_end = 0;  // byte offset just after the frame
+  // A frame parsed from a prefix of its bytes (ParseFrame with allow_partial; dec_frame.cc:735-795 Flush): per group, 1 when
+  // one of its AC sections is not complete in the buffer. Such groups are rendered from their DC alone. Empty = whole frame.
+  std::vector<uint8_t> group_absent;
   size_t frame_index = 0, nonvisible_index = 0;  // shown frames before this one, invisible ones since (dec_frame.cc:160-168)
   // Extra channels (alpha, ...): Modular-coded beside the VarDCT colour (dec_frame.cc:511-542, dec_modular.cc:209-425).
   // `extra` is the frame's global Modular image; channels no larger than a group are complete after the DC global
@@ -159,7 +162,7 @@ class FrameParser {
   // they seed the noise). The plan is of the frame at its own size: where it sits on the canvas and how it blends with
   // a reference slot (fh.x0 / y0, fh.blend) is the caller's business (the decoder API composes on a JxlHipCanvas).
   void ParseFrame(size_t pos, const ImageHeader& ih, FramePlan* plan, const ParallelFor& pfor = SerialFor, size_t frame_index = 0,
-                  size_t nonvisible_index = 0) {
+                  size_t nonvisible_index = 0, bool allow_partial = false) {
     FramePlan& P = *plan;
     P.ih = ih;
     P.frame_index = frame_index;
@@ -187,7 +190,15 @@ class FrameParser {
     ReadToc(br, entries, &toc);
     JXH_CHECK(!br.Overread(), "truncated frame header");
     const size_t base = pos + br.BitPos() / 8;
-    JXH_CHECK(base + toc.total <= codestream_base_ + cs_size_, "truncated frame");
+    const size_t have = codestream_base_ + cs_size_;  // bytes of the buffer that belong to the codestream
+    bool partial = false;
+    if (base + toc.total > have) {
+      // A prefix of the frame: usable once the DC image and the AC global section are whole (FrameDecoder::HasDecodedDC,
+      // decode.cc:2464-2468). Frames in one section, and frames whose AC sections also carry extra-channel data, wait.
+      JXH_CHECK(allow_partial && entries > 1 && ih.extra.empty(), "truncated frame");
+      for (size_t i = 0; i < 2 + d.num_dc_groups; i++) JXH_CHECK(base + toc.offset[i] + toc.size[i] <= have, "truncated frame");
+      partial = true;
+    }
     P.frame_end = base + toc.total;
     const size_t xb = d.xsize_blocks, yb = d.ysize_blocks;
     P.dc.assign(3 * xb * yb, 0.0f);
@@ -256,6 +267,21 @@ class FrameParser {
           P.section_offset[p * d.num_groups + g] = base + toc.offset[i];
           P.section_size[p * d.num_groups + g] = toc.size[i];
         }
+      if (partial) {
+        P.group_absent.assign(d.num_groups, 0);
+        for (size_t p = 0; p < np; p++)
+          for (size_t g = 0; g < d.num_groups; g++) {
+            const size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
+            if (base + toc.offset[i] + toc.size[i] > have) {
+              P.group_absent[g] = 1;
+              P.section_offset[p * d.num_groups + g] = base;  // (never read; kept inside the buffer)
+              P.section_size[p * d.num_groups + g] = 0;
+            }
+          }
+        for (size_t g = 0; g < d.num_groups; g++)  // (a group is drawn from all of its passes or from none)
+          if (P.group_absent[g])
+            for (size_t p = 0; p < np; p++) P.section_size[p * d.num_groups + g] = 0;
+      }
     }
     BuildBlockLists(&P);
     if (!P.extra.ch.empty()) {

@@ -49,10 +49,18 @@ _DTYPES = {"rgb8": np.uint8, "rgbf": np.float32, "coeffs": np.int32, "nzeros": n
 
 
 class Decoded:
-    def __init__(self, data, dumps=True, frame=0):
+    def __init__(self, data, dumps=True, frame=0, prefix=0, preview=False):
+        """prefix: draw the frame from the first `prefix` bytes of the codestream alone (FrameDecoder::Flush: AC groups
+        whose sections are not whole inside the prefix keep all-zero coefficients); 0 = the whole stream."""
         L = lib()
         data = bytes(data)
-        self._h = L.jxlo_decode(data, len(data), (1 if dumps else 0) | frame << 8)
+        L.jxlo_set_flush_prefix.argtypes = [ctypes.c_size_t]
+        L.jxlo_set_flush_prefix.restype = None
+        L.jxlo_set_flush_prefix(prefix)
+        try:
+            self._h = L.jxlo_decode(data, len(data), (1 if dumps else 0) | (2 if preview else 0) | frame << 8)  # preview: the preview frame
+        finally:
+            L.jxlo_set_flush_prefix(0)
         err = L.jxlo_error(self._h)
         if err:
             msg = err.decode()

@@ -28,6 +28,7 @@
 #include "jxlo_vardct.h"
 
 namespace jxlo {
+static size_t g_flush_prefix = 0;  // jxlo_set_flush_prefix: bytes of the codestream that "have arrived" (0 = all)
 
 struct Decoded {
   ImageHeader ih;
@@ -541,6 +542,16 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       DecodeAcGlobal(r, s);
       check_section(r, "AC global");
     }
+    // A frame drawn from a prefix of its bytes (FrameDecoder::Flush, dec_frame.cc:735-795: the groups whose sections have
+    // not all arrived are drawn with zero passes, i.e. every AC coefficient 0; decode.cc:2458-2475 JxlDecoderFlushImage):
+    // g_flush_prefix = number of bytes of the codestream that are there; 0 = all.
+    std::vector<uint8_t> absent(d.num_groups, 0);
+    if (g_flush_prefix)
+      for (size_t p = 0; p < np; p++)
+        for (size_t g = 0; g < d.num_groups; g++) {
+          const size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
+          if (base + toc.offset[i] + toc.size[i] > g_flush_prefix) absent[g] = 1;
+        }
     for (size_t p = 0; p < np; p++) {
       // Downsampling bracket (frame_header.h:268-284) for streams without progressive-downsampling info:
       // the last pass carries shifts 0..2, earlier passes carry no Modular data.
@@ -551,6 +562,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       const bool parallel = !fh.modular && s->full.ch.empty();
 #pragma omp parallel for schedule(dynamic) if (parallel)
       for (size_t g = 0; g < d.num_groups; g++) {
+        if (absent[g]) continue;
         try {
           size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
           BitReader r(data + base + toc.offset[i], toc.size[i]);
@@ -752,7 +764,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     }
 }
 
-static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dumps, size_t frame_index = 0) {
+static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dumps, size_t frame_index = 0, bool want_preview = false) {
   // bare codestream, or a container whose first codestream box is `jxlc`
   static const uint8_t kContainer[12] = {0, 0, 0, 0xC, 'J', 'X', 'L', ' ', 0xD, 0xA, 0x87, 0xA};
   if (size >= 12 && !memcmp(data, kContainer, 12)) {
@@ -797,6 +809,21 @@ static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dum
   } slots[4];
   XybSlot xyb_slots[4];
   size_t visible = 0, nonvisible = 0;
+  JXLO_CHECK(!want_preview || ih.have_preview, "the image has no preview");
+  if (ih.have_preview) {
+    // The codestream's first frame is the preview (decode.cc:1266-1268): a regular frame whose default size is the
+    // preview size (frame_header.h:450-463), never blended (frame_header.cc:372-376), counted among the frames that are
+    // not shown (dec_frame.cc:160-168).
+    ImageHeader pih = ih;
+    pih.xsize = ih.preview_xsize;
+    pih.ysize = ih.preview_ysize;
+    DecodeFrame(br, pih, out, want_dumps && want_preview, visible, nonvisible, xyb_slots);
+    JXLO_CHECK(out->fh.frame_type == 0 && !out->fh.custom_size && out->fh.blend.mode == 0, "invalid preview frame");
+    if (want_preview) return;
+    nonvisible++;
+    *out = Decoded();
+    out->ih = ih;
+  }
   for (;;) {
     DecodeFrame(br, ih, out, want_dumps && visible == frame_index, visible, nonvisible, xyb_slots);
     const FrameHeader fh = out->fh;
@@ -928,10 +955,11 @@ struct JxloHandle {
 
 // flags: bit0 = keep intermediate dumps, bits 8.. = index of the frame to decode (animations). Returns a handle (never NULL);
 // check jxlo_error().
+void jxlo_set_flush_prefix(size_t nbytes) { jxlo::g_flush_prefix = nbytes; }
 JxloHandle* jxlo_decode(const uint8_t* data, size_t size, int flags) {
   JxloHandle* h = new JxloHandle;
   try {
-    jxlo::Decode(data, size, &h->d, (flags & 1) != 0, size_t(flags) >> 8);
+    jxlo::Decode(data, size, &h->d, (flags & 1) != 0, size_t(flags) >> 8, (flags & 2) != 0);
   } catch (const std::exception& e) {
     h->error = e.what();
     if (h->error.empty()) h->error = "unknown error";

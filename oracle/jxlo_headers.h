@@ -40,6 +40,8 @@ struct ImageHeader {
   int32_t white_xy[2] = {0, 0}, primaries_xy[6] = {0, 0, 0, 0, 0, 0};
   bool linear_tf = false;  // output transfer function: false = sRGB, true = linear
   bool want_icc = false;   // an ICC profile is embedded (the oracle skips it: it only checks pixels)
+  bool have_preview = false;
+  uint32_t preview_xsize = 0, preview_ysize = 0;
   bool have_animation = false, have_timecodes = false;
   uint32_t anim_tps_num = 0, anim_tps_den = 0, anim_loops = 0;  // AnimationHeader (image_metadata.cc:235-250)
   float intensity_target = 255.0f;
@@ -187,7 +189,17 @@ static inline void ReadImageHeader(BitReader& br, ImageHeader* h) {
         (void)ys;
       }
       have_preview = br.ReadBool();
-      JXLO_CHECK(!have_preview, "unsupported: preview frame");
+      if (have_preview) {  // headers.cc:155-183 PreviewHeader; the preview is the codestream's first frame, of this size
+        const bool div8 = br.ReadBool();
+        auto dim = [&]() {
+          return div8 ? ReadU32(br, Val(16), Val(32), BitsOffset(5, 1), BitsOffset(9, 33)) * 8
+                      : ReadU32(br, BitsOffset(6, 1), BitsOffset(8, 65), BitsOffset(10, 321), BitsOffset(12, 1345));
+        };
+        h->preview_ysize = dim();
+        const uint32_t ratio = uint32_t(br.Read(3));
+        h->preview_xsize = ratio == 0 ? dim() : AspectRatioX(h->preview_ysize, ratio);
+        h->have_preview = true;
+      }
       h->have_animation = br.ReadBool();
       if (h->have_animation) {
         h->anim_tps_num = ReadU32(br, Val(100), Val(1000), BitsOffset(10, 1), BitsOffset(30, 1));

@@ -58,7 +58,12 @@ int main(int argc, char** argv) {
   if (!strcmp(argv[3], "u16")) format.data_type = JXL_TYPE_UINT16;
   if (!strcmp(argv[3], "f16")) format.data_type = JXL_TYPE_FLOAT16;
   if (!strcmp(argv[3], "f32")) format.data_type = JXL_TYPE_FLOAT;
-  int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0, multi = 0, frames_done = 0, swap = 0;
+  int use_callback = 0, use_mt = 0, linear = 0, keep = 0, want_ec = 0, multi = 0, frames_done = 0, swap = 0, layers = 0;
+  uint32_t cur_w = 0, cur_h = 0; /* size of the frame being delivered: the image, or (layers) the frame's own */
+  uint8_t* preview_pixels = NULL;
+  size_t preview_bytes = 0;
+  int nopreview = 0; /* nopreview: do not subscribe to JXL_DEC_PREVIEW_IMAGE (the preview frame is stepped over) */
+  int flush = 0, in_frame = 0, flushes = 0; /* flush: JxlDecoderFlushImage whenever the decoder runs out of input inside a frame */
   size_t skip = 0;
   long skipcur = -1; /* skipcur=K: JxlDecoderSkipCurrentFrame at the FRAME event of the K-th frame that has one */
   long frame_events = 0;
@@ -71,11 +76,14 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "linear")) linear = 1;
     if (!strcmp(argv[i], "swap")) swap = 1; /* hand the input back and in again after every frame (decode.h: JxlDecoderReleaseInput) */
     if (!strcmp(argv[i], "frames")) multi = 1; /* animation: every frame's pixels are appended to the output file */
+    if (!strcmp(argv[i], "layers")) layers = multi = 1; /* JxlDecoderSetCoalescing(false): every regular frame by itself */
     if (!strncmp(argv[i], "skip=", 5)) skip = (size_t)atol(argv[i] + 5); /* JxlDecoderSkipFrames before decoding */
     if (!strncmp(argv[i], "skipcur=", 8)) skipcur = atol(argv[i] + 8);
     if (!strcmp(argv[i], "keep")) keep = 1; /* the pixels as coded, the orientation left to the caller */
     if (!strcmp(argv[i], "ec")) want_ec = 1; /* also fetch every extra channel into its own buffer (jxl.cc:571-590) */
     if (!strncmp(argv[i], "chunk=", 6)) chunk = (size_t)atol(argv[i] + 6);
+    if (!strcmp(argv[i], "flush")) flush = 1;
+    if (!strcmp(argv[i], "nopreview")) nopreview = 1;
   }
   if (JxlSignatureCheck(bytes, size) == JXL_SIG_INVALID) return 2;
   JxlMemoryManager mm = {NULL, CountingAlloc, CountingFree};
@@ -84,11 +92,12 @@ int main(int argc, char** argv) {
   if (!dec || !runner) return 2;
   if (JxlDecoderSetParallelRunner(dec, JxlThreadParallelRunner, runner) != JXL_DEC_SUCCESS) return 2;
   int events = JXL_DEC_BASIC_INFO | JXL_DEC_FULL_IMAGE | JXL_DEC_COLOR_ENCODING | JXL_DEC_FRAME | JXL_DEC_PREVIEW_IMAGE | JXL_DEC_BOX;
+  if (nopreview) events &= ~JXL_DEC_PREVIEW_IMAGE;
   if (JxlDecoderSubscribeEvents(dec, events) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetRenderSpotcolors(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetKeepOrientation(dec, keep ? JXL_TRUE : JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetUnpremultiplyAlpha(dec, JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
-  if (JxlDecoderSetCoalescing(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
+  if (JxlDecoderSetCoalescing(dec, layers ? JXL_FALSE : JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetDecompressBoxes(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (skip) JxlDecoderSkipFrames(dec, skip);
   /* input in one piece, or in chunks the way a streaming caller feeds it (decode.h: unprocessed bytes are re-supplied) */
@@ -108,6 +117,19 @@ int main(int argc, char** argv) {
       rc = JxlDecoderGetFrameHeader(dec, &fh) == JXL_DEC_SUCCESS && g_pixels ? 3 : 1;
       break;
     } else if (st == JXL_DEC_NEED_MORE_INPUT) {
+      if (flush && in_frame) { /* decode.h: between the frame's output buffer and its FULL_IMAGE */
+        if (JxlDecoderFlushImage(dec) == JXL_DEC_SUCCESS) {
+          char name[1024];
+          FILE* o;
+          snprintf(name, sizeof(name), "%s.flush%d", argv[2], flushes);
+          o = fopen(name, "wb");
+          fwrite(g_pixels, 1, g_stride * cur_h, o);
+          fclose(o);
+          printf("flushed %d bytes_given=%zu\n", flushes++, consumed + given);
+        } else {
+          printf("flush refused bytes_given=%zu\n", consumed + given);
+        }
+      }
       size_t left = JxlDecoderReleaseInput(dec);
       consumed += given - left;
       if (consumed + left >= size) {
@@ -182,6 +204,12 @@ int main(int argc, char** argv) {
       if (JxlDecoderGetFrameName(dec, name, sizeof(name)) != JXL_DEC_SUCCESS) return 2;
       printf("event FRAME %ux%u last=%d downsampling=%zu\n", fh.layer_info.xsize, fh.layer_info.ysize, fh.is_last,
              JxlDecoderGetIntendedDownsamplingRatio(dec));
+      cur_w = layers ? fh.layer_info.xsize : info.xsize;
+      cur_h = layers ? fh.layer_info.ysize : info.ysize;
+      if (layers)
+        printf("layer crop=%d x0=%d y0=%d blend=%d source=%u alpha=%u clamp=%d save_as=%u\n", fh.layer_info.have_crop, fh.layer_info.crop_x0,
+               fh.layer_info.crop_y0, (int)fh.layer_info.blend_info.blendmode, fh.layer_info.blend_info.source, fh.layer_info.blend_info.alpha,
+               fh.layer_info.blend_info.clamp, fh.layer_info.save_as_reference);
       if (info.have_animation)
         printf("animation tps=%u/%u loops=%u duration=%u timecode=%u\n", info.animation.tps_numerator, info.animation.tps_denominator,
                info.animation.num_loops, fh.duration, fh.timecode);
@@ -193,11 +221,13 @@ int main(int argc, char** argv) {
       size_t buffer_size = 0;
       if (JxlDecoderImageOutBufferSize(dec, &format, &buffer_size) != JXL_DEC_SUCCESS) return 2;
       g_bpp = format.num_channels * (format.data_type == JXL_TYPE_UINT8 ? 1 : (format.data_type == JXL_TYPE_FLOAT ? 4 : 2));
-      g_stride = (size_t)info.xsize * g_bpp;
-      if (buffer_size != g_stride * info.ysize) return 2;
+      if (!cur_w) { cur_w = info.xsize; cur_h = info.ysize; } /* (no FRAME event subscribed / delivered) */
+      g_stride = (size_t)cur_w * g_bpp;
+      if (buffer_size != g_stride * cur_h) return 2;
       free(g_pixels);
       g_pixels = (uint8_t*)calloc(buffer_size, 1);
       printf("event NEED_IMAGE_OUT_BUFFER size=%zu\n", buffer_size);
+      in_frame = 1;
       if (use_mt) {
         if (JxlDecoderSetMultithreadedImageOutCallback(dec, &format, MtInit, MtRun, MtDestroy, &info) != JXL_DEC_SUCCESS) return 2;
       } else if (use_callback) {
@@ -211,17 +241,34 @@ int main(int argc, char** argv) {
         size_t ec_size = 0;
         if (JxlDecoderExtraChannelBufferSize(dec, &format, &ec_size, i) != JXL_DEC_SUCCESS) return 2;
         if (want_ec && i < 4) {
-          if (ec_size != (size_t)info.xsize * info.ysize * (g_bpp / format.num_channels)) return 2;
+          if (ec_size != (size_t)cur_w * cur_h * (g_bpp / format.num_channels)) return 2;
           ec_pixels[i] = (uint8_t*)calloc(ec_size, 1);
           ec_sizes[i] = ec_size;
           if (JxlDecoderSetExtraChannelBuffer(dec, &format, ec_pixels[i], ec_size, i) != JXL_DEC_SUCCESS) return 2;
         }
       }
+    } else if (st == JXL_DEC_NEED_PREVIEW_OUT_BUFFER) { /* jxl.cc:300-320: the preview frame has a buffer of its own */
+      size_t preview_size = 0;
+      if (JxlDecoderPreviewOutBufferSize(dec, &format, &preview_size) != JXL_DEC_SUCCESS) return 2;
+      free(preview_pixels);
+      preview_pixels = (uint8_t*)calloc(preview_size, 1);
+      preview_bytes = preview_size;
+      printf("event NEED_PREVIEW_OUT_BUFFER size=%zu preview=%ux%u\n", preview_size, info.preview.xsize, info.preview.ysize);
+      if (JxlDecoderSetPreviewOutBuffer(dec, &format, preview_pixels, preview_size) != JXL_DEC_SUCCESS) return 2;
+    } else if (st == JXL_DEC_PREVIEW_IMAGE) {
+      char name[1024];
+      FILE* o;
+      printf("event PREVIEW_IMAGE\n");
+      snprintf(name, sizeof(name), "%s.preview", argv[2]);
+      o = fopen(name, "wb");
+      fwrite(preview_pixels, 1, preview_bytes, o);
+      fclose(o);
     } else if (st == JXL_DEC_FULL_IMAGE) {
       printf("event FULL_IMAGE\n");
+      in_frame = 0;
       if (multi && g_pixels) {
         FILE* o = fopen(argv[2], frames_done ? "ab" : "wb");
-        fwrite(g_pixels, 1, g_stride * info.ysize, o);
+        fwrite(g_pixels, 1, g_stride * cur_h, o);
         fclose(o);
         frames_done++;
       }
@@ -254,6 +301,7 @@ int main(int argc, char** argv) {
       if (ec_pixels[i]) fwrite(ec_pixels[i], 1, ec_sizes[i], o);
     fclose(o);
   }
+  free(preview_pixels);
   if (use_mt) printf("mt init=%d destroy=%d\n", g_mt_inits, g_mt_destroys);
   JxlDecoderDestroy(dec);
   JxlThreadParallelRunnerDestroy(runner);

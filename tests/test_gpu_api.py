@@ -291,3 +291,63 @@ def test_orientation_is_undone_by_the_pixel_writer(built, tmp_path, orientation)
         assert rc == 0 and "event BASIC_INFO %ux%u " % (xs, ys) in out and "orientation=%d" % orientation in out, out
         got = np.frombuffer(px, np.uint8).reshape(ys, xs, 4)
         assert np.abs(got.astype(int) - coded8.astype(int)).max() <= (0 if name == "lossless" else 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("passes", [1, 2])
+def test_flush_image_draws_what_has_arrived(built, tmp_path, passes):
+    """JxlDecoderFlushImage (decode.cc:2458-2475, FrameDecoder::Flush dec_frame.cc:735-795): with a part of the frame's
+    bytes, the groups whose AC sections are whole are decoded and the others are drawn from the DC image alone (zero
+    passes). Expectation: the oracle told to use the same prefix of the codestream. The input comes in chunks; every time the
+    decoder runs out inside the frame the replay program flushes and keeps the buffer."""
+    import os
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(1100, 800, seed=9), num_passes=passes)  # 5 x 4 groups
+    chunk = len(data) // 7
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3, "flush", "chunk=%d" % chunk)
+    assert rc == 0 and events.count("FULL_IMAGE") == 1, out
+    final = np.frombuffer(px, np.uint8).reshape(800, 1100, 3)
+    o = jxlo.Decoded(data, dumps=False)
+    assert np.abs(final.astype(int) - o.rgb8.astype(int)).max() <= 1
+    o.close()
+    flushed = [l for l in out.splitlines() if l.startswith("flushed ")]
+    assert len(flushed) >= 3, out  # (the frame header, TOC and DC image fit the first chunks; several chunks of AC follow)
+    partial_seen = 0
+    for line in flushed:
+        k, given = int(line.split()[1]), int(line.split("bytes_given=")[1])
+        got = np.fromfile(os.path.join(str(tmp_path), "out.raw.flush%d" % k), np.uint8).reshape(800, 1100, 3)
+        want = jxlo.Decoded(data, dumps=False, prefix=given)
+        d = np.abs(got.astype(int) - want.rgb8.astype(int))
+        want.close()
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, line
+        if np.abs(got.astype(int) - final.astype(int)).max() > 8:
+            partial_seen += 1  # (this flush really lacked groups)
+    assert partial_seen >= 2
+    # without a buffer, outside a frame, or with everything there, nothing is flushed (and nothing breaks)
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3, "flush")
+    assert rc == 0 and "flushed" not in out
+
+
+@pytest.mark.gpu
+def test_preview_frame_through_the_decoder_api(built, tmp_path):
+    """JXL_DEC_PREVIEW_IMAGE (decode.cc:1326-1343, 1448-1450, 1554-1559, 2522-2562): the preview has its own buffer request
+    and event, no FRAME event, and is stepped over when nobody subscribed to it."""
+    import os
+    import jxlo
+    J = built
+    img, pv = J.synth_image(600, 400, seed=3), J.synth_image(75, 50, seed=4)
+    data = J.encode_with_preview(img, pv)
+    want_pv = jxlo.Decoded(data, dumps=False, preview=True).rgb8
+    want = jxlo.Decoded(data, dumps=False).rgb8
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3)
+    assert rc == 0, out
+    assert [e for e in events if e not in ("BASIC_INFO", "COLOR_ENCODING")] == [
+        "NEED_PREVIEW_OUT_BUFFER", "PREVIEW_IMAGE", "FRAME", "NEED_IMAGE_OUT_BUFFER", "FULL_IMAGE", "SUCCESS"], out
+    assert "size=%d preview=75x50" % (75 * 50 * 3) in out
+    got_pv = np.fromfile(os.path.join(str(tmp_path), "out.raw.preview"), np.uint8).reshape(50, 75, 3)
+    assert np.abs(got_pv.astype(int) - want_pv.astype(int)).max() <= 1
+    assert np.abs(np.frombuffer(px, np.uint8).reshape(400, 600, 3).astype(int) - want.astype(int)).max() <= 1
+    rc, events, out, px = R.run(R.container(data), tmp_path, "u8", 3, "nopreview", "chunk=3000")
+    assert rc == 0 and "PREVIEW_IMAGE" not in events and events.count("FULL_IMAGE") == 1, out
+    assert np.abs(np.frombuffer(px, np.uint8).reshape(400, 600, 3).astype(int) - want.astype(int)).max() <= 1

@@ -524,3 +524,22 @@ def test_halo_exchange_schedule_gloo(built, tmp_path, world):
     assert all(p.returncode == 0 for p in procs), outs
     for r in range(world):
         assert "HALO %d True" % r in outs[r], outs[r]
+
+
+def test_oracle_and_host_read_a_preview_frame(built):
+    """The image header's PreviewHeader (headers.cc:155-183) and the preview as the codestream's first frame, sized by it
+    (frame_header.h:450-463, decode.cc:1266-1268): oracle and host front-end, no GPU."""
+    import jxlo
+    J = built
+    img, pv = J.synth_image(600, 400, seed=3), J.synth_image(75, 50, seed=4)
+    for preview in (pv, J.synth_image(80, 48, seed=5)):  # (sizes coded directly, and as multiples of 8)
+        data = J.encode_with_preview(img, preview)
+        o = jxlo.Decoded(data, dumps=False, preview=True)
+        assert o.rgb8.shape == preview.shape and np.abs(o.rgb8.astype(int) - preview).mean() < 6
+        o.close()
+        o = jxlo.Decoded(data, dumps=False)
+        assert o.rgb8.shape == img.shape and np.abs(o.rgb8.astype(int) - img).mean() < 4
+        o.close()
+        f = J.Frame(data)  # the first frame of the codestream: the preview
+        assert (f.info["xsize"], f.info["ysize"]) == (preview.shape[1], preview.shape[0])
+        f.close()

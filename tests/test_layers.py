@@ -165,3 +165,39 @@ def test_reference_alpha_blending_vectors_on_the_kernel(built):
     assert np.abs(o[:3] - 2500).max() < 0.05
     o = blend([100, 100, 100, 1], [25, 25, 25, 1], 4, 0, 0, 1)
     assert np.abs(o[:3] - 100).max() < 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lossless", [True, False])
+def test_layers_delivered_one_by_one_without_coalescing(built, tmp_path, lossless):
+    """JxlDecoderSetCoalescing(false) (decode.cc:973-979, 1350-1354, 2725-2768): every regular frame is a still of its own
+    size, unblended, and its frame header carries the crop, the blend mode, the source slot and the slot it is saved to;
+    the buffer sizes follow the frame (decode.cc:980-1001). Lossless layers come back as the arrays that were coded."""
+    J = built
+    base, opaque, patch, ramp = _parts(J)
+    layers = [dict(img=np.dstack([base, opaque]), save_as=1),
+              dict(img=np.dstack([patch, ramp]), x0=-10, y0=100, mode=2, alpha_mode=2, source=1, save_as=2),
+              dict(img=np.dstack([patch[::-1].copy(), ramp]), x0=150, y0=20, mode=3, alpha_mode=3, source=2, clamp=1)]
+    data = J.encode_layers(layers, lossless=lossless)  # (the writer gives every layer an explicit size and origin)
+    rc, events, out, px = R.run(data, tmp_path, "u8", 4, "layers")
+    assert rc == 0 and [e for e in events if e in ("FRAME", "FULL_IMAGE")] == ["FRAME", "FULL_IMAGE"] * 3, out
+    heads = [l for l in out.splitlines() if l.startswith("layer ")]
+    assert heads == ["layer crop=1 x0=0 y0=0 blend=0 source=0 alpha=0 clamp=0 save_as=1",
+                     "layer crop=1 x0=-10 y0=100 blend=2 source=1 alpha=0 clamp=0 save_as=2",
+                     "layer crop=1 x0=150 y0=20 blend=3 source=2 alpha=0 clamp=1 save_as=0"], out
+    sizes = [l.split()[2] for l in out.splitlines() if l.startswith("event FRAME")]
+    assert sizes == ["%dx%d" % (W, H), "80x60", "80x60"], out
+    pos = 0
+    for k, layer in enumerate(layers):
+        h, w = layer["img"].shape[:2]
+        got = np.frombuffer(px[pos:pos + h * w * 4], np.uint8).reshape(h, w, 4)
+        pos += h * w * 4
+        if lossless:
+            assert np.array_equal(got, layer["img"]), k
+        else:  # VarDCT colour at d1.0, lossless alpha
+            assert np.array_equal(got[..., 3], layer["img"][..., 3]), k
+            assert np.abs(got[..., :3].astype(int) - layer["img"][..., :3].astype(int)).mean() < 4.0, k
+    assert pos == len(px)
+    # the same stream coalesced is one still of the canvas size
+    rc, events, out, px = R.run(data, tmp_path, "u8", 4)
+    assert rc == 0 and events.count("FULL_IMAGE") == 1 and len(px) == W * H * 4
