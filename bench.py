@@ -675,8 +675,16 @@ def main():
         if three:
             # three independent launches: the planes `ent` got from its transform in the previous step are filtered (on its
             # second stream) while its next coefficients are decoded and the other set is transformed
-            J.run_filter_color_batch(ent)
-            J.run_entropy_batch(ent)
+            # The entropy launch must find the chip's LDS free (EntropyGate in jxl_hip_api.hip): the transform launch of the
+            # other set, enqueued behind it, is held back by the library until the entropy workgroups are resident. Same
+            # box, same call (GP/s): filter, entropy, transform 70.4 / 70.0 with the gate, 62.4 / 69.6 without (two modes:
+            # in the bad one the entropy launch takes 153 ms); entropy, filter, transform 65.6 / 65.0 (BENCH_ORDER=efd).
+            if os.environ.get("BENCH_ORDER", "fed") == "efd":  # measurement aid
+                J.run_entropy_batch(ent)
+                J.run_filter_color_batch(ent)
+            else:
+                J.run_filter_color_batch(ent)
+                J.run_entropy_batch(ent)
             J.run_transform_batch(down)
             exchange_halos(down)
             return ent

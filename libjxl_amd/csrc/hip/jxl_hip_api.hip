@@ -280,6 +280,8 @@ struct JxlHipContext {
   hipStream_t stream2 = nullptr;
   hipStream_t fstream = nullptr;  // stream of the filter launch in progress (set by BeginDownstreamBatch)
   hipEvent_t fork_event = nullptr, filter_done = nullptr, filter_wait = nullptr;
+  hipEvent_t transform_done = nullptr;  // filter_async: end of the set's last batched transform launch on `stream`
+  bool transform_done_valid = false;
   JxlHipContext* plane_lender = nullptr;
   hipEvent_t planes_event = nullptr;
   hipStream_t planes_stream = nullptr;
@@ -474,6 +476,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->batch_done) (void)hipEventDestroy(c->batch_done);
   if (c->down_done) (void)hipEventDestroy(c->down_done);
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
+  if (c->transform_done) (void)hipEventDestroy(c->transform_done);
   if (c->filter_done) (void)hipEventDestroy(c->filter_done);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -1452,6 +1455,59 @@ static int EnsureOwnStream(JxlHipContext* c) {
   return 0;
 }
 
+// A batched entropy launch must get the machine FIRST. Its workgroups are few (one per frame), long-lived and large in LDS
+// (37 - 54 KB: 640 of them take 84 % of the chip's LDS); when a transform launch of another frame set is already streaming
+// its small workgroups through the CUs, the entropy workgroups find no CU with that much LDS free and trickle in only as the
+// other launch drains: 133 ms per launch instead of 62 ms (scripts/r03_interference.py; 80 ms behind a filter launch,
+// which holds registers, not LDS). Arriving first it loses nothing to the same neighbours (62 ms). So: every workgroup of a
+// batched entropy launch counts itself in when it starts, and the batched transform / filter launches enqueued after it,
+// on whatever stream, wait (hipStreamWaitValue64, a wait packet in their own queue) until that count says the whole
+// entropy launch is resident. The counter only grows: a launch's target is the running total after it.
+struct EntropyGate {
+  unsigned long long* counter = nullptr;  // device memory (hipMallocSignalMemory)
+  unsigned long long total = 0;           // workgroups of every launch so far
+  unsigned long long target = 0;          // count at which the latest launch is resident
+  bool tried = false;
+};
+static std::mutex g_gate_mu;
+static EntropyGate g_gate[16];
+// the counter the next batched entropy launch of `device` counts into (NULL: gating unavailable or switched off)
+static unsigned long long* GateCounter(int device) {
+  if (device < 0 || device >= 16 || !EnvInt("JXLHIP_ENTROPY_GATE", 1)) return nullptr;
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  EntropyGate& g = g_gate[device];
+  if (!g.tried) {
+    g.tried = true;
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can) {
+      void* p = nullptr;
+      if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess && hipMemset(p, 0, 8) == hipSuccess)
+        g.counter = static_cast<unsigned long long*>(p);
+    }
+    (void)hipGetLastError();
+  }
+  return g.counter;
+}
+static void GateAdvance(int device, unsigned long long workgroups, unsigned long long resident_cap) {
+  std::lock_guard<std::mutex> lk(g_gate_mu);
+  EntropyGate& g = g_gate[device];
+  g.target = g.total + (workgroups < resident_cap ? workgroups : resident_cap);
+  g.total += workgroups;
+}
+static int GateWait(int device, hipStream_t stream) {
+  if (device < 0 || device >= 16) return 0;
+  unsigned long long* counter;
+  unsigned long long target;
+  {
+    std::lock_guard<std::mutex> lk(g_gate_mu);
+    counter = g_gate[device].counter;
+    target = g_gate[device].target;
+  }
+  if (!counter || !target) return 0;
+  HIP_TRY(hipStreamWaitValue64(stream, counter, target, hipStreamWaitValueGte, ~0ull));
+  return 0;
+}
+
 static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_stage = false) {
   if (!ctxs || !n) return JXLHIP_ERR_INVALID_ARGUMENT;
   JxlHipContext* c0 = ctxs[0];
@@ -1473,10 +1529,21 @@ static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filte
       HIP_TRY(hipEventCreateWithFlags(&c0->filter_done, hipEventDisableTiming));
     }
     ls = c0->stream2;
-    HIP_TRY(hipEventRecord(c0->fork_event, c0->stream));  // after everything the first stream holds (the transform)
-    HIP_TRY(hipStreamWaitEvent(ls, c0->fork_event, 0));
+    if (c0->transform_done_valid) {
+      // after the set's transform launch, NOT after whatever the first stream has been given since: the caller may
+      // already have queued the set's next entropy launch there (which must reach the machine before this launch does:
+      // see EntropyGate), and the filter stage has nothing to do with it
+      HIP_TRY(hipStreamWaitEvent(ls, c0->transform_done, 0));
+    } else {
+      HIP_TRY(hipEventRecord(c0->fork_event, c0->stream));  // after everything the first stream holds
+      HIP_TRY(hipStreamWaitEvent(ls, c0->fork_event, 0));
+    }
   }
   c0->fstream = ls;
+  if (n > 1) {  // (see EntropyGate)
+    const int r = GateWait(c0->device, ls);
+    if (r) return r;
+  }
   hipEvent_t waited = nullptr;
   for (size_t i = 0; i < n; i++)
     if (ctxs[i]->pending_wait) {
@@ -1517,6 +1584,11 @@ static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_
     HIP_TRY(hipEventRecord(c0->down_done, c0->stream));
     done = c0->down_done;
     for (size_t i = 1; i < n; i++) ctxs[i]->pending_wait = done;
+  }
+  if (!filter_stage && c0->filter_async) {
+    if (!c0->transform_done) HIP_TRY(hipEventCreateWithFlags(&c0->transform_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c0->transform_done, c0->stream));
+    c0->transform_done_valid = true;
   }
   if (shared && filter_stage)
     for (size_t i = 0; i < n; i++) {
@@ -1566,6 +1638,7 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
   b.wave_log_ls = c0->batch_wave_ls.as<uint8_t>();
   b.debug = uint32_t(EnvInt("JXLHIP_LANES_DEBUG", 0));
   b.prof = nullptr;
+  b.started = c0->batch_ctxs.size() > 1 ? GateCounter(c0->device) : nullptr;
   const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
   const size_t nwaves = size_t(c0->batch_wgs) * WPG;
   if (prof) {
@@ -1574,6 +1647,12 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
   }
   hipLaunchKernelGGL(k, dim3(c0->batch_wgs), dim3(64 * WPG), c0->batch_lds, c0->stream, b);
   HIP_TRY(hipGetLastError());
+  if (b.started) {
+    // "resident" = as many of its workgroups as the chip's LDS holds at once, less a margin (the rest start as the first
+    // ones end, and are not waited for)
+    const unsigned long long per_cu = c0->batch_lds ? (160 * 1024) / c0->batch_lds : 8, cap = 256 * (per_cu ? per_cu : 1) * 3 / 4;
+    GateAdvance(c0->device, c0->batch_wgs, cap);
+  }
   if (prof) {
     std::vector<unsigned long long> h(nwaves * 8);
     HIP_TRY(hipStreamSynchronize(c0->stream));
@@ -1878,6 +1957,21 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
       waited = ctxs[i]->pending_wait;
       ctxs[i]->pending_wait = nullptr;
     }
+  // Measurement aid (JXLHIP_SERIAL_ENTROPY=1): batched entropy launches of one device one after the other, whatever
+  // streams they are on.
+  static std::mutex serial_mu;
+  static hipEvent_t serial_tail[16] = {};
+  // MEASURED WORSE, hence off: alone beside the other sets' transform / filter launches for its whole length, a launch
+  // takes 112 - 126 ms (77 - 82 ms when two entropy launches overlap part of the time; 62 ms with nothing beside it):
+  // the lone waves lose far more to issue-bound neighbours on their SIMDs than to each other. s_setprio does not help.
+  const bool serial = n > 1 && c0->device >= 0 && c0->device < 16 && EnvInt("JXLHIP_SERIAL_ENTROPY", 0) != 0;
+  std::unique_lock<std::mutex> serial_lock(serial_mu, std::defer_lock);  // (held from the wait to the record: host threads)
+  if (serial) {
+    serial_lock.lock();
+    hipEvent_t& tail = serial_tail[c0->device];
+    if (!tail) HIP_TRY(hipEventCreateWithFlags(&tail, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(c0->stream, tail, 0));
+  }
   lap("waits");
   HIP_TRY(hipEventRecord(c0->ev[0], c0->stream));
   for (size_t i = 0; i < n; i++)  // (the lane kernel writes every section's flag word itself, unless passes share it)
@@ -1908,6 +2002,7 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
   if (prof) fprintf(stderr, "[entropy batch] %s\n", prof_line.c_str());
   HIP_TRY(hipEventRecord(c0->ev[1], c0->stream));
   c0->ev_valid[0] = true;
+  if (serial) HIP_TRY(hipEventRecord(serial_tail[c0->device], c0->stream));
   if (n > 1) {
     HIP_TRY(hipEventRecord(c0->batch_done, c0->stream));
     for (size_t i = 1; i < n; i++) {

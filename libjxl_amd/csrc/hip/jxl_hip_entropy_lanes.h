@@ -63,6 +63,8 @@ struct EntropyLaneBatch {
                                 // cost of one wave); bit 7 clear = rows of its own, column l
   uint32_t debug;               // measurement aid: bit 0 = skip the coefficient stores (results are then invalid),
                                 // bit 1 = report every section's coefficient-token count in its error word
+  unsigned long long* started;  // optional (may be NULL): every workgroup adds 1 when it begins (the host gates other launches on
+                                // "all of this launch's workgroups hold their LDS": jxl_hip_api.hip EntropyGate)
   unsigned long long* prof;     // optional (may be NULL): per wave {cycles total, cycles in service, services, hot trips,
                                 // lane-trips taken, 0, 0, 0}
 };
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   extern __shared__ __align__(16) uint8_t lds_raw[];
   if (B_.prio) __builtin_amdgcn_s_setprio(3);
   const uint32_t tid = threadIdx.x, lane = tid & 63;
+  if (B_.started && tid == 0) __hip_atomic_fetch_add(B_.started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- the launch description and the frame's parameter block, through the scalar cache into SGPRs
   typedef const uint32_t __attribute__((address_space(4)))* CU32;
