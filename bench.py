@@ -96,6 +96,8 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
     parse_threads = 1  # one frame per thread: frames in parallel, not DC groups in parallel
     parsers = max(1, min(64, int(round(ncpu_eff)) - 2))
     movers = 4 if ncpu_eff >= 8 else (2 if ncpu_eff >= 4 else 1)  # threads of the upload pool and of the download pool
+    movers = int(os.environ.get("JXLAMD_E2E_MOVERS", movers))  # (measurement aid)
+    parsers = int(os.environ.get("JXLAMD_E2E_PARSERS", parsers))
     nsets = 4  # one being uploaded, two on the GPU (the entropy launch of one beside the transform / filter of the other), one downloading
     sets = [[J.HipContext(device) for _ in range(chunk)] for _ in range(nsets)]
     try:

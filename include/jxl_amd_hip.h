@@ -168,6 +168,18 @@ typedef struct JxlHipFrameDesc {
    * per group, non-zero = the group's AC sections are missing. Such a group is not entropy-decoded (its section sizes must
    * be 0); its blocks are rendered from the DC image alone, as the reference draws them with zero passes. */
   const uint8_t* group_absent;
+  /* The block-resolution stencils of the DC path on the device (lib/jxl/compressed_dc.cc:130-198 AdaptiveDCSmoothing,
+   * lib/jxl/epf.cc:39-81 ComputeSigma), so that the host front-end does no per-block float work:
+   *  dc_smoothing != 0: `dc` is the dequantised DC image BEFORE smoothing; the upload smooths it (dc_step = the DC
+   *    quantisation step of X, Y, B, i.e. inv_global_scale / quant_dc * dc_quant[c]). 0: `dc` is used as it is (a caller
+   *    that holds libjxl's own state passes its smoothed image, or the frame has kSkipAdaptiveDCSmoothing).
+   *  inv_sigma == NULL and epf_iters > 0: 1 / sigma per block is computed by the upload from `sharpness` (one byte 0..7 per
+   *    block, row-major like `dc`), the varblocks' qf, quant_scale (= global_scale / 65536), epf_quant_mul and epf_sharp_lut. */
+  uint32_t dc_smoothing;
+  float dc_step[3];
+  const uint8_t* sharpness;
+  float quant_scale, epf_quant_mul;
+  float epf_sharp_lut[8];
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);

@@ -353,6 +353,8 @@ class HipContext:
         if name == "coeffs":
             dt = np.int16 if fi["coef_bits"] == 16 else np.int32
             return buf.view(dt).reshape(fi["num_groups"], 3, 65536)
+        if name in ("dc", "inv_sigma"):  # block-resolution planes as the transform / filter stages read them
+            return buf.view(np.float32)
         return buf.view(np.float32).reshape(3, fi["ysize_blocks"] * 8, fi["xsize_blocks"] * 8)
 
 

@@ -308,7 +308,13 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   memcpy(d.dequant_offset, P.dequant_offset, sizeof(d.dequant_offset));
   memcpy(d.dequant_size, P.dequant_size, sizeof(d.dequant_size));
   d.dc = P.dc.data();
-  d.inv_sigma = P.inv_sigma.data();
+  d.dc_smoothing = P.dc_smoothing ? 1 : 0;  // smoothing and 1 / sigma are computed by the upload (csrc/hip/jxl_hip_dc.h)
+  memcpy(d.dc_step, P.dc_step, sizeof(d.dc_step));
+  d.inv_sigma = nullptr;
+  d.sharpness = P.sharpness.data();
+  d.quant_scale = float(P.global_scale) * (1.0f / 65536.0f);
+  d.epf_quant_mul = P.fh.lf.epf_quant_mul;
+  memcpy(d.epf_sharp_lut, P.fh.lf.epf_sharp_lut, sizeof(d.epf_sharp_lut));
   d.ytox = P.ytox.data();
   d.ytob = P.ytob.data();
   d.inv_global_scale = P.inv_global_scale;

@@ -23,6 +23,7 @@
 #include "jxl_hip_modular.h"
 #include "jxl_hip_enc.h"
 #include "jxl_hip_canvas.h"
+#include "jxl_hip_dc.h"
 
 namespace {
 #include "../host/afv_basis.inc"
@@ -173,6 +174,7 @@ struct JxlHipContext {
   float epf_pass0 = 0.9f, epf_pass2 = 6.5f, epf_border = 2.0f / 3;
   // buffers
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
+  Buf dc_raw, sharp;  // inputs of the DC-path kernels (jxl_hip_dc.h) when the upload smooths the DC image / computes 1 / sigma
   Buf plane[3], rgb, tlist, scratch, sec_end, lz_window;
   bool generic_codec = false;  // a pass is prefix-coded or uses LZ77 (k_entropy_generic decodes the frame unless lane_prefix)
   bool lane_prefix = false;    // every pass is prefix-coded without LZ77: the lane kernel's prefix form decodes the frame
@@ -450,7 +452,7 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
 }
 
 static std::vector<Buf*> AllBufs(JxlHipContext* c) {
-  std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc,
+  std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc, &c->dc_raw, &c->sharp,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
@@ -609,11 +611,21 @@ static int BlobBegin(JxlHipContext* c, size_t bound) {
   c->blob_mode = true;
   return 0;
 }
-static int BlobEnd(JxlHipContext* c) {
+// `smooth` / `sigma`: the DC-path kernels of this frame (NULL = not asked for), launched on the copy stream behind the copy
+// they read, so that the event the upload waits for covers them too.
+static int BlobEnd(JxlHipContext* c, const jxlhip::DcSmoothParams* smooth = nullptr, const jxlhip::SigmaParams* sigma = nullptr) {
   c->blob_mode = false;
   hipStream_t cs = CopyStream(c->device);
   if (!cs) cs = c->stream;
   if (c->stage.used) HIP_TRY(hipMemcpyAsync(c->frame_blob.p, c->stage.p, c->stage.used, hipMemcpyHostToDevice, cs));
+  if (smooth) {
+    hipLaunchKernelGGL(jxlhip::k_dc_smooth, dim3((smooth->xs + 63) / 64, (smooth->ys + 3) / 4), dim3(256), 0, cs, *smooth);
+    HIP_TRY(hipGetLastError());
+  }
+  if (sigma && sigma->num_blocks) {
+    hipLaunchKernelGGL(jxlhip::k_epf_sigma, dim3((sigma->num_blocks + 255) / 256), dim3(256), 0, cs, *sigma);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(c->stage.done, cs));
   c->stage.recorded = true;
   return 0;
@@ -726,7 +738,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     const size_t nblk_b = size_t(d->xsize_blocks) * d->ysize_blocks, ntiles_b = size_t((d->xsize_blocks + 7) / 8) * ((d->ysize_blocks + 7) / 8);
     add(total + 256); add(nsec * 4); add(nsec * 4);
     add(size_t(d->num_blocks) * sizeof(JxlHipVarBlock)); add((size_t(d->num_groups) + 1) * 4); add(d->block_ctx_lut_size);
-    add(size_t(d->dequant_floats) * 4); add(nblk_b * 12); add(nblk_b * 4); add(ntiles_b); add(ntiles_b);
+    add(size_t(d->dequant_floats) * 4); add(nblk_b * 12); add(nblk_b * 4); add(nblk_b); add(ntiles_b); add(ntiles_b);
     for (uint32_t p = 0; p < d->num_passes; p++) {
       const JxlHipPassDesc& q = d->passes[p];
       if (q.num_clusters > 256 || (!q.use_prefix && q.log_alpha > 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -781,8 +793,42 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = Upload(c, c->bctx_lut, d->block_ctx_lut, d->block_ctx_lut_size))) return r;
   if ((r = Upload(c, c->dequant, d->dequant, size_t(d->dequant_floats) * 4))) return r;
   const size_t nblk = size_t(c->xb) * c->yb;
-  if ((r = Upload(c, c->dc, d->dc, nblk * 3 * 4))) return r;
-  if ((r = Upload(c, c->inv_sigma, d->inv_sigma, nblk * 4))) return r;
+  // DC image and 1 / sigma: final as handed over, or finished on the device (jxl_hip_dc.h) behind the table copy
+  jxlhip::DcSmoothParams smooth_p;
+  jxlhip::SigmaParams sigma_p;
+  const bool dev_smooth = d->dc_smoothing != 0 && c->xb > 2 && c->yb > 2;  // (compressed_dc.cc:134: smaller images are left alone)
+  const bool dev_sigma = !d->inv_sigma && d->epf_iters > 0;
+  if (!d->dc || (dev_sigma && !d->sharpness)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (dev_smooth) {
+    for (int ch = 0; ch < 3; ch++)
+      if (!(d->dc_step[ch] > 0.0f)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if ((r = Upload(c, c->dc_raw, d->dc, nblk * 3 * 4))) return r;
+    if ((r = c->dc.Ensure(nblk * 3 * 4))) return r;
+    smooth_p.in = c->dc_raw.as<float>();
+    smooth_p.out = c->dc.as<float>();
+    smooth_p.xs = c->xb;
+    smooth_p.ys = c->yb;
+    for (int ch = 0; ch < 3; ch++) smooth_p.step[ch] = d->dc_step[ch];
+  } else if ((r = Upload(c, c->dc, d->dc, nblk * 3 * 4))) {
+    return r;
+  }
+  if (dev_sigma) {
+    if (!(d->quant_scale > 0.0f)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if ((r = Upload(c, c->sharp, d->sharpness, nblk))) return r;
+    if ((r = c->inv_sigma.Ensure(nblk * 4))) return r;
+    sigma_p.blocks = c->blocks.as<JxlHipVarBlock>();
+    sigma_p.num_blocks = d->num_blocks;
+    sigma_p.xb = c->xb;
+    sigma_p.sharpness = c->sharp.as<uint8_t>();
+    sigma_p.inv_sigma = c->inv_sigma.as<float>();
+    sigma_p.quant_scale = d->quant_scale;
+    sigma_p.epf_quant_mul = d->epf_quant_mul;
+    memcpy(sigma_p.sharp_lut, d->epf_sharp_lut, sizeof(sigma_p.sharp_lut));
+  } else if (d->inv_sigma) {
+    if ((r = Upload(c, c->inv_sigma, d->inv_sigma, nblk * 4))) return r;
+  } else if ((r = c->inv_sigma.Ensure(nblk * 4))) {  // (no EPF: never read)
+    return r;
+  }
   const size_t ntiles = size_t((c->xb + 7) / 8) * ((c->yb + 7) / 8);
   if ((r = Upload(c, c->ytox, d->ytox, ntiles))) return r;
   if ((r = Upload(c, c->ytob, d->ytob, ntiles))) return r;
@@ -1156,7 +1202,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->epf_pass2 = d->epf_pass2_sigma_scale;
   c->epf_border = d->epf_border_sad_mul;
   c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = false;
-  if ((r = BlobEnd(c))) return r;  // (records the staging block's event on the copy stream)
+  if ((r = BlobEnd(c, dev_smooth ? &smooth_p : nullptr, dev_sigma ? &sigma_p : nullptr))) return r;  // (records the staging block's event on the copy stream)
   // The tables are resident when the call returns (batch launches over this context run on other contexts' streams).
   // (Leaving the copies of many contexts in flight at once instead, ordered by events, made every later kernel of the
   // process ~1.35x slower on this runtime: scripts/async_probe.py.)
@@ -3070,6 +3116,12 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
   } else if (n == "xyb_idct") {
     src = PlaneHolder(c)->plane[0].p;
     bytes = plane_bytes;
+  } else if (n == "dc") {  // the DC image the transform stage reads (after smoothing): [3][yb][xb]
+    src = c->dc.p;
+    bytes = size_t(c->xb) * c->yb * 12;
+  } else if (n == "inv_sigma") {
+    src = c->inv_sigma.p;
+    bytes = size_t(c->xb) * c->yb * 4;
   } else if (n == "xyb_filtered") {
     if (!c->keep_filtered || !c->plane[1].p) return JXLHIP_ERR_INVALID_ARGUMENT;  // needs jxlhip_set_option("keep_filtered", 1)
     src = c->plane[1].p;

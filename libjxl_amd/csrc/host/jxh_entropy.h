@@ -527,6 +527,59 @@ class SymbolReader {
   uint32_t Read(size_t ctx) { return ReadClustered(c_->ctx_map[ctx]); }
   bool FinalStateOk() const { return state_ == (kAnsSignature << 16); }
 
+  // `n` values of one clustered context in a row, handed to sink(i, value) in order. rANS codes without LZ77 run with the
+  // state and the bit position in locals and ONE unaligned 8-byte load per value (a value consumes at most 16 bits of
+  // state refill + 32 extra bits out of the >= 57 the load provides), both conditionals as selects: the chain per value is
+  // load -> alias entry -> multiply, not the byte-wise Peek of the general reader. Values the loads cannot cover (the last
+  // eight bytes of the section) and every other kind of code go through ReadClustered. Same values, same final position.
+  template <class Sink>
+  void ReadRun(size_t cluster, size_t n, Sink&& sink) {
+    size_t i = 0;
+    if (!c_->lz77 && !c_->use_prefix && n) {
+      const uint8_t* const data = br_->data();
+      const size_t size = br_->size();
+      size_t pos = br_->BitPos();
+      uint32_t state = state_;
+      const int log_entry = kAnsLogTab - int(c_->log_alpha);
+      const uint32_t pos_mask = (1u << log_entry) - 1;
+      const AliasEntry* const tab = c_->alias.data() + (cluster << c_->log_alpha);
+      const HybridCfg cfg = c_->cfg[cluster];
+      const uint32_t in_token = cfg.msb + cfg.lsb, lsb_mask = (1u << cfg.lsb) - 1, msb_mask = (1u << cfg.msb) - 1;
+      while (i < n && (pos >> 3) + 8 <= size) {
+        uint64_t w;
+        memcpy(&w, data + (pos >> 3), 8);
+        w >>= (pos & 7);
+        const uint32_t res = state & (kAnsTab - 1);
+        const uint32_t slot = res >> log_entry, p = res & pos_mask;
+        const AliasEntry e = tab[slot];
+        const bool right = p >= e.cutoff;
+        const uint32_t token = right ? e.right_value : slot;
+        const uint32_t off = right ? e.offsets1 + p : p;
+        const uint32_t freq = right ? e.freq1 : e.freq0;
+        state = freq * (state >> kAnsLogTab) + off;
+        const bool refill = state < (1u << 16);
+        const uint32_t refilled = (state << 16) | uint32_t(w & 0xFFFF);
+        state = refill ? refilled : state;
+        const unsigned adv = refill ? 16u : 0u;
+        w >>= adv;
+        uint32_t value = token;
+        unsigned nbits = 0;
+        if (token >= cfg.split_token) {
+          nbits = (cfg.split_exp - in_token + ((token - cfg.split_token) >> in_token)) & 31;
+          const uint32_t low = token & lsb_mask, hi = (token >> cfg.lsb) & msb_mask;
+          const uint64_t bits = w & ((uint64_t(1) << nbits) - 1);
+          value = uint32_t((((((uint64_t(1) << cfg.msb) | hi) << nbits) | bits) << cfg.lsb) | low);
+        }
+        pos += adv + nbits;
+        sink(i, value);
+        i++;
+      }
+      state_ = state;
+      br_->Skip(pos - br_->BitPos());
+    }
+    for (; i < n; i++) sink(i, ReadClustered(cluster));
+  }
+
  private:
   static uint32_t SpecialDistance(uint32_t index, int mult) {
     static const int8_t kSD[120][2] = {

@@ -58,9 +58,13 @@ struct FramePlan {
   float inv_global_scale = 1.0f, x_dm = 1.0f, b_dm = 1.0f;
   float color_scale = 1.0f / 84, base_corr_x = 0.0f, base_corr_b = 1.0f;
   // block-resolution planes (xsize_blocks x ysize_blocks)
-  std::vector<float> dc;            // 3 planes X, Y, B after adaptive smoothing
+  // The two stencils over these planes, adaptive DC smoothing (compressed_dc.cc:130-198) and the EPF's 1 / sigma per
+  // block (epf.cc:39-81), run on the device inside the upload (csrc/hip/jxl_hip_dc.h): the plan carries their inputs.
+  std::vector<float> dc;            // 3 planes X, Y, B, dequantised, BEFORE adaptive smoothing
+  bool dc_smoothing = false;        // the frame asks for the smoothing (no kSkipAdaptiveDCSmoothing)
+  float dc_step[3] = {1, 1, 1};     // DC quantisation step per channel (the smoothing measures its gap in steps)
   std::vector<uint8_t> acs;         // (strategy << 1) | is_first
-  std::vector<float> inv_sigma;     // EPF 1/sigma per block
+  std::vector<uint8_t> sharpness;   // EPF sharpness 0..7 per block
   std::vector<int8_t> ytox, ytob;   // per 64x64 tile
   // varblocks
   std::vector<VarBlock> blocks;             // all groups concatenated, decode order inside each group
@@ -203,11 +207,10 @@ class FrameParser {
     const size_t xb = d.xsize_blocks, yb = d.ysize_blocks;
     P.dc.assign(3 * xb * yb, 0.0f);
     P.acs.assign(xb * yb, 0xFF);
-    P.inv_sigma.assign(xb * yb, 0.0f);
     P.ytox.assign(DivCeil(xb, 8) * DivCeil(yb, 8), 0);
     P.ytob.assign(P.ytox.size(), 0);
     quant_.assign(xb * yb, 0);
-    sharp_.assign(xb * yb, 0);
+    P.sharpness.assign(xb * yb, 0);
     quant_dc_ctx_.assign(xb * yb, 0);
 
     P.section_offset.assign(d.num_groups * np, 0);
@@ -483,7 +486,7 @@ class FrameParser {
           size_t x = bx0 + ix;
           int sh = img.ch[3].Row(iy)[ix];
           JXH_CHECK(sh >= 0 && sh < 8, "corrupted sharpness field");
-          sharp_[y * xb + x] = uint8_t(sh);
+          P->sharpness[y * xb + x] = uint8_t(sh);
           if (P->acs[y * xb + x] != 0xFF) continue;
           JXH_CHECK(num < count, "AC metadata: too few strategies");
           int raw = r1[num];
@@ -512,50 +515,11 @@ class FrameParser {
     __atomic_fetch_or(&P->used_acs, used, __ATOMIC_RELAXED);
   }
 
+  // What the device needs to finish the DC path (smoothing and 1 / sigma are kernels: see FramePlan::dc).
   void FinalizeDc(FramePlan* P) {
-    const FrameDim& d = P->dim;
-    const size_t xs = d.xsize_blocks, ys = d.ysize_blocks, plane = xs * ys;
-    const LoopFilter& lf = P->fh.lf;
-    if (lf.epf_iters > 0) {
-      const float kInvSigmaNum = -1.1715728752538099024f;
-      const float quant_scale = float(P->global_scale) * (1.0f / 65536.0f);
-      for (size_t by = 0; by < ys; by++)
-        for (size_t bx = 0; bx < xs; bx++) {
-          uint8_t a = P->acs[by * xs + bx];
-          if (!(a & 1)) continue;
-          int st = a >> 1;
-          float sigma_quant = lf.epf_quant_mul / (quant_scale * float(quant_[by * xs + bx]) * kInvSigmaNum);
-          for (size_t iy = 0; iy < kCoveredY[st]; iy++)
-            for (size_t ix = 0; ix < kCoveredX[st]; ix++) {
-              float sigma = sigma_quant * lf.epf_sharp_lut[sharp_[(by + iy) * xs + bx + ix]];
-              sigma = std::min(-1e-4f, sigma);
-              P->inv_sigma[(by + iy) * xs + bx + ix] = 1.0f / sigma;
-            }
-        }
-    }
-    if (!(P->fh.flags & FrameHeader::kSkipDcSmoothing) && xs > 2 && ys > 2) {
-      const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
-      float dcf[3];
-      for (int c = 0; c < 3; c++) dcf[c] = inv_quant_dc * dq_.dc_quant[c];
-      const float w1 = 0.20345139757231578f, w2 = 0.0334829185968739f, w0 = 1.0f - 4.0f * (w1 + w2);
-      std::vector<float> sm(P->dc);
-      for (size_t y = 1; y + 1 < ys; y++)
-        for (size_t x = 1; x + 1 < xs; x++) {
-          float mc[3], smv[3], gap = 0.5f;
-          for (int c = 0; c < 3; c++) {
-            const float* p = P->dc.data() + plane * c;
-            const float *t = p + (y - 1) * xs, *m = p + y * xs, *b = p + (y + 1) * xs;
-            float corner = (t[x - 1] + t[x + 1]) + (b[x - 1] + b[x + 1]);
-            float side = (m[x - 1] + m[x + 1]) + (t[x] + b[x]);
-            mc[c] = m[x];
-            smv[c] = corner * w2 + (side * w1 + mc[c] * w0);
-            gap = std::max(gap, std::fabs((mc[c] - smv[c]) / dcf[c]));
-          }
-          float factor = std::max(0.0f, -4.0f * gap + 3.0f);
-          for (int c = 0; c < 3; c++) sm[plane * c + y * xs + x] = (smv[c] - mc[c]) * factor + mc[c];
-        }
-      P->dc.swap(sm);
-    }
+    const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
+    for (int c = 0; c < 3; c++) P->dc_step[c] = inv_quant_dc * dq_.dc_quant[c];
+    P->dc_smoothing = !(P->fh.flags & FrameHeader::kSkipDcSmoothing);
   }
 
   void AcGlobal(BitReader& br, FramePlan* P) {
@@ -683,7 +647,7 @@ class FrameParser {
   std::mutex extra_mu_;
   int32_t ytox_dc_ = 0, ytob_dc_ = 0;
   std::vector<uint16_t> quant_;
-  std::vector<uint8_t> sharp_, quant_dc_ctx_;
+  std::vector<uint8_t> quant_dc_ctx_;
 };
 
 }  // namespace jxh

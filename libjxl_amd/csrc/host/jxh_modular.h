@@ -218,7 +218,7 @@ static inline void DecodeLeafChannel(SymbolReader& rd, size_t cluster, const Tre
   const int64_t offset = leaf.offset, mul = int64_t(leaf.multiplier);
   for (size_t y = 0; y < c.h; y++) {
     int32_t* p = c.Row(y);
-    for (size_t x = 0; x < c.w; x++) {
+    rd.ReadRun(cluster, c.w, [&](size_t x, uint32_t v) {
       const int32_t* pp = p + x;
       const int64_t left = x ? pp[-1] : (y ? pp[-stride] : 0);
       const int64_t top = y ? pp[-stride] : left;
@@ -228,9 +228,8 @@ static inline void DecodeLeafChannel(SymbolReader& rd, size_t cluster, const Tre
       const int64_t toptop = y > 1 ? pp[-2 * stride] : top;
       const int64_t toprightright = (x + 2 < c.w && y) ? pp[2 - stride] : topright;
       const int64_t guess = offset + PredictOne(predictor, left, top, toptop, topleft, topright, leftleft, toprightright, 0);
-      const uint32_t v = rd.ReadClustered(cluster);
       p[x] = int32_t(int64_t(UnpackSigned(v)) * mul + guess);
-    }
+    });
   }
 }
 

@@ -35,6 +35,8 @@ def lib():
         L.jxlo_animation.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.jxlo_out_size.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
         L.jxlo_free.argtypes = [ctypes.c_void_p]
+        L.jxlo_dc_params.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.jxlo_dc_params.restype = None
         L.jxlo_set_threads.argtypes = [ctypes.c_int]
         L.jxlo_set_threads.restype = ctypes.c_int
         _lib = L
@@ -45,7 +47,8 @@ INFO = ("xsize", "ysize", "channels", "modular", "xsize_blocks", "ysize_blocks",
         "num_groups", "num_dc_groups", "epf_iters", "gab", "num_passes", "used_acs", "bits", "ac_symbols")
 _DTYPES = {"rgb8": np.uint8, "rgbf": np.float32, "coeffs": np.int32, "nzeros": np.int32, "xyb_idct": np.float32,
            "xyb_filtered": np.float32, "dc": np.float32, "acs": np.uint8, "quant": np.int32, "sharpness": np.uint8,
-           "ytox": np.int8, "ytob": np.int8, "inv_sigma": np.float32, "quant_dc": np.uint8, "modular": np.int32}
+           "ytox": np.int8, "ytob": np.int8, "inv_sigma": np.float32, "quant_dc": np.uint8, "modular": np.int32,
+           "dc_unsmoothed": np.float32}
 
 
 class Decoded:
@@ -77,6 +80,14 @@ class Decoded:
         L.jxlo_animation(self._h, a)
         self.animation = dict(zip(("have_animation", "tps_numerator", "tps_denominator", "num_loops", "duration", "is_last", "timecode"),
                                   list(a)))
+
+    @property
+    def dc_params(self):
+        """Scalars of the DC path: the three DC quantisation steps, quant_scale, epf_quant_mul, epf_sharp_lut[8]."""
+        a = (ctypes.c_float * 13)()
+        lib().jxlo_dc_params(self._h, a)
+        v = [float(x) for x in a]
+        return {"dc_step": v[0:3], "quant_scale": v[3], "epf_quant_mul": v[4], "epf_sharp_lut": v[5:13]}
 
     def buffer(self, name):
         n = ctypes.c_size_t()

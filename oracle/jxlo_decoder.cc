@@ -46,6 +46,9 @@ struct Decoded {
   std::vector<float> xyb_idct;     // 3 planes, ysize_padded x xsize_padded (storage order X, Y, B)
   std::vector<float> xyb_filtered; // 3 planes, ysize x xsize, stride xsize_padded
   std::vector<float> dc;           // 3 planes, ysize_blocks x xsize_blocks (after smoothing)
+  std::vector<float> dc_unsmoothed;  // the same before AdaptiveDCSmoothing (kept for the tests' third reading of it)
+  float dc_step[3] = {0, 0, 0};      // DC quantisation step per channel (what the smoothing measures its gap in)
+  float sigma_params[10] = {0};      // quant_scale, epf_quant_mul, epf_sharp_lut[8] (inputs of ComputeSigma)
   std::vector<uint8_t> acs;        // ysize_blocks x xsize_blocks: (strategy<<1)|is_first
   std::vector<int32_t> quant;      // raw quant field (valid at first blocks)
   std::vector<uint8_t> sharpness;
@@ -289,6 +292,9 @@ static void FinalizeDc(FrameState* s) {
   // EPF sigma (epf.cc:39-133); stored as 1/sigma per 8x8 block
   if (s->fh.lf.epf_iters > 0) {
     const float quant_scale = float(s->global_scale) * (1.0f / 65536.0f);
+    o->sigma_params[0] = quant_scale;
+    o->sigma_params[1] = s->fh.lf.epf_quant_mul;
+    for (int i = 0; i < 8; i++) o->sigma_params[2 + i] = s->fh.lf.epf_sharp_lut[i];
     for (size_t by = 0; by < ys; by++)
       for (size_t bx = 0; bx < xs; bx++) {
         uint8_t a = o->acs[by * xs + bx];
@@ -311,6 +317,8 @@ static void FinalizeDc(FrameState* s) {
     for (int c = 0; c < 3; c++) dcf[c] = inv_quant_dc * s->dq.dc_quant[c];
     const float w1 = 0.20345139757231578f, w2 = 0.0334829185968739f, w0 = 1.0f - 4.0f * (w1 + w2);
     std::vector<float> sm(o->dc);
+    o->dc_unsmoothed = o->dc;
+    for (int c = 0; c < 3; c++) o->dc_step[c] = dcf[c];
     for (size_t y = 1; y + 1 < ys; y++)
       for (size_t x = 1; x + 1 < xs; x++) {
         float mc[3], smv[3], gap = 0.5f;
@@ -1020,11 +1028,18 @@ const void* jxlo_buffer(JxloHandle* h, const char* name, size_t* nbytes) {
     return d.field.empty() ? nullptr : (const void*)d.field.data(); \
   }
   JXLO_BUF(rgb8) JXLO_BUF(rgbf) JXLO_BUF(coeffs) JXLO_BUF(nzeros) JXLO_BUF(xyb_idct) JXLO_BUF(xyb_filtered) JXLO_BUF(dc)
-  JXLO_BUF(acs) JXLO_BUF(quant) JXLO_BUF(sharpness) JXLO_BUF(ytox) JXLO_BUF(ytob) JXLO_BUF(inv_sigma) JXLO_BUF(quant_dc)
+  JXLO_BUF(acs) JXLO_BUF(quant) JXLO_BUF(sharpness) JXLO_BUF(ytox) JXLO_BUF(ytob) JXLO_BUF(inv_sigma) JXLO_BUF(quant_dc) JXLO_BUF(dc_unsmoothed)
   JXLO_BUF(modular)
 #undef JXLO_BUF
   *nbytes = 0;
   return nullptr;
+}
+
+// Scalars of the DC path for the tests' float64 reading of it: out[0..2] = DC quantisation steps of X, Y, B,
+// out[3] = quant_scale, out[4] = epf_quant_mul, out[5..12] = epf_sharp_lut.
+void jxlo_dc_params(JxloHandle* h, float* out) {
+  for (int i = 0; i < 3; i++) out[i] = h->d.dc_step[i];
+  for (int i = 0; i < 10; i++) out[3 + i] = h->d.sigma_params[i];
 }
 
 // Known-answer hook for the colour stage: n XYB triples, planar [3][n], through XybToRgb (+ the sRGB transfer function

@@ -13,6 +13,9 @@ OUT=gpurun_out/r03/profiles
 mkdir -p $R/$OUT
 cd $R
 bash scripts/profile_round.sh $OUT r03 > $R/$OUT/profile_round.log 2>&1
+( while true; do date >> $R/$OUT/heartbeat.txt; sleep 45; done ) &
+HB=$!
+trap "kill $HB" EXIT
 JXLHIP_LANES_PROF=1 python3 scripts/r03_entropy_probe.py 640 base 2>&1 | grep "lanes prof" | tail -1 | sed 's/^\[lanes prof\] //' > $R/$OUT/r03_entropy_split.json
 bash scripts/r03_pmc_probe.sh $OUT/pmc 640 > /dev/null 2>&1
 cp $R/$OUT/pmc/summary.txt $R/$OUT/r03_sq_counters_entropy.txt

@@ -89,3 +89,44 @@ def loop_filters(xyb_idct, inv_sigma_blocks, xsize, ysize, gab, epf_iters):
     if epf_iters >= 2:
         p = _epf_stage(p, inv_sigma_blocks, 2)
     return p
+
+
+# ---- the DC path's two stencils, same rules: float64, written from the reference's formulas only.
+def dc_smoothing(dc, step):
+    """AdaptiveDCSmoothing, lib/jxl/compressed_dc.cc:50-52 (weights) and :64-128: per block a 3x3 weighted mean of each of
+    the three DC planes; gap = max over the channels of |dc - mean| in units of the channel's DC quantisation step, at
+    least 0.5; the result moves from dc towards the mean by max(0, 3 - 4 * gap). Border blocks keep their value (:141-175);
+    images of at most 2 blocks in either direction are left alone (:134)."""
+    dc = np.asarray(dc, np.float64)
+    _, h, w = dc.shape
+    if h <= 2 or w <= 2:
+        return dc.copy()
+    w1, w2 = float(np.float32(0.20345139757231578)), float(np.float32(0.0334829185968739))
+    w0 = float(np.float32(1.0) - np.float32(4.0) * (np.float32(w1) + np.float32(w2)))
+    c = dc[:, 1:-1, 1:-1]
+    side = dc[:, 1:-1, :-2] + dc[:, 1:-1, 2:] + dc[:, :-2, 1:-1] + dc[:, 2:, 1:-1]
+    corner = dc[:, :-2, :-2] + dc[:, :-2, 2:] + dc[:, 2:, :-2] + dc[:, 2:, 2:]
+    sm = corner * w2 + side * w1 + c * w0
+    gap = np.maximum(0.5, (np.abs(c - sm) / np.asarray(step, np.float64)[:, None, None]).max(axis=0))
+    factor = np.maximum(0.0, 3.0 - 4.0 * gap)
+    out = dc.copy()
+    out[:, 1:-1, 1:-1] = (sm - c) * factor + c
+    return out
+
+
+def inv_sigma_blocks(acs, quant, sharpness, quant_scale, epf_quant_mul, sharp_lut):
+    """ComputeSigma, lib/jxl/epf.cc:39-81: for every varblock (acs = strategy << 1 | first block, quant = raw quant field
+    at first blocks) sigma = epf_quant_mul / (quant_scale * quant * kInvSigmaNum) * sharp_lut[sharpness of the block],
+    at most -1e-4; stored as 1 / sigma for each 8x8 block the varblock covers (ac_strategy.h:130-167)."""
+    cx = [1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32]
+    cy = [1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1, 1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16]
+    k_inv_sigma_num = -1.1715728752538099024
+    h, w = acs.shape
+    out = np.zeros((h, w), np.float64)
+    lut = np.asarray(sharp_lut, np.float64)
+    for by, bx in zip(*np.nonzero(acs & 1)):
+        st = int(acs[by, bx]) >> 1
+        sq = epf_quant_mul / (quant_scale * float(quant[by, bx]) * k_inv_sigma_num)
+        sl = (slice(by, by + cy[st]), slice(bx, bx + cx[st]))
+        out[sl] = 1.0 / np.minimum(-1e-4, sq * lut[sharpness[sl]])
+    return out

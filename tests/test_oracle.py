@@ -296,3 +296,27 @@ def test_loop_filters_against_a_float64_third_reading(built, kw):
     got = o.planes("xyb_filtered")[:, :i["ysize"], :i["xsize"]]
     o.close()
     assert np.abs(got - want).max() < 2e-6
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(distance=3.0, epf_iters=3), dict(distance=0.5, epf_iters=2)])
+def test_dc_path_against_a_float64_third_reading(built, kw):
+    """Adaptive DC smoothing (compressed_dc.cc:50-52,64-198) and the EPF's 1 / sigma per block (epf.cc:39-81) restated in
+    float64 NumPy (tests/filters_f64.py) from the reference's formulas: the oracle's smoothed DC image and its 1 / sigma
+    plane must agree with that reading on decoded frames (the same reading the device kernels are held to on the GPU box)."""
+    import filters_f64 as F
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(403, 277, seed=5), **kw)
+    o = jxlo.Decoded(data)
+    i = o.info
+    yb, xb = i["ysize_blocks"], i["xsize_blocks"]
+    p = o.dc_params
+    raw, got = o.buffer("dc_unsmoothed").reshape(3, yb, xb), o.buffer("dc").reshape(3, yb, xb)
+    want = F.dc_smoothing(raw, p["dc_step"])
+    assert np.abs(raw - got).max() > 1e-4, "the stream must exercise the smoothing"
+    assert np.abs(got - want).max() < 2e-6
+    sig = o.buffer("inv_sigma").reshape(yb, xb)
+    want = F.inv_sigma_blocks(o.buffer("acs").reshape(yb, xb), o.buffer("quant").reshape(yb, xb), o.buffer("sharpness").reshape(yb, xb),
+                              p["quant_scale"], p["epf_quant_mul"], p["epf_sharp_lut"])
+    o.close()
+    assert np.abs(sig / want - 1.0).max() < 2e-6
