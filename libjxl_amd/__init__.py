@@ -463,6 +463,15 @@ def icc_decode(coded):
     return out.raw[:n.value], bits.value
 
 
+def set_custom_upsampling(mask=0, seed=1):
+    """Test aid: the next VarDCT streams code their own upsampling weights (CustomTransformData, image_metadata.cc:87-214):
+    bit k of `mask` = the 2^(k+1)-fold weight matrix is coded (seeded variations of the default weights); 0 = default again."""
+    E = _enc_lib()
+    E.jxlenc_set_custom_upsampling.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    E.jxlenc_set_custom_upsampling.restype = None
+    E.jxlenc_set_custom_upsampling(mask, seed)
+
+
 def set_embedded_icc(coded=None):
     """Test aid: the synthetic encoders embed this coded ICC profile (want_icc) in the streams they write from now on
     (None: no profile again)."""

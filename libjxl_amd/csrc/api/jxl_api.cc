@@ -220,11 +220,12 @@ void jxlamd_frame_out_size(const JxlAmdFrame* f, uint32_t* wh) {
   wh[1] = uint32_t(P.fh.upsampling == 1 ? P.dim.ysize : P.ih.ysize);
 }
 
-// The N*N 5x5 upsampling kernels from the upper triangle of the symmetric default weight matrix
-// (stage_upsampling.cc:59-84; weights image_metadata.cc:98-214).
+// The N*N 5x5 upsampling kernels from the upper triangle of the symmetric weight matrix (stage_upsampling.cc:59-84):
+// the weights the image header codes (image_metadata.cc:87-214, CustomTransformData) or the default ones (:98-214).
 #include "../host/upsampling_weights.inc"
-static void UpsamplingKernels(uint32_t N, std::vector<float>* kernel) {
-  const float* weights = N == 2 ? kUpsamplingWeights2 : (N == 4 ? kUpsamplingWeights4 : kUpsamplingWeights8);
+static void UpsamplingKernels(uint32_t N, const jxh::ImageHeader& ih, std::vector<float>* kernel) {
+  const std::vector<float>& coded = N == 2 ? ih.ups_weights2 : (N == 4 ? ih.ups_weights4 : ih.ups_weights8);
+  const float* weights = !coded.empty() ? coded.data() : (N == 2 ? kUpsamplingWeights2 : (N == 4 ? kUpsamplingWeights4 : kUpsamplingWeights8));
   kernel->assign(size_t(N) * N * 25, 0.0f);
   const size_t H = N / 2;
   for (size_t ky = 0; ky < H; ++ky)
@@ -361,7 +362,7 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.noise_frame_index[1] = uint32_t(P.nonvisible_index);
   std::vector<float> ups_kernel;
   if (P.fh.upsampling != 1) {
-    UpsamplingKernels(P.fh.upsampling, &ups_kernel);
+    UpsamplingKernels(P.fh.upsampling, P.ih, &ups_kernel);
     d.upsampling = P.fh.upsampling;
     d.out_xsize = uint32_t(P.ih.xsize);
     d.out_ysize = uint32_t(P.ih.ysize);

@@ -1016,6 +1016,18 @@ static void WriteSplines(BitWriter& bw) {
   WriteTokens(bw, tk.data(), tk.size(), code);
 }
 static std::vector<uint8_t> g_embedded_icc;
+// CustomTransformData with coded upsampling weights (image_metadata.cc:87-214): bit k of the mask = the 2^(k+1)-fold
+// matrix is coded, as the default weights scaled by seeded factors in [0.75, 1.25] and rounded to half precision.
+static uint32_t g_custom_ups_mask = 0, g_custom_ups_seed = 1;
+#include "../host/upsampling_weights.inc"
+static float RoundToF16(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  u = (u + 0x1000u) & ~0x1FFFu;  // nearest value with a 10-bit mantissa
+  float r;
+  memcpy(&r, &u, 4);
+  return std::fabs(r) < 6.2e-5f ? 0.0f : r;  // (below the normal half-precision range: zero)
+}
 static size_t g_embedded_icc_bits = 0;  // its exact length (the decoder aligns to a byte right after the last bit)
 static void AppendEmbeddedIcc(BitWriter& bw) {
   for (size_t i = 0; i < g_embedded_icc_bits; i += 8) {
@@ -1474,7 +1486,22 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     WriteToneMapping(bw);
     bw.Write(2, 0);  // no extensions
   }
-  bw.Write(1, 1);  // CustomTransformData all_default
+  if (!g_custom_ups_mask) {
+    bw.Write(1, 1);  // CustomTransformData all_default
+  } else {
+    bw.Write(1, 0);
+    bw.Write(1, 1);  // OpsinInverseMatrix all_default (the image is XYB encoded)
+    bw.Write(3, g_custom_ups_mask & 7);
+    uint32_t st = g_custom_ups_seed * 2654435761u + 12345u;
+    const float* defaults[3] = {kUpsamplingWeights2, kUpsamplingWeights4, kUpsamplingWeights8};
+    const int counts[3] = {15, 55, 210};
+    for (int k = 0; k < 3; k++)
+      if (g_custom_ups_mask & (1u << k))
+        for (int i = 0; i < counts[k]; i++) {
+          st = st * 1664525u + 1013904223u;
+          WriteF16(bw, RoundToF16(defaults[k][i] * (0.75f + 0.5f * float(st >> 8) * (1.0f / 16777216.0f))));
+        }
+  }
   if (with_icc) AppendEmbeddedIcc(bw);  // (decode.cc: after the transform data, before the byte boundary)
   bw.ZeroPad();
   g_last_header_bytes = bw.bytes().size();
@@ -2543,6 +2570,13 @@ struct JxlEncParams {
   int32_t noise;           // > 0: noise synthesis, see jxe::Params
   int32_t cfl_fit;         // 1 = per-tile chroma-from-luma fit (the reference's fast FindBestMultiplier), see jxe::Params
 };
+
+// The next VarDCT streams code their own upsampling weights (mask bit k: the 2^(k+1)-fold matrix; 0: default weights again).
+// Test aid, not thread-safe.
+void jxlenc_set_custom_upsampling(uint32_t mask, uint32_t seed) {
+  jxe::g_custom_ups_mask = mask & 7;
+  jxe::g_custom_ups_seed = seed;
+}
 
 // The next encoded streams embed this coded ICC profile of exactly `bits` bits (n = 0: none again). Test aid, not thread-safe.
 void jxlenc_set_embedded_icc(const uint8_t* coded, size_t n, size_t bits) {

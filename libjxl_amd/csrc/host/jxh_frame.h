@@ -177,7 +177,6 @@ class FrameParser {
     JXH_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
     JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
-    JXH_CHECK(fh.upsampling == 1 || !ih.custom_upsampling, "unsupported: custom upsampling weights");
     JXH_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");

@@ -55,6 +55,8 @@ struct ImageHeader {
   float quant_bias[4] = {1.0f - 0.05465007330715401f, 1.0f - 0.07005449891748593f, 1.0f - 0.049935103337343655f,
                          0.145f};
   bool custom_upsampling = false;
+  // coded upsampling weights (image_metadata.cc:87-214: upper triangle of the symmetric 5N/2 x 5N/2 matrix); empty = default
+  std::vector<float> ups_weights2, ups_weights4, ups_weights8;
 };
 
 static inline void ReadBitDepth(BitReader& br, uint32_t* bits, uint32_t* exp_bits, bool* floating) {
@@ -219,9 +221,9 @@ static inline void ReadImageHeader(BitReader& br, ImageHeader* h) {
       }
     }
     uint32_t mask = uint32_t(br.Read(3));
-    if (mask & 1) for (int i = 0; i < 15; i++) ReadF16(br);
-    if (mask & 2) for (int i = 0; i < 55; i++) ReadF16(br);
-    if (mask & 4) for (int i = 0; i < 210; i++) ReadF16(br);
+    if (mask & 1) for (int i = 0; i < 15; i++) h->ups_weights2.push_back(ReadF16(br));
+    if (mask & 2) for (int i = 0; i < 55; i++) h->ups_weights4.push_back(ReadF16(br));
+    if (mask & 4) for (int i = 0; i < 210; i++) h->ups_weights8.push_back(ReadF16(br));
     h->custom_upsampling = mask != 0;
   }
   if (h->want_icc) ReadIcc(br, &h->icc);  // decode.cc: after the transform data, before the byte boundary

@@ -489,7 +489,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   ReadFrameHeader(br, ih, &s->fh);
   const FrameHeader& fh = s->fh;
   JXLO_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
-  JXLO_CHECK(fh.upsampling == 1 || (!fh.modular && !ih.custom_upsampling), "unsupported: upsampled Modular frames / custom weights");
+  JXLO_CHECK(fh.upsampling == 1 || !fh.modular, "unsupported: upsampled Modular frames");
   JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
   JXLO_CHECK(fh.modular || ih.xyb_encoded, "unsupported: non-XYB VarDCT");
@@ -670,7 +670,8 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       Planes3 crop;  // the filters work on the padded stride; the upsampler mirrors about the frame size
       crop.xs = d.xsize; crop.ys = d.ysize; crop.stride = cur->stride;
       for (int c = 0; c < 3; c++) crop.p[c] = cur->p[c];
-      Upsample(crop, fh.upsampling, xs, ys, &up);
+      const std::vector<float>& cw = fh.upsampling == 2 ? ih.ups_weights2 : (fh.upsampling == 4 ? ih.ups_weights4 : ih.ups_weights8);
+      Upsample(crop, fh.upsampling, cw.empty() ? nullptr : cw.data(), xs, ys, &up);
       cur = &up;
     }
     Planes3 noisy;

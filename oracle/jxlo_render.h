@@ -129,10 +129,10 @@ static inline OpsinParams MakeOpsinParams(const ImageHeader& h) {
 // ---- upsampling by N = 2, 4, 8 (lib/jxl/render_pipeline/stage_upsampling.cc:49-282): every output pixel
 // (N x + ox, N y + oy) is a 5x5 weighted sum of the input around (x, y) with kernel k = N oy + ox, clamped to the
 // minimum / maximum of that 5x5 window. The N*N kernels come from the upper triangle of a symmetric weight matrix
-// (default weights: image_metadata.cc:98-214) by the four mirror symmetries.
+// (the weights the image header codes, or the default ones: image_metadata.cc:87-214) by the four mirror symmetries.
 #include "upsampling_weights.inc"
-static inline void UpsamplingKernels(uint32_t N, float* kernel /* N*N*25 */) {
-  const float* weights = N == 2 ? kUpsamplingWeights2 : (N == 4 ? kUpsamplingWeights4 : kUpsamplingWeights8);
+static inline void UpsamplingKernels(uint32_t N, const float* coded, float* kernel /* N*N*25 */) {
+  const float* weights = coded ? coded : (N == 2 ? kUpsamplingWeights2 : (N == 4 ? kUpsamplingWeights4 : kUpsamplingWeights8));
   const size_t H = N / 2;
   for (size_t ky = 0; ky < H; ++ky)
     for (size_t kx = 0; kx < H; ++kx) {
@@ -149,9 +149,9 @@ static inline void UpsamplingKernels(uint32_t N, float* kernel /* N*N*25 */) {
         }
     }
 }
-static inline void Upsample(const Planes3& in, uint32_t N, size_t out_xs, size_t out_ys, Planes3* out) {
+static inline void Upsample(const Planes3& in, uint32_t N, const float* coded_weights, size_t out_xs, size_t out_ys, Planes3* out) {
   std::vector<float> kernel(size_t(N) * N * 25);
-  UpsamplingKernels(N, kernel.data());
+  UpsamplingKernels(N, coded_weights, kernel.data());
   out->Alloc(out_xs, out_ys, out_xs);
   for (int c = 0; c < 3; c++)
     for (size_t y = 0; y < in.ys; y++)

@@ -247,6 +247,29 @@ def test_upsampled_frames(built, factor):
         o.close()
 
 
+@pytest.mark.parametrize("factor", [2, 4, 8])
+def test_upsampling_with_coded_weights(built, factor):
+    """Images whose header codes its own upsampling weights (CustomTransformData, image_metadata.cc:87-214; applied by
+    stage_upsampling.cc:59-84 like the default ones): the GPU upsamples with the coded matrix like the oracle, and the
+    result differs from what the default weights give (so the coded ones were really used)."""
+    import jxlo
+    J = built
+    img = J.synth_image(411, 307, seed=30 + factor)
+    plain = J.decode_rgb8(J.encode_rgb8(img, upsampling=factor))
+    J.set_custom_upsampling(7, seed=factor)
+    try:
+        data = J.encode_rgb8(img, upsampling=factor)
+    finally:
+        J.set_custom_upsampling(0)
+    o = jxlo.Decoded(data, dumps=False)
+    rgb = J.decode_rgb8(data)
+    assert rgb.shape == o.rgb8.shape == plain.shape
+    d = np.abs(rgb.astype(int) - o.rgb8.astype(int))
+    o.close()
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    assert (np.abs(rgb.astype(int) - plain.astype(int)) > 2).mean() > 0.01
+
+
 def test_randomized_parity_sweep(built):
     """A short run of scripts/fuzz_parity.py: random sizes, distances, filter settings, strategy sets, histogram counts."""
     import os

@@ -320,3 +320,24 @@ def test_dc_path_against_a_float64_third_reading(built, kw):
                               p["quant_scale"], p["epf_quant_mul"], p["epf_sharp_lut"])
     o.close()
     assert np.abs(sig / want - 1.0).max() < 2e-6
+
+
+def test_coded_upsampling_weights_are_parsed_and_used(built):
+    """CustomTransformData with coded upsampling weights (image_metadata.cc:87-214): both front-ends read the header (the
+    host parser reaches the frame behind it), the oracle's output follows the coded matrix, not the default one."""
+    import jxlo
+    J = built
+    img = J.synth_image(203, 149, seed=8)
+    plain = jxlo.Decoded(J.encode_rgb8(img, upsampling=2), dumps=False)
+    J.set_custom_upsampling(1, seed=5)
+    try:
+        data = J.encode_rgb8(img, upsampling=2)
+    finally:
+        J.set_custom_upsampling(0)
+    o = jxlo.Decoded(data, dumps=False)
+    f = J.Frame(data)
+    assert (f.info["out_xsize"], f.info["out_ysize"]) == o.out_size == (203, 149)
+    f.close()
+    assert (np.abs(o.rgb8.astype(int) - plain.rgb8.astype(int)) > 2).mean() > 0.01
+    o.close()
+    plain.close()
