@@ -40,9 +40,12 @@ size_t jxlamd_frame_end(const JxlAmdFrame* frame, uint32_t* duration_last_timeco
 typedef struct {
   int32_t x0, y0;
   uint32_t xsize, ysize;
-  uint32_t custom_size, frame_type; /* frame_type: 0 regular, 2 reference only (kept in XYB for patches), 3 skip-progressive */
+  uint32_t custom_size, frame_type; /* frame_type: 0 regular, 1 DC frame, 2 reference only (kept in XYB for patches), 3 skip-progressive */
   uint32_t mode, alpha_mode, source, alpha_source, clamp, alpha_clamp;
   uint32_t duration, is_last, save_as_reference, save_before_color_transform;
+  /* DC frames (frame_header.h:319,348,439): dc_level 1..4 for a kDCFrame (its output, kept before the colour transform, is
+   * the DC image of level dc_level - 1); use_dc_frame != 0: this frame's DC image is the DC frame of level dc_level + 1. */
+  uint32_t dc_level, use_dc_frame;
 } JxlAmdFramePlacement;
 void jxlamd_frame_placement(const JxlAmdFrame* frame, JxlAmdFramePlacement* placement);
 /* The frame's position among the shown / invisible frames (seeds its noise: dec_frame.cc:160-168); before upload. */
@@ -51,6 +54,9 @@ void jxlamd_frame_set_indices(JxlAmdFrame* frame, uint32_t visible_index, uint32
  * patch rectangle against them. Before upload; returns non-zero (see jxlamd_last_error) when a patch refers to an empty
  * slot or reaches outside its reference frame. */
 int jxlamd_frame_set_patch_sources(JxlAmdFrame* frame, const float* const* planes, const uint32_t* xsize, const uint32_t* ysize);
+/* A frame with kUseDcFrame: the device planes of the DC frame it names ([3][ysize][xsize] floats, e.g. from
+ * jxlhip_canvas_xyb_source(canvas, 4 + placement.dc_level, ...)); fails unless the size is the frame's size in blocks. */
+int jxlamd_frame_set_dc_source(JxlAmdFrame* frame, const float* planes, uint32_t xsize, uint32_t ysize);
 void jxlamd_frame_free(JxlAmdFrame* frame);
 /* info[0..15]: xsize, ysize, xsize_blocks, ysize_blocks, num_groups, num_dc_groups, num_passes, used_acs mask,
  * epf_iters, gab, coefficient storage bits (16/32), total AC section bytes, then of pass 0: log2 alphabet size,

@@ -177,6 +177,10 @@ typedef struct JxlHipFrameDesc {
    *    block, row-major like `dc`), the varblocks' qf, quant_scale (= global_scale / 65536), epf_quant_mul and epf_sharp_lut. */
   uint32_t dc_smoothing;
   float dc_step[3];
+  /* kUseDcFrame (frame_header.h:348, passes_state.cc:62-77): the DC image is an earlier DC frame's output, resident on
+   * this device as 3 planes of xsize_blocks * ysize_blocks floats (jxlhip_canvas_xyb_source of slot 4 + level); `dc` may
+   * then be NULL and no smoothing runs. The planes must stay valid until the transform stage has run. */
+  const float* dc_device;
   const uint8_t* sharpness;
   float quant_scale, epf_quant_mul;
   float epf_sharp_lut[8];

@@ -667,6 +667,36 @@ def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=Fal
         E.jxlenc_set_image_size(0, 0)
 
 
+def encode_with_dc_frame(img, dc_vardct=False, **kw):
+    """Test aid: what `cjxl --progressive_dc` lays out: a kDCFrame of level 1 (the image's 8x8 block means, 1/8 size; coded as
+    an XYB Modular frame like libjxl's DC frames, or as a VarDCT frame), then `img` as a VarDCT frame with kUseDcFrame, whose
+    DC groups carry no DC stream: its DC image is the DC frame's output (frame_header.h:348, passes_state.cc:62-77)."""
+    E = _enc_lib()
+    E.jxlenc_set_image_size.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    E.jxlenc_set_image_size.restype = None
+    E.jxlenc_set_dc_frame.argtypes = [ctypes.c_int]
+    E.jxlenc_set_dc_frame.restype = None
+    E.jxlenc_set_use_dc_frame.argtypes = [ctypes.c_int]
+    E.jxlenc_set_use_dc_frame.restype = None
+    E.jxlenc_last_header_bytes.restype = ctypes.c_size_t
+    h, w = img.shape[:2]
+    xb, yb = (w + 7) // 8, (h + 7) // 8
+    pad = np.pad(img, ((0, yb * 8 - h), (0, xb * 8 - w), (0, 0)), mode="edge")
+    small = np.ascontiguousarray(pad.reshape(yb, 8, xb, 8, 3).mean(axis=(1, 3)).round().astype(np.uint8))
+    try:
+        E.jxlenc_set_image_size(w, h)
+        E.jxlenc_set_dc_frame(1)
+        first = encode_rgb8(small, **kw) if dc_vardct else encode_lossless(small, MODULAR_XYB)
+        E.jxlenc_set_dc_frame(0)
+        E.jxlenc_set_use_dc_frame(1)
+        second = encode_rgb8(img, **kw)
+        return first + second[E.jxlenc_last_header_bytes():]
+    finally:
+        E.jxlenc_set_dc_frame(0)
+        E.jxlenc_set_use_dc_frame(0)
+        E.jxlenc_set_image_size(0, 0)
+
+
 def synth_image(xsize, ysize, seed=177):
     """Deterministic synthetic RGB8 test image (gradient background, rectangles, discs, texture, noise)."""
     a = np.zeros((ysize, xsize, 3), np.uint8)

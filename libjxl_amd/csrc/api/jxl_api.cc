@@ -145,6 +145,8 @@ static void FillPlacement(const jxh::ImageHeader& ih, const jxh::FrameHeader& fh
   p->is_last = fh.is_last;
   p->save_as_reference = fh.save_as_reference;
   p->save_before_color_transform = fh.save_before_color_transform;
+  p->dc_level = fh.dc_level;
+  p->use_dc_frame = (fh.flags & jxh::FrameHeader::kUseDcFrame) ? 1 : 0;
 }
 void jxlamd_frame_placement(const JxlAmdFrame* f, JxlAmdFramePlacement* p) {
   FillPlacement(f->plan.ih, f->plan.fh, f->plan.dim.xsize * f->plan.fh.upsampling, f->plan.dim.ysize * f->plan.fh.upsampling, p);
@@ -153,6 +155,18 @@ void jxlamd_frame_placement(const JxlAmdFrame* f, JxlAmdFramePlacement* p) {
     p->ysize = uint32_t(f->plan.ih.ysize);
   }
 }
+int jxlamd_frame_set_dc_source(JxlAmdFrame* f, const float* planes, uint32_t xs, uint32_t ys) {
+  g_last_error.clear();
+  jxh::FramePlan& P = f->plan;
+  if (!P.use_dc_frame || !planes || xs != P.dim.xsize_blocks || ys != P.dim.ysize_blocks) {
+    // (passes_state.cc:70-75: "kUseDcFrame specified for dc_level %u, but no frame was decoded with level %u")
+    g_last_error = !P.use_dc_frame ? "the frame does not use a DC frame" : "kUseDcFrame: no DC frame of that level and size was decoded";
+    return 1;
+  }
+  P.dc_source = planes;
+  return 0;
+}
+
 int jxlamd_frame_set_patch_sources(JxlAmdFrame* f, const float* const* planes, const uint32_t* xs, const uint32_t* ys) {
   g_last_error.clear();
   jxh::FramePlan& P = f->plan;
@@ -308,7 +322,12 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.dequant_floats = uint32_t(P.dequant.size());
   memcpy(d.dequant_offset, P.dequant_offset, sizeof(d.dequant_offset));
   memcpy(d.dequant_size, P.dequant_size, sizeof(d.dequant_size));
+  if (P.use_dc_frame && !P.dc_source) {
+    g_last_error = "kUseDcFrame: the DC frame's planes were not set (jxlamd_frame_set_dc_source)";
+    return 1;
+  }
   d.dc = P.dc.data();
+  d.dc_device = P.use_dc_frame ? P.dc_source : nullptr;
   d.dc_smoothing = P.dc_smoothing ? 1 : 0;  // smoothing and 1 / sigma are computed by the upload (csrc/hip/jxl_hip_dc.h)
   memcpy(d.dc_step, P.dc_step, sizeof(d.dc_step));
   d.inv_sigma = nullptr;
@@ -1083,7 +1102,7 @@ JxlDecoderStatus DecodeModularPixels(JxlDecoder* d, bool to_canvas) {
   {
     JxlAmdFramePlacement pl;
     jxlamd_modframe_placement(d->mframe, &pl);
-    if (!r) r = jxlhip_set_option(d->ctx, "keep_xyb_planes", pl.frame_type == 2 ? 1 : 0);
+    if (!r) r = jxlhip_set_option(d->ctx, "keep_xyb_planes", (pl.frame_type == 2 || pl.frame_type == 1) ? 1 : 0);
   }
   if (!r) r = jxlamd_modframe_upload(d->mframe, d->ctx);
   if (!r) r = jxlhip_modular_run(d->ctx);
@@ -1141,6 +1160,12 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
     uint32_t pw[4] = {0, 0, 0, 0}, ph[4] = {0, 0, 0, 0};
     for (uint32_t i = 0; i < 4 && d->canvas; i++) jxlhip_canvas_xyb_source(d->canvas, i, &planes[i], &pw[i], &ph[i]);
     if (jxlamd_frame_set_patch_sources(d->frame, planes, pw, ph)) return Fail(d, g_last_error);
+  }
+  if (!r && P.use_dc_frame) {  // the DC frame decoded earlier: DC slot of the canvas (BlendIntoCanvas put it there)
+    const float* planes = nullptr;
+    uint32_t w = 0, h = 0;
+    if (d->canvas) jxlhip_canvas_xyb_source(d->canvas, 4 + P.fh.dc_level, &planes, &w, &h);
+    if (jxlamd_frame_set_dc_source(d->frame, planes, w, h)) return Fail(d, g_last_error);
   }
   if (!r) r = jxlamd_frame_upload(d->frame, d->ctx);
   if (!r) r = jxlhip_run_entropy(d->ctx);
@@ -1211,6 +1236,11 @@ JxlDecoderStatus BlendIntoCanvas(JxlDecoder* d) {
     r = jxlhip_canvas_create(dev ? atoi(dev) : 0, uint32_t(d->ih.xsize), uint32_t(d->ih.ysize), has_alpha ? 1 : 0,
                              has_alpha && d->ih.extra[0].alpha_associated ? 1 : 0, &d->canvas);
     if (r) return Fail(d, "jxlhip_canvas_create failed (" + std::to_string(r) + ")");
+  }
+  if (p.frame_type == 1) {  // kDCFrame (dec_cache.cc:221-224): kept before the colour transform as the DC image of level dc_level - 1
+    r = jxlhip_canvas_save_xyb(d->canvas, d->ctx, 4 + p.dc_level - 1);
+    if (r) return Fail(d, "jxlhip_canvas_save_xyb failed (" + std::to_string(r) + ")");
+    return JXL_DEC_SUCCESS;
   }
   if (p.frame_type == 2) {  // kReferenceOnly: kept before the colour transform for the patches of later frames, never blended
     r = jxlhip_canvas_save_xyb(d->canvas, d->ctx, p.save_as_reference);
@@ -1389,7 +1419,8 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
       if (!d->frame_shown || d->frame_skipped) {
         // no events for it; its pixels are still needed when a later frame may be blended with them
         // (coalescing off: nothing is blended, but the patches of later frames still read the reference-only frames)
-        if ((d->coalescing ? d->canvas_mode : pl.frame_type == 2) && CanBeReferenced(pl) && (d->events & JXL_DEC_FULL_IMAGE)) {
+        // (a DC frame is never referenced by blending, but it is the DC image of a frame behind it)
+        if ((((d->coalescing ? d->canvas_mode : pl.frame_type == 2) && CanBeReferenced(pl)) || pl.frame_type == 1) && (d->events & JXL_DEC_FULL_IMAGE)) {
           const JxlDecoderStatus st = DecodePixels(d, true);
           if (st != JXL_DEC_SUCCESS) {
             *ev = st;

@@ -775,6 +775,12 @@ static LayerState g_layer;
 // reference: slot, x0, y0, xsize, ysize, count, then per position: x, y, colour blend mode 0..3, clamp), written the way
 // PatchDictionary::Decode reads it (dec_patch_dictionary.cc:32-175; extra channels are left alone: mode kNone).
 static int g_reference_slot = -1;
+// jxlenc_set_dc_frame: the next frame is a kDCFrame of this level (frame_header.cc:310-320, 372-411: a Passes bundle and the
+// level, then no size, no blending, no timing, no save_as_reference), coded at the size the image header implies
+// (image / 8^level); jxlenc_set_use_dc_frame: the next VarDCT frame sets kUseDcFrame (no upsampling fields in its header,
+// no DC stream in its DC groups: frame_header.cc:263, dec_frame.cc:322-326).
+static int g_dc_frame_level = 0;
+static bool g_use_dc_frame = false;
 static uint32_t g_image_w = 0, g_image_h = 0;
 static std::vector<int32_t> g_patches;
 // jxlenc_set_frame_name: the name the next frames carry (frame_header.cc:431 VisitNameString: U32 length, bytes)
@@ -839,6 +845,7 @@ static void WriteAlphaChannelInfo(BitWriter& bw) {
 static bool WriteCropAndBlending(BitWriter& bw, uint32_t fw, uint32_t fh, bool have_alpha) {
   const LayerState& L = g_layer;
   static const uint32_t db[4] = {8, 11, 14, 30}, dof[4] = {0, 256, 2304, 18688};
+  if (g_dc_frame_level > 0) return false;  // kDCFrame: nothing (its size follows from the image's)
   if (g_reference_slot >= 0) {  // kReferenceOnly: its own size, no origin, no blending info
     bw.Write(1, 1);
     WriteU32Sel(bw, fw, db, dof);
@@ -912,6 +919,7 @@ static void WriteToneMapping(BitWriter& bw) {
 // frame_header.cc:130-150, 372-399: the animation fields of a frame header, is_last, and (not last) save_as_reference 0.
 // A frame with a duration and no reference slot cannot be referenced: no save_before_color_transform bit follows.
 static void WriteFrameTiming(BitWriter& bw, bool replace_whole_canvas = true) {
+  if (g_dc_frame_level > 0) return;  // kDCFrame: no timing, never last, no reference slot
   if (g_reference_slot >= 0) {  // no duration, no is_last (= false); save_as_reference, then save_before_color_transform
     bw.Write(2, uint32_t(g_reference_slot));
     bw.Write(1, 1);
@@ -1383,9 +1391,11 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(2, 0);  // no transforms
   };
   auto write_dc_group = [&](BitWriter& bw, size_t g) {
-    bw.Write(2, 0);  // extra precision
-    write_group_header(bw);
-    WriteTokens(bw, dc_tokens[g].data(), dc_tokens[g].size(), mod_code);
+    if (!g_use_dc_frame) {  // (dec_frame.cc:322-326: the DC stream is absent when the DC image comes from a DC frame)
+      bw.Write(2, 0);  // extra precision
+      write_group_header(bw);
+      WriteTokens(bw, dc_tokens[g].data(), dc_tokens[g].size(), mod_code);
+    }
     size_t bx0 = (g % xdg) * 256, by0 = (g / xdg) * 256;
     size_t bw_ = std::min<size_t>(256, f.xb - bx0), bh = std::min<size_t>(256, f.yb - by0);
     bw.Write(CeilLog2(bw_ * bh), meta_count[g] - 1);
@@ -1507,19 +1517,22 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   g_last_header_bytes = bw.bytes().size();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
-  bw.Write(2, g_reference_slot >= 0 ? 2 : 0);  // regular frame, or kReferenceOnly
+  bw.Write(2, g_dc_frame_level > 0 ? 1 : (g_reference_slot >= 0 ? 2 : 0));  // regular frame, kDCFrame or kReferenceOnly
   bw.Write(1, 0);  // VarDCT
-  if (f.flags == 0) {
+  const uint64_t hflags = f.flags | (g_use_dc_frame ? 32 : 0);
+  if (hflags == 0) {
     bw.Write(2, 0);
-  } else if (f.flags <= 16) {  // U64 selector 1: 1 + 4 bits
+  } else if (hflags <= 16) {  // U64 selector 1: 1 + 4 bits
     bw.Write(2, 1);
-    bw.Write(4, f.flags - 1);
+    bw.Write(4, hflags - 1);
   } else {  // U64 selector 2: 17 + 8 bits
     bw.Write(2, 2);
-    bw.Write(8, f.flags - 17);
+    bw.Write(8, hflags - 17);
   }
-  bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
-  if (have_alpha) bw.Write(2, 0);  // extra channel upsampling 1
+  if (!g_use_dc_frame) {  // (frame_header.cc:263: no upsampling fields with kUseDcFrame)
+    bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
+    if (have_alpha) bw.Write(2, 0);  // extra channel upsampling 1
+  }
   bw.Write(3, p.custom_cmap ? 2 : 3);  // x_qm_scale
   bw.Write(3, p.custom_cmap ? 4 : 2);  // b_qm_scale
   if (g_reference_slot >= 0) {
@@ -1531,6 +1544,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(2, 0);  // no downsampling brackets
     bw.Write(2, 1);  // shift of pass 0 = 1 (the last pass always has shift 0)
   }
+  if (g_dc_frame_level > 0) bw.Write(2, uint32_t(g_dc_frame_level - 1));  // dc_level: U32(Val(1), Val(2), Val(3), Val(4))
   const bool whole = WriteCropAndBlending(bw, uint32_t(f.xs), uint32_t(f.ys), have_alpha);
   WriteFrameTiming(bw, whole);
   WriteFrameName(bw);
@@ -2511,7 +2525,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   g_last_header_bytes = bw.bytes().size();
   // FrameHeader
   bw.Write(1, 0);  // not all_default
-  bw.Write(2, g_reference_slot >= 0 ? 2 : 0);  // regular frame, or kReferenceOnly
+  bw.Write(2, g_dc_frame_level > 0 ? 1 : (g_reference_slot >= 0 ? 2 : 0));  // regular frame, kDCFrame or kReferenceOnly
   bw.Write(1, 1);  // Modular
   {
     const uint32_t mflags = (g_splines.empty() ? 0 : 16) | (g_patches.empty() ? 0 : 2);
@@ -2527,7 +2541,8 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   bw.Write(2, 0);  // upsampling 1
   if (alpha) bw.Write(2, 0);
   bw.Write(2, 1);  // group_size_shift 1 (256)
-  if (g_reference_slot < 0) bw.Write(2, 0);  // one pass (a kReferenceOnly frame has no Passes bundle: frame_header.cc:303)
+  if (g_reference_slot < 0 || g_dc_frame_level > 0) bw.Write(2, 0);  // one pass (a kReferenceOnly frame has no Passes bundle: frame_header.cc:303)
+  if (g_dc_frame_level > 0) bw.Write(2, uint32_t(g_dc_frame_level - 1));  // dc_level
   const bool whole = WriteCropAndBlending(bw, uint32_t(xs), uint32_t(ys), alpha);
   WriteFrameTiming(bw, whole);
   WriteFrameName(bw);
@@ -2636,6 +2651,10 @@ void jxlenc_set_color_encoding(int enabled, uint32_t white_point, uint32_t prima
   for (int i = 0; i < 8; i++) jxe::g_color.xy[i] = xy8 ? xy8[i] : 0;
 }
 void jxlenc_set_reference_frame(int slot) { jxe::g_reference_slot = slot; }
+// The next frame is a kDCFrame of `level` (1..4; 0 = a regular frame again) / the next VarDCT frame takes its DC image from
+// the DC frame before it (kUseDcFrame). Test aids, not thread-safe.
+void jxlenc_set_dc_frame(int level) { jxe::g_dc_frame_level = level >= 1 && level <= 4 ? level : 0; }
+void jxlenc_set_use_dc_frame(int on) { jxe::g_use_dc_frame = on != 0; }
 void jxlenc_set_image_size(uint32_t w, uint32_t h) {
   jxe::g_image_w = w;
   jxe::g_image_h = h;

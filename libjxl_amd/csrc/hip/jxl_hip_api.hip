@@ -798,8 +798,13 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   jxlhip::SigmaParams sigma_p;
   const bool dev_smooth = d->dc_smoothing != 0 && c->xb > 2 && c->yb > 2;  // (compressed_dc.cc:134: smaller images are left alone)
   const bool dev_sigma = !d->inv_sigma && d->epf_iters > 0;
-  if (!d->dc || (dev_sigma && !d->sharpness)) return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (dev_smooth) {
+  if ((!d->dc && !d->dc_device) || (dev_sigma && !d->sharpness)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (d->dc_device) {  // the planes of a DC frame decoded earlier (kUseDcFrame): used where they are, never smoothed
+    if (!c->dc.view) c->dc.Free();
+    c->dc.p = const_cast<float*>(d->dc_device);
+    c->dc.cap = nblk * 3 * 4;
+    c->dc.view = true;
+  } else if (dev_smooth) {
     for (int ch = 0; ch < 3; ch++)
       if (!(d->dc_step[ch] > 0.0f)) return JXLHIP_ERR_INVALID_ARGUMENT;
     if ((r = Upload(c, c->dc_raw, d->dc, nblk * 3 * 4))) return r;
@@ -1202,7 +1207,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->epf_pass2 = d->epf_pass2_sigma_scale;
   c->epf_border = d->epf_border_sad_mul;
   c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = false;
-  if ((r = BlobEnd(c, dev_smooth ? &smooth_p : nullptr, dev_sigma ? &sigma_p : nullptr))) return r;  // (records the staging block's event on the copy stream)
+  if ((r = BlobEnd(c, dev_smooth && !d->dc_device ? &smooth_p : nullptr, dev_sigma ? &sigma_p : nullptr))) return r;  // (records the staging block's event on the copy stream)
   // The tables are resident when the call returns (batch launches over this context run on other contexts' streams).
   // (Leaving the copies of many contexts in flight at once instead, ordered by events, made every later kernel of the
   // process ~1.35x slower on this runtime: scripts/async_probe.py.)
@@ -3172,8 +3177,10 @@ struct JxlHipCanvas {
   bool has_alpha = false, premultiplied = false;
   Buf cur, slot[4], pixels;
   bool slot_valid[4] = {false, false, false, false};
-  Buf xyb[4];  // reference frames kept before the colour transform: [3][xyb_h][xyb_w]
-  uint32_t xyb_w[4] = {0, 0, 0, 0}, xyb_h[4] = {0, 0, 0, 0};
+  // frames kept before the colour transform, [3][xyb_h][xyb_w]: 0..3 the reference slots (patch sources), 4..7 the DC
+  // frames of level 1..4 (passes_state.h:90 dc_frames: the DC image of a later frame with kUseDcFrame)
+  Buf xyb[8];
+  uint32_t xyb_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xyb_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   hipStream_t last_stream = nullptr;  // the stream of the last blend: later work on the canvas is ordered behind it
 };
 
@@ -3208,7 +3215,7 @@ void jxlhip_canvas_destroy(JxlHipCanvas* v) {
 }
 
 int jxlhip_canvas_save_xyb(JxlHipCanvas* v, JxlHipContext* c, uint32_t slot) {
-  if (!v || !c || slot > 3 || c->device != v->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!v || !c || slot > 7 || c->device != v->device) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(v->device));
   {
     int pw = ApplyPendingWait(c);
@@ -3243,13 +3250,13 @@ int jxlhip_canvas_save_xyb(JxlHipCanvas* v, JxlHipContext* c, uint32_t slot) {
   HIP_TRY(hipStreamSynchronize(c->stream));  // (later frames read the slot from other streams of other contexts)
   v->xyb_w[slot] = w;
   v->xyb_h[slot] = h;
-  v->slot_valid[slot] = false;  // (the slot now holds a frame saved BEFORE the colour transform: not a blending source)
+  if (slot < 4) v->slot_valid[slot] = false;  // (the slot now holds a frame saved BEFORE the colour transform: not a blending source)
   v->last_stream = c->stream;
   return 0;
 }
 
 int jxlhip_canvas_xyb_source(JxlHipCanvas* v, uint32_t slot, const float** planes, uint32_t* xsize, uint32_t* ysize) {
-  if (!v || slot > 3 || !planes || !xsize || !ysize) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!v || slot > 7 || !planes || !xsize || !ysize) return JXLHIP_ERR_INVALID_ARGUMENT;
   *planes = v->xyb_w[slot] ? v->xyb[slot].as<float>() : nullptr;
   *xsize = v->xyb_w[slot];
   *ysize = v->xyb_h[slot];

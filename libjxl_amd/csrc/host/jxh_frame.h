@@ -62,6 +62,8 @@ struct FramePlan {
   // block (epf.cc:39-81), run on the device inside the upload (csrc/hip/jxl_hip_dc.h): the plan carries their inputs.
   std::vector<float> dc;            // 3 planes X, Y, B, dequantised, BEFORE adaptive smoothing
   bool dc_smoothing = false;        // the frame asks for the smoothing (no kSkipAdaptiveDCSmoothing)
+  bool use_dc_frame = false;        // kUseDcFrame: `dc` stays empty, the DC image is `dc_source` (device planes of a DC frame)
+  const float* dc_source = nullptr;  // [3][ysize_blocks][xsize_blocks] floats on the device (jxlamd_frame_set_dc_source)
   float dc_step[3] = {1, 1, 1};     // DC quantisation step per channel (the smoothing measures its gap in steps)
   std::vector<uint8_t> acs;         // (strategy << 1) | is_first
   std::vector<uint8_t> sharpness;   // EPF sharpness 0..7 per block
@@ -174,14 +176,20 @@ class FrameParser {
     BitReader br(data_ + pos, codestream_base_ + cs_size_ - pos);
     ReadFrameHeader(br, ih, &P.fh);
     const FrameHeader& fh = P.fh;
-    JXH_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
+    // (frame types: 1 = kDCFrame, decoded like any frame and kept before the colour transform as the DC image of a later
+    // frame; 2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
     JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
     JXH_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(ih.extra.empty() || fh.upsampling == 1, "unsupported: extra channels of upsampled frames");
-    JXH_CHECK(!(fh.flags & FrameHeader::kUseDcFrame), "unsupported: DC frames");
+    // kUseDcFrame (frame_header.h:348; passes_state.cc:62-77, dec_frame.cc:319-326,347-356): the DC image is the output
+    // of the DC frame of level fh.dc_level + 1 decoded earlier; the DC groups then carry no DC stream, the DC-derived block
+    // context is 0 everywhere and nothing is smoothed. The planes live on the device (FramePlan::dc_source).
+    P.use_dc_frame = (fh.flags & FrameHeader::kUseDcFrame) != 0;
+    JXH_CHECK(!P.use_dc_frame || fh.dc_level < 4, "invalid DC level for kUseDcFrame");
+    JXH_CHECK(fh.frame_type != 1 || ih.extra.empty(), "unsupported: DC frames of images with extra channels");
     JXH_CHECK(!(fh.flags & FrameHeader::kPatches) || fh.upsampling == 1, "unsupported: patches on upsampled frames");
     JXH_CHECK(!(fh.flags & FrameHeader::kSplines) || fh.upsampling == 1, "unsupported: splines on upsampled frames");
     JXH_CHECK(!(fh.flags & FrameHeader::kNoise) || fh.upsampling == 1, "unsupported: noise on upsampled frames");
@@ -421,7 +429,7 @@ class FrameParser {
     const size_t bx0 = gx * d.group_dim, by0 = gy * d.group_dim;
     const size_t bw = std::min(d.group_dim, d.xsize_blocks - bx0), bh = std::min(d.group_dim, d.ysize_blocks - by0);
     const size_t ndc = d.num_dc_groups, xb = d.xsize_blocks;
-    {
+    if (!P->use_dc_frame) {
       uint32_t extra_precision = uint32_t(br.Read(2));
       float mul = 1.0f / float(1 << extra_precision);
       MImage img;
@@ -518,7 +526,7 @@ class FrameParser {
   void FinalizeDc(FramePlan* P) {
     const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
     for (int c = 0; c < 3; c++) P->dc_step[c] = inv_quant_dc * dq_.dc_quant[c];
-    P->dc_smoothing = !(P->fh.flags & FrameHeader::kSkipDcSmoothing);
+    P->dc_smoothing = !(P->fh.flags & FrameHeader::kSkipDcSmoothing) && !P->use_dc_frame;
   }
 
   void AcGlobal(BitReader& br, FramePlan* P) {

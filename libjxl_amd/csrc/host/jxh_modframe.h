@@ -70,7 +70,7 @@ class ModFrameParser {
     ReadFrameHeader(br, ih, &P.fh);
     const FrameHeader& fh = P.fh;
     JXH_CHECK(fh.modular, "not a Modular frame");
-    JXH_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
+    // (1 = kDCFrame: kept before the colour transform as a later frame's DC image; 2 = kReferenceOnly; 3 = kSkipProgressive)
     // (where the frame sits on the canvas and how it blends: the caller's business, as for FrameParser::ParseFrame)
     JXH_CHECK(!fh.ycbcr, "unsupported: YCbCr Modular frames");
     JXH_CHECK(!(ih.xyb_encoded && ih.gray), "unsupported: grey XYB Modular frames");

@@ -104,7 +104,6 @@ static void DecodeDcGlobal(BitReader& br, FrameState* s) {
     DecodeSplines(br, s->dim.xsize * s->dim.ysize, &s->splines);
     s->has_splines = true;
   }
-  JXLO_CHECK(!(fh.flags & FrameHeader::kUseDcFrame), "unsupported: DC frames");
   if (fh.flags & FrameHeader::kNoise) {  // dec_frame.cc:294-296, dec_noise.cc:154-164: eight 10-bit LUT points
     for (float& v : s->noise_lut) v = float(br.Read(10)) / 1024.0f;
     s->has_noise = true;
@@ -194,7 +193,7 @@ static void DecodeDcGroup(BitReader& br, FrameState* s, size_t g) {
   const size_t bx0 = gx * d.group_dim, by0 = gy * d.group_dim;  // in blocks
   const size_t bw = std::min(d.group_dim, d.xsize_blocks - bx0), bh = std::min(d.group_dim, d.ysize_blocks - by0);
   const size_t ndc = d.num_dc_groups;
-  if (!s->fh.modular) {
+  if (!s->fh.modular && !(s->fh.flags & FrameHeader::kUseDcFrame)) {  // (dec_frame.cc:322-326: no DC stream with kUseDcFrame)
     // VarDCT DC: three channels in Y, X, B order (dec_modular.cc:427-465)
     uint32_t extra_precision = uint32_t(br.Read(2));
     float mul = 1.0f / float(1 << extra_precision);
@@ -310,7 +309,7 @@ static void FinalizeDc(FrameState* s) {
       }
   }
   // Adaptive DC smoothing (compressed_dc.cc:128-198)
-  if (!(s->fh.flags & FrameHeader::kSkipDcSmoothing) && xs > 2 && ys > 2) {
+  if (!(s->fh.flags & (FrameHeader::kSkipDcSmoothing | FrameHeader::kUseDcFrame)) && xs > 2 && ys > 2) {  // (dec_frame.cc:347-356)
     const float inv_global_scale = 65536.0f / float(s->global_scale);
     const float inv_quant_dc = inv_global_scale / float(s->quant_dc);
     float dcf[3];
@@ -488,7 +487,9 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   s->xyb_slots = xyb_slots;
   ReadFrameHeader(br, ih, &s->fh);
   const FrameHeader& fh = s->fh;
-  JXLO_CHECK(fh.frame_type != 1, "unsupported: DC frames");  // (2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
+  // (frame types: 1 = kDCFrame: rendered like any frame, kept before the colour transform as the DC image of a later
+  // frame, dec_cache.cc:221-224; 2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
+  JXLO_CHECK(fh.frame_type != 1 || ih.extra.empty(), "unsupported: DC frames of images with extra channels");
   JXLO_CHECK(fh.upsampling == 1 || !fh.modular, "unsupported: upsampled Modular frames");
   JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
   JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
@@ -508,6 +509,12 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   const size_t xb = d.xsize_blocks, yb = d.ysize_blocks;
   if (!fh.modular) {
     out->dc.assign(3 * xb * yb, 0.0f);
+    if (fh.flags & FrameHeader::kUseDcFrame) {  // passes_state.cc:62-77: the DC image is the DC frame of level dc_level + 1
+      JXLO_CHECK(fh.dc_level < 4 && xyb_slots, "invalid DC level for kUseDcFrame");
+      const XybSlot& dcf = xyb_slots[4 + fh.dc_level];
+      JXLO_CHECK(dcf.w == xb && dcf.h == yb, "kUseDcFrame: no DC frame of that level and size was decoded");
+      for (int c = 0; c < 3; c++) memcpy(out->dc.data() + c * xb * yb, dcf.p[c].data(), xb * yb * sizeof(float));
+    }
     out->acs.assign(xb * yb, 0xFF);
     out->quant.assign(xb * yb, 0);
     out->sharpness.assign(xb * yb, 0);
@@ -688,7 +695,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
         }
       }
     }
-    if (fh.frame_type == 2 || fh.save_before_color_transform) {  // what a later frame's patches read
+    if (fh.frame_type == 2 || fh.frame_type == 1 || fh.save_before_color_transform) {  // what a later frame's patches / DC read
       out->xyb_save.resize(3 * xs * ys);
       for (int c = 0; c < 3; c++)
         for (size_t y = 0; y < ys; y++) memcpy(out->xyb_save.data() + (c * ys + y) * xs, cur->p[c].data() + y * cur->stride, xs * sizeof(float));
@@ -733,7 +740,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       InitSplineDrawCache(&s->splines, xs, ys, s->base_corr_x, s->base_corr_b);
       DrawSplines(s->splines, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs, xs, ys);
     }
-    if (fh.frame_type == 2 || fh.save_before_color_transform) out->xyb_save = out->rgbf;
+    if (fh.frame_type == 2 || fh.frame_type == 1 || fh.save_before_color_transform) out->xyb_save = out->rgbf;
     if (ih.xyb_encoded) {  // then the colour stage of every XYB frame
       OpsinParams op = MakeOpsinParams(ih);
       for (size_t i = 0; i < xs * ys; i++) {
@@ -816,7 +823,7 @@ static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dum
     std::vector<float> p[4];
     bool valid = false;
   } slots[4];
-  XybSlot xyb_slots[4];
+  XybSlot xyb_slots[8];  // 0..3 reference slots, 4..7 the DC frames of level 1..4 (passes_state.h:90)
   size_t visible = 0, nonvisible = 0;
   JXLO_CHECK(!want_preview || ih.have_preview, "the image has no preview");
   if (ih.have_preview) {
@@ -842,7 +849,13 @@ static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dum
       slot.h = out->out_ysize;
       for (int c = 0; c < 3; c++) slot.p[c].assign(out->xyb_save.begin() + c * slot.w * slot.h, out->xyb_save.begin() + (c + 1) * slot.w * slot.h);
     }
-    if (fh.frame_type == 2) {  // never shown, never blended
+    if (fh.frame_type == 1) {
+      XybSlot& slot = xyb_slots[4 + fh.dc_level - 1];
+      slot.w = out->out_xsize;
+      slot.h = out->out_ysize;
+      for (int c = 0; c < 3; c++) slot.p[c].assign(out->xyb_save.begin() + c * slot.w * slot.h, out->xyb_save.begin() + (c + 1) * slot.w * slot.h);
+    }
+    if (fh.frame_type == 2 || fh.frame_type == 1) {  // never shown, never blended
       nonvisible++;
       *out = Decoded();
       out->ih = ih;

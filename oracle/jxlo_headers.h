@@ -277,6 +277,7 @@ struct BlendInfo {
 
 struct FrameHeader {
   uint32_t frame_type = 0;  // 0 regular, 1 DC frame, 2 reference only, 3 skip progressive
+  uint32_t dc_level = 0;    // 1..4 for a DC frame (it becomes the DC image of level dc_level - 1), else 0
   bool modular = false;
   uint64_t flags = 0;
   bool ycbcr = false;
@@ -391,7 +392,11 @@ static inline void ReadFrameHeader(BitReader& br, const ImageHeader& ih, FrameHe
       for (uint32_t i = 0; i < num_ds; i++) ReadU32(br, Val(0), Val(1), Val(2), Bits(3));
     }
   }
-  if (f->frame_type == 1) ReadU32(br, Val(1), Val(2), Val(3), Val(4));  // dc_level
+  if (f->frame_type == 1) {  // frame_header.cc:310-318, frame_header.h:470-476: a DC frame has the image's size / 8^level
+    f->dc_level = ReadU32(br, Val(1), Val(2), Val(3), Val(4));
+    f->xsize = DivCeil(f->xsize, size_t(1) << (3 * f->dc_level));
+    f->ysize = DivCeil(f->ysize, size_t(1) << (3 * f->dc_level));
+  }
   bool partial = false;
   if (f->frame_type != 1) {
     f->custom_size = br.ReadBool();
