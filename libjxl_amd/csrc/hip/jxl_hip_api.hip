@@ -56,12 +56,17 @@ inline hipError_t WaitEvent(hipEvent_t ev) {
 
 // JXLHIP_GUARD=1 (debug aid, read at every allocation): every device buffer gets a guard band either side, filled with a
 // pattern that jxlhip_check_guards() verifies: stray WRITES of a kernel next to its buffers show up in a test instead of
-// silently landing in a neighbour (stray reads still only show as faults).
+// silently landing in a neighbour. Stray READS: the pattern is JXLHIP_GUARD_BYTE (default 0xA5), and a fresh allocation is
+// filled with it as a whole; a decode whose result changes with the pattern has read a guard band or memory nothing wrote
+// (tests/test_gpu_parity.py::test_no_result_depends_on_bytes_outside_the_buffers runs the kernels under three patterns).
 constexpr size_t kGuardBytes = 4096;
-constexpr int kGuardByte = 0xA5;
 inline bool GuardOn() {
   const char* e = getenv("JXLHIP_GUARD");
   return e && *e && atoi(e) != 0;
+}
+inline int GuardByte() {
+  const char* e = getenv("JXLHIP_GUARD_BYTE");
+  return e && *e ? (int(strtol(e, nullptr, 0)) & 0xFF) : 0xA5;
 }
 
 struct Buf {
@@ -69,6 +74,7 @@ struct Buf {
   size_t cap = 0;
   bool view = false;  // p points into another allocation (a frame's table blob): nothing to free
   void* base = nullptr;  // the allocation when it has guard bands (p = base + kGuardBytes), else NULL
+  int guard_byte = 0xA5;  // the pattern its bands were filled with
   int Ensure(size_t n) {
     if (view) {
       p = nullptr;
@@ -86,8 +92,8 @@ struct Buf {
     if (GuardOn()) {
       want = (want + 255) & ~size_t(255);
       hipError_t e = hipMalloc(&base, want + 2 * kGuardBytes);
-      if (e == hipSuccess) e = hipMemset(base, kGuardByte, kGuardBytes);
-      if (e == hipSuccess) e = hipMemset(static_cast<uint8_t*>(base) + kGuardBytes + want, kGuardByte, kGuardBytes);
+      guard_byte = GuardByte();
+      if (e == hipSuccess) e = hipMemset(base, guard_byte, want + 2 * kGuardBytes);  // (bands and body: see GuardByte)
       if (e != hipSuccess) {
         if (base) (void)hipFree(base);
         base = nullptr;
@@ -119,8 +125,8 @@ struct Buf {
     if (hipMemcpy(h.data() + kGuardBytes, static_cast<uint8_t*>(base) + kGuardBytes + cap, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return 3;
     int r = 0;
     for (size_t i = 0; i < kGuardBytes; i++) {
-      if (h[i] != kGuardByte) r |= 1;
-      if (h[kGuardBytes + i] != kGuardByte) r |= 2;
+      if (h[i] != guard_byte) r |= 1;
+      if (h[kGuardBytes + i] != guard_byte) r |= 2;
     }
     return r;
   }

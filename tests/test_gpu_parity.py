@@ -522,6 +522,48 @@ def test_no_kernel_writes_outside_its_buffers(built, monkeypatch):
             f.close()
 
 
+def test_no_result_depends_on_bytes_outside_the_buffers(built, monkeypatch):
+    """Stray READS: with JXLHIP_GUARD=1 a fresh device allocation is filled, guard bands and
+    body, with JXLHIP_GUARD_BYTE. The same tour of the kernels is decoded under three patterns (0xA5, 0x00, 0xFF = NaN as a
+    float): every output (coefficients, inverse-transform planes, pixels; Modular samples) must be identical, so no kernel's
+    result depends on what lies outside its buffers (up to 4 KiB either side) or on memory nothing has written."""
+    import hashlib
+    J = built
+    monkeypatch.setenv("JXLHIP_GUARD", "1")
+    cases = [((257, 255), dict()), ((520, 300), dict(distance=4.5, gab=0, epf_iters=3)), ((300, 200), dict(upsampling=4)),
+             ((520, 300), dict(num_passes=2)), ((300, 280), dict(ac_code_mode=3)), ((600, 400), dict(noise=40)),
+             ((777, 513), dict(strategy_mode=2, random_cmap=1))]
+    streams = [J.encode_rgb8(J.synth_image(size[0], size[1], seed=5), **kw) for size, kw in cases]
+    lossless = [J.encode_lossless(J.synth_image(700, 300, seed=4), flags) for flags in (0, 16 | 4 | 8, 1 | 2 | 16)]
+
+    def tour():
+        out = []
+        for data in streams:
+            f = J.Frame(data, threads=2)
+            c = J.HipContext()
+            try:
+                c.upload(f)
+                c.run_all()
+                c.sync()
+                assert c.check_guards() == 0
+                h = hashlib.sha256()
+                for a in (c.download("coeffs"), c.download("xyb_idct"), c.rgb8()):
+                    h.update(np.ascontiguousarray(a).tobytes())
+                out.append(h.hexdigest())
+            finally:
+                c.close()
+                f.close()
+        for data in lossless:
+            out.append(hashlib.sha256(J.decode_lossless(data).tobytes()).hexdigest())
+        return out
+
+    results = []
+    for byte in ("0xA5", "0x00", "0xFF"):
+        monkeypatch.setenv("JXLHIP_GUARD_BYTE", byte)
+        results.append(tour())
+    assert results[0] == results[1] == results[2], [i for i in range(len(results[0])) if len({r[i] for r in results}) > 1]
+
+
 def test_corrupt_sections_are_flagged_not_fatal(built):
     J = built
     data = bytearray(J.encode_rgb8(J.synth_image(520, 300)))
