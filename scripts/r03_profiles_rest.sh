@@ -1,0 +1,25 @@
+#!/bin/bash
+# The counter / probe part of the round-3 profile set on its own (run on the GPU box after scripts/profile_round.sh's kernel
+# statistics are in): HBM traffic per kernel, the lane kernel's cycle split and SQ counters, isolated stage launches.
+set -x
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=gpurun_out/r03/profiles
+mkdir -p $R/$OUT
+cd $R
+( while true; do date >> $R/$OUT/heartbeat.txt; sleep 45; done ) &
+HB=$!
+trap "kill $HB" EXIT
+RAW=/tmp/prof_raw_$$
+mkdir -p $RAW
+export TMPDIR=/tmp
+PMCBENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0"
+( cd /tmp && rocprofv3 --output-format csv --kernel-include-regex "jxlhip" --pmc FETCH_SIZE -d $RAW/f -o f -- $PMCBENCH > $R/$OUT/pmc_bench.json 2> $RAW/f.log )
+( cd /tmp && rocprofv3 --output-format csv --kernel-include-regex "jxlhip" --pmc WRITE_SIZE -d $RAW/w -o w -- $PMCBENCH > /dev/null 2> $RAW/w.log )
+python3 $R/scripts/pmc_summary.py $(find $RAW/f -name "*counter_collection.csv" | head -1) $(find $RAW/w -name "*counter_collection.csv" | head -1) $R/$OUT/r03_pmc_traffic.json 640
+tail -3 $RAW/f.log
+JXLHIP_LANES_PROF=1 python3 scripts/r03_entropy_probe.py 640 base 2>&1 | grep "lanes prof" | tail -1 | sed 's/^\[lanes prof\] //' > $R/$OUT/r03_entropy_split.json
+python3 scripts/r03_stage_times.py 256 base 2>&1 | tail -4 > $R/$OUT/r03_stage_times.txt
+bash scripts/r03_pmc_probe.sh $OUT/pmc 640 > /dev/null 2>&1
+cp $R/$OUT/pmc/summary.txt $R/$OUT/r03_sq_counters_entropy.txt
+rm -rf $RAW
+ls -la $R/$OUT
