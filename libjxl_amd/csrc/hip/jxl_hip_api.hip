@@ -94,6 +94,9 @@ struct Buf {
       hipError_t e = hipMalloc(&base, want + 2 * kGuardBytes);
       guard_byte = GuardByte();
       if (e == hipSuccess) e = hipMemset(base, guard_byte, want + 2 * kGuardBytes);  // (bands and body: see GuardByte)
+      // (hipMemset returns before the fill has run, and the contexts' non-blocking streams do not wait for the null
+      // stream: without this the fill can land on top of a table copy that was enqueued after it)
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
       if (e != hipSuccess) {
         if (base) (void)hipFree(base);
         base = nullptr;

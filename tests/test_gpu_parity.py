@@ -525,8 +525,9 @@ def test_no_kernel_writes_outside_its_buffers(built, monkeypatch):
 def test_no_result_depends_on_bytes_outside_the_buffers(built, monkeypatch):
     """Stray READS: with JXLHIP_GUARD=1 a fresh device allocation is filled, guard bands and
     body, with JXLHIP_GUARD_BYTE. The same tour of the kernels is decoded under three patterns (0xA5, 0x00, 0xFF = NaN as a
-    float): every output (coefficients, inverse-transform planes, pixels; Modular samples) must be identical, so no kernel's
-    result depends on what lies outside its buffers (up to 4 KiB either side) or on memory nothing has written."""
+    float): every output (inverse-transform planes, pixels; Modular samples) must be identical, so no kernel's result
+    depends on what lies outside its buffers (up to 4 KiB either side) or on memory nothing has written. (The coefficient
+    buffer itself is not compared: the tail of a partial group's area is never written, nor read.)"""
     import hashlib
     J = built
     monkeypatch.setenv("JXLHIP_GUARD", "1")
@@ -547,7 +548,7 @@ def test_no_result_depends_on_bytes_outside_the_buffers(built, monkeypatch):
                 c.sync()
                 assert c.check_guards() == 0
                 h = hashlib.sha256()
-                for a in (c.download("coeffs"), c.download("xyb_idct"), c.rgb8()):
+                for a in (c.download("xyb_idct"), c.rgb8()):
                     h.update(np.ascontiguousarray(a).tobytes())
                 out.append(h.hexdigest())
             finally:
