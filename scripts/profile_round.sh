@@ -23,8 +23,8 @@ cp $(find $RAW/iso -name "*kernel_stats.csv" | head -1) $R/$OUT/${TAG}_kernel_st
 ( while true; do date >> $R/$OUT/heartbeat.txt; sleep 45; done ) &
 HB=$!
 PMCBENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0 $@"
-rocprofv3 --output-format csv --kernel-include-regex "jxlhip" --pmc FETCH_SIZE -d $RAW/f -o f -- $PMCBENCH > /dev/null 2> $RAW/f.log
-rocprofv3 --output-format csv --kernel-include-regex "jxlhip" --pmc WRITE_SIZE -d $RAW/w -o w -- $PMCBENCH > /dev/null 2> $RAW/w.log
+rocprofv3 --output-format csv --kernel-include-regex "k_entropy|k_idct|k_filter|k_dct|k_special|k_color" --pmc FETCH_SIZE -d $RAW/f -o f -- $PMCBENCH > /dev/null 2> $RAW/f.log
+rocprofv3 --output-format csv --kernel-include-regex "k_entropy|k_idct|k_filter|k_dct|k_special|k_color" --pmc WRITE_SIZE -d $RAW/w -o w -- $PMCBENCH > /dev/null 2> $RAW/w.log
 kill $HB
 # frames per launch: what the bench line of this very run says (not a literal: --batch may be among the arguments)
 FRAMES=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['config']['frames_per_step_per_gpu'])" $R/$OUT/${TAG}_bench.json)

@@ -14,7 +14,7 @@ P2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACT
 P3="GRBM_GUI_ACTIVE SQ_IFETCH SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM"
 i=1
 for P in "$P1" "$P2" "$P3"; do
-  rocprofv3 --output-format csv --kernel-trace --kernel-include-regex "jxlhip" --pmc $P -d $RAW/p$i -o p$i -- python3 $R/scripts/r03_entropy_probe.py $BATCH ${PROBE_CFG:-base} > $RAW/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --output-format csv --kernel-trace --kernel-include-regex "k_entropy|k_idct|k_filter|k_dct|k_special|k_color" --pmc $P -d $RAW/p$i -o p$i -- python3 $R/scripts/r03_entropy_probe.py $BATCH ${PROBE_CFG:-base} > $RAW/p$i.log 2>&1 || echo "pass $i failed"
   tail -2 $RAW/p$i.log | cut -c1-300
   i=$((i+1))
 done
