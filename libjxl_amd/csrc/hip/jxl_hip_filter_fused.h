@@ -566,8 +566,15 @@ __device__ __forceinline__ P2 BufP2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uin
   return P2{f.x, f.y};
 }
 
-template <bool U8SRGB>
+// EPF = 2 (two iterations: what encoders choose between d1.5 and d4): the EPF1 outputs are not emitted but kept in one
+// more ring of rows, and the last stage (stage_epf.cc:369-494: four plus-shaped neighbours, single-point SADs) runs on
+// them one row behind, with one more halo row and the fourth halo column the pair layout already had. Rows just outside
+// the frame are EPF1 outputs of mirrored inputs with sigma and block-border flag taken at the mirrored row, which is the
+// mirrored EPF1 output (the filters are reflection-symmetric).
+template <bool U8SRGB, int EPF = 1>
 __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFilterParams* params, int strip_rows) {
+  static_assert(EPF == 1 || EPF == 2, "Gaborish + one or two EPF iterations");
+  constexpr int HALO = kRowsHalo + (EPF == 2 ? 1 : 0);
   FusedFilterParams P;
   LoadParams(P, params + blockIdx.z);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -606,20 +613,22 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
   // sliding windows as rings of 4 rows indexed with the step's phase (the row loop is unrolled by 4): a window shift is a
   // renaming, not register moves
   P2 p[3][4], h1[3][4], g[3][4], dh[4], dv[4];
+  P2 e[3][4];            // EPF == 2: the EPF1 outputs of the last rows
+  float is_prev = 0.0f;  // EPF == 2: 1 / sigma of the row before the current EPF1 row (the row the last stage emits)
   P2 pv_prev = zero2, dh_new = zero2;
 #pragma unroll
   for (int c = 0; c < 3; c++) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) p[c][k] = h1[c][k] = g[c][k] = zero2;
+    for (int k = 0; k < 4; k++) p[c][k] = h1[c][k] = g[c][k] = e[c][k] = zero2;
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) dh[k] = dv[k] = zero2;
-  const int steps = (y1 - y0 + 2 * kRowsHalo + 3) / 4 * 4;  // whole groups of 4 steps (the extra steps emit nothing)
+  const int steps = (y1 - y0 + 2 * HALO + 3) / 4 * 4;  // whole groups of 4 steps (the extra steps emit nothing)
   // the mirrored input row as a state machine: image_ops.h:184-196 maps ..., -2, -1, 0, 1, ... to ..., 1, 0, 0, 1, ...
   // (and likewise at the far end), a triangle wave whose turning samples repeat; (ym, ydir) walks it one row per step
-  int ym = MirrorI(y0 - kRowsHalo, ys), ydir;
+  int ym = MirrorI(y0 - HALO, ys), ydir;
   {
-    const int ym_next = MirrorI(y0 - kRowsHalo + 1, ys);
+    const int ym_next = MirrorI(y0 - HALO + 1, ys);
     ydir = ym_next > ym ? 1 : (ym_next < ym ? -1 : (ym == 0 ? -1 : 1));
   }
   auto load_row = [&](P2 (&dst)[3]) {  // row ym, then advance the state machine
@@ -643,8 +652,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
   };
   // everything a step reads from memory is loaded one step ahead (see k_filter_rows), unconditionally: rows outside the
   // strip's output range are clamped into the frame and their values never used
-  auto load_aux = [&](int r, float& is, P2 (&di)[3]) {
-    const int rc = r < 0 ? 0 : (r >= ys ? ys - 1 : r);
+  // (rs: the row whose sigma the next step's EPF1 row needs; r: the row the next step emits, for the dither cells)
+  auto load_aux = [&](int rs, int r, float& is, P2 (&di)[3]) {
+    const int rc = rs < 0 ? 0 : (rs >= ys ? ys - 1 : rs);
     is = BufF32(sig_buf, vsig, uint32_t(rc >> 3) * uint32_t(P.f.xb) * 4u);
     if (!has_rgb) return;
     di[0] = BufP2(dither_buf, vd0, uint32_t(r & 31) * 128u);
@@ -654,7 +664,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
   P2 nx[3], ndi[3] = {zero2, zero2, zero2};
   float nis = 0.0f;
   load_row(nx);
-  load_aux(y0 - 2 * kRowsHalo, nis, ndi);
+  load_aux(y0 - 2 * HALO + (EPF == 2 ? 1 : 0), y0 - 2 * HALO, nis, ndi);
   auto step = [&](auto phase, int j) {
     constexpr int PH = decltype(phase)::value;
     // ring slots: N = newest (written in this step), M1 / M2 / M3 = one / two / three rows older
@@ -662,9 +672,12 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
     const P2 cur[3] = {nx[0], nx[1], nx[2]};
     const float is = nis;
     const P2 di[3] = {ndi[0], ndi[1], ndi[2]};
-    const int r = y0 - 2 * kRowsHalo + j;  // output row of this step, valid from step 6 (inside the frame then: r == its mirror)
+    // r: the row this step emits (inside the frame when it does: r == its mirror); r1: the row whose EPF1 output this
+    // step forms (EPF == 1: the same row; EPF == 2: one further, from y0 - 1 to y1, i.e. possibly one row outside the frame)
+    const int r = y0 - 2 * HALO + j;
+    const int r1 = EPF == 2 ? r + 1 : r;
     load_row(nx);
-    load_aux(r + 1, nis, ndi);
+    load_aux(r1 + 1, r + 1, nis, ndi);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       p[c][N] = cur[c];
@@ -700,13 +713,14 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
     };
     const P2 pv = plus_sum(dv);
     const P2 ph = plus_sum(dh);
-    if (j >= 2 * kRowsHalo && r < y1) {
+    if (EPF == 2 ? (j >= 2 * HALO - 2 && r1 <= y1) : (j >= 2 * HALO && r < y1)) {
       P2 o[3] = {g[0][M2], g[1][M2], g[2][M2]};
       {
         // no branch on the lane's sigma here: the DPP reads below must see their neighbours whatever the neighbours' own
         // sigma is (a lane switched off by a divergent branch reads as 0); the unfiltered pixels are selected at the end
         const bool keep = is < -3.90524291751269967465540850526868f;  // sigma too small: pixels unchanged (the pair shares a block)
-        const bool yb = ((r & 7) == 0) || ((r & 7) == 7);
+        const int rm1 = EPF == 2 ? (r1 < 0 ? -1 - r1 : (r1 >= ys ? 2 * ys - 1 - r1 : r1)) : r;  // (the EPF1 row, mirrored into the frame)
+        const bool yb = ((rm1 & 7) == 0) || ((rm1 & 7) == 7);
         const P2 inv_sig = P2{is * ((xb0 || yb) ? P.bsm[1] : P.sm[1]), is * ((xb1 || yb) ? P.bsm[1] : P.sm[1])};
         // neighbours in the reference's order: up, left, right, down (SADs pv_prev, ph of column x - 1, ph, pv)
         P2 wk[4];
@@ -732,6 +746,46 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
           a = wk[3] * g[c][M1] + a;
           o[c] = P2{keep ? oc.x : a.x * inv_w.x, keep ? oc.y : a.y * inv_w.y};
         }
+      }
+      if constexpr (EPF == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) e[c][N] = o[c];
+      }
+     if (EPF == 1 || (j >= 2 * HALO && r < y1)) {
+      if constexpr (EPF == 2) {
+        // the last stage on rows r - 1 (M2), r (M1), r + 1 (N) of the EPF1 outputs; neighbours in the reference's order: up,
+        // left, right, down; a neighbour's weight from the three channels' differences at that one position
+        const float is2 = is_prev;
+        const bool keep2 = is2 < -3.90524291751269967465540850526868f;
+        const bool yb2 = ((r & 7) == 0) || ((r & 7) == 7);
+        const P2 inv_sig2 = P2{is2 * ((xb0 || yb2) ? P.bsm[2] : P.sm[2]), is2 * ((xb1 || yb2) ? P.bsm[2] : P.sm[2])};
+        P2 nb[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          const P2 cc = e[c][M1];
+          nb[0][c] = e[c][M2];
+          nb[1][c] = P2{FromLeft(cc.y), cc.x};
+          nb[2][c] = P2{cc.y, FromRight(cc.x)};
+          nb[3][c] = e[c][N];
+        }
+        P2 wsum = P2{1.0f, 1.0f};
+        P2 acc[3] = {e[0][M1], e[1][M1], e[2][M1]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          P2 sad = zero2;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            sad.x = __builtin_fabsf(nb[k][c].x - e[c][M1].x) * P.f.ch_scale[c] + sad.x;
+            sad.y = __builtin_fabsf(nb[k][c].y - e[c][M1].y) * P.f.ch_scale[c] + sad.y;
+          }
+          const P2 wk2 = Max0(sad * inv_sig2 + 1.0f);
+          wsum = wsum + wk2;
+#pragma unroll
+          for (int c = 0; c < 3; c++) acc[c] = wk2 * nb[k][c] + acc[c];
+        }
+        const P2 inv_w2 = P2{__builtin_amdgcn_rcpf(wsum.x), __builtin_amdgcn_rcpf(wsum.y)};
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[c] = P2{keep2 ? e[c][M1].x : acc[c].x * inv_w2.x, keep2 ? e[c][M1].y : acc[c].y * inv_w2.y};
       }
       if (emit0) {
         if (!U8SRGB && filtered) {
@@ -807,7 +861,9 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
           }
         }
       }
+     }
     }
+    if constexpr (EPF == 2) is_prev = is;
     pv_prev = pv;
   };
   for (int j = 0; j < steps; j += 4) {
