@@ -110,7 +110,13 @@ def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
                J.encode_rgb8(img, ac_code_mode=3, num_passes=2, custom_orders=1, custom_bctx=1, noise=50), J.encode_rgb8(img, upsampling=2),
                J.encode_lossless(img, J.LOSSLESS_RCT | J.LOSSLESS_SQUEEZE | J.LOSSLESS_WP),
                J.encode_lossless(np.dstack([img, img[..., 1]]), J.LOSSLESS_RCT), J.encode_animation(frames, [1, 2]),
-               J.encode_animation(frames, [1, 2], lossless=True), with_icc, oriented]
+               J.encode_animation(frames, [1, 2], lossless=True), with_icc, oriented,
+               J.encode_with_dc_frame(img), J.encode_with_dc_frame(img, dc_vardct=True)]
+    J.set_custom_upsampling(7, seed=3)
+    try:
+        streams.append(J.encode_rgb8(img, upsampling=4))
+    finally:
+        J.set_custom_upsampling(0)
     files = []
     for i, s in enumerate(streams):
         files.append(os.path.join(str(tmp_path), "s%d.jxl" % i))
@@ -147,7 +153,8 @@ def test_decoder_api_under_sanitizers_on_damaged_files(built, tmp_path):
                                dict(img=np.dstack([patch, ramp]), x0=-10, y0=100, mode=2, alpha_mode=2, source=1)], lossless=True)
     files = []
     for i, s in enumerate([J.encode_rgb8(img), R.container(J.encode_rgb8(img)), R.container(with_icc, pieces=3), anim,
-                           R.container(anim, pieces=4), R.container(J.encode_lossless(img), pieces=1), layered]):
+                           R.container(anim, pieces=4), R.container(J.encode_lossless(img), pieces=1), layered,
+                           J.encode_with_dc_frame(img)]):
         files.append(os.path.join(str(tmp_path), "f%d.jxl" % i))
         open(files[-1], "wb").write(s)
     r = subprocess.run([out, "60"] + files, capture_output=True, text=True, timeout=900)
