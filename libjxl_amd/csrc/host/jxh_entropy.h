@@ -530,8 +530,8 @@ class SymbolReader {
   // `n` values of one clustered context in a row, handed to sink(i, value) in order. rANS codes without LZ77 run with the
   // state and the bit position in locals and ONE unaligned 8-byte load per value (a value consumes at most 16 bits of
   // state refill + 32 extra bits out of the >= 57 the load provides), both conditionals as selects: the chain per value is
-  // load -> alias entry -> multiply, not the byte-wise Peek of the general reader. Values the loads cannot cover (the last
-  // eight bytes of the section) and every other kind of code go through ReadClustered. Same values, same final position.
+  // load -> alias entry -> multiply, not the byte-wise Peek of the general reader. Every other kind of code goes through
+  // ReadClustered. Same values, same final position (bytes past the section read as zero, like BitReader::Peek).
   template <class Sink>
   void ReadRun(size_t cluster, size_t n, Sink&& sink) {
     size_t i = 0;
@@ -545,9 +545,15 @@ class SymbolReader {
       const AliasEntry* const tab = c_->alias.data() + (cluster << c_->log_alpha);
       const HybridCfg cfg = c_->cfg[cluster];
       const uint32_t in_token = cfg.msb + cfg.lsb, lsb_mask = (1u << cfg.lsb) - 1, msb_mask = (1u << cfg.msb) - 1;
-      while (i < n && (pos >> 3) + 8 <= size) {
+      while (i < n) {
         uint64_t w;
-        memcpy(&w, data + (pos >> 3), 8);
+        const size_t byte = pos >> 3;
+        if (byte + 8 <= size) {
+          memcpy(&w, data + byte, 8);
+        } else {  // the section's last bytes (a channel of zero-entropy symbols can sit there whole): zero-extended
+          w = 0;
+          for (size_t b = 0; b < 8 && byte + b < size; b++) w |= uint64_t(data[byte + b]) << (8 * b);
+        }
         w >>= (pos & 7);
         const uint32_t res = state & (kAnsTab - 1);
         const uint32_t slot = res >> log_entry, p = res & pos_mask;
