@@ -94,7 +94,9 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
             fr.close()
         ncpu_eff = max(1.0, min(float(ncpu), (time.process_time() - c0) / (time.perf_counter() - w0)))
     parse_threads = 1  # one frame per thread: frames in parallel, not DC groups in parallel
-    parsers = max(1, min(64, int(round(ncpu_eff)) - 2))
+    # (the calibration is noisy on a shared box: 8.4, 6.0 and 5.7 for the same share in three runs. Too few parser threads
+    # starve the pipeline, a few too many only time-slice: never fewer than 8.)
+    parsers = max(8, min(64, int(round(ncpu_eff))))
     movers = 4 if ncpu_eff >= 8 else (2 if ncpu_eff >= 4 else 1)  # threads of the upload pool and of the download pool
     movers = int(os.environ.get("JXLAMD_E2E_MOVERS", movers))  # (measurement aid)
     parsers = int(os.environ.get("JXLAMD_E2E_PARSERS", parsers))
