@@ -22,6 +22,7 @@ cp $(find $RAW/iso -name "*kernel_stats.csv" | head -1) $R/$OUT/${TAG}_kernel_st
 # looking hung to the GPU box's silence watchdog while rocprofv3 writes only under /tmp)
 ( while true; do date >> $R/$OUT/heartbeat.txt; sleep 45; done ) &
 HB=$!
+export JXLHIP_ENTROPY_GATE=0  # (counter collection serialises the kernels: a gated launch would wait for one that cannot start)
 PMCBENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0 $@"
 rocprofv3 --output-format csv --kernel-include-regex "k_entropy|k_idct|k_filter|k_dct|k_special|k_color" --pmc FETCH_SIZE -d $RAW/f -o f -- $PMCBENCH > /dev/null 2> $RAW/f.log
 rocprofv3 --output-format csv --kernel-include-regex "k_entropy|k_idct|k_filter|k_dct|k_special|k_color" --pmc WRITE_SIZE -d $RAW/w -o w -- $PMCBENCH > /dev/null 2> $RAW/w.log

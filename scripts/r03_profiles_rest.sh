@@ -12,6 +12,7 @@ trap "kill $HB" EXIT
 RAW=/tmp/prof_raw_$$
 mkdir -p $RAW
 export TMPDIR=/tmp
+export JXLHIP_ENTROPY_GATE=0  # (counter collection serialises the kernels: a gated launch would wait for one that cannot start)
 PMCBENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0"
 ( cd /tmp && timeout -k 10 300 rocprofv3 --output-format csv --kernel-include-regex "k_entropy|k_idct|k_filter|k_dct|k_special|k_color" --pmc FETCH_SIZE -d $RAW/f -o f -- $PMCBENCH > $R/$OUT/pmc_bench.json 2> $RAW/f.log )
 ( cd /tmp && timeout -k 10 300 rocprofv3 --output-format csv --kernel-include-regex "k_entropy|k_idct|k_filter|k_dct|k_special|k_color" --pmc WRITE_SIZE -d $RAW/w -o w -- $PMCBENCH > /dev/null 2> $RAW/w.log )
