@@ -757,7 +757,7 @@ def test_filter_kernels_against_a_float64_third_reading(built, kw):
     assert np.abs(got - want).max() < 2e-5
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(epf_iters=3), dict(gab=0, epf_iters=2)])
+@pytest.mark.parametrize("kw", [dict(), dict(epf_iters=3), dict(gab=0, epf_iters=2), dict(epf_iters=2)])
 def test_bands_with_halo_exchange_match_the_whole_frame(built, kw):
     """The multi-GPU band split without redundant decoding (option "band_halo", jxlhip_halo_*): three bands of
     a 700x1500 frame (6 rows of groups), each in a context of its own that entropy-decodes and transforms ONLY its own
