@@ -307,12 +307,21 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         // as that trip knows its new state, bit position and context, ahead of its own bookkeeping (coefficient chunk,
         // store, end-of-channel test): a lone wave has nothing else to cover the LDS round trip with. The group's first trip
         // requests its own reads here.
-        constexpr bool kPipe = !GALIAS && !PREFIX;
+        // (GALIAS: the same pipeline with the alias entry as a global load: one trip's worth of instructions between the
+        // request and the use covers most of an L2 hit; the prefix form keeps its table walk inside the trip)
+        constexpr bool kPipe = !PREFIX;
         uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pe_zero = 0, pe_nonzero = 0, pnnz_c = 0;
         LanesU32x2 pe = {0, 0};
         auto request = [&]() {
           LdsU32* const rp = ring + ((bitpos >> 5) & (kLanesRingWords - 1)) * 64;
-          pe = *(LdsU32x2*)(lds + ((ctxe << cl_shift) + (((state & 0xFFFu) >> log_entry) << 3)));
+          if (GALIAS) {
+            if (act) {  // (only lanes of the trip: a lane's entry is a cache line of its own to the memory pipeline)
+              const uint2 ge = galias[(ctxe << log_alpha) + ((state & 0xFFFu) >> log_entry)];
+              pe = LanesU32x2{ge.x, ge.y};
+            }
+          } else {
+            pe = *(LdsU32x2*)(lds + ((ctxe << cl_shift) + (((state & 0xFFFu) >> log_entry) << 3)));
+          }
           pw0 = rp[0];
           pw1 = rp[64];
           pw2 = rp[128];
@@ -321,8 +330,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           // kCoeffFreqContext(b) for b = (k + 1) / covered in 1..63 is min(b - 1, 7 + b / 2, 15 + b / 4)
           const uint32_t b = (k + 1) >> log2c;
           const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
-          pe_zero = l_ctx[addr_a + f2];
-          pe_nonzero = l_ctx[cbase + 1 + nnz_b + f2];
+          pe_zero = l_ctx[GALIAS ? ((addr_a + f2) & 0x1FFF) : (addr_a + f2)];
+          pe_nonzero = l_ctx[GALIAS ? ((cbase + 1 + nnz_b + f2) & 0x1FFF) : (cbase + 1 + nnz_b + f2)];
           // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays)
           pnnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
         };
