@@ -575,6 +575,13 @@ def main():
     if args.workload == "lossless":
         return lossless_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, ysize)
 
+    # Frames larger than 4K without an explicit --batch: as many per step as two frame sets of ~21 B per pixel (int16
+    # coefficients, f32 XYB planes, RGB8) leave room for in HBM: 16 for 16384 x 16384 (63 GP/s; 34 at 8 frames per step: a
+    # launch lasts as long as its longest section whatever the number of frames), and one distinct frame (encoding a 16K
+    # frame on the host takes a minute).
+    if args.batch == 640 and xsize * ysize > 2 * 3840 * 2160:
+        args.batch = max(1, min(640, int(185e9 / (2 * 21.0 * xsize * ysize))))
+        args.distinct = min(args.distinct, 1)
     # `--distinct` different frames (the synthetic image generator with seeds 177, 178, ...), cycled through every frame
     # set: sections, token counts and entropy tables differ from frame to frame, so the workgroups of a launch do not all
     # finish together
