@@ -308,13 +308,18 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         // store, end-of-channel test): a lone wave has nothing else to cover the LDS round trip with. The group's first trip
         // requests its own reads here.
         // (GALIAS: the same pipeline with the alias entry as a global load: one trip's worth of instructions between the
-        // request and the use covers most of an L2 hit; the prefix form keeps its table walk inside the trip)
-        constexpr bool kPipe = !PREFIX;
+        // request and the use covers most of an L2 hit. PREFIX: the root lookup of the next token's code leaves as soon as
+        // the window words and the cluster's table offset are back from LDS; a second-level lookup, for codes longer than
+        // the root index, stays inside the trip.)
         uint32_t pw0 = 0, pw1 = 0, pw2 = 0, pe_zero = 0, pe_nonzero = 0, pnnz_c = 0;
+        uint32_t ppo = 0, pcfg = 0, proot = 0;  // (PREFIX)
         LanesU32x2 pe = {0, 0};
         auto request = [&]() {
           LdsU32* const rp = ring + ((bitpos >> 5) & (kLanesRingWords - 1)) * 64;
-          if (GALIAS) {
+          if (PREFIX) {
+            ppo = l_poff[ctxe & 255];
+            pcfg = l_cfg[ctxe & 255];
+          } else if (GALIAS) {
             if (act) {  // (only lanes of the trip: a lane's entry is a cache line of its own to the memory pipeline)
               const uint2 ge = galias[(ctxe << log_alpha) + ((state & 0xFFFu) >> log_entry)];
               pe = LanesU32x2{ge.x, ge.y};
@@ -330,12 +335,17 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           // kCoeffFreqContext(b) for b = (k + 1) / covered in 1..63 is min(b - 1, 7 + b / 2, 15 + b / 4)
           const uint32_t b = (k + 1) >> log2c;
           const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
-          pe_zero = l_ctx[GALIAS ? ((addr_a + f2) & 0x1FFF) : (addr_a + f2)];
-          pe_nonzero = l_ctx[GALIAS ? ((cbase + 1 + nnz_b + f2) & 0x1FFF) : (cbase + 1 + nnz_b + f2)];
+          pe_zero = l_ctx[(GALIAS || PREFIX) ? ((addr_a + f2) & 0x1FFF) : (addr_a + f2)];
+          pe_nonzero = l_ctx[(GALIAS || PREFIX) ? ((cbase + 1 + nnz_b + f2) & 0x1FFF) : (cbase + 1 + nnz_b + f2)];
           // nnz table entry for the trip after next if this token is non-zero (if it is zero, nnz_b stays)
           pnnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
+          if (PREFIX) {
+            const uint32_t win = __builtin_amdgcn_alignbit(pw1, pw0, bitpos);
+            proot = 0;
+            if (act) proot = ptable[(ppo & 0xFFFFFFu) + (win & ((1u << (ppo >> 24)) - 1))];  // (global table: only from valid state)
+          }
         };
-        if (kPipe) request();
+        request();
 #pragma unroll
         for (int rep = 0; rep < kLanesTrips; rep++) {
           if (AIDS && B.prof) n_lane_trips += act ? 1u : 0u;
@@ -343,8 +353,17 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           const uint32_t kn = k + 1;
           const uint32_t addr_b = cbase + 1 + nnz_b;
           uint32_t tok, cfg, adv, nstate = state;
-          if (kPipe) {
-            w0 = pw0, w1 = pw1, w2 = pw2, e_zero = pe_zero, e_nonzero = pe_nonzero, nnz_c = pnnz_c;
+          w0 = pw0, w1 = pw1, w2 = pw2, e_zero = pe_zero, e_nonzero = pe_nonzero, nnz_c = pnnz_c;
+          if (PREFIX) {
+            uint32_t e = proot;
+            if (act && (e & 0x80u)) {  // second level (jxl_hip_kernels.h PrefixLookup)
+              const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
+              e = ptable[(ppo & 0xFFFFFFu) + (e >> 8) + ((win >> (ppo >> 24)) & ((1u << (e & 0x7Fu)) - 1))];
+            }
+            tok = e >> 8;
+            adv = e & 0xFFu;
+            cfg = pcfg;
+          } else {
             const LanesU32x2 e = pe;
             const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & entry_mask;
             const bool gt = pos >= (e.x >> 24);
@@ -357,43 +376,6 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             nstate = need ? ((nstate << 16) | (win & 0xFFFFu)) : nstate;
             adv = need ? 16u : 0u;
             cfg = e.x >> 12;
-          } else {
-            // ---- everything the trip reads from LDS, up front (one round trip): the stream window, the alias entry, and
-            // the context entries of coefficient k + 1 for both outcomes of this one
-            const uint32_t slotw = (bitpos >> 5) & (kLanesRingWords - 1);
-            LdsU32* const rp = ring + slotw * 64;
-            w0 = rp[0], w1 = rp[64], w2 = rp[128];
-            const uint32_t b = kn >> log2c;
-            const uint32_t f2 = min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)) << 1;
-            e_zero = l_ctx[(addr_a + f2) & 0x1FFF];
-            e_nonzero = l_ctx[(addr_b + f2) & 0x1FFF];
-            nnz_c = l_nnz2[((nzeros - 2 + covm1) >> log2c) & 63];
-            if (PREFIX) {
-              const uint32_t po = l_poff[ctxe & 255];
-              const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
-              uint32_t e = 0;
-              if (act) e = PrefixLookup(ptable + (po & 0xFFFFFFu), po >> 24, win);  // (global table: only from valid state)
-              tok = e >> 8;
-              adv = e & 0xFFu;
-              cfg = l_cfg[ctxe & 255];
-            } else {
-              const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & entry_mask;
-              LanesU32x2 e = {0, 0};
-              if (act) {
-                const uint2 ge = galias[(ctxe << log_alpha) + slot];
-                e = LanesU32x2{ge.x, ge.y};
-              }
-              const bool gt = pos >= (e.x >> 24);
-              const uint32_t x = gt ? e.y : e.x;
-              tok = gt ? (e.y >> 24) : slot;
-              const uint32_t hi = state >> 12;
-              nstate = (x & 0xFFFu) * hi + hi + (gt ? ((e.y >> 12) & 0xFFFu) : 0u) + pos;
-              const bool need = nstate < (1u << 16);
-              const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
-              nstate = need ? ((nstate << 16) | (win & 0xFFFFu)) : nstate;
-              adv = need ? 16u : 0u;
-              cfg = e.x >> 12;
-            }
           }
           // Tokens with extra bits are rare (|coefficient| >= 8 at the usual split of 16): their ~25 instructions are
           // skipped when no lane of the trip has one (a wave-uniform branch).
@@ -417,7 +399,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           ctxe = act ? (nz ? e_nonzero : e_zero) : ctxe;
           addr_a = (act && nz) ? addr_b - 1 : addr_a;
           nnz_b = (act && nz) ? nnz_c : nnz_b;
-          if (kPipe && rep + 1 < kLanesTrips) request();
+          if (rep + 1 < kLanesTrips) request();
           // ---- the trip's own bookkeeping, under the round trip of those reads
           const uint32_t sgn = uint32_t(-int32_t(tok & 1));  // odd token: negative
           const int32_t coeff = int32_t(((tok >> 1) ^ sgn) << shift);
