@@ -935,7 +935,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (!c->plane_lender && (r = c->plane[0].Ensure(plane_bytes))) return r;
   // pixels: RGB8 from every filter kernel, RGB f32 from the row-streaming one; any other format from the generic writer
   // (k_color_out on the filtered planes, or k_upsample_color)
-  c->color_out = !OutIsRgb8(c) && !(OutIsRgbF32(c) && c->ups == 1 && (c->gab && (c->epf_iters == 1 || c->epf_iters == 2)) &&
+  c->color_out = !OutIsRgb8(c) && !(OutIsRgbF32(c) && c->ups == 1 && (c->epf_iters == 1 || c->epf_iters == 2) &&
                                     !EnvInt("JXLHIP_FILTER_TILES", 0) && !EnvInt("JXLHIP_FILTER_ROWS1", 0));
   if (c->out_orient) c->color_out = true;  // (the oriented layout is written by the generic writer)
   // noise is added to the filtered planes between the filter launch and the colour conversion
@@ -1395,12 +1395,6 @@ static int FilterKey(const JxlHipContext* c) {
   const int epf = c->epf_iters < 0 ? 0 : (c->epf_iters > 3 ? 3 : c->epf_iters);
   return (c->gab ? 4 : 0) + epf;
 }
-// The frame's filter stage runs on k_filter_rows2 (Gaborish + one or two EPF iterations: what encoders choose between d0.7
-// and d4), which writes RGB f32 itself.
-static bool UsesRows2(const JxlHipContext* c) {
-  return (FilterKey(c) == 5 || FilterKey(c) == 6) && !EnvInt("JXLHIP_FILTER_TILES", 0) && !EnvInt("JXLHIP_FILTER_ROWS1", 0);
-}
-
 // Builds (or re-uses) the description of a set of frames for the batched transform and filter launches.
 static int PrepareDownstream(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n) {
   bool same = c0->db_ctxs.size() == n;
@@ -1474,9 +1468,9 @@ static int LaunchFused(JxlHipContext* c0, const JxlHipContext::FilterGroup& g) {
 }
 
 // Gaborish + EPF1 (the d1.0 configuration) or + EPF1 + EPF2 (`epf` = 2): the row-streaming kernel, no LDS.
-static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup& g, int epf = 1) {
+static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup& g, int epf = 1, bool gab = true) {
   const uint32_t cols = g.tiles_x * jxlhip::kFusedTW, rows = g.tiles_y * jxlhip::kFusedTH;  // upper bounds of the group
-  const bool one_px = epf == 1 && EnvInt("JXLHIP_FILTER_ROWS1", 0) != 0;  // measurement aid: the one-column-per-lane form
+  const bool one_px = epf == 1 && gab && EnvInt("JXLHIP_FILTER_ROWS1", 0) != 0;  // measurement aid: the one-column-per-lane form
   const uint32_t per_wave = one_px ? jxlhip::kRowsLanes : jxlhip::kRows2Cols;
   const uint32_t gx = ((cols + per_wave - 1) / per_wave + jxlhip::kRowsWaves - 1) / jxlhip::kRowsWaves;
   // strip height: every strip re-reads and re-filters 6 halo rows, so the taller the better as long as the launch still
@@ -1500,7 +1494,10 @@ static int LaunchFilterRows(JxlHipContext* c0, const JxlHipContext::FilterGroup&
       typedef void (*RowsKernel)(const jxlhip::FusedFilterParams*, int);
       const RowsKernel k1t = jxlhip::k_filter_rows2<true, 1>, k1f = jxlhip::k_filter_rows2<false, 1>;
       const RowsKernel k2t = jxlhip::k_filter_rows2<true, 2>, k2f = jxlhip::k_filter_rows2<false, 2>;
-      const RowsKernel k = epf == 2 ? (g.u8srgb ? k2t : k2f) : (g.u8srgb ? k1t : k1f);
+      const RowsKernel n1t = jxlhip::k_filter_rows2<true, 1, false>, n1f = jxlhip::k_filter_rows2<false, 1, false>;
+      const RowsKernel n2t = jxlhip::k_filter_rows2<true, 2, false>, n2f = jxlhip::k_filter_rows2<false, 2, false>;
+      const RowsKernel k = gab ? (epf == 2 ? (g.u8srgb ? k2t : k2f) : (g.u8srgb ? k1t : k1f))
+                               : (epf == 2 ? (g.u8srgb ? n2t : n2f) : (g.u8srgb ? n1t : n1f));
       hipLaunchKernelGGL(k, dim3(gx, gy, zn), dim3(64 * jxlhip::kRowsWaves), 0, c0->fstream, fp, int(strip));
     }
   }
@@ -2721,8 +2718,8 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
   for (const JxlHipContext::FilterGroup& g : c0->fgroups) {
     switch (g.key) {
       case 0: r = LaunchFused<false, 0>(c0, g); break;
-      case 1: r = LaunchFused<false, 1>(c0, g); break;
-      case 2: r = LaunchFused<false, 2>(c0, g); break;
+      case 1: r = EnvInt("JXLHIP_FILTER_TILES", 0) ? LaunchFused<false, 1>(c0, g) : LaunchFilterRows(c0, g, 1, false); break;
+      case 2: r = EnvInt("JXLHIP_FILTER_TILES", 0) ? LaunchFused<false, 2>(c0, g) : LaunchFilterRows(c0, g, 2, false); break;
       case 3: r = LaunchFused<false, 3>(c0, g); break;
       case 4: r = LaunchFused<true, 0>(c0, g); break;
       case 5: r = EnvInt("JXLHIP_FILTER_TILES", 0) ? LaunchFused<true, 1>(c0, g) : LaunchFilterRows(c0, g); break;

@@ -571,9 +571,12 @@ __device__ __forceinline__ P2 BufP2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uin
 // them one row behind, with one more halo row and the fourth halo column the pair layout already had. Rows just outside
 // the frame are EPF1 outputs of mirrored inputs with sigma and block-border flag taken at the mirrored row, which is the
 // mirrored EPF1 output (the filters are reflection-symmetric).
-template <bool U8SRGB, int EPF = 1>
+// GAB = false (what the reference's encoder writes at its fast efforts, Gaborish off: enc_frame.cc:316-322): the
+// "Gaborish output" ring is fed with the input row itself, one row behind like the filtered one would be; nothing else
+// changes (the halo stays the same, one row and column more than needed).
+template <bool U8SRGB, int EPF = 1, bool GAB = true>
 __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFilterParams* params, int strip_rows) {
-  static_assert(EPF == 1 || EPF == 2, "Gaborish + one or two EPF iterations");
+  static_assert(EPF == 1 || EPF == 2, "(Gaborish +) one or two EPF iterations");
   constexpr int HALO = kRowsHalo + (EPF == 2 ? 1 : 0);
   FusedFilterParams P;
   LoadParams(P, params + blockIdx.z);
@@ -681,14 +684,18 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       p[c][N] = cur[c];
-      h1[c][N] = P2{FromLeft(cur[c].y) + cur[c].y, cur[c].x + FromRight(cur[c].x)};  // columns x - 1 and x + 1 of each element
+      if constexpr (GAB) h1[c][N] = P2{FromLeft(cur[c].y) + cur[c].y, cur[c].x + FromRight(cur[c].x)};  // columns x - 1 and x + 1 of each element
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
       const P2 m = p[c][M1];
-      const P2 s1 = h1[c][M1] + (p[c][M2] + p[c][N]);
-      const P2 s2 = h1[c][M2] + h1[c][N];
-      g[c][N] = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
+      if constexpr (GAB) {
+        const P2 s1 = h1[c][M1] + (p[c][M2] + p[c][N]);
+        const P2 s2 = h1[c][M2] + h1[c][N];
+        g[c][N] = s2 * P.f.gab_w[c * 3 + 2] + (s1 * P.f.gab_w[c * 3 + 1] + m * P.f.gab_w[c * 3]);
+      } else {
+        g[c][N] = m;
+      }
     }
     dh[N] = dh_new;
     {
