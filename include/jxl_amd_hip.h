@@ -403,10 +403,12 @@ typedef struct JxlHipBlend {
   uint32_t clamp, alpha_clamp;
   int32_t save_slot;          /* 0..3: the blended canvas is also kept in this slot; -1: not kept */
 } JxlHipBlend;
-/* Reference frames kept BEFORE the colour transform (kReferenceOnly frames, the sources of patches): copies the XYB
- * planes `frame` holds after its last run (VarDCT: the filtered planes; Modular: needs jxlhip_set_option(frame,
- * "keep_xyb_planes", 1) before the upload) into XYB slot 0..3; jxlhip_canvas_xyb_source hands the device planes out
- * ([3][h][w]; NULL / 0 while the slot is empty). */
+/* Frames kept BEFORE the colour transform: copies the XYB planes `frame` holds after its last run (VarDCT: the filtered
+ * planes; Modular: needs jxlhip_set_option(frame, "keep_xyb_planes", 1) before the upload) into an XYB slot of the canvas:
+ * slots 0..3 = the reference slots (kReferenceOnly frames, the sources of patches), slots 4..7 = the DC frames of level
+ * 1..4 (kDCFrame; the DC image of a later frame with kUseDcFrame: JxlHipFrameDesc::dc_device). jxlhip_canvas_xyb_source
+ * hands the device planes out ([3][h][w]; NULL / 0 while the slot is empty); they stay valid until the slot is written
+ * again or the canvas is destroyed. */
 int jxlhip_canvas_save_xyb(JxlHipCanvas* canvas, JxlHipContext* frame, uint32_t slot);
 int jxlhip_canvas_xyb_source(JxlHipCanvas* canvas, uint32_t slot, const float** planes, uint32_t* xsize, uint32_t* ysize);
 /* Blends the pixels `frame` holds (its last run, f32 x 4) into the canvas. */
