@@ -77,6 +77,8 @@ void jxlamd_frame_set_linear_output(JxlAmdFrame* frame, int linear);
  * (the frame's size), or NULL while pending / when there is no such channel. */
 int jxlamd_frame_extra_pending(const JxlAmdFrame* frame);
 int jxlamd_frame_finish_extra(JxlAmdFrame* frame, JxlHipContext* ctx);
+/* The same with the groups' Modular streams spread over the caller's runner (NULL: serial). */
+int jxlamd_frame_finish_extra_mt(JxlAmdFrame* frame, JxlHipContext* ctx, JxlParallelRunner runner, void* runner_opaque);
 const int32_t* jxlamd_frame_extra_plane(const JxlAmdFrame* frame, uint32_t index);
 /* ---- Modular (lossless) frames: host parse into the plan the device decodes (csrc/host/jxh_modframe.h) ---- */
 typedef struct JxlAmdModFrame JxlAmdModFrame;

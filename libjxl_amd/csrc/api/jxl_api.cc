@@ -620,7 +620,8 @@ void jxlamd_frame_set_linear_output(JxlAmdFrame* f, int linear) {
   if (f) f->plan.ih.linear_tf = linear != 0;
 }
 int jxlamd_frame_extra_pending(const JxlAmdFrame* f) { return f && f->plan.extra_pending ? 1 : 0; }
-int jxlamd_frame_finish_extra(JxlAmdFrame* f, JxlHipContext* ctx) {
+int jxlamd_frame_finish_extra(JxlAmdFrame* f, JxlHipContext* ctx) { return jxlamd_frame_finish_extra_mt(f, ctx, nullptr, nullptr); }
+int jxlamd_frame_finish_extra_mt(JxlAmdFrame* f, JxlHipContext* ctx, JxlParallelRunner runner, void* runner_opaque) {
   g_last_error.clear();
   if (!f || !ctx) return 1;
   if (!f->plan.extra_pending) return 0;
@@ -628,7 +629,7 @@ int jxlamd_frame_finish_extra(JxlAmdFrame* f, JxlHipContext* ctx) {
   int r = jxlhip_get_section_end_bits(ctx, bits.data(), bits.size());
   if (r) return r;
   try {
-    jxh::FrameParser::FinishExtraChannels(f->data, &f->plan, bits.data());
+    jxh::FrameParser::FinishExtraChannels(f->data, &f->plan, bits.data(), MakeParallelFor(runner, runner_opaque));
   } catch (const std::exception& e) {
     g_last_error = e.what();
     return 2;
@@ -1174,7 +1175,7 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
   if (r) return Fail(d, "GPU decode failed (" + std::to_string(r) + ")");
   const bool need_extra = want_alpha || (!to_canvas && !d->extra_out.empty());
   if (need_extra && jxlamd_frame_extra_pending(d->frame)) {
-    r = jxlamd_frame_finish_extra(d->frame, d->ctx);
+    r = jxlamd_frame_finish_extra_mt(d->frame, d->ctx, d->runner, d->runner_opaque);
     if (r) return Fail(d, "extra channels: " + g_last_error);
   }
   uint32_t out_wh[2];
