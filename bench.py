@@ -231,7 +231,7 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
                     "stage_busy_ms_per_frame = wall time of each pipeline thread (gpu_stages: summed over its two threads)" % chunk}
 
 
-def single_image_api(J, data, xsize, ysize, reps=10):
+def single_image_api(J, data, xsize, ysize, reps=10, channels=3):
     """One image through the drop-in boundary, the way djxl times it (tools/djxl_main.cc:415-422: wall clock around the whole
     DecodeImageJXL call sequence, compressed bytes in memory -> RGB8 in the caller's buffer; tools/speed_stats.cc:23-69: with
     three or more repetitions the geometric mean without the first)."""
@@ -252,8 +252,8 @@ def single_image_api(J, data, xsize, ysize, reps=10):
 
     class Fmt(ctypes.Structure):
         _fields_ = [("num_channels", ctypes.c_uint32), ("data_type", ctypes.c_int), ("endianness", ctypes.c_int), ("align", ctypes.c_size_t)]
-    fmt = Fmt(3, 2, 0, 0)  # RGB, JXL_TYPE_UINT8, native endian
-    out = ctypes.create_string_buffer(xsize * ysize * 3)
+    fmt = Fmt(channels, 2, 0, 0)  # RGB (or RGBA), JXL_TYPE_UINT8, native endian
+    out = ctypes.create_string_buffer(xsize * ysize * channels)
     try:
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
