@@ -582,9 +582,53 @@ static int TestQuantUniform() {
   return 0;
 }
 
+// "defaults": the floating-point constants this front-end carries (default-constructed headers, the .inc tables next to
+// it), one "name v0 v1 ..." line each, for tests/test_kats.py to compare with the numbers extracted from the reference's
+// source (tests/golden/ref_constant_floats.json).
+namespace kat_tables {
+#ifdef KAT_ORACLE
+#include "../../oracle/upsampling_weights.inc"
+#include "../../oracle/dither.inc"
+#else
+#include "../../libjxl_amd/csrc/host/upsampling_weights.inc"
+#include "../../libjxl_amd/csrc/host/dither.inc"
+#include "../../libjxl_amd/csrc/host/afv_basis.inc"
+#endif
+}  // namespace kat_tables
+static void Dump(const char* name, const float* v, size_t n) {
+  printf("%s", name);
+  for (size_t i = 0; i < n; i++) printf(" %.9g", double(v[i]));
+  printf("\n");
+}
+static int DumpDefaults() {
+  H::ImageHeader ih;
+  Dump("inverse_opsin", ih.inv_opsin, 9);
+  Dump("opsin_bias", ih.opsin_bias, 3);
+  Dump("quant_bias", ih.quant_bias, 4);
+  H::LoopFilter lf;
+  Dump("gab_weights", &lf.gab_w[0][0], 6);
+  Dump("epf_sharp_lut", lf.epf_sharp_lut, 8);
+  Dump("epf_channel_scale", lf.epf_channel_scale, 3);
+  const float epf[4] = {lf.epf_quant_mul, lf.epf_pass0_sigma_scale, lf.epf_pass2_sigma_scale, lf.epf_border_sad_mul};
+  Dump("epf_scalars", epf, 4);
+  H::DequantTables dq;
+  Dump("dc_quant", dq.dc_quant, 3);
+  Dump("upsampling_weights2", kat_tables::kUpsamplingWeights2, 15);
+  Dump("upsampling_weights4", kat_tables::kUpsamplingWeights4, 55);
+  Dump("upsampling_weights8", kat_tables::kUpsamplingWeights8, 210);
+  Dump("dither32", &kat_tables::kDither32[0][0], 1024);
+#ifdef KAT_ORACLE
+  Dump("afv_basis", &H::kAfvBasis[0][0], 256);
+#else
+  Dump("afv_basis", &kat_tables::kAfvBasis[0][0], 256);
+#endif
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string t = argv[1];
+  if (t == "defaults") return DumpDefaults();
   if (t == "alias") return TestAlias();
   if (t == "hybrid") return TestHybrid();
   if (t == "lehmer") return TestLehmer();

@@ -41,6 +41,45 @@ def test_reference_closed_form_kats(which, kat):
     assert r.returncode == 0, r.stderr
 
 
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_float_constants_match_the_reference_source(which):
+    """The floating-point constants the format fixes, as the reference's source lists them
+    (tests/golden/ref_constant_floats.json, extracted by tests/golden/make_float_tables_golden.py: default upsampling
+    weights, the dither table, the AFV basis, inverse opsin matrix and bias, quant biases, DC quantisation steps, Gaborish and
+    EPF defaults), against what each front-end carries: its default-constructed headers and the .inc tables next to it (the
+    product's are what the kernels are built with). A transcription error in a copy, or one shared by all copies, fails
+    here; self-consistency tests cannot see it."""
+    import numpy as np
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_constant_floats.json")))
+    r = subprocess.run([_binary(which), "defaults"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = {}
+    for line in r.stdout.splitlines():
+        name, *vals = line.split()
+        got[name] = np.array([float(v) for v in vals])
+
+    def same(name, want, tol=2e-7):
+        want = np.asarray(want, np.float64)
+        assert got[name].shape == want.shape, name
+        assert np.all(np.abs(got[name] - np.float32(want)) <= tol * np.maximum(1.0, np.abs(want))), name
+
+    for name in ("upsampling_weights2", "upsampling_weights4", "upsampling_weights8", "dither32", "afv_basis", "inverse_opsin",
+                 "quant_bias", "epf_sharp_lut", "epf_channel_scale"):
+        same(name, ref[name])
+    same("opsin_bias", [-ref["opsin_bias"][0]] * 3)  # (the decoder's default is kNegOpsinAbsorbanceBiasRGB: opsin_params.h:58-60)
+    same("gab_weights", [ref["gab_weight1"], ref["gab_weight2"]] * 3)
+    same("epf_scalars", [ref["epf_quant_mul"], ref["epf_pass0_sigma_scale"], ref["epf_pass2_sigma_scale"], ref["epf_border_sad_mul"]])
+    same("dc_quant", [1.0 / v for v in ref["inv_dc_quant"]])
+    # the two EPF constants are literals in the code (epf.h:19-22)
+    import re
+    files = (["oracle/jxlo_render.h"] if which == "oracle" else
+             ["libjxl_amd/csrc/hip/jxl_hip_dc.h", "libjxl_amd/csrc/hip/jxl_hip_filter_fused.h"])
+    text = "".join(open(os.path.join(ROOT, f)).read() for f in files)
+    sig = {float(v) for v in re.findall(r"-1\.17157\d+", text)}
+    mins = {float(v) for v in re.findall(r"-3\.90524\d+", text)}
+    assert sig and mins and all(abs(v - ref["inv_sigma_num"]) < 1e-12 for v in sig) and all(abs(v - ref["min_sigma"]) < 1e-12 for v in mins)
+
+
 def test_embedded_icc_profile_reference_vector():
     """lib/jxl/icc_codec_test.cc:52-211 (kEncodedTestProfile -> kTestProfile), extracted by tests/golden/make_icc_golden.py:
     the product's ICC decoder (41-context entropy decode + the inverse of the profile predictor) against the reference's
