@@ -617,6 +617,33 @@ static int DumpDefaults() {
   Dump("upsampling_weights4", kat_tables::kUpsamplingWeights4, 55);
   Dump("upsampling_weights8", kat_tables::kUpsamplingWeights8, 210);
   Dump("dither32", &kat_tables::kDither32[0][0], 1024);
+  {  // the default dequantisation-table parameters, per kind in the reference's own order of writing them down
+    for (int k = 0; k < 17; k++) {
+      std::vector<float> v;
+      if (k == 1) {
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 3; i++) v.push_back(float(H::kQLIdentity[c][i]));
+      } else if (k == 2) {
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 6; i++) v.push_back(float(H::kQLDct2[c][i]));
+      } else if (k == 10) {  // (its bands are DCT4X8's and DCT4X4's: the line carries the 27 weights)
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 9; i++) v.push_back(float(H::kQLAfv[c][i]));
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < 4; i++)
+            if (H::kQLBands[10][c][i] != H::kQLBands[9][c][i]) return 1;
+      } else {
+        for (int c = 0; c < 3; c++)
+          for (int i = 0; i < H::kQLNumBands[k]; i++) v.push_back(float(H::kQLBands[k][c][i]));
+        if (k == 3)
+          for (int c = 0; c < 3; c++)
+            for (int i = 0; i < 2; i++) v.push_back(float(H::kQLDct4Mul[c][i]));
+        if (k == 9)
+          for (int c = 0; c < 3; c++) v.push_back(float(H::kQLDct4x8Mul[c]));
+      }
+      Dump(("quant_library_" + std::to_string(k)).c_str(), v.data(), v.size());
+    }
+  }
 #ifdef KAT_ORACLE
   Dump("afv_basis", &H::kAfvBasis[0][0], 256);
 #else

@@ -10,6 +10,7 @@ tests/golden/ref_constant_floats.json, so that a test can hold every copy in thi
   kInvDCQuant (DC quantisation steps = 1 / these)             lib/jxl/quant_weights.h:289-299
   loop-filter defaults (Gaborish weights, EPF parameters)     lib/jxl/loop_filter.cc:28-87
   kInvSigmaNum, kMinSigma                                     lib/jxl/epf.h:19-22
+  default dequantisation-table parameters (the "library")     lib/jxl/quant_weights.cc:533-1106
 usage (where /root/reference exists): python tests/golden/make_float_tables_golden.py"""
 import json
 import os
@@ -72,6 +73,18 @@ def main():
     ep = text("epf.h")
     out["inv_sigma_num"] = floats(re.search(r"kInvSigmaNum\s*=\s*([^;]+);", ep).group(1))[0]
     out["min_sigma"] = floats(re.search(r"kMinSigma\s*=\s*([^;]+);", ep).group(1))[0]
+    # the default dequantisation-table parameters ("library", quant_weights.cc:533-1106): per table kind, in the order of the
+    # enum, every V(...) of its definition in source order (DCT kinds: the three channels' distance bands; IDENTITY / DCT2X2:
+    # the per-channel weights; DCT4X4 / DCT4X8: bands then multipliers; AFV: the 27 weights, its bands being DCT4X8's and
+    # DCT4X4's)
+    qw = text("quant_weights.cc")
+    lib = qw[qw.index("struct DequantMatricesLibraryDef"):qw.index("DequantMatricesLibraryDef::DCT()", qw.index("DCT128X256()"))]
+    parts = re.split(r"static (?:constexpr )?QuantEncodingInternal (\w+)\(\)", lib)
+    names, bodies = parts[1::2], parts[2::2]
+    assert names == ["DCT", "IDENTITY", "DCT2X2", "DCT4X4", "DCT16X16", "DCT32X32", "DCT8X16", "DCT8X32", "DCT16X32", "DCT4X8", "AFV0",
+                     "DCT64X64", "DCT32X64", "DCT128X128", "DCT64X128", "DCT256X256", "DCT128X256"], names
+    out["quant_library"] = [[float(eval(re.sub(r"(?<=[\d.])f\b", "", e).strip(), {"__builtins__": {}})) for e in re.findall(r"\bV\(([^)]*)\)", b)]
+                            for b in bodies]
     sizes = {k: (len(v) if isinstance(v, list) else 1) for k, v in out.items()}
     assert (sizes["upsampling_weights2"], sizes["upsampling_weights4"], sizes["upsampling_weights8"], sizes["dither32"], sizes["afv_basis"],
             sizes["inverse_opsin"], sizes["quant_bias"], sizes["inv_dc_quant"]) == (15, 55, 210, 1024, 256, 9, 4, 3), sizes

@@ -46,7 +46,7 @@ def test_float_constants_match_the_reference_source(which):
     """The floating-point constants the format fixes, as the reference's source lists them
     (tests/golden/ref_constant_floats.json, extracted by tests/golden/make_float_tables_golden.py: default upsampling
     weights, the dither table, the AFV basis, inverse opsin matrix and bias, quant biases, DC quantisation steps, Gaborish and
-    EPF defaults), against what each front-end carries: its default-constructed headers and the .inc tables next to it (the
+    EPF defaults, the 17 default dequantisation-table definitions), against what each front-end carries: its default-constructed headers and the .inc tables next to it (the
     product's are what the kernels are built with). A transcription error in a copy, or one shared by all copies, fails
     here; self-consistency tests cannot see it."""
     import numpy as np
@@ -70,6 +70,8 @@ def test_float_constants_match_the_reference_source(which):
     same("gab_weights", [ref["gab_weight1"], ref["gab_weight2"]] * 3)
     same("epf_scalars", [ref["epf_quant_mul"], ref["epf_pass0_sigma_scale"], ref["epf_pass2_sigma_scale"], ref["epf_border_sad_mul"]])
     same("dc_quant", [1.0 / v for v in ref["inv_dc_quant"]])
+    for k, want in enumerate(ref["quant_library"]):  # the 17 default dequantisation-table definitions (quant_weights.cc:533-1106)
+        same("quant_library_%d" % k, want, tol=1e-6)
     # the two EPF constants are literals in the code (epf.h:19-22)
     import re
     files = (["oracle/jxlo_render.h"] if which == "oracle" else
