@@ -11,6 +11,7 @@ tests/golden/ref_constant_floats.json, so that a test can hold every copy in thi
   loop-filter defaults (Gaborish weights, EPF parameters)     lib/jxl/loop_filter.cc:28-87
   kInvSigmaNum, kMinSigma                                     lib/jxl/epf.h:19-22
   default dequantisation-table parameters (the "library")     lib/jxl/quant_weights.cc:533-1106
+  WcMultipliers<N>, DCTResampleScales<FROM, TO>               lib/jxl/dct_scales.h:42-353
 usage (where /root/reference exists): python tests/golden/make_float_tables_golden.py"""
 import json
 import os
@@ -85,6 +86,11 @@ def main():
                      "DCT64X64", "DCT32X64", "DCT128X128", "DCT64X128", "DCT256X256", "DCT128X256"], names
     out["quant_library"] = [[float(eval(re.sub(r"(?<=[\d.])f\b", "", e).strip(), {"__builtins__": {}})) for e in re.findall(r"\bV\(([^)]*)\)", b)]
                             for b in bodies]
+    # IDCT butterfly multipliers and the resample scales of the LLF-from-DC step (dct_scales.h:42-353)
+    ds = text("dct_scales.h")
+    out["wc_multipliers"] = {n: floats(b) for n, b in re.findall(r"struct WcMultipliers<(\d+)>\s*\{[^{]*\{(.*?)\};", ds, re.S)}
+    out["dct_resample_scales"] = {"%s_%s" % (a, b): floats(body)
+                                  for a, b, body in re.findall(r"struct DCTResampleScales<(\d+),\s*(\d+)>\s*\{[^{]*\{(.*?)\};", ds, re.S)}
     sizes = {k: (len(v) if isinstance(v, list) else 1) for k, v in out.items()}
     assert (sizes["upsampling_weights2"], sizes["upsampling_weights4"], sizes["upsampling_weights8"], sizes["dither32"], sizes["afv_basis"],
             sizes["inverse_opsin"], sizes["quant_bias"], sizes["inv_dc_quant"]) == (15, 55, 210, 1024, 256, 9, 4, 3), sizes

@@ -41,6 +41,36 @@ def test_reference_closed_form_kats(which, kat):
     assert r.returncode == 0, r.stderr
 
 
+def test_dct_scale_tables_match_the_reference_source():
+    """dct_scales.h:42-353 as the reference lists them (ref_constant_floats.json): the IDCT kernels' butterfly multipliers
+    (WcTable<N> literals of jxl_hip_kernels.h = WcMultipliers<N>) and the scales of the LLF-from-DC step, which the oracle
+    (jxlo_vardct.h ResampleScale) and the HIP layer (jxl_hip_api.hip: c_resample) both compute from the formula in the
+    reference's comment: that formula must reproduce the reference's DCTResampleScales<n, 8n> tables."""
+    import math
+    import re
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_constant_floats.json")))
+    text = open(os.path.join(ROOT, "libjxl_amd", "csrc", "hip", "jxl_hip_kernels.h")).read()
+    seen = 0
+    for n, body in re.findall(r"struct WcTable<(\d+)>\s*\{[^{]*\{(.*?)\};", text, re.S):
+        vals = [float(v) for v in re.findall(r"[-+]?\d+\.\d+e[-+]\d+", body)]
+        assert len(vals) == int(n) // 2
+        if n in ref["wc_multipliers"]:
+            want = ref["wc_multipliers"][n]
+            assert len(want) == len(vals) and all(abs(a - b) <= 2e-9 * abs(b) for a, b in zip(vals, want)), n
+            seen += 1
+        else:  # WcTable<2>: 1 / (2 cos(pi / 4)), the same formula (the reference has no 2-point table)
+            assert abs(vals[0] - 1.0 / (2.0 * math.cos(math.pi / 4))) < 1e-9
+    assert seen == 5  # N = 4, 8, 16, 32, 64
+    for n in (1, 2, 4, 8, 16, 32):
+        N = 8.0 * n
+        ours = [1.0 / (math.cos(i / (2 * N) * math.pi) * math.cos(i / N * math.pi) * math.cos(i / (N / 2) * math.pi)) for i in range(n)]
+        want = ref["dct_resample_scales"]["%d_%d" % (n, 8 * n)]
+        assert len(want) == n and all(abs(a - b) <= 1e-12 * abs(b) + 1e-15 for a, b in zip(ours, want)), n
+    for f in ("oracle/jxlo_vardct.h", "libjxl_amd/csrc/hip/jxl_hip_api.hip"):  # both spell exactly that formula
+        src = open(os.path.join(ROOT, f)).read()
+        assert "std::cos(i / (2 * N) * M_PI) * std::cos(i / N * M_PI) * std::cos(i / (N / 2) * M_PI)" in src, f
+
+
 @pytest.mark.parametrize("which", ["product", "oracle"])
 def test_float_constants_match_the_reference_source(which):
     """The floating-point constants the format fixes, as the reference's source lists them
