@@ -177,6 +177,13 @@ typedef struct JxlHipFrameDesc {
    *    block, row-major like `dc`), the varblocks' qf, quant_scale (= global_scale / 65536), epf_quant_mul and epf_sharp_lut. */
   uint32_t dc_smoothing;
   float dc_step[3];
+  /* DequantDC on the device (compressed_dc.cc:201-296): dc_quantised != NULL hands over the three coded integer planes
+   * (X, Y, B; each xsize_blocks * ysize_blocks) instead of `dc` (which may then be NULL); the upload forms
+   * Y = q_y * step_y, X = Y * dc_cfl_x + q_x * step_x, B = Y * dc_cfl_b + q_b * step_b with step = dc_step[c] / 2^e, e =
+   * dc_extra_precision[DC group] (one byte per group of 256 x 256 blocks, row-major; NULL = 0). */
+  const int32_t* dc_quantised;
+  const uint8_t* dc_extra_precision;
+  float dc_cfl_x, dc_cfl_b;
   /* kUseDcFrame (frame_header.h:348, passes_state.cc:62-77): the DC image is an earlier DC frame's output, resident on
    * this device as 3 planes of xsize_blocks * ysize_blocks floats (jxlhip_canvas_xyb_source of slot 4 + level); `dc` may
    * then be NULL and no smoothing runs. The planes must stay valid until the transform stage has run. */

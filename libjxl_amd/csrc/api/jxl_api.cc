@@ -326,7 +326,11 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
     g_last_error = "kUseDcFrame: the DC frame's planes were not set (jxlamd_frame_set_dc_source)";
     return 1;
   }
-  d.dc = P.dc.data();
+  d.dc = nullptr;  // DequantDC, smoothing and 1 / sigma run inside the upload (csrc/hip/jxl_hip_dc.h)
+  d.dc_quantised = P.use_dc_frame ? nullptr : P.dc_q.data();
+  d.dc_extra_precision = P.dc_extra_precision.data();
+  d.dc_cfl_x = P.dc_cfl_x;
+  d.dc_cfl_b = P.dc_cfl_b;
   d.dc_device = P.use_dc_frame ? P.dc_source : nullptr;
   d.dc_smoothing = P.dc_smoothing ? 1 : 0;  // smoothing and 1 / sigma are computed by the upload (csrc/hip/jxl_hip_dc.h)
   memcpy(d.dc_step, P.dc_step, sizeof(d.dc_step));

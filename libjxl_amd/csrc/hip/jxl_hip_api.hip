@@ -183,6 +183,7 @@ struct JxlHipContext {
   float epf_pass0 = 0.9f, epf_pass2 = 6.5f, epf_border = 2.0f / 3;
   // buffers
   Buf sections, sec_word, sec_size, blocks, gbb, bctx_lut, dequant, dc, inv_sigma, ytox, ytob, passes_dev, coeffs, errors;
+  Buf dc_q, dc_ep;    // coded DC integers and the DC groups' extra-precision bytes (DequantDC on the device)
   Buf dc_raw, sharp;  // inputs of the DC-path kernels (jxl_hip_dc.h) when the upload smooths the DC image / computes 1 / sigma
   Buf plane[3], rgb, tlist, scratch, sec_end, lz_window;
   bool generic_codec = false;  // a pass is prefix-coded or uses LZ77 (k_entropy_generic decodes the frame unless lane_prefix)
@@ -461,7 +462,7 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
 }
 
 static std::vector<Buf*> AllBufs(JxlHipContext* c) {
-  std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc, &c->dc_raw, &c->sharp,
+  std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc, &c->dc_raw, &c->dc_q, &c->dc_ep, &c->sharp,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
@@ -622,11 +623,16 @@ static int BlobBegin(JxlHipContext* c, size_t bound) {
 }
 // `smooth` / `sigma`: the DC-path kernels of this frame (NULL = not asked for), launched on the copy stream behind the copy
 // they read, so that the event the upload waits for covers them too.
-static int BlobEnd(JxlHipContext* c, const jxlhip::DcSmoothParams* smooth = nullptr, const jxlhip::SigmaParams* sigma = nullptr) {
+static int BlobEnd(JxlHipContext* c, const jxlhip::DcSmoothParams* smooth = nullptr, const jxlhip::SigmaParams* sigma = nullptr,
+                   const jxlhip::DcDequantParams* dequant = nullptr) {
   c->blob_mode = false;
   hipStream_t cs = CopyStream(c->device);
   if (!cs) cs = c->stream;
   if (c->stage.used) HIP_TRY(hipMemcpyAsync(c->frame_blob.p, c->stage.p, c->stage.used, hipMemcpyHostToDevice, cs));
+  if (dequant) {
+    hipLaunchKernelGGL(jxlhip::k_dc_dequant, dim3((dequant->xs + 63) / 64, (dequant->ys + 3) / 4), dim3(256), 0, cs, *dequant);
+    HIP_TRY(hipGetLastError());
+  }
   if (smooth) {
     hipLaunchKernelGGL(jxlhip::k_dc_smooth, dim3((smooth->xs + 63) / 64, (smooth->ys + 3) / 4), dim3(256), 0, cs, *smooth);
     HIP_TRY(hipGetLastError());
@@ -747,7 +753,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     const size_t nblk_b = size_t(d->xsize_blocks) * d->ysize_blocks, ntiles_b = size_t((d->xsize_blocks + 7) / 8) * ((d->ysize_blocks + 7) / 8);
     add(total + 256); add(nsec * 4); add(nsec * 4);
     add(size_t(d->num_blocks) * sizeof(JxlHipVarBlock)); add((size_t(d->num_groups) + 1) * 4); add(d->block_ctx_lut_size);
-    add(size_t(d->dequant_floats) * 4); add(nblk_b * 12); add(nblk_b * 4); add(nblk_b); add(ntiles_b); add(ntiles_b);
+    add(size_t(d->dequant_floats) * 4); add(nblk_b * 12); add(nblk_b * 4); add(nblk_b); add(ntiles_b); add(ntiles_b); add(ntiles_b + 64);
     for (uint32_t p = 0; p < d->num_passes; p++) {
       const JxlHipPassDesc& q = d->passes[p];
       if (q.num_clusters > 256 || (!q.use_prefix && q.log_alpha > 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -807,7 +813,24 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   jxlhip::SigmaParams sigma_p;
   const bool dev_smooth = d->dc_smoothing != 0 && c->xb > 2 && c->yb > 2;  // (compressed_dc.cc:134: smaller images are left alone)
   const bool dev_sigma = !d->inv_sigma && d->epf_iters > 0;
-  if ((!d->dc && !d->dc_device) || (dev_sigma && !d->sharpness)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  jxlhip::DcDequantParams dequant_p;
+  const bool dev_dequant = d->dc_quantised != nullptr && !d->dc_device;
+  if ((!d->dc && !d->dc_device && !d->dc_quantised) || (dev_sigma && !d->sharpness)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (dev_dequant) {
+    for (int ch = 0; ch < 3; ch++)
+      if (!(d->dc_step[ch] > 0.0f)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    const uint32_t xdg = (c->xb + 255) / 256, ydg = (c->yb + 255) / 256;
+    if ((r = Upload(c, c->dc_q, d->dc_quantised, nblk * 3 * 4))) return r;
+    if (d->dc_extra_precision && (r = Upload(c, c->dc_ep, d->dc_extra_precision, size_t(xdg) * ydg))) return r;
+    dequant_p.q = c->dc_q.as<int32_t>();
+    dequant_p.xs = c->xb;
+    dequant_p.ys = c->yb;
+    dequant_p.xgroups = xdg;
+    dequant_p.extra_precision = d->dc_extra_precision ? c->dc_ep.as<uint8_t>() : nullptr;
+    for (int ch = 0; ch < 3; ch++) dequant_p.step[ch] = d->dc_step[ch];
+    dequant_p.cfl_x = d->dc_cfl_x;
+    dequant_p.cfl_b = d->dc_cfl_b;
+  }
   if (d->dc_device) {  // the planes of a DC frame decoded earlier (kUseDcFrame): used where they are, never smoothed
     if (!c->dc.view) c->dc.Free();
     c->dc.p = const_cast<float*>(d->dc_device);
@@ -816,13 +839,21 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   } else if (dev_smooth) {
     for (int ch = 0; ch < 3; ch++)
       if (!(d->dc_step[ch] > 0.0f)) return JXLHIP_ERR_INVALID_ARGUMENT;
-    if ((r = Upload(c, c->dc_raw, d->dc, nblk * 3 * 4))) return r;
+    if (dev_dequant) {  // (the dequantised planes are a kernel's output: an allocation of their own, not a view of the blob)
+      if ((r = c->dc_raw.Ensure(nblk * 3 * 4))) return r;
+      dequant_p.out = c->dc_raw.as<float>();
+    } else if ((r = Upload(c, c->dc_raw, d->dc, nblk * 3 * 4))) {
+      return r;
+    }
     if ((r = c->dc.Ensure(nblk * 3 * 4))) return r;
     smooth_p.in = c->dc_raw.as<float>();
     smooth_p.out = c->dc.as<float>();
     smooth_p.xs = c->xb;
     smooth_p.ys = c->yb;
     for (int ch = 0; ch < 3; ch++) smooth_p.step[ch] = d->dc_step[ch];
+  } else if (dev_dequant) {
+    if ((r = c->dc.Ensure(nblk * 3 * 4))) return r;
+    dequant_p.out = c->dc.as<float>();
   } else if ((r = Upload(c, c->dc, d->dc, nblk * 3 * 4))) {
     return r;
   }
@@ -1216,7 +1247,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->epf_pass2 = d->epf_pass2_sigma_scale;
   c->epf_border = d->epf_border_sad_mul;
   c->ev_valid[0] = c->ev_valid[1] = c->ev_valid[2] = false;
-  if ((r = BlobEnd(c, dev_smooth && !d->dc_device ? &smooth_p : nullptr, dev_sigma ? &sigma_p : nullptr))) return r;  // (records the staging block's event on the copy stream)
+  if ((r = BlobEnd(c, dev_smooth && !d->dc_device ? &smooth_p : nullptr, dev_sigma ? &sigma_p : nullptr, dev_dequant ? &dequant_p : nullptr))) return r;  // (records the staging block's event on the copy stream)
   // The tables are resident when the call returns (batch launches over this context run on other contexts' streams).
   // (Leaving the copies of many contexts in flight at once instead, ordered by events, made every later kernel of the
   // process ~1.35x slower on this runtime: scripts/async_probe.py.)

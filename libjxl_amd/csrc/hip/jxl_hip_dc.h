@@ -1,11 +1,14 @@
 // libjxl_amd: the block-resolution stencils of the DC path as kernels.
+//   k_dc_dequant = DequantDC, reference lib/jxl/compressed_dc.cc:201-296 (the three coded integer planes times the channels'
+//                  quantisation steps, each DC group's extra-precision shift, chroma from luma with the DC factors).
 //   k_dc_smooth  = AdaptiveDCSmoothing, reference lib/jxl/compressed_dc.cc:50-52 (weights), :64-128 (ComputePixelChannel /
 //                  ComputePixel: the multiply-adds below are the reference's MulAdd chain), :130-198 (borders kept).
 //   k_epf_sigma  = ComputeSigma, reference lib/jxl/epf.cc:39-81 (1 / sigma per 8x8 block from the varblock's quant-field
 //                  value and the block's sharpness; the reference's mirrored padding is not stored: the filter kernels
 //                  mirror their reads about the frame).
-// Both run inside jxlhip_frame_upload, on the copy stream behind the frame's table copy, for frames whose descriptor asks
-// for it (JxlHipFrameDesc::dc_smoothing / ::sharpness): the host front-end then does no per-block float work at all.
+// They run inside jxlhip_frame_upload, on the copy stream behind the frame's table copy, for frames whose descriptor asks
+// for it (JxlHipFrameDesc::dc_quantised / ::dc_smoothing / ::sharpness): the host front-end then does no per-block float
+// work at all.
 #ifndef JXL_HIP_DC_H_
 #define JXL_HIP_DC_H_
 
@@ -15,6 +18,32 @@
 #include "../../../include/jxl_amd_hip.h"
 
 namespace jxlhip {
+
+struct DcDequantParams {
+  const int32_t* q;   // [3][ys][xs]: the coded integers of X, Y, B
+  float* out;         // [3][ys][xs]
+  uint32_t xs, ys, xgroups;   // xgroups: DC groups (256 x 256 blocks) per row
+  const uint8_t* extra_precision;  // per DC group: the values are in units of step / 2^this (NULL: 0)
+  float step[3];      // DC quantisation step of X, Y, B
+  float cfl_x, cfl_b; // chroma from luma at DC: base correlation + DC factor * colour scale
+};
+
+// One thread per block. The products are not contracted into multiply-adds: the oracle's (and the reference's scalar)
+// order of operations, so that the planes agree bit for bit.
+__global__ __launch_bounds__(256) void k_dc_dequant(DcDequantParams P) {
+#pragma clang fp contract(off)
+  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.xs || y >= P.ys) return;
+  const size_t plane = size_t(P.xs) * P.ys, at = size_t(y) * P.xs + x;
+  const uint32_t ep = P.extra_precision ? P.extra_precision[(y >> 8) * P.xgroups + (x >> 8)] : 0u;
+  const float mul = 1.0f / float(1u << (ep & 3u));
+  const float in_x = float(P.q[at]) * (P.step[0] * mul);
+  const float in_y = float(P.q[plane + at]) * (P.step[1] * mul);
+  const float in_b = float(P.q[2 * plane + at]) * (P.step[2] * mul);
+  P.out[plane + at] = in_y;
+  P.out[at] = in_y * P.cfl_x + in_x;
+  P.out[2 * plane + at] = in_y * P.cfl_b + in_b;
+}
 
 struct DcSmoothParams {
   const float* in;   // [3][ys][xs] dequantised DC

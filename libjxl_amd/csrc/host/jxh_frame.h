@@ -60,7 +60,10 @@ struct FramePlan {
   // block-resolution planes (xsize_blocks x ysize_blocks)
   // The two stencils over these planes, adaptive DC smoothing (compressed_dc.cc:130-198) and the EPF's 1 / sigma per
   // block (epf.cc:39-81), run on the device inside the upload (csrc/hip/jxl_hip_dc.h): the plan carries their inputs.
-  std::vector<float> dc;            // 3 planes X, Y, B, dequantised, BEFORE adaptive smoothing
+  // DequantDC (compressed_dc.cc:201-296) runs there too: the plan carries the coded integers.
+  std::vector<int32_t> dc_q;        // 3 planes X, Y, B of coded DC integers (empty with kUseDcFrame)
+  std::vector<uint8_t> dc_extra_precision;  // per DC group: the integers are in units of step / 2^this
+  float dc_cfl_x = 0.0f, dc_cfl_b = 1.0f;   // chroma from luma at DC: base correlation + DC factor * colour scale
   bool dc_smoothing = false;        // the frame asks for the smoothing (no kSkipAdaptiveDCSmoothing)
   bool use_dc_frame = false;        // kUseDcFrame: `dc` stays empty, the DC image is `dc_source` (device planes of a DC frame)
   const float* dc_source = nullptr;  // [3][ysize_blocks][xsize_blocks] floats on the device (jxlamd_frame_set_dc_source)
@@ -212,7 +215,8 @@ class FrameParser {
     }
     P.frame_end = base + toc.total;
     const size_t xb = d.xsize_blocks, yb = d.ysize_blocks;
-    P.dc.assign(3 * xb * yb, 0.0f);
+    P.dc_q.assign(3 * xb * yb, 0);
+    P.dc_extra_precision.assign(d.num_dc_groups, 0);
     P.acs.assign(xb * yb, 0xFF);
     P.ytox.assign(DivCeil(xb, 8) * DivCeil(yb, 8), 0);
     P.ytob.assign(P.ytox.size(), 0);
@@ -440,27 +444,24 @@ class FrameParser {
     const size_t bw = std::min(d.group_dim, d.xsize_blocks - bx0), bh = std::min(d.group_dim, d.ysize_blocks - by0);
     const size_t ndc = d.num_dc_groups, xb = d.xsize_blocks;
     if (!P->use_dc_frame) {
-      uint32_t extra_precision = uint32_t(br.Read(2));
-      float mul = 1.0f / float(1 << extra_precision);
+      P->dc_extra_precision[g] = uint8_t(br.Read(2));
       MImage img;
       for (int c = 0; c < 3; c++) img.ch.emplace_back(bw, bh);
       ModularDecode(br, &img, int(1 + g), &P->mglobal);
-      const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
-      float fac[3];
-      for (int c = 0; c < 3; c++) fac[c] = (inv_quant_dc * dq_.dc_quant[c]) * mul;
-      const float cfl_x = P->base_corr_x + ytox_dc_ * P->color_scale, cfl_b = P->base_corr_b + ytob_dc_ * P->color_scale;
+      // (the channels are coded in Y, X, B order; dequantisation and chroma from luma happen on the device)
       const size_t plane = xb * d.ysize_blocks;
       const BlockCtxMap& bc = P->bctx;
       for (size_t y = 0; y < bh; y++) {
         const int32_t *qx = img.ch[1].Row(y), *qy = img.ch[0].Row(y), *qb = img.ch[2].Row(y);
+        const size_t row = (by0 + y) * xb + bx0;
+        memcpy(&P->dc_q[row], qx, bw * sizeof(int32_t));
+        memcpy(&P->dc_q[plane + row], qy, bw * sizeof(int32_t));
+        memcpy(&P->dc_q[2 * plane + row], qb, bw * sizeof(int32_t));
+        if (bc.num_dc_ctxs <= 1) continue;  // (one DC context: the buckets stay 0)
         for (size_t x = 0; x < bw; x++) {
-          size_t idx = (by0 + y) * xb + bx0 + x;
-          float in_x = float(qx[x]) * fac[0], in_y = float(qy[x]) * fac[1], in_b = float(qb[x]) * fac[2];
-          P->dc[plane + idx] = in_y;
-          P->dc[idx] = in_y * cfl_x + in_x;
-          P->dc[2 * plane + idx] = in_y * cfl_b + in_b;
+          size_t idx = row + x;
           uint8_t bucket = 0;
-          if (bc.num_dc_ctxs > 1) {
+          {
             int kx = 0, ky = 0, kb = 0;
             for (int t : bc.dc_thresholds[0]) kx += qx[x] > t;
             for (int t : bc.dc_thresholds[1]) ky += qy[x] > t;
@@ -536,6 +537,9 @@ class FrameParser {
   void FinalizeDc(FramePlan* P) {
     const float inv_quant_dc = P->inv_global_scale / float(P->quant_dc);
     for (int c = 0; c < 3; c++) P->dc_step[c] = inv_quant_dc * dq_.dc_quant[c];
+    P->dc_cfl_x = P->base_corr_x + ytox_dc_ * P->color_scale;
+    P->dc_cfl_b = P->base_corr_b + ytob_dc_ * P->color_scale;
+    if (P->use_dc_frame) P->dc_q.clear();
     P->dc_smoothing = !(P->fh.flags & FrameHeader::kSkipDcSmoothing) && !P->use_dc_frame;
   }
 

@@ -833,10 +833,12 @@ def test_bands_with_halo_exchange_match_the_whole_frame(built, kw):
         hip.hipFree(p)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(distance=3.0, epf_iters=3), dict(distance=0.5, epf_iters=2), dict(size=(1000, 700))])
+@pytest.mark.parametrize("kw", [dict(), dict(distance=3.0, epf_iters=3), dict(distance=0.5, epf_iters=2), dict(size=(1000, 700)),
+                                dict(skip_dc_smoothing=1, custom_cmap=1), dict(custom_lf=1, custom_cmap=1, size=(2300, 300))])
 def test_dc_path_kernels_against_the_oracle_and_a_float64_reading(built, kw):
-    """Row a12 on the device (csrc/hip/jxl_hip_dc.h): the host front-end hands over the dequantised DC image and the
-    sharpness field; k_dc_smooth (AdaptiveDCSmoothing, compressed_dc.cc:64-198) and k_epf_sigma (ComputeSigma,
+    """Row a12 on the device (csrc/hip/jxl_hip_dc.h): the host front-end hands over the coded DC integers and the
+    sharpness field; k_dc_dequant (DequantDC, compressed_dc.cc:201-296; also with non-default DC steps and chroma-from-luma
+    DC factors, and across several DC groups), k_dc_smooth (AdaptiveDCSmoothing, :64-198) and k_epf_sigma (ComputeSigma,
     epf.cc:39-81) run inside the upload. What the transform and filter stages then read is compared with the oracle's
     planes (2e-6, the bar VERDICT round 2 item 4 sets) and with the float64 reading of tests/filters_f64.py."""
     import filters_f64 as F
@@ -849,7 +851,8 @@ def test_dc_path_kernels_against_the_oracle_and_a_float64_reading(built, kw):
     i = o.info
     yb, xb = i["ysize_blocks"], i["xsize_blocks"]
     p = o.dc_params
-    raw, dc_o, sig_o = o.buffer("dc_unsmoothed").reshape(3, yb, xb), o.buffer("dc").reshape(3, yb, xb), o.buffer("inv_sigma").reshape(yb, xb)
+    raw, dc_o, sig_o = o.buffer("dc_unsmoothed"), o.buffer("dc").reshape(3, yb, xb), o.buffer("inv_sigma").reshape(yb, xb)
+    raw = None if raw is None else raw.reshape(3, yb, xb)  # (kSkipAdaptiveDCSmoothing: nothing was smoothed)
     acs, quant, sharp = o.buffer("acs").reshape(yb, xb), o.buffer("quant").reshape(yb, xb), o.buffer("sharpness").reshape(yb, xb)
     o.close()
     f = J.Frame(data, threads=2)
@@ -862,5 +865,8 @@ def test_dc_path_kernels_against_the_oracle_and_a_float64_reading(built, kw):
         c.close()
         f.close()
     assert np.abs(dc_g - dc_o).max() < 2e-6 and np.abs(sig_g / sig_o - 1.0).max() < 2e-6
-    assert np.abs(dc_g - F.dc_smoothing(raw, p["dc_step"])).max() < 2e-6
+    if raw is None:
+        assert np.array_equal(dc_g, dc_o)  # DequantDC alone: the same operations in the same order
+    else:
+        assert np.abs(dc_g - F.dc_smoothing(raw, p["dc_step"])).max() < 2e-6
     assert np.abs(sig_g / F.inv_sigma_blocks(acs, quant, sharp, p["quant_scale"], p["epf_quant_mul"], p["epf_sharp_lut"]) - 1.0).max() < 2e-6
