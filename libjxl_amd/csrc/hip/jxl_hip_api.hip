@@ -1567,6 +1567,10 @@ static EntropyGate g_gate[16];
 // the counter the next batched entropy launch of `device` counts into (NULL: gating unavailable or switched off)
 static unsigned long long* GateCounter(int device) {
   if (device < 0 || device >= 16 || !EnvInt("JXLHIP_ENTROPY_GATE", 1)) return nullptr;
+  // rocprofv3 --pmc (it exports ROCPROF_COUNTER_COLLECTION to the program) runs the kernels one at a time: a launch gated on
+  // another launch's workgroups being resident would wait for a kernel that cannot start. No gate under counter collection.
+  if (const char* cc = getenv("ROCPROF_COUNTER_COLLECTION"))
+    if (*cc && *cc != '0') return nullptr;
   std::lock_guard<std::mutex> lk(g_gate_mu);
   EntropyGate& g = g_gate[device];
   if (!g.tried) {
