@@ -51,7 +51,7 @@ def test_host_reports_the_placement_of_every_frame(built):
     class Placement(ctypes.Structure):
         _fields_ = [("x0", ctypes.c_int32), ("y0", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in (
             "xsize", "ysize", "custom_size", "frame_type", "mode", "alpha_mode", "source", "alpha_source", "clamp", "alpha_clamp", "duration",
-            "is_last", "save_as_reference", "save_before_color_transform")]
+            "is_last", "save_as_reference", "save_before_color_transform", "dc_level", "use_dc_frame")]  # include/jxl_amd.h
 
     L.jxlamd_modframe_placement.argtypes = [ctypes.c_void_p, ctypes.POINTER(Placement)]
     L.jxlamd_modframe_placement.restype = None
