@@ -91,6 +91,12 @@ def main():
     out["wc_multipliers"] = {n: floats(b) for n, b in re.findall(r"struct WcMultipliers<(\d+)>\s*\{[^{]*\{(.*?)\};", ds, re.S)}
     out["dct_resample_scales"] = {"%s_%s" % (a, b): floats(body)
                                   for a, b, body in re.findall(r"struct DCTResampleScales<(\d+),\s*(\d+)>\s*\{[^{]*\{(.*?)\};", ds, re.S)}
+    # splines: kChannelWeight (splines.cc:248); noise: the correlation and normalisation constants (stage_noise.cc:147-193)
+    out["spline_channel_weight"] = array(text("splines.cc"), "kChannelWeight")
+    sn = text("render_pipeline/stage_noise.cc")
+    out["noise_rg_corr"] = floats(re.search(r"kRGCorr\s*=\s*Set\(d,\s*([^)]+)\)", sn).group(1))[0]
+    out["noise_rgn_corr"] = floats(re.search(r"kRGNCorr\s*=\s*Set\(d,\s*([^)]+)\)", sn).group(1))[0]
+    out["noise_norm_const"] = floats(re.search(r"norm_const\s*=\s*Set\(d,\s*([^)]+)\)", sn).group(1))[0]
     sizes = {k: (len(v) if isinstance(v, list) else 1) for k, v in out.items()}
     assert (sizes["upsampling_weights2"], sizes["upsampling_weights4"], sizes["upsampling_weights8"], sizes["dither32"], sizes["afv_basis"],
             sizes["inverse_opsin"], sizes["quant_bias"], sizes["inv_dc_quant"]) == (15, 55, 210, 1024, 256, 9, 4, 3), sizes

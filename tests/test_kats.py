@@ -107,6 +107,13 @@ def test_float_constants_match_the_reference_source(which):
     files = (["oracle/jxlo_render.h"] if which == "oracle" else
              ["libjxl_amd/csrc/hip/jxl_hip_dc.h", "libjxl_amd/csrc/hip/jxl_hip_filter_fused.h"])
     text = "".join(open(os.path.join(ROOT, f)).read() for f in files)
+    # splines' channel weights (splines.cc:248) and the noise stage's constants (stage_noise.cc:147-193): literals as well
+    sp = open(os.path.join(ROOT, "oracle/jxlo_splines.h" if which == "oracle" else "libjxl_amd/csrc/host/jxh_splines.h")).read()
+    cw = [float(v) for v in re.findall(r"[\d.]+", re.search(r"kChannelWeight\[4\]\s*=\s*\{([^}]*)\}", sp).group(1).replace("f", ""))]
+    assert cw == ref["spline_channel_weight"]
+    nz = open(os.path.join(ROOT, "oracle/jxlo_render.h" if which == "oracle" else "libjxl_amd/csrc/hip/jxl_hip_filter_fused.h")).read()
+    for const in (ref["noise_rg_corr"], ref["noise_rgn_corr"], ref["noise_norm_const"]):
+        assert ("%sf" % repr(const)) in nz, const
     sig = {float(v) for v in re.findall(r"-1\.17157\d+", text)}
     mins = {float(v) for v in re.findall(r"-3\.90524\d+", text)}
     assert sig and mins and all(abs(v - ref["inv_sigma_num"]) < 1e-12 for v in sig) and all(abs(v - ref["min_sigma"]) < 1e-12 for v in mins)
