@@ -38,7 +38,7 @@ def test_oracle_alpha_over_closed_form(built):
     assert np.array_equal(got[:40, :, :3], base[:40])  # untouched outside the rectangle
 
 
-def test_host_reports_the_placement_of_every_frame(built):
+def test_host_reports_the_placement_of_every_frame(built, tmp_path):
     J = built
     base, opaque, patch, ramp = _parts(J)
     data = J.encode_layers([dict(img=np.dstack([base, opaque]), save_as=1, duration=2),
@@ -53,6 +53,14 @@ def test_host_reports_the_placement_of_every_frame(built):
             "xsize", "ysize", "custom_size", "frame_type", "mode", "alpha_mode", "source", "alpha_source", "clamp", "alpha_clamp", "duration",
             "is_last", "save_as_reference", "save_before_color_transform", "dc_level", "use_dc_frame")]  # include/jxl_amd.h
 
+    # (this mirror is written to by the C side: it must be as large as the header's struct, or the call corrupts the heap)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(tmp_path), "placement_size")
+    subprocess.run(["gcc", "-x", "c", "-", "-I" + os.path.join(root, "include"), "-o", exe], check=True, text=True,
+                   input='#include <stdio.h>\n#include "jxl_amd.h"\nint main(void) { printf("%zu", sizeof(JxlAmdFramePlacement)); return 0; }\n')
+    assert int(subprocess.run([exe], capture_output=True, text=True, check=True).stdout) == ctypes.sizeof(Placement)
     L.jxlamd_modframe_placement.argtypes = [ctypes.c_void_p, ctypes.POINTER(Placement)]
     L.jxlamd_modframe_placement.restype = None
     pos, seen = 0, []
