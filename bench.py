@@ -54,6 +54,21 @@ def cpu_baseline(data, xsize, ysize, budget_s=20.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    # A timing-only object of the same source, built HERE for this host's CPU: -O3 -march=native as SURVEY.md 8d / BASELINE.md
+    # B2 ask (the parity build oracle/libjxlo.so is -O2 -ffp-contract=off for every x86-64: its arithmetic must not depend on
+    # the machine, its speed undersells the CPU). Falls back to the parity build, and says so, when the host cannot compile.
+    flags = "-O2 -ffp-contract=off (the parity build: this host could not build the timing-only object)"
+    try:
+        import subprocess
+        import tempfile
+        fast = os.path.join(tempfile.mkdtemp(prefix="jxlo_fast_"), "libjxlo_fast.so")
+        fast_flags = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-fopenmp", "-Wno-unused-function"]
+        subprocess.run(["g++"] + fast_flags + ["-shared", "-o", fast, os.path.join(ROOT, "oracle", "jxlo_decoder.cc")], check=True,
+                       capture_output=True, timeout=300)
+        jxlo.LIB_PATH, jxlo._lib = fast, None
+        flags = " ".join(fast_flags[:2]) + " (timing-only object built on this host; the parity build is -O2 -ffp-contract=off)"
+    except Exception:  # noqa: BLE001
+        pass
     threads = jxlo.lib().jxlo_set_threads(min(avail, 64))
     times, used = [], []
     t_start = time.time()
@@ -66,7 +81,7 @@ def cpu_baseline(data, xsize, ysize, budget_s=20.0):
     best = min(times)
     # cores = what the threads really got (a cgroup CPU share can be far below the visible CPU count): CPU time / wall time
     cores = max(1, int(round(used[times.index(best)])))
-    return {"value": round(xsize * ysize * 1e-6 / best, 3), "unit": "MP/s", "cores": cores, "threads": threads, "kind": "port",
+    return {"value": round(xsize * ysize * 1e-6 / best, 3), "unit": "MP/s", "cores": cores, "threads": threads, "kind": "port", "build": flags,
             "sample": "%d full %dx%d frame decode(s) of the benchmark stream, best of %d" % (len(times), xsize, ysize, len(times))}
 
 
@@ -503,6 +518,8 @@ def main():
                          "them are exchanged with the neighbouring ranks after the transform stage (RCCL send / recv of dense "
                          "device blocks; jxlhip_halo_*), instead of decoding one group row of overlap either side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-libjxl-tables", action="store_true",
+                    help="skip the second measurement of the default line (the same schedule over streams with 128 histogram clusters)")
     ap.add_argument("--no-pipeline", action="store_true", help="one frame set: entropy, then transform+filter, in sequence")
     ap.add_argument("--two-set", action="store_true",
                     help="the round-1 schedule: entropy(set A) beside transform(B) -> filter+colour(B), the sets' XYB planes shared")
@@ -624,6 +641,12 @@ def main():
     if three:
         for cs in sets:
             cs[0].set_option("filter_async", 1)
+    if nsets == 2 and not free_running:
+        # this schedule keeps a set's entropy launch and the other set's transform / filter launches in flight together
+        # and enqueues every launch itself, in an order in which each one can start: it asks for the entropy gate (off by
+        # default in the library; ignored by it when the runtime may run kernels one at a time)
+        for cs in sets:
+            cs[0].set_option("entropy_gate", 1)
     if nsets == 2 and not args.no_share_planes and not three and not free_running:  # (three-stage: both sets' planes are live at once)
         # the XYB planes of a frame only live between its transform and its filter stage, and the two sets are never in
         # those stages at the same time: set 1 keeps its planes in set 0's buffers (100 MB less per pair of 4K frames)
@@ -631,13 +654,16 @@ def main():
             b.share_planes(a)
     if chain:
         sets[0][0].set_option("filter_async", 1)
-    nth = 0
-    for cs in sets:
-        for c in cs:
-            if band is not None and args.halo:
-                c.set_option("band_halo", 1)
-            c.upload(frames[nth % ndistinct], band=band)
-            nth += 1
+    def load(frs):
+        nth = 0
+        for cs in sets:
+            for c in cs:
+                if band is not None and args.halo:
+                    c.set_option("band_halo", 1)
+                c.upload(frs[nth % len(frs)], band=band)
+                nth += 1
+
+    load(frames)
 
     def exchange_halos(cs):
         # after the transform stage of a band set: this rank's boundary rows to its neighbours, theirs beside its band; one
@@ -646,15 +672,20 @@ def main():
             return
         n = cs[0].halo_floats()
 
+        # Ordering: the library copies on ITS stream, the transport (c10d over RCCL) orders its
+        # communication stream against torch's CURRENT stream only. The _batch calls tie the two together with events:
+        # pack -> torch's stream waits for the copies -> dist.send; dist.recv (the current stream waits for the receive
+        # when the call returns) -> the library's stream waits for torch's stream -> unpack -> the set's filter launch.
+        # No host synchronisation anywhere.
+        ts = torch.cuda.current_stream().cuda_stream
+
         def pack(side):
             t = torch.empty(len(cs) * n, dtype=torch.float32, device="cuda")
-            for i, c in enumerate(cs):
-                c.halo_pack(side, t.data_ptr() + i * n * 4, n * 4)
+            J.halo_pack_batch(cs, side, t.data_ptr(), n * 4, ts)
             return t
 
         def unpack(side, t):
-            for i, c in enumerate(cs):
-                c.halo_unpack(side, t.data_ptr() + i * n * 4, n * 4)
+            J.halo_unpack_batch(cs, side, t.data_ptr(), n * 4, ts)
 
         def recv(peer):
             t = torch.empty(len(cs) * n, dtype=torch.float32, device="cuda")
@@ -662,11 +693,14 @@ def main():
             return t
 
         sharding.exchange_halos(rank, world, pack, unpack, lambda t, peer: dist.send(t, peer), recv)
-    for cs in sets:  # prime: every set holds decoded coefficients before the first (warmup) step
-        J.run_entropy_batch(cs)
-    for cs in sets:
-        for c in cs:
-            c.sync()
+    def prime():  # every set holds decoded coefficients before the first (warmup) step
+        for cs in sets:
+            J.run_entropy_batch(cs)
+        for cs in sets:
+            for c in cs:
+                c.sync()
+
+    prime()
     step_no = [0]
 
     def step():
@@ -753,6 +787,32 @@ def main():
         c.sync()
         ent_alone = min(ent_alone, c.stage_ms(0))
     stage_ms = [entropy_ms / args.steps / args.batch, iso[0], iso[1]]
+    # The same schedule over streams with libjxl-sized entropy tables: the synthetic encoder clusters
+    # to at most 64 histograms by default, libjxl to kClustersLimit = 128 (lib/jxl/enc_ans.cc:931), whose alias tables
+    # (128 x 2^6 entries x 8 B = 64 KB per frame) no longer leave every frame of the launch resident in LDS: the lane kernel
+    # then reads them in place from global memory. Reported beside `value`, never instead of it.
+    libjxl_tables = None
+    if world == 1 and args.max_clusters == 0 and args.ac_code_mode == 0 and not args.no_libjxl_tables and args.shard == "frames":
+        datas128 = [make_stream(xsize, ysize, args.distance, 177 + i, 128, 0) for i in range(ndistinct)]
+        frames128 = [J.Frame(d, threads=min(8, os.cpu_count() or 1)) for d in datas128]
+        load(frames128)
+        prime()
+        for _ in range(max(1, args.warmup)):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        el128 = time.perf_counter() - t1
+        libjxl_tables = {"value": round(args.batch * args.steps * xsize * ysize * 1e-6 / el128, 2), "unit": "MP/s",
+                         "ms_per_step": round(el128 / args.steps * 1e3, 3), "max_clusters": 128,
+                         "clusters": [f.info["num_clusters"] for f in frames128],
+                         "bpp": round(sum(len(d) for d in datas128) / float(ndistinct) * 8.0 / (xsize * ysize), 3),
+                         "note": "same frames, schedule and timed region as `value`; histograms clustered to libjxl's limit of 128 "
+                                 "(enc_ans.cc:931) instead of the synthetic encoder's default 64"}
+        for f in frames128:
+            f.close()
     for cs in sets:  # the frame sets' device memory is released before the end-to-end measurement allocates its own
         for c in cs:
             c.close()
@@ -794,6 +854,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 3),
+            "value_libjxl_tables": libjxl_tables["value"] if libjxl_tables else None,
+            "libjxl_tables": libjxl_tables,
             "higher_is_better": True,
             "scaling": "weak" if args.shard == "frames" else "strong",
             "vs_baseline": None,
@@ -817,6 +879,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "frames_per_launch": frames_per_launch, "launch_ms": round(stage_ms[dom] * frames_per_launch, 4),
                          "launch_ms_alone": round(ent_alone, 4) if dom == 0 else None,
+                         # > 1: consecutive steps' launches of this kernel (one per frame set, each on its own stream) overlap
+                         "launch_overlap_factor": round(stage_ms[dom] * frames_per_launch / (max_elapsed / args.steps * 1e3), 3) if dom == 0 else None,
                          "frac_alone": round(alg[names[0]] * args.batch / (ent_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if dom == 0 else None,
                          "algorithmic_bytes_per_launch": int(alg[names[dom]] * frames_per_launch),
                          "note": ("entropy decode is serial per 256x256 group (latency-bound, not HBM-bound); amortised over the frames of one "

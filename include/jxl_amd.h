@@ -48,6 +48,11 @@ typedef struct {
   uint32_t dc_level, use_dc_frame;
 } JxlAmdFramePlacement;
 void jxlamd_frame_placement(const JxlAmdFrame* frame, JxlAmdFramePlacement* placement);
+/* The struct above has grown (dc_level, use_dc_frame) and may grow again; it carries no size field. Callers that are not
+ * compiled against THIS header (FFI mirrors, older binaries) use the sized forms: at most `out_size` bytes are written,
+ * the return value is sizeof(JxlAmdFramePlacement) as this library knows it (also: jxlamd_sizeof_frame_placement). */
+size_t jxlamd_sizeof_frame_placement(void);
+size_t jxlamd_frame_placement_sized(const JxlAmdFrame* frame, void* placement, size_t out_size);
 /* The frame's position among the shown / invisible frames (seeds its noise: dec_frame.cc:160-168); before upload. */
 void jxlamd_frame_set_indices(JxlAmdFrame* frame, uint32_t visible_index, uint32_t nonvisible_index);
 /* The reference frames a frame's patches read (device XYB planes of the four slots, jxlhip_canvas_xyb_source); checks every
@@ -89,6 +94,7 @@ int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** fra
 int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlAmdModFrame** frame);
 size_t jxlamd_modframe_end(const JxlAmdModFrame* frame, uint32_t* duration_last_timecode);
 void jxlamd_modframe_placement(const JxlAmdModFrame* frame, JxlAmdFramePlacement* placement);
+size_t jxlamd_modframe_placement_sized(const JxlAmdModFrame* frame, void* placement, size_t out_size);
 void jxlamd_modframe_free(JxlAmdModFrame* frame);
 /* info[0..9]: xsize, ysize, colour channels, has alpha, bits per sample, streams, channel buffers, transform operations,
  * extra channels, compressed bytes of all sections. */

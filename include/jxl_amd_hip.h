@@ -271,6 +271,12 @@ int jxlhip_download(JxlHipContext* ctx, const char* name, void* dst, size_t dst_
  * with the next entropy launch (which touches neither planes nor pixels): the LDS-hungry entropy and transform kernels
  * never share the GPU, the LDS-free filter fills the gaps of the latency-bound entropy kernel. The library keeps the
  * order: the next transform, upload, download or sync of any frame of the set waits for the filter launch.
+ * "entropy_gate" = 1 on the FIRST context of a frame set, for callers that keep a set's batched entropy launch and other
+ * sets' batched transform / filter launches in flight together: the entropy launch must get the machine first (its few,
+ * LDS-heavy workgroups find no room behind a stream of small ones: 133 ms instead of 62), so the transform / filter
+ * launches enqueued after it wait ON THE DEVICE (hipStreamWaitValue64) until its workgroups are resident. The wait has no
+ * bound, hence off by default, and the library ignores the option when the runtime may run kernels one at a time
+ * (AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, GPU_MAX_HW_QUEUES=1, counter collection by rocprofv3).
  * "blocking_sync" = 1 (process-wide for the context's device): host threads that wait for the device sleep instead of
  * spinning; for servers that pipeline frames over more host threads than they have CPUs to spare. */
 int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
@@ -282,11 +288,21 @@ int jxlhip_set_option(JxlHipContext* ctx, const char* name, int value);
  * EPF 2 / 3 / 6 more) are exchanged after the transform stage: the neighbour packs them (side 0 = its first rows,
  * side 1 = its last rows) into a dense [3][rows][padded xsize] f32 block of DEVICE memory, any device-to-device transport
  * (hipMemcpyPeerAsync, an RCCL send / recv) moves the block, and jxlhip_halo_unpack writes it beside the band (side 0 =
- * above it, side 1 = below it). Both calls run behind the context's transform stage and are complete when they return;
- * the filter stage follows them. */
+ * above it, side 1 = below it). Both calls run behind the context's transform stage and are complete when they return
+ * (one host synchronisation per call); the filter stage follows them.
+ * The _batch forms take every frame of a set (the contexts of one jxlhip_run_transform_batch call, in that order; block i
+ * of `block_bytes` bytes at `device + i * block_bytes`) and never block the host: `transport_stream` is the hipStream_t the
+ * caller's transport is enqueued on (for torch.distributed over RCCL: torch's current stream, which c10d orders its
+ * communication stream against). pack: the copies follow the set's transform launch, and everything enqueued on
+ * transport_stream after the call follows the copies. unpack: the copies follow everything enqueued on transport_stream
+ * BEFORE the call (the receive), the set's filter launch follows the copies, and work enqueued on transport_stream after
+ * the call (re-use of the blocks) follows them too. */
 int jxlhip_halo_rows(JxlHipContext* ctx, uint32_t* rows);
 int jxlhip_halo_pack(JxlHipContext* ctx, int side, void* dst_device, size_t dst_bytes);
 int jxlhip_halo_unpack(JxlHipContext* ctx, int side, const void* src_device, size_t src_bytes);
+int jxlhip_halo_pack_batch(JxlHipContext* const* ctxs, size_t n, int side, void* dst_device, size_t block_bytes, void* transport_stream);
+int jxlhip_halo_unpack_batch(JxlHipContext* const* ctxs, size_t n, int side, const void* src_device, size_t block_bytes,
+                             void* transport_stream);
 
 /* Test entry: runs the colour stage alone (XYB -> linear RGB -> sRGB transfer function unless linear_output) on n
  * XYB triples, planar [3][n], with the opsin parameters of the frame the context last uploaded; interleaved f32 RGB out.

@@ -364,6 +364,24 @@ def run_entropy_batch(ctxs):
     _check(lib().jxlhip_run_entropy_batch(arr, len(ctxs)), "jxlhip_run_entropy_batch")
 
 
+def halo_pack_batch(ctxs, side, device_ptr, block_bytes, transport_stream=0):
+    """jxlhip_halo_pack_batch: block i (frame i of the set) at device_ptr + i * block_bytes; whatever is enqueued on
+    `transport_stream` (a hipStream_t as an integer; 0 = the null stream) afterwards follows the copies. No host wait."""
+    L = lib()
+    L.jxlhip_halo_pack_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(L.jxlhip_halo_pack_batch(arr, len(ctxs), side, device_ptr, block_bytes, transport_stream), "jxlhip_halo_pack_batch")
+
+
+def halo_unpack_batch(ctxs, side, device_ptr, block_bytes, transport_stream=0):
+    """jxlhip_halo_unpack_batch: the copies follow what `transport_stream` holds now (the receive); the set's filter launch
+    follows the copies. No host wait."""
+    L = lib()
+    L.jxlhip_halo_unpack_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    _check(L.jxlhip_halo_unpack_batch(arr, len(ctxs), side, device_ptr, block_bytes, transport_stream), "jxlhip_halo_unpack_batch")
+
+
 def run_transform_batch(ctxs):
     arr = (ctypes.c_void_p * len(ctxs))(*[c._h for c in ctxs])
     _check(lib().jxlhip_run_transform_batch(arr, len(ctxs)), "jxlhip_run_transform_batch")

@@ -463,6 +463,24 @@ int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos,
 void jxlamd_modframe_placement(const JxlAmdModFrame* f, JxlAmdFramePlacement* p) {
   FillPlacement(f->plan.ih, f->plan.fh, f->plan.dim.xsize, f->plan.dim.ysize, p);
 }
+// The sized forms: the caller says how large ITS struct is; never more than that is written (a caller built against an
+// older header, or a hand-written FFI mirror, gets the leading fields it knows about), and the return value is the size
+// of this library's struct so that a binding can tell.
+size_t jxlamd_sizeof_frame_placement(void) { return sizeof(JxlAmdFramePlacement); }
+size_t jxlamd_frame_placement_sized(const JxlAmdFrame* f, void* out, size_t out_size) {
+  JxlAmdFramePlacement p;
+  memset(&p, 0, sizeof(p));
+  jxlamd_frame_placement(f, &p);
+  if (out) memcpy(out, &p, out_size < sizeof(p) ? out_size : sizeof(p));
+  return sizeof(p);
+}
+size_t jxlamd_modframe_placement_sized(const JxlAmdModFrame* f, void* out, size_t out_size) {
+  JxlAmdFramePlacement p;
+  memset(&p, 0, sizeof(p));
+  jxlamd_modframe_placement(f, &p);
+  if (out) memcpy(out, &p, out_size < sizeof(p) ? out_size : sizeof(p));
+  return sizeof(p);
+}
 void jxlamd_modframe_free(JxlAmdModFrame* f) { delete f; }
 size_t jxlamd_modframe_end(const JxlAmdModFrame* f, uint32_t* t) {
   if (t) {

@@ -288,6 +288,8 @@ struct JxlHipContext {
   // the launch's end event; waited for by whatever touches the planes or the pixels next (transform, download, sync,
   // upload), never by an entropy launch.
   bool filter_async = false;
+  bool entropy_gate = false;  // option "entropy_gate" (see EntropyGate)
+  hipEvent_t halo_event = nullptr;  // jxlhip_halo_*_batch: orders the halo copies against the transport's stream
   bool owns_stream = false;   // `stream` is this context's own (it heads batched launches), not one of the shared pool
   hipStream_t stream2 = nullptr;
   hipStream_t fstream = nullptr;  // stream of the filter launch in progress (set by BeginDownstreamBatch)
@@ -490,6 +492,7 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->transform_done) (void)hipEventDestroy(c->transform_done);
   if (c->filter_done) (void)hipEventDestroy(c->filter_done);
+  if (c->halo_event) (void)hipEventDestroy(c->halo_event);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream && c->owns_stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1560,17 +1563,37 @@ struct EntropyGate {
   unsigned long long* counter = nullptr;  // device memory (hipMallocSignalMemory)
   unsigned long long total = 0;           // workgroups of every launch so far
   unsigned long long target = 0;          // count at which the latest launch is resident
+  unsigned cus = 256;                     // compute units and LDS bytes per unit of the device (read with the counter)
+  size_t lds_per_cu = 160 * 1024;
   bool tried = false;
 };
 static std::mutex g_gate_mu;
 static EntropyGate g_gate[16];
-// the counter the next batched entropy launch of `device` counts into (NULL: gating unavailable or switched off)
-static unsigned long long* GateCounter(int device) {
-  if (device < 0 || device >= 16 || !EnvInt("JXLHIP_ENTROPY_GATE", 1)) return nullptr;
-  // rocprofv3 --pmc (it exports ROCPROF_COUNTER_COLLECTION to the program) runs the kernels one at a time: a launch gated on
-  // another launch's workgroups being resident would wait for a kernel that cannot start. No gate under counter collection.
-  if (const char* cc = getenv("ROCPROF_COUNTER_COLLECTION"))
-    if (*cc && *cc != '0') return nullptr;
+// True when this process's kernels may be run one at a time (runtime debug switches, a single hardware queue, counter
+// collection by a profiler): a device-side wait for ANOTHER launch's workgroups could then wait for a kernel that is not
+// allowed to start, so the gate is never used there. Read once.
+static bool RuntimeMaySerialise() {
+  static const bool v = [] {
+    auto on = [](const char* n) {
+      const char* e = getenv(n);
+      return e && *e && !(e[0] == '0' && !e[1]);
+    };
+    if (on("AMD_SERIALIZE_KERNEL") || on("AMD_SERIALIZE_COPY") || on("HIP_LAUNCH_BLOCKING") || on("ROCPROF_COUNTER_COLLECTION") ||
+        on("HSA_ENABLE_DEBUG") || on("ROCM_DEBUG_AGENT") || on("HIP_ENABLE_DEFERRED_LOADING_DEBUG"))
+      return true;
+    if (const char* q = getenv("GPU_MAX_HW_QUEUES"))
+      if (*q && atoi(q) < 2) return true;
+    if (const char* t = getenv("HSA_TOOLS_LIB"))  // a debugger / tracer intercepting the queues (rocgdb, roctracer)
+      if (*t && (strstr(t, "debug") || strstr(t, "rocgdb"))) return true;
+    return false;
+  }();
+  return v;
+}
+// the counter the next batched entropy launch of `device` counts into (NULL: gating unavailable, not asked for by the
+// caller -- option "entropy_gate" of the launch's first context, off by default -- or unsafe in this process)
+static unsigned long long* GateCounter(const JxlHipContext* c0) {
+  const int device = c0->device;
+  if (device < 0 || device >= 16 || !c0->entropy_gate || !EnvInt("JXLHIP_ENTROPY_GATE", 1) || RuntimeMaySerialise()) return nullptr;
   std::lock_guard<std::mutex> lk(g_gate_mu);
   EntropyGate& g = g_gate[device];
   if (!g.tried) {
@@ -1581,6 +1604,10 @@ static unsigned long long* GateCounter(int device) {
       if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess && hipMemset(p, 0, 8) == hipSuccess)
         g.counter = static_cast<unsigned long long*>(p);
     }
+    (void)hipGetLastError();
+    int cus = 0, lds = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) g.cus = unsigned(cus);
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess && lds > 0) g.lds_per_cu = size_t(lds);
     (void)hipGetLastError();
   }
   return g.counter;
@@ -1637,7 +1664,7 @@ static int BeginDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filte
     }
   }
   c0->fstream = ls;
-  if (n > 1) {  // (see EntropyGate)
+  if (n > 1 && c0->entropy_gate && !RuntimeMaySerialise()) {  // (see EntropyGate)
     const int r = GateWait(c0->device, ls);
     if (r) return r;
   }
@@ -1735,7 +1762,7 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
   b.wave_log_ls = c0->batch_wave_ls.as<uint8_t>();
   b.debug = uint32_t(EnvInt("JXLHIP_LANES_DEBUG", 0));
   b.prof = nullptr;
-  b.started = c0->batch_ctxs.size() > 1 ? GateCounter(c0->device) : nullptr;
+  b.started = c0->batch_ctxs.size() > 1 ? GateCounter(c0) : nullptr;
   const bool prof = EnvInt("JXLHIP_LANES_PROF", 0) != 0;  // debugging aid: per-wave cycle split, printed to stderr
   const size_t nwaves = size_t(c0->batch_wgs) * WPG;
   if (prof) {
@@ -1747,7 +1774,13 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
   if (b.started) {
     // "resident" = as many of its workgroups as the chip's LDS holds at once, less a margin (the rest start as the first
     // ones end, and are not waited for)
-    const unsigned long long per_cu = c0->batch_lds ? (160 * 1024) / c0->batch_lds : 8, cap = 256 * (per_cu ? per_cu : 1) * 3 / 4;
+    unsigned long long cus, lds_cu;
+    {
+      std::lock_guard<std::mutex> lk(g_gate_mu);
+      cus = g_gate[c0->device].cus;
+      lds_cu = g_gate[c0->device].lds_per_cu;
+    }
+    const unsigned long long per_cu = c0->batch_lds ? lds_cu / c0->batch_lds : 8, cap = cus * (per_cu ? per_cu : 1) * 3 / 4;
     GateAdvance(c0->device, c0->batch_wgs, cap);
   }
   if (prof) {
@@ -2897,43 +2930,100 @@ int jxlhip_halo_rows(JxlHipContext* c, uint32_t* rows) {
   return 0;
 }
 namespace {
-// rows [y0, y0 + rows) of the three planes <-> a dense [3][rows][xp] f32 block
-int HaloCopy(JxlHipContext* c, uint32_t y0, uint32_t rows, void* block, bool to_block) {
+// rows [y0, y0 + rows) of the three planes <-> a dense [3][rows][xp] f32 block, enqueued on `st`
+int HaloCopy(JxlHipContext* c, uint32_t y0, uint32_t rows, void* block, bool to_block, hipStream_t st) {
   const size_t row_bytes = size_t(c->xp) * 4, plane = size_t(c->xp) * c->yp;
   float* planes = PlaneHolder(c)->plane[0].as<float>();
-  int r = ApplyPendingWait(c);  // (behind the batched transform launch that produced the planes)
-  if (r) return r;
   for (int ch = 0; ch < 3; ch++) {
     float* in_plane = planes + ch * plane + size_t(y0) * c->xp;
     float* in_block = static_cast<float*>(block) + size_t(ch) * rows * c->xp;
-    HIP_TRY(hipMemcpyAsync(to_block ? in_block : in_plane, to_block ? in_plane : in_block, row_bytes * rows, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(to_block ? in_block : in_plane, to_block ? in_plane : in_block, row_bytes * rows, hipMemcpyDeviceToDevice, st));
   }
-  // the block is handed to a transport / the planes to a filter launch on another stream: complete before returning
-  HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
+int HaloCheck(JxlHipContext* c, int side, const void* p, size_t bytes, bool pack, uint32_t* rows) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  int r = jxlhip_halo_rows(c, rows);
+  if (r) return r;
+  if (!p || (side != 0 && side != 1) || bytes < size_t(3) * *rows * c->xp * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (pack ? c->band_y1 - c->band_y0 < *rows : (side == 0 ? c->band_y0 < *rows : c->band_y1 + *rows > c->ys)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  return 0;
+}
+// the stream on which the halo copies of a frame set led by c0 run: the one its batched transform launch ran on
+hipStream_t HaloStream(JxlHipContext* c0) { return c0->stream; }
 }  // namespace
 // side 0: the first rows of this band (what the band ABOVE needs), side 1: its last rows (what the band BELOW needs);
 // `dst` = device memory of at least 3 * rows * xp floats. Runs behind the context's transform; complete on return.
 int jxlhip_halo_pack(JxlHipContext* c, int side, void* dst, size_t dst_bytes) {
   uint32_t rows = 0;
-  int r = jxlhip_halo_rows(c, &rows);
+  int r = HaloCheck(c, side, dst, dst_bytes, true, &rows);
   if (r) return r;
-  if (!dst || (side != 0 && side != 1) || dst_bytes < size_t(3) * rows * c->xp * 4 || c->band_y1 - c->band_y0 < rows) return JXLHIP_ERR_INVALID_ARGUMENT;
   HIP_TRY(hipSetDevice(c->device));
   if (!rows) return 0;
-  return HaloCopy(c, side == 0 ? c->band_y0 : c->band_y1 - rows, rows, dst, true);
+  if ((r = ApplyPendingWait(c))) return r;  // (behind the batched transform launch that produced the planes)
+  if ((r = HaloCopy(c, side == 0 ? c->band_y0 : c->band_y1 - rows, rows, dst, true, c->stream))) return r;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the block is handed to a transport this library knows nothing about
+  return 0;
 }
 // side 0: the rows just above this band (the band above packed them with side 1), side 1: the rows just below it.
 int jxlhip_halo_unpack(JxlHipContext* c, int side, const void* src, size_t src_bytes) {
   uint32_t rows = 0;
-  int r = jxlhip_halo_rows(c, &rows);
+  int r = HaloCheck(c, side, src, src_bytes, false, &rows);
   if (r) return r;
-  if (!src || (side != 0 && side != 1) || src_bytes < size_t(3) * rows * c->xp * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (side == 0 ? c->band_y0 < rows : c->band_y1 + rows > c->ys) return JXLHIP_ERR_INVALID_ARGUMENT;  // (no band on that side)
   HIP_TRY(hipSetDevice(c->device));
   if (!rows) return 0;
-  return HaloCopy(c, side == 0 ? c->band_y0 - rows : c->band_y1, rows, const_cast<void*>(src), false);
+  if ((r = ApplyPendingWait(c))) return r;
+  if ((r = HaloCopy(c, side == 0 ? c->band_y0 - rows : c->band_y1, rows, const_cast<void*>(src), false, c->stream))) return r;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the planes go to a filter launch on another stream
+  return 0;
+}
+// The set forms: every frame of a set (the contexts of one batched transform launch, same order) in one call, block i at
+// `dst + i * block_bytes`, ordered against the TRANSPORT's stream by events instead of host synchronisation.
+int jxlhip_halo_pack_batch(JxlHipContext* const* ctxs, size_t n, int side, void* dst, size_t block_bytes, void* transport_stream) {
+  if (!ctxs || !n || !ctxs[0]) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JxlHipContext* c0 = ctxs[0];
+  HIP_TRY(hipSetDevice(c0->device));
+  hipStream_t st = HaloStream(c0);
+  uint32_t rows = 0;
+  for (size_t i = 0; i < n; i++) {
+    int r = HaloCheck(ctxs[i], side, dst, block_bytes, true, &rows);
+    if (r) return r;
+    if (ctxs[i]->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (!rows) continue;
+    // (the set's transform launch ran on this very stream: a frame's `pending_wait`, which names that launch, stays for its filter stage)
+    if ((r = HaloCopy(ctxs[i], side == 0 ? ctxs[i]->band_y0 : ctxs[i]->band_y1 - rows, rows, static_cast<uint8_t*>(dst) + i * block_bytes, true, st))) return r;
+  }
+  if (!c0->halo_event) HIP_TRY(hipEventCreateWithFlags(&c0->halo_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c0->halo_event, st));
+  HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(transport_stream), c0->halo_event, 0));  // the transport reads the blocks after the copies
+  return 0;
+}
+int jxlhip_halo_unpack_batch(JxlHipContext* const* ctxs, size_t n, int side, const void* src, size_t block_bytes, void* transport_stream) {
+  if (!ctxs || !n || !ctxs[0]) return JXLHIP_ERR_INVALID_ARGUMENT;
+  JxlHipContext* c0 = ctxs[0];
+  HIP_TRY(hipSetDevice(c0->device));
+  hipStream_t st = HaloStream(c0);
+  // the copies read the blocks after whatever the transport's stream holds NOW (the receive the caller enqueued there)
+  if (!c0->halo_event) HIP_TRY(hipEventCreateWithFlags(&c0->halo_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(c0->halo_event, static_cast<hipStream_t>(transport_stream)));
+  HIP_TRY(hipStreamWaitEvent(st, c0->halo_event, 0));
+  uint32_t rows = 0;
+  for (size_t i = 0; i < n; i++) {
+    int r = HaloCheck(ctxs[i], side, src, block_bytes, false, &rows);
+    if (r) return r;
+    if (ctxs[i]->device != c0->device) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (!rows) continue;
+    if ((r = HaloCopy(ctxs[i], side == 0 ? ctxs[i]->band_y0 - rows : ctxs[i]->band_y1, rows,
+                      const_cast<uint8_t*>(static_cast<const uint8_t*>(src)) + i * block_bytes, false, st)))
+      return r;
+  }
+  // the set's filter launch follows the copies: on this stream by stream order; on the second stream (option
+  // "filter_async") it waits for `transform_done`, which is moved behind the copies here. The transport's stream must not
+  // recycle the blocks before the copies have read them either.
+  if (c0->filter_async && c0->transform_done_valid) HIP_TRY(hipEventRecord(c0->transform_done, st));
+  HIP_TRY(hipEventRecord(c0->halo_event, st));
+  HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(transport_stream), c0->halo_event, 0));
+  return 0;
 }
 
 int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
@@ -2948,6 +3038,14 @@ int jxlhip_set_option(JxlHipContext* c, const char* name, int value) {
   }
   if (std::string(name) == "filter_async") {
     c->filter_async = value != 0;
+    return 0;
+  }
+  if (std::string(name) == "entropy_gate") {
+    // Set on the FIRST context of a frame set by callers that keep several batched launches in flight (bench.py's
+    // pipeline): the set's batched entropy launches then count their workgroups in, and batched transform / filter
+    // launches enqueued after one wait (a device-side wait packet) until it is resident: see EntropyGate. Off by default:
+    // the wait has no bound, so it is only for callers that know every launch they enqueue can start.
+    c->entropy_gate = value != 0;
     return 0;
   }
   if (std::string(name) == "keep_xyb_planes") {  // (takes effect at the next Modular upload)

@@ -16,6 +16,7 @@ BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-frames 0
 RE="k_entropy|k_idct|k_filter|k_dct|k_special|k_color"
 timeout -k 10 ${PMC_TIMEOUT:-260} rocprofv3 --output-format csv --kernel-include-regex "$RE" --pmc FETCH_SIZE -d $RAW/f -o f -- $BENCH > $OUT/pmc_bench.json 2> $RAW/f.log; echo "fetch pass rc $?"
 timeout -k 10 ${PMC_TIMEOUT:-260} rocprofv3 --output-format csv --kernel-include-regex "$RE" --pmc WRITE_SIZE -d $RAW/w -o w -- $BENCH > /dev/null 2> $RAW/w.log; echo "write pass rc $?"
-python3 $R/scripts/pmc_summary.py $(find $RAW/f -name "*counter_collection.csv" | head -1) $(find $RAW/w -name "*counter_collection.csv" | head -1) $OUT/r03_pmc_traffic.json 640 && head -c 600 $OUT/r03_pmc_traffic.json
+FRAMES=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['config']['frames_per_step_per_gpu'])" $OUT/pmc_bench.json)  # (what the bench line of this very pass says: not a literal)
+python3 $R/scripts/pmc_summary.py $(find $RAW/f -name "*counter_collection.csv" | head -1) $(find $RAW/w -name "*counter_collection.csv" | head -1) $OUT/r03_pmc_traffic.json $FRAMES && head -c 600 $OUT/r03_pmc_traffic.json
 tail -2 $RAW/f.log | cut -c1-300
 rm -rf $RAW

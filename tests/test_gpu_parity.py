@@ -833,6 +833,89 @@ def test_bands_with_halo_exchange_match_the_whole_frame(built, kw):
         hip.hipFree(p)
 
 
+@pytest.mark.parametrize("env", [dict(AMD_SERIALIZE_KERNEL="3"), dict(GPU_MAX_HW_QUEUES="1"), dict(HIP_LAUNCH_BLOCKING="1")])
+def test_the_pipelined_bench_ends_when_the_runtime_runs_kernels_one_at_a_time(built, env):
+    """The entropy gate is a device-side wait without a bound (jxl_hip_api.hip EntropyGate): under a runtime that runs
+    one kernel at a time a launch gated on ANOTHER launch's workgroups being resident may wait for a kernel that is not
+    allowed to start. The library therefore drops the gate in such processes (RuntimeMaySerialise) whatever the caller
+    asked for: the default pipelined schedule of bench.py, which asks for the gate, must end under each of the
+    serialising switches. A child process under a timeout, small frames."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--size", "768x512", "--batch", "12", "--distinct", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--e2e-frames", "0"]
+    r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] > 0 and line["steps"] == 3
+
+
+@pytest.mark.parametrize("filter_async", [0, 1])
+def test_band_halos_through_an_asynchronous_transport(built, filter_async):
+    """The set forms jxlhip_halo_pack_batch / _unpack_batch with a transport that is what RCCL is to this library: work on
+    ANOTHER stream that the host does not wait for (a receive that has merely been enqueued). Two bands
+    of a 600x1100 frame, three frames per band set, batched launches. The "network" is a second torch stream that first
+    sleeps (the host runs far ahead of it), then copies the packed blocks into receive buffers that start out as NaN; the
+    unpack and the filter launch are enqueued while that stream is still asleep. Any missing dependency (unpack before the
+    copy has landed, filter before the unpack) leaves NaN or stale rows at the band edges and the bands stop matching the
+    whole-frame decode. Both filter placements: the set's own stream and its second stream (option "filter_async")."""
+    import torch
+    from libjxl_amd import sharding
+    J = built
+    H, W = 1100, 600
+    frames = [J.Frame(J.encode_rgb8(J.synth_image(W, H, seed=70 + i), distance=1.0 + i), threads=4) for i in range(3)]
+    whole = []
+    for f in frames:
+        c = J.HipContext()
+        c.upload(f)
+        c.run_all()
+        whole.append(c.rgb8())
+        c.close()
+    world = 2
+    bands = [sharding.band_of((H + 255) // 256, r, world) for r in range(world)]
+    sets = []
+    for r in range(world):
+        cs = [J.HipContext() for _ in frames]
+        if filter_async:
+            cs[0].set_option("filter_async", 1)
+        for c, f in zip(cs, frames):
+            c.set_option("band_halo", 1)
+            c.upload(f, band=bands[r])
+        sets.append(cs)
+    n = max(c.halo_floats() for cs in sets for c in cs)
+    net = torch.cuda.Stream()
+    for cs in sets:
+        J.run_entropy_batch(cs)
+        J.run_transform_batch(cs)
+    # (the blocks exist, filled with NaN, before anything is enqueued: the fills are not part of what is being ordered)
+    blocks = [torch.full((len(frames) * n,), float("nan"), dtype=torch.float32, device="cuda") for _ in range(4)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(net):
+        for it, (r, peer, side) in enumerate(((0, 1, 1), (1, 0, 0))):  # band 0's last rows to band 1's top; band 1's first rows to band 0's bottom
+            sent, got = blocks[2 * it], blocks[2 * it + 1]
+            J.halo_pack_batch(sets[r], side, sent.data_ptr(), n * 4, net.cuda_stream)
+            torch.cuda._sleep(200_000_000)  # ~0.1 s of "network latency" on the transport's stream
+            got.copy_(sent, non_blocking=True)
+            J.halo_unpack_batch(sets[peer], 1 - side, got.data_ptr(), n * 4, net.cuda_stream)
+    for cs in sets:  # enqueued at once: nothing above has waited for the device
+        J.run_filter_color_batch(cs)
+    for r, cs in enumerate(sets):
+        b0, b1 = bands[r]
+        for i, c in enumerate(cs):
+            c.sync()
+            got = c.rgb8_rows(b0 * 256, min(b1 * 256, H))
+            assert np.array_equal(got, whole[i][b0 * 256:min(b1 * 256, H)]), "band %d of frame %d differs from the whole-frame decode" % (r, i)
+    torch.cuda.synchronize()
+    for cs in sets:
+        for c in cs:
+            c.close()
+    for f in frames:
+        f.close()
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(distance=3.0, epf_iters=3), dict(distance=0.5, epf_iters=2), dict(size=(1000, 700)),
                                 dict(skip_dc_smoothing=1, custom_cmap=1), dict(custom_lf=1, custom_cmap=1, size=(2300, 300))])
 def test_dc_path_kernels_against_the_oracle_and_a_float64_reading(built, kw):

@@ -53,21 +53,20 @@ def test_host_reports_the_placement_of_every_frame(built, tmp_path):
             "xsize", "ysize", "custom_size", "frame_type", "mode", "alpha_mode", "source", "alpha_source", "clamp", "alpha_clamp", "duration",
             "is_last", "save_as_reference", "save_before_color_transform", "dc_level", "use_dc_frame")]  # include/jxl_amd.h
 
-    # (this mirror is written to by the C side: it must be as large as the header's struct, or the call corrupts the heap)
-    import os
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(str(tmp_path), "placement_size")
-    subprocess.run(["gcc", "-x", "c", "-", "-I" + os.path.join(root, "include"), "-o", exe], check=True, text=True,
-                   input='#include <stdio.h>\n#include "jxl_amd.h"\nint main(void) { printf("%zu", sizeof(JxlAmdFramePlacement)); return 0; }\n')
-    assert int(subprocess.run([exe], capture_output=True, text=True, check=True).stdout) == ctypes.sizeof(Placement)
-    L.jxlamd_modframe_placement.argtypes = [ctypes.c_void_p, ctypes.POINTER(Placement)]
-    L.jxlamd_modframe_placement.restype = None
+    # (this mirror is written to by the C side: the sized form never writes more than the mirror holds, and the library
+    # reports its own struct size, which must be the header's)
+    L.jxlamd_sizeof_frame_placement.restype = ctypes.c_size_t
+    assert L.jxlamd_sizeof_frame_placement() == ctypes.sizeof(Placement)
+    L.jxlamd_modframe_placement_sized.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.jxlamd_modframe_placement_sized.restype = ctypes.c_size_t
     pos, seen = 0, []
     for k in range(3):
         f = J.ModFrame(data, frame_pos=pos, frame_index=k)
         p = Placement()
-        L.jxlamd_modframe_placement(f._h, ctypes.byref(p))
+        assert L.jxlamd_modframe_placement_sized(f._h, ctypes.byref(p), ctypes.sizeof(p)) == ctypes.sizeof(p)
+        short = (ctypes.c_uint32 * 6)(*([0xAAAAAAAA] * 6))  # an older caller's 16-byte struct + guard words: nothing past 16 bytes is written
+        assert L.jxlamd_modframe_placement_sized(f._h, short, 16) == ctypes.sizeof(p)
+        assert (short[2], short[3], short[4], short[5]) == (p.xsize, p.ysize, 0xAAAAAAAA, 0xAAAAAAAA)
         seen.append((p.x0, p.y0, p.xsize, p.ysize, p.mode, p.alpha_mode, p.source, p.duration, p.is_last, p.save_as_reference))
         pos = f.end
         f.close()
