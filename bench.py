@@ -612,7 +612,7 @@ def main():
     # nnz / config tables, 64 lanes of rings and line buffers; a CU has 160 KB
     tables = []
     for f in frames:
-        lds = (f.info["num_clusters"] << f.info["log_alpha"]) * 8 + ((f.info["ctx_map_size"] + 15) & ~15) + 128 + 512 + 64 * 200
+        lds = (f.info["num_clusters"] << f.info["log_alpha"]) * 8 + ((f.info["ctx_map_size"] + 16 + 15) & ~15) + 128 + 128 + 64 * 200
         tables.append({"clusters": f.info["num_clusters"], "log_alpha": f.info["log_alpha"], "lds_bytes": lds,
                        "workgroups_per_cu": (160 * 1024) // lds})
     # Two sets of `batch` frames: while one set is in the (latency-bound, serial per section) entropy stage, the other

@@ -961,7 +961,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   // ---- work buffers
   // (progressive frames: the natural-layout buffer + one scan-order buffer per pass for the lane kernel)
   const size_t coef_bytes = size_t(d->num_groups) * 3 * 65536 * (d->coef_bits / 8);
-  if ((r = c->coeffs.Ensure(coef_bytes * (d->num_passes > 1 ? d->num_passes + 1 : 1)))) return r;
+  // (+ 64 bytes: a lane of the entropy kernel that decodes a CORRUPT section may write up to three coefficients past the
+  // last scan position of a block before it is stopped, jxl_hip_lanes_trip.inc: past the buffer for the very last block)
+  if ((r = c->coeffs.Ensure(coef_bytes * (d->num_passes > 1 ? d->num_passes + 1 : 1) + 64))) return r;
   if ((r = c->errors.Ensure(size_t(d->num_groups) * 4))) return r;
   HIP_TRY(hipMemsetAsync(c->errors.p, 0, size_t(d->num_groups) * 4, c->stream));  // groups outside a band stay clean
   const size_t plane_bytes = size_t(c->xp) * c->yp * 3 * 4;
@@ -1723,15 +1725,26 @@ static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_
   return 0;
 }
 
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX = false>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX = false, bool ASMT = false>
 static int LaunchEntropyLanesW(JxlHipContext* c0);
+template <typename CoefT, bool GALIAS, bool ASMT>
+static int LaunchEntropyLanesA(JxlHipContext* c0) {
+  if (EnvInt("JXLHIP_LANES_DEBUG", 0) || EnvInt("JXLHIP_LANES_PROF", 0))  // measurement aids: instrumented build of the kernel
+    return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, true, GALIAS, false, ASMT>(c0)
+                              : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, true, GALIAS, false, ASMT>(c0)
+                                                    : LaunchEntropyLanesW<CoefT, 4, true, GALIAS, false, ASMT>(c0));
+  return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, false, GALIAS, false, ASMT>(c0)
+                            : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, false, GALIAS, false, ASMT>(c0)
+                                                  : LaunchEntropyLanesW<CoefT, 4, false, GALIAS, false, ASMT>(c0));
+}
 template <typename CoefT, bool GALIAS>
 static int LaunchEntropyLanesG(JxlHipContext* c0) {
-  if (EnvInt("JXLHIP_LANES_DEBUG", 0) || EnvInt("JXLHIP_LANES_PROF", 0))  // measurement aids: instrumented build of the kernel
-    return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, true, GALIAS>(c0)
-                              : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, true, GALIAS>(c0) : LaunchEntropyLanesW<CoefT, 4, true, GALIAS>(c0));
-  return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, false, GALIAS>(c0)
-                            : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, false, GALIAS>(c0) : LaunchEntropyLanesW<CoefT, 4, false, GALIAS>(c0));
+  // the hand-written trip (jxl_hip_lanes_trip.inc) serves LDS alias tables with int16 coefficients; JXLHIP_LANES_CPP=1 keeps
+  // the C++ trip for that form too (the two are held against each other by tests/test_gpu_parity.py)
+  if constexpr (!GALIAS && sizeof(CoefT) == 2) {
+    if (!EnvInt("JXLHIP_LANES_CPP", 0)) return LaunchEntropyLanesA<CoefT, GALIAS, true>(c0);
+  }
+  return LaunchEntropyLanesA<CoefT, GALIAS, false>(c0);
 }
 template <typename CoefT>
 static int LaunchEntropyLanes(JxlHipContext* c0) {
@@ -1741,9 +1754,9 @@ static int LaunchEntropyLanes(JxlHipContext* c0) {
                                                     : LaunchEntropyLanesW<CoefT, 4, false, true, true>(c0));
   return c0->batch_galias ? LaunchEntropyLanesG<CoefT, true>(c0) : LaunchEntropyLanesG<CoefT, false>(c0);
 }
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX, bool ASMT>
 static int LaunchEntropyLanesW(JxlHipContext* c0) {
-  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS, GALIAS, PREFIX>;
+  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS, GALIAS, PREFIX, ASMT>;
   if (c0->batch_lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
   jxlhip::EntropyLaneBatch b;
@@ -1756,6 +1769,12 @@ static int LaunchEntropyLanesW(JxlHipContext* c0) {
   b.wave_lanes = blob + c0->batch_off_wave_lanes;
   HIP_TRY(hipMemsetAsync(b.queue, 0, c0->batch_units * 4, c0->stream));
   b.wait_shift = c0->batch_wait_shift;
+  {
+    // rounds (hot trips + transition pass) per refill round; the hand-written loop runs several groups of trips per round
+    int every = EnvInt("JXLHIP_REFILL_EVERY", ASMT ? 1 : int(jxlhip::kLanesRefillEvery));
+    if (every < 1 || (every & (every - 1))) every = int(jxlhip::kLanesRefillEvery);
+    b.refill_mask = uint32_t(every - 1);
+  }
   b.prio = uint32_t(EnvInt("JXLHIP_LANES_PRIO", 0));
   b.extra_pass_min = uint32_t(EnvInt("JXLHIP_EXTRA_PASS_MIN", 8));
   if (b.extra_pass_min < 1) b.extra_pass_min = 1;

@@ -40,6 +40,7 @@
 #define JXL_HIP_ENTROPY_LANES_H_
 
 #include "jxl_hip_kernels.h"
+#include "jxl_hip_lanes_trip.inc"
 
 namespace jxlhip {
 
@@ -57,6 +58,7 @@ struct EntropyLaneBatch {
   uint32_t prio;                // non-zero: the waves raise their issue priority (s_setprio 3)
   uint32_t extra_pass_min;      // a service phase makes a further round of transitions only for at least this many lanes (>= 1)
   uint32_t wait_shift;          // the service phase runs once (waiting lanes << wait_shift) >= runnable lanes
+  uint32_t refill_mask;         // a refill round every (refill_mask + 1) rounds (a power of two)
   const uint8_t* wave_log_ls;   // per wave: where its lanes sit in the per-wave LDS rows (64 lanes wide): bit 7 set = the
                                 // workgroup's waves share ONE set of rows and this wave's lane l uses column (low 6 bits) + l
                                 // (a few lanes for the frame's largest sections beside a wave for all the others, at the LDS
@@ -71,8 +73,9 @@ struct EntropyLaneBatch {
 
 // LDS layout of one workgroup (byte offsets, every region 16-byte aligned); the host sizes the launch with it.
 struct LanesLds {
-  uint32_t alias, ctx, ctx2, cfg, poff, wave0, per_wave, total;
+  uint32_t f2, alias, ctx, ctx2, cfg, poff, wave0, per_wave, total;
 };
+constexpr uint32_t kLanesF2Bytes = 128;  // 2 * kCoeffFreqContext[b], b < 128, at LDS offset 0 (jxl_hip_lanes_trip.inc reads it with no base)
 // Per-wave LDS, all [row][lane] with a row of 64 entries (conflict-free):
 constexpr uint32_t kLanesNzRows = 96;               // nzeros line buffer [channel * 32 + column], u8
 constexpr uint32_t kLanesRingWords = 16;            // stream ring, u32; + 2 mirror rows (a 3-word read at slot 15 needs no wrap)
@@ -85,11 +88,12 @@ constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 2) * 4
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
                                                    uint32_t waves, uint32_t lanes, bool alias_lds = true, bool prefix = false) {
   LanesLds l;
-  l.alias = 0;
-  l.ctx = alias_lds ? (num_clusters << log_alpha) * 8 : 0;
+  l.f2 = 0;
+  l.alias = kLanesF2Bytes;  // (jxl_hip_lanes_trip.inc: ds_read_b64 ... offset:128)
+  l.ctx = l.alias + (alias_lds ? (num_clusters << log_alpha) * 8 : 0);
   l.ctx2 = l.ctx + ((num_hist * nctx + 16 + 15) & ~15u);
   l.cfg = l.ctx2 + 64 * 2;
-  l.poff = l.cfg + 256 * 2;
+  l.poff = l.cfg + (prefix ? 256 * 2 : 0);  // (the rANS forms carry a cluster's uint config in its alias entries)
   l.wave0 = l.poff + (prefix ? 256 * 4 : 0);
   l.per_wave = kLanesPerLaneBytes * lanes;
   l.total = l.wave0 + waves * l.per_wave;
@@ -110,6 +114,9 @@ __device__ __forceinline__ void LaneStore64(const void* base, uint32_t off, uint
 }
 __device__ __forceinline__ void LaneStore32(const void* base, uint32_t off, uint32_t v) {
   asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
+}
+__device__ __forceinline__ void LaneStore16(const void* base, uint32_t off, uint32_t v) {
+  asm volatile("global_store_short %0, %1, %2" : : "v"(off), "v"(v), "s"(base));
 }
 // LDS-DMA of one dword per active lane: lane l's word at `base + off` lands at LDS byte address `lds_row + 4 * l`
 // (`lds_row` wave-uniform). Counted by vmcnt like any load; the caller waits (LaneDmaWait) before it reads the row.
@@ -138,8 +145,12 @@ __device__ __forceinline__ uint32_t LaneHybrid(uint32_t tok, uint32_t cfg, uint3
 // AIDS = false compiles the measurement aids (B.prof, B.debug) out. GALIAS: the alias entries are read in place from
 // global memory (tables that would not leave every frame of the launch resident in LDS). PREFIX: prefix codes
 // (dec_huffman.h:28-41 in the two-level table form the host builds) instead of rANS.
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS = false, bool PREFIX = false>
+// ASMT: the hot trips are the hand-written group of jxl_hip_lanes_trip.inc (LDS alias tables, rANS, int16 coefficients only);
+// the C++ trip below is the statement of the algorithm, serves every other form and stays selectable for this one
+// (JXLHIP_LANES_CPP=1) so that the two can be held against each other bit for bit.
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS = false, bool PREFIX = false, bool ASMT = false>
 __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_) {
+  static_assert(!ASMT || (!GALIAS && !PREFIX && sizeof(CoefT) == 2), "the assembly trip: LDS alias tables, int16 coefficients");
   EntropyLaneBatch B = B_;
   if (!AIDS) {
     B.prof = nullptr;
@@ -192,10 +203,11 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       const uint32_t cl = ctx_slice[i];
       l_ctx[i] = uint8_t(cl < nclusters ? cl : nclusters - 1);
     }
-    for (uint32_t i = tid; i < nclusters; i += 64 * WPG) {
-      const uint32_t cfg = T.cfg[i];
-      l_cfg[i] = uint16_t((cfg & 15) | (((cfg >> 8) & 15) << 4) | (((cfg >> 16) & 15) << 8));
-    }
+    if (PREFIX)
+      for (uint32_t i = tid; i < nclusters; i += 64 * WPG) {
+        const uint32_t cfg = T.cfg[i];
+        l_cfg[i] = uint16_t((cfg & 15) | (((cfg >> 8) & 15) << 4) | (((cfg >> 16) & 15) << 8));
+      }
     // alias entry {cutoff u8, right u8, freq0 u16 | offsets1 u16, freq1 u16} ->
     //   x = (freq0 - 1) & 0xFFF | uint config << 12 | cutoff << 24   taken when pos <  cutoff: symbol = slot, offset = pos
     //   y = (freq1 - 1) & 0xFFF | offsets1 << 12 | right << 24        taken when pos >= cutoff
@@ -210,6 +222,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       l_alias[i] = LanesU32x2{e.x, e.y};
     }
     if (tid < 64) l_nnz2[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 2);
+    // 2 * kCoeffFreqContext(b) (ac_context.h:63-80), b = (k + 1) >> log2 covered: 1..63 in a valid stream; the entries
+    // beyond continue the closed form (a corrupt stream may run a few positions past its block before it is stopped)
+    for (uint32_t b = tid; b < kLanesF2Bytes; b += 64 * WPG)
+      lds[L.f2 + b] = uint8_t(b < 64 ? uint32_t(c_coeff_freq_ctx[b]) * 2 : 2 * min(min(b - 1, 7 + (b >> 1)), 15 + (b >> 2)));
     LdsU32* z = (LdsU32*)(lds + wave_base);
     for (uint32_t i = lane; i < kLanesNzRows * 64 / 4; i += 64) z[i] = 0;
   }
@@ -255,7 +271,10 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   // addr_a / nnz_b: LDS byte address (relative to the context map) of the context entry of the NEXT coefficient at
   // frequency context 0, if the current token turns out zero (same non-zero count, prev = 0) / the raw table value from
   // which the address for a non-zero token (one fewer to come, prev = 1) is formed where it is used
-  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, nnz_b = 0, ctxe = 0, kidx = 0;
+  // (ASMT: addr_a and cbase are LDS byte addresses, i.e. include the context map's offset; covm2 = covm1 - 2)
+  uint32_t nzeros = 0, k = 0, size = 0, log2c = 0, covm1 = 0, cbase = 0, addr_a = 0, nnz_b = 0, ctxe = 0, kidx = 0, covm2 = 0;
+  const uint32_t ring_addr = uint32_t(uintptr_t(ring)), cl_mul = 1u << cl_shift, nnz2_addr = uint32_t(uintptr_t(l_nnz2));
+  if (ASMT && uint32_t(uintptr_t(lds)) != 0) __builtin_trap();  // (jxl_hip_lanes_trip.inc addresses the tables from LDS offset 0)
   uint32_t acc_lo = 0, acc_hi = 0;  // the coefficient chunk in progress
   uint32_t dst = 0;                 // byte offset (from coef_base) of the chunk in progress
   const uint32_t shift = T.shift;
@@ -299,6 +318,35 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       // i.e. bits of at most 2 * kLanesTrips ring words (words read beyond ring_end are stale but never consumed)
       const bool low = (ring_end - (bitpos >> 5)) < 2 * kLanesTrips + 1;
       bool act = mode == kRun && !low;
+      if constexpr (ASMT) {
+        const unsigned long long actm = __ballot(act);
+        if (actm) {
+          unsigned long long th = 0;
+          const uint32_t k_before = k;
+          // The loop goes on, group after group, until the transition pass is due: as many lanes waiting for it as the pass
+          // threshold asks for ((waiting << wait_shift) >= running, the rule of the C++ form), counting the lanes that wait
+          // already and those that leave the loop.
+          const uint32_t n_total = uint32_t(__popcll(actm)) + uint32_t(__popcll(__ballot(mode == kWait || mode == kFlush)));
+          const uint32_t cont_min = __builtin_amdgcn_readfirstlane(((n_total << B.wait_shift) / (1u + (1u << B.wait_shift))) + 1u);
+          uint32_t groups = 0;
+          // (operands: the lane's decoder state and cursors; its per-run constants; the loop's lanes and threshold; the frame's constants)
+          if (AIDS) {
+            if (B.prof) th = __builtin_readcyclecounter();
+            JXL_LANES_TRIP_LOOP_COUNTED(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr, ring_end,
+                                        size, actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base);
+            if (B.prof) t_wait += __builtin_readcyclecounter() - th;
+            n_trips += groups * kLanesTrips;
+          } else {
+            JXL_LANES_TRIP_LOOP(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr, ring_end, size,
+                                actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base);
+          }
+          // lanes of the group that finished their (block, channel), or ran past its last scan position (corrupt stream:
+          // the transition pass sees non-zeros left and abandons the section)
+          mode = (act && (nzeros == 0 || k >= size)) ? uint32_t(kFlush) : mode;
+          if (AIDS && B.prof) n_lane_trips += act ? k - k_before : 0u;
+          if (AIDS && (B.debug & 2)) ntok += act ? k - k_before : 0u;
+        }
+      } else
       if (__ballot(act)) {
         unsigned long long th = 0;
         if (B.prof) th = __builtin_readcyclecounter();
@@ -325,7 +373,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
               pe = LanesU32x2{ge.x, ge.y};
             }
           } else {
-            pe = *(LdsU32x2*)(lds + ((ctxe << cl_shift) + (((state & 0xFFFu) >> log_entry) << 3)));
+            pe = *(LdsU32x2*)(lds + L.alias + ((ctxe << cl_shift) + (((state & 0xFFFu) >> log_entry) << 3)));
           }
           pw0 = rp[0];
           pw1 = rp[64];
@@ -442,6 +490,17 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       // (a pass costs about two trips: it runs once enough lanes wait for it, or nothing else can run)
       const uint32_t n_go = uint32_t(__popcll(__ballot(fl || go))), n_run = uint32_t(__popcll(__ballot(mode == kRun)));
       if (n_go && (n_go << B.wait_shift) >= n_run) {
+        if (ASMT) {
+          if (fl) {  // the 1 - 3 coefficients decoded since the lane's last whole group of four (a run starts at position
+                     // `covered` and every whole group stored four): exactly those, from acc_lo | acc_hi << 32 upwards
+            const uint32_t part = (k - covm1 - 1) & 3;
+            if (!(B.debug & 1)) {
+              if (part >= 2) LaneStore32(coef_base, dst, acc_lo);
+              if (part & 1) LaneStore16(coef_base, dst + (part & 2) * 2, part == 3 ? acc_hi : acc_lo);
+            }
+            if (!(B.debug & 4)) LaneStore32(kend_base, kidx * 4, k);
+          }
+        } else
         if (fl) {  // the chunk in progress (its entries sit at the top of the register pair), the number of scan positions
           const uint32_t part = k & (kPerChunk - 1);
           const uint64_t v = ((uint64_t(acc_hi) << 32) | acc_lo) >> (((kPerChunk - part) & (kPerChunk - 1)) * (64 / kPerChunk));
@@ -494,7 +553,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
               e = LanesU32x2{ge.x, ge.y};
             }
           } else {
-            e = *(LdsU32x2*)(lds + (cluster << cl_shift) + slot * 8);
+            e = *(LdsU32x2*)(lds + L.alias + (cluster << cl_shift) + slot * 8);
           }
           const bool gt = pos >= (e.x >> 24);
           const uint32_t x = gt ? e.y : e.x;
@@ -546,11 +605,18 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         nzeros = go ? tok : nzeros;
         k = go ? covered : k;
         covm1 = go ? n_covm1 : covm1;
+        if (ASMT) {
+          covm2 = go ? n_covm1 - 2 : covm2;
+          cbase = go ? n_cbase + L.ctx : cbase;
+          dst = go ? uint32_t(((g * 3 + c) * 65536 + n_coef_offset + covered) * sizeof(CoefT)) : dst;  // position `covered` itself
+          addr_a = go ? n_addr_a + L.ctx : addr_a;
+        } else {
         cbase = go ? n_cbase : cbase;
         dst = go ? uint32_t(((g * 3 + c) * 65536 + n_coef_offset + (covered & ~(kPerChunk - 1))) * sizeof(CoefT)) : dst;  // chunk of position `covered`
         acc_lo = go ? 0u : acc_lo;
         acc_hi = go ? 0u : acc_hi;
         addr_a = go ? n_addr_a : addr_a;
+        }
         nnz_b = go ? n_nnz_b : nnz_b;
         ctxe = go ? n_ctxe : ctxe;
         mode = (go && tok != 0 && !bad) ? uint32_t(kRun) : mode;
@@ -565,7 +631,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       }
     }
     // ================================================================= every few rounds: ring refills, rare transitions
-    if ((++round & (kLanesRefillEvery - 1)) != 0) continue;
+    if ((++round & B.refill_mask) != 0) continue;
     {
       unsigned long long t0 = 0;
       if (B.prof) t0 = __builtin_readcyclecounter();
