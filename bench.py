@@ -795,6 +795,14 @@ def main():
     if world == 1 and args.max_clusters == 0 and args.ac_code_mode == 0 and not args.no_libjxl_tables and args.shard == "frames":
         datas128 = [make_stream(xsize, ysize, args.distance, 177 + i, 128, 0) for i in range(ndistinct)]
         frames128 = [J.Frame(d, threads=min(8, os.cpu_count() or 1)) for d in datas128]
+        # frames per step: as many as stay RESIDENT with these tables (a launch with more runs in two rounds, each as long
+        # as its slowest section): 160 KB of LDS per CU / the largest workgroup, times the CUs; at most the batch
+        lds128 = max((f.info["num_clusters"] << f.info["log_alpha"]) * 8 + ((f.info["ctx_map_size"] + 16 + 15) & ~15) + 128 + 128 + 64 * 200
+                     for f in frames128)
+        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        batch128 = max(1, min(args.batch, cus * max(1, (160 * 1024) // lds128)))
+        full_sets = sets
+        sets = [cs[:batch128] for cs in full_sets]
         load(frames128)
         prime()
         for _ in range(max(1, args.warmup)):
@@ -805,12 +813,14 @@ def main():
             step()
         barrier()
         el128 = time.perf_counter() - t1
-        libjxl_tables = {"value": round(args.batch * args.steps * xsize * ysize * 1e-6 / el128, 2), "unit": "MP/s",
-                         "ms_per_step": round(el128 / args.steps * 1e3, 3), "max_clusters": 128,
-                         "clusters": [f.info["num_clusters"] for f in frames128],
+        libjxl_tables = {"value": round(batch128 * args.steps * xsize * ysize * 1e-6 / el128, 2), "unit": "MP/s",
+                         "ms_per_step": round(el128 / args.steps * 1e3, 3), "frames_per_step": batch128, "max_clusters": 128,
+                         "clusters": [f.info["num_clusters"] for f in frames128], "lds_bytes_per_frame": lds128,
                          "bpp": round(sum(len(d) for d in datas128) / float(ndistinct) * 8.0 / (xsize * ysize), 3),
                          "note": "same frames, schedule and timed region as `value`; histograms clustered to libjxl's limit of 128 "
-                                 "(enc_ans.cc:931) instead of the synthetic encoder's default 64"}
+                                 "(enc_ans.cc:931) instead of the synthetic encoder's default 64; frames per step = what stays resident "
+                                 "with these tables in LDS (two workgroups per CU)"}
+        sets = full_sets
         for f in frames128:
             f.close()
     for cs in sets:  # the frame sets' device memory is released before the end-to-end measurement allocates its own

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   const uint32_t shift = T.shift;
   constexpr uint32_t kPerChunk = 8 / sizeof(CoefT);
 
-  unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, n_lane_trips = 0, t_wait = 0, t_dma = 0, t_trans = 0;
+  unsigned long long t_begin = 0, t_service = 0, n_service = 0, n_trips = 0, n_lane_trips = 0, t_wait = 0, t_dma = 0, t_trans = 0, n_calls = 0;
   if (B.prof) t_begin = __builtin_readcyclecounter();
   __builtin_amdgcn_s_waitcnt(0);  // everything loaded so far has landed: the loop starts with empty counters
   // One 4-row group of a ring: the rows' LDS-DMA requests for the lanes in `in` (word index `w0i` at the group's first
@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
                                         size, actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base);
             if (B.prof) t_wait += __builtin_readcyclecounter() - th;
             n_trips += groups * kLanesTrips;
+            n_calls++;
           } else {
             JXL_LANES_TRIP_LOOP(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr, ring_end, size,
                                 actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base);
@@ -511,6 +512,84 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         bi = ran_out ? b1 : bi;
         ci = ran_out ? 2u : ci;
         mode = fl ? uint32_t(kWait) : mode;
+        if constexpr (ASMT) {
+          // ---- the transition proper, for the `go` lanes only (one EXEC region, plain assignments: the select form below
+          // costs 339 instructions per pass, a third of them scalar mask bookkeeping)
+          if (go) {
+            const bool nb = ci == 2;
+            const uint32_t n_ci = nb ? 0u : ci + 1, n_bi = bi + (nb ? 1u : 0u);
+            if (nb) {
+              info = bring[(n_bi & (kLanesBlockRing - 1)) * 64];
+              coef_offset = next_offset;
+            }
+            const uint32_t n_log2c = ((info >> 6) & 7) + ((info >> 9) & 7);
+            if (nb) next_offset += 64u << n_log2c;
+            const uint32_t n_lbx = info & 31, n_lby = (info >> 5) & 1;
+            const uint32_t c = n_ci == 0 ? 1u : (n_ci == 1 ? 0u : 2u);
+            const uint32_t log2cx = (info >> 6) & 7;
+            const uint32_t bctx = (info >> (12 + 4 * c)) & 15;
+            LdsU8* line = l_nz + (c * 32) * 64;
+            const uint32_t top = line[n_lbx * 64], left = line[(n_lbx ? n_lbx - 1 : 0) * 64];
+            const uint32_t l0 = n_lbx ? left : 32u, tt = n_lby ? top : l0, ll = n_lbx ? left : tt;
+            const uint32_t pred = (tt + ll + 1) >> 1;
+            uint32_t nzb = pred >= 64 ? 64 : pred;
+            nzb = nzb < 8 ? nzb : 4 + nzb / 2;
+            const uint32_t cluster = l_ctx[(nzb * num_bctx + bctx) & 0x1FFF];
+            const uint32_t slotw = (bitpos >> 5) & (kLanesRingWords - 1);
+            const uint32_t w0 = ring[slotw * 64], w1 = ring[slotw * 64 + 64], w2 = ring[slotw * 64 + 128];
+            const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & entry_mask;
+            const LanesU32x2 e = *(LdsU32x2*)(lds + L.alias + (cluster << cl_shift) + slot * 8);
+            const bool gt = pos >= (e.x >> 24);
+            const uint32_t x = gt ? e.y : e.x;
+            uint32_t tok = gt ? (e.y >> 24) : slot;
+            const uint32_t hi = state >> 12;
+            uint32_t nstate = (x & 0xFFFu) * hi + hi + (gt ? ((e.y >> 12) & 0xFFFu) : 0u) + pos;
+            const bool need = nstate < (1u << 16);
+            const uint32_t win = __builtin_amdgcn_alignbit(w1, w0, bitpos);
+            state = need ? ((nstate << 16) | (win & 0xFFFFu)) : nstate;
+            uint32_t adv = need ? 16u : 0u;
+            const uint32_t cfg = e.x >> 12;
+            const bool take = tok >= (1u << (cfg & 15));
+            if (__ballot(take)) {
+              uint32_t nbits;
+              const uint32_t big = LaneHybrid(tok, cfg, w0, w1, w2, (bitpos & 31) + adv, nbits);
+              tok = take ? big : tok;
+              adv += take ? nbits : 0u;
+            }
+            bitpos += adv;
+            const uint32_t covered = 1u << n_log2c;
+            log2c = n_log2c;
+            size = covered * 64;
+            kidx = n_bi * 3 + c;
+            const bool bad = tok > size - covered;
+            const uint8_t nzv = uint8_t((tok + covered - 1) >> n_log2c);
+            if (!bad) {
+              line[n_lbx * 64] = nzv;
+              if (__ballot(log2cx != 0)) {
+                const uint32_t cx = 1u << log2cx;
+                for (uint32_t i = 1; i < cx; i++) line[(n_lbx + i) * 64] = nzv;
+              }
+            }
+            if (tok == 0 && !(B.debug & 4)) LaneStore32(kend_base, kidx * 4, 0);  // stays waiting: next channel / block
+            // the coefficient run's cursor (unused when the channel is empty or the count invalid)
+            covm1 = covered - 1;
+            covm2 = covered - 3;
+            const uint32_t n_cbase = num_bctx * 37 + 458 * bctx;
+            const uint32_t prev = tok > size / 16 ? 0 : 1;
+            const uint32_t n_addr_a = n_cbase + l_nnz2[((tok + covm1) >> n_log2c) & 63];
+            nnz_b = l_nnz2[((tok - 1 + covm1) >> n_log2c) & 63];
+            ctxe = l_ctx[(n_addr_a + prev) & 0x1FFF];  // frequency context of k = covered is 0
+            cbase = n_cbase + L.ctx;
+            addr_a = n_addr_a + L.ctx;
+            dst = uint32_t(((g * 3 + c) * 65536 + coef_offset + covered) * sizeof(CoefT));  // position `covered` itself
+            nzeros = tok;
+            k = covered;
+            mode = (tok != 0 && !bad) ? uint32_t(kRun) : mode;
+            err |= bad ? kErrNzeros : 0u;  // abandon the section: the refill round takes the "section complete" path
+            bi = bad ? b1 : n_bi;
+            ci = bad ? 2u : n_ci;
+          }
+        } else {
         // ---- the transition proper (every lane computes; `go` lanes commit)
         const bool nb = ci == 2;
         const uint32_t n_ci = nb ? 0u : ci + 1, n_bi = bi + (nb ? 1u : 0u);
@@ -623,6 +702,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         err |= (go && bad) ? kErrNzeros : 0u;  // abandon the section: the refill round takes the "section complete" path
         bi = go ? (bad ? b1 : n_bi) : bi;
         ci = go ? (bad ? 2u : n_ci) : ci;
+        }
         if (B.prof) {
           t_trans += __builtin_readcyclecounter() - t2;
           n_service++;
@@ -732,6 +812,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
     o[5] = t_wait;
     o[6] = t_dma;
     o[7] = t_trans;
+    if (B.debug & 32) o[6] = n_calls;  // (measurement aid: calls of the trip loop instead of the lanes served)
     if (B.debug & 16) {  // (measurement aid: where the wave ran: HW_ID | XCC_ID << 32 instead of the lanes served)
       uint32_t hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
