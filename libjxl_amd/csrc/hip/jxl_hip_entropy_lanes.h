@@ -129,6 +129,22 @@ __device__ __forceinline__ void LaneDmaDword(uint32_t lds_row, const void* base,
       : "memory");
 }
 __device__ __forceinline__ void LaneDmaWait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+// A 16-byte load per lane of `mask` into registers, hidden from the compiler's wait insertion like the stores: the caller
+// waits (LaneLoadWait) before it reads `d`, and nothing touches `d` in between.
+typedef uint32_t LanesU32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void LaneLoad128(LanesU32x4& d, unsigned long long mask, const void* base, uint32_t off) {
+  asm volatile("s_mov_b64 s[96:97], exec\n\ts_and_b64 exec, exec, %3\n\tglobal_load_dwordx4 %0, %1, %2\n\ts_mov_b64 exec, s[96:97]"
+               : "+v"(d)
+               : "v"(off), "s"(base), "s"(mask)
+               : "memory", "s96", "s97", "scc");
+}
+// Waits until the loads of LaneLoad128 have landed. vmcnt(0), i.e. also for every coefficient store issued since: loads
+// and stores share the counter on gfx9 but do NOT complete in order with each other (a younger store may be acknowledged
+// before an older load returns), so "at most n outstanding" with n > 0 says nothing about the load. (Tried: n = a lower
+// bound of the stores issued since; sections then decoded garbage on and off.)
+__device__ __forceinline__ void LaneLoadWait(LanesU32x4& a, LanesU32x4& b) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b) : : "memory");
+}
 
 // Hybrid-uint value of a token with extra bits (dec_ans.h:170-197); cfg = split_exp | msb << 4 | lsb << 8, boff = bit
 // offset of the extra bits in the window w0 | w1 << 32 | w2 << 64 (< 64). Returns the value, `nb` = bits consumed.
@@ -246,6 +262,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   const void* const coef_base = static_cast<CoefT*>(P.coeffs) + P.coef_pass_base + size_t(pass) * P.coef_pass_stride;
   // stream cursor: `ring_end` words of the section have landed in the ring, `pend_s` more are in flight (DMA)
   uint32_t sec_off = 0, nwords = 0, sec_size = 0, ring_end = 0, pend_s = 0, bring_end = 0, pend_b = 0, bitpos = 0, state = 0;
+  LanesU32x4 stg = {0, 0, 0, 0}, btg = {0, 0, 0, 0};  // (ASMT) stream words / block records on their way into the rings
+  uint32_t stg_n = 0, btg_n = 0;  // 4: requested; 8: requested past the section's end (zeros)
   bool started = false;
   // block / channel cursor
   uint32_t info = 0, lbx = 0, lby = 0, coef_offset = 0, next_offset = 0;
@@ -261,6 +279,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
     bitpos = sec0 + g == 0 ? P.first_bit_offset : 0;
     ring_end = 0;
     pend_s = pend_b = 0;       // (what is still in flight for the finished section lands before the next request is made)
+    stg_n = btg_n = 0;
     next_offset = 0;
     ci = 2;
     err = 0;
@@ -718,10 +737,44 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       if (!__ballot(mode != kDone)) break;
       // (1) what the previous refill round requested has landed (the wait also covers the coefficient stores since: a
       // write round trip, once per refill round)
+      if constexpr (ASMT) {
+        // the words and block records requested by the previous refill round sit in registers (one 16-byte load per lane):
+        // into this lane's rows of the rings
+        if (__ballot(stg_n | btg_n)) LaneLoadWait(stg, btg);
+        if (__ballot(stg_n != 0)) {
+          if (stg_n) {
+            const bool zeros = stg_n == 8;
+            const uint32_t s0 = zeros ? 0u : stg.x, s1 = zeros ? 0u : stg.y, s2 = zeros ? 0u : stg.z, s3 = zeros ? 0u : stg.w;
+            LdsU32* const r4 = ring + (ring_end & (kLanesRingWords - 1)) * 64;  // (ring_end is a multiple of 4: the rows do not wrap)
+            r4[0] = s0;
+            r4[64] = s1;
+            r4[128] = s2;
+            r4[192] = s3;
+            if ((ring_end & (kLanesRingWords - 1)) == 0) {  // mirror rows
+              ring[16 * 64] = s0;
+              ring[17 * 64] = s1;
+            }
+            ring_end += 4;
+            stg_n = 0;
+          }
+        }
+        if (__ballot(btg_n != 0)) {
+          if (btg_n) {
+            LdsU32* const r4 = bring + (bring_end & (kLanesBlockRing - 1) & ~3u) * 64;
+            r4[0] = btg.x;
+            r4[64] = btg.y;
+            r4[128] = btg.z;
+            r4[192] = btg.w;
+            bring_end = (bring_end & ~3u) + 4;  // (a section's first request starts at the aligned block at or below its first one)
+            btg_n = 0;
+          }
+        }
+      } else {
       LaneDmaWait();
       ring_end += pend_s;
       bring_end += pend_b;
       pend_s = pend_b = 0;
+      }
       // (2) the rare transitions (section header, section complete) behind a wave-uniform branch
       {
         const bool next_block = ci == 2 && started;
@@ -758,7 +811,20 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
       // (3) request this round's ring refills: groups of four rows of the [slot][lane] rings, one LDS-DMA instruction per
       // row and only for the lanes whose next words belong there. Words past the section are zeros
       // (dec_bit_reader.h:84-144): those lanes write them themselves.
-      {
+      if constexpr (ASMT) {
+        // (3) this round's requests: four stream words / four block records per lane that has four free rows, as ONE 16-byte
+        // load each into registers (the LDS-DMA form below costs an instruction per ring row and row group whatever the
+        // number of lanes that need it: ~130 issue slots per round against ~30). Words past the section are zeros
+        // (dec_bit_reader.h:84-144).
+        const uint32_t used = ring_end - (bitpos >> 5);
+        const bool want_s = mode != kDone && kLanesRingWords - used >= 4;
+        const bool want_b = mode != kDone && bring_end < b1 && (bi + 1 + kLanesBlockRing - bring_end) >= 4;
+        const unsigned long long ms = __ballot(want_s && ring_end < nwords), mb = __ballot(want_b);
+        if (ms) LaneLoad128(stg, ms, P.sections, sec_off + ring_end * 4);
+        if (mb) LaneLoad128(btg, mb, P.block_recs, (bring_end & ~3u) * 4);
+        stg_n = want_s ? (ring_end < nwords ? 4u : 8u) : 0u;
+        btg_n = want_b ? 4u : 0u;
+      } else {
         const uint32_t used = ring_end - (bitpos >> 5);  // words of the ring still holding unread bits
         const uint32_t groups_s = mode == kDone ? 0u : (kLanesRingWords - used) >> 2;  // whole groups of 4 free rows
         const uint32_t first_g = (ring_end >> 2) & 3;

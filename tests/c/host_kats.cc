@@ -652,10 +652,76 @@ static int DumpDefaults() {
   return 0;
 }
 
+// tables OUT [STREAM]: what the host-only rows compute, for the independent NumPy readings of tests/host_tables_np.py
+// (tests/test_host_tables.py): the 17 dequantisation tables (3 channels each, float32) from the default library or from a
+// coded DequantMatrices section (quant_weights.cc:497-511: one all_default bit, then 17 encodings) read with THIS
+// front-end's reader; the natural coefficient order of the 13 order buckets (ac_strategy.cc:28-79); samples of the context
+// arithmetic (ac_context.h:63-143). A flat binary file: uint32 count, then float32 / uint32 words, per item.
+static int DumpTables(const char* out_path, const char* stream_path) {
+  FILE* f = fopen(out_path, "wb");
+  REQUIRE(f != nullptr, "cannot write %s", out_path);
+  auto put = [&](const void* p, size_t words) {
+    const uint32_t n = uint32_t(words);
+    fwrite(&n, 4, 1, f);
+    fwrite(p, 4, words, f);
+  };
+  H::DequantTables dq;
+  if (stream_path) {
+    std::vector<uint8_t> bytes;
+    FILE* g = fopen(stream_path, "rb");
+    REQUIRE(g != nullptr, "cannot read %s", stream_path);
+    int ch;
+    while ((ch = fgetc(g)) != EOF) bytes.push_back(uint8_t(ch));
+    fclose(g);
+    bytes.resize(bytes.size() + 16, 0);
+    try {
+      H::BitReader br(bytes.data(), bytes.size());
+      if (!br.ReadBool())
+        for (int k = 0; k < 17; k++) H::ReadQuantEncoding(br, k, &dq.enc[k]);
+    } catch (const std::exception& e) {
+      fclose(f);
+      REQUIRE(false, "reading the coded tables: %s", e.what());
+    }
+  }
+  for (int k = 0; k < 17; k++) {
+    try {
+      dq.Compute(k);
+    } catch (const std::exception& e) {
+      fclose(f);
+      REQUIRE(false, "table %d: %s", k, e.what());
+    }
+    put(dq.table[k].data(), dq.table[k].size());
+  }
+  for (int ord = 0; ord < 13; ord++) {
+    std::vector<uint32_t> o;
+    H::NaturalOrder(H::OrderBucketStrategy(ord), &o);
+    put(o.data(), o.size());
+  }
+  {  // ZeroDensityContext over (non-zeros left, k) for every covered-block count that occurs, prev = 0 and 1
+    std::vector<uint32_t> z;
+    for (int log2c = 0; log2c <= 10; log2c++) {
+      const size_t covered = size_t(1) << log2c, size = covered * 64;
+      for (size_t k = covered; k < size; k += (size / 64 > 7 ? size / 61 : 1))
+        for (size_t nz = 1; nz <= size - k && nz <= 4096; nz += (nz < 70 ? 1 : 37))
+          for (size_t prev = 0; prev < 2; prev++) {
+            z.push_back(uint32_t(log2c));
+            z.push_back(uint32_t(k));
+            z.push_back(uint32_t(nz));
+            z.push_back(uint32_t(prev));
+            z.push_back(uint32_t(H::ZeroDensityContext(nz, k, covered, size_t(log2c), prev)));
+          }
+    }
+    put(z.data(), z.size());
+  }
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
   const std::string t = argv[1];
   if (t == "defaults") return DumpDefaults();
+  if (t == "tables" && (argc == 3 || argc == 4)) return DumpTables(argv[2], argc == 4 ? argv[3] : nullptr);
   if (t == "alias") return TestAlias();
   if (t == "hybrid") return TestHybrid();
   if (t == "lehmer") return TestLehmer();
