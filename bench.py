@@ -795,12 +795,12 @@ def main():
     if world == 1 and args.max_clusters == 0 and args.ac_code_mode == 0 and not args.no_libjxl_tables and args.shard == "frames":
         datas128 = [make_stream(xsize, ysize, args.distance, 177 + i, 128, 0) for i in range(ndistinct)]
         frames128 = [J.Frame(d, threads=min(8, os.cpu_count() or 1)) for d in datas128]
-        # frames per step: as many as stay RESIDENT with these tables (a launch with more runs in two rounds, each as long
-        # as its slowest section): 160 KB of LDS per CU / the largest workgroup, times the CUs; at most the batch
+        # (frames per step as for `value`: with 86 KB of tables per frame only one workgroup per CU would stay resident with
+        # the tables in LDS, 256 frames per launch, and a launch lasts as long as its slowest section whatever its size:
+        # 45.8 GP/s at 256 frames per step against 53 at 640 with the tables read in place from global memory)
         lds128 = max((f.info["num_clusters"] << f.info["log_alpha"]) * 8 + ((f.info["ctx_map_size"] + 16 + 15) & ~15) + 128 + 128 + 64 * 200
                      for f in frames128)
-        cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        batch128 = max(1, min(args.batch, cus * max(1, (160 * 1024) // lds128)))
+        batch128 = args.batch
         full_sets = sets
         sets = [cs[:batch128] for cs in full_sets]
         load(frames128)
@@ -817,9 +817,9 @@ def main():
                          "ms_per_step": round(el128 / args.steps * 1e3, 3), "frames_per_step": batch128, "max_clusters": 128,
                          "clusters": [f.info["num_clusters"] for f in frames128], "lds_bytes_per_frame": lds128,
                          "bpp": round(sum(len(d) for d in datas128) / float(ndistinct) * 8.0 / (xsize * ysize), 3),
-                         "note": "same frames, schedule and timed region as `value`; histograms clustered to libjxl's limit of 128 "
-                                 "(enc_ans.cc:931) instead of the synthetic encoder's default 64; frames per step = what stays resident "
-                                 "with these tables in LDS (two workgroups per CU)"}
+                         "note": "same frames, schedule, frames per step and timed region as `value`; histograms clustered to libjxl's limit "
+                                 "of 128 (enc_ans.cc:931) instead of the synthetic encoder's default 64: the alias tables no longer fit "
+                                 "every frame's workgroup into LDS and are read in place from global memory (the C++ trip)"}
         sets = full_sets
         for f in frames128:
             f.close()

