@@ -1312,6 +1312,39 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
   float yout[R];  // this thread's column of the Y output (threads t < C)
 #pragma unroll
   for (int y = 0; y < R; y++) yout[y] = 0.0f;
+  // Scan-order input: everything a channel's staging reads from memory (four coefficients, their positions and their
+  // weights per round) is requested a whole channel ahead, all rounds at once, and the three channels' coefficient counts
+  // with the block record: the kernel sat in memory waits for 82 % of its wave cycles (profiles/r04_sq_counters_*.txt)
+  // with one dependent round trip after the other (list -> block -> count -> coefficients, the last two per channel).
+  struct alignas(sizeof(CoefT) * 4) Coef4 {
+    CoefT v[4];
+  };
+  constexpr int ROUNDS = SIZE / (TB * 4);     // rounds of four scan positions per thread: 2 (8x8) .. 16 (64x64)
+  constexpr bool PF = ROUNDS <= 4;            // (the larger classes keep their loads inside the staging loop)
+  constexpr int PR = PF ? ROUNDS : 1;
+  Coef4 pq[PR];
+  ushort4 pp[PR];
+  float4 pw[PR];
+  uint32_t ke3[3] = {0, 0, 0};
+  auto prefetch = [&](int c) {
+    const CoefT* gqc = gq + size_t(c) * 65536;
+    const uint16_t* order = P.orders + P.order_offset[ord * 3 + c];
+    const float* ms = P.dequant_scan + ((m + size_t(c) * msize) - P.dequant);
+#pragma unroll
+    for (int r = 0; r < PR; r++) {
+      const uint32_t k4 = uint32_t(t) * 4 + uint32_t(r) * TB * 4;
+      pq[r] = *reinterpret_cast<const Coef4*>(gqc + k4);
+      pp[r] = *reinterpret_cast<const ushort4*>(order + k4);
+      pw[r] = *reinterpret_cast<const float4*>(ms + k4);
+    }
+  };
+  const bool pf = PF && P.scan_order != 0;
+  if (pf && active) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) ke3[c] = P.kend[bidx * 3 + c];
+    prefetch(1);
+  }
+#pragma unroll
   for (int ci = 0; ci < 3; ci++) {
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
     const float cc = c == 1 ? 0.0f : (c == 0 ? x_cc : b_cc);
@@ -1322,7 +1355,36 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
       const float mul = c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm);
       const CoefT* gqc = gq + size_t(c) * 65536;
       const float* mc = m + size_t(c) * msize;
-      if (P.scan_order) {
+      if (pf) {
+        // this channel's rounds are in registers; the next channel's leave now
+        Coef4 cq[PR];
+        ushort4 cp[PR];
+        float4 cw[PR];
+#pragma unroll
+        for (int r = 0; r < PR; r++) {
+          cq[r] = pq[r];
+          cp[r] = pp[r];
+          cw[r] = pw[r];
+        }
+        if (ci < 2) prefetch(ci == 0 ? 0 : 2);
+        const uint32_t ke = ke3[c];
+        const uint32_t k1 = ke < uint32_t(SIZE) ? ke : uint32_t(SIZE);
+#pragma unroll
+        for (int r = 0; r < PR; r++) {
+          const uint32_t k4 = uint32_t(t) * 4 + uint32_t(r) * TB * 4;
+          const uint32_t pos4[4] = {cp[r].x, cp[r].y, cp[r].z, cp[r].w};
+          const float wv[4] = {cw[r].x, cw[r].y, cw[r].z, cw[r].w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint32_t k = k4 + j;
+            const int q = int(cq[r].v[j]);
+            const uint32_t pos = pos4[j];
+            const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
+            const float val = QuantBiasNoBranch(c, q, P.biases) * (wv[j] * mul);
+            if (k >= uint32_t(CX * CY) && k < k1 && q) l[(idx >> LOGC) * S + (idx & (C - 1))] = val;
+          }
+        }
+      } else if (P.scan_order) {
         // entry k: coefficient, its position and its dequant weight are three independent coalesced loads
         const uint16_t* order = P.orders + P.order_offset[ord * 3 + c];
         const float* ms = P.dequant_scan + (mc - P.dequant);
@@ -1331,9 +1393,6 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
         // four scan positions per thread and round: one 8-byte (int16) coefficient load, one 8-byte load of their positions
         // and one 16-byte load of their weights instead of four rounds of 2 + 2 + 4 bytes (the kernel is bound by the number
         // of its small memory operations, not by their bytes); all three tables are 16-byte aligned per (block, channel)
-        struct alignas(sizeof(CoefT) * 4) Coef4 {
-          CoefT v[4];
-        };
         for (uint32_t k4 = uint32_t(t) * 4; k4 < k1; k4 += TB * 4) {
           const Coef4 q4 = *reinterpret_cast<const Coef4*>(gqc + k4);
           const ushort4 p4 = *reinterpret_cast<const ushort4*>(order + k4);
