@@ -987,16 +987,14 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     if ((r = c->noise.Ensure(size_t(c->xs) * c->ys * 3 * 4))) return r;
   }
   // splines are drawn over the filtered planes before noise and the colour conversion
-  if (d->splines.num_segments) {
-    if (c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
-    c->color_out = true;
-  }
+  // (an upsampled frame's splines and patches are drawn at its own resolution, on the planes the upsampling kernel reads:
+  // dec_cache.cc:193-212)
+  if (d->splines.num_segments) c->color_out = true;
   if ((r = UploadSplines(c, d->splines, c->ys))) return r;
   // patches: validated like every table a kernel indexes with (rectangles inside the frame and inside their reference)
   c->pat_positions = 0;
   if (d->patches.num_positions) {
     const JxlHipPatches& pt = d->patches;
-    if (c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
     if (!pt.records || !pt.row_start || !pt.row_list || pt.num_positions > (1u << 24) || pt.num_row_entries > (1u << 26)) return JXLHIP_ERR_INVALID_ARGUMENT;
     if (pt.row_start[0] != 0 || pt.row_start[c->ys] != pt.num_row_entries) return JXLHIP_ERR_INVALID_ARGUMENT;
     for (uint32_t y = 0; y < c->ys; y++)

@@ -95,12 +95,11 @@ struct FrameState {
 static void DecodeDcGlobal(BitReader& br, FrameState* s) {
   const FrameHeader& fh = s->fh;
   if (fh.flags & FrameHeader::kPatches) {  // dec_frame.cc:271-285
-    JXLO_CHECK(fh.upsampling == 1 && s->xyb_slots, "unsupported: patches on upsampled frames");
+    JXLO_CHECK(s->xyb_slots != nullptr, "patches without reference frames");  // (drawn at the frame's resolution, before any upsampling: dec_cache.cc:193-212)
     DecodePatches(br, s->dim.xsize_padded, s->dim.ysize_padded, s->ih->extra.size(), s->xyb_slots, &s->patches);
     s->has_patches = true;
   }
   if (fh.flags & FrameHeader::kSplines) {  // dec_frame.cc:289-293
-    JXLO_CHECK(fh.upsampling == 1, "unsupported: splines on upsampled frames");
     DecodeSplines(br, s->dim.xsize * s->dim.ysize, &s->splines);
     s->has_splines = true;
   }

@@ -78,13 +78,13 @@ def test_host_builds_the_draw_cache_of_both_frame_kinds(built):
     J.Frame(vardct).close()
     J.ModFrame(lossless).close()
     J.ModFrame(open(REF, "rb").read()).close()
-    with pytest.raises(J.JxlAmdError, match="upsampled"):
-        J.set_splines(_test_splines())
-        try:
-            up = J.encode_rgb8(img, upsampling=2)
-        finally:
-            J.set_splines(None)
-        J.Frame(up)
+    # an upsampled frame's splines are drawn at the frame's own resolution, before the upsampling (dec_cache.cc:198-212)
+    J.set_splines(_test_splines())
+    try:
+        up = J.encode_rgb8(img, upsampling=2)
+    finally:
+        J.set_splines(None)
+    J.Frame(up).close()
     # identical successive control points have no direction: refused like splines.cc:676-683
     J.set_splines([dict(points=[(10, 10), (10, 10), (50, 50)], color=[[0] * 32, [100] + [0] * 31, [0] * 32], sigma=[9] + [0] * 31)])
     try:
@@ -112,15 +112,21 @@ def test_reference_spline_stream_through_the_gpu(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["vardct", "lossless", "vardct_noise_epf2"])
+@pytest.mark.parametrize("kind", ["vardct", "lossless", "vardct_noise_epf2", "vardct_upsampled2", "vardct_upsampled4"])
 def test_splines_on_synthetic_frames_match_the_oracle(built, tmp_path, kind):
+    """(upsampled2 / 4: the frame is coded at half / a quarter of the image's size; its splines -- coordinates in frame pixels
+    -- are drawn before the upsampling, dec_cache.cc:198-212, so the strokes come out two / four times as wide)"""
     import jxlo
     J = built
     img = J.synth_image(300, 200, seed=5)
-    J.set_splines(_test_splines(), quantization_adjustment=1)
+    J.set_splines(_test_splines() if "upsampled" not in kind else
+                  [dict(points=[(10, 15), (60, 45), (110, 20)], color=[[40] + [0] * 31, [300, 10] + [0] * 30, [0] * 32], sigma=[12] + [0] * 31)]
+                  if kind.endswith("2") else [dict(points=[(5, 8), (30, 22), (60, 10)], color=[[0] * 32, [250] + [0] * 31, [0] * 32], sigma=[8] + [0] * 31)],
+                  quantization_adjustment=1)
     try:
         data = (J.encode_lossless(img) if kind == "lossless" else
-                J.encode_rgb8(img, **(dict(noise=60, epf_iters=2) if kind.endswith("epf2") else {})))
+                J.encode_rgb8(img, **(dict(noise=60, epf_iters=2) if kind.endswith("epf2") else
+                                      (dict(upsampling=int(kind[-1])) if "upsampled" in kind else {}))))
     finally:
         J.set_splines(None)
     o = jxlo.Decoded(data)
