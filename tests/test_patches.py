@@ -71,6 +71,29 @@ def test_patches_through_the_gpu(built, tmp_path, kw):
     assert np.abs(np.frombuffer(px, np.uint8).reshape(200, 300, 3).astype(int) - want8.astype(int)).max() <= 1
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ups", [2, 4])
+def test_patches_on_an_upsampled_frame(built, tmp_path, ups):
+    """dec_cache.cc:193-212: the patches of a frame coded at 1 / 2 or 1 / 4 of the image's size are placed at the FRAME's
+    resolution (positions in frame pixels) before the upsampling stage enlarges them with everything else."""
+    import jxlo
+    J = built
+    img, atlas, _ = _case(J)
+    fx, fy = (300 + ups - 1) // ups, (200 + ups - 1) // ups
+    patches = [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(3, 2, 2, 0), (fx - 22, fy - 18, 1, 0)]),
+               dict(x0=30, y0=0, xsize=30, ysize=40, positions=[(fx // 2 - 15, 4, 3, 1), (1, fy - 41, 2, 0)])]
+    data = J.encode_patched(img, atlas, patches, upsampling=ups)
+    o = jxlo.Decoded(data)
+    want8, wantf = o.rgb8.copy(), o.planes("rgbf").transpose(1, 2, 0).copy()
+    o.close()
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.float32).reshape(200, 300, 3) - wantf).max() < 1e-4
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3)
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.uint8).reshape(200, 300, 3).astype(int) - want8.astype(int)).max() <= 1
+
+
 def test_patch_rectangles_are_checked_against_the_reference_frames(built):
     """jxlamd_frame_set_patch_sources (dec_patch_dictionary.cc:63-83): a patch that names an empty slot, or reaches outside
     the reference frame it names, is refused before anything is uploaded (the pointers are only carried, never read here)."""
