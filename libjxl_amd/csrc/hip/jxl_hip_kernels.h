@@ -1348,9 +1348,11 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
   for (int ci = 0; ci < 3; ci++) {
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
     const float cc = c == 1 ? 0.0f : (c == 0 ? x_cc : b_cc);
-    if (active)
-      for (int i = t * 4; i < TILE; i += TB * 4) *reinterpret_cast<float4*>(l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-    WaveLdsSync();
+    if (!pf) {
+      if (active)
+        for (int i = t * 4; i < TILE; i += TB * 4) *reinterpret_cast<float4*>(l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      WaveLdsSync();
+    }
     if (active) {
       const float mul = c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm);
       const CoefT* gqc = gq + size_t(c) * 65536;
@@ -1381,7 +1383,11 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
             const uint32_t pos = pos4[j];
             const uint32_t idx = R < C ? pos : (pos % R) * C + pos / R;  // natural layout keeps the short side as rows
             const float val = QuantBiasNoBranch(c, q, P.biases) * (wv[j] * mul);
-            if (k >= uint32_t(CX * CY) && k < k1 && q) l[(idx >> LOGC) * S + (idx & (C - 1))] = val;
+            // every position of the tile is written exactly once by these rounds, so nothing zeroes it first and no store
+            // is predicated (24 EXEC regions with their branches per thread otherwise): zero where there is no coefficient
+            // (beyond the count, or a zero), and at the lowest-frequency corner, which the wave overwrites below (its LDS
+            // operations execute in order)
+            l[(idx >> LOGC) * S + (idx & (C - 1))] = (k >= uint32_t(CX * CY) && k < k1 && q) ? val : 0.0f;
           }
         }
       } else if (P.scan_order) {
@@ -1445,13 +1451,17 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
 #pragma unroll
       for (int ky = 0; ky < R; ky++) v[ky] = l[ky * S + t];
       FastIdct<R>(v);
-      float* out = P.out + size_t(c) * P.xp * P.yp + size_t(vb.by) * 8 * P.xp + size_t(vb.bx) * 8 + t;
+      // rows through a raw buffer: one 32-bit lane offset for the column, the row's offset in a scalar register (24 64-bit
+      // address computations per thread otherwise); three planes of at most 1 GiB: the offsets fit 32 bits
+      const __amdgpu_buffer_rsrc_t out_buf = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, 0xFFFFFFFFu, 0x00020000);
+      const uint32_t voff = (uint32_t(c) * P.xp * P.yp + uint32_t(vb.by) * 8 * P.xp + uint32_t(vb.bx) * 8 + uint32_t(t)) * 4u;
+      const uint32_t row_bytes = P.xp * 4u;
 #pragma unroll
       for (int y = 0; y < R; y++) {
         float r = v[y];
         if (c == 1) yout[y] = r;
         else r += cc * yout[y];
-        out[size_t(y) * P.xp] = r;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), out_buf, voff, uint32_t(y) * row_bytes, 0);
       }
     }
     WaveLdsSync();
