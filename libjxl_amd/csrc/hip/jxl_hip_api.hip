@@ -290,6 +290,7 @@ struct JxlHipContext {
   bool filter_async = false;
   bool entropy_gate = false;  // option "entropy_gate" (see EntropyGate)
   hipEvent_t halo_event = nullptr;  // jxlhip_halo_*_batch: orders the halo copies against the transport's stream
+  Buf ups_planes;                   // upsampled X, Y, B planes of a frame with noise ([3][oys][oxs padded to 8])
   bool owns_stream = false;   // `stream` is this context's own (it heads batched launches), not one of the shared pool
   hipStream_t stream2 = nullptr;
   hipStream_t fstream = nullptr;  // stream of the filter launch in progress (set by BeginDownstreamBatch)
@@ -468,7 +469,7 @@ static std::vector<Buf*> AllBufs(JxlHipContext* c) {
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
                 &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
-                &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob};
+                &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob, &c->ups_planes};
   for (auto& pb : c->pass_bufs)
     for (Buf* b : {&pb.ctx_map, &pb.alias, &pb.cfg, &pb.orders, &pb.ptable, &pb.poffset, &pb.alias_packed}) all.push_back(b);
   return all;
@@ -977,14 +978,17 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   // noise is added to the filtered planes between the filter launch and the colour conversion
   c->has_noise = d->has_noise != 0;
   if (c->has_noise) {
-    if (c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
     c->color_out = true;
     memcpy(c->noise_lut, d->noise_lut, sizeof(c->noise_lut));
     c->noise_seed[0] = d->noise_frame_index[0];
     c->noise_seed[1] = d->noise_frame_index[1];
     c->noise_ytox = d->base_corr_x;
     c->noise_ytob = d->base_corr_b;
-    if ((r = c->noise.Ensure(size_t(c->xs) * c->ys * 3 * 4))) return r;
+    // (an upsampled frame's noise is generated and added at the IMAGE's resolution, behind the upsampling:
+    // dec_cache.cc:206-216, dec_group.cc PrepareNoiseInput: one generator per 256 x 256 square of the image)
+    const size_t nxs = c->ups == 1 ? c->xs : c->oxs, nys = c->ups == 1 ? c->ys : c->oys;
+    if ((r = c->noise.Ensure(nxs * nys * 3 * 4))) return r;
+    if (c->ups != 1 && (r = c->ups_planes.Ensure(size_t((c->oxs + 7) & ~7u) * c->oys * 3 * 4))) return r;
   }
   // splines are drawn over the filtered planes before noise and the colour conversion
   // (an upsampled frame's splines and patches are drawn at its own resolution, on the planes the upsampling kernel reads:
@@ -2854,7 +2858,7 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
   }
   for (size_t i = 0; i < n; i++) {
     const JxlHipContext* c = ctxs[i];
-    if (!c->has_noise) continue;
+    if (!c->has_noise || c->ups != 1) continue;  // (upsampled frames: behind the upsampling, below)
     jxlhip::NoiseParams np;
     memset(&np, 0, sizeof(np));
     np.raw = c->noise.as<float>();
@@ -2910,8 +2914,47 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
     up.oxs = c->oxs;
     up.oys = c->oys;
     up.po = po;
+    up.xyb_out = nullptr;
+    up.oxp = 0;
+    if (c->has_noise) {  // upsample to planes, add the noise at the image's resolution, then the colour stage
+      up.xyb_out = c->ups_planes.as<float>();
+      up.oxp = (c->oxs + 7) & ~7u;
+    }
     hipLaunchKernelGGL(jxlhip::k_upsample_color, dim3((c->xs + 63) / 64, (c->ys + 3) / 4), dim3(256), 0, ls, up);
     HIP_TRY(hipGetLastError());
+    if (c->has_noise) {
+      jxlhip::NoiseParams np;
+      memset(&np, 0, sizeof(np));
+      np.raw = c->noise.as<float>();
+      np.planes = up.xyb_out;
+      np.xsize = c->oxs;
+      np.ysize = c->oys;
+      np.xp = up.oxp;
+      np.yp = c->oys;
+      np.xgroups = (c->oxs + 255) / 256;
+      np.ngroups = np.xgroups * ((c->oys + 255) / 256);
+      np.seed[0] = c->noise_seed[0];
+      np.seed[1] = c->noise_seed[1];
+      memcpy(np.lut, c->noise_lut, sizeof(np.lut));
+      np.ytox = c->noise_ytox;
+      np.ytob = c->noise_ytob;
+      np.y_begin = 0;
+      np.y_end = c->oys;
+      hipLaunchKernelGGL(jxlhip::k_noise_random, dim3((np.ngroups * 8 + 63) / 64), dim3(64), 0, ls, np);
+      hipLaunchKernelGGL(jxlhip::k_noise_add, dim3((c->oxs + 63) / 64, (c->oys + 3) / 4), dim3(256), 0, ls, np);
+      jxlhip::ColorOutParams cp;
+      cp.f = c->fp;
+      cp.f.in = up.xyb_out;
+      cp.f.xs = c->oxs;
+      cp.f.ys = c->oys;
+      cp.f.xp = up.oxp;
+      cp.f.yp = c->oys;
+      cp.f.y_begin = 0;
+      cp.f.y_end = c->oys;
+      cp.po = po;
+      hipLaunchKernelGGL(jxlhip::k_color_out, dim3((c->oxs + 63) / 64, (c->oys + 3) / 4), dim3(256), 0, ls, cp);
+      HIP_TRY(hipGetLastError());
+    }
   }
   HIP_TRY(hipEventRecord(c0->ev[5], ls));
   c0->ev_valid[2] = true;

@@ -191,6 +191,8 @@ struct UpsampleParams {
   const float* kernel;  // [N * N][25]
   uint32_t n, oxs, oys;
   PixelOut po;          // po.dst != NULL: the image in this format instead of RGB8 in f.rgb
+  float* xyb_out;       // != NULL: the upsampled X, Y, B as planes [3][oys][oxp] instead of pixels (the frame's noise is added
+  uint32_t oxp;         // to them at the image's resolution before the colour stage: dec_cache.cc:206-216)
 };
 
 // XYB -> linear RGB -> (sRGB) for one pixel (stage_xyb.cc:80-92 + dec_xyb-inl.h:38-86, stage_from_linear.cc:114-144).
@@ -267,6 +269,13 @@ __global__ __launch_bounds__(256) void k_upsample_color(UpsampleParams P) {
         ch[c] = r < mn[c] ? mn[c] : (r > mx[c] ? mx[c] : r);
       }
       const float Xc = ch[0], Yc = ch[1], Bc = ch[2];
+      if (P.xyb_out) {
+        const size_t oplane = size_t(P.oxp) * P.oys, gi = size_t(Y) * P.oxp + X;
+        P.xyb_out[gi] = Xc;
+        P.xyb_out[oplane + gi] = Yc;
+        P.xyb_out[2 * oplane + gi] = Bc;
+        continue;
+      }
       const float gr = (Yc + Xc) - P.f.opsin_bias_cbrt[0], gg = (Yc - Xc) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
       const float mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
       float r = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);

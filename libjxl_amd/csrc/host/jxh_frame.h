@@ -201,8 +201,7 @@ class FrameParser {
     JXH_CHECK(!P.use_dc_frame || fh.dc_level < 4, "invalid DC level for kUseDcFrame");
     JXH_CHECK(fh.frame_type != 1 || ih.extra.empty(), "unsupported: DC frames of images with extra channels");
     // (patches and splines of an upsampled frame are drawn at the FRAME's resolution, before the upsampling: dec_cache.cc:193-212;
-    // its noise is added behind the upsampling, at the image's resolution: still refused)
-    JXH_CHECK(!(fh.flags & FrameHeader::kNoise) || fh.upsampling == 1, "unsupported: noise on upsampled frames");
+    // its noise is added behind the upsampling, at the image's resolution)
     P.dim = MakeFrameDim(fh);
     const FrameDim& d = P.dim;
     const size_t np = fh.num_passes;

@@ -233,8 +233,11 @@ def test_upsampled_frames(built, factor):
     image like the oracle, for ragged image sizes, and through the JxlDecoder-level helper as well."""
     import jxlo
     J = built
+    # (the third stream: with noise, which an upsampled frame gets at the IMAGE's resolution, behind the upsampling --
+    # dec_cache.cc:206-216; one generator per 256 x 256 square of the image, several of them and ragged ones here)
     for data in (J.encode_rgb8(J.synth_image(701, 523, seed=factor), upsampling=factor),
-                 J.encode_random(300, 203, seed=20 + factor, upsampling=factor, epf_iters=2)):
+                 J.encode_random(300, 203, seed=20 + factor, upsampling=factor, epf_iters=2),
+                 J.encode_rgb8(J.synth_image(701, 523, seed=40 + factor), upsampling=factor, noise=120)):
         o = jxlo.Decoded(data, dumps=False)
         f = J.Frame(data)
         assert (f.info["out_xsize"], f.info["out_ysize"]) == o.out_size
