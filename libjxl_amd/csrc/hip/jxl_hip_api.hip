@@ -291,6 +291,7 @@ struct JxlHipContext {
   bool entropy_gate = false;  // option "entropy_gate" (see EntropyGate)
   hipEvent_t halo_event = nullptr;  // jxlhip_halo_*_batch: orders the halo copies against the transport's stream
   Buf ups_planes;                   // upsampled X, Y, B planes of a frame with noise ([3][oys][oxs padded to 8])
+  bool pooled_once = false;         // the object has been through the context pool (RecycleContext frees it for good)
   bool owns_stream = false;   // `stream` is this context's own (it heads batched launches), not one of the shared pool
   hipStream_t stream2 = nullptr;
   hipStream_t fstream = nullptr;  // stream of the filter launch in progress (set by BeginDownstreamBatch)
@@ -407,10 +408,59 @@ static hipStream_t PoolStream(int device) {
 // The head context of a batched launch runs the batch on a stream of its own (created on first use).
 static int EnsureOwnStream(JxlHipContext* c);
 
+// Contexts that callers have destroyed are kept, a few per process, with their device buffers, pinned staging block and
+// events: a caller that creates a decoder per image (JxlDecoderCreate .. JxlDecoderDestroy, what djxl does) otherwise pays
+// for the basis tables, a dozen hipMalloc of up to 100 MB and as many hipFree (each a device synchronisation) on every
+// image: 5 - 9 ms of a 27 ms 4K decode. A recycled context is a NEW JxlHipContext object (every option and per-frame field
+// at its default) that takes over the old one's allocations. Off with JXLHIP_CTX_POOL=0 and in guard mode (whose tests
+// want fresh, pattern-filled allocations).
+static std::mutex g_ctx_pool_mu;
+static std::vector<JxlHipContext*> g_ctx_pool;
+constexpr size_t kCtxPoolMax = 4, kCtxPoolBytes = size_t(1) << 30;
+static std::vector<Buf*> AllBufs(JxlHipContext* c);
+static JxlHipContext* RecycleContext(int device) {
+  if (GuardOn() || !EnvInt("JXLHIP_CTX_POOL", 1)) return nullptr;
+  JxlHipContext* o = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_pool_mu);
+    for (size_t i = 0; i < g_ctx_pool.size(); i++)
+      if (g_ctx_pool[i]->device == device) {
+        o = g_ctx_pool[i];
+        g_ctx_pool.erase(g_ctx_pool.begin() + long(i));
+        break;
+      }
+  }
+  if (!o) return nullptr;
+  JxlHipContext* c = new (std::nothrow) JxlHipContext;
+  if (!c) {
+    jxlhip_ctx_destroy(o);
+    return nullptr;
+  }
+  c->device = device;
+  c->stream = PoolStream(device);
+  std::vector<Buf*> to = AllBufs(c), from = AllBufs(o);  // (the new object has no per-pass buffers yet: the common prefix)
+  for (size_t i = 0; i < to.size(); i++) {
+    *to[i] = *from[i];
+    if (to[i]->view) *to[i] = Buf();  // (a view into the old frame's table blob means nothing here)
+    *from[i] = Buf();
+  }
+  c->pass_bufs = std::move(o->pass_bufs);
+  o->pass_bufs.clear();
+  for (size_t i = 0; i < sizeof(c->ev) / sizeof(c->ev[0]); i++) std::swap(c->ev[i], o->ev[i]);
+  for (size_t i = 0; i < sizeof(c->enc_ev) / sizeof(c->enc_ev[0]); i++) std::swap(c->enc_ev[i], o->enc_ev[i]);
+  std::swap(c->stage, o->stage);
+  jxlhip_ctx_destroy(o);  // (what is left of it: lazily created events, a stream of its own)
+  return c;
+}
+
 int jxlhip_ctx_create(int device, JxlHipContext** out) {
   if (!out) return JXLHIP_ERR_INVALID_ARGUMENT;
   *out = nullptr;
   HIP_TRY(hipSetDevice(device));
+  if (JxlHipContext* recycled = RecycleContext(device)) {
+    *out = recycled;
+    return 0;
+  }
   JxlHipContext* c = new (std::nothrow) JxlHipContext;
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
   c->device = device;
@@ -480,6 +530,17 @@ void jxlhip_ctx_destroy(JxlHipContext* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+  if (c->basis.p && !c->pooled_once && !GuardOn() && EnvInt("JXLHIP_CTX_POOL", 1)) {  // keep it for the next jxlhip_ctx_create (see RecycleContext)
+    size_t bytes = 0;
+    for (Buf* b : AllBufs(c))
+      if (!b->view) bytes += b->cap;
+    std::lock_guard<std::mutex> lk(g_ctx_pool_mu);
+    if (bytes <= kCtxPoolBytes && g_ctx_pool.size() < kCtxPoolMax) {
+      c->pooled_once = true;  // (a context leaves the pool through RecycleContext, which destroys the shell for good)
+      g_ctx_pool.push_back(c);
+      return;
+    }
+  }
   std::vector<Buf*> all = AllBufs(c);
   for (Buf* b : all) b->Free();
   for (auto& ev : c->ev)
@@ -1877,7 +1938,11 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     const int forced = EnvInt("JXLHIP_LANES", 0);  // measurement aid: lanes per wave
     const int spread = EnvInt("JXLHIP_SPREAD", 100);  // percent of the minimum lane count (>= 100)
     c0->batch_wait_shift = uint32_t(EnvInt("JXLHIP_WAIT_SHIFT", 1));
-    uint32_t wpg = uint32_t(EnvInt("JXLHIP_WPG", kLanesWPG));  // waves per workgroup
+    // waves per workgroup: ONE. The waves of a workgroup slow each other down (a lone 4K frame, one lane per wave: 832
+    // cycles per trip with four waves per workgroup, 517 with two, 417 with one; 29.6 / 24.1 / 19.6 ms for the frame:
+    // profiles/r04_single_frame.txt), and a workgroup of its own per wave costs only another copy of the tables in LDS.
+    // JXLHIP_WPG = 2 / 4 keeps the shared-table forms reachable.
+    uint32_t wpg = uint32_t(EnvInt("JXLHIP_WPG", 1));
     if (wpg != 1 && wpg != 2) wpg = 4;
     c0->batch_wpg = wpg;
     struct Unit {

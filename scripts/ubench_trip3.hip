@@ -39,22 +39,24 @@ __global__ __launch_bounds__(64) void k(uint64_t* out, uint8_t* coef, uint32_t g
 }
 int main(int argc, char** argv) {
   const uint32_t groups = argc > 1 ? atoi(argv[1]) : 2000;
-  const int blocks = 1024;
+  const int per_cu = argc > 2 ? atoi(argv[2]) : 3;  // workgroups (one wave each) per CU: the dynamic LDS request sets it
+  const int blocks = 256 * per_cu;
   uint64_t* out;
   uint8_t* coef;
   hipMalloc(&out, blocks * 8);
   const size_t coef_bytes = size_t(blocks) * 64 * (groups * 8 + 64);
   hipMalloc(&coef, coef_bytes);
-  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+  const size_t lds_bytes = per_cu <= 1 ? 100 * 1024 : (per_cu == 2 ? 70 * 1024 : (per_cu == 3 ? 45 * 1024 : 42 * 1024 * 3 / per_cu));
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   for (uint32_t split = 4; split <= 8; split += 4)        // split 4: some tokens carry extra bits; 8: (almost) none
     for (uint32_t lanes = 64; lanes >= 16; lanes /= 2) {
-      hipLaunchKernelGGL(k, dim3(blocks), dim3(64), 42 * 1024, 0, out, coef, groups, split, lanes);
+      hipLaunchKernelGGL(k, dim3(blocks), dim3(64), lds_bytes, 0, out, coef, groups, split, lanes);
       if (hipDeviceSynchronize() != hipSuccess) { printf("failed\n"); return 1; }
-      uint64_t h[1024];
-      hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+      uint64_t h[2048];
+      hipMemcpy(h, out, blocks * 8, hipMemcpyDeviceToHost);
       double s = 0;
       for (int i = 0; i < blocks; i++) s += double(h[i]);
-      printf("split_exp %u lanes %2u: %.1f shader cycles (s_memtime) per trip\n", split, lanes, s / blocks / (groups * 4.0));
+      printf("%d per CU, split_exp %u lanes %2u: %.1f shader cycles (s_memtime) per trip\n", per_cu, split, lanes, s / blocks / (groups * 4.0));
     }
   return 0;
 }
