@@ -351,3 +351,34 @@ def test_preview_frame_through_the_decoder_api(built, tmp_path):
     rc, events, out, px = R.run(R.container(data), tmp_path, "u8", 3, "nopreview", "chunk=3000")
     assert rc == 0 and "PREVIEW_IMAGE" not in events and events.count("FULL_IMAGE") == 1, out
     assert np.abs(np.frombuffer(px, np.uint8).reshape(400, 600, 3).astype(int) - want.astype(int)).max() <= 1
+
+
+def test_more_contexts_than_pool_streams_on_concurrent_host_threads(built):
+    """Contexts share a pool of 4 HIP streams per device (JXLHIP_STREAMS), so a context's synchronisation also waits for
+    whatever unrelated contexts have queued on the same stream, and destroyed contexts are recycled with their buffers
+    (RecycleContext): 12 host threads, each with a context of its own, upload / decode / download different frames at once,
+    three rounds each (so every thread also gets recycled contexts); every result must be bit-identical to the serial decode
+    of the same stream (no test used more contexts than pool streams from concurrent threads)."""
+    import concurrent.futures
+    J = built
+    streams = [J.encode_rgb8(J.synth_image(300 + 37 * i, 200 + 23 * i, seed=50 + i), distance=1.0 + 0.5 * (i % 3), noise=40 * (i % 2))
+               for i in range(6)]
+    serial = [J.decode_rgb8(s) for s in streams]
+
+    def work(t):
+        out = []
+        for r in range(3):
+            i = (t + r) % len(streams)
+            f = J.Frame(streams[i], threads=1)
+            c = J.HipContext()
+            c.upload(f)
+            c.run_all()
+            out.append((i, c.rgb8()))
+            c.close()
+            f.close()
+        return out
+
+    with concurrent.futures.ThreadPoolExecutor(12) as ex:
+        for res in ex.map(work, range(12)):
+            for i, rgb in res:
+                assert np.array_equal(rgb, serial[i]), "stream %d decoded differently on a shared stream" % i
