@@ -141,7 +141,11 @@ typedef struct JxlHipFrameDesc {
   /* colour */
   float opsin_inv[9]; /* inverse opsin matrix, already scaled by 255 / intensity_target */
   float opsin_bias[3];
-  int32_t linear_output; /* 0 = sRGB transfer function, 1 = linear */
+  /* the colour stage behind the filters: 0 = XYB -> linear sRGB -> sRGB transfer function, 1 = XYB -> linear sRGB;
+   * frames of images that are not xyb_encoded (frame_header.h ColorTransform; dec_cache.cc:256-263): 2 = kYCbCr (full-range
+   * BT.601, stage_ycbcr.cc:41-60: channels Cb, Y, Cr), 3 = kNone (the channels are the samples); no transfer function
+   * follows either (the samples are in the image's own colour space) */
+  int32_t linear_output;
   /* Band decode (one frame split over several GPUs by rows of 256x256 groups): produce only the pixel
    * rows of group rows [band_group_row_begin, band_group_row_end). The context then also decodes and transforms the
    * one group row above and below the band (the loop filters need up to 7 rows of their output), so no exchange

@@ -361,7 +361,8 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   d.epf_pass2_sigma_scale = lf.epf_pass2_sigma_scale;
   d.epf_border_sad_mul = lf.epf_border_sad_mul;
   for (int i = 0; i < 9; i++) d.opsin_inv[i] = P.ih.inv_opsin[i] * (255.0f / P.ih.intensity_target);
-  d.linear_output = P.ih.linear_tf;
+  // (frames of images that are not xyb_encoded: their own colour transform, frame_header.h:176-184, and no transfer function)
+  d.linear_output = P.ih.xyb_encoded ? (P.ih.linear_tf ? 1 : 0) : (P.fh.ycbcr ? 2 : 3);
   d.band_group_row_begin = group_row_begin;
   d.band_group_row_end = group_row_end;
   d.has_noise = P.has_noise ? 1 : 0;

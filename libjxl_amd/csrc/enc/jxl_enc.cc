@@ -684,6 +684,42 @@ static void RgbToXyb(const uint8_t* rgb, size_t xs, size_t ys, size_t xp, size_t
   }
 }
 
+// The frame's three channels of an image that is NOT xyb_encoded: the sRGB samples in [0, 1] as they are (ColorTransform
+// kNone: channel c = component c) or the inverse of the decoder's YCbCr stage (stage_ycbcr.cc:41-60: R = Y' + 1.402 Cr,
+// B = Y' + 1.772 Cb, G from the luma equation, Y' = Y + 128 / 255; channels Cb, Y, Cr).
+static void RgbToPlain(const uint8_t* rgb, size_t xs, size_t ys, size_t xp, size_t yp, bool ycbcr, std::vector<float> planes[3]) {
+  for (int c = 0; c < 3; c++) planes[c].assign(xp * yp, 0.0f);
+  for (size_t y = 0; y < yp; y++) {
+    size_t sy = std::min(y, ys - 1);
+    for (size_t x = 0; x < xp; x++) {
+      size_t sx = std::min(x, xs - 1);
+      const uint8_t* p = rgb + (sy * xs + sx) * 3;
+      const float r = p[0] / 255.0f, g = p[1] / 255.0f, b = p[2] / 255.0f;
+      if (!ycbcr) {
+        planes[0][y * xp + x] = r;
+        planes[1][y * xp + x] = g;
+        planes[2][y * xp + x] = b;
+        continue;
+      }
+      const float yy = 0.299f * r + 0.587f * g + 0.114f * b;
+      planes[0][y * xp + x] = (b - yy) / 1.772f;
+      planes[1][y * xp + x] = yy - 128.0f / 255.0f;
+      planes[2][y * xp + x] = (r - yy) / 1.402f;
+    }
+  }
+}
+
+// The RAW table of Params::raw_quant: a JPEG-like ramp per channel (positive integers), and its denominator (an exact
+// binary16): weight = 1 / (den * q), so the decoder multiplies by den * q.
+static const float kRawQuantDen = 1.0f / 2048.0f;
+static std::vector<int32_t> RawQuantTable() {
+  std::vector<int32_t> q(3 * 64);
+  for (int c = 0; c < 3; c++)
+    for (int y = 0; y < 8; y++)
+      for (int x = 0; x < 8; x++) q[c * 64 + y * 8 + x] = 1 + (x + y) + (x * y) / 4 + (c == 1 ? 0 : 2 + c);
+  return q;
+}
+
 struct Basis {
   std::vector<float> m[9];
   Basis() {
@@ -1069,6 +1105,11 @@ struct Params {
   int32_t noise;           // > 0: frame flag kNoise with the strength LUT point i = min(1023, noise + 40 * i) / 1024
   int32_t cfl_fit;         // 1 = image mode fits the chroma-from-luma factor of every 64x64 tile the way the reference's
                            //     fast path does (enc_chroma_from_luma.cc:128-151, 204-352): least squares over the tile's AC
+  int32_t color_transform; // ColorTransform of the frame (frame_header.h): 0 = XYB, 1 = none (the sRGB samples themselves in
+                           //     the three channels), 2 = YCbCr (full-range BT.601, stage_ycbcr.cc:41-60; channels Cb, Y, Cr);
+                           //     1 and 2 make an image that is not xyb_encoded
+  int32_t raw_quant;       // 1 = the 8x8 DCT's dequantisation table is coded RAW (quant_weights.cc:268-276: a denominator and
+                           //     the table as a small Modular image, what JPEG recompression writes): a JPEG-like ramp
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -1140,6 +1181,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   jxh::HybridCfg cfg420;
   cfg420.split_exp = 4; cfg420.split_token = 16; cfg420.msb = 2; cfg420.lsb = 0;
   EncCode tree_code, mod_code;
+  std::vector<Token> raw_quant_tokens;
   // alpha: channel 0 of the frame's global Modular image. Up to a group in size it is coded whole in stream 0 (DC global),
   // else one rectangle per AC group section, behind the coefficients (stream ids: dec_modular.h:44-67).
   const bool have_alpha = !f.alpha.empty();
@@ -1167,6 +1209,11 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     for (int c : tree.leaf_ctx) nleaf += c >= 0;
     if (alpha_global) all.push_back(&alpha_global_tokens);
     for (const auto& t : alpha_group_tokens) all.push_back(&t);
+    if (p.raw_quant) {  // the RAW table of the 8x8 DCT: Modular stream 1 + 3 * num_dc_groups + 0 (dec_modular.h:59-61)
+      const std::vector<int32_t> q = RawQuantTable();
+      for (int c = 0; c < 3; c++) ModularTokens(tree, q.data() + c * 64, 8, 8, c, int(1 + 3 * ndc), &raw_quant_tokens);
+      all.push_back(&raw_quant_tokens);
+    }
     BuildCode(all, nleaf, 8, cfg420, &mod_code);
   }
   // ---- tokenise AC groups
@@ -1403,7 +1450,18 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     WriteTokens(bw, meta_tokens[g].data(), meta_tokens[g].size(), mod_code);
   };
   auto write_ac_global = [&](BitWriter& bw) {
-    bw.Write(1, 1);                            // default dequant tables
+    if (!p.raw_quant) {
+      bw.Write(1, 1);                          // default dequant tables
+    } else {                                   // quant_weights.cc:497-511: all 17 encodings; the first one RAW, the others library
+      bw.Write(1, 0);
+      bw.Write(3, 7);
+      WriteF16(bw, kRawQuantDen);
+      bw.Write(1, 1);  // (GroupHeader) use global tree
+      bw.Write(1, 1);  //   default weighted-predictor header
+      bw.Write(2, 0);  //   no transforms
+      WriteTokens(bw, raw_quant_tokens.data(), raw_quant_tokens.size(), mod_code);
+      for (int k = 1; k < 17; k++) bw.Write(3, 0);
+    }
     bw.Write(CeilLog2(num_groups), uint32_t(num_hist - 1));  // number of histogram sets - 1
     for (size_t pass = 0; pass < num_passes; pass++) {
       if (!used_orders) {
@@ -1475,7 +1533,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(3, 0);  // no aspect-ratio shortcut
   WriteSizeDim(bw, g_image_w ? g_image_w : uint32_t(ups == 1 ? f.xs : f.img_xs));
   const bool with_icc = !g_embedded_icc.empty();
-  if (!have_alpha && !with_icc && !ExtraFields()) {
+  if (!have_alpha && !with_icc && !ExtraFields() && !p.color_transform) {
     bw.Write(1, 1);  // ImageMetadata all_default (8-bit sRGB, XYB encoded)
   } else {           // image_metadata.cc:283-356
     bw.Write(1, 0);  // not all_default
@@ -1485,7 +1543,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
     bw.Write(2, have_alpha ? 1 : 0);  // extra channels
     if (have_alpha) WriteAlphaChannelInfo(bw);
-    bw.Write(1, 1);  // xyb_encoded
+    bw.Write(1, p.color_transform ? 0 : 1);  // xyb_encoded
     if (!with_icc) {
       bw.Write(1, 1);  // ColorEncoding all_default (sRGB)
     } else {
@@ -1500,7 +1558,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(1, 1);  // CustomTransformData all_default
   } else {
     bw.Write(1, 0);
-    bw.Write(1, 1);  // OpsinInverseMatrix all_default (the image is XYB encoded)
+    if (!p.color_transform) bw.Write(1, 1);  // OpsinInverseMatrix all_default (only coded when the image is XYB encoded)
     bw.Write(3, g_custom_ups_mask & 7);
     uint32_t st = g_custom_ups_seed * 2654435761u + 12345u;
     const float* defaults[3] = {kUpsamplingWeights2, kUpsamplingWeights4, kUpsamplingWeights8};
@@ -1529,12 +1587,19 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     bw.Write(2, 2);
     bw.Write(8, hflags - 17);
   }
+  if (p.color_transform) {  // (frame_header.cc:247-258: only images that are not xyb_encoded say whether the frame is YCbCr)
+    bw.Write(1, p.color_transform == 2 ? 1 : 0);
+    if (p.color_transform == 2 && !g_use_dc_frame)
+      for (int c = 0; c < 3; c++) bw.Write(2, 0);  // YCbCrChromaSubsampling: 4:4:4
+  }
   if (!g_use_dc_frame) {  // (frame_header.cc:263: no upsampling fields with kUseDcFrame)
     bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
     if (have_alpha) bw.Write(2, 0);  // extra channel upsampling 1
   }
-  bw.Write(3, p.custom_cmap ? 2 : 3);  // x_qm_scale
-  bw.Write(3, p.custom_cmap ? 4 : 2);  // b_qm_scale
+  if (!p.color_transform) {  // (frame_header.cc:287-291: an image that is not xyb_encoded has both at 2)
+    bw.Write(3, p.custom_cmap ? 2 : 3);  // x_qm_scale
+    bw.Write(3, p.custom_cmap ? 4 : 2);  // b_qm_scale
+  }
   if (g_reference_slot >= 0) {
     // (frame_header.cc:303: a kReferenceOnly frame has no Passes bundle)
   } else if (num_passes == 1) {
@@ -1709,7 +1774,8 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     return;
   }
   std::vector<float> xyb[3];
-  RgbToXyb(rgb, xs, ys, xp, yp, xyb);
+  if (p.color_transform) RgbToPlain(rgb, xs, ys, xp, yp, p.color_transform == 2, xyb);
+  else RgbToXyb(rgb, xs, ys, xp, yp, xyb);
   if (f.gab) {
     // Approximate inverse of the decoder's Gaborish blur K (3x3, default weights): y <- y + (x - K*y), 4 rounds.
     const float w1 = 1.1f * 0.104699568f, w2 = 1.1f * 0.055680538f, nrm = 1.0f / (1.0f + 4 * (w1 + w2));
@@ -1868,9 +1934,16 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
   const size_t xg = DivCeil(xs, 256), yg = DivCeil(ys, 256);
   f.coeffs.assign(xg * yg, {});
   jxh::DequantTables dq;
+  if (p.raw_quant) {
+    dq.enc[0] = jxh::QuantEncoding();
+    dq.enc[0].mode = 7;
+    dq.enc[0].qraw_den = kRawQuantDen;
+    dq.enc[0].qraw = RawQuantTable();
+  }
   for (int s = 0; s < 27; s++) dq.Matrix(s, 0);  // precompute (not thread-safe lazily)
   const float inv_gs = 65536.0f / float(f.global_scale);
-  const float x_dm = std::pow(1.25f, 2.0f - 3.0f), b_dm = std::pow(1.25f, 2.0f - 2.0f);
+  // (x_qm_scale 3, b_qm_scale 2 in the frame header; an image that is not xyb_encoded codes neither: both are 2)
+  const float x_dm = p.color_transform ? 1.0f : std::pow(1.25f, 2.0f - 3.0f), b_dm = std::pow(1.25f, 2.0f - 2.0f);
   const float inv_quant_dc = inv_gs / float(f.quant_dc);
   const float dc_step[3] = {inv_quant_dc / 4096.0f, inv_quant_dc / 512.0f, inv_quant_dc / 256.0f};
   const size_t tiles_x = DivCeil(f.xb, 8);
@@ -2584,6 +2657,8 @@ struct JxlEncParams {
   int32_t ac_code_mode;    // AC coefficient streams: bit 0 = prefix codes instead of ANS, bit 1 = LZ77
   int32_t noise;           // > 0: noise synthesis, see jxe::Params
   int32_t cfl_fit;         // 1 = per-tile chroma-from-luma fit (the reference's fast FindBestMultiplier), see jxe::Params
+  int32_t color_transform; // 0 = XYB, 1 = none, 2 = YCbCr, see jxe::Params
+  int32_t raw_quant;       // 1 = RAW dequantisation table for the 8x8 DCT, see jxe::Params
 };
 
 // The next VarDCT streams code their own upsampling weights (mask bit k: the 2^(k+1)-fold matrix; 0: default weights again).

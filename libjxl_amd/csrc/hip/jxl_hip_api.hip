@@ -1036,6 +1036,10 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   c->color_out = !OutIsRgb8(c) && !(OutIsRgbF32(c) && c->ups == 1 && (c->epf_iters == 1 || c->epf_iters == 2) &&
                                     !EnvInt("JXLHIP_FILTER_TILES", 0) && !EnvInt("JXLHIP_FILTER_ROWS1", 0));
   if (c->out_orient) c->color_out = true;  // (the oriented layout is written by the generic writer)
+  // frames of images that are not XYB encoded (linear_output 2 = YCbCr, 3 = no colour transform): the colour stage is
+  // XybToRgb's other branches, which only the generic writers take
+  if (d->linear_output < 0 || d->linear_output > 3) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (d->linear_output >= 2) c->color_out = true;
   // noise is added to the filtered planes between the filter launch and the colour conversion
   c->has_noise = d->has_noise != 0;
   if (c->has_noise) {

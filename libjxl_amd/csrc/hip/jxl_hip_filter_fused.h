@@ -197,6 +197,19 @@ struct UpsampleParams {
 
 // XYB -> linear RGB -> (sRGB) for one pixel (stage_xyb.cc:80-92 + dec_xyb-inl.h:38-86, stage_from_linear.cc:114-144).
 __device__ __forceinline__ void XybToRgb(const FilterParams& f, float X, float Y, float Bc, float* r, float* g, float* b) {
+  if (f.linear_output >= 2) {  // a frame of an image that is not XYB encoded (wave-uniform)
+    if (f.linear_output == 2) {  // kYCbCr (stage_ycbcr.cc:41-60): full-range BT.601 of JFIF; channels Cb, Y, Cr
+      const float y = Y + 128.0f / 255;
+      *r = fmaf(1.402f, Bc, y);
+      *g = fmaf(-0.299f * 1.402f / 0.587f, Bc, fmaf(-0.114f * 1.772f / 0.587f, X, y));
+      *b = fmaf(1.772f, X, y);
+    } else {  // kNone: the channels are the samples
+      *r = X;
+      *g = Y;
+      *b = Bc;
+    }
+    return;
+  }
   const float gr = (Y + X) - f.opsin_bias_cbrt[0], gg = (Y - X) - f.opsin_bias_cbrt[1], gb = Bc - f.opsin_bias_cbrt[2];
   const float mr = (gr * gr) * gr + f.opsin_bias[0], mg = (gg * gg) * gg + f.opsin_bias[1], mb = (gb * gb) * gb + f.opsin_bias[2];
   *r = f.opsin_inv[2] * mb + (f.opsin_inv[1] * mg + f.opsin_inv[0] * mr);
@@ -276,16 +289,8 @@ __global__ __launch_bounds__(256) void k_upsample_color(UpsampleParams P) {
         P.xyb_out[2 * oplane + gi] = Bc;
         continue;
       }
-      const float gr = (Yc + Xc) - P.f.opsin_bias_cbrt[0], gg = (Yc - Xc) - P.f.opsin_bias_cbrt[1], gb = Bc - P.f.opsin_bias_cbrt[2];
-      const float mr = (gr * gr) * gr + P.f.opsin_bias[0], mg = (gg * gg) * gg + P.f.opsin_bias[1], mb = (gb * gb) * gb + P.f.opsin_bias[2];
-      float r = P.f.opsin_inv[2] * mb + (P.f.opsin_inv[1] * mg + P.f.opsin_inv[0] * mr);
-      float g = P.f.opsin_inv[5] * mb + (P.f.opsin_inv[4] * mg + P.f.opsin_inv[3] * mr);
-      float b = P.f.opsin_inv[8] * mb + (P.f.opsin_inv[7] * mg + P.f.opsin_inv[6] * mr);
-      if (!P.f.linear_output) {
-        r = LinearToSrgb(r);
-        g = LinearToSrgb(g);
-        b = LinearToSrgb(b);
-      }
+      float r, g, b;
+      XybToRgb(P.f, Xc, Yc, Bc, &r, &g, &b);
       if (P.po.dst) {
         StorePixel(P.po, X, Y, r, g, b);
         continue;

@@ -189,7 +189,8 @@ class FrameParser {
     // (frame types: 1 = kDCFrame, decoded like any frame and kept before the colour transform as the DC image of a later
     // frame; 2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
-    JXH_CHECK(ih.xyb_encoded, "unsupported: non-XYB VarDCT");
+    // (a VarDCT frame of an image that is not xyb_encoded: ColorTransform kNone or kYCbCr, 4:4:4: the same decode with the
+    // quant-matrix scales at 2 and another colour stage; chroma subsampling is refused by the header reader)
     JXH_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
@@ -551,8 +552,17 @@ class FrameParser {
 
   void AcGlobal(BitReader& br, FramePlan* P) {
     if (!br.ReadBool()) {
+      // RAW tables (what JPEG recompression writes) are small Modular images behind the frame's global tree
+      const RawTableReader raw = [P](BitReader& r, size_t w, size_t h, int kind, std::vector<int32_t>* out) {
+        MImage img;
+        for (int c = 0; c < 3; c++) img.ch.emplace_back(w, h);
+        ModularDecode(r, &img, int(1 + 3 * P->dim.num_dc_groups + size_t(kind)), &P->mglobal);
+        out->resize(3 * w * h);
+        for (int c = 0; c < 3; c++)
+          for (size_t y = 0; y < h; y++) memcpy(out->data() + (size_t(c) * h + y) * w, img.ch[c].Row(y), w * sizeof(int32_t));
+      };
       for (int k = 0; k < 17; k++) {
-        ReadQuantEncoding(br, k, &dq_.enc[k]);
+        ReadQuantEncoding(br, k, &dq_.enc[k], &raw);
         dq_.table[k].clear();
       }
     }

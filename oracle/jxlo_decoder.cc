@@ -340,8 +340,17 @@ static void FinalizeDc(FrameState* s) {
 static void DecodeAcGlobal(BitReader& br, FrameState* s) {
   if (s->fh.modular) return;
   if (!br.ReadBool()) {
+    // RAW tables (dec_modular.cc:795-841): a small Modular image each, stream id 1 + 3 * num_dc_groups + kind, global tree
+    const RawTableReader raw = [s](BitReader& r, size_t w, size_t h, int kind, std::vector<int32_t>* out) {
+      MImage img;
+      for (int c = 0; c < 3; c++) img.ch.emplace_back(w, h);
+      ModularDecode(r, &img, int(1 + 3 * s->dim.num_dc_groups + size_t(kind)), &s->mglobal);
+      out->resize(3 * w * h);
+      for (int c = 0; c < 3; c++)
+        for (size_t y = 0; y < h; y++) memcpy(out->data() + (size_t(c) * h + y) * w, img.ch[c].Row(y), w * sizeof(int32_t));
+    };
     for (int k = 0; k < 17; k++) {
-      ReadQuantEncoding(br, k, &s->dq.enc[k]);
+      ReadQuantEncoding(br, k, &s->dq.enc[k], &raw);
       s->dq.table[k].clear();
     }
   }
@@ -491,8 +500,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   JXLO_CHECK(fh.frame_type != 1 || ih.extra.empty(), "unsupported: DC frames of images with extra channels");
   JXLO_CHECK(fh.upsampling == 1 || !fh.modular, "unsupported: upsampled Modular frames");
   JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
-  JXLO_CHECK(!fh.ycbcr, "unsupported: YCbCr frames");
-  JXLO_CHECK(fh.modular || ih.xyb_encoded, "unsupported: non-XYB VarDCT");
+  JXLO_CHECK(!(fh.ycbcr && fh.modular), "unsupported: YCbCr Modular frames");
   JXLO_CHECK(!(fh.modular && ih.xyb_encoded && ih.gray), "unsupported: grey XYB Modular frames");
   s->dim = MakeFrameDim(fh);
   const FrameDim& d = s->dim;
@@ -705,11 +713,27 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       for (size_t x = 0; x < xs; x++) {
         size_t i = y * cur->stride + x;
         float r, g, bb;
+        if (!ih.xyb_encoded) {
+          // dec_cache.cc:256-263: kYCbCr -> stage_ycbcr.cc:41-60 (full-range BT.601 of JFIF; channels Cb, Y, Cr; fused
+          // multiply-adds like the reference's MulAdd), kNone -> nothing; no transfer function follows either
+          const float c0 = cur->p[0][i], c1 = cur->p[1][i], c2 = cur->p[2][i];
+          if (fh.ycbcr) {
+            const float yv = c1 + 128.0f / 255;
+            r = std::fma(1.402f, c2, yv);
+            g = std::fma(-0.299f * 1.402f / 0.587f, c2, std::fma(-0.114f * 1.772f / 0.587f, c0, yv));
+            bb = std::fma(1.772f, c0, yv);
+          } else {
+            r = c0;
+            g = c1;
+            bb = c2;
+          }
+        } else {
         XybToRgb(op, cur->p[0][i], cur->p[1][i], cur->p[2][i], &r, &g, &bb);
         if (!ih.linear_tf) {
           r = LinearToSrgb(r);
           g = LinearToSrgb(g);
           bb = LinearToSrgb(bb);
+        }
         }
         out->rgbf[0 * xs * ys + y * xs + x] = r;
         out->rgbf[1 * xs * ys + y * xs + x] = g;

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "jxlo_entropy.h"
@@ -156,7 +157,12 @@ struct QuantEncoding {
   float bands[3][17] = {};
   int nb4 = 0;
   float bands4[3][17] = {};  // AFV: 4x4 bands
+  float qraw_den = 0.0f;      // RAW (quant_weights.cc:268-276, dec_modular.cc:795-841): weights = 1 / (qraw_den * qraw[i])
+  std::vector<int32_t> qraw;  //   3 channels of 8 * required_size_x by 8 * required_size_y integers, as the Modular stream lays them out
 };
+// Reads the three channels (w x h each) of RAW table `kind` from the Modular sub-stream at the reader's position (stream id
+// 1 + 3 * num_dc_groups + kind, with the frame's global tree: dec_modular.cc:805-819) into out[c * w * h + y * w + x].
+typedef std::function<void(BitReader&, size_t w, size_t h, int kind, std::vector<int32_t>* out)> RawTableReader;
 
 #include "quant_library.inc"
 
@@ -191,7 +197,7 @@ static inline void ReadDctParams(BitReader& br, int* nb, float bands[3][17]) {
   }
 }
 
-static inline void ReadQuantEncoding(BitReader& br, int kind, QuantEncoding* e) {
+static inline void ReadQuantEncoding(BitReader& br, int kind, QuantEncoding* e, const RawTableReader* raw = nullptr) {
   int req = kQTReqX[kind] * kQTReqY[kind];
   int mode = int(br.Read(3));
   *e = QuantEncoding();
@@ -247,8 +253,19 @@ static inline void ReadQuantEncoding(BitReader& br, int kind, QuantEncoding* e) 
     case 6:
       ReadDctParams(br, &e->nb, e->bands);
       break;
-    default:
-      throw Error("unsupported: RAW quant tables");
+    default: {  // RAW: a denominator and the table itself as a small Modular image (what JPEG recompression writes)
+      if (!raw) throw Error("unsupported: RAW quant tables");
+      const float den = ReadF16(br);
+      JXLO_CHECK(den >= 1e-8f, "invalid qtable_den: value too small");
+      std::vector<int32_t> q;
+      (*raw)(br, size_t(8) * kQTReqX[kind], size_t(8) * kQTReqY[kind], kind, &q);
+      JXLO_CHECK(q.size() == size_t(3) * 64 * req, "RAW quant table size");
+      for (int32_t v : q) JXLO_CHECK(v > 0, "invalid raw quantization table");
+      e->mode = 7;
+      e->qraw_den = den;
+      e->qraw = std::move(q);
+      break;
+    }
   }
 }
 
@@ -398,6 +415,10 @@ struct DequantTables {
         }
         break;
       }
+      case 7:
+        JXLO_CHECK(e.qraw.size() == 3 * num, "RAW quant table size");
+        for (size_t i = 0; i < 3 * num; i++) w[i] = 1.0f / (e.qraw_den * float(e.qraw[i]));
+        break;
       default:
         throw Error("unsupported quant table mode");
     }

@@ -84,6 +84,13 @@ def _compare(J, jxlo, data, check_rgb=True):
     ((700, 520), dict(num_passes=2)),                     # progressive: two passes, pass 0 shifted by one bit
     ((200, 100), dict(num_passes=2)),                     # ... with a single group
     ((1000, 700), dict(num_passes=2, num_histograms=3, distance=2.0)),
+    ((520, 300), dict(color_transform=2)),                # an image that is not XYB encoded: YCbCr frame (stage_ycbcr.cc), 4:4:4
+    ((777, 513), dict(color_transform=2, distance=2.0, strategy_mode=2)),
+    ((520, 300), dict(color_transform=1)),                # ... ColorTransform kNone: the channels are the sRGB samples
+    ((600, 400), dict(color_transform=2, upsampling=2)),  # ... through the upsampling kernel's colour stage
+    ((520, 300), dict(raw_quant=1, strategy_mode=0)),     # the 8x8 DCT's dequantisation table coded RAW (a Modular image in AC global)
+    ((777, 513), dict(raw_quant=1)),                      # ... beside library tables for the other transforms
+    ((600, 400), dict(raw_quant=1, color_transform=2, strategy_mode=0, epf_iters=0, gab=0)),  # what a recompressed 4:4:4 JPEG looks like
 ])
 def test_image_streams(built, size, kw):
     import jxlo
