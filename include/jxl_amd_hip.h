@@ -195,6 +195,15 @@ typedef struct JxlHipFrameDesc {
   const uint8_t* sharpness;
   float quant_scale, epf_quant_mul;
   float epf_sharp_lut[8];
+  /* Chroma subsampling of a YCbCr frame (frame_header.h:81-166 YCbCrChromaSubsampling; linear_output 2 only, else all 0):
+   * channel c (Cb, Y, Cr) has (xsize_blocks >> chroma_hshift[c]) x (ysize_blocks >> chroma_vshift[c]) blocks, shifts 0 or 1.
+   * Its block at (sx, sy) is coded with the varblock at (sx << hshift, sy << vshift) (dec_group.cc:568-578: the other
+   * varblocks carry nothing for it), its DC samples (`dc_quantised` / `dc`) sit in the top-left part of its plane with the
+   * plane's row stride, and DequantDC applies no chroma from luma (compressed_dc.cc:232-250). xsize_blocks / ysize_blocks
+   * are then whole MCUs (multiples of 1 << the largest shift); only varblocks of one block; dc_smoothing must be 0
+   * (dec_frame.cc:206-212). The decoded channel is upsampled in front of the loop filters
+   * (render_pipeline/stage_chroma_upsampling.cc:29-111, dec_cache.cc:138-150). */
+  uint8_t chroma_hshift[3], chroma_vshift[3];
 } JxlHipFrameDesc;
 
 int jxlhip_device_count(void);

@@ -341,6 +341,10 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
   memcpy(d.epf_sharp_lut, P.fh.lf.epf_sharp_lut, sizeof(d.epf_sharp_lut));
   d.ytox = P.ytox.data();
   d.ytob = P.ytob.data();
+  for (int c = 0; c < 3; c++) {
+    d.chroma_hshift[c] = uint8_t(P.fh.hshift[c]);
+    d.chroma_vshift[c] = uint8_t(P.fh.vshift[c]);
+  }
   d.inv_global_scale = P.inv_global_scale;
   d.x_dm = P.x_dm;
   d.b_dm = P.b_dm;

@@ -779,6 +779,32 @@ struct FrameModel {
   uint64_t flags;
   size_t img_xs = 0, img_ys = 0;  // image size when the frame is coded downsampled (upsampling > 1)
   std::vector<uint8_t> alpha;     // optional 8-bit alpha plane (xs * ys): one Modular-coded extra channel (dec_frame.cc:511-542)
+  // YCbCr chroma subsampling (frame_header.h:81-166): channel_mode per channel (0 = 1x1, 1 = 2x2, 2 = 2x1, 3 = 1x2 samples per
+  // MCU), and the shifts that follow from it: channel c has (xb >> hs[c]) x (yb >> vs[c]) blocks; its block at (sx, sy) is
+  // coded with the frame's block (sx << hs, sy << vs); its DC sits in the top-left part of dc[c] (row stride xb)
+  uint32_t cmode[3] = {0, 0, 0};
+  int hs[3] = {0, 0, 0}, vs[3] = {0, 0, 0}, maxhs = 0, maxvs = 0;
+  bool Subsampled() const { return maxhs || maxvs; }
+  bool Present(int c, size_t bx, size_t by) const { return ((bx & ((size_t(1) << hs[c]) - 1)) | (by & ((size_t(1) << vs[c]) - 1))) == 0; }
+  void SetSubsampling(uint32_t packed) {
+    static const int kH[4] = {0, 1, 1, 0}, kV[4] = {0, 1, 0, 1};
+    maxhs = maxvs = 0;
+    for (int c = 0; c < 3; c++) {
+      cmode[c] = (packed >> (2 * c)) & 3;
+      maxhs = std::max(maxhs, kH[cmode[c]]);
+      maxvs = std::max(maxvs, kV[cmode[c]]);
+    }
+    for (int c = 0; c < 3; c++) {
+      hs[c] = maxhs - kH[cmode[c]];
+      vs[c] = maxvs - kV[cmode[c]];
+    }
+  }
+  // blocks per side: whole MCUs (frame_dimensions.h:43-44)
+  void SetSize(size_t x, size_t y) {
+    xs = x; ys = y;
+    xb = DivCeil(x, size_t(8) << maxhs) << maxhs;
+    yb = DivCeil(y, size_t(8) << maxvs) << maxvs;
+  }
 };
 
 // Test aid: a coded ICC profile (the byte stream lib/jxl/icc_codec.cc reads: U64 size, histograms, ANS data) that the
@@ -1110,6 +1136,9 @@ struct Params {
                            //     1 and 2 make an image that is not xyb_encoded
   int32_t raw_quant;       // 1 = the 8x8 DCT's dequantisation table is coded RAW (quant_weights.cc:268-276: a denominator and
                            //     the table as a small Modular image, what JPEG recompression writes): a JPEG-like ramp
+  int32_t chroma_subsampling;  // YCbCr frames (color_transform 2) only: channel_mode of Cb, Y, Cr in bits 0-1, 2-3, 4-5
+                           //     (frame_header.h:81-166; 0 = one sample per MCU side, 1 = 2x2, 2 = 2x1, 3 = 1x2): 4:2:0 = 0b000100 = 4,
+                           //     4:2:2 = 8, 4:4:0 = 12. Only transforms that cover one block; no adaptive DC smoothing.
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -1148,9 +1177,12 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     std::vector<int32_t> tmp(bw_ * bh);
     static const int kDcChan[3] = {1, 0, 2};  // stream channel order Y, X, B
     for (int ch = 0; ch < 3; ch++) {
-      for (size_t y = 0; y < bh; y++)
-        for (size_t x = 0; x < bw_; x++) tmp[y * bw_ + x] = f.dc[kDcChan[ch]][(by0 + y) * f.xb + bx0 + x];
-      ModularTokens(tree, tmp.data(), bw_, bh, ch, int(1 + g), &dc_tokens[g]);
+      // (a subsampled channel's part of the DC group: dec_modular.cc:443-452)
+      const int c = kDcChan[ch];
+      const size_t sx0 = bx0 >> f.hs[c], sy0 = by0 >> f.vs[c], sw = bw_ >> f.hs[c], sh = bh >> f.vs[c];
+      for (size_t y = 0; y < sh; y++)
+        for (size_t x = 0; x < sw; x++) tmp[y * sw + x] = f.dc[c][(sy0 + y) * f.xb + sx0 + x];
+      ModularTokens(tree, tmp.data(), sw, sh, ch, int(1 + g), &dc_tokens[g]);
     }
     // AC metadata
     size_t cw = (bw_ + 7) / 8, chh = (bh + 7) / 8, tiles_x = DivCeil(f.xb, 8);
@@ -1252,9 +1284,12 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   auto dc_bucket = [&](size_t i) -> int {
     if (bctx.num_dc_ctxs <= 1) return 0;
     int kx = 0, ky = 0, kb = 0;
-    for (int t : bctx.dc_thresholds[0]) kx += f.dc[0][i] > t;
-    for (int t : bctx.dc_thresholds[1]) ky += f.dc[1][i] > t;
-    for (int t : bctx.dc_thresholds[2]) kb += f.dc[2][i] > t;
+    // (compressed_dc.cc:256-290: a subsampled channel's sample that covers the block)
+    const size_t bx = i % f.xb, by = i / f.xb;
+    auto at = [&](int c) { return f.dc[c][(by >> f.vs[c]) * f.xb + (bx >> f.hs[c])]; };
+    for (int t : bctx.dc_thresholds[0]) kx += at(0) > t;
+    for (int t : bctx.dc_thresholds[1]) ky += at(1) > t;
+    for (int t : bctx.dc_thresholds[2]) kb += at(2) > t;
     int b = kx;
     b = b * int(bctx.dc_thresholds[2].size() + 1) + kb;
     b = b * int(bctx.dc_thresholds[1].size() + 1) + ky;
@@ -1324,8 +1359,9 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     std::vector<int32_t> nzmap(3 * 1024, 0);
     std::vector<Token>& out_t = ac_tokens[pg];
     size_t offset = 0;
-    for (size_t by = 0; by < gh; by++)
-      for (size_t bx = 0; bx < gw; bx++) {
+    for (size_t by_ = 0; by_ < gh; by_++)
+      for (size_t bx_ = 0; bx_ < gw; bx_++) {
+        const size_t bx = bx_, by = by_;
         uint8_t a = f.acs[(by0 + by) * f.xb + bx0 + bx];
         if (!(a & 1)) continue;
         const int st = a >> 1;
@@ -1336,15 +1372,17 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
         static const int kOrder[3] = {1, 0, 2};
         for (int ci = 0; ci < 3; ci++) {
           const int c = kOrder[ci];
+          if (!f.Present(c, bx0 + bx, by0 + by)) continue;  // (dec_group.cc:572-578: only the blocks a subsampled channel has)
           const int32_t* q = f.GroupCoeffs(g) + size_t(c) * 65536 + offset;
           int32_t* nzc = nzmap.data() + c * 1024;
+          const size_t bx = bx_ >> f.hs[c], by = by_ >> f.vs[c];
           const int32_t* top = by ? nzc + (by - 1) * 32 : nullptr;
           int32_t* cur = nzc + by * 32;
           int32_t pred = bx == 0 ? (top ? top[0] : 32) : (!top ? cur[bx - 1] : (top[bx] + cur[bx - 1] + 1) / 2);
           const uint32_t* order = scan[(pass * 13 + ord) * 3 + c].data();
           size_t nz = 0;
           for (size_t k = covered; k < size; k++) nz += part(q[order[k]]) != 0;
-          size_t bc = bctx.Context(dc_bucket((by0 + by) * f.xb + bx0 + bx), qf, ord, c);
+          size_t bc = bctx.Context(dc_bucket((by0 + by_) * f.xb + bx0 + bx_), qf, ord, c);
           const size_t hist_off = (g % num_hist) * nctx;  // this group's histogram set
           out_t.push_back({uint32_t(hist_off + bctx.NonZeroContext(uint32_t(pred), bc)), uint32_t(nz)});
           for (size_t y = 0; y < cy; y++)
@@ -1577,7 +1615,8 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   bw.Write(1, 0);  // not all_default
   bw.Write(2, g_dc_frame_level > 0 ? 1 : (g_reference_slot >= 0 ? 2 : 0));  // regular frame, kDCFrame or kReferenceOnly
   bw.Write(1, 0);  // VarDCT
-  const uint64_t hflags = f.flags | (g_use_dc_frame ? 32 : 0);
+  // (dec_frame.cc:206-212: a subsampled frame must not ask for adaptive DC smoothing)
+  const uint64_t hflags = f.flags | (g_use_dc_frame ? 32 : 0) | (f.Subsampled() ? 128 : 0);
   if (hflags == 0) {
     bw.Write(2, 0);
   } else if (hflags <= 16) {  // U64 selector 1: 1 + 4 bits
@@ -1590,7 +1629,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   if (p.color_transform) {  // (frame_header.cc:247-258: only images that are not xyb_encoded say whether the frame is YCbCr)
     bw.Write(1, p.color_transform == 2 ? 1 : 0);
     if (p.color_transform == 2 && !g_use_dc_frame)
-      for (int c = 0; c < 3; c++) bw.Write(2, 0);  // YCbCrChromaSubsampling: 4:4:4
+      for (int c = 0; c < 3; c++) bw.Write(2, f.cmode[c]);  // YCbCrChromaSubsampling (all 0: 4:4:4)
   }
   if (!g_use_dc_frame) {  // (frame_header.cc:263: no upsampling fields with kUseDcFrame)
     bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
@@ -1702,7 +1741,9 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
                         FrameModel* model_only = nullptr) {
   FrameModel f;
   if (alpha) f.alpha = *alpha;
-  f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
+  f.SetSubsampling(p.color_transform == 2 ? uint32_t(p.chroma_subsampling) : 0u);
+  f.SetSize(xs, ys);
+  if (hook && f.Subsampled()) throw std::runtime_error("forward hook: unsupported parameters");
   f.img_xs = img_xs ? img_xs : xs;
   f.img_ys = img_ys ? img_ys : ys;
   const size_t xp = f.xb * 8, yp = f.yb * 8;
@@ -1798,6 +1839,22 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
       xyb[c].swap(y);
     }
   }
+  if (f.Subsampled()) {
+    // a subsampled channel: the mean of each 2x1 / 1x2 / 2x2 cell, kept in the top-left part of its plane (same row stride)
+    for (int c = 0; c < 3; c++) {
+      if (!f.hs[c] && !f.vs[c]) continue;
+      const size_t sw = xp >> f.hs[c], sh = yp >> f.vs[c], nx = size_t(1) << f.hs[c], ny = size_t(1) << f.vs[c];
+      std::vector<float> sub(xp * yp, 0.0f);
+      for (size_t y = 0; y < sh; y++)
+        for (size_t x = 0; x < sw; x++) {
+          float sum = 0;
+          for (size_t dy = 0; dy < ny; dy++)
+            for (size_t dx = 0; dx < nx; dx++) sum += xyb[c][(y * ny + dy) * xp + x * nx + dx];
+          sub[y * xp + x] = sum / float(nx * ny);
+        }
+      xyb[c].swap(sub);
+    }
+  }
   f.epf_iters = p.epf_iters >= 0 ? p.epf_iters : (p.distance >= 4.0f ? 3 : p.distance >= 1.5f ? 2 : p.distance >= 0.7f ? 1 : 0);
   f.flags = (p.skip_dc_smoothing ? 128 : 0) | (p.noise > 0 ? 1 : 0) | (g_splines.empty() ? 0 : 16) | (g_patches.empty() ? 0 : 2);
   f.acs.assign(f.xb * f.yb, 0xFF);
@@ -1848,12 +1905,13 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
           if (!(mask & (1u << cand))) continue;
           size_t cx = jxh::kCoveredX[cand], cy = jxh::kCoveredY[cand];
           if (bx % cx || by % cy) continue;
+          if (f.Subsampled() && cx * cy != 1) continue;  // (dec_modular.cc:534-538)
           if (Fits(f, bx, by, cand)) {
             st = cand;
             break;
           }
         }
-      } else if (p.strategy_mode == 1) {
+      } else if (p.strategy_mode == 1 && !f.Subsampled()) {
         auto ok = [&](int cand, float thr) {
           size_t cx = jxh::kCoveredX[cand], cy = jxh::kCoveredY[cand];
           return bx % cx == 0 && by % cy == 0 && Fits(f, bx, by, cand) && region_max(bx, by, cx, cy) < thr;
@@ -1885,7 +1943,7 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
       int q = int(quant_ac * mul * inv_gs + 0.5f);
       f.qf[by * f.xb + bx] = std::max(1, std::min(256, q));
     }
-  if (p.cfl_fit && !p.random_cmap) {
+  if (p.cfl_fit && !p.random_cmap && !f.Subsampled()) {
     // enc_chroma_from_luma.cc:204-352 ComputeTile + :128-151 FindBestMultiplier (fast): over the AC coefficients of the
     // tile's transforms (lowest frequencies excluded), weighted by the inverse quantisation matrix of the chroma channel
     // and q = Scale() * 128 * quant field, the least-squares factor of chroma against luma, pulled 2.6 towards zero.
@@ -1966,9 +2024,10 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
         const int R = cy * 8, C = cx * 8;
         const size_t size = size_t(R) * C;
         const size_t cstride = size_t(std::max(cx, cy)) * 8;  // coefficient columns
+        const bool present[3] = {f.Present(0, abx, aby), f.Present(1, abx, aby), f.Present(2, abx, aby)};
         for (int c = 0; c < 3; c++) {
-          coef[c].resize(size);
-          ForwardDct(xyb[c].data() + aby * 8 * xp + abx * 8, xp, R, C, coef[c].data(), tmp);
+          coef[c].assign(size, 0.0f);
+          if (present[c]) ForwardDct(xyb[c].data() + (aby >> f.vs[c]) * 8 * xp + (abx >> f.hs[c]) * 8, xp, R, C, coef[c].data(), tmp);
         }
         // DC samples of the covered blocks from the LLF corner (inverse of LowestFrequenciesFromDC)
         float dcv[3][32 * 32];
@@ -1990,6 +2049,10 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
               dcv[c][y * cx + x] = s;
             }
         }
+        if (f.Subsampled()) {  // (compressed_dc.cc:230-250: no chroma from luma on the DC of such a frame)
+          for (int c = 0; c < 3; c++)
+            if (present[c]) f.dc[c][(aby >> f.vs[c]) * f.xb + (abx >> f.hs[c])] = int32_t(std::lround(dcv[c][0] / dc_step[c]));
+        } else
         for (int y = 0; y < cy; y++)
           for (int x = 0; x < cx; x++) {
             size_t bi = (aby + y) * f.xb + abx + x;
@@ -2016,12 +2079,14 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
             float r = std::nearbyint(v);
             return std::fabs(v) < 0.58f ? 0 : int32_t(r);
           };
-          int32_t iy = quant(coef[1][k] / (my[k] * mulc[1]));
+          // (a subsampled frame: a channel's block is coded with the frame's block that shares its top-left corner in block
+          // units, and the chroma-from-luma term is whatever luma that block carries: dec_group.cc:432-452)
+          int32_t iy = present[1] ? quant(coef[1][k] / (my[k] * mulc[1])) : 0;
           qyv[k] = iy;
           float ybias = iy == 0 ? 0.0f : (iy == 1 ? biases[1] : iy == -1 ? -biases[1] : float(iy) - biases[3] / float(iy));
           float ydeq = ybias * (my[k] * mulc[1]);
-          qx[k] = quant((coef[0][k] - x_cc * ydeq) / (mx[k] * mulc[0]));
-          qb[k] = quant((coef[2][k] - b_cc * ydeq) / (mb[k] * mulc[2]));
+          if (present[0]) qx[k] = quant((coef[0][k] - x_cc * ydeq) / (mx[k] * mulc[0]));
+          if (present[2]) qb[k] = quant((coef[2][k] - b_cc * ydeq) / (mb[k] * mulc[2]));
         }
         offset += size;
       }
@@ -2040,7 +2105,8 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
   const size_t xs = DivCeil(img_xs, ups), ys = DivCeil(img_ys, ups);  // the coded frame
   f.img_xs = img_xs;
   f.img_ys = img_ys;
-  f.xs = xs; f.ys = ys; f.xb = DivCeil(xs, 8); f.yb = DivCeil(ys, 8);
+  f.SetSubsampling(p.color_transform == 2 ? uint32_t(p.chroma_subsampling) : 0u);
+  f.SetSize(xs, ys);
   Rng rng(p.seed);
   f.global_scale = 3000 + rng.Below(9000);
   f.quant_dc = 8 + rng.Below(16);
@@ -2063,6 +2129,10 @@ static void EncodeRandom(size_t img_xs, size_t img_ys, const Params& p, std::vec
     std::fill(f.ytob.begin(), f.ytob.end(), 0);
   }
   uint32_t mask = p.strategy_mask ? p.strategy_mask : 0x7FFFFFFu;
+  if (f.Subsampled()) {  // only the transforms that cover one block (dec_modular.cc:534-538)
+    mask &= 0x3F00Fu;
+    if (!mask) mask = 1;
+  }
   std::vector<int> allowed;
   for (int s = 0; s < 27; s++)
     if (mask & (1u << s)) allowed.push_back(s);
@@ -2659,6 +2729,7 @@ struct JxlEncParams {
   int32_t cfl_fit;         // 1 = per-tile chroma-from-luma fit (the reference's fast FindBestMultiplier), see jxe::Params
   int32_t color_transform; // 0 = XYB, 1 = none, 2 = YCbCr, see jxe::Params
   int32_t raw_quant;       // 1 = RAW dequantisation table for the 8x8 DCT, see jxe::Params
+  int32_t chroma_subsampling;  // YCbCr frames: channel modes of Cb, Y, Cr (4 = 4:2:0, 8 = 4:2:2, 12 = 4:4:0), see jxe::Params
 };
 
 // The next VarDCT streams code their own upsampling weights (mask bit k: the 2^(k+1)-fold matrix; 0: default weights again).

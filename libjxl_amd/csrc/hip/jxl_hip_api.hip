@@ -226,6 +226,7 @@ struct JxlHipContext {
   std::vector<uint32_t> absent_groups;  // JxlHipFrameDesc::group_absent: drawn from the DC image alone
   std::vector<uint32_t> absent_blocks;  // per absent group: first block, block count
   uint32_t band_y0 = 0, band_y1 = 0;
+  uint32_t ext_y0 = 0, ext_y1 = 0;  // the pixel rows the transforms produce (the band and the group rows decoded around it)
   // upsampled frames: factor (1 = none), image size, kernels
   uint32_t ups = 1, oxs = 0, oys = 0;
   Buf ups_kernel;
@@ -310,7 +311,8 @@ struct JxlHipContext {
   Buf tb_params, tb_desc, fb_params;
   std::vector<const JxlHipContext*> db_ctxs;
   std::vector<uint64_t> db_gens;
-  uint32_t desc_begin[27] = {}, desc_count[27] = {};
+  uint32_t desc_begin[27] = {}, desc_count[27] = {};  // (entry 21: the 8x8 DCT varblocks of chroma-subsampled frames)
+  uint32_t cs = 0;  // chroma-subsampled frame: hshift of channel c in bit 2 * c, vshift in bit 2 * c + 1 (0 = 4:4:4)
   std::vector<FilterGroup> fgroups;
   hipEvent_t down_done = nullptr;
   uint64_t generation = 0;            // bumped by every jxlhip_frame_upload
@@ -725,7 +727,23 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   };
   if (!d->xsize || !d->ysize || !d->num_groups || !d->num_passes || d->num_passes > 11) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (d->coef_bits != 16 && d->coef_bits != 32) return JXLHIP_ERR_INVALID_ARGUMENT;
-  if (d->xsize_blocks != (d->xsize + 7) / 8 || d->ysize_blocks != (d->ysize + 7) / 8) return JXLHIP_ERR_INVALID_ARGUMENT;
+  uint32_t cs = 0, cs_maxh = 0, cs_maxv = 0;
+  for (int ch = 0; ch < 3; ch++) {
+    if (d->chroma_hshift[ch] > 1 || d->chroma_vshift[ch] > 1) return JXLHIP_ERR_INVALID_ARGUMENT;
+    cs |= uint32_t(d->chroma_hshift[ch]) << (2 * ch) | uint32_t(d->chroma_vshift[ch]) << (2 * ch + 1);
+    cs_maxh |= d->chroma_hshift[ch];
+    cs_maxv |= d->chroma_vshift[ch];
+  }
+  // (frame_dimensions.h:43-44: whole MCUs of a chroma-subsampled frame)
+  if (d->xsize_blocks != ((d->xsize + (8u << cs_maxh) - 1) / (8u << cs_maxh)) << cs_maxh ||
+      d->ysize_blocks != ((d->ysize + (8u << cs_maxv) - 1) / (8u << cs_maxv)) << cs_maxv)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (cs) {
+    // no adaptive DC smoothing (dec_frame.cc:206-212), no DC frame behind it, every varblock one block (checked below);
+    // a band whose neighbours' rows arrive as halos cannot upsample its edge rows: the other band form works
+    if (d->dc_smoothing || d->dc_device || d->linear_output != 2) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (c->band_halo && (d->band_group_row_begin | d->band_group_row_end)) return JXLHIP_ERR_UNSUPPORTED;
+  }
   if (d->num_groups != d->xsize_groups * ((d->ysize + 255) / 256) || d->xsize_groups != (d->xsize + 255) / 256)
     return JXLHIP_ERR_INVALID_ARGUMENT;
   if (d->num_qf_thresholds > 15 || d->num_block_ctxs == 0 || d->num_block_ctxs > 16 || d->num_dc_ctxs == 0)
@@ -740,6 +758,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
   }
   c->have_frame = false;
+  c->cs = cs;
   c->xs = d->xsize; c->ys = d->ysize; c->xb = d->xsize_blocks; c->yb = d->ysize_blocks;
   c->xg = d->xsize_groups; c->ng = d->num_groups; c->np = d->num_passes;
   c->nblocks = d->num_blocks;
@@ -761,6 +780,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     ext_row0 = (rb && !c->band_halo) ? rb - 1 : rb;
     ext_row1 = (re < yg && !c->band_halo) ? re + 1 : re;
     c->band_y0 = rb * 256;
+    c->ext_y0 = ext_row0 * 256;
+    c->ext_y1 = ext_row1 * 256 < d->ysize ? ext_row1 * 256 : d->ysize;
     c->band_y1 = re * 256 < d->ysize ? re * 256 : d->ysize;
     c->group_list.clear();
     c->absent_groups.clear();
@@ -794,6 +815,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
             v.bx + cx[v.strategy] > d->xsize_blocks || v.by + cy[v.strategy] > d->ysize_blocks)
           return JXLHIP_ERR_INVALID_ARGUMENT;
         if (v.coef_offset != off) return JXLHIP_ERR_INVALID_ARGUMENT;
+        if (cs && cx[v.strategy] * cy[v.strategy] != 1) return JXLHIP_ERR_INVALID_ARGUMENT;  // (dec_modular.cc:534-538)
         off += 64u * cx[v.strategy] * cy[v.strategy];
         if (off > 65536) return JXLHIP_ERR_INVALID_ARGUMENT;
       }
@@ -895,6 +917,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     for (int ch = 0; ch < 3; ch++) dequant_p.step[ch] = d->dc_step[ch];
     dequant_p.cfl_x = d->dc_cfl_x;
     dequant_p.cfl_b = d->dc_cfl_b;
+    dequant_p.cs = cs;
   }
   if (d->dc_device) {  // the planes of a DC frame decoded earlier (kUseDcFrame): used where they are, never smoothed
     if (!c->dc.view) c->dc.Free();
@@ -1142,6 +1165,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   for (uint32_t i = 0; i < d->num_qf_thresholds; i++) ep.qf_thr[i] = d->qf_thresholds[i];
   ep.num_hist = d->num_histograms;
   ep.nctx = nctx;
+  ep.cs = cs;
   ep.passes = c->passes_dev.as<jxlhip::PassDev>();
   ep.num_passes = d->num_passes;
   ep.num_groups = d->num_groups;
@@ -1212,6 +1236,11 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       for (uint32_t ch = 0; ch < 3; ch++) {
         const uint32_t bctx = d->block_ctx_lut[((ch * 13 + kOrderBucket[v.strategy]) * ep.nq + qfi) * ep.ndc + v.quant_dc_ctx];
         rec |= (bctx & 15u) << (12 + 4 * ch);
+        // (chroma-subsampled frames: bit 24 + channel = the block is off the channel's grid and carries nothing for it,
+        // bit 27 + channel = the channel's columns are half the frame's)
+        const uint32_t hs = (cs >> (2 * ch)) & 1u, vs = (cs >> (2 * ch + 1)) & 1u;
+        if ((v.bx & hs) | (v.by & vs)) rec |= 1u << (24 + ch);
+        rec |= hs << (27 + ch);
       }
       recs[i] = rec;
     }
@@ -1249,6 +1278,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     if (d->dequant_size[k] != 64u * areas[s] || size_t(d->dequant_offset[k]) + 3 * size_t(d->dequant_size[k]) > d->dequant_floats)
       return JXLHIP_ERR_INVALID_ARGUMENT;
   }
+  tp.cs = cs;
+  tp.cs_out = c->plane[1].as<float>();  // (a YCbCr frame's colour stage is the generic writer: the second plane set exists)
   tp.dc = c->dc.as<float>();
   tp.ytox = c->ytox.as<int8_t>();
   tp.ytob = c->ytob.as<int8_t>();
@@ -1402,12 +1433,13 @@ static uint32_t BlocksPerWG(int s) {
   return 4;                                                       // k_special
 }
 
-template <typename CoefT, int CX, int CY>
+template <typename CoefT, int CX, int CY, bool CS = false>
 static int LaunchIdctFast(JxlHipContext* c0, int s) {
   constexpr int C = CX * 8, R = CY * 8, TB = R > C ? R : C, GROUPS = jxlhip::IdctFastThreads(CX, CY) / TB;
   constexpr size_t lds = size_t(GROUPS) * R * (C + 1) * sizeof(float);
-  hipLaunchKernelGGL((jxlhip::k_idct_fast<CoefT, CX, CY>), dim3(c0->desc_count[s]), dim3(jxlhip::IdctFastThreads(CX, CY)), lds, c0->stream,
-                     c0->tb_params.as<jxlhip::TransformParams>(), c0->tb_desc.as<uint2>() + c0->desc_begin[s], uint32_t(s));
+  const int li = CS ? 21 : s;  // (the work list; the strategy stays s)
+  hipLaunchKernelGGL((jxlhip::k_idct_fast<CoefT, CX, CY, CS>), dim3(c0->desc_count[li]), dim3(jxlhip::IdctFastThreads(CX, CY)), lds, c0->stream,
+                     c0->tb_params.as<jxlhip::TransformParams>(), c0->tb_desc.as<uint2>() + c0->desc_begin[li], uint32_t(s));
   return 0;
 }
 
@@ -1463,6 +1495,32 @@ static int LaunchTransforms(JxlHipContext* c0) {
     if (e) return e;
     HIP_TRY(hipGetLastError());
   }
+  if (c0->desc_count[21]) {  // the 8x8 DCT varblocks of chroma-subsampled frames
+    int e = LaunchIdctFast<CoefT, 1, 1, true>(c0, 0);
+    if (e) return e;
+    HIP_TRY(hipGetLastError());
+  }
+  // ... whose subsampled channels then go back to the frame's resolution, in front of the filters
+  for (const JxlHipContext* c : c0->db_ctxs) {
+    if (!c->cs) continue;
+    for (uint32_t ch = 0; ch < 3; ch++) {
+      jxlhip::ChromaUpParams up;
+      up.hs = (c->cs >> (2 * ch)) & 1u;
+      up.vs = (c->cs >> (2 * ch + 1)) & 1u;
+      if (!(up.hs | up.vs)) continue;
+      const size_t plane = size_t(c->xp) * c->yp;
+      up.src = c->plane[1].as<float>() + ch * plane;
+      up.dst = PlaneHolder(c)->plane[0].as<float>() + ch * plane;
+      up.xs = c->xs;
+      up.ys = c->ys;
+      up.xp = c->xp;
+      up.y0 = c->ext_y0;
+      up.y1 = c->ext_y1;
+      if (up.y1 <= up.y0) continue;
+      hipLaunchKernelGGL(jxlhip::k_chroma_upsample, dim3((up.xs + 63) / 64, (up.y1 - up.y0 + 3) / 4), dim3(256), 0, c0->stream, up);
+    }
+    HIP_TRY(hipGetLastError());
+  }
   // 128/256-class transforms go through per-frame global scratch: one frame at a time (rare)
   for (const JxlHipContext* c : c0->db_ctxs)
     for (int s = 21; s < 27; s++) {
@@ -1509,13 +1567,18 @@ static int PrepareDownstream(JxlHipContext* c0, JxlHipContext* const* ctxs, size
     const JxlHipContext* h = PlaneHolder(ctxs[i]);
     if (!h->plane[0].p || h->plane[0].cap < ctxs[i]->plane_bytes) return JXLHIP_ERR_INVALID_ARGUMENT;  // lender too small
     tparams[i].out = h->plane[0].as<float>();
+    if (ctxs[i]->cs && (!ctxs[i]->plane[1].p || ctxs[i]->plane[1].cap < ctxs[i]->plane_bytes)) return JXLHIP_ERR_INVALID_ARGUMENT;
+    tparams[i].cs_out = ctxs[i]->plane[1].as<float>();
   }
   std::vector<uint2> desc;
-  for (int s = 0; s < 21; s++) {
+  for (int s = 0; s < 22; s++) {  // (21: the 8x8 DCT varblocks of chroma-subsampled frames, which list 0 leaves out)
     c0->desc_begin[s] = uint32_t(desc.size());
-    const uint32_t bpw = BlocksPerWG(s);
-    for (size_t i = 0; i < n; i++)
-      for (uint32_t j = 0; j < ctxs[i]->list_count[s]; j += bpw) desc.push_back(make_uint2(uint32_t(i), j));
+    const int st = s == 21 ? 0 : s;
+    const uint32_t bpw = BlocksPerWG(st);
+    for (size_t i = 0; i < n; i++) {
+      if (st == 0 && (ctxs[i]->cs != 0) != (s == 21)) continue;
+      for (uint32_t j = 0; j < ctxs[i]->list_count[st]; j += bpw) desc.push_back(make_uint2(uint32_t(i), j));
+    }
     c0->desc_count[s] = uint32_t(desc.size()) - c0->desc_begin[s];
   }
   // filter launches: frames grouped by (gaborish, epf iterations), one grid z slice per frame

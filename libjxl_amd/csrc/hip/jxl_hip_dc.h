@@ -26,6 +26,9 @@ struct DcDequantParams {
   const uint8_t* extra_precision;  // per DC group: the values are in units of step / 2^this (NULL: 0)
   float step[3];      // DC quantisation step of X, Y, B
   float cfl_x, cfl_b; // chroma from luma at DC: base correlation + DC factor * colour scale
+  uint32_t cs;        // chroma-subsampled frames (JxlHipFrameDesc::chroma_hshift / _vshift): hshift of channel c in bit 2 * c,
+                      // vshift in bit 2 * c + 1; 0 = 4:4:4. Non-zero: every channel on its own grid in the top-left part of its
+                      // plane, no chroma from luma (compressed_dc.cc:232-250)
 };
 
 // One thread per block. The products are not contracted into multiply-adds: the oracle's (and the reference's scalar)
@@ -35,6 +38,16 @@ __global__ __launch_bounds__(256) void k_dc_dequant(DcDequantParams P) {
   const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= P.xs || y >= P.ys) return;
   const size_t plane = size_t(P.xs) * P.ys, at = size_t(y) * P.xs + x;
+  if (P.cs) {
+    for (uint32_t c = 0; c < 3; c++) {
+      const uint32_t hs = (P.cs >> (2 * c)) & 1u, vs = (P.cs >> (2 * c + 1)) & 1u;
+      if (x >= (P.xs >> hs) || y >= (P.ys >> vs)) continue;
+      // (the sample belongs to the DC group of the frame's block it is coded with)
+      const uint32_t epc = P.extra_precision ? P.extra_precision[((y << vs) >> 8) * P.xgroups + ((x << hs) >> 8)] : 0u;
+      P.out[c * plane + at] = float(P.q[c * plane + at]) * (P.step[c] * (1.0f / float(1u << (epc & 3u))));
+    }
+    return;
+  }
   const uint32_t ep = P.extra_precision ? P.extra_precision[(y >> 8) * P.xgroups + (x >> 8)] : 0u;
   const float mul = 1.0f / float(1u << (ep & 3u));
   const float in_x = float(P.q[at]) * (P.step[0] * mul);

@@ -543,8 +543,15 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             }
             const uint32_t n_log2c = ((info >> 6) & 7) + ((info >> 9) & 7);
             if (nb) next_offset += 64u << n_log2c;
-            const uint32_t n_lbx = info & 31, n_lby = (info >> 5) & 1;
             const uint32_t c = n_ci == 0 ? 1u : (n_ci == 1 ? 0u : 2u);
+            // (chroma-subsampled frames: record bit 24 + c = the block carries nothing for channel c, bit 27 + c = the
+            // channel's columns are half the frame's; both 0 otherwise)
+            if ((info >> (24 + c)) & 1u) {
+              if (!(B.debug & 4)) LaneStore32(kend_base, (n_bi * 3 + c) * 4, 0);  // stays waiting: next channel / block
+              bi = n_bi;
+              ci = n_ci;
+            } else {
+            const uint32_t n_lbx = (info & 31) >> ((info >> (27 + c)) & 1u), n_lby = (info >> 5) & 1;
             const uint32_t log2cx = (info >> 6) & 7;
             const uint32_t bctx = (info >> (12 + 4 * c)) & 15;
             LdsU8* line = l_nz + (c * 32) * 64;
@@ -607,6 +614,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             err |= bad ? kErrNzeros : 0u;  // abandon the section: the refill round takes the "section complete" path
             bi = bad ? b1 : n_bi;
             ci = bad ? 2u : n_ci;
+            }
           }
         } else {
         // ---- the transition proper (every lane computes; `go` lanes commit)
@@ -618,8 +626,13 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         const uint32_t n_info = nb ? rec : info;
         const uint32_t n_log2c = ((n_info >> 6) & 7) + ((n_info >> 9) & 7);
         const uint32_t n_coef_offset = nb ? next_offset : coef_offset;  // blocks of a group are contiguous in its planes
-        const uint32_t n_lbx = n_info & 31, n_lby = (n_info >> 5) & 1;
         const uint32_t c = n_ci == 0 ? 1u : (n_ci == 1 ? 0u : 2u);
+        // chroma-subsampled frames: record bit 24 + c = the block carries nothing for channel c (the lane moves on without
+        // reading a symbol), bit 27 + c = the channel's columns are half the frame's; both 0 otherwise
+        const bool absent = ((n_info >> (24 + c)) & 1u) != 0;
+        const bool go_all = go;        // the block / channel cursor advances
+        const bool go = go_all && !absent;  // ... and a symbol is read
+        const uint32_t n_lbx = (n_info & 31) >> ((n_info >> (27 + c)) & 1u), n_lby = (n_info >> 5) & 1;
         const uint32_t log2cx = (n_info >> 6) & 7;
         const uint32_t bctx = (n_info >> (12 + 4 * c)) & 15;
         LdsU8* line = l_nz + (c * 32) * 64;
@@ -683,7 +696,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             for (uint32_t i = 1; i < cx; i++) line[(n_lbx + i) * 64] = nzv;
           }
         }
-        if (go && tok == 0 && !(B.debug & 4)) LaneStore32(kend_base, n_kidx * 4, 0);  // stays waiting: next channel / block
+        if (((go && tok == 0) || (go_all && absent)) && !(B.debug & 4)) LaneStore32(kend_base, n_kidx * 4, 0);  // stays waiting: next channel / block
         // the coefficient run's cursor (unused when the channel is empty or the count invalid)
         const uint32_t n_covm1 = covered - 1;
         const uint32_t n_cbase = num_bctx * 37 + 458 * bctx;
@@ -694,9 +707,9 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         // ---- commit
         state = go ? nstate : state;
         bitpos += go ? adv : 0u;
-        info = go ? n_info : info;
-        coef_offset = go ? n_coef_offset : coef_offset;
-        next_offset += (go && nb) ? (64u << n_log2c) : 0u;
+        info = go_all ? n_info : info;
+        coef_offset = go_all ? n_coef_offset : coef_offset;
+        next_offset += (go_all && nb) ? (64u << n_log2c) : 0u;
         log2c = go ? n_log2c : log2c;
         size = go ? n_size : size;
         kidx = go ? n_kidx : kidx;
@@ -719,8 +732,8 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
         ctxe = go ? n_ctxe : ctxe;
         mode = (go && tok != 0 && !bad) ? uint32_t(kRun) : mode;
         err |= (go && bad) ? kErrNzeros : 0u;  // abandon the section: the refill round takes the "section complete" path
-        bi = go ? (bad ? b1 : n_bi) : bi;
-        ci = go ? (bad ? 2u : n_ci) : ci;
+        bi = go_all ? ((go && bad) ? b1 : n_bi) : bi;
+        ci = go_all ? ((go && bad) ? 2u : n_ci) : ci;
         }
         if (B.prof) {
           t_trans += __builtin_readcyclecounter() - t2;

@@ -86,6 +86,7 @@ struct EntropyParams {
   uint32_t nq, ndc, num_bctx;
   uint32_t qf_thr[16];
   uint32_t num_hist, nctx;  // nctx = num_bctx * 495
+  uint32_t cs;              // chroma-subsampled frames: hshift of channel c in bit 2 * c, vshift in bit 2 * c + 1 (0 = 4:4:4)
   const PassDev* passes;
   uint32_t num_passes, num_groups;
   void* coeffs;
@@ -244,10 +245,14 @@ __global__ __launch_bounds__(64) void k_entropy_ans(EntropyParams P) {
       const uint32_t ord = c_strategy_order[st];
       uint32_t qfi = 0;
       for (uint32_t t = 0; t + 1 < P.nq; t++) qfi += vb.qf > P.qf_thr[t];
-      const uint32_t lbx = vb.bx & 31, lby = vb.by & 31;
+      const uint32_t fbx = vb.bx & 31, fby = vb.by & 31;
 #pragma unroll 1
       for (int ci = 0; ci < 3 && !err; ci++) {
         const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+        // (a subsampled channel, EntropyParams::cs: only the blocks on its own grid carry it, and its counts live there)
+        const uint32_t hs = (P.cs >> (2 * c)) & 1u, vs = (P.cs >> (2 * c + 1)) & 1u;
+        if ((fbx & hs) | (fby & vs)) continue;
+        const uint32_t lbx = fbx >> hs, lby = fby >> vs;
         uint8_t* nzc = l_nz + c * 1024;
         uint32_t pred;
         if (lbx == 0) pred = lby ? nzc[(lby - 1) * 32] : 32;
@@ -440,10 +445,13 @@ __global__ __launch_bounds__(64) void k_entropy_generic(EntropyParams P) {
       const uint32_t ord = c_strategy_order[st];
       uint32_t qfi = 0;
       for (uint32_t t = 0; t + 1 < P.nq; t++) qfi += vb.qf > P.qf_thr[t];
-      const uint32_t lbx = vb.bx & 31, lby = vb.by & 31;
+      const uint32_t fbx = vb.bx & 31, fby = vb.by & 31;
 #pragma unroll 1
       for (int ci = 0; ci < 3 && !r.err; ci++) {
         const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+        const uint32_t hs = (P.cs >> (2 * c)) & 1u, vs = (P.cs >> (2 * c + 1)) & 1u;  // (subsampled channels: see k_entropy_ans)
+        if ((fbx & hs) | (fby & vs)) continue;
+        const uint32_t lbx = fbx >> hs, lby = fby >> vs;
         uint8_t* nzc = l_nz + c * 1024;
         uint32_t pred;
         if (lbx == 0) pred = lby ? nzc[(lby - 1) * 32] : 32;
@@ -722,10 +730,13 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_uni(EntropyBatch B) {
       const uint32_t covered = 1u << log2c, size = covered * 64;
       uint32_t qfi = 0;
       for (uint32_t t = 0; t + 1 < P.nq; t++) qfi += qf > P.qf_thr[t];
-      const uint32_t lbx = w0 & 31, lby = (w0 >> 16) & 31;
+      const uint32_t fbx = w0 & 31, fby = (w0 >> 16) & 31;
 #pragma unroll 1
       for (int ci = 0; ci < 3 && !err; ci++) {
         const uint32_t c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
+        const uint32_t hs = (P.cs >> (2 * c)) & 1u, vs = (P.cs >> (2 * c + 1)) & 1u;  // (subsampled channels: see k_entropy_ans)
+        if ((fbx & hs) | (fby & vs)) continue;
+        const uint32_t lbx = fbx >> hs, lby = fby >> vs;
         uint8_t* nzc = l_nz + c * 1024;
         uint32_t pred;
         if (lbx == 0) pred = lby ? Uni(nzc[(lby - 1) * 32]) : 32;
@@ -891,6 +902,13 @@ struct TransformParams {
   // transform work lists: block indices bucketed by strategy (tlist[list_begin[s] .. + list_count[s]))
   const uint32_t* tlist;
   uint32_t list_begin[27], list_count[27];
+  // Chroma-subsampled YCbCr frames (JxlHipFrameDesc::chroma_hshift / _vshift; dec_group.cc:443-451): cs = hshift of channel c
+  // in bit 2 * c, vshift in bit 2 * c + 1 (0 = 4:4:4). A varblock carries channel c only when it lies on the channel's grid;
+  // the pixels then go to block (bx >> hshift, by >> vshift) of the channel's plane in `cs_out` (same geometry as `out`: the
+  // channel fills the top-left part), for k_chroma_upsample to spread into `out`; channels with no shift go to `out` directly.
+  // The lowest frequencies come from the channel's own DC sample, at the same shifted position of its DC plane.
+  uint32_t cs;
+  float* cs_out;
 };
 
 // Batched launches: one workgroup descriptor per workgroup = {frame index into the parameter array, index of the
@@ -1275,11 +1293,13 @@ __device__ __forceinline__ void WaveLdsSync() {
 // the LDS the resident entropy workgroups leave free and a barrier stalls one wave only
 __host__ __device__ constexpr int IdctFastThreads(int cx, int cy) { return (void(cx), void(cy), 64); }
 
-template <typename CoefT, int CX, int CY>
+// CS: the frame is chroma subsampled (TransformParams::cs; the 8x8 class only: such frames have no larger varblocks).
+template <typename CoefT, int CX, int CY, bool CS = false>
 // (the 32-point instantiations need ~150 registers for a column of Y output plus the transform's temporaries: at four
 // waves per SIMD they spilled 8-21 of them to scratch; the 64-point ones, one varblock per wave, take two waves' share)
 __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_waves_per_eu((CX == 8 || CY == 8) ? 2 : ((CX == 4 || CY == 4) ? 3 : 4), 8))) void k_idct_fast(const TransformParams* params, const uint2* desc, uint32_t strategy) {
   JXL_TRANSFORM_PREAMBLE();
+  static_assert(!CS || (CX == 1 && CY == 1), "chroma-subsampled frames: varblocks of one block only");
   static_assert(IdctFastThreads(CX, CY) == 64, "WaveLdsSync: the workgroup is one wave");
   constexpr int R = CY * 8, C = CX * 8, SIZE = R * C, TB = R > C ? R : C, S = C + 1, TILE = R * S;
   constexpr int LOGC = CX == 1 ? 3 : (CX == 2 ? 4 : (CX == 4 ? 5 : 6));
@@ -1348,6 +1368,10 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
   for (int ci = 0; ci < 3; ci++) {
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
     const float cc = c == 1 ? 0.0f : (c == 0 ? x_cc : b_cc);
+    // (CS) does this varblock carry channel c, and where do the channel's DC sample and pixels sit
+    const uint32_t hs = CS ? (P.cs >> (2 * c)) & 1u : 0u, vs = CS ? (P.cs >> (2 * c + 1)) & 1u : 0u;
+    const bool act_c = active && (!CS || ((uint32_t(vb.bx) & hs) | (uint32_t(vb.by) & vs)) == 0);
+    const uint32_t obx = active ? uint32_t(vb.bx) >> hs : 0u, oby = active ? uint32_t(vb.by) >> vs : 0u;
     if (!pf) {
       if (active)
         for (int i = t * 4; i < TILE; i += TB * 4) *reinterpret_cast<float4*>(l + i) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1428,16 +1452,16 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
         }
       }
       if (t < CX * CY) {  // lowest frequencies from the DC image (minus the part the pixel-domain chroma from luma adds back)
-        const float* dc = P.dc + size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx;
+        const float* dc = P.dc + size_t(c) * P.xb * P.yb + size_t(oby) * P.xb + obx;
         const int ky = t / CX, kx = t % CX;
         float v = LlfFromDc<CX, CY>(P, dc, ky, kx);
-        if (c == 1) llf_y = v;  // (Y comes first)
+        if (c == 1) llf_y = act_c ? v : 0.0f;  // (Y comes first)
         else v -= cc * llf_y;
         l[ky * S + kx] = v;
       }
     }
     WaveLdsSync();
-    if (active && t < R) {  // pass 1: row ky = t
+    if (act_c && t < R) {  // pass 1: row ky = t
       float v[C];
 #pragma unroll
       for (int kx = 0; kx < C; kx++) v[kx] = l[t * S + kx];
@@ -1446,15 +1470,15 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
       for (int x = 0; x < C; x++) l[t * S + x] = v[x];
     }
     WaveLdsSync();
-    if (active && t < C) {  // pass 2: column x = t
+    if (act_c && t < C) {  // pass 2: column x = t
       float v[R];
 #pragma unroll
       for (int ky = 0; ky < R; ky++) v[ky] = l[ky * S + t];
       FastIdct<R>(v);
       // rows through a raw buffer: one 32-bit lane offset for the column, the row's offset in a scalar register (24 64-bit
       // address computations per thread otherwise); three planes of at most 1 GiB: the offsets fit 32 bits
-      const __amdgpu_buffer_rsrc_t out_buf = __builtin_amdgcn_make_buffer_rsrc(P.out, 0, 0xFFFFFFFFu, 0x00020000);
-      const uint32_t voff = (uint32_t(c) * P.xp * P.yp + uint32_t(vb.by) * 8 * P.xp + uint32_t(vb.bx) * 8 + uint32_t(t)) * 4u;
+      const __amdgpu_buffer_rsrc_t out_buf = __builtin_amdgcn_make_buffer_rsrc((CS && (hs | vs)) ? P.cs_out : P.out, 0, 0xFFFFFFFFu, 0x00020000);
+      const uint32_t voff = (uint32_t(c) * P.xp * P.yp + oby * 8 * P.xp + obx * 8 + uint32_t(t)) * 4u;
       const uint32_t row_bytes = P.xp * 4u;
 #pragma unroll
       for (int y = 0; y < R; y++) {
@@ -1589,7 +1613,12 @@ __global__ __launch_bounds__(256) void k_special(const TransformParams* params, 
                           c == 1 ? sc : sc * (c == 0 ? P.x_dm : P.b_dm), c == 0 ? x_cc : b_cc, l_y, co, t, 64);
     }
     __syncthreads();
-    if (active && t == 0) co[0] = P.dc[size_t(c) * P.xb * P.yb + size_t(vb.by) * P.xb + vb.bx];
+    // (chroma-subsampled frames, TransformParams::cs: the channel's own grid; a varblock off that grid carries nothing for it,
+    // its staged coefficients are all zero then)
+    const uint32_t hs = (P.cs >> (2 * c)) & 1u, vs = (P.cs >> (2 * c + 1)) & 1u;
+    const bool act_c = active && ((uint32_t(vb.bx) & hs) | (uint32_t(vb.by) & vs)) == 0;
+    const uint32_t obx = active ? uint32_t(vb.bx) >> hs : 0u, oby = active ? uint32_t(vb.by) >> vs : 0u;
+    if (active && t == 0) co[0] = P.dc[size_t(c) * P.xb * P.yb + size_t(oby) * P.xb + obx];
     __syncthreads();
     float result = 0.0f;
     if (strategy == 1) {  // IDENTITY
@@ -1707,9 +1736,49 @@ __global__ __launch_bounds__(256) void k_special(const TransformParams* params, 
         }
       }
     }
-    if (active) P.out[size_t(c) * P.xp * P.yp + (size_t(vb.by) * 8 + py) * P.xp + size_t(vb.bx) * 8 + px] = result;
+    if (act_c) ((hs | vs) ? P.cs_out : P.out)[size_t(c) * P.xp * P.yp + (size_t(oby) * 8 + py) * P.xp + size_t(obx) * 8 + px] = result;
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------------------------- chroma upsampling
+// The subsampled channels of a YCbCr frame back at the frame's resolution, in front of the loop filters
+// (render_pipeline/stage_chroma_upsampling.cc:29-111; dec_cache.cc:138-150: per channel the horizontal stage, then the
+// vertical one). Each stage turns a sample into two: 3/4 of itself + 1/4 of its neighbour on that side, computed as one
+// multiply and one fused multiply-add like the reference's Mul / MulAdd, and mirrors about the channel's own image size,
+// ceil(xs / 2) columns / ceil(ys / 2) rows (low_memory_render_pipeline.cc:348-355, 668-683). One thread per output pixel;
+// the horizontal stage is evaluated for the two input rows the vertical one reads.
+struct ChromaUpParams {
+  const float* src;  // the channel as the transforms wrote it: the top-left part of a plane with row stride xp
+  float* dst;        // the channel's plane of the frame, row stride xp
+  uint32_t xs, ys, xp;
+  uint32_t y0, y1;   // output rows to produce
+  uint32_t hs, vs;   // the channel's shifts (0 or 1, not both 0)
+};
+__device__ __forceinline__ uint32_t ChromaMirror(int32_t i, uint32_t n) { return i < 0 ? 0u : (uint32_t(i) >= n ? n - 1 : uint32_t(i)); }
+__global__ __launch_bounds__(256) void k_chroma_upsample(ChromaUpParams P) {
+#pragma clang fp contract(off)
+  const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63), y = P.y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= P.xs || y >= P.y1) return;
+  const uint32_t ws = (P.xs + 1) / 2, hh = (P.ys + 1) / 2;
+  auto row_value = [&](uint32_t r) -> float {  // the horizontal stage's output at column x of (subsampled) row r
+    const float* in = P.src + size_t(r) * P.xp;
+    if (!P.hs) return in[x];
+    const uint32_t sx = x >> 1;
+    // (the neighbour one step outside the ws samples is the edge sample itself: Mirror(-1) = 0, Mirror(ws) = ws - 1)
+    const float nb = in[ChromaMirror((x & 1) ? int32_t(sx) + 1 : int32_t(sx) - 1, ws)];
+    return __builtin_fmaf(0.25f, nb, in[sx] * 0.75f);
+  };
+  float v;
+  if (P.vs) {
+    const uint32_t sy = y >> 1;
+    const float mid = row_value(sy) * 0.75f;
+    const float other = row_value(ChromaMirror((y & 1) ? int32_t(sy) + 1 : int32_t(sy) - 1, hh));
+    v = __builtin_fmaf(other, 0.25f, mid);
+  } else {
+    v = row_value(y);
+  }
+  P.dst[size_t(y) * P.xp + x] = v;
 }
 
 // ---------------------------------------------------------------------------------------------- filters + colour

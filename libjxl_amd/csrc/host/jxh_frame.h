@@ -189,8 +189,11 @@ class FrameParser {
     // (frame types: 1 = kDCFrame, decoded like any frame and kept before the colour transform as the DC image of a later
     // frame; 2 = kReferenceOnly: kept for patches; 3 = kSkipProgressive)
     JXH_CHECK(!fh.modular, "unsupported: Modular frames on the GPU path");
-    // (a VarDCT frame of an image that is not xyb_encoded: ColorTransform kNone or kYCbCr, 4:4:4: the same decode with the
-    // quant-matrix scales at 2 and another colour stage; chroma subsampling is refused by the header reader)
+    // (a VarDCT frame of an image that is not xyb_encoded: ColorTransform kNone or kYCbCr: the same decode with the
+    // quant-matrix scales at 2 and another colour stage; a chroma-subsampled YCbCr frame: see FrameHeader::hshift)
+    // dec_frame.cc:206-212
+    JXH_CHECK(fh.Is444() || (fh.flags & FrameHeader::kSkipDcSmoothing), "chroma subsampling is not allowed when adaptive DC smoothing is enabled");
+    JXH_CHECK(fh.Is444() || fh.frame_type != 1, "unsupported: chroma-subsampled DC frames");
     JXH_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
     for (size_t e = 0; e < ih.extra.size(); e++)
       JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
@@ -453,11 +456,36 @@ class FrameParser {
     if (!P->use_dc_frame) {
       P->dc_extra_precision[g] = uint8_t(br.Read(2));
       MImage img;
-      for (int c = 0; c < 3; c++) img.ch.emplace_back(bw, bh);
+      // (dec_modular.cc:443-452: stream channel 0 is Y, 1 is X / Cb, 2 is B / Cr; a subsampled channel is smaller)
+      const FrameHeader& fh = P->fh;
+      static const int kStreamChan[3] = {1, 0, 2};
+      for (int i = 0; i < 3; i++) img.ch.emplace_back(bw >> fh.hshift[kStreamChan[i]], bh >> fh.vshift[kStreamChan[i]]);
       ModularDecode(br, &img, int(1 + g), &P->mglobal);
       // (the channels are coded in Y, X, B order; dequantisation and chroma from luma happen on the device)
       const size_t plane = xb * d.ysize_blocks;
       const BlockCtxMap& bc = P->bctx;
+      if (!fh.Is444()) {
+        // compressed_dc.cc:232-290: every channel on its own grid, kept in the top-left part of its plane; a block's bucket
+        // from the samples that cover it
+        for (int c = 0; c < 3; c++) {
+          const MChannel& ch = img.ch[c < 2 ? c ^ 1 : c];
+          const size_t sx0 = bx0 >> fh.hshift[c], sy0 = by0 >> fh.vshift[c];
+          for (size_t y = 0; y < ch.h; y++) memcpy(&P->dc_q[plane * c + (sy0 + y) * xb + sx0], ch.Row(y), ch.w * sizeof(int32_t));
+        }
+        for (size_t y = 0; bc.num_dc_ctxs > 1 && y < bh; y++) {
+          const int32_t *qx = img.ch[1].Row(y >> fh.vshift[0]), *qy = img.ch[0].Row(y >> fh.vshift[1]), *qb = img.ch[2].Row(y >> fh.vshift[2]);
+          for (size_t x = 0; x < bw; x++) {
+            int kx = 0, ky = 0, kb = 0;
+            for (int t : bc.dc_thresholds[0]) kx += qx[x >> fh.hshift[0]] > t;
+            for (int t : bc.dc_thresholds[1]) ky += qy[x >> fh.hshift[1]] > t;
+            for (int t : bc.dc_thresholds[2]) kb += qb[x >> fh.hshift[2]] > t;
+            int b = kx;
+            b = b * int(bc.dc_thresholds[2].size() + 1) + kb;
+            b = b * int(bc.dc_thresholds[1].size() + 1) + ky;
+            quant_dc_ctx_[(by0 + y) * xb + bx0 + x] = uint8_t(b);
+          }
+        }
+      } else
       for (size_t y = 0; y < bh; y++) {
         const int32_t *qx = img.ch[1].Row(y), *qy = img.ch[0].Row(y), *qb = img.ch[2].Row(y);
         const size_t row = (by0 + y) * xb + bx0;
@@ -519,6 +547,7 @@ class FrameParser {
           used |= 1u << raw;
           size_t cx = kCoveredX[raw], cy = kCoveredY[raw];
           size_t nx = (x / 32 + 1) * 32, ny = (y / 32 + 1) * 32;
+          JXH_CHECK(cx * cy == 1 || P->fh.Is444(), "AC strategy not compatible with chroma subsampling");  // dec_modular.cc:534-538
           JXH_CHECK(x + cx <= nx && x + cx <= std::min(d.xsize_blocks, bx0 + bw), "AC strategy x overflow");
           JXH_CHECK(y + cy <= ny && y + cy <= std::min(d.ysize_blocks, by0 + bh), "AC strategy y overflow");
           for (size_t jy = 0; jy < cy; jy++)

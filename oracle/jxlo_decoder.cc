@@ -198,7 +198,10 @@ static void DecodeDcGroup(BitReader& br, FrameState* s, size_t g) {
     float mul = 1.0f / float(1 << extra_precision);
     MImage img;
     img.bitdepth = s->full.bitdepth;
-    for (int c = 0; c < 3; c++) img.ch.emplace_back(bw, bh);
+    // (dec_modular.cc:443-452: stream channel 0 is Y, 1 is X / Cb, 2 is B / Cr; a subsampled channel is smaller)
+    const FrameHeader& fh = s->fh;
+    static const int kStreamChan[3] = {1, 0, 2};
+    for (int i = 0; i < 3; i++) img.ch.emplace_back(bw >> fh.hshift[kStreamChan[i]], bh >> fh.vshift[kStreamChan[i]]);
     ModularDecode(br, &img, int(1 + g), &s->mglobal);
     // DequantDC (compressed_dc.cc:201-296)
     const float inv_global_scale = 65536.0f / float(s->global_scale);
@@ -208,6 +211,33 @@ static void DecodeDcGroup(BitReader& br, FrameState* s, size_t g) {
     const float color_scale = 1.0f / float(s->color_factor);
     const float cfl_x = s->base_corr_x + s->ytox_dc * color_scale, cfl_b = s->base_corr_b + s->ytob_dc * color_scale;
     const size_t plane = d.xsize_blocks * d.ysize_blocks;
+    if (!fh.Is444()) {
+      // compressed_dc.cc:232-250: every channel on its own grid (the top-left part of its plane), no chroma from luma;
+      // :253-290: a block's bucket from the samples that cover it
+      for (int c = 0; c < 3; c++) {
+        const MChannel& ch = img.ch[c < 2 ? c ^ 1 : c];
+        const size_t sx0 = bx0 >> fh.hshift[c], sy0 = by0 >> fh.vshift[c];
+        for (size_t y = 0; y < ch.h; y++)
+          for (size_t x = 0; x < ch.w; x++) o->dc[plane * c + (sy0 + y) * d.xsize_blocks + sx0 + x] = float(ch.Row(y)[x]) * fac[c];
+      }
+      for (size_t y = 0; y < bh; y++) {
+        const int32_t *qx = img.ch[1].Row(y >> fh.vshift[0]), *qy = img.ch[0].Row(y >> fh.vshift[1]), *qb = img.ch[2].Row(y >> fh.vshift[2]);
+        for (size_t x = 0; x < bw; x++) {
+          uint8_t bucket = 0;
+          if (s->bctx.num_dc_ctxs > 1) {
+            int bxk = 0, byk = 0, bbk = 0;
+            for (int t : s->bctx.dc_thresholds[0]) if (qx[x >> fh.hshift[0]] > t) bxk++;
+            for (int t : s->bctx.dc_thresholds[1]) if (qy[x >> fh.hshift[1]] > t) byk++;
+            for (int t : s->bctx.dc_thresholds[2]) if (qb[x >> fh.hshift[2]] > t) bbk++;
+            int b = bxk;
+            b = b * int(s->bctx.dc_thresholds[2].size() + 1) + bbk;
+            b = b * int(s->bctx.dc_thresholds[1].size() + 1) + byk;
+            bucket = uint8_t(b);
+          }
+          o->quant_dc[(by0 + y) * d.xsize_blocks + bx0 + x] = bucket;
+        }
+      }
+    } else
     for (size_t y = 0; y < bh; y++) {
       const int32_t *qx = img.ch[1].Row(y), *qy = img.ch[0].Row(y), *qb = img.ch[2].Row(y);
       for (size_t x = 0; x < bw; x++) {
@@ -268,6 +298,7 @@ static void DecodeDcGroup(BitReader& br, FrameState* s, size_t g) {
         o->used_acs |= 1u << raw;
         size_t cx = kCoveredX[raw], cy = kCoveredY[raw];
         size_t nx = (x / 32 + 1) * 32, ny = (y / 32 + 1) * 32;
+        JXLO_CHECK(cx * cy == 1 || s->fh.Is444(), "AC strategy not compatible with chroma subsampling");  // dec_modular.cc:534-538
         JXLO_CHECK(x + cx <= nx && x + cx <= std::min(d.xsize_blocks, bx0 + bw), "AC strategy x overflow");
         JXLO_CHECK(y + cy <= ny && y + cy <= std::min(d.ysize_blocks, by0 + bh), "AC strategy y overflow");
         for (size_t jy = 0; jy < cy; jy++)
@@ -390,8 +421,9 @@ static void DecodeAcGroupPass(BitReader& br, FrameState* s, size_t g, uint32_t p
   const std::vector<uint32_t>& orders = s->orders[pass];
   const uint32_t shift = s->fh.pass_shift[pass];
   size_t offset = 0;
-  for (size_t by = 0; by < bh; by++) {
-    for (size_t bx = 0; bx < bw; bx++) {
+  for (size_t fby = 0; fby < bh; fby++) {
+    for (size_t fbx = 0; fbx < bw; fbx++) {
+      const size_t bx = fbx, by = fby;
       uint8_t a = o->acs[(by0 + by) * d.xsize_blocks + bx0 + bx];
       if (!(a & 1)) continue;
       const int st = a >> 1;
@@ -403,6 +435,11 @@ static void DecodeAcGroupPass(BitReader& br, FrameState* s, size_t g, uint32_t p
       static const int kChanOrder[3] = {1, 0, 2};
       for (int ci = 0; ci < 3; ci++) {
         const int c = kChanOrder[ci];
+        // dec_group.cc:568-578, 619-631: a subsampled channel has a block only where the frame's block lands on its grid; its
+        // non-zero counts live on that grid
+        const size_t hs = s->fh.hshift[c], vs = s->fh.vshift[c];
+        const size_t bx = fbx >> hs, by = fby >> vs;
+        if ((bx << hs) != fbx || (by << vs) != fby) continue;
         int32_t* nzc = nz + c * 1024;
         const int32_t* top = by ? nzc + (by - 1) * 32 : nullptr;
         int32_t* cur = nzc + by * 32;
@@ -473,9 +510,13 @@ static void ReconstructGroup(FrameState* s, size_t g, const int32_t* coeffs) {
         block[2 * size + k] = b_cc * dy + db;
       }
       for (int c = 0; c < 3; c++) {
-        LowestFrequenciesFromDC(st, o->dc.data() + plane * c + aby * d.xsize_blocks + abx, d.xsize_blocks,
+        // dec_group.cc:176-179, 443-451: the lowest frequencies from the channel's own DC sample; pixels only for the blocks
+        // a subsampled channel has, at its own position (the top-left part of its plane)
+        const size_t hs = s->fh.hshift[c], vs = s->fh.vshift[c], sbx = abx >> hs, sby = aby >> vs;
+        LowestFrequenciesFromDC(st, o->dc.data() + plane * c + sby * d.xsize_blocks + sbx, d.xsize_blocks,
                                 block.data() + c * size);
-        TransformToPixels(st, block.data() + c * size, s->idct.p[c].data() + aby * 8 * s->idct.stride + abx * 8,
+        if ((sbx << hs) != abx || (sby << vs) != aby) continue;
+        TransformToPixels(st, block.data() + c * size, s->idct.p[c].data() + sby * 8 * s->idct.stride + sbx * 8,
                           s->idct.stride);
       }
       offset += size;
@@ -501,6 +542,9 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   JXLO_CHECK(fh.upsampling == 1 || !fh.modular, "unsupported: upsampled Modular frames");
   JXLO_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
   JXLO_CHECK(!(fh.ycbcr && fh.modular), "unsupported: YCbCr Modular frames");
+  // dec_frame.cc:206-212
+  JXLO_CHECK(fh.Is444() || (fh.flags & FrameHeader::kSkipDcSmoothing), "chroma subsampling is not allowed when adaptive DC smoothing is enabled");
+  JXLO_CHECK(fh.Is444() || fh.frame_type != 1, "unsupported: chroma-subsampled DC frames");
   JXLO_CHECK(!(fh.modular && ih.xyb_encoded && ih.gray), "unsupported: grey XYB Modular frames");
   s->dim = MakeFrameDim(fh);
   const FrameDim& d = s->dim;
@@ -635,6 +679,11 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       }
     }
     if (!group_error.empty()) throw Error(group_error);
+    if (!fh.Is444()) {
+      // dec_cache.cc:138-150: per channel the horizontal, then the vertical chroma upsampling, in front of every other stage
+      // (the dump below then holds what the filters read)
+      for (int c = 0; c < 3; c++) ChromaUpsample(&s->idct.p[c], s->idct.stride, d.xsize, d.ysize, d.ysize_padded, fh.hshift[c] != 0, fh.vshift[c] != 0);
+    }
     if (want_dumps) {
       out->xyb_idct.resize(3 * d.xsize_padded * d.ysize_padded);
       for (int c = 0; c < 3; c++)

@@ -281,6 +281,24 @@ struct FrameHeader {
   bool modular = false;
   uint64_t flags = 0;
   bool ycbcr = false;
+  // YCbCrChromaSubsampling (frame_header.h:81-166, frame_header.cc:30-31): channel_mode per channel (Cb, Y, Cr) picks the
+  // samples per MCU side {1x1, 2x2, 2x1, 1x2}; a channel's shift is the largest log2 factor minus its own
+  uint32_t cs_mode[3] = {0, 0, 0};
+  uint32_t hshift[3] = {0, 0, 0}, vshift[3] = {0, 0, 0}, max_hshift = 0, max_vshift = 0;
+  bool Is444() const { return !max_hshift && !max_vshift; }
+  void SetChannelModes(uint32_t m0, uint32_t m1, uint32_t m2) {
+    static const uint32_t kH[4] = {0, 1, 1, 0}, kV[4] = {0, 1, 0, 1};
+    cs_mode[0] = m0; cs_mode[1] = m1; cs_mode[2] = m2;
+    max_hshift = max_vshift = 0;
+    for (uint32_t m : cs_mode) {
+      if (kH[m] > max_hshift) max_hshift = kH[m];
+      if (kV[m] > max_vshift) max_vshift = kV[m];
+    }
+    for (int c = 0; c < 3; c++) {
+      hshift[c] = max_hshift - kH[cs_mode[c]];
+      vshift[c] = max_vshift - kV[cs_mode[c]];
+    }
+  }
   uint32_t upsampling = 1;
   std::vector<uint32_t> ec_upsampling;
   uint32_t group_size_shift = 1;
@@ -364,7 +382,7 @@ static inline void ReadFrameHeader(BitReader& br, const ImageHeader& ih, FrameHe
   if (f->ycbcr && !use_dc_frame) {
     // YCbCrChromaSubsampling: 3 x 2 bits
     uint32_t m0 = uint32_t(br.Read(2)), m1 = uint32_t(br.Read(2)), m2 = uint32_t(br.Read(2));
-    JXLO_CHECK(m0 == 0 && m1 == 0 && m2 == 0, "unsupported: chroma subsampling");
+    f->SetChannelModes(m0, m1, m2);
   }
   if (!use_dc_frame) {
     f->upsampling = ReadU32(br, Val(1), Val(2), Val(4), Val(8));
@@ -459,8 +477,9 @@ static inline FrameDim MakeFrameDim(const FrameHeader& f) {
   d.dc_group_dim = d.group_dim * 8;
   d.xsize = DivCeil(f.xsize, f.upsampling);
   d.ysize = DivCeil(f.ysize, f.upsampling);
-  d.xsize_blocks = DivCeil(d.xsize, 8);
-  d.ysize_blocks = DivCeil(d.ysize, 8);
+  // (frame_dimensions.h:43-44: whole MCUs of a subsampled frame)
+  d.xsize_blocks = DivCeil(d.xsize, size_t(8) << f.max_hshift) << f.max_hshift;
+  d.ysize_blocks = DivCeil(d.ysize, size_t(8) << f.max_vshift) << f.max_vshift;
   d.xsize_padded = f.modular ? d.xsize : d.xsize_blocks * 8;
   d.ysize_padded = f.modular ? d.ysize : d.ysize_blocks * 8;
   d.xsize_groups = DivCeil(d.xsize, d.group_dim);

@@ -40,6 +40,46 @@ struct Planes3 {
   float At(int c, int64_t x, int64_t y) const { return p[c][size_t(Mirror(y, ys)) * stride + size_t(Mirror(x, xs))]; }
 };
 
+// Chroma upsampling of one channel of a subsampled YCbCr frame, in place (render_pipeline/stage_chroma_upsampling.cc:29-111;
+// dec_cache.cc:138-150: horizontally first, then vertically). The subsampled samples sit in the top-left part of the plane:
+// ceil(xsize / 2) columns / ceil(ysize / 2) rows of them belong to the image, and the stage mirrors about that size
+// (low_memory_render_pipeline.cc:348-355, 668-683); each sample becomes two: 3/4 of itself + 1/4 of the neighbour on that
+// side, as one multiply and one fused multiply-add like the reference's Mul / MulAdd.
+static inline void ChromaUpsample(std::vector<float>* plane, size_t stride, size_t xsize, size_t ysize, size_t rows, bool horizontal,
+                                  bool vertical) {
+  std::vector<float>& p = *plane;
+  const size_t in_rows = vertical ? (ysize + 1) / 2 : ysize;
+  if (horizontal) {
+    const int64_t ws = int64_t((xsize + 1) / 2);
+    std::vector<float> row(static_cast<size_t>(ws), 0.0f);
+    for (size_t y = 0; y < in_rows; y++) {
+      float* r = p.data() + y * stride;
+      memcpy(row.data(), r, size_t(ws) * sizeof(float));
+      for (int64_t x = 0; x < ws; x++) {
+        const float cur = row[size_t(x)] * 0.75f;
+        r[2 * x] = std::fma(0.25f, row[size_t(Mirror(x - 1, ws))], cur);
+        r[2 * x + 1] = std::fma(0.25f, row[size_t(Mirror(x + 1, ws))], cur);
+      }
+    }
+  }
+  if (vertical) {
+    const int64_t hh = int64_t(in_rows);
+    const size_t w = std::min(stride, 2 * ((xsize + 1) / 2));
+    std::vector<float> src(size_t(hh) * w);
+    for (int64_t y = 0; y < hh; y++) memcpy(src.data() + size_t(y) * w, p.data() + size_t(y) * stride, w * sizeof(float));
+    for (int64_t y = 0; y < hh && size_t(2 * y + 1) < rows; y++) {
+      const float *top = src.data() + size_t(Mirror(y - 1, hh)) * w, *mid = src.data() + size_t(y) * w,
+                  *bot = src.data() + size_t(Mirror(y + 1, hh)) * w;
+      float *o0 = p.data() + size_t(2 * y) * stride, *o1 = o0 + stride;
+      for (size_t x = 0; x < w; x++) {
+        const float m = mid[x] * 0.75f;
+        o0[x] = std::fma(top[x], 0.25f, m);
+        o1[x] = std::fma(bot[x], 0.25f, m);
+      }
+    }
+  }
+}
+
 static inline void Gaborish(const Planes3& in, const LoopFilter& lf, Planes3* out) {
   out->Alloc(in.xs, in.ys, in.stride);
   for (int c = 0; c < 3; c++) {

@@ -88,6 +88,24 @@ def test_noise_frame_through_the_decoder_api(built, tmp_path):
     assert np.abs(np.frombuffer(px, np.float32).reshape(270, 300, 3) - ref_f).max() < 5e-5
 
 
+@pytest.mark.parametrize("cs", [4, 8, 12])
+def test_chroma_subsampled_ycbcr_frames_through_the_decoder_api(built, tmp_path, cs):
+    """What a recompressed 4:2:0 / 4:2:2 / 4:4:0 JPEG holds (YCbCr frame, subsampled chroma, RAW quantisation table, no loop
+    filter) through JxlDecoder, at sizes that are not whole MCUs: pixels equal to the oracle's."""
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(333, 277, seed=9), color_transform=2, chroma_subsampling=cs, strategy_mode=0, raw_quant=1, gab=0,
+                         epf_iters=0)
+    ref_f, ref_8 = _oracle_float(jxlo, data)
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3)
+    assert rc == 0 and events[-2:] == ["FULL_IMAGE", "SUCCESS"], out
+    got = np.frombuffer(px, np.uint8).reshape(277, 333, 3)
+    assert np.abs(got.astype(int) - ref_8.astype(int)).max() <= 1
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.float32).reshape(277, 333, 3) - ref_f).max() < 5e-5
+
+
 def test_images_with_an_embedded_icc_profile(built, tmp_path):
     """Streams whose original colours are described by an ICC profile (want_icc): the profile - here the reference's own
     test vector, lib/jxl/icc_codec_test.cc:52-211 - comes back through JxlDecoderGetICCProfileSize /

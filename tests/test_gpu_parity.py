@@ -22,7 +22,7 @@ def _used_mask(o):
     return used
 
 
-def _compare(J, jxlo, data, check_rgb=True):
+def _compare(J, jxlo, data, check_rgb=True, crop_idct=False):
     f = J.Frame(data, threads=2)
     o = jxlo.Decoded(data)
     c = J.HipContext()
@@ -41,10 +41,13 @@ def _compare(J, jxlo, data, check_rgb=True):
         c.run_transform()
         c.sync()
         x = c.download("xyb_idct")
-        assert np.abs(x - o.planes("xyb_idct")).max() < 2e-5
+        ys, xs = o.info["ysize"], o.info["xsize"]
+        if crop_idct:  # (chroma-subsampled frames: the padding beyond the frame is not specified once the channels are upsampled)
+            assert np.abs(x[:, :ys, :xs] - o.planes("xyb_idct")[:, :ys, :xs]).max() < 2e-5
+        else:
+            assert np.abs(x - o.planes("xyb_idct")).max() < 2e-5
         c.run_filter_color()
         c.sync()
-        ys, xs = o.info["ysize"], o.info["xsize"]
         xf = c.download("xyb_filtered")[:, :ys, :xs]
         assert np.abs(xf - o.planes("xyb_filtered")[:, :, :xs]).max() < 2e-5
         rgb = c.rgb8()
@@ -96,6 +99,80 @@ def test_image_streams(built, size, kw):
     import jxlo
     J = built
     _compare(J, jxlo, J.encode_rgb8(J.synth_image(size[0], size[1], seed=size[0]), **kw))
+
+
+CS420, CS422, CS440 = 4, 8, 12  # channel modes of Cb, Y, Cr (frame_header.h:81-166): Y at 2x2 / 2x1 / 1x2 samples per MCU
+
+
+@pytest.mark.parametrize("size,kw", [
+    ((520, 300), dict(chroma_subsampling=CS420)),                          # what a recompressed 4:2:0 JPEG's frame looks like
+    ((520, 300), dict(chroma_subsampling=CS422)),
+    ((520, 300), dict(chroma_subsampling=CS440, distance=2.0)),
+    ((257, 255), dict(chroma_subsampling=CS420)),                          # odd sizes: half-MCU edges, ragged groups
+    ((17, 9), dict(chroma_subsampling=CS420)),
+    ((8, 8), dict(chroma_subsampling=CS420)),                              # one MCU: 2 x 2 blocks for one block of image
+    ((1, 1), dict(chroma_subsampling=CS422)),
+    ((777, 513), dict(chroma_subsampling=CS420, distance=4.5, gab=0)),     # every EPF stage behind the upsampled channels
+    ((600, 400), dict(chroma_subsampling=CS420, epf_iters=0, gab=0, raw_quant=1)),  # no filters, RAW table: the JPEG case
+    ((600, 400), dict(chroma_subsampling=CS420, random_cmap=1)),           # chroma from luma still applies to AC (dec_group.cc:432-441)
+    ((700, 520), dict(chroma_subsampling=CS420, custom_bctx=1)),           # DC thresholds read the subsampled DC (compressed_dc.cc:253-290)
+    ((1000, 700), dict(chroma_subsampling=CS422, num_histograms=3, custom_orders=1)),
+    ((520, 300), dict(chroma_subsampling=CS420, num_passes=2)),
+    ((600, 400), dict(chroma_subsampling=CS420, upsampling=2)),            # ... and the frame upsampled behind them
+    ((600, 400), dict(chroma_subsampling=CS420, noise=60)),
+    ((520, 300), dict(chroma_subsampling=1)),                              # legal oddities: Cb at twice the resolution of Y and Cr
+    ((520, 300), dict(chroma_subsampling=0b100100)),                       # Cb full, Y and Cr subsampled 2x1
+    ((520, 300), dict(chroma_subsampling=0b011011)),                       # Cb 1x2, Y 2x1, Cr 2x2: every shift pair occurs
+])
+def test_chroma_subsampled_frames(built, size, kw):
+    """YCbCr frames with subsampled channels (frame_header.h:81-166; dec_group.cc:568-578: a channel's blocks ride on the
+    varblocks that lie on its grid; compressed_dc.cc:232-250: DC without chroma from luma; stage_chroma_upsampling.cc: the
+    channels back at full resolution in front of the filters): coefficients bit for bit, planes and pixels at the usual bars."""
+    import jxlo
+    J = built
+    _compare(J, jxlo, J.encode_rgb8(J.synth_image(size[0], size[1], seed=size[0]), color_transform=2, strategy_mode=0, **kw), crop_idct=True)
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (1, dict(chroma_subsampling=CS420)),
+    (2, dict(chroma_subsampling=CS422, custom_bctx=1, custom_orders=1)),
+    (3, dict(chroma_subsampling=CS440, custom_cmap=1, custom_lf=1, epf_iters=3)),
+    (4, dict(chroma_subsampling=CS420, ac_code_mode=1)),      # prefix codes: the lane kernel's other symbol reader
+    (5, dict(chroma_subsampling=CS420, ac_code_mode=2)),      # LZ77: the one-lane-per-section kernel
+    (6, dict(chroma_subsampling=CS420, ac_code_mode=3)),
+    (7, dict(chroma_subsampling=CS420, max_clusters=128)),    # alias tables read in place from global memory
+    (8, dict(chroma_subsampling=CS420, num_passes=2, num_histograms=2)),
+])
+def test_chroma_subsampled_random_streams(built, seed, kw):
+    """Random streams over every transform a subsampled frame may use (the ten that cover one block: dec_modular.cc:534-538),
+    random chroma-from-luma maps, sharpness and quantisation fields."""
+    import jxlo
+    J = built
+    _compare(J, jxlo, J.encode_random(777, 600, seed=seed, color_transform=2, **kw), crop_idct=True)
+
+
+@pytest.mark.parametrize("choice", ["1", "0"])
+def test_chroma_subsampled_frames_through_the_fallback_entropy_kernels(built, choice):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, libjxl_amd as J, jxlo\n"
+        "for data in (J.encode_random(520, 300, seed=6, color_transform=2, chroma_subsampling=4),\n"
+        "             J.encode_rgb8(J.synth_image(600, 400, seed=9), color_transform=2, chroma_subsampling=8, strategy_mode=0)):\n"
+        "    o = jxlo.Decoded(data)\n"
+        "    f = J.Frame(data); c = J.HipContext(); c.upload(f); c.run_entropy(); c.sync()\n"
+        "    r, flags = c.errors(); assert r == 0\n"
+        "    c.run_transform(); c.run_filter_color()\n"
+        "    d = np.abs(c.rgb8().astype(int) - o.rgb8.astype(int)); assert d.max() <= 1, d.max()\n"
+        "    xs, ys = o.info['xsize'], o.info['ysize']\n"
+        "    x = c.download('xyb_idct'); assert np.abs(x[:, :ys, :xs] - o.planes('xyb_idct')[:, :ys, :xs]).max() < 2e-5\n"
+        "    c.close(); f.close(); o.close()\n"
+        "print('ok')\n") % (root, os.path.join(root, "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, JXLHIP_ENTROPY=choice))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("strategy", list(range(27)))
@@ -435,7 +512,7 @@ def test_batched_entropy_launch(built):
             f.close()
 
 
-@pytest.mark.parametrize("kind", ["image", "random_epf3"])
+@pytest.mark.parametrize("kind", ["image", "random_epf3", "chroma_420"])
 def test_band_decode_matches_whole_frame(built, kind):
     """One frame split into bands of group rows (the multi-GPU split of a large frame, here on one device): every band
     context produces exactly the rows of the whole-frame decode, with no data exchanged between the contexts."""
@@ -443,6 +520,8 @@ def test_band_decode_matches_whole_frame(built, kind):
     J = built
     if kind == "image":
         data = J.encode_rgb8(J.synth_image(1000, 1300, seed=11), distance=2.0)  # gab + EPF1 + EPF2: 4 rows of halo
+    elif kind == "chroma_420":  # the vertical chroma upsampling reads one more (subsampled) row either side
+        data = J.encode_rgb8(J.synth_image(700, 1100, seed=13), distance=2.0, color_transform=2, chroma_subsampling=4, strategy_mode=0)
     else:
         data = J.encode_random(700, 1100, seed=12, epf_iters=3)                 # all strategies, 7 rows of halo
     f = J.Frame(data, threads=2)

@@ -75,7 +75,9 @@ def test_streams_with_an_embedded_icc_profile_parse(built):
 def test_frame_plan_matches_oracle(built):
     import jxlo
     J = built
-    for kw in [dict(), dict(strategy_mode=0, distance=2.0), dict(strategy_mode=2, random_cmap=1)]:
+    for kw in [dict(), dict(strategy_mode=0, distance=2.0), dict(strategy_mode=2, random_cmap=1),
+               dict(color_transform=2, chroma_subsampling=4, strategy_mode=0, custom_bctx=1),   # 4:2:0: whole MCUs, subsampled DC streams
+               dict(color_transform=2, chroma_subsampling=0b011011, strategy_mode=0)]:
         data = J.encode_rgb8(J.synth_image(600, 410, seed=9), **kw)
         f = J.Frame(data, threads=2)
         o = jxlo.Decoded(data, dumps=False)
