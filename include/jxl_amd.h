@@ -85,6 +85,13 @@ int jxlamd_frame_finish_extra(JxlAmdFrame* frame, JxlHipContext* ctx);
 /* The same with the groups' Modular streams spread over the caller's runner (NULL: serial). */
 int jxlamd_frame_finish_extra_mt(JxlAmdFrame* frame, JxlHipContext* ctx, JxlParallelRunner runner, void* runner_opaque);
 const int32_t* jxlamd_frame_extra_plane(const JxlAmdFrame* frame, uint32_t index);
+/* An extra channel carries an upsampling factor of its own (frame_header.cc:265-283; dec_modular.cc:262-271): whu[0], whu[1] =
+ * the size jxlamd_frame_extra_plane() has, ceil(image / factor); whu[2] = the factor (1, 2, 4, 8). jxlhip_upsample_plane
+ * makes the image-sized plane of a factor > 1. Returns 0, or 1 for a bad argument. */
+int jxlamd_frame_extra_dims(const JxlAmdFrame* frame, uint32_t index, uint32_t* whu);
+/* The factor * factor 5x5 upsampling kernels of the image (its coded weights or the default ones: image_metadata.cc:87-214,
+ * stage_upsampling.cc:59-84), factor * factor * 25 floats in JxlHipFrameDesc::upsampling_kernel's layout. */
+int jxlamd_upsampling_kernels(const JxlAmdFrame* frame, uint32_t factor, float* kernels);
 /* ---- Modular (lossless) frames: host parse into the plan the device decodes (csrc/host/jxh_modframe.h) ---- */
 typedef struct JxlAmdModFrame JxlAmdModFrame;
 /* Parses the first frame of a codestream as a Modular frame: headers, TOC, global tree and histograms and every stream's

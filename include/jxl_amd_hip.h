@@ -251,6 +251,13 @@ int jxlhip_set_output_orientation(JxlHipContext* ctx, uint32_t orientation);
 /* Alpha plane of the image (f32 in [0, 1], xsize * ysize, host memory; copied synchronously) for 2- and 4-channel output;
  * NULL = opaque again. */
 int jxlhip_set_alpha(JxlHipContext* ctx, const float* alpha, uint32_t xsize, uint32_t ysize);
+/* An extra channel that is coded smaller than the image (JxlHipFrameDesc-independent; dec_cache.cc:172-190, 203-212: the
+ * upsampling stage, stage_upsampling.cc:49-282, on that one channel): `plane` = xsize * ysize floats in host memory, `kernels`
+ * = factor * factor * 25 weights (factor 2, 4 or 8), the result out_xsize x out_ysize with out in (factor * (size - 1),
+ * factor * size]. as_alpha != 0: the result becomes the context's alpha plane (as after jxlhip_set_alpha); host_out != NULL:
+ * it is copied there (out_xsize * out_ysize floats). Synchronous. */
+int jxlhip_upsample_plane(JxlHipContext* ctx, const float* plane, uint32_t xsize, uint32_t ysize, uint32_t factor, const float* kernels,
+                          uint32_t out_xsize, uint32_t out_ysize, int as_alpha, float* host_out);
 /* Copies the interleaved result in the format of jxlhip_set_output_format (row stride in bytes); synchronous. */
 int jxlhip_download_pixels(JxlHipContext* ctx, void* dst, size_t stride);
 /* Same for pixel rows [y_begin, y_end) only (dst receives y_end - y_begin rows): the rows a band context produced. */

@@ -439,7 +439,7 @@ class EncParams(ctypes.Structure):
                 ("zero_ac", ctypes.c_int32), ("num_histograms", ctypes.c_int32), ("big_coeffs", ctypes.c_int32), ("num_passes", ctypes.c_int32), ("upsampling", ctypes.c_int32), ("custom_orders", ctypes.c_int32), ("custom_bctx", ctypes.c_int32),
                 ("custom_cmap", ctypes.c_int32), ("custom_lf", ctypes.c_int32), ("ac_code_mode", ctypes.c_int32),
                 ("noise", ctypes.c_int32), ("cfl_fit", ctypes.c_int32), ("color_transform", ctypes.c_int32), ("raw_quant", ctypes.c_int32),
-                ("chroma_subsampling", ctypes.c_int32)]
+                ("chroma_subsampling", ctypes.c_int32), ("ec_upsampling", ctypes.c_int32)]
 
 
 def _enc_lib():

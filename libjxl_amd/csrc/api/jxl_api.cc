@@ -666,8 +666,26 @@ int jxlamd_frame_finish_extra_mt(JxlAmdFrame* f, JxlHipContext* ctx, JxlParallel
 const int32_t* jxlamd_frame_extra_plane(const JxlAmdFrame* f, uint32_t index) {
   if (!f || f->plan.extra_pending || index >= f->plan.extra.ch.size()) return nullptr;
   const jxh::MChannel& c = f->plan.extra.ch[index];
-  if (c.w != f->plan.dim.xsize || c.h != f->plan.dim.ysize) return nullptr;
+  uint32_t whu[3];
+  jxlamd_frame_extra_dims(f, index, whu);
+  if (c.w != whu[0] || c.h != whu[1]) return nullptr;
   return c.d.data();
+}
+int jxlamd_frame_extra_dims(const JxlAmdFrame* f, uint32_t index, uint32_t* whu) {
+  if (!f || !whu || index >= f->plan.ih.extra.size()) return 1;
+  const jxh::FramePlan& P = f->plan;
+  const uint32_t ups = P.fh.ec_upsampling.empty() ? 1 : P.fh.ec_upsampling[index];
+  whu[0] = uint32_t((size_t(P.fh.xsize) + ups - 1) / ups);
+  whu[1] = uint32_t((size_t(P.fh.ysize) + ups - 1) / ups);
+  whu[2] = ups;
+  return 0;
+}
+int jxlamd_upsampling_kernels(const JxlAmdFrame* f, uint32_t factor, float* kernels) {
+  if (!f || !kernels || (factor != 2 && factor != 4 && factor != 8)) return 1;
+  std::vector<float> k;
+  UpsamplingKernels(factor, f->plan.ih, &k);
+  memcpy(kernels, k.data(), k.size() * sizeof(float));
+  return 0;
 }
 }  // extern "C"
 
@@ -1208,14 +1226,34 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
   uint32_t out_wh[2];
   jxlamd_frame_out_size(d->frame, out_wh);
   size_t xs = out_wh[0], ys = out_wh[1];
+  // An extra channel as floats in [0, 1] at the size it is coded in, and - for a channel with an upsampling factor
+  // (frame_header.cc:265-283) - through the upsampling stage on the device (dec_cache.cc:172-190, 203-212), as the alpha plane
+  // of the context or back to the host.
+  const size_t img_xs = xs, img_ys = ys;  // (xs / ys are swapped below for a transposing orientation)
+  auto extra_floats = [&, img_xs, img_ys](uint32_t ec, bool as_alpha, std::vector<float>* host) -> const char* {
+    const size_t xs = img_xs, ys = img_ys;
+    const int32_t* a = jxlamd_frame_extra_plane(d->frame, ec);
+    uint32_t whu[3];
+    if (!a || jxlamd_frame_extra_dims(d->frame, ec, whu)) return "extra channel unavailable";
+    const size_t n = size_t(whu[0]) * whu[1];
+    std::vector<float> af(n);
+    const float inv = 1.0f / float((uint64_t(1) << d->ih.extra[ec].bits) - 1);
+    for (size_t i = 0; i < n; i++) af[i] = float(a[i]) * inv;
+    if (whu[2] == 1) {
+      if (as_alpha && jxlhip_set_alpha(d->ctx, af.data(), uint32_t(xs), uint32_t(ys))) return "jxlhip_set_alpha failed";
+      if (host) host->swap(af);
+      return nullptr;
+    }
+    std::vector<float> kernels(size_t(whu[2]) * whu[2] * 25);
+    if (jxlamd_upsampling_kernels(d->frame, whu[2], kernels.data())) return "upsampling kernels unavailable";
+    if (host) host->resize(xs * ys);
+    if (jxlhip_upsample_plane(d->ctx, af.data(), whu[0], whu[1], whu[2], kernels.data(), uint32_t(xs), uint32_t(ys), as_alpha ? 1 : 0,
+                              host ? host->data() : nullptr))
+      return "jxlhip_upsample_plane failed";
+    return nullptr;
+  };
   if (want_alpha) {
-    const int32_t* a = jxlamd_frame_extra_plane(d->frame, uint32_t(alpha_ec));
-    if (!a) return Fail(d, "alpha channel unavailable");
-    std::vector<float> af(xs * ys);
-    const float inv = 1.0f / float((uint64_t(1) << d->ih.extra[alpha_ec].bits) - 1);
-    for (size_t i = 0; i < xs * ys; i++) af[i] = float(a[i]) * inv;
-    r = jxlhip_set_alpha(d->ctx, af.data(), uint32_t(xs), uint32_t(ys));
-    if (r) return Fail(d, "jxlhip_set_alpha failed");
+    if (const char* e = extra_floats(uint32_t(alpha_ec), true, nullptr)) return Fail(d, e);
   }
   r = jxlhip_run_transform(d->ctx);
   if (!r) r = jxlhip_run_filter_color(d->ctx);
@@ -1226,6 +1264,17 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
   for (const auto& eo : d->extra_out) {
     const int32_t* p = jxlamd_frame_extra_plane(d->frame, eo.first);
     if (!p) return Fail(d, "extra channel unavailable");
+    std::vector<int32_t> upsampled;
+    uint32_t whu[3] = {0, 0, 1};
+    jxlamd_frame_extra_dims(d->frame, eo.first, whu);
+    if (whu[2] != 1) {  // the upsampled channel back as integers of its bit depth (what the rows below are converted from)
+      std::vector<float> f;
+      if (const char* e = extra_floats(eo.first, false, &f)) return Fail(d, e);
+      const float maxv = float((uint64_t(1) << d->ih.extra[eo.first].bits) - 1);
+      upsampled.resize(f.size());
+      for (size_t i = 0; i < f.size(); i++) upsampled[i] = int32_t(std::lrint(std::min(1.0f, std::max(0.0f, f[i])) * maxv));
+      p = upsampled.data();
+    }
     std::vector<int32_t> oriented;
     if (orientation != 1) {
       oriented = OrientPlane(p, coded_xs, coded_ys, orientation);

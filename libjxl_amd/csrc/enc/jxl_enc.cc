@@ -779,6 +779,11 @@ struct FrameModel {
   uint64_t flags;
   size_t img_xs = 0, img_ys = 0;  // image size when the frame is coded downsampled (upsampling > 1)
   std::vector<uint8_t> alpha;     // optional 8-bit alpha plane (xs * ys): one Modular-coded extra channel (dec_frame.cc:511-542)
+  // ... or, with an extra-channel upsampling factor `alpha_ups` (1, 2, 4, 8; at least the frame's own: frame_header.cc:272-283),
+  // alpha_w x alpha_h = ceil(image / alpha_ups) samples: the channel's shift against the frame is log2(alpha_ups / upsampling)
+  // (dec_modular.cc:262-271)
+  size_t alpha_w = 0, alpha_h = 0;
+  uint32_t alpha_ups = 1, alpha_shift = 0;
   // YCbCr chroma subsampling (frame_header.h:81-166): channel_mode per channel (0 = 1x1, 1 = 2x2, 2 = 2x1, 3 = 1x2 samples per
   // MCU), and the shifts that follow from it: channel c has (xb >> hs[c]) x (yb >> vs[c]) blocks; its block at (sx, sy) is
   // coded with the frame's block (sx << hs, sy << vs); its DC sits in the top-left part of dc[c] (row stride xb)
@@ -1139,6 +1144,8 @@ struct Params {
   int32_t chroma_subsampling;  // YCbCr frames (color_transform 2) only: channel_mode of Cb, Y, Cr in bits 0-1, 2-3, 4-5
                            //     (frame_header.h:81-166; 0 = one sample per MCU side, 1 = 2x2, 2 = 2x1, 3 = 1x2): 4:2:0 = 0b000100 = 4,
                            //     4:2:2 = 8, 4:4:0 = 12. Only transforms that cover one block; no adaptive DC smoothing.
+  int32_t ec_upsampling;   // jxlenc_encode_rgba8: the alpha channel is coded at ceil(size / this) (0/1, 2, 4, 8; at least `upsampling`,
+                           //     at most four times it) and flagged for upsampling (frame_header.cc:265-283)
 };
 
 static bool Fits(const FrameModel& f, size_t bx, size_t by, int st) {
@@ -1217,18 +1224,26 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   // alpha: channel 0 of the frame's global Modular image. Up to a group in size it is coded whole in stream 0 (DC global),
   // else one rectangle per AC group section, behind the coefficients (stream ids: dec_modular.h:44-67).
   const bool have_alpha = !f.alpha.empty();
-  const bool alpha_global = have_alpha && f.xs <= 256 && f.ys <= 256;
+  const size_t aw = have_alpha ? (f.alpha_w ? f.alpha_w : f.xs) : 0, ah = have_alpha ? (f.alpha_h ? f.alpha_h : f.ys) : 0;
+  const uint32_t ash = f.alpha_shift;
+  if (have_alpha && (f.alpha.size() != aw * ah || ash > 2)) throw std::runtime_error("alpha plane: size / shift");
+  const bool alpha_global = have_alpha && aw <= 256 && ah <= 256;
   std::vector<Token> alpha_global_tokens;
   std::vector<std::vector<Token>> alpha_group_tokens(have_alpha && !alpha_global ? num_groups : 0);
+  std::vector<uint8_t> alpha_group_present(alpha_group_tokens.size(), 0);  // (a group the shifted channel does not reach codes nothing)
   if (alpha_global) {
     std::vector<int32_t> px(f.alpha.begin(), f.alpha.end());
-    ModularTokens(tree, px.data(), f.xs, f.ys, 0, 0, &alpha_global_tokens);
+    ModularTokens(tree, px.data(), aw, ah, 0, 0, &alpha_global_tokens);
   }
   for (size_t g = 0; g < alpha_group_tokens.size(); g++) {
-    const size_t x0 = (g % xg) * 256, y0 = (g / xg) * 256, w = std::min<size_t>(256, f.xs - x0), h = std::min<size_t>(256, f.ys - y0);
+    // the group's rectangle of the channel (dec_modular.cc:343-368: the frame rectangle shifted by the channel's shift)
+    const size_t x0 = ((g % xg) * 256) >> ash, y0 = ((g / xg) * 256) >> ash;
+    if (x0 >= aw || y0 >= ah) continue;
+    const size_t w = std::min<size_t>(256 >> ash, aw - x0), h = std::min<size_t>(256 >> ash, ah - y0);
+    alpha_group_present[g] = 1;
     std::vector<int32_t> px(w * h);
     for (size_t y = 0; y < h; y++)
-      for (size_t x = 0; x < w; x++) px[y * w + x] = f.alpha[(y0 + y) * f.xs + x0 + x];
+      for (size_t x = 0; x < w; x++) px[y * w + x] = f.alpha[(y0 + y) * aw + x0 + x];
     const size_t last_pass = (p.num_passes == 2 ? 2 : 1) - 1;
     ModularTokens(tree, px.data(), w, h, 0, int(1 + 3 * ndc + 17 + num_groups * last_pass + g), &alpha_group_tokens[g]);
   }
@@ -1517,7 +1532,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     const size_t g = pg % num_groups;
     bw.Write(CeilLog2(num_hist), uint32_t(g % num_hist));  // histogram selector (dec_group.cc:594-610)
     WriteTokens(bw, ac_tokens[pg].data(), ac_tokens[pg].size(), ac_codes[pg / num_groups]);
-    if (!alpha_group_tokens.empty() && pg / num_groups == num_passes - 1) {  // Modular data of the group, behind the coefficients
+    if (!alpha_group_tokens.empty() && alpha_group_present[g] && pg / num_groups == num_passes - 1) {  // Modular data of the group, behind the coefficients
       write_group_header(bw);
       WriteTokens(bw, alpha_group_tokens[g].data(), alpha_group_tokens[g].size(), mod_code);
     }
@@ -1633,7 +1648,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   }
   if (!g_use_dc_frame) {  // (frame_header.cc:263: no upsampling fields with kUseDcFrame)
     bw.Write(2, ups == 1 ? 0 : (ups == 2 ? 1 : (ups == 4 ? 2 : 3)));  // upsampling factor
-    if (have_alpha) bw.Write(2, 0);  // extra channel upsampling 1
+    if (have_alpha) bw.Write(2, f.alpha_ups == 8 ? 3 : (f.alpha_ups == 4 ? 2 : (f.alpha_ups == 2 ? 1 : 0)));  // extra channel upsampling
   }
   if (!p.color_transform) {  // (frame_header.cc:287-291: an image that is not xyb_encoded has both at 2)
     bw.Write(3, p.custom_cmap ? 2 : 3);  // x_qm_scale
@@ -1735,12 +1750,22 @@ static double NowSeconds() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// (jxlenc_encode_rgba8 -> EncodeImage: width, height, upsampling factor and shift of a subsampled alpha plane; 0 = frame sized)
+static thread_local uint32_t g_alpha_dims[4] = {0, 0, 0, 0};
 // model_only: stop before the bitstream assembly and hand the frame model out (the CPU form of the forward path).
 static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& p, std::vector<uint8_t>* out, size_t img_xs = 0,
                         size_t img_ys = 0, const std::vector<uint8_t>* alpha = nullptr, ForwardHook* hook = nullptr,
                         FrameModel* model_only = nullptr) {
   FrameModel f;
-  if (alpha) f.alpha = *alpha;
+  if (alpha) {
+    f.alpha = *alpha;
+    if (g_alpha_dims[0]) {
+      f.alpha_w = g_alpha_dims[0];
+      f.alpha_h = g_alpha_dims[1];
+      f.alpha_ups = g_alpha_dims[2];
+      f.alpha_shift = g_alpha_dims[3];
+    }
+  }
   f.SetSubsampling(p.color_transform == 2 ? uint32_t(p.chroma_subsampling) : 0u);
   f.SetSize(xs, ys);
   if (hook && f.Subsampled()) throw std::runtime_error("forward hook: unsupported parameters");
@@ -2730,6 +2755,7 @@ struct JxlEncParams {
   int32_t color_transform; // 0 = XYB, 1 = none, 2 = YCbCr, see jxe::Params
   int32_t raw_quant;       // 1 = RAW dequantisation table for the 8x8 DCT, see jxe::Params
   int32_t chroma_subsampling;  // YCbCr frames: channel modes of Cb, Y, Cr (4 = 4:2:0, 8 = 4:2:2, 12 = 4:4:0), see jxe::Params
+  int32_t ec_upsampling;   // jxlenc_encode_rgba8: upsampling factor of the alpha channel, see jxe::Params
 };
 
 // The next VarDCT streams code their own upsampling weights (mask bit k: the 2^(k+1)-fold matrix; 0: default weights again).
@@ -2935,18 +2961,43 @@ int jxlenc_encode_rgba8(const uint8_t* rgba, uint32_t xs, uint32_t ys, const Jxl
   if (!rgba || !xs || !ys || !p || p->distance <= 0) return -1;
   jxe::Params q;
   memcpy(&q, p, sizeof(q));
-  if (q.upsampling > 1) return -1;
-  std::vector<uint8_t> rgb(size_t(xs) * ys * 3), alpha(size_t(xs) * ys);
-  for (size_t i = 0; i < size_t(xs) * ys; i++) {
-    rgb[i * 3] = rgba[i * 4];
-    rgb[i * 3 + 1] = rgba[i * 4 + 1];
-    rgb[i * 3 + 2] = rgba[i * 4 + 2];
-    alpha[i] = rgba[i * 4 + 3];
-  }
+  const uint32_t ups = (q.upsampling == 2 || q.upsampling == 4 || q.upsampling == 8) ? uint32_t(q.upsampling) : 1;
+  uint32_t ecu = (q.ec_upsampling == 2 || q.ec_upsampling == 4 || q.ec_upsampling == 8) ? uint32_t(q.ec_upsampling) : 1;
+  if (ecu < ups) ecu = ups;
+  if (ecu > 4 * ups) return -1;
+  // colour and alpha box-downsampled by their factors; the decoder upsamples each back to xs x ys
+  auto shrink = [&](uint32_t N, int first, int count, std::vector<uint8_t>* dst, uint32_t* w, uint32_t* h) {
+    *w = (xs + N - 1) / N;
+    *h = (ys + N - 1) / N;
+    dst->resize(size_t(*w) * *h * count);
+    for (uint32_t y = 0; y < *h; y++)
+      for (uint32_t x = 0; x < *w; x++)
+        for (int c = 0; c < count; c++) {
+          uint32_t sum = 0, cnt = 0;
+          for (uint32_t dy = 0; dy < N && y * N + dy < ys; dy++)
+            for (uint32_t dx = 0; dx < N && x * N + dx < xs; dx++) {
+              sum += rgba[(size_t(y * N + dy) * xs + x * N + dx) * 4 + first + c];
+              cnt++;
+            }
+          (*dst)[(size_t(y) * *w + x) * count + c] = uint8_t((sum + cnt / 2) / cnt);
+        }
+  };
+  std::vector<uint8_t> rgb, alpha;
+  uint32_t sx, sy, aw, ah;
+  shrink(ups, 0, 3, &rgb, &sx, &sy);
+  shrink(ecu, 3, 1, &alpha, &aw, &ah);
+  uint32_t shift = 0;
+  while ((ups << shift) < ecu) shift++;
   std::vector<uint8_t> v;
   try {
-    jxe::EncodeImage(rgb.data(), xs, ys, q, &v, 0, 0, &alpha);
+    jxe::g_alpha_dims[0] = ecu == 1 ? 0 : aw;
+    jxe::g_alpha_dims[1] = ah;
+    jxe::g_alpha_dims[2] = ecu;
+    jxe::g_alpha_dims[3] = shift;
+    jxe::EncodeImage(rgb.data(), sx, sy, q, &v, ups == 1 ? 0 : xs, ups == 1 ? 0 : ys, &alpha);
+    jxe::g_alpha_dims[0] = 0;
   } catch (...) {
+    jxe::g_alpha_dims[0] = 0;
     return -2;
   }
   return Finish(v, out, n);

@@ -267,6 +267,7 @@ struct JxlHipContext {
   bool have_alpha = false;
   bool color_out = false;   // the pixels come from k_color_out / k_upsample_color's generic writer (set at upload)
   Buf kend, block_recs, dequant_scan;
+  Buf ec_stage;  // jxlhip_upsample_plane: a coded extra channel, its kernels and (unless it becomes the alpha plane) the result
   std::vector<JxlHipVarBlock> blocks_host;  // for jxlhip_download("coeffs") of a scan-order frame
   std::vector<uint32_t> gbb_host;
   std::vector<uint16_t> orders_host;
@@ -519,7 +520,7 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
 static std::vector<Buf*> AllBufs(JxlHipContext* c) {
   std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc, &c->dc_raw, &c->dc_q, &c->dc_ep, &c->sharp,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->ec_stage, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
                 &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob, &c->ups_planes};
   for (auto& pb : c->pass_bufs)
@@ -3290,6 +3291,42 @@ int jxlhip_set_alpha(JxlHipContext* c, const float* alpha, uint32_t xsize, uint3
   if (r) return r;
   HIP_TRY(hipMemcpy(c->alpha.p, alpha, bytes, hipMemcpyHostToDevice));
   c->have_alpha = true;
+  return 0;
+}
+
+int jxlhip_upsample_plane(JxlHipContext* c, const float* plane, uint32_t xsize, uint32_t ysize, uint32_t factor, const float* kernels,
+                          uint32_t out_xsize, uint32_t out_ysize, int as_alpha, float* host_out) {
+  if (!c || !plane || !kernels || !xsize || !ysize || (factor != 2 && factor != 4 && factor != 8)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if ((uint64_t(out_xsize) + factor - 1) / factor != xsize || (uint64_t(out_ysize) + factor - 1) / factor != ysize || !out_xsize || !out_ysize)
+    return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  const size_t in_bytes = size_t(xsize) * ysize * 4, k_bytes = size_t(factor) * factor * 25 * 4, out_bytes = size_t(out_xsize) * out_ysize * 4;
+  int r;
+  // (the staging buffer: the coded plane, then the kernels; the result goes to the alpha plane or behind them)
+  const size_t k_at = (in_bytes + 255) & ~size_t(255), out_at = (k_at + k_bytes + 255) & ~size_t(255);
+  if ((r = c->ec_stage.Ensure(out_at + (as_alpha ? 0 : out_bytes)))) return r;
+  if (as_alpha && (r = c->alpha.Ensure(out_bytes))) return r;
+  uint8_t* base = static_cast<uint8_t*>(c->ec_stage.p);
+  HIP_TRY(hipMemcpyAsync(base, plane, in_bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(base + k_at, kernels, k_bytes, hipMemcpyHostToDevice, c->stream));
+  jxlhip::UpsamplePlaneParams up;
+  up.in = reinterpret_cast<const float*>(base);
+  up.kernel = reinterpret_cast<const float*>(base + k_at);
+  up.out = as_alpha ? c->alpha.as<float>() : reinterpret_cast<float*>(base + out_at);
+  up.xs = xsize;
+  up.ys = ysize;
+  up.n = factor;
+  up.oxs = out_xsize;
+  up.oys = out_ysize;
+  hipLaunchKernelGGL(jxlhip::k_upsample_plane, dim3((xsize + 63) / 64, (ysize + 3) / 4), dim3(256), 0, c->stream, up);
+  HIP_TRY(hipGetLastError());
+  if (host_out) HIP_TRY(hipMemcpyAsync(host_out, up.out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // (the host buffers are the caller's; pageable copies are staged by the runtime)
+  if (as_alpha) c->have_alpha = true;
   return 0;
 }
 

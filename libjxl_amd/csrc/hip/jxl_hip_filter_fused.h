@@ -303,6 +303,52 @@ __global__ __launch_bounds__(256) void k_upsample_color(UpsampleParams P) {
   }
 }
 
+// The upsampling stage on ONE plane (an extra channel with an upsampling factor: dec_cache.cc:172-190, 203-212): the same
+// 5x5 sums, accumulation order and clamp as k_upsample_color, one thread per sample of the coded plane.
+struct UpsamplePlaneParams {
+  const float* in;      // ys rows of xs samples, dense
+  float* out;           // oys rows of oxs samples, dense
+  const float* kernel;  // [N * N][25]
+  uint32_t xs, ys, n, oxs, oys;
+};
+__global__ __launch_bounds__(256) void k_upsample_plane(UpsamplePlaneParams P) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int xs = int(P.xs), ys = int(P.ys);
+  if (x >= xs || y >= ys) return;
+  float v[25], mn = 0.0f, mx = 0.0f;
+#pragma unroll
+  for (int iy = 0; iy < 5; iy++) {
+    const size_t row = size_t(MirrorI(y + iy - 2, ys)) * P.xs;
+#pragma unroll
+    for (int ix = 0; ix < 5; ix++) {
+      const float t = P.in[row + MirrorI(x + ix - 2, xs)];
+      v[iy * 5 + ix] = t;
+      mn = (iy | ix) == 0 ? t : fminf(mn, t);
+      mx = (iy | ix) == 0 ? t : fmaxf(mx, t);
+    }
+  }
+  const int N = int(P.n);
+  for (int oy = 0; oy < N; oy++) {
+    const int Y = y * N + oy;
+    if (Y >= int(P.oys)) break;
+    for (int ox = 0; ox < N; ox++) {
+      const int X = x * N + ox;
+      if (X >= int(P.oxs)) break;
+      const float* k = P.kernel + (N * oy + ox) * 25;
+      float a0 = v[0] * k[0], a1 = v[1] * k[1], a2 = v[2] * k[2];
+#pragma unroll
+      for (int i = 3; i < 24; i += 3) {
+        a0 = fmaf(v[i], k[i], a0);
+        a1 = fmaf(v[i + 1], k[i + 1], a1);
+        a2 = fmaf(v[i + 2], k[i + 2], a2);
+      }
+      a0 = fmaf(v[24], k[24], a0);
+      const float r = (a1 + a2) + a0;
+      P.out[size_t(Y) * P.oxs + X] = r < mn ? mn : (r > mx ? mx : r);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Row-streaming form of Gaborish -> EPF1 -> colour (the d1.0 configuration): no LDS at all, so it runs beside the
 // LDS-hungry entropy workgroups instead of queueing for their LDS.

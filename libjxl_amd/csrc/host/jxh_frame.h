@@ -195,9 +195,10 @@ class FrameParser {
     JXH_CHECK(fh.Is444() || (fh.flags & FrameHeader::kSkipDcSmoothing), "chroma subsampling is not allowed when adaptive DC smoothing is enabled");
     JXH_CHECK(fh.Is444() || fh.frame_type != 1, "unsupported: chroma-subsampled DC frames");
     JXH_CHECK(!fh.custom_size || fh.upsampling == 1, "unsupported: cropped upsampled frames");
+    // (extra channels carry an upsampling factor of their own, at least the frame's: frame_header.cc:272-283; the channel is
+    // coded at ceil(image / factor) and upsampled by the stage of that factor: dec_cache.cc:172-190, 203-212)
     for (size_t e = 0; e < ih.extra.size(); e++)
-      JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] == 1, "unsupported: upsampled extra channels");
-    JXH_CHECK(ih.extra.empty() || fh.upsampling == 1, "unsupported: extra channels of upsampled frames");
+      JXH_CHECK(fh.ec_upsampling.empty() || fh.ec_upsampling[e] >= fh.upsampling, "EC upsampling < color upsampling, which is invalid");
     // kUseDcFrame (frame_header.h:348; passes_state.cc:62-77, dec_frame.cc:319-326,347-356): the DC image is the output
     // of the DC frame of level fh.dc_level + 1 decoded earlier; the DC groups then carry no DC stream, the DC-derived block
     // context is 0 everywhere and nothing is smoothed. The planes live on the device (FramePlan::dc_source).
@@ -366,7 +367,11 @@ class FrameParser {
     // no larger than a group; the transforms stay pending until every channel is complete (dec_modular.cc:209-318).
     P->extra.ch.clear();
     P->extra.bitdepth = int(P->ih.bits);
-    for (size_t e = 0; e < P->ih.extra.size(); e++) P->extra.ch.emplace_back(P->dim.xsize, P->dim.ysize);
+    for (size_t e = 0; e < P->ih.extra.size(); e++) {  // dec_modular.cc:262-271
+      const uint32_t ups = P->fh.ec_upsampling.empty() ? 1 : P->fh.ec_upsampling[e];
+      const int shift = CeilLog2(ups) - CeilLog2(P->fh.upsampling);
+      P->extra.ch.emplace_back(DivCeil(size_t(P->fh.xsize), size_t(ups)), DivCeil(size_t(P->fh.ysize), size_t(ups)), shift, shift);
+    }
     ModularDecode(br, &P->extra, 0, &mglobal_, P->dim.group_dim, /*undo_transforms=*/false);
   }
 

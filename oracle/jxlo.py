@@ -48,7 +48,7 @@ INFO = ("xsize", "ysize", "channels", "modular", "xsize_blocks", "ysize_blocks",
 _DTYPES = {"rgb8": np.uint8, "rgbf": np.float32, "coeffs": np.int32, "nzeros": np.int32, "xyb_idct": np.float32,
            "xyb_filtered": np.float32, "dc": np.float32, "acs": np.uint8, "quant": np.int32, "sharpness": np.uint8,
            "ytox": np.int8, "ytob": np.int8, "inv_sigma": np.float32, "quant_dc": np.uint8, "modular": np.int32,
-           "dc_unsmoothed": np.float32}
+           "dc_unsmoothed": np.float32, "alphaf": np.float32}
 
 
 class Decoded:

@@ -142,9 +142,13 @@ static void DecodeDcGlobal(BitReader& br, FrameState* s) {
   s->full.bitdepth = int(s->ih->bits);
   for (size_t c = 0; c < nb_color; c++) s->full.ch.emplace_back(s->dim.xsize, s->dim.ysize);
   for (size_t e = 0; e < s->ih->extra.size(); e++) {
+    // dec_modular.cc:262-271: ceil(image / its own upsampling factor) samples, shifted against the frame by the ratio of the
+    // two factors (frame_header.cc:272-283: at least the frame's)
     uint32_t ups = s->fh.ec_upsampling.empty() ? 1 : s->fh.ec_upsampling[e];
-    JXLO_CHECK(ups == 1 && fh.upsampling == 1, "unsupported: upsampling");
-    s->full.ch.emplace_back(s->dim.xsize, s->dim.ysize);
+    JXLO_CHECK(ups >= fh.upsampling, "EC upsampling < color upsampling, which is invalid");
+    JXLO_CHECK(!fh.modular || (ups == 1 && fh.upsampling == 1), "unsupported: upsampled Modular frames");
+    const int shift = int(CeilLog2(ups)) - int(CeilLog2(fh.upsampling));
+    s->full.ch.emplace_back(DivCeil(size_t(fh.xsize), size_t(ups)), DivCeil(size_t(fh.ysize), size_t(ups)), shift, shift);
   }
   // Stream 0: channels no larger than a group are coded here; transforms stay pending on the full image.
   ModularDecode(br, &s->full, 0, &s->mglobal, s->dim.group_dim, /*undo_transforms=*/false);
@@ -840,8 +844,21 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
   if (has_alpha) {
     const MChannel& ch = s->full.ch[s->modular_color_channels];
     const float af = float(1.0 / double((1u << ih.extra[0].bits) - 1));
-    alpha.resize(xs * ys);
-    for (size_t i = 0; i < xs * ys; i++) alpha[i] = float(ch.d[i]) * af;
+    const uint32_t ecu = fh.ec_upsampling.empty() ? 1 : fh.ec_upsampling[0];
+    if (ecu == 1) {
+      alpha.resize(xs * ys);
+      for (size_t i = 0; i < xs * ys; i++) alpha[i] = float(ch.d[i]) * af;
+    } else {
+      // dec_cache.cc:172-190, 203-212: the channel as floats (dec_modular.cc:640-700) through the upsampling stage of its own
+      // factor, cropped to the image
+      Planes3 in, up;
+      in.xs = ch.w; in.ys = ch.h; in.stride = ch.w;
+      in.p[0].resize(ch.w * ch.h);
+      for (size_t i = 0; i < ch.w * ch.h; i++) in.p[0][i] = float(ch.d[i]) * af;
+      const std::vector<float>& cw = ecu == 2 ? ih.ups_weights2 : (ecu == 4 ? ih.ups_weights4 : ih.ups_weights8);
+      Upsample(in, ecu, cw.empty() ? nullptr : cw.data(), xs, ys, &up, 1);
+      alpha = up.p[0];
+    }
     out->alphaf = alpha;
   }
 #pragma omp parallel for schedule(static)
@@ -1115,7 +1132,7 @@ const void* jxlo_buffer(JxloHandle* h, const char* name, size_t* nbytes) {
   }
   JXLO_BUF(rgb8) JXLO_BUF(rgbf) JXLO_BUF(coeffs) JXLO_BUF(nzeros) JXLO_BUF(xyb_idct) JXLO_BUF(xyb_filtered) JXLO_BUF(dc)
   JXLO_BUF(acs) JXLO_BUF(quant) JXLO_BUF(sharpness) JXLO_BUF(ytox) JXLO_BUF(ytob) JXLO_BUF(inv_sigma) JXLO_BUF(quant_dc) JXLO_BUF(dc_unsmoothed)
-  JXLO_BUF(modular)
+  JXLO_BUF(modular) JXLO_BUF(alphaf)
 #undef JXLO_BUF
   *nbytes = 0;
   return nullptr;

@@ -189,11 +189,12 @@ static inline void UpsamplingKernels(uint32_t N, const float* coded, float* kern
         }
     }
 }
-static inline void Upsample(const Planes3& in, uint32_t N, const float* coded_weights, size_t out_xs, size_t out_ys, Planes3* out) {
+static inline void Upsample(const Planes3& in, uint32_t N, const float* coded_weights, size_t out_xs, size_t out_ys, Planes3* out,
+                            int nplanes = 3) {
   std::vector<float> kernel(size_t(N) * N * 25);
   UpsamplingKernels(N, coded_weights, kernel.data());
   out->Alloc(out_xs, out_ys, out_xs);
-  for (int c = 0; c < 3; c++)
+  for (int c = 0; c < nplanes; c++)
     for (size_t y = 0; y < in.ys; y++)
       for (size_t x = 0; x < in.xs; x++) {
         float v[25], mn = 0, mx = 0;

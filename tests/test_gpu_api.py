@@ -247,6 +247,39 @@ def test_image_with_alpha_in_group_sections(built, tmp_path):
     assert np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("ups,ecu", [(1, 2), (1, 4), (2, 2), (2, 4), (2, 8), (4, 4), (8, 8)])
+def test_extra_channel_with_an_upsampling_factor(built, tmp_path, ups, ecu):
+    """An alpha channel coded at ceil(image / its own factor) (frame_header.cc:265-283, dec_modular.cc:262-271; what
+    `cjxl --resampling` / `--ec_resampling` write), with the frame at the same or a smaller factor: the host decodes the
+    smaller channel (its groups' rectangles shifted against the frame's), the device upsamples it with the image's kernels
+    (dec_cache.cc:172-190, 203-212). Sizes that are not multiples of either factor; alpha larger than a group."""
+    import jxlo
+    J = built
+    xs, ys = 1101, 613
+    rgb = J.synth_image(xs, ys, seed=8)
+    yy, xx = np.mgrid[0:ys, 0:xs]
+    alpha = (128 + 100 * np.sin(xx / 37.0) * np.cos(yy / 29.0) + 20 * ((xx // 64 + yy // 64) & 1)).clip(0, 255).astype(np.uint8)
+    data = J.encode_rgba8(np.dstack([rgb, alpha]), upsampling=ups, ec_upsampling=ecu)
+    o = jxlo.Decoded(data, dumps=False)
+    want8, wantf = o.rgb8.copy(), o.buffer("alphaf").reshape(ys, xs)
+    o.close()
+    assert want8.shape == (ys, xs, 4) and np.abs(want8[..., 3].astype(int) - alpha).mean() < 6
+    rc, events, out, px = R.run(data, tmp_path, "u8", 4)
+    assert rc == 0, out
+    got = np.frombuffer(px, np.uint8).reshape(ys, xs, 4)
+    d = np.abs(got.astype(int) - want8.astype(int))
+    assert d.max() <= 1 and (d[..., 3] > 0).mean() < 1e-3
+    rc, events, out, px = R.run(data, tmp_path, "f32", 4)
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.float32).reshape(ys, xs, 4)[..., 3] - wantf).max() < 1e-6
+    # ... and as an extra channel buffer of its own (JxlDecoderSetExtraChannelBuffer: the integers of its bit depth, undithered)
+    rc, events, out, px = R.run(data, tmp_path, "u8", 4, "ec")
+    assert rc == 0, out
+    ec = np.frombuffer(px[xs * ys * 4:], np.uint8).reshape(ys, xs).astype(int)
+    d = np.abs(ec - np.rint(wantf.astype(np.float64) * 255.0))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
 def _oriented(img, orientation):
     """The image a viewer shows for `orientation` (EXIF numbering): mirror y, mirror x, then transpose, as the reference's
     writer applies them (stage_write.cc:441-458, 664-699)."""
