@@ -59,6 +59,11 @@ void jxlamd_frame_set_indices(JxlAmdFrame* frame, uint32_t visible_index, uint32
  * patch rectangle against them. Before upload; returns non-zero (see jxlamd_last_error) when a patch refers to an empty
  * slot or reaches outside its reference frame. */
 int jxlamd_frame_set_patch_sources(JxlAmdFrame* frame, const float* const* planes, const uint32_t* xsize, const uint32_t* ysize);
+/* ... and their alpha planes (jxlhip_canvas_xyb_alpha; NULL entries: none), for patches that blend through alpha or write the
+ * alpha channel (PatchBlendMode 4..7, or a mode on the alpha channel: blending.cc:40-190). Fails when such a patch names a
+ * reference frame without alpha, when the frame is upsampled, or when the image's extra channel is not alpha. Call after
+ * jxlamd_frame_set_patch_sources, before the upload. */
+int jxlamd_frame_set_patch_alpha_sources(JxlAmdFrame* frame, const float* const* alpha);
 /* A frame with kUseDcFrame: the device planes of the DC frame it names ([3][ysize][xsize] floats, e.g. from
  * jxlhip_canvas_xyb_source(canvas, 4 + placement.dc_level, ...)); fails unless the size is the frame's size in blocks. */
 int jxlamd_frame_set_dc_source(JxlAmdFrame* frame, const float* planes, uint32_t xsize, uint32_t ysize);

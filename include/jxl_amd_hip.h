@@ -95,6 +95,16 @@ typedef struct JxlHipPatches {
   const uint32_t* row_list;
   const float* slot_planes[4];
   uint32_t slot_w[4], slot_h[4];
+  /* Patches that blend through alpha or change the alpha channel (PatchBlendMode 4..7: blend above / below, alpha-weighted
+   * add above / below, dec_patch_dictionary.h:32-58; blending.cc:40-190), for images whose one extra channel is alpha:
+   * records[7] also carries the alpha channel's own mode << 16 | its clamp << 24; uses_alpha != 0: some record needs the
+   * alpha planes: slot_alpha[slot] = the reference frame's alpha, slot_h x slot_w floats on the device (jxlhip_canvas_xyb_alpha),
+   * and the frame's own alpha plane must have been set (jxlhip_set_alpha) before the filter stage runs; the stage then leaves
+   * the blended alpha for the pixel writer, the canvas and jxlhip_download_alpha. premultiplied = ExtraChannelInfo::
+   * alpha_associated. Not on upsampled frames. Without uses_alpha modes 4 / 5 replace and 6 / 7 add (an image without alpha:
+   * blending.cc:154-168). */
+  uint32_t uses_alpha, premultiplied;
+  const float* slot_alpha[4];
 } JxlHipPatches;
 
 typedef struct JxlHipFrameDesc {
@@ -256,6 +266,9 @@ int jxlhip_set_alpha(JxlHipContext* ctx, const float* alpha, uint32_t xsize, uin
  * = factor * factor * 25 weights (factor 2, 4 or 8), the result out_xsize x out_ysize with out in (factor * (size - 1),
  * factor * size]. as_alpha != 0: the result becomes the context's alpha plane (as after jxlhip_set_alpha); host_out != NULL:
  * it is copied there (out_xsize * out_ysize floats). Synchronous. */
+/* The context's alpha plane as the filter stage left it (the patches of the frame may have blended into it), out_xsize *
+ * out_ysize floats to host memory; synchronous. */
+int jxlhip_download_alpha(JxlHipContext* ctx, float* dst);
 int jxlhip_upsample_plane(JxlHipContext* ctx, const float* plane, uint32_t xsize, uint32_t ysize, uint32_t factor, const float* kernels,
                           uint32_t out_xsize, uint32_t out_ysize, int as_alpha, float* host_out);
 /* Copies the interleaved result in the format of jxlhip_set_output_format (row stride in bytes); synchronous. */
@@ -454,6 +467,8 @@ typedef struct JxlHipBlend {
  * again or the canvas is destroyed. */
 int jxlhip_canvas_save_xyb(JxlHipCanvas* canvas, JxlHipContext* frame, uint32_t slot);
 int jxlhip_canvas_xyb_source(JxlHipCanvas* canvas, uint32_t slot, const float** planes, uint32_t* xsize, uint32_t* ysize);
+/* The alpha plane kept with that slot's frame (ysize x xsize floats), or NULL when the frame had none. */
+int jxlhip_canvas_xyb_alpha(JxlHipCanvas* canvas, uint32_t slot, const float** alpha);
 /* Blends the pixels `frame` holds (its last run, f32 x 4) into the canvas. */
 int jxlhip_canvas_blend(JxlHipCanvas* canvas, JxlHipContext* frame, const JxlHipBlend* blend);
 /* The canvas in a sample format (as jxlhip_set_output_format) and orientation (as jxlhip_set_output_orientation), into

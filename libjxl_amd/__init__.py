@@ -651,11 +651,13 @@ def encode_with_preview(img, preview, **kw):
     return m[:h] + pframe + m[h:]
 
 
-def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=False, **kw):
+def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=False, premultiplied=False, **kw):
     """Test aid: a reference-only frame holding `atlas` (HxWx3 uint8; coded as an XYB Modular frame like libjxl's patch
     frames, or as a VarDCT frame) kept in `slot`, then `img` coded with a patch dictionary. patches: list of dicts with
-    x0, y0, xsize, ysize (rectangle in the atlas) and positions: list of (x, y, mode, clamp) with PatchBlendMode 0 none,
-    1 replace, 2 add, 3 multiply. The patches are drawn over the decoded frame; nothing is subtracted when encoding."""
+    x0, y0, xsize, ysize (rectangle in the atlas) and positions: list of (x, y, mode, clamp[, alpha mode, alpha clamp]) with
+    PatchBlendMode 0 none, 1 replace, 2 add, 3 multiply, 4 / 5 blend above / below, 6 / 7 alpha-weighted add above / below
+    (dec_patch_dictionary.h:32-58); the last two apply to the image's alpha channel (RGBA `img` and `atlas`, VarDCT atlas).
+    The patches are drawn over the decoded frame; nothing is subtracted when encoding."""
     E = _enc_lib()
     E.jxlenc_set_reference_frame.argtypes = [ctypes.c_int]
     E.jxlenc_set_reference_frame.restype = None
@@ -669,18 +671,22 @@ def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=Fal
     flat = [len(patches)]
     for p in patches:
         flat += [slot, p["x0"], p["y0"], p["xsize"], p["ysize"], len(p["positions"])]
-        for (x, y, mode, clamp) in p["positions"]:
-            flat += [x, y, mode, clamp]
+        for pos in p["positions"]:
+            flat += list(pos) + [0] * (6 - len(pos))
+    E.jxlenc_set_alpha_premultiplied.argtypes = [ctypes.c_int]
+    E.jxlenc_set_alpha_premultiplied.restype = None
     try:
+        E.jxlenc_set_alpha_premultiplied(1 if premultiplied else 0)  # (the alpha channel is declared associated; samples as given)
         E.jxlenc_set_image_size(img.shape[1], img.shape[0])
         E.jxlenc_set_reference_frame(slot)
-        first = encode_rgb8(atlas, **kw) if atlas_vardct else encode_lossless(atlas, MODULAR_XYB)
+        first = (encode_rgba8(atlas, **kw) if atlas.shape[2] == 4 else encode_rgb8(atlas, **kw)) if atlas_vardct else encode_lossless(atlas, MODULAR_XYB)
         E.jxlenc_set_reference_frame(-1)
         arr = (ctypes.c_int32 * len(flat))(*flat)
         E.jxlenc_set_patches(arr, len(flat))
         second = encode_lossless(img, MODULAR_XYB) if lossless else (encode_rgba8(img, **kw) if img.shape[2] == 4 else encode_rgb8(img, **kw))
         return first + second[E.jxlenc_last_header_bytes():]
     finally:
+        E.jxlenc_set_alpha_premultiplied(0)
         E.jxlenc_set_reference_frame(-1)
         E.jxlenc_set_patches(None, 0)
         E.jxlenc_set_image_size(0, 0)

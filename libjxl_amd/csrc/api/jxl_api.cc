@@ -187,6 +187,30 @@ int jxlamd_frame_set_patch_sources(JxlAmdFrame* f, const float* const* planes, c
   }
   return 0;
 }
+// Does the frame's patch stage read and write the alpha channel (blending.cc:47-56: an image with an alpha channel)?
+static bool PatchesBlendAlpha(const jxh::FramePlan& P) {
+  return P.has_patches && P.patches.uses_alpha && P.ih.extra.size() == 1 && P.ih.extra[0].type == 0;
+}
+int jxlamd_frame_set_patch_alpha_sources(JxlAmdFrame* f, const float* const* alpha) {
+  g_last_error.clear();
+  jxh::FramePlan& P = f->plan;
+  for (int i = 0; i < 4; i++) P.patch_src_alpha[i] = alpha ? alpha[i] : nullptr;
+  if (P.has_patches && P.patches.uses_alpha && !P.ih.extra.empty() && !PatchesBlendAlpha(P)) {
+    g_last_error = "unsupported: patches that blend extra channels of an image whose extra channel is not alpha";
+    return 2;
+  }
+  if (!PatchesBlendAlpha(P)) return 0;
+  if (P.fh.upsampling != 1 || (!P.fh.ec_upsampling.empty() && P.fh.ec_upsampling[0] != 1)) {
+    g_last_error = "unsupported: patches that blend through alpha on upsampled frames";
+    return 2;
+  }
+  for (const jxh::PatchRef& r : P.patches.refs)
+    if (!P.patch_src_alpha[r.slot]) {
+      g_last_error = "patches: the reference frame kept no alpha channel";
+      return 2;
+    }
+  return 0;
+}
 void jxlamd_frame_set_indices(JxlAmdFrame* f, uint32_t visible_index, uint32_t nonvisible_index) {
   f->plan.frame_index = visible_index;
   f->plan.nonvisible_index = nonvisible_index;
@@ -382,7 +406,10 @@ int jxlamd_frame_upload_band(const JxlAmdFrame* f, JxlHipContext* ctx, uint32_t 
       d.patches.slot_planes[i] = P.patch_src[i];
       d.patches.slot_w[i] = P.patch_src_w[i];
       d.patches.slot_h[i] = P.patch_src_h[i];
+      d.patches.slot_alpha[i] = P.patch_src_alpha[i];
     }
+    d.patches.uses_alpha = PatchesBlendAlpha(P) ? 1 : 0;
+    d.patches.premultiplied = (d.patches.uses_alpha && P.ih.extra[0].alpha_associated) ? 1 : 0;
   }
   memcpy(d.noise_lut, P.noise_lut, sizeof(d.noise_lut));
   // dec_frame.cc:160-168: the number of visible frames before this one, and of invisible ones since (none are accepted)
@@ -1206,6 +1233,9 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
     uint32_t pw[4] = {0, 0, 0, 0}, ph[4] = {0, 0, 0, 0};
     for (uint32_t i = 0; i < 4 && d->canvas; i++) jxlhip_canvas_xyb_source(d->canvas, i, &planes[i], &pw[i], &ph[i]);
     if (jxlamd_frame_set_patch_sources(d->frame, planes, pw, ph)) return Fail(d, g_last_error);
+    const float* alphas[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (uint32_t i = 0; i < 4 && d->canvas; i++) jxlhip_canvas_xyb_alpha(d->canvas, i, &alphas[i]);
+    if (jxlamd_frame_set_patch_alpha_sources(d->frame, alphas)) return Fail(d, g_last_error);
   }
   if (!r && P.use_dc_frame) {  // the DC frame decoded earlier: DC slot of the canvas (BlendIntoCanvas put it there)
     const float* planes = nullptr;
@@ -1267,9 +1297,13 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
     std::vector<int32_t> upsampled;
     uint32_t whu[3] = {0, 0, 1};
     jxlamd_frame_extra_dims(d->frame, eo.first, whu);
-    if (whu[2] != 1) {  // the upsampled channel back as integers of its bit depth (what the rows below are converted from)
+    const bool blended = int(eo.first) == alpha_ec && PatchesBlendAlpha(P);  // (the patch stage wrote the alpha channel)
+    if (whu[2] != 1 || blended) {  // the channel from the device, back as integers of its bit depth (what the rows below are converted from)
       std::vector<float> f;
-      if (const char* e = extra_floats(eo.first, false, &f)) return Fail(d, e);
+      if (blended) {
+        f.resize(coded_xs * coded_ys);
+        if (jxlhip_download_alpha(d->ctx, f.data())) return Fail(d, "jxlhip_download_alpha failed");
+      } else if (const char* e = extra_floats(eo.first, false, &f)) return Fail(d, e);
       const float maxv = float((uint64_t(1) << d->ih.extra[eo.first].bits) - 1);
       upsampled.resize(f.size());
       for (size_t i = 0; i < f.size(); i++) upsampled[i] = int32_t(std::lrint(std::min(1.0f, std::max(0.0f, f[i])) * maxv));

@@ -839,8 +839,9 @@ static LayerState g_layer;
 // kept before its colour transform in slot `save_as` for the patches of later frames; coded with its own size.
 // jxlenc_set_image_size: the image size the next stream's headers declare (a reference frame that comes first is smaller
 // or larger than the image). jxlenc_set_patches: the patch dictionary of the next frames (flat: number of references, per
-// reference: slot, x0, y0, xsize, ysize, count, then per position: x, y, colour blend mode 0..3, clamp), written the way
-// PatchDictionary::Decode reads it (dec_patch_dictionary.cc:32-175; extra channels are left alone: mode kNone).
+// reference: slot, x0, y0, xsize, ysize, count, then per position: x, y, colour blend mode 0..7, clamp, the first extra
+// channel's blend mode 0..7 and clamp), written the way PatchDictionary::Decode reads it (dec_patch_dictionary.cc:32-175;
+// further extra channels are left alone: mode kNone).
 static int g_reference_slot = -1;
 // jxlenc_set_dc_frame: the next frame is a kDCFrame of this level (frame_header.cc:310-320, 372-411: a Passes bundle and the
 // level, then no size, no blending, no timing, no save_as_reference), coded at the size the image header implies
@@ -1026,7 +1027,7 @@ static void WritePatches(BitWriter& bw, size_t num_extra) {
     tk.push_back({7, uint32_t(count - 1)});
     d += 6;
     int64_t px = 0, py = 0;
-    for (size_t i = 0; i < count; i++, d += 4) {
+    for (size_t i = 0; i < count; i++, d += 6) {
       if (i == 0) {
         tk.push_back({4, uint32_t(d[0])});
         tk.push_back({4, uint32_t(d[1])});
@@ -1036,9 +1037,16 @@ static void WritePatches(BitWriter& bw, size_t num_extra) {
       }
       px = d[0];
       py = d[1];
+      // dec_patch_dictionary.cc:135-163: the colour channels' mode, then every extra channel's; a mode that blends through
+      // alpha (4..7) names the alpha channel when the image has more than one extra channel (never here), and it and kMul
+      // carry a clamp flag (contexts patch_dictionary_internal.h:12-24)
       tk.push_back({5, uint32_t(d[2])});
-      if (d[2] == 3) tk.push_back({9, uint32_t(d[3] ? 1 : 0)});
-      for (size_t e = 0; e < num_extra; e++) tk.push_back({5, 0});  // extra channels: kNone
+      if (d[2] >= 3) tk.push_back({9, uint32_t(d[3] ? 1 : 0)});
+      for (size_t e = 0; e < num_extra; e++) {
+        const uint32_t em = e == 0 ? uint32_t(d[4]) : 0u;
+        tk.push_back({5, em});
+        if (em >= 3) tk.push_back({9, uint32_t(d[5] ? 1 : 0)});
+      }
     }
   }
   jxh::HybridCfg cfg;

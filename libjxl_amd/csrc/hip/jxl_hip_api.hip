@@ -255,6 +255,12 @@ struct JxlHipContext {
   Buf pat_rec, pat_row_start, pat_row_list;
   uint32_t pat_positions = 0;
   const float* pat_src[4] = {nullptr, nullptr, nullptr, nullptr};
+  const float* pat_src_alpha[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool pat_uses_alpha = false, pat_premultiplied = false;
+  // the alpha plane the patch stage blended into (a copy: the plane that was set stays as it is, the stages can run again);
+  // valid from the filter stage of such a frame on
+  Buf alpha_patched;
+  bool alpha_patched_valid = false;
   uint32_t pat_src_w[4] = {0, 0, 0, 0}, pat_src_h[4] = {0, 0, 0, 0};
   bool keep_xyb = false;  // option "keep_xyb_planes": a Modular frame also leaves its colour as float planes (spl_planes)
   // noise synthesis (JxlHipFrameDesc::has_noise): raw random planes [3][ys][xs], LUT, seeds, base colour correlation
@@ -520,7 +526,7 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
 static std::vector<Buf*> AllBufs(JxlHipContext* c) {
   std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc, &c->dc_raw, &c->dc_q, &c->dc_ep, &c->sharp,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->ec_stage, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->ec_stage, &c->alpha_patched, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
                 &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob, &c->ups_planes};
   for (auto& pb : c->pass_bufs)
@@ -1086,6 +1092,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if ((r = UploadSplines(c, d->splines, c->ys))) return r;
   // patches: validated like every table a kernel indexes with (rectangles inside the frame and inside their reference)
   c->pat_positions = 0;
+  c->pat_uses_alpha = false;
+  c->alpha_patched_valid = false;
   if (d->patches.num_positions) {
     const JxlHipPatches& pt = d->patches;
     if (!pt.records || !pt.row_start || !pt.row_list || pt.num_positions > (1u << 24) || pt.num_row_entries > (1u << 26)) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -1095,7 +1103,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     for (uint32_t i = 0; i < pt.num_positions; i++) {
       const uint32_t* q = pt.records + size_t(i) * 8;
       const uint32_t slot = q[6];
-      if (slot > 3 || !pt.slot_planes[slot] || (q[7] & 255) > 3 || !q[2] || !q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (slot > 3 || !pt.slot_planes[slot] || (q[7] & 255) > 7 || ((q[7] >> 16) & 255) > 7 || !q[2] || !q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;
+      if (pt.uses_alpha && !pt.slot_alpha[slot]) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the reference frame kept no alpha plane)
       if (uint64_t(q[4]) + q[2] > pt.slot_w[slot] || uint64_t(q[5]) + q[3] > pt.slot_h[slot]) return JXLHIP_ERR_INVALID_ARGUMENT;
       if (uint64_t(q[0]) + q[2] > c->xp || uint64_t(q[1]) + q[3] > c->yp) return JXLHIP_ERR_INVALID_ARGUMENT;
     }
@@ -1109,7 +1118,11 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     if ((r = Upload(c, c->pat_rec, pt.records, size_t(pt.num_positions) * 32))) return r;
     if ((r = Upload(c, c->pat_row_start, pt.row_start, (size_t(c->ys) + 1) * 4))) return r;
     if ((r = Upload(c, c->pat_row_list, pt.row_list, std::max<size_t>(4, size_t(pt.num_row_entries) * 4)))) return r;
+    if (pt.uses_alpha && c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
+    c->pat_uses_alpha = pt.uses_alpha != 0;
+    c->pat_premultiplied = pt.premultiplied != 0;
     for (int i = 0; i < 4; i++) {
+      c->pat_src_alpha[i] = pt.slot_alpha[i];
       c->pat_src[i] = pt.slot_planes[i];
       c->pat_src_w[i] = pt.slot_w[i];
       c->pat_src_h[i] = pt.slot_h[i];
@@ -2951,10 +2964,23 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
     if (r) return r;
   }
   for (size_t i = 0; i < n; i++) {
-    const JxlHipContext* c = ctxs[i];
+    JxlHipContext* c = ctxs[i];
+    c->alpha_patched_valid = false;
     if (!c->pat_positions) continue;
     jxlhip::PatchParams pp;
     memset(&pp, 0, sizeof(pp));
+    if (c->pat_uses_alpha) {  // the frame's alpha plane must be there by now (jxlhip_set_alpha); blended into a copy of it
+      const size_t bytes = size_t(c->xs) * c->ys * 4;
+      if (!c->have_alpha || c->alpha.cap < bytes) return JXLHIP_ERR_INVALID_ARGUMENT;
+      int ar = c->alpha_patched.Ensure(bytes);
+      if (ar) return ar;
+      HIP_TRY(hipMemcpyAsync(c->alpha_patched.p, c->alpha.p, bytes, hipMemcpyDeviceToDevice, ls));
+      pp.alpha = c->alpha_patched.as<float>();
+      pp.alpha_stride = c->xs;
+      pp.premultiplied = c->pat_premultiplied ? 1 : 0;
+      for (int k = 0; k < 4; k++) pp.slot_alpha[k] = c->pat_src_alpha[k];
+      c->alpha_patched_valid = true;
+    }
     pp.planes = c->plane[1].as<float>();
     pp.records = c->pat_rec.as<uint32_t>();
     pp.row_start = c->pat_row_start.as<uint32_t>();
@@ -3020,7 +3046,7 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
     memset(&po, 0, sizeof(po));
     if (c->color_out) {
       po.dst = c->rgb.p;
-      po.alpha = c->have_alpha ? c->alpha.as<float>() : nullptr;
+      po.alpha = c->have_alpha ? (c->alpha_patched_valid ? c->alpha_patched.as<float>() : c->alpha.as<float>()) : nullptr;
       po.xsize = c->oxs;
       po.ysize = c->oys;
       po.orient = c->out_orient;
@@ -3281,6 +3307,7 @@ int jxlhip_set_output_orientation(JxlHipContext* c, uint32_t orientation) {
 
 int jxlhip_set_alpha(JxlHipContext* c, const float* alpha, uint32_t xsize, uint32_t ysize) {
   if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->alpha_patched_valid = false;
   if (!alpha) {
     c->have_alpha = false;
     return 0;
@@ -3291,6 +3318,20 @@ int jxlhip_set_alpha(JxlHipContext* c, const float* alpha, uint32_t xsize, uint3
   if (r) return r;
   HIP_TRY(hipMemcpy(c->alpha.p, alpha, bytes, hipMemcpyHostToDevice));
   c->have_alpha = true;
+  return 0;
+}
+
+int jxlhip_download_alpha(JxlHipContext* c, float* dst) {
+  if (!c || !dst) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->have_alpha) return JXLHIP_ERR_NO_FRAME;
+  HIP_TRY(hipSetDevice(c->device));
+  {
+    int pw = ApplyPendingWait(c);
+    if (pw) return pw;
+  }
+  const Buf& a = c->alpha_patched_valid ? c->alpha_patched : c->alpha;
+  HIP_TRY(hipMemcpyAsync(dst, a.p, size_t(c->oxs) * c->oys * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -3554,6 +3595,7 @@ struct JxlHipCanvas {
   // frames of level 1..4 (passes_state.h:90 dc_frames: the DC image of a later frame with kUseDcFrame)
   Buf xyb[8];
   uint32_t xyb_w[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xyb_h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool xyb_alpha[8] = {false, false, false, false, false, false, false, false};  // a fourth plane: the frame's alpha
   hipStream_t last_stream = nullptr;  // the stream of the last blend: later work on the canvas is ordered behind it
 };
 
@@ -3614,12 +3656,26 @@ int jxlhip_canvas_save_xyb(JxlHipCanvas* v, JxlHipContext* c, uint32_t slot) {
   } else {
     return JXLHIP_ERR_NO_FRAME;
   }
-  int r = v->xyb[slot].Ensure(size_t(w) * h * 12);
+  // (the frame's extra channels are kept with it, for patches that blend through alpha: dec_patch_dictionary.cc:342-347)
+  const bool mod_alpha = c->mod.have && c->mod.has_alpha;
+  const bool with_alpha = mod_alpha || (!c->mod.have && c->have_alpha && c->alpha.cap >= size_t(w) * h * 4);
+  int r = v->xyb[slot].Ensure(size_t(w) * h * (with_alpha ? 16 : 12));
   if (r) return r;
   if (v->last_stream && v->last_stream != c->stream) HIP_TRY(hipStreamSynchronize(v->last_stream));
   hipLaunchKernelGGL(jxlhip::k_copy_planes, dim3((w + 255) / 256, h, 3), dim3(256), 0, c->stream, src, src_stride, src_plane,
                      v->xyb[slot].as<float>(), w, h);
   HIP_TRY(hipGetLastError());
+  if (mod_alpha) {
+    const JxlHipContext::Modular& M = c->mod;
+    const size_t n = size_t(w) * h;
+    hipLaunchKernelGGL(jxlhip::k_int_plane_to_float, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, c->stream,
+                       M.pool.as<int32_t>() + M.buf_off[M.out_buffer[M.num_color]], v->xyb[slot].as<float>() + n * 3, n,
+                       1.0f / float((uint64_t(1) << M.alpha_bits) - 1));
+    HIP_TRY(hipGetLastError());
+  } else if (with_alpha)
+    HIP_TRY(hipMemcpyAsync(v->xyb[slot].as<float>() + size_t(w) * h * 3, (c->alpha_patched_valid ? c->alpha_patched : c->alpha).p,
+                           size_t(w) * h * 4, hipMemcpyDeviceToDevice, c->stream));
+  v->xyb_alpha[slot] = with_alpha;
   HIP_TRY(hipStreamSynchronize(c->stream));  // (later frames read the slot from other streams of other contexts)
   v->xyb_w[slot] = w;
   v->xyb_h[slot] = h;
@@ -3633,6 +3689,12 @@ int jxlhip_canvas_xyb_source(JxlHipCanvas* v, uint32_t slot, const float** plane
   *planes = v->xyb_w[slot] ? v->xyb[slot].as<float>() : nullptr;
   *xsize = v->xyb_w[slot];
   *ysize = v->xyb_h[slot];
+  return 0;
+}
+
+int jxlhip_canvas_xyb_alpha(JxlHipCanvas* v, uint32_t slot, const float** alpha) {
+  if (!v || slot > 7 || !alpha) return JXLHIP_ERR_INVALID_ARGUMENT;
+  *alpha = (v->xyb_w[slot] && v->xyb_alpha[slot]) ? v->xyb[slot].as<float>() + size_t(v->xyb_w[slot]) * v->xyb_h[slot] * 3 : nullptr;
   return 0;
 }
 

@@ -80,6 +80,12 @@ __global__ __launch_bounds__(256) void k_canvas_blend(BlendParams P) {
 }
 
 // Three planes of w x h samples out of planes with a row stride (a frame's XYB planes into a reference slot).
+// An integer plane (a Modular frame's alpha channel) as floats in [0, 1]: sample * scale (dec_modular.cc:640-700).
+__global__ __launch_bounds__(256) void k_int_plane_to_float(const int32_t* __restrict__ src, float* __restrict__ dst, size_t n, float scale) {
+  const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) dst[i] = float(src[i]) * scale;
+}
+
 __global__ __launch_bounds__(256) void k_copy_planes(const float* __restrict__ src, size_t src_stride, size_t src_plane, float* __restrict__ dst,
                                                      uint32_t w, uint32_t h) {
   const uint32_t x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, c = blockIdx.z;

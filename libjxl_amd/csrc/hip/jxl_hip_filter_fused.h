@@ -1251,9 +1251,14 @@ __global__ __launch_bounds__(256) void k_splines_add_batch(const SplineParams* o
   if (y < P.y_end) SplinesAddRow(P, y);
 }
 
-// ---- patches (lib/jxl/dec_patch_dictionary.cc:317-356 AddOneRow + blending.cc PerformBlending for the alpha-free colour
-// modes): like the splines, one workgroup per row walks the row's positions in dictionary order and a thread owns the
-// samples x = tid (mod 256), so that overlapping patches combine in the order the dictionary gives.
+// ---- patches (lib/jxl/dec_patch_dictionary.cc:317-356 AddOneRow + blending.cc:40-190 PerformBlending + alpha.cc:17-101):
+// like the splines, one workgroup per row walks the row's positions in dictionary order and a thread owns the samples
+// x = tid (mod 256), so that overlapping patches combine in the order the dictionary gives. Every PatchBlendMode on the
+// colour channels; on images whose one extra channel is alpha, every mode on that channel too (`alpha` != NULL: the frame's
+// alpha plane, read before and written after each position like the reference's rows; slot_alpha: the reference frames').
+// The alpha channel's own mode is evaluated first, from the values before blending; the colour channels' blend above /
+// below then writes the alpha channel as well (blending.cc:127-136), whatever its own mode gave. Not contracted: the
+// oracle's (the reference's scalar) operation order.
 struct PatchParams {
   float* planes;  // [3] planes `plane_stride` floats apart, rows of `stride` floats
   const uint32_t* records;
@@ -1263,25 +1268,65 @@ struct PatchParams {
   uint32_t slot_w[4], slot_h[4];
   size_t stride, plane_stride;
   uint32_t xsize, y_begin, y_end;
+  float* alpha;                // NULL: the image has no alpha channel (modes 4 / 5 then replace, 6 / 7 add: blending.cc:154-168)
+  const float* slot_alpha[4];  // [slot_h][slot_w]
+  size_t alpha_stride;
+  uint32_t premultiplied;      // ExtraChannelInfo::alpha_associated
 };
+__device__ __forceinline__ float PatchClamp01(float v, bool clamp) { return clamp ? __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f) : v; }
 __global__ __launch_bounds__(256) void k_patches_add(PatchParams P) {
+#pragma clang fp contract(off)
   const uint32_t y = P.y_begin + blockIdx.x, tid = threadIdx.x;
   if (y >= P.y_end) return;
   for (uint32_t i = P.row_start[y]; i < P.row_start[y + 1]; i++) {
     const uint32_t* r = P.records + size_t(P.row_list[i]) * 8;
-    const uint32_t px = r[0], py = r[1], w = r[2], rx0 = r[4], ry0 = r[5], slot = r[6], mode = r[7] & 255, clamp = r[7] >> 8;
-    if (mode == 0) continue;
+    const uint32_t px = r[0], py = r[1], w = r[2], rx0 = r[4], ry0 = r[5], slot = r[6];
+    uint32_t mode = r[7] & 255;
+    const bool clamp = ((r[7] >> 8) & 1) != 0, ec_clamp = ((r[7] >> 24) & 1) != 0;
+    const uint32_t ec_mode = P.alpha ? (r[7] >> 16) & 255 : 0;
+    if (!P.alpha && mode >= 4) mode = mode >= 6 ? 2 : 1;
+    if (mode == 0 && ec_mode == 0) continue;
     const float* src = P.slot_planes[slot];
+    const float* src_a = P.alpha ? P.slot_alpha[slot] : nullptr;
     const size_t sw = P.slot_w[slot], splane = sw * P.slot_h[slot];
     const uint32_t x1 = min(px + w, P.xsize);
     for (uint32_t x = (px & ~255u) + tid; x < x1; x += 256) {
       if (x < px) continue;
       const size_t si = size_t(ry0 + (y - py)) * sw + rx0 + (x - px);
       float* p = P.planes + size_t(y) * P.stride + x;
+      float* ap = P.alpha ? P.alpha + size_t(y) * P.alpha_stride + x : nullptr;
+      const float fga = src_a ? src_a[si] : 1.0f, bga = ap ? *ap : 1.0f;
+      float a_out = bga;
+      switch (ec_mode) {
+        case 1: a_out = fga; break;
+        case 2: a_out = bga + fga; break;
+        case 3: a_out = bga * PatchClamp01(fga, ec_clamp); break;
+        case 4: a_out = 1.0f - (1.0f - PatchClamp01(fga, ec_clamp)) * (1.0f - bga); break;
+        case 5: a_out = 1.0f - (1.0f - PatchClamp01(bga, ec_clamp)) * (1.0f - fga); break;
+        case 7: a_out = fga; break;
+        default: break;  // kNone, and kAlphaWeightedAddAbove of a channel that is its own alpha: unchanged (alpha.cc:74-77)
+      }
+      // blend above: the patch over the frame; blend below: the frame over the patch (top / bottom layer of alpha.cc:17-43)
+      const float top_a = PatchClamp01(mode == 5 ? bga : fga, clamp), bot_a = mode == 5 ? fga : bga;
+      const float new_a = 1.0f - (1.0f - top_a) * (1.0f - bot_a);
+      const float rnew_a = new_a > 0.0f ? 1.0f / new_a : 0.0f;
       for (int c = 0; c < 3; c++) {
         const float fg = src[c * splane + si], bg = p[c * P.plane_stride];
-        p[c * P.plane_stride] = mode == 1 ? fg : (mode == 2 ? bg + fg : bg * (clamp ? __builtin_amdgcn_fmed3f(fg, 0.0f, 1.0f) : fg));
+        float o = bg;
+        switch (mode) {
+          case 1: o = fg; break;
+          case 2: o = bg + fg; break;
+          case 3: o = bg * PatchClamp01(fg, clamp); break;
+          case 4: o = P.premultiplied ? fg + bg * (1.0f - top_a) : (fg * top_a + bg * bga * (1.0f - top_a)) * rnew_a; break;
+          case 5: o = P.premultiplied ? bg + fg * (1.0f - top_a) : (bg * top_a + fg * fga * (1.0f - top_a)) * rnew_a; break;
+          case 6: o = bg + fg * PatchClamp01(fga, clamp); break;
+          case 7: o = fg + bg * PatchClamp01(bga, clamp); break;
+          default: break;
+        }
+        p[c * P.plane_stride] = o;
       }
+      if (mode == 4 || mode == 5) a_out = new_a;
+      if (ap) *ap = a_out;
     }
   }
 }

@@ -91,6 +91,7 @@ struct FramePlan {
   bool has_patches = false;
   std::vector<uint32_t> patch_records, patch_row_start, patch_row_list;
   const float* patch_src[4] = {nullptr, nullptr, nullptr, nullptr};  // device planes of the reference slots (set_patch_sources)
+  const float* patch_src_alpha[4] = {nullptr, nullptr, nullptr, nullptr};  // ... and their alpha planes (set_patch_alpha_sources)
   uint32_t patch_src_w[4] = {0, 0, 0, 0}, patch_src_h[4] = {0, 0, 0, 0};
   Splines splines;  // frame flag kSplines: dictionary + draw cache (jxh_splines.h)
   bool has_splines = false;

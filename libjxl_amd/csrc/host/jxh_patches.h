@@ -1,8 +1,9 @@
 // Patches of a frame (host half): the dictionary is entropy-decoded here (lib/jxl/dec_patch_dictionary.cc:32-175; contexts
 // patch_dictionary_internal.h:12-24) and laid out for the device: one record per patch position and, like the splines,
-// per-row lists in dictionary order that k_patches_add walks (dec_patch_dictionary.cc:317-356 AddOneRow; the colour modes
-// that need no alpha: kNone, kReplace, kAdd, kMul; extra channels must be left alone). The rectangles are checked against
-// the reference frames when the sources are known (jxlamd_frame_set_patch_sources).
+// per-row lists in dictionary order that k_patches_add walks (dec_patch_dictionary.cc:317-356 AddOneRow; every colour mode,
+// and every mode on the alpha channel of an image whose only extra channel is alpha: blending.cc:40-190; other extra
+// channels must be left alone). The rectangles are checked against the reference frames when the sources are known
+// (jxlamd_frame_set_patch_sources).
 #ifndef JXH_PATCHES_H_
 #define JXH_PATCHES_H_
 
@@ -19,12 +20,16 @@ struct PatchRef {
 };
 struct PatchPos {
   uint32_t x, y, ref;  // ref: index into refs
-  uint32_t mode;       // PatchBlendMode of the colour channels: 0 none, 1 replace, 2 add, 3 multiply
+  uint32_t mode;       // PatchBlendMode of the colour channels (dec_patch_dictionary.h:32-58): 0 none, 1 replace, 2 add, 3 multiply,
+                       // 4 / 5 blend above / below, 6 / 7 alpha-weighted add above / below
   bool clamp;
+  uint32_t ec_mode = 0;  // ... of the alpha channel (extra channel 0)
+  bool ec_clamp = false;
 };
 struct Patches {
   std::vector<PatchRef> refs;
   std::vector<PatchPos> pos;
+  bool uses_alpha = false;  // some position blends through alpha or changes the alpha channel
 };
 
 static inline void DecodePatches(BitReader& br, size_t xsize, size_t ysize, size_t num_extra, Patches* out) {
@@ -65,17 +70,24 @@ static inline void DecodePatches(BitReader& br, size_t xsize, size_t ysize, size
       JXH_CHECK(uint64_t(p.x) + r.xsize <= xsize && uint64_t(p.y) + r.ysize <= ysize, "patches: outside the frame");
       p.mode = 0;
       p.clamp = false;
-      for (size_t j = 0; j < num_extra + 1; j++) {
+      for (size_t j = 0; j < num_extra + 1; j++) {  // dec_patch_dictionary.cc:135-163
         const uint32_t mode = rd.Read(5);
         JXH_CHECK(mode < 8, "invalid patch blend mode");
-        JXH_CHECK(mode < 4, "unsupported: patches blended through an alpha channel");
+        if (mode >= 4 && num_extra > 1) JXH_CHECK(rd.Read(8) < num_extra, "invalid alpha channel for blending");
         bool clamp = false;
-        if (mode == 3) clamp = rd.Read(9) != 0;
+        if (mode >= 3) clamp = rd.Read(9) != 0;
         if (j == 0) {
           p.mode = mode;
           p.clamp = clamp;
+        } else if (j == 1) {
+          p.ec_mode = mode;
+          p.ec_clamp = clamp;
         } else {
-          JXH_CHECK(mode == 0, "unsupported: patches that touch extra channels");
+          JXH_CHECK(mode == 0, "unsupported: patches that touch extra channels other than alpha");
+        }
+        if (mode >= 4 || (j > 0 && mode != 0)) {
+          JXH_CHECK(num_extra <= 1, "unsupported: patches that blend through alpha in images with several extra channels");
+          out->uses_alpha = true;
         }
       }
       out->pos.push_back(p);
@@ -85,7 +97,8 @@ static inline void DecodePatches(BitReader& br, size_t xsize, size_t ysize, size
   JXH_CHECK(rd.FinalStateOk(), "patches: bad ANS final state");
 }
 
-// Device layout: 8 u32 per position {x, y, xsize, ysize, ref x0, ref y0, slot, mode | clamp << 8}; row y applies
+// Device layout: 8 u32 per position {x, y, xsize, ysize, ref x0, ref y0, slot, mode | clamp << 8 | the alpha channel's
+// mode << 16 | its clamp << 24}; row y applies
 // positions row_list[row_start[y] .. row_start[y + 1]) in dictionary order.
 static inline void BuildPatchRows(const Patches& P, size_t ysize, std::vector<uint32_t>* records, std::vector<uint32_t>* row_start,
                                   std::vector<uint32_t>* row_list) {
@@ -94,7 +107,8 @@ static inline void BuildPatchRows(const Patches& P, size_t ysize, std::vector<ui
   uint64_t total = 0;
   for (const PatchPos& q : P.pos) {
     const PatchRef& r = P.refs[q.ref];
-    const uint32_t rec[8] = {q.x, q.y, r.xsize, r.ysize, r.x0, r.y0, r.slot, q.mode | (q.clamp ? 256u : 0u)};
+    const uint32_t rec[8] = {q.x, q.y, r.xsize, r.ysize, r.x0, r.y0, r.slot,
+                             q.mode | (q.clamp ? 256u : 0u) | q.ec_mode << 16 | (q.ec_clamp ? 1u << 24 : 0u)};
     records->insert(records->end(), rec, rec + 8);
     total += r.ysize;
   }

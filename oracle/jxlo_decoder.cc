@@ -78,6 +78,7 @@ struct FrameState {
   Patches patches;
   bool has_patches = false;
   const XybSlot* xyb_slots = nullptr;  // the reference frames kept before their colour transform
+  std::vector<float> patch_alpha;      // the alpha channel the patch stage read and wrote (empty: the patches left it alone)
   float noise_lut[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool has_noise = false;
   MGlobal mglobal;
@@ -527,6 +528,21 @@ static void ReconstructGroup(FrameState* s, size_t g, const int32_t* coeffs) {
     }
 }
 
+// The frame's alpha channel as floats for the patch stage, when the patches blend through it or write it (blending.cc:47-56:
+// an image whose only extra channel is alpha; the patch stage sees the channel at the frame's resolution).
+static void PatchAlpha(FrameState* s, size_t xs, size_t ys) {
+  s->patch_alpha.clear();
+  const ImageHeader& ih = *s->ih;
+  if (!s->patches.uses_alpha || ih.extra.size() != 1 || ih.extra[0].type != 0) return;
+  JXLO_CHECK(s->fh.upsampling == 1 && (s->fh.ec_upsampling.empty() || s->fh.ec_upsampling[0] == 1),
+             "unsupported: patches that blend through alpha on upsampled frames");
+  const MChannel& ch = s->full.ch[s->modular_color_channels];
+  JXLO_CHECK(ch.w == xs && ch.h == ys, "alpha channel size");
+  const float af = float(1.0 / double((1u << ih.extra[0].bits) - 1));
+  s->patch_alpha.resize(xs * ys);
+  for (size_t i = 0; i < xs * ys; i++) s->patch_alpha[i] = float(ch.d[i]) * af;
+}
+
 // frame_index / nonvisible_index: the visible frames before this one and the invisible ones since (they seed the noise).
 // The frame is rendered at its own size; Decode() places it on the canvas (crop origin, blending with a reference slot).
 static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool want_dumps, size_t frame_index = 0,
@@ -716,7 +732,9 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     Planes3 patched;
     if (s->has_patches) {  // dec_cache.cc:193-197: patches, then splines
       patched = *cur;
-      ApplyPatches(s->patches, s->xyb_slots, patched.p[0].data(), patched.p[1].data(), patched.p[2].data(), patched.stride);
+      PatchAlpha(s, d.xsize, d.ysize);
+      ApplyPatches(s->patches, s->xyb_slots, patched.p[0].data(), patched.p[1].data(), patched.p[2].data(), patched.stride,
+                   s->patch_alpha.empty() ? nullptr : s->patch_alpha.data(), d.xsize, !ih.extra.empty() && ih.extra[0].alpha_associated);
       cur = &patched;
       if (want_dumps)
         for (int c = 0; c < 3; c++)
@@ -811,7 +829,11 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
         for (size_t i = 0; i < xs * ys; i++) out->rgbf[c * xs * ys + i] = float(ch.d[i]) * factor;
       }
     }
-    if (s->has_patches) ApplyPatches(s->patches, s->xyb_slots, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs);
+    if (s->has_patches) {
+      PatchAlpha(s, xs, ys);
+      ApplyPatches(s->patches, s->xyb_slots, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs,
+                   s->patch_alpha.empty() ? nullptr : s->patch_alpha.data(), xs, !ih.extra.empty() && ih.extra[0].alpha_associated);
+    }
     if (s->has_splines) {  // the same stage on the three colour channels of a Modular frame (default colour correlation: 0, 1)
       InitSplineDrawCache(&s->splines, xs, ys, s->base_corr_x, s->base_corr_b);
       DrawSplines(s->splines, out->rgbf.data(), out->rgbf.data() + xs * ys, out->rgbf.data() + 2 * xs * ys, xs, xs, ys);
@@ -845,7 +867,9 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
     const MChannel& ch = s->full.ch[s->modular_color_channels];
     const float af = float(1.0 / double((1u << ih.extra[0].bits) - 1));
     const uint32_t ecu = fh.ec_upsampling.empty() ? 1 : fh.ec_upsampling[0];
-    if (ecu == 1) {
+    if (!s->patch_alpha.empty()) {  // the patches have written the alpha channel too
+      alpha = s->patch_alpha;
+    } else if (ecu == 1) {
       alpha.resize(xs * ys);
       for (size_t i = 0; i < xs * ys; i++) alpha[i] = float(ch.d[i]) * af;
     } else {
@@ -937,6 +961,7 @@ static void Decode(const uint8_t* data, size_t size, Decoded* out, bool want_dum
       slot.w = out->out_xsize;
       slot.h = out->out_ysize;
       for (int c = 0; c < 3; c++) slot.p[c].assign(out->xyb_save.begin() + c * slot.w * slot.h, out->xyb_save.begin() + (c + 1) * slot.w * slot.h);
+      slot.alpha = out->alphaf;  // (the frame's extra channels are kept with it: dec_patch_dictionary.cc:342-347)
     }
     if (fh.frame_type == 1) {
       XybSlot& slot = xyb_slots[4 + fh.dc_level - 1];

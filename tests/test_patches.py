@@ -120,3 +120,114 @@ def test_patch_rectangles_are_checked_against_the_reference_frames(built):
     assert check([0, 1, 0, 0], [0, 59, 0, 0], [0, 48, 0, 0]) != 0 and b"outside" in L.jxlamd_last_error()
     assert check([0, 1, 0, 0], [0, 64, 0, 0], [0, 39, 0, 0]) != 0 and b"outside" in L.jxlamd_last_error()
     f.close()
+
+
+def _alpha_case(J):
+    """RGBA frame and RGBA atlas; positions over every colour mode and every alpha-channel mode, some overlapping."""
+    yy, xx = np.mgrid[0:200, 0:300]
+    img = np.dstack([J.synth_image(300, 200, seed=5), (40 + 150 * (0.5 + 0.5 * np.sin(xx / 23.0) * np.cos(yy / 17.0))).astype(np.uint8)])
+    ay, ax = np.mgrid[0:48, 0:64]
+    atlas = np.dstack([J.synth_image(64, 48, seed=9), ((ax * 4 + ay * 3) & 255).astype(np.uint8)])
+    pos = []
+    k = 0
+    for mode in range(8):
+        for ec_mode in range(8):
+            # (x, y, colour mode, clamp, alpha mode, alpha clamp): a 6 x 11 grid of 20 x 16 rectangles, a few pixels of overlap
+            pos.append((4 + (k % 13) * 22, 3 + (k // 13) * 17, mode, (k >> 1) & 1, ec_mode, k & 1))
+            k += 1
+    return img, atlas, [dict(x0=4, y0=6, xsize=24, ysize=18, positions=pos)]
+
+
+def _blend_np(bg, bga, fg, fga, mode, clamp, ec_mode, ec_clamp, premultiplied):
+    """blending.cc:40-190 + alpha.cc:17-101 for an image whose one extra channel is alpha, read independently of the oracle's
+    restatement: float32 arithmetic, array-wise. bg / fg: [3][h][w]; returns the blended colour planes and alpha."""
+    f = np.float32
+    c01 = lambda v: np.clip(v, f(0), f(1))
+    one = f(1)
+    a = {0: bga, 1: fga, 2: bga + fga, 3: bga * (c01(fga) if ec_clamp else fga),
+         4: one - (one - (c01(fga) if ec_clamp else fga)) * (one - bga), 5: one - (one - (c01(bga) if ec_clamp else bga)) * (one - fga),
+         6: bga, 7: fga}[ec_mode]
+    if mode == 0:
+        out = bg
+    elif mode == 1:
+        out = fg
+    elif mode == 2:
+        out = bg + fg
+    elif mode == 3:
+        out = bg * (c01(fg) if clamp else fg)
+    elif mode in (4, 5):
+        bot, bota, top, topa = (bg, bga, fg, fga) if mode == 4 else (fg, fga, bg, bga)
+        ta = c01(topa) if clamp else topa
+        new_a = one - (one - ta) * (one - bota)
+        if premultiplied:
+            out = top + bot * (one - ta)
+        else:
+            with np.errstate(divide="ignore"):
+                r = np.where(new_a > 0, one / new_a, f(0)).astype(f)
+            out = (top * ta + bot * bota * (one - ta)) * r
+        a = new_a
+    elif mode == 6:
+        out = bg + fg * (c01(fga) if clamp else fga)
+    else:
+        out = fg + bg * (c01(bga) if clamp else bga)
+    return out.astype(f), a.astype(f)
+
+
+@pytest.mark.parametrize("premultiplied", [False, True])
+def test_oracle_blends_patches_through_alpha_like_the_reference_text(built, premultiplied):
+    """Every PatchBlendMode on the colour channels x every one on the alpha channel (dec_patch_dictionary.h:32-58): the
+    oracle's patched XYB planes and alpha against a NumPy reading of blending.cc / alpha.cc applied to the frame decoded
+    without patches and the atlas decoded on its own."""
+    import jxlo
+    J = built
+    img, atlas, patches = _alpha_case(J)
+    data = J.encode_patched(img, atlas, patches, atlas_vardct=True, premultiplied=premultiplied)
+    o = jxlo.Decoded(data)
+    got, got_a = o.planes("xyb_filtered").copy(), o.buffer("alphaf").reshape(200, 300).copy()
+    o.close()
+    o = jxlo.Decoded(J.encode_rgba8(img))
+    bg, bga = o.planes("xyb_filtered").copy(), o.buffer("alphaf").reshape(200, 300).copy()
+    o.close()
+    o = jxlo.Decoded(J.encode_rgba8(atlas))
+    fg, fga = o.planes("xyb_filtered").copy(), o.buffer("alphaf").reshape(48, 64).copy()
+    o.close()
+    assert np.array_equal((bga * 255).round().astype(np.uint8), img[..., 3])
+    p = patches[0]
+    for (x, y, mode, clamp, ec_mode, ec_clamp) in p["positions"]:
+        sy, sx = slice(p["y0"], p["y0"] + p["ysize"]), slice(p["x0"], p["x0"] + p["xsize"])
+        dy, dx = slice(y, y + p["ysize"]), slice(x, x + p["xsize"])
+        out, a = _blend_np(bg[:, dy, dx], bga[dy, dx], fg[:, sy, sx], fga[sy, sx], mode, clamp, ec_mode, ec_clamp, premultiplied)
+        bg[:, dy, dx] = out
+        bga[dy, dx] = a
+    xs = 300
+    assert np.abs(got[:, :, :xs] - bg[:, :, :xs]).max() < 1e-6
+    assert np.abs(got_a - bga).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("premultiplied,atlas_vardct", [(False, True), (True, True), (False, False), (True, False)])
+def test_patches_that_blend_through_alpha_on_the_gpu(built, tmp_path, premultiplied, atlas_vardct):
+    """Every PatchBlendMode on the colour channels x every one on the alpha channel through JxlDecoder: the reference frame's
+    alpha travels with its XYB planes in the canvas slot, k_patches_add blends colour and alpha, and the pixel writer, the
+    extra-channel buffer and the canvas all see the blended alpha."""
+    import jxlo
+    J = built
+    img, atlas, patches = _alpha_case(J)
+    # (the reference frame as a VarDCT frame, or as libjxl codes its patch frames: an XYB Modular frame, alpha beside it)
+    data = J.encode_patched(img, atlas, patches, atlas_vardct=atlas_vardct, premultiplied=premultiplied)
+    o = jxlo.Decoded(data)
+    want8, wantf, wanta = o.rgb8.copy(), o.planes("rgbf").transpose(1, 2, 0).copy(), o.buffer("alphaf").reshape(200, 300).copy()
+    o.close()
+    assert np.abs(wanta - img[..., 3] / np.float32(255)).max() > 0.2  # (the patches really changed the alpha channel)
+    rc, events, out, px = R.run(data, tmp_path, "f32", 4)
+    assert rc == 0 and [e for e in events if e in ("FRAME", "FULL_IMAGE")] == ["FRAME", "FULL_IMAGE"], out
+    got = np.frombuffer(px, np.float32).reshape(200, 300, 4)
+    assert np.abs(got[..., 3] - wanta).max() < 1e-6
+    # (colour: a blend divides by the new alpha, which may be tiny: relative to the sample)
+    assert (np.abs(got[..., :3] - wantf) <= 1e-4 * np.maximum(1.0, np.abs(wantf))).all()
+    rc, events, out, px = R.run(data, tmp_path, "u8", 4, "ec")
+    assert rc == 0, out
+    got8 = np.frombuffer(px[:300 * 200 * 4], np.uint8).reshape(200, 300, 4)
+    assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 1
+    ec = np.frombuffer(px[300 * 200 * 4:], np.uint8).reshape(200, 300).astype(int)
+    assert np.abs(ec - np.rint(np.clip(wanta.astype(np.float64), 0, 1) * 255.0)).max() <= 1
