@@ -32,6 +32,11 @@ int jxlhip_canvas_download(JxlHipCanvas*, uint32_t, uint32_t, uint32_t, int, uin
 int jxlhip_canvas_download_alpha(JxlHipCanvas*, float*, size_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_canvas_save_xyb(JxlHipCanvas*, JxlHipContext*, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_canvas_xyb_source(JxlHipCanvas*, uint32_t, const float**, uint32_t*, uint32_t*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_canvas_xyb_alpha(JxlHipCanvas*, uint32_t, const float**) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_download_alpha(JxlHipContext*, float*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_upsample_plane(JxlHipContext*, const float*, uint32_t, uint32_t, uint32_t, const float*, uint32_t, uint32_t, int, float*) {
+  return JXLHIP_ERR_INVALID_ARGUMENT;
+}
 int jxlhip_set_option(JxlHipContext*, const char*, int) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 }
 
