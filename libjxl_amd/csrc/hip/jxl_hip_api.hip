@@ -273,6 +273,7 @@ struct JxlHipContext {
   bool have_alpha = false;
   bool color_out = false;   // the pixels come from k_color_out / k_upsample_color's generic writer (set at upload)
   Buf kend, block_recs, dequant_scan;
+  Buf trecs;     // the transform work lists as 16-byte varblock records (TransformParams::trecs)
   Buf ec_stage;  // jxlhip_upsample_plane: a coded extra channel, its kernels and (unless it becomes the alpha plane) the result
   std::vector<JxlHipVarBlock> blocks_host;  // for jxlhip_download("coeffs") of a scan-order frame
   std::vector<uint32_t> gbb_host;
@@ -526,7 +527,7 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
 static std::vector<Buf*> AllBufs(JxlHipContext* c) {
   std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc, &c->dc_raw, &c->dc_q, &c->dc_ep, &c->sharp,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->ec_stage, &c->alpha_patched, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->ec_stage, &c->alpha_patched, &c->trecs, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
                 &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob, &c->ups_planes};
   for (auto& pb : c->pass_bufs)
@@ -856,6 +857,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       add(size_t(q.orders_size) * 2); add(size_t(q.prefix_table_size) * 4); add(size_t(q.num_clusters) * 4);
     }
     add(size_t(d->num_passes) * sizeof(jxlhip::PassDev)); add(64 * 25 * 4); add((size_t(d->num_blocks) + 1) * 4);
+    add((size_t(d->num_blocks) + 1) * 16);
     add((size_t(d->num_blocks) + 16) * 4); add(sizeof(jxlhip::EntropyParams)); add(size_t(d->dequant_floats) * 4);
     add(size_t(d->splines.num_segments) * 32); add((size_t(d->ysize) + 1) * 4); add(size_t(d->splines.num_row_segments) * 4 + 16);
     add(size_t(d->patches.num_positions) * 32); add((size_t(d->ysize) + 1) * 4); add(size_t(d->patches.num_row_entries) * 4 + 16);
@@ -1155,6 +1157,29 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
       list[c->list_begin[s] + fill[s]++] = i;
     }
     if ((r = Upload(c, c->tlist, list.data(), list.size() * 4))) return r;
+    {
+      // ... and, in the same order, everything k_idct_fast needs to know of a varblock in ONE 16-byte load (the kernel's
+      // waves live for a handful of dependent memory round trips: list entry -> block -> coefficients was three of them):
+      // {bx | by << 16, raw quant field, element offset of its coefficients (group * 3 * 65536 + offset in the group's planes),
+      // index of the varblock (for its coefficient counts)}
+      void* st = nullptr;
+      if ((r = StageAlloc(c, list.size() * 16, &st))) return r;
+      uint32_t* rec = static_cast<uint32_t*>(st);
+      for (size_t j = 0; j < list.size(); j++) {
+        const uint32_t i = list[j];
+        if (i >= d->num_blocks || (j >= acc)) {
+          rec[4 * j] = rec[4 * j + 1] = rec[4 * j + 2] = rec[4 * j + 3] = 0;
+          continue;
+        }
+        const JxlHipVarBlock& v = d->blocks[i];
+        const uint32_t g = uint32_t(v.by >> 5) * d->xsize_groups + (v.bx >> 5);
+        rec[4 * j] = uint32_t(v.bx) | uint32_t(v.by) << 16;
+        rec[4 * j + 1] = v.qf;
+        rec[4 * j + 2] = g * (3u * 65536u) + v.coef_offset;
+        rec[4 * j + 3] = i;
+      }
+      if ((r = UploadStaged(c, c->trecs, st, list.size() * 16))) return r;
+    }
     uint32_t big = 0;
     for (int s = 21; s < 27; s++) big = big > count[s] ? big : count[s];
     if (big) {
@@ -1310,6 +1335,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   tp.out = PlaneHolder(c)->plane[0].as<float>();  // (a lender's buffer is checked again at launch: PrepareDownstream)
   tp.scratch = c->scratch.as<float>();
   tp.tlist = c->tlist.as<uint32_t>();
+  tp.trecs = c->trecs.as<uint4>();
   memcpy(tp.list_begin, c->list_begin, sizeof(tp.list_begin));
   memcpy(tp.list_count, c->list_count, sizeof(tp.list_count));
   tp.scan_order = c->scan_order ? 1 : 0;

@@ -902,6 +902,10 @@ struct TransformParams {
   // transform work lists: block indices bucketed by strategy (tlist[list_begin[s] .. + list_count[s]))
   const uint32_t* tlist;
   uint32_t list_begin[27], list_count[27];
+  // the same lists as records (k_idct_fast: one load instead of list entry -> JxlHipVarBlock): x = bx | by << 16, y = raw quant
+  // field, z = element offset of the varblock's coefficients in `coeffs` (channel 0; the channels are 65536 apart), w = the
+  // varblock's index (kend)
+  const uint4* trecs;
   // Chroma-subsampled YCbCr frames (JxlHipFrameDesc::chroma_hshift / _vshift; dec_group.cc:443-451): cs = hshift of channel c
   // in bit 2 * c, vshift in bit 2 * c + 1 (0 = 4:4:4). A varblock carries channel c only when it lies on the channel's grid;
   // the pixels then go to block (bx >> hshift, by >> vshift) of the channel's plane in `cs_out` (same geometry as `out`: the
@@ -1308,16 +1312,20 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
   float* l = lds_f + grp * TILE;
   const uint32_t li = wgd.y + grp;
   const bool active = li < n;
-  JxlHipVarBlock vb;
+  struct {
+    uint32_t bx, by, qf;
+  } vb = {0, 0, 1};
   const CoefT* gq = nullptr;
   const float* m = nullptr;
   uint32_t msize = 0, bidx = 0;
   float sc = 0, x_cc = 0, b_cc = 0;
   if (active) {
-    bidx = list[li];
-    vb = P.blocks[bidx];
-    const uint32_t g = (vb.by >> 5) * P.xg + (vb.bx >> 5);
-    gq = static_cast<const CoefT*>(P.coeffs) + size_t(g) * 3 * 65536 + vb.coef_offset;
+    const uint4 rec = P.trecs[P.list_begin[strategy] + li];
+    vb.bx = rec.x & 0xFFFFu;
+    vb.by = rec.x >> 16;
+    vb.qf = rec.y;
+    bidx = rec.w;
+    gq = static_cast<const CoefT*>(P.coeffs) + rec.z;
     const uint32_t kind = c_strategy_qtable[strategy];
     m = P.dequant + P.dq_offset[kind];
     msize = P.dq_size[kind];
@@ -1476,7 +1484,10 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
       for (int ky = 0; ky < R; ky++) v[ky] = l[ky * S + t];
       FastIdct<R>(v);
       // rows through a raw buffer: one 32-bit lane offset for the column, the row's offset in a scalar register (24 64-bit
-      // address computations per thread otherwise); three planes of at most 1 GiB: the offsets fit 32 bits
+      // address computations per thread otherwise); three planes of at most 1 GiB: the offsets fit 32 bits.
+      // (Measured and not kept, round 4: rows in the last pass, so that a thread stores C adjacent pixels as 16-byte pieces
+      // - a quarter of the store instructions, but 64 scattered pieces each instead of whole 32-byte-and-longer row segments:
+      // all transform launches 25.6 -> 34.2 ms; and a wave walking several sets of varblocks: no faster.)
       const __amdgpu_buffer_rsrc_t out_buf = __builtin_amdgcn_make_buffer_rsrc((CS && (hs | vs)) ? P.cs_out : P.out, 0, 0xFFFFFFFFu, 0x00020000);
       const uint32_t voff = (uint32_t(c) * P.xp * P.yp + oby * 8 * P.xp + obx * 8 + uint32_t(t)) * 4u;
       const uint32_t row_bytes = P.xp * 4u;
