@@ -1487,7 +1487,14 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
       // address computations per thread otherwise); three planes of at most 1 GiB: the offsets fit 32 bits.
       // (Measured and not kept, round 4: rows in the last pass, so that a thread stores C adjacent pixels as 16-byte pieces
       // - a quarter of the store instructions, but 64 scattered pieces each instead of whole 32-byte-and-longer row segments:
-      // all transform launches 25.6 -> 34.2 ms; and a wave walking several sets of varblocks: no faster.)
+      // all transform launches 25.6 -> 34.2 ms; a wave walking several sets of varblocks: no faster; the staging loads through
+      // raw buffers with two register sets instead of copies: 62 vector instructions fewer per wave of the 8x8 class, 12 more
+      // registers, 24.6 -> 26.0 ms.)
+      // The 8x8 class stores with the non-temporal hint (cache policy bit `nt`): its 32-byte row segments cost 13 % less
+      // that way (8.72 -> 7.59 ms per 640 frames alone; the stores are 44 % of this launch: 4.9 ms without them), while the
+      // 128-byte rows of the larger classes cost MORE with it (32x32: 8.40 -> 9.78 ms) and keep the default policy; sc0 and
+      // sc0 + nt are worse everywhere (profiles/r04_transform_store_policy.txt).
+      constexpr int kStoreAux = (CX == 1 && CY == 1) ? 2 : 0;
       const __amdgpu_buffer_rsrc_t out_buf = __builtin_amdgcn_make_buffer_rsrc((CS && (hs | vs)) ? P.cs_out : P.out, 0, 0xFFFFFFFFu, 0x00020000);
       const uint32_t voff = (uint32_t(c) * P.xp * P.yp + oby * 8 * P.xp + obx * 8 + uint32_t(t)) * 4u;
       const uint32_t row_bytes = P.xp * 4u;
@@ -1496,7 +1503,7 @@ __global__ __launch_bounds__(IdctFastThreads(CX, CY)) __attribute__((amdgpu_wave
         float r = v[y];
         if (c == 1) yout[y] = r;
         else r += cc * yout[y];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), out_buf, voff, uint32_t(y) * row_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), out_buf, voff, uint32_t(y) * row_bytes, kStoreAux);
       }
     }
     WaveLdsSync();
