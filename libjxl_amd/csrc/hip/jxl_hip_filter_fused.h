@@ -616,12 +616,14 @@ __device__ __forceinline__ P2 Srgb2ForU8(P2 v) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t RawBuffer(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
 }
+template <int AUX = 0>
 __device__ __forceinline__ float BufF32(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ P2 BufP2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
   typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-  const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
   const f2 f = __builtin_bit_cast(f2, v);  // (the whole vector: __builtin_bit_cast of one element reads element 0 with this clang)
   return P2{f.x, f.y};
 }
@@ -694,14 +696,15 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
     const int ym_next = MirrorI(y0 - HALO + 1, ys);
     ydir = ym_next > ym ? 1 : (ym_next < ym ? -1 : (ym == 0 ? -1 : 1));
   }
+  constexpr int kPlaneAux = 0;  // (default policy: neighbouring waves and strips re-read the halo)
   auto load_row = [&](P2 (&dst)[3]) {  // row ym, then advance the state machine
     const uint32_t row = uint32_t(ym) * uint32_t(P.f.xp) * 4u;
     if (paired) {
 #pragma unroll
-      for (int c = 0; c < 3; c++) dst[c] = BufP2(in_buf, vo0, row + c * plane_bytes);
+      for (int c = 0; c < 3; c++) dst[c] = BufP2<kPlaneAux>(in_buf, vo0, row + c * plane_bytes);
     } else {
 #pragma unroll
-      for (int c = 0; c < 3; c++) dst[c] = P2{BufF32(in_buf, vo0, row + c * plane_bytes), BufF32(in_buf, vo1, row + c * plane_bytes)};
+      for (int c = 0; c < 3; c++) dst[c] = P2{BufF32<kPlaneAux>(in_buf, vo0, row + c * plane_bytes), BufF32<kPlaneAux>(in_buf, vo1, row + c * plane_bytes)};
     }
     int nxt = ym + ydir;
     if (nxt < 0) {
@@ -907,11 +910,14 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
             uint32_t w2 = __builtin_amdgcn_cvt_pk_u8_f32(cg.y * 255.0f + di[1].y, 0, 0u);
             w2 = __builtin_amdgcn_cvt_pk_u8_f32(cb.y * 255.0f + di[2].y, 1, w2);
             const uint32_t orow = uint32_t(r) * uint32_t(xs) * 3u;  // (at most 16K x 16K x 3 bytes)
+            // (cache policy, measured alone / pipelined step: the non-temporal hint on these 2-byte stores 22.6 -> 24.0 ms /
+            // 58.2 -> 60.0 ms: they need the L2 to merge them into lines; on the plane loads 22.6 -> 24.8 ms)
+            constexpr int kRgbAux = 0;
             if (even) {  // six bytes from an even offset: 16-bit stores
-              __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01), rgb_buf, vout, orow, 0);
+              __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01), rgb_buf, vout, orow, kRgbAux);
               if (emit1) {
-                __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01 >> 16), rgb_buf, vout + 2, orow, 0);
-                __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w2), rgb_buf, vout + 4, orow, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01 >> 16), rgb_buf, vout + 2, orow, kRgbAux);
+                __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w2), rgb_buf, vout + 4, orow, kRgbAux);
               } else {
                 __builtin_amdgcn_raw_buffer_store_b8(uint8_t(w01 >> 16), rgb_buf, vout + 2, orow, 0);
               }
