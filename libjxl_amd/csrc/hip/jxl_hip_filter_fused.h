@@ -373,6 +373,19 @@ __device__ __forceinline__ float FromLeft(float v) {  // the value held by the l
 __device__ __forceinline__ float FromRight(float v) {  // the value held by the lane of column x + 1 (wave_shl:1)
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
 }
+// acc + FromLeft(v) * w / acc + FromRight(v) * w as ONE instruction. The compiler folds a neighbour-lane read into an add or
+// a multiply but not into a multiply-add (it picks the three-address form first, which has no DPP encoding, and only later
+// turns it into v_fmac): a v_mov_dpp + v_fma pair otherwise. `v` must not have been written by the two instructions before
+// (a DPP source needs two wait states behind a vector write, and inline assembly is not checked for it): here it is always a
+// value of an earlier step's ring.
+__device__ __forceinline__ float FmacFromLeft(float acc, float v, float w) {
+  asm("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(v), "v"(w));
+  return acc;
+}
+__device__ __forceinline__ float FmacFromRight(float acc, float v, float w) {
+  asm("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(v), "v"(w));
+  return acc;
+}
 
 __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows(const FusedFilterParams* params) {
   FusedFilterParams P;
@@ -767,7 +780,7 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
       for (int c = 0; c < 3; c++) {
         const P2 gn = g[c][N], gm = g[c][M1];
         a.x = __builtin_fabsf(gn.x - gn.y) * P.f.ch_scale[c] + a.x;  // |G(x) - G(x + 1)|: the pair's other element ...
-        a.y = __builtin_fabsf(gn.y - FromRight(gn.x)) * P.f.ch_scale[c] + a.y;  // ... and the next lane's first
+        a.y = __builtin_fabsf(FromRight(gn.x) - gn.y) * P.f.ch_scale[c] + a.y;  // ... and the next lane's first (the shifted operand first: it folds into the subtraction)
         b.x = __builtin_fabsf(gm.x - gn.x) * P.f.ch_scale[c] + b.x;
         b.y = __builtin_fabsf(gm.y - gn.y) * P.f.ch_scale[c] + b.y;
       }
@@ -788,10 +801,13 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
       {
         // no branch on the lane's sigma here: the DPP reads below must see their neighbours whatever the neighbours' own
         // sigma is (a lane switched off by a divergent branch reads as 0); the unfiltered pixels are selected at the end
-        const bool keep = is < -3.90524291751269967465540850526868f;  // sigma too small: pixels unchanged (the pair shares a block)
+        // sigma too small: pixels unchanged (the pair shares a block). Not a select per output: 1 / sigma becomes -infinity,
+        // every weight then max(0, sad * -inf + 1) = 0 (a zero sad gives NaN, and v_max returns its other operand), the sum
+        // of weights 1, its reciprocal exactly 1 and the output the centre pixel itself, bit for bit.
+        const float is_k = is < -3.90524291751269967465540850526868f ? -__builtin_inff() : is;
         const int rm1 = EPF == 2 ? (r1 < 0 ? -1 - r1 : (r1 >= ys ? 2 * ys - 1 - r1 : r1)) : r;  // (the EPF1 row, mirrored into the frame)
         const bool yb = ((rm1 & 7) == 0) || ((rm1 & 7) == 7);
-        const P2 inv_sig = P2{is * ((xb0 || yb) ? P.bsm[1] : P.sm[1]), is * ((xb1 || yb) ? P.bsm[1] : P.sm[1])};
+        const P2 inv_sig = P2{is_k * ((xb0 || yb) ? P.bsm[1] : P.sm[1]), is_k * ((xb1 || yb) ? P.bsm[1] : P.sm[1])};
         // neighbours in the reference's order: up, left, right, down (SADs pv_prev, ph of column x - 1, ph, pv)
         P2 wk[4];
         wk[0] = pv_prev * inv_sig + 1.0f;
@@ -809,12 +825,12 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
         for (int c = 0; c < 3; c++) {
           const P2 oc = o[c];
           P2 a = wk[0] * g[c][M3] + oc;
-          a.x = wk[1].x * FromLeft(oc.y) + a.x;
+          a.x = FmacFromLeft(a.x, oc.y, wk[1].x);
           a.y = wk[1].y * oc.x + a.y;
           a.x = wk[2].x * oc.y + a.x;
-          a.y = wk[2].y * FromRight(oc.x) + a.y;
+          a.y = FmacFromRight(a.y, oc.x, wk[2].y);
           a = wk[3] * g[c][M1] + a;
-          o[c] = P2{keep ? oc.x : a.x * inv_w.x, keep ? oc.y : a.y * inv_w.y};
+          o[c] = a * inv_w;
         }
       }
       if constexpr (EPF == 2) {
@@ -857,7 +873,11 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
 #pragma unroll
         for (int c = 0; c < 3; c++) o[c] = P2{keep2 ? e[c][M1].x : acc[c].x * inv_w2.x, keep2 ? e[c][M1].y : acc[c].y * inv_w2.y};
       }
-      if (emit0) {
+      // U8SRGB: only the stores sit under the lanes' emit mask. With the whole block under it the compiler sinks the EPF
+      // sums and the colour arithmetic into the masked region too (nothing else reads them) and must then take every
+      // neighbour-lane read out of it as a v_mov_dpp of its own (a DPP operand of a masked instruction reads a disabled
+      // neighbour as 0): 12 extra vector instructions per step.
+      if (U8SRGB || emit0) {
         if (!U8SRGB && filtered) {
           const size_t gi = size_t(r) * P.f.xp + x;
 #pragma unroll
@@ -913,7 +933,14 @@ __global__ __launch_bounds__(64 * kRowsWaves) void k_filter_rows2(const FusedFil
             // (cache policy, measured alone / pipelined step: the non-temporal hint on these 2-byte stores 22.6 -> 24.0 ms /
             // 58.2 -> 60.0 ms: they need the L2 to merge them into lines; on the plane loads 22.6 -> 24.8 ms)
             constexpr int kRgbAux = 0;
-            if (even) {  // six bytes from an even offset: 16-bit stores
+            // (the packed bytes exist for every lane before the masked stores: without this the optimiser sinks the
+            // arithmetic that only feeds them under the mask again)
+            if constexpr (U8SRGB) asm volatile("" : "+v"(w01), "+v"(w2));
+            // (the RGB stores are 11 % of the kernel: 22.6 ms alone, 20.0 without them. Measured and not kept: two lanes' twelve
+            // bytes as an 8-byte store of the even lane and a 4-byte one of the odd lane, 22.6 -> 22.8 ms, pipelined step + 3 %.)
+            if (U8SRGB && !emit0) {
+              // (a lane of the halo columns, or beyond the frame: nothing to store)
+            } else if (even) {  // six bytes from an even offset: 16-bit stores
               __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01), rgb_buf, vout, orow, kRgbAux);
               if (emit1) {
                 __builtin_amdgcn_raw_buffer_store_b16(uint16_t(w01 >> 16), rgb_buf, vout + 2, orow, kRgbAux);
