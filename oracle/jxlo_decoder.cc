@@ -1189,6 +1189,15 @@ void jxlo_color_kat(const float* xyb, size_t n, int linear, float* rgb) {
   }
 }
 
+// Known-answer hook for the chroma upsampling of subsampled YCbCr frames: `plane` holds ceil(xsize / 2) x ceil(ysize / 2) (or
+// xsize / ysize in the direction that is not subsampled) samples in its top-left part, rows of `stride` floats, `rows` rows in
+// all; upsampled in place (render_pipeline/stage_chroma_upsampling.cc:29-111).
+void jxlo_chroma_upsample_kat(float* plane, size_t stride, size_t xsize, size_t ysize, size_t rows, int horizontal, int vertical) {
+  std::vector<float> p(plane, plane + stride * rows);
+  jxlo::ChromaUpsample(&p, stride, xsize, ysize, rows, horizontal != 0, vertical != 0);
+  memcpy(plane, p.data(), p.size() * sizeof(float));
+}
+
 // Known-answer hook for the noise generator: `vectors` steps of the single-seed generator, 8 values each
 // (lib/jxl/xorshift128plus_test.cc:60-257 holds the expected values for seed 12345).
 void jxlo_xorshift_fill(uint64_t seed, uint64_t* out, size_t vectors) {

@@ -341,3 +341,56 @@ def test_coded_upsampling_weights_are_parsed_and_used(built):
     assert (np.abs(o.rgb8.astype(int) - plain.rgb8.astype(int)) > 2).mean() > 0.01
     o.close()
     plain.close()
+
+
+@pytest.mark.parametrize("xs,ys,h,v", [(17, 9, 1, 1), (16, 8, 1, 1), (33, 20, 1, 0), (20, 33, 0, 1), (1, 1, 1, 1), (2, 3, 1, 1)])
+def test_chroma_upsampling_against_a_numpy_reading(built, xs, ys, h, v):
+    """render_pipeline/stage_chroma_upsampling.cc:29-111 read independently: each stage turns a sample into two, 3/4 of itself
+    + 1/4 of the neighbour on that side (one multiply, one fused multiply-add), horizontally first; the stage's image is the
+    channel's own ceil(size / 2) samples and it mirrors about that (low_memory_render_pipeline.cc:348-355, 668-683). Odd
+    sizes, a single sample, both directions and each alone."""
+    import ctypes
+    import jxlo
+    L = jxlo.lib()
+    L.jxlo_chroma_upsample_kat.argtypes = [ctypes.c_void_p] + [ctypes.c_size_t] * 4 + [ctypes.c_int] * 2
+    L.jxlo_chroma_upsample_kat.restype = None
+    rng = np.random.default_rng(xs * 100 + ys)
+    stride, rows = xs + 7, ys + 5
+    ws, hs = ((xs + 1) // 2 if h else xs), ((ys + 1) // 2 if v else ys)
+    plane = np.full((rows, stride), np.nan, np.float32)
+    plane[:hs, :ws] = rng.normal(size=(hs, ws)).astype(np.float32)
+    src = plane[:hs, :ws].astype(np.float64)
+
+    def up(a, axis):  # one stage along `axis`, in float64 with the float32 roundings of Mul and MulAdd made explicit
+        a = np.moveaxis(a, axis, 0)
+        prev, nxt = np.concatenate([a[:1], a[:-1]]), np.concatenate([a[1:], a[-1:]])  # mirrored: the edge sample itself
+        cur = (a.astype(np.float32) * np.float32(0.75)).astype(np.float64)
+        out = np.empty((2 * a.shape[0],) + a.shape[1:], np.float64)
+        out[0::2] = (np.float32(0.25) * prev + cur).astype(np.float32)  # (exact in float64, rounded once: a fused multiply-add)
+        out[1::2] = (np.float32(0.25) * nxt + cur).astype(np.float32)
+        return np.moveaxis(out, 0, axis)
+
+    want = src
+    if h:
+        want = up(want, 1)
+    if v:
+        want = up(want, 0)
+    L.jxlo_chroma_upsample_kat(plane.ctypes.data, stride, xs, ys, rows, h, v)
+    assert np.array_equal(plane[:ys, :xs], want[:ys, :xs].astype(np.float32))
+
+
+@pytest.mark.parametrize("cs", [4, 8, 12, 1, 0b100100, 0b011011])
+def test_chroma_subsampled_round_trip_on_a_smooth_image(built, cs):
+    """No reference-made subsampled stream exists here, so the subsampled path is pinned by what it must reproduce: a smooth
+    image coded at d0.5 with its channels subsampled (the synthetic encoder box-averages them) comes back within 46 dB in
+    every mode. A half-sample phase error in the upsampling, a channel's blocks attached to the wrong varblocks or DC taken
+    from the wrong grid each cost 10 dB and more on this image."""
+    import jxlo
+    J = built
+    h, w = 277, 333
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 37.0) * np.cos(y / 29.0), 128 + 90 * np.cos(x / 23.0 + y / 41.0), 128 + 80 * np.sin(y / 31.0)], -1).clip(0, 255).astype(np.uint8)
+    o = jxlo.Decoded(J.encode_rgb8(img, distance=0.5, color_transform=2, chroma_subsampling=cs, strategy_mode=0), dumps=False)
+    d = o.rgb8[..., :3].astype(np.float64) - img
+    o.close()
+    assert 10 * np.log10(255.0 ** 2 / (d * d).mean()) > 46.0
