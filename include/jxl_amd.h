@@ -102,6 +102,8 @@ typedef struct JxlAmdModFrame JxlAmdModFrame;
 /* Parses the first frame of a codestream as a Modular frame: headers, TOC, global tree and histograms and every stream's
  * group header; no sample is decoded on the host. `data` must stay valid until the frame has been uploaded. */
 int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** frame);
+/* The reference frames a Modular frame's patches read: as jxlamd_frame_set_patch_sources (before the upload). */
+int jxlamd_modframe_set_patch_sources(JxlAmdModFrame* frame, const float* const* planes, const uint32_t* xsize, const uint32_t* ysize);
 /* As jxlamd_frame_parse_at / jxlamd_frame_end, for Modular frames. */
 int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlAmdModFrame** frame);
 size_t jxlamd_modframe_end(const JxlAmdModFrame* frame, uint32_t* duration_last_timecode);

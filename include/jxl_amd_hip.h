@@ -423,6 +423,9 @@ typedef struct JxlHipModFrameDesc {
   uint32_t num_color, has_alpha, bits, alpha_bits;
   /* splines over the three colour channels (as floats, before the sample conversion); colour images only */
   JxlHipSplines splines;
+  /* patches over the three colour channels, before the splines (dec_cache.cc:193-201), from the reference slots' planes; colour
+   * images only; not the modes that blend through the frame's alpha channel (uses_alpha must be 0) */
+  JxlHipPatches patches;
   /* XYB Modular frames (dec_modular.cc:583-631): the colour buffers hold Y, X, B - Y as integers in units of
    * xyb_factor[] = the DC quantisation steps of X, Y, B; the colour stage (opsin_inv scaled by 255 / intensity_target,
    * opsin_bias, linear_output as in JxlHipFrameDesc) makes the samples. */

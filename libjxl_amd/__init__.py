@@ -651,7 +651,7 @@ def encode_with_preview(img, preview, **kw):
     return m[:h] + pframe + m[h:]
 
 
-def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=False, premultiplied=False, **kw):
+def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=False, premultiplied=False, lossless_flags=None, **kw):
     """Test aid: a reference-only frame holding `atlas` (HxWx3 uint8; coded as an XYB Modular frame like libjxl's patch
     frames, or as a VarDCT frame) kept in `slot`, then `img` coded with a patch dictionary. patches: list of dicts with
     x0, y0, xsize, ysize (rectangle in the atlas) and positions: list of (x, y, mode, clamp[, alpha mode, alpha clamp]) with
@@ -679,11 +679,12 @@ def encode_patched(img, atlas, patches, slot=1, atlas_vardct=False, lossless=Fal
         E.jxlenc_set_alpha_premultiplied(1 if premultiplied else 0)  # (the alpha channel is declared associated; samples as given)
         E.jxlenc_set_image_size(img.shape[1], img.shape[0])
         E.jxlenc_set_reference_frame(slot)
-        first = (encode_rgba8(atlas, **kw) if atlas.shape[2] == 4 else encode_rgb8(atlas, **kw)) if atlas_vardct else encode_lossless(atlas, MODULAR_XYB)
+        mflags = MODULAR_XYB if lossless_flags is None else lossless_flags  # (lossless_flags: both frames Modular, e.g. plain RGB with an RCT)
+        first = (encode_rgba8(atlas, **kw) if atlas.shape[2] == 4 else encode_rgb8(atlas, **kw)) if atlas_vardct else encode_lossless(atlas, mflags)
         E.jxlenc_set_reference_frame(-1)
         arr = (ctypes.c_int32 * len(flat))(*flat)
         E.jxlenc_set_patches(arr, len(flat))
-        second = encode_lossless(img, MODULAR_XYB) if lossless else (encode_rgba8(img, **kw) if img.shape[2] == 4 else encode_rgb8(img, **kw))
+        second = encode_lossless(img, mflags) if lossless else (encode_rgba8(img, **kw) if img.shape[2] == 4 else encode_rgb8(img, **kw))
         return first + second[E.jxlenc_last_header_bytes():]
     finally:
         E.jxlenc_set_alpha_premultiplied(0)

@@ -458,6 +458,26 @@ extern "C" {
 int jxlamd_modframe_parse(const uint8_t* data, size_t size, JxlAmdModFrame** out) {
   return jxlamd_modframe_parse_at(data, size, 0, 0, out);
 }
+int jxlamd_modframe_set_patch_sources(JxlAmdModFrame* f, const float* const* planes, const uint32_t* xs, const uint32_t* ys) {
+  g_last_error.clear();
+  jxh::ModFramePlan& P = f->plan;
+  for (int i = 0; i < 4; i++) {
+    P.patch_src[i] = planes[i];
+    P.patch_src_w[i] = planes[i] ? xs[i] : 0;
+    P.patch_src_h[i] = planes[i] ? ys[i] : 0;
+  }
+  for (const jxh::PatchRef& r : P.patches.refs) {  // dec_patch_dictionary.cc:63-83
+    if (!P.patch_src[r.slot]) {
+      g_last_error = "patches: the reference frame is missing";
+      return 2;
+    }
+    if (uint64_t(r.x0) + r.xsize > P.patch_src_w[r.slot] || uint64_t(r.y0) + r.ysize > P.patch_src_h[r.slot]) {
+      g_last_error = "patches: rectangle outside the reference frame";
+      return 2;
+    }
+  }
+  return 0;
+}
 
 int jxlamd_modframe_parse_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlAmdModFrame** out) {
   g_last_error.clear();
@@ -657,6 +677,19 @@ int jxlamd_modframe_upload(const JxlAmdModFrame* f, JxlHipContext* ctx) {
   d.bits = P.ih.bits;
   d.alpha_bits = P.alpha_bits;
   FillSplines(P.has_splines, P.splines, &d.splines);
+  memset(&d.patches, 0, sizeof(d.patches));
+  if (P.has_patches && !P.patches.pos.empty()) {
+    d.patches.num_positions = uint32_t(P.patches.pos.size());
+    d.patches.num_row_entries = uint32_t(P.patch_row_list.size());
+    d.patches.records = P.patch_records.data();
+    d.patches.row_start = P.patch_row_start.data();
+    d.patches.row_list = P.patch_row_list.data();
+    for (int i = 0; i < 4; i++) {
+      d.patches.slot_planes[i] = P.patch_src[i];
+      d.patches.slot_w[i] = P.patch_src_w[i];
+      d.patches.slot_h[i] = P.patch_src_h[i];
+    }
+  }
   d.xyb = P.xyb ? 1 : 0;
   for (int c = 0; c < 3; c++) {
     d.xyb_factor[c] = P.dc_quant[c];
@@ -1176,6 +1209,12 @@ JxlDecoderStatus DecodeModularPixels(JxlDecoder* d, bool to_canvas) {
     JxlAmdFramePlacement pl;
     jxlamd_modframe_placement(d->mframe, &pl);
     if (!r) r = jxlhip_set_option(d->ctx, "keep_xyb_planes", (pl.frame_type == 2 || pl.frame_type == 1) ? 1 : 0);
+  }
+  if (!r && d->mframe->plan.has_patches) {  // the reference frames the patches read: the XYB slots of the canvas
+    const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t pw[4] = {0, 0, 0, 0}, ph[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < 4 && d->canvas; i++) jxlhip_canvas_xyb_source(d->canvas, i, &planes[i], &pw[i], &ph[i]);
+    if (jxlamd_modframe_set_patch_sources(d->mframe, planes, pw, ph)) return Fail(d, g_last_error);
   }
   if (!r) r = jxlamd_modframe_upload(d->mframe, d->ctx);
   if (!r) r = jxlhip_modular_run(d->ctx);

@@ -721,6 +721,47 @@ static int BlobEnd(JxlHipContext* c, const jxlhip::DcSmoothParams* smooth = null
   return 0;
 }
 
+// The patch dictionary of a frame to the device: validated like every table a kernel indexes with (rectangles inside the
+// frame and inside their reference frame, row lists consistent). ysize rows; positions may reach xlimit x ylimit.
+static int UploadPatches(JxlHipContext* c, const JxlHipPatches& pt, uint32_t ysize, uint32_t xlimit, uint32_t ylimit) {
+  c->pat_positions = 0;
+  c->pat_uses_alpha = false;
+  c->alpha_patched_valid = false;
+  if (!pt.num_positions) return 0;
+  int r;
+  if (!pt.records || !pt.row_start || !pt.row_list || pt.num_positions > (1u << 24) || pt.num_row_entries > (1u << 26)) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (pt.row_start[0] != 0 || pt.row_start[ysize] != pt.num_row_entries) return JXLHIP_ERR_INVALID_ARGUMENT;
+  for (uint32_t y = 0; y < ysize; y++)
+    if (pt.row_start[y] > pt.row_start[y + 1]) return JXLHIP_ERR_INVALID_ARGUMENT;
+  for (uint32_t i = 0; i < pt.num_positions; i++) {
+    const uint32_t* q = pt.records + size_t(i) * 8;
+    const uint32_t slot = q[6];
+    if (slot > 3 || !pt.slot_planes[slot] || (q[7] & 255) > 7 || ((q[7] >> 16) & 255) > 7 || !q[2] || !q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (pt.uses_alpha && !pt.slot_alpha[slot]) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the reference frame kept no alpha plane)
+    if (uint64_t(q[4]) + q[2] > pt.slot_w[slot] || uint64_t(q[5]) + q[3] > pt.slot_h[slot]) return JXLHIP_ERR_INVALID_ARGUMENT;
+    if (uint64_t(q[0]) + q[2] > xlimit || uint64_t(q[1]) + q[3] > ylimit) return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
+  for (uint32_t y = 0; y < ysize; y++)
+    for (uint32_t i = pt.row_start[y]; i < pt.row_start[y + 1]; i++) {
+      if (pt.row_list[i] >= pt.num_positions) return JXLHIP_ERR_INVALID_ARGUMENT;
+      const uint32_t* q = pt.records + size_t(pt.row_list[i]) * 8;
+      if (y < q[1] || y >= q[1] + q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the row is one of the patch's rows)
+    }
+  if ((r = Upload(c, c->pat_rec, pt.records, size_t(pt.num_positions) * 32))) return r;
+  if ((r = Upload(c, c->pat_row_start, pt.row_start, (size_t(ysize) + 1) * 4))) return r;
+  if ((r = Upload(c, c->pat_row_list, pt.row_list, std::max<size_t>(4, size_t(pt.num_row_entries) * 4)))) return r;
+  c->pat_uses_alpha = pt.uses_alpha != 0;
+  c->pat_premultiplied = pt.premultiplied != 0;
+  for (int i = 0; i < 4; i++) {
+    c->pat_src_alpha[i] = pt.slot_alpha[i];
+    c->pat_src[i] = pt.slot_planes[i];
+    c->pat_src_w[i] = pt.slot_w[i];
+    c->pat_src_h[i] = pt.slot_h[i];
+  }
+  c->pat_positions = pt.num_positions;
+  return 0;
+}
+
 int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (!c || !d) return JXLHIP_ERR_INVALID_ARGUMENT;
   // measurement aid: JXLHIP_UPLOAD_PROF=1 prints where the host time of an upload goes (microseconds per phase)
@@ -1093,44 +1134,9 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   if (d->splines.num_segments) c->color_out = true;
   if ((r = UploadSplines(c, d->splines, c->ys))) return r;
   // patches: validated like every table a kernel indexes with (rectangles inside the frame and inside their reference)
-  c->pat_positions = 0;
-  c->pat_uses_alpha = false;
-  c->alpha_patched_valid = false;
-  if (d->patches.num_positions) {
-    const JxlHipPatches& pt = d->patches;
-    if (!pt.records || !pt.row_start || !pt.row_list || pt.num_positions > (1u << 24) || pt.num_row_entries > (1u << 26)) return JXLHIP_ERR_INVALID_ARGUMENT;
-    if (pt.row_start[0] != 0 || pt.row_start[c->ys] != pt.num_row_entries) return JXLHIP_ERR_INVALID_ARGUMENT;
-    for (uint32_t y = 0; y < c->ys; y++)
-      if (pt.row_start[y] > pt.row_start[y + 1]) return JXLHIP_ERR_INVALID_ARGUMENT;
-    for (uint32_t i = 0; i < pt.num_positions; i++) {
-      const uint32_t* q = pt.records + size_t(i) * 8;
-      const uint32_t slot = q[6];
-      if (slot > 3 || !pt.slot_planes[slot] || (q[7] & 255) > 7 || ((q[7] >> 16) & 255) > 7 || !q[2] || !q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;
-      if (pt.uses_alpha && !pt.slot_alpha[slot]) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the reference frame kept no alpha plane)
-      if (uint64_t(q[4]) + q[2] > pt.slot_w[slot] || uint64_t(q[5]) + q[3] > pt.slot_h[slot]) return JXLHIP_ERR_INVALID_ARGUMENT;
-      if (uint64_t(q[0]) + q[2] > c->xp || uint64_t(q[1]) + q[3] > c->yp) return JXLHIP_ERR_INVALID_ARGUMENT;
-    }
-    for (uint32_t y = 0; y < c->ys; y++)
-      for (uint32_t i = pt.row_start[y]; i < pt.row_start[y + 1]; i++) {
-        if (pt.row_list[i] >= pt.num_positions) return JXLHIP_ERR_INVALID_ARGUMENT;
-        const uint32_t* q = pt.records + size_t(pt.row_list[i]) * 8;
-        if (y < q[1] || y >= q[1] + q[3]) return JXLHIP_ERR_INVALID_ARGUMENT;  // (the row is one of the patch's rows)
-      }
-    c->color_out = true;
-    if ((r = Upload(c, c->pat_rec, pt.records, size_t(pt.num_positions) * 32))) return r;
-    if ((r = Upload(c, c->pat_row_start, pt.row_start, (size_t(c->ys) + 1) * 4))) return r;
-    if ((r = Upload(c, c->pat_row_list, pt.row_list, std::max<size_t>(4, size_t(pt.num_row_entries) * 4)))) return r;
-    if (pt.uses_alpha && c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
-    c->pat_uses_alpha = pt.uses_alpha != 0;
-    c->pat_premultiplied = pt.premultiplied != 0;
-    for (int i = 0; i < 4; i++) {
-      c->pat_src_alpha[i] = pt.slot_alpha[i];
-      c->pat_src[i] = pt.slot_planes[i];
-      c->pat_src_w[i] = pt.slot_w[i];
-      c->pat_src_h[i] = pt.slot_h[i];
-    }
-    c->pat_positions = pt.num_positions;
-  }
+  if ((r = UploadPatches(c, d->patches, c->ys, c->xp, c->yp))) return r;
+  if (c->pat_positions) c->color_out = true;
+  if (c->pat_uses_alpha && c->ups != 1) return JXLHIP_ERR_UNSUPPORTED;
   if (c->have_alpha && c->alpha.cap < size_t(c->oxs) * c->oys * 4) return JXLHIP_ERR_INVALID_ARGUMENT;
   if ((c->keep_filtered || c->ups != 1 || c->color_out) && (r = c->plane[1].Ensure(plane_bytes))) return r;
   if ((r = c->rgb.Ensure(size_t(c->oxs) * c->oys * OutPixelBytes(c)))) return r;
@@ -2625,8 +2631,11 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
     M.xyb_color.linear_output = d->linear_output;
   }
   if ((r = UploadSplines(c, d->splines, d->ysize))) return r;
-  if ((c->spl_segments || c->keep_xyb) && d->num_color != 3) return JXLHIP_ERR_UNSUPPORTED;
-  if ((c->spl_segments || c->keep_xyb) && (r = c->spl_planes.Ensure(size_t(d->xsize) * d->ysize * 3 * 4))) return r;
+  if (d->patches.num_positions && d->patches.uses_alpha) return JXLHIP_ERR_UNSUPPORTED;  // (the frame's alpha is an integer channel here)
+  if ((r = UploadPatches(c, d->patches, d->ysize, d->xsize, d->ysize))) return r;
+  const bool float_planes = c->spl_segments || c->keep_xyb || c->pat_positions;
+  if (float_planes && d->num_color != 3) return JXLHIP_ERR_UNSUPPORTED;
+  if (float_planes && (r = c->spl_planes.Ensure(size_t(d->xsize) * d->ysize * 3 * 4))) return r;
   M.have = true;
   M.batch_ctxs.clear();
   c->generation++;
@@ -2717,15 +2726,35 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
       if (L.count) launches->push_back(L);
     }
   }
-  // frames with splines: colour samples to float planes (kind 4), the splines over them (kind 5), then the output reads them
-  for (uint32_t pass = 4; pass <= 5; pass++) {
+  // frames with patches / splines: colour samples to float planes (kind 4), the patches (kind 6), then the splines (kind 5)
+  // over them (dec_cache.cc:193-201), then the output reads them
+  for (uint32_t pass : {4u, 6u, 5u}) {
     align();
     ModLaunch S{pass, blob->size(), 0, 0, 0};
     for (size_t i = 0; i < n; i++) {
       const JxlHipContext* c = ctxs[i];
       const JxlHipContext::Modular& M = c->mod;
-      if (pass == 4 ? !(c->spl_segments || c->keep_xyb) : !c->spl_segments) continue;
-      if (pass == 4) {
+      if (pass == 4 ? !(c->spl_segments || c->keep_xyb || c->pat_positions) : (pass == 6 ? !c->pat_positions : !c->spl_segments)) continue;
+      if (pass == 6) {
+        jxlhip::PatchParams pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.planes = c->spl_planes.as<float>();
+        pp.records = c->pat_rec.as<uint32_t>();
+        pp.row_start = c->pat_row_start.as<uint32_t>();
+        pp.row_list = c->pat_row_list.as<uint32_t>();
+        for (int k = 0; k < 4; k++) {
+          pp.slot_planes[k] = c->pat_src[k];
+          pp.slot_w[k] = c->pat_src_w[k];
+          pp.slot_h[k] = c->pat_src_h[k];
+        }
+        pp.stride = M.xs;
+        pp.plane_stride = size_t(M.xs) * M.ys;
+        pp.xsize = M.xs;
+        pp.y_begin = 0;
+        pp.y_end = M.ys;
+        append(&pp, sizeof(pp));
+        S.gx = 1;
+      } else if (pass == 4) {
         jxlhip::ModOutput o;
         memset(&o, 0, sizeof(o));
         for (uint32_t j = 0; j < 3; j++) {
@@ -2770,7 +2799,7 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
     int32_t* pool = M.pool.as<int32_t>();
     jxlhip::ModOutput o;
     memset(&o, 0, sizeof(o));
-    if (c->spl_segments || c->keep_xyb) {
+    if (c->spl_segments || c->keep_xyb || c->pat_positions) {
       o.fplanes = c->spl_planes.as<float>();
       o.fmode = 2;
     }
@@ -2816,6 +2845,8 @@ static int ModularLaunchOps(const std::vector<ModLaunch>& launches, const uint8_
         hipLaunchKernelGGL(jxlhip::k_modular_unsqueeze, dim3(L.gx, zn), dim3(64), 0, st, reinterpret_cast<const jxlhip::ModUnsqueeze*>(dev + L.offset) + z);
       else if (L.kind == 5)  // (one workgroup per row: the full height, not the strided grid of the sample kernels)
         hipLaunchKernelGGL(jxlhip::k_splines_add_batch, dim3(L.gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::SplineParams*>(dev + L.offset) + z);
+      else if (L.kind == 6)
+        hipLaunchKernelGGL(jxlhip::k_patches_add_batch, dim3(L.gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::PatchParams*>(dev + L.offset) + z);
       else
         hipLaunchKernelGGL(jxlhip::k_modular_output, dim3(L.gx, gy, zn), dim3(256), 0, st, reinterpret_cast<const jxlhip::ModOutput*>(dev + L.offset) + z);
       HIP_TRY(hipGetLastError());

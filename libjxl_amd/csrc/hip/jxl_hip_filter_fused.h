@@ -1307,10 +1307,8 @@ struct PatchParams {
   uint32_t premultiplied;      // ExtraChannelInfo::alpha_associated
 };
 __device__ __forceinline__ float PatchClamp01(float v, bool clamp) { return clamp ? __builtin_amdgcn_fmed3f(v, 0.0f, 1.0f) : v; }
-__global__ __launch_bounds__(256) void k_patches_add(PatchParams P) {
+__device__ __forceinline__ void PatchesAddRow(const PatchParams& P, uint32_t y, uint32_t tid) {
 #pragma clang fp contract(off)
-  const uint32_t y = P.y_begin + blockIdx.x, tid = threadIdx.x;
-  if (y >= P.y_end) return;
   for (uint32_t i = P.row_start[y]; i < P.row_start[y + 1]; i++) {
     const uint32_t* r = P.records + size_t(P.row_list[i]) * 8;
     const uint32_t px = r[0], py = r[1], w = r[2], rx0 = r[4], ry0 = r[5], slot = r[6];
@@ -1362,6 +1360,17 @@ __global__ __launch_bounds__(256) void k_patches_add(PatchParams P) {
       if (ap) *ap = a_out;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_patches_add(PatchParams P) {
+  const uint32_t y = P.y_begin + blockIdx.x;
+  if (y < P.y_end) PatchesAddRow(P, y, threadIdx.x);
+}
+// The same for a set of frames (the Modular path's parameter-block launches): one grid row of workgroups per frame.
+__global__ __launch_bounds__(256) void k_patches_add_batch(const PatchParams* ops) {
+  const PatchParams& P = ops[blockIdx.y];
+  const uint32_t y = P.y_begin + blockIdx.x;
+  if (y < P.y_end) PatchesAddRow(P, y, threadIdx.x);
 }
 
 }  // namespace jxlhip

@@ -55,6 +55,12 @@ struct ModFramePlan {
   float dc_quant[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
   Splines splines;  // frame flag kSplines: drawn over the colour channels before the sample conversion
   bool has_splines = false;
+  // frame flag kPatches (dec_frame.cc:271-285): drawn over the colour channels before the splines, like on a VarDCT frame
+  Patches patches;
+  bool has_patches = false;
+  std::vector<uint32_t> patch_records, patch_row_start, patch_row_list;
+  const float* patch_src[4] = {nullptr, nullptr, nullptr, nullptr};  // device planes of the reference slots (set_patch_sources)
+  uint32_t patch_src_w[4] = {0, 0, 0, 0}, patch_src_h[4] = {0, 0, 0, 0};
 };
 
 class ModFrameParser {
@@ -76,8 +82,7 @@ class ModFrameParser {
     JXH_CHECK(!(ih.xyb_encoded && ih.gray), "unsupported: grey XYB Modular frames");
     JXH_CHECK(fh.upsampling == 1 && fh.num_passes == 1, "unsupported: upsampled / multi-pass Modular frames");
     for (uint32_t u : fh.ec_upsampling) JXH_CHECK(u == 1, "unsupported: upsampled extra channels");
-    JXH_CHECK(!(fh.flags & (FrameHeader::kPatches | FrameHeader::kNoise | FrameHeader::kUseDcFrame)),
-              "unsupported: patches/noise/DC frames");
+    JXH_CHECK(!(fh.flags & (FrameHeader::kNoise | FrameHeader::kUseDcFrame)), "unsupported: noise / kUseDcFrame on Modular frames");
     JXH_CHECK(!ih.floating && ih.bits <= 16, "unsupported: float or > 16-bit samples");
     P.dim = MakeFrameDim(fh);
     const FrameDim& d = P.dim;
@@ -96,6 +101,14 @@ class ModFrameParser {
     P.trees.assign(1, MTree());
     P.codes.assign(1, EntropyCode());
     BitReader g(data_ + P.section_offset[0], P.section_size[0]);
+    if (fh.flags & FrameHeader::kPatches) {  // dec_frame.cc:271-285: the dictionary comes first in DC global
+      JXH_CHECK(!ih.gray, "unsupported: patches on grey images");
+      DecodePatches(g, d.xsize, d.ysize, ih.extra.size(), &P.patches);
+      // (a Modular frame's alpha channel lives with its integer channels: blending through it is not wired up)
+      JXH_CHECK(!P.patches.uses_alpha || ih.extra.empty(), "unsupported: patches that blend through alpha on Modular frames");
+      BuildPatchRows(P.patches, d.ysize, &P.patch_records, &P.patch_row_start, &P.patch_row_list);
+      P.has_patches = true;
+    }
     if (fh.flags & FrameHeader::kSplines) {  // dec_frame.cc:289-308; a Modular frame has the default colour correlation (0, 1)
       JXH_CHECK(!ih.gray, "unsupported: splines on grey images");
       DecodeSplines(g, d.xsize * d.ysize, &P.splines);

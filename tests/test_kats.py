@@ -195,7 +195,9 @@ def test_host_front_end_under_sanitizers_on_damaged_streams(built, tmp_path):
                J.encode_random(264, 200, seed=5, color_transform=2, chroma_subsampling=0b011011),
                J.encode_rgb8(img, color_transform=1), J.encode_rgba8(np.dstack([img, img[..., 0]]), upsampling=2, ec_upsampling=4),
                J.encode_patched(np.dstack([img, img[..., 1]]), np.dstack([J.synth_image(64, 48, seed=9), np.full((48, 64), 99, np.uint8)]),
-                                [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(10, 10, 4, 1, 5, 0), (250, 170, 7, 0, 3, 1)])], atlas_vardct=True)]
+                                [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(10, 10, 4, 1, 5, 0), (250, 170, 7, 0, 3, 1)])], atlas_vardct=True),
+               J.encode_patched(img, J.synth_image(64, 48, seed=9), [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(10, 10, 2, 0), (250, 170, 5, 0)])],
+                                lossless=True, lossless_flags=J.LOSSLESS_RCT)]
     J.set_custom_upsampling(7, seed=3)
     try:
         streams.append(J.encode_rgb8(img, upsampling=4))

@@ -231,3 +231,29 @@ def test_patches_that_blend_through_alpha_on_the_gpu(built, tmp_path, premultipl
     assert np.abs(got8.astype(int) - want8.astype(int)).max() <= 1
     ec = np.frombuffer(px[300 * 200 * 4:], np.uint8).reshape(200, 300).astype(int)
     assert np.abs(ec - np.rint(np.clip(wanta.astype(np.float64), 0, 1) * 255.0)).max() <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["xyb", "rgb"])
+def test_patches_on_a_modular_frame(built, tmp_path, kind):
+    """A Modular frame with a patch dictionary (what libjxl's lossless mode writes for screen content: the frame flag is read
+    in DC global like a VarDCT frame's, dec_frame.cc:271-285): the colour samples go to float planes, the patches are drawn
+    over them from the reference slot, then the pixel writer reads them back. XYB-coded ("lossy Modular") and plain RGB
+    (RCT) frames; add, replace, multiply and the alpha-less forms of the blend modes (blending.cc:154-168), overlapping."""
+    import jxlo
+    J = built
+    img, atlas, _ = _case(J)
+    patches = [dict(x0=4, y0=6, xsize=20, ysize=16, positions=[(10, 10, 2, 0), (100, 50, 1, 0), (250, 170, 4, 0), (255, 175, 6, 1)]),
+               dict(x0=30, y0=0, xsize=30, ysize=40, positions=[(60, 120, 3, 1), (200, 20, 7, 0), (270, 160, 0, 0), (5, 150, 5, 0)])]
+    data = J.encode_patched(img, atlas, patches, lossless=True, lossless_flags=None if kind == "xyb" else J.LOSSLESS_RCT)
+    o = jxlo.Decoded(data)
+    want8, wantf = o.rgb8.copy(), o.planes("rgbf").transpose(1, 2, 0).copy()
+    o.close()
+    plain = jxlo.Decoded(J.encode_lossless(img, J.MODULAR_XYB if kind == "xyb" else J.LOSSLESS_RCT), dumps=False).rgb8
+    assert (want8 != plain).any(axis=2).sum() > 1500  # (the patches are there)
+    rc, events, out, px = R.run(data, tmp_path, "f32", 3)
+    assert rc == 0 and [e for e in events if e in ("FRAME", "FULL_IMAGE")] == ["FRAME", "FULL_IMAGE"], out
+    assert np.abs(np.frombuffer(px, np.float32).reshape(200, 300, 3) - wantf).max() < 1e-4
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3)
+    assert rc == 0, out
+    assert np.abs(np.frombuffer(px, np.uint8).reshape(200, 300, 3).astype(int) - want8.astype(int)).max() <= 1
