@@ -1189,6 +1189,33 @@ void jxlo_color_kat(const float* xyb, size_t n, int linear, float* rgb) {
   }
 }
 
+// Known-answer hook for the patch blending (lib/jxl/alpha_test.cc holds expected values for the blend and multiply arithmetic):
+// one pixel, colour bg[3] / fg[3] with alpha bga / fga, through ApplyPatches with the given colour and alpha-channel modes;
+// out[0..2] = colour, out[3] = alpha.
+void jxlo_patch_blend_kat(const float* bg, float bga, const float* fg, float fga, int mode, int clamp, int ec_mode, int ec_clamp,
+                          int premultiplied, int has_alpha, float* out) {
+  jxlo::XybSlot slots[4];
+  slots[1].w = slots[1].h = 1;
+  for (int c = 0; c < 3; c++) slots[1].p[c].assign(1, fg[c]);
+  slots[1].alpha.assign(1, fga);
+  jxlo::Patches P;
+  P.refs.push_back({1, 0, 0, 1, 1});
+  jxlo::PatchPos q;
+  q.x = q.y = q.ref = 0;
+  q.mode = uint32_t(mode);
+  q.clamp = clamp != 0;
+  q.ec_mode = uint32_t(ec_mode);
+  q.ec_clamp = ec_clamp != 0;
+  P.pos.push_back(q);
+  P.uses_alpha = true;
+  float p0 = bg[0], p1 = bg[1], p2 = bg[2], a = bga;
+  jxlo::ApplyPatches(P, slots, &p0, &p1, &p2, 1, has_alpha ? &a : nullptr, 1, premultiplied != 0);
+  out[0] = p0;
+  out[1] = p1;
+  out[2] = p2;
+  out[3] = a;
+}
+
 // Known-answer hook for the chroma upsampling of subsampled YCbCr frames: `plane` holds ceil(xsize / 2) x ceil(ysize / 2) (or
 // xsize / ysize in the direction that is not subsampled) samples in its top-left part, rows of `stride` floats, `rows` rows in
 // all; upsampled in place (render_pipeline/stage_chroma_upsampling.cc:29-111).

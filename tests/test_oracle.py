@@ -394,3 +394,46 @@ def test_chroma_subsampled_round_trip_on_a_smooth_image(built, cs):
     d = o.rgb8[..., :3].astype(np.float64) - img
     o.close()
     assert 10 * np.log10(255.0 ** 2 / (d * d).mean()) > 46.0
+
+
+def test_patch_blending_against_the_reference_tests_known_answers(built):
+    """lib/jxl/alpha_test.cc:29-86 (BlendingWithNonPremultiplied, BlendingWithPremultiplied, Mul) holds expected values for
+    PerformAlphaBlending and PerformMulBlending: the patch stage's blend above (= that function with the frame below and the
+    patch on top, blending.cc:127-136, 163-165) and multiply must reproduce them, and blend below is the same call with the
+    layers swapped. The NumPy reading the GPU test's oracle is checked against (tests/test_patches.py) is held to them too."""
+    import ctypes
+    import jxlo
+    import test_patches as TP
+    L = jxlo.lib()
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.jxlo_patch_blend_kat.argtypes = [fp, ctypes.c_float, fp, ctypes.c_float] + [ctypes.c_int] * 6 + [fp]
+    L.jxlo_patch_blend_kat.restype = None
+
+    def blend(bg, bga, fg, fga, mode, clamp, ec_mode=0, ec_clamp=0, premultiplied=False, has_alpha=True):
+        out = (ctypes.c_float * 4)()
+        L.jxlo_patch_blend_kat((ctypes.c_float * 3)(*bg), bga, (ctypes.c_float * 3)(*fg), fga, mode, clamp, ec_mode, ec_clamp,
+                               1 if premultiplied else 0, 1 if has_alpha else 0, out)
+        got = np.array(list(out), np.float32)
+        f32 = np.float32
+        col, a = TP._blend_np(np.array(bg, f32).reshape(3, 1, 1), np.full((1, 1), bga, f32), np.array(fg, f32).reshape(3, 1, 1),
+                              np.full((1, 1), fga, f32), mode, clamp, ec_mode, ec_clamp, premultiplied)
+        assert np.abs(col.ravel() - got[:3]).max() <= 1e-4 * max(1.0, float(np.abs(got[:3]).max())) and abs(float(a.ravel()[0]) - got[3]) < 1e-6
+        return got
+
+    bg, bga, fg, fga = (100.0, 110.0, 120.0), 180.0 / 255, (25.0, 21.0, 23.0), 15420.0 / 65535
+    got = blend(bg, bga, fg, fga, 4, 0)  # alpha_test.cc:29-43
+    assert np.abs(got[:3] - [77.2, 83.0, 90.6]).max() < 0.05 and abs(got[3] - 3174.0 / 4095) < 1e-5
+    got = blend(bg, bga, fg, 2.0, 4, 1)   # :44-51: alpha 2 clamped to 1: the top layer alone
+    assert np.abs(got[:3] - fg).max() < 0.05 and abs(got[3] - 1.0) < 1e-5
+    got = blend(bg, bga, fg, fga, 4, 0, premultiplied=True)  # :53-67
+    assert np.abs(got[:3] - [101.5, 105.1, 114.8]).max() < 0.05 and abs(got[3] - 3174.0 / 4095) < 1e-5
+    got = blend(bg, bga, fg, 2.0, 4, 1, premultiplied=True)  # :68-75
+    assert np.abs(got[:3] - fg).max() < 0.05 and abs(got[3] - 1.0) < 1e-5
+    # blend below = the same function with the layers swapped: the frame on top of the patch
+    got = blend(fg, fga, bg, bga, 5, 0)
+    assert np.abs(got[:3] - [77.2, 83.0, 90.6]).max() < 0.05 and abs(got[3] - 3174.0 / 4095) < 1e-5
+    # :77-86 Mul: 100 * 25, and with the top value clamped to 1
+    got = blend((100.0,) * 3, 1.0, (25.0,) * 3, 1.0, 3, 0)
+    assert np.abs(got[:3] - 2500.0).max() < 0.05
+    got = blend((100.0,) * 3, 1.0, (25.0,) * 3, 1.0, 3, 1)
+    assert np.abs(got[:3] - 100.0).max() < 0.05
