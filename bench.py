@@ -100,6 +100,7 @@ def end_to_end(J, datas, nframes, device, xsize, ysize, chunk=256):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
+    chunk = int(os.environ.get("JXLAMD_E2E_CHUNK", chunk))  # (measurement aid)
     chunk = max(1, min(chunk, nframes))
     # CPUs this process really gets (a container's CPU share does not show in the affinity mask): CPU time / wall time of
     # 64 frame parses on 64 threads. The host front-end is the end-to-end bottleneck, so the pools are sized by it.
