@@ -345,7 +345,7 @@ def test_orientation_is_undone_by_the_pixel_writer(built, tmp_path, orientation)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("passes", [1, 2])
+@pytest.mark.parametrize("passes", [1, 2, "420"])
 def test_flush_image_draws_what_has_arrived(built, tmp_path, passes):
     """JxlDecoderFlushImage (decode.cc:2458-2475, FrameDecoder::Flush dec_frame.cc:735-795): with a part of the frame's
     bytes, the groups whose AC sections are whole are decoded and the others are drawn from the DC image alone (zero
@@ -354,7 +354,10 @@ def test_flush_image_draws_what_has_arrived(built, tmp_path, passes):
     import os
     import jxlo
     J = built
-    data = J.encode_rgb8(J.synth_image(1100, 800, seed=9), num_passes=passes)  # 5 x 4 groups
+    if passes == "420":  # a chroma-subsampled YCbCr frame: the groups drawn from DC alone take each channel's DC from its own grid
+        data = J.encode_rgb8(J.synth_image(1100, 800, seed=9), color_transform=2, chroma_subsampling=4, strategy_mode=0)
+    else:
+        data = J.encode_rgb8(J.synth_image(1100, 800, seed=9), num_passes=passes)  # 5 x 4 groups
     chunk = len(data) // 7
     rc, events, out, px = R.run(data, tmp_path, "u8", 3, "flush", "chunk=%d" % chunk)
     assert rc == 0 and events.count("FULL_IMAGE") == 1, out
