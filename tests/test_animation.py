@@ -124,7 +124,7 @@ def test_decoder_api_walks_the_frames_without_pixels(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lossless", [False, True])
+@pytest.mark.parametrize("lossless", [False, True, "ycbcr420"])
 def test_every_frame_of_an_animation_through_the_gpu(built, tmp_path, lossless):
     """The replay of DecodeImageJXL's loop (jxl.cc:495-640: one NEED_IMAGE_OUT_BUFFER + FULL_IMAGE per frame) gets every
     frame's pixels; each equals the oracle's decode of that frame (VarDCT: +-1, lossless: exact); with alpha, in a
@@ -134,7 +134,11 @@ def test_every_frame_of_an_animation_through_the_gpu(built, tmp_path, lossless):
     fr = _frames(J, 3, size=(300, 200))
     alpha = ((np.mgrid[0:200, 0:300][1] * 255) // 299).astype(np.uint8)
     frames = [np.dstack([f, np.roll(alpha, 17 * i, axis=1)]) for i, f in enumerate(fr)]
-    data = J.encode_animation(frames, [4, 2, 9], lossless=lossless)
+    if lossless == "ycbcr420":  # frames of an image that is not XYB encoded, chroma subsampled, composed on the canvas like any other
+        lossless = False
+        data = J.encode_animation(frames, [4, 2, 9], color_transform=2, chroma_subsampling=4, strategy_mode=0)
+    else:
+        data = J.encode_animation(frames, [4, 2, 9], lossless=lossless)
     want = []
     for k in range(3):
         o = jxlo.Decoded(data, dumps=False, frame=k)
