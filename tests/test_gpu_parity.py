@@ -142,6 +142,9 @@ def test_chroma_subsampled_frames(built, size, kw):
     (6, dict(chroma_subsampling=CS420, ac_code_mode=3)),
     (7, dict(chroma_subsampling=CS420, max_clusters=128)),    # alias tables read in place from global memory
     (8, dict(chroma_subsampling=CS420, num_passes=2, num_histograms=2)),
+    (9, dict(chroma_subsampling=0b011011)),                   # Y subsampled too: a varblock may carry no luma for the chroma-from-luma term
+    (10, dict(chroma_subsampling=1, num_passes=2)),           # ... with the passes merged into the natural layout
+    (11, dict(chroma_subsampling=0b100100, ac_code_mode=2)),  # ... through the one-lane-per-section kernel
 ])
 def test_chroma_subsampled_random_streams(built, seed, kw):
     """Random streams over every transform a subsampled frame may use (the ten that cover one block: dec_modular.cc:534-538),
