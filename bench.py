@@ -480,16 +480,25 @@ def encode_main(args, J, sharding, torch, dist, rank, local_rank, world, xsize, 
                             "traffic": None, "launch_ms": round(transform_ms, 4), "algorithmic_bytes_per_launch": alg,
                             "kernels_ms_per_frame": round(span_ms / batch, 4)}}
         if world == 1:
-            best = None
-            for _ in range(3):
-                t1 = time.perf_counter()
-                J.encode_rgb8_gpu(img, ctx, timings=t, distance=args.distance, cfl_fit=1)
-                dt = time.perf_counter() - t1
-                if best is None or dt < best[0]:
-                    best = (dt, dict(t))
+            def best_of(device_tokens):
+                best = None
+                for _ in range(3):
+                    t1 = time.perf_counter()
+                    d = J.encode_rgb8_gpu(img, ctx, timings=t, device_tokens=device_tokens, distance=args.distance, cfl_fit=1)
+                    dt = time.perf_counter() - t1
+                    if best is None or dt < best[0]:
+                        best = (dt, dict(t), d)
+                return best
+            host_tok, best = best_of(False), best_of(True)
+            assert best[2] == host_tok[2] == data  # the same codestream whichever side tokenises
             out["e2e"] = {"value": round(px * 1e-6 / best[0], 2), "unit": "MP/s", "seconds_per_frame": round(best[0], 4),
                           "forward_call_s": round(best[1]["forward_s"], 4), "host_entropy_coding_s": round(best[1]["assemble_s"], 4),
-                          "note": "one frame, RGB8 in host memory to codestream bytes: upload, kernels, download, host rANS coding"}
+                          "device_tokens": best[1]["device_tokens"],
+                          "host_tokenised": {"seconds_per_frame": round(host_tok[0], 4), "forward_call_s": round(host_tok[1]["forward_s"], 4),
+                                             "host_entropy_coding_s": round(host_tok[1]["assemble_s"], 4)},
+                          "note": "one frame, RGB8 in host memory to codestream bytes: upload, kernels (AC tokenisation included), "
+                                  "token download, host histogram clustering + rANS coding; host_tokenised = the coefficients "
+                                  "copied back and tokenised by the host instead (the same bytes)"}
             if not args.no_cpu_baseline:
                 t1, c1 = time.perf_counter(), time.process_time()
                 J.enc_forward_model(img, None, distance=args.distance, cfl_fit=1)

@@ -514,9 +514,30 @@ typedef struct {
 /* rgb: interleaved sRGB8 in host memory, `stride` bytes per row. Outputs (host memory): acs[yb * xb] = (strategy << 1) |
  * first-block bit, qf[yb * xb] (quant field at first blocks), dc[3][yb * xb] quantised DC stored X, Y, B, and
  * coeffs[groups][3][65536] quantised AC, block-contiguous per 256x256 group in raster order of the first blocks
- * (xb = ceil(xsize / 8), groups = ceil(xsize / 256) * ceil(ysize / 256)). Synchronous. */
+ * (xb = ceil(xsize / 8), groups = ceil(xsize / 256) * ceil(ysize / 256)); coeffs may be NULL (the coefficients then stay
+ * on the device: a caller that takes the tokens from jxlhip_enc_tokens needs no copy of them). Synchronous. */
 int jxlhip_enc_forward(JxlHipContext* ctx, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* desc, uint8_t* acs, int32_t* qf,
                        int32_t* dc, int32_t* coeffs);
+/* Tokenisation of the last jxlhip_enc_forward's coefficients on the device (lib/jxl/enc_entropy_coder.cc:153-255
+ * TokenizeCoefficients; csrc/hip/jxl_hip_enc.h): the (context, value) pairs the host entropy coder codes, in bitstream order
+ * per 256x256 group (block by block in raster order of the first blocks, channels Y, X, B: the non-zero count, then the
+ * coefficients from the first scan position behind the lowest-frequency corner to the last non-zero one). Single pass.
+ *   orders: the coefficient orders of the 13 order buckets (one per bucket: the same for the three channels), bucket b at
+ *   orders[order_offset[b]]; ctx_map: the block context of (channel, order bucket) at [(c < 2 ? c ^ 1 : 2) * 13 + bucket]
+ *   (a block context map without quant-field / DC thresholds, ac_context.h:101-143); num_ctxs its number of contexts;
+ *   num_hist: histogram sets (group g uses set g % num_hist: its contexts start at (g % num_hist) * num_ctxs * 495).
+ * jxlhip_enc_token_counts computes everything but the tokens and returns every group's token count in totals[groups];
+ * jxlhip_enc_tokens then writes group g's tokens at tokens[2 * bases[g] ...] as {context, value} pairs of uint32 (the
+ * caller's prefix sum of the totals; `capacity` = number of pairs `tokens` holds). Both synchronous. */
+typedef struct {
+  const uint16_t* orders;
+  uint32_t orders_size;
+  uint32_t order_offset[13];
+  uint8_t ctx_map[39];
+  uint32_t num_ctxs, num_hist;
+} JxlHipEncTokDesc;
+int jxlhip_enc_token_counts(JxlHipContext* ctx, const JxlHipEncTokDesc* desc, uint32_t* totals);
+int jxlhip_enc_tokens(JxlHipContext* ctx, const uint32_t* bases, uint32_t* tokens, size_t capacity);
 /* Measurement: runs the kernel sequence of the last jxlhip_enc_forward `times` more times on its input, which is still
  * resident on the device (no copies); jxlhip_enc_last_ms then gives the time of all `times` passes. Synchronous. */
 int jxlhip_enc_forward_rerun(JxlHipContext* ctx, uint32_t times);

@@ -749,10 +749,11 @@ def encode_rgb8(img, **kw):
     return _finish(E, r, out, n, "jxlenc_encode_rgb8")
 
 
-def encode_rgb8_gpu(img, ctx, timings=None, **kw):
+def encode_rgb8_gpu(img, ctx, timings=None, device_tokens=False, **kw):
     """VarDCT-encodes an RGB8 image with the pixel-domain half (colour, sharpening, transform selection, forward DCT,
     quantisation) on the GPU (jxlhip_enc_forward on `ctx`) and entropy coding / headers on the host. `timings` (a dict)
-    receives forward_s (the call, copies included), assemble_s and kernels_ms (HIP events around the launches)."""
+    receives forward_s (the call, copies included), assemble_s and kernels_ms (HIP events around the launches).
+    device_tokens: the coefficients are tokenised on the device too (jxlhip_enc_tokens) and never copied to the host."""
     E, L = _enc_lib(), lib()
     pp = ctypes.POINTER(ctypes.POINTER(ctypes.c_uint8))
     E.jxlenc_encode_rgb8_forward.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), ctypes.c_void_p,
@@ -761,15 +762,22 @@ def encode_rgb8_gpu(img, ctx, timings=None, **kw):
     img = np.ascontiguousarray(img, np.uint8)
     p = _params(**kw)
     out, n = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_size_t()
-    secs = (ctypes.c_double * 2)()
+    secs = (ctypes.c_double * 3)()
     fn = ctypes.cast(L.jxlhip_enc_forward, ctypes.c_void_p)
-    r = E.jxlenc_encode_rgb8_forward(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), fn, ctx._h, ctypes.byref(out),
-                                     ctypes.byref(n), secs)
+    if device_tokens:
+        E.jxlenc_encode_rgb8_forward_tokens.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams)] + \
+            [ctypes.c_void_p] * 4 + [pp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_double)]
+        r = E.jxlenc_encode_rgb8_forward_tokens(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), fn,
+                                                ctypes.cast(L.jxlhip_enc_token_counts, ctypes.c_void_p),
+                                                ctypes.cast(L.jxlhip_enc_tokens, ctypes.c_void_p), ctx._h, ctypes.byref(out), ctypes.byref(n), secs)
+    else:
+        r = E.jxlenc_encode_rgb8_forward(img.tobytes(), img.shape[1], img.shape[0], ctypes.byref(p), fn, ctx._h, ctypes.byref(out),
+                                         ctypes.byref(n), secs)
     data = _finish(E, r, out, n, "jxlenc_encode_rgb8_forward")
     if timings is not None:
         ms = ctypes.c_float()
         _check(L.jxlhip_enc_last_ms(ctx._h, ctypes.byref(ms)), "jxlhip_enc_last_ms")
-        timings.update(forward_s=secs[0], assemble_s=secs[1], kernels_ms=ms.value)
+        timings.update(forward_s=secs[0], assemble_s=secs[1], kernels_ms=ms.value, device_tokens=int(secs[2]))
     return data
 
 

@@ -774,6 +774,10 @@ struct FrameModel {
   // ... or, when the forward path delivered them in one block: [group][3][65536] (then `coeffs` stays empty)
   std::unique_ptr<int32_t[]> flat_coeffs;
   const int32_t* GroupCoeffs(size_t g) const { return flat_coeffs ? flat_coeffs.get() + g * 3 * 65536 : coeffs[g].data(); }
+  // ... or they never came to the host: the forward path tokenised them on the device (jxlhip_enc_tokens): every group's
+  // (context, value) pairs in bitstream order, group g at dev_tokens[dev_token_base[g] .. + dev_token_count[g])
+  std::vector<uint64_t> dev_tokens;  // {context, value} pairs of uint32
+  std::vector<uint32_t> dev_token_base, dev_token_count;
   uint32_t global_scale, quant_dc;
   int epf_iters, gab;
   uint64_t flags;
@@ -1375,6 +1379,11 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
 #pragma omp parallel for schedule(dynamic)
   for (size_t pg = 0; pg < num_groups * num_passes; pg++) {
     const size_t g = pg % num_groups, pass = pg / num_groups;
+    if (!f.dev_tokens.empty()) {  // tokenised on the device: the same pairs, already in order
+      const Token* t = reinterpret_cast<const Token*>(f.dev_tokens.data()) + f.dev_token_base[g];
+      ac_tokens[pg].assign(t, t + f.dev_token_count[g]);
+      continue;
+    }
     // the part of a coefficient this pass carries (the decoder adds value << shift over the passes, dec_group.cc:335-338)
     auto part = [&](int32_t v) -> int32_t { return num_passes == 1 ? v : (pass == 0 ? (v >> 1) : v - ((v >> 1) << 1)); };
     const size_t bx0 = (g % xg) * 32, by0 = (g / xg) * 32;
@@ -1745,10 +1754,17 @@ static void QuantParams(float distance, FrameModel* f, float* quant_ac) {
 // whose signature this is): the caller hands the function and its context over, this library does not link against it.
 typedef int (*ForwardFn)(void* ctx, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* desc, uint8_t* acs, int32_t* qf, int32_t* dc,
                          int32_t* coeffs);
+// ... and the tokenisation of its coefficients (jxlhip_enc_token_counts / jxlhip_enc_tokens): when both are given the
+// coefficients stay on the device and the host entropy coder starts from the tokens.
+typedef int (*TokenCountsFn)(void* ctx, const JxlHipEncTokDesc* desc, uint32_t* totals);
+typedef int (*TokensFn)(void* ctx, const uint32_t* bases, uint32_t* tokens, size_t capacity);
 struct ForwardHook {
   ForwardFn fn;
   void* ctx;
   double seconds[2];  // out: forward call, assembly (entropy coding + headers)
+  TokenCountsFn tok_counts = nullptr;
+  TokensFn tok_emit = nullptr;
+  uint64_t device_tokens = 0;  // out: how many tokens came from the device (0: the host tokenised)
   // test access: when set, the raw outputs of the forward call are copied here and nothing is assembled
   uint8_t* cap_acs = nullptr;
   int32_t *cap_qf = nullptr, *cap_dc = nullptr, *cap_coeffs = nullptr;
@@ -1829,10 +1845,48 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     f.qf.assign(nb, 0);
     // (no zero fill and no second copy of the coefficients: 100 MB at 4K)
     std::vector<int32_t> dc(3 * nb);
-    f.flat_coeffs.reset(new int32_t[ng * 3 * 65536]);
+    // device tokenisation: one pass, natural orders, the default block context map (what it is written for)
+    const bool dev_tok = hook->tok_counts && hook->tok_emit && !hook->cap_acs && p.num_passes != 2 && !p.custom_orders && !p.custom_bctx;
+    if (!dev_tok) f.flat_coeffs.reset(new int32_t[ng * 3 * 65536]);
     int32_t* const co = f.flat_coeffs.get();
     const int r = hook->fn(hook->ctx, rgb, xs * 3, &d, f.acs.data(), f.qf.data(), dc.data(), co);
     if (r) throw std::runtime_error("forward hook failed (" + std::to_string(r) + ")");
+    if (dev_tok) {
+      JxlHipEncTokDesc td;
+      memset(&td, 0, sizeof(td));
+      std::vector<uint16_t> orders;
+      bool have[13] = {};
+      for (int s2 = 0; s2 < 27; s2++) {
+        const int ord = jxh::kStrategyOrder[s2];
+        if (have[ord]) continue;
+        have[ord] = true;
+        td.order_offset[ord] = uint32_t(orders.size());
+        if (size_t(jxh::kCoveredX[s2]) * jxh::kCoveredY[s2] > 64) continue;  // (the forward path selects up to 64x64)
+        std::vector<uint32_t> nat;
+        jxh::NaturalOrder(s2, &nat);
+        for (uint32_t v : nat) orders.push_back(uint16_t(v));
+      }
+      td.orders = orders.data();
+      td.orders_size = uint32_t(orders.size());
+      const jxh::BlockCtxMap bctx;
+      memcpy(td.ctx_map, bctx.ctx_map.data(), sizeof(td.ctx_map));
+      td.num_ctxs = uint32_t(bctx.num_ctxs);
+      td.num_hist = uint32_t((p.num_histograms > 1 && ng > 1) ? std::min<size_t>(size_t(p.num_histograms), ng) : 1);
+      f.dev_token_count.assign(ng, 0);
+      int tr = hook->tok_counts(hook->ctx, &td, f.dev_token_count.data());
+      if (tr) throw std::runtime_error("token hook failed (" + std::to_string(tr) + ")");
+      f.dev_token_base.assign(ng, 0);
+      uint64_t total = 0;
+      for (size_t g = 0; g < ng; g++) {
+        f.dev_token_base[g] = uint32_t(total);
+        total += f.dev_token_count[g];
+      }
+      if (total >= (uint64_t(1) << 32)) throw std::runtime_error("token hook: too many tokens");
+      f.dev_tokens.assign(size_t(total) + 1, 0);
+      tr = hook->tok_emit(hook->ctx, f.dev_token_base.data(), reinterpret_cast<uint32_t*>(f.dev_tokens.data()), size_t(total));
+      if (tr) throw std::runtime_error("token hook failed (" + std::to_string(tr) + ")");
+      hook->device_tokens = total;
+    }
     if (hook->cap_acs) {
       memcpy(hook->cap_acs, f.acs.data(), nb);
       memcpy(hook->cap_qf, f.qf.data(), nb * 4);
@@ -2903,6 +2957,32 @@ int jxlenc_encode_rgb8_forward(const uint8_t* rgb, uint32_t xs, uint32_t ys, con
   if (seconds) {
     seconds[0] = hook.seconds[0];
     seconds[1] = hook.seconds[1];
+  }
+  return Finish(v, out, n);
+}
+
+// The same with the coefficients tokenised on the device too (jxlhip_enc_token_counts / jxlhip_enc_tokens on the same context):
+// the host starts from the tokens. Falls back to host tokenisation for progressive passes, coded orders or a coded block
+// context map; seconds[2] receives the number of tokens the device produced (0 after that fallback).
+int jxlenc_encode_rgb8_forward_tokens(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, jxe::ForwardFn forward,
+                                      jxe::TokenCountsFn tok_counts, jxe::TokensFn tok_emit, void* ctx, uint8_t** out, size_t* n, double* seconds) {
+  if (!rgb || !xs || !ys || !p || p->distance <= 0 || !forward || !tok_counts || !tok_emit) return -1;
+  jxe::Params q;
+  memcpy(&q, p, sizeof(q));
+  if (q.upsampling > 1) return -1;
+  std::vector<uint8_t> v;
+  jxe::ForwardHook hook = {forward, ctx, {0, 0}};
+  hook.tok_counts = tok_counts;
+  hook.tok_emit = tok_emit;
+  try {
+    jxe::EncodeImage(rgb, xs, ys, q, &v, 0, 0, nullptr, &hook);
+  } catch (...) {
+    return -2;
+  }
+  if (seconds) {
+    seconds[0] = hook.seconds[0];
+    seconds[1] = hook.seconds[1];
+    seconds[2] = double(hook.device_tokens);
   }
   return Finish(v, out, n);
 }

@@ -245,6 +245,10 @@ struct JxlHipContext {
   Buf enc_rgb, enc_planes[3], enc_act, enc_acs, enc_qf, enc_off, enc_dc, enc_coef, enc_lut, enc_dq, enc_ytox, enc_ytob;
   hipEvent_t enc_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // whole sequence; the transform kernel of its last pass
   bool enc_timed = false;
+  jxlhip::EncTok enc_tok;      // jxlhip_enc_token_counts -> jxlhip_enc_tokens
+  bool enc_tok_ready = false;
+  std::vector<uint32_t> enc_tok_totals;
+  Buf enc_tok_orders, enc_tok_blk, enc_tok_info, enc_tok_off, enc_tok_nzmap, enc_tok_small, enc_tok_out, enc_tok_base;
   jxlhip::EncFwd enc_last;     // the parameters of the last jxlhip_enc_forward (its input stays resident): jxlhip_enc_forward_rerun
   bool enc_last_gaborish = false;
   uint32_t out_orient = 0;  // jxlhip_set_output_orientation: PixelOut::orient bits (0 = the image as coded)
@@ -527,7 +531,8 @@ int jxlhip_ctx_create(int device, JxlHipContext** out) {
 static std::vector<Buf*> AllBufs(JxlHipContext* c) {
   std::vector<Buf*> all = {&c->basis, &c->sections, &c->sec_word, &c->sec_size, &c->blocks, &c->gbb, &c->bctx_lut, &c->dequant, &c->dc, &c->dc_raw, &c->dc_q, &c->dc_ep, &c->sharp,
                 &c->inv_sigma, &c->ytox, &c->ytob, &c->passes_dev, &c->coeffs, &c->errors, &c->plane[0], &c->plane[1],
-                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->ec_stage, &c->alpha_patched, &c->trecs, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
+                &c->plane[2], &c->rgb, &c->tlist, &c->scratch, &c->ep_dev, &c->batch_params, &c->batch_map, &c->batch_lanes, &c->batch_wave_ls, &c->ups_kernel, &c->kend, &c->block_recs, &c->dequant_scan, &c->ec_stage, &c->alpha_patched, &c->trecs, &c->enc_tok_orders, &c->enc_tok_blk, &c->enc_tok_info,
+                &c->enc_tok_off, &c->enc_tok_nzmap, &c->enc_tok_small, &c->enc_tok_out, &c->enc_tok_base, &c->tb_params, &c->tb_desc, &c->fb_params, &c->alpha, &c->sec_end, &c->lz_window, &c->mod.pool, &c->mod.sections, &c->mod.blob, &c->mod.streams,
                 &c->mod.rects, &c->mod.status, &c->mod.end_bits, &c->mod.scratch, &c->mod.windows, &c->mod.batch_streams, &c->mod.batch_ops, &c->frame_blob, &c->noise, &c->spl_seg, &c->spl_row_start, &c->spl_row_seg, &c->spl_planes, &c->pat_rec, &c->pat_row_start, &c->pat_row_list,
                 &c->enc_rgb, &c->enc_planes[0], &c->enc_planes[1], &c->enc_planes[2], &c->enc_act, &c->enc_acs, &c->enc_qf, &c->enc_off, &c->enc_dc, &c->enc_coef, &c->enc_lut, &c->enc_dq, &c->enc_ytox, &c->enc_ytob, &c->ups_planes};
   for (auto& pb : c->pass_bufs)
@@ -3922,7 +3927,7 @@ static int EncLaunch(JxlHipContext* c, jxlhip::EncFwd& P, bool gaborish) {
 
 int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* d, uint8_t* acs, int32_t* qf, int32_t* dc,
                        int32_t* coeffs) {
-  if (!c || !rgb || !d || !acs || !qf || !dc || !coeffs) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c || !rgb || !d || !acs || !qf || !dc) return JXLHIP_ERR_INVALID_ARGUMENT;  // (coeffs may be NULL: they stay on the device)
   if (!d->xsize || !d->ysize || d->xsize > (1u << 18) || d->ysize > (1u << 18) || stride < size_t(d->xsize) * 3) return JXLHIP_ERR_INVALID_ARGUMENT;
   if (!(d->distance > 0) || !d->global_scale || !d->quant_dc || !d->dequant || d->strategy_mode > 1) return JXLHIP_ERR_INVALID_ARGUMENT;
   for (int k = 0; k < 17; k++)
@@ -4000,7 +4005,84 @@ int jxlhip_enc_forward(JxlHipContext* c, const uint8_t* rgb, size_t stride, cons
   HIP_TRY(hipMemcpyAsync(acs, c->enc_acs.p, nb, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(qf, c->enc_qf.p, nb * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(dc, c->enc_dc.p, 3 * nb * 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(coeffs, c->enc_coef.p, ng * 3 * 65536 * 4, hipMemcpyDeviceToHost, c->stream));
+  if (coeffs) HIP_TRY(hipMemcpyAsync(coeffs, c->enc_coef.p, ng * 3 * 65536 * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->enc_tok_ready = false;
+  return 0;
+}
+
+// ---- tokenisation of the last forward call's coefficients (jxl_hip_enc.h)
+int jxlhip_enc_token_counts(JxlHipContext* c, const JxlHipEncTokDesc* d, uint32_t* totals) {
+  if (!c || !d || !totals || !d->orders || !d->num_ctxs || !d->num_hist || d->num_ctxs > 16) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->enc_timed) return JXLHIP_ERR_NO_FRAME;
+  // every index the kernels form from the tables must stay inside them: the order buckets of the transforms the forward
+  // path selects (up to 64x64), complete and with entries below their size; block contexts below num_ctxs
+  static const uint32_t kBucketSize[9] = {64, 64, 256, 1024, 128, 256, 512, 4096, 2048};
+  for (int b = 0; b < 9; b++) {
+    if (uint64_t(d->order_offset[b]) + kBucketSize[b] > d->orders_size) return JXLHIP_ERR_INVALID_ARGUMENT;
+    for (uint32_t k = 0; k < kBucketSize[b]; k++)
+      if (d->orders[d->order_offset[b] + k] >= kBucketSize[b]) return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
+  for (int i = 0; i < 39; i++)
+    if (d->ctx_map[i] >= d->num_ctxs) return JXLHIP_ERR_INVALID_ARGUMENT;
+  HIP_TRY(hipSetDevice(c->device));
+  const jxlhip::EncFwd& F = c->enc_last;
+  const size_t ng = size_t(F.xg) * F.yg;
+  int r;
+  if ((r = c->enc_tok_orders.Ensure(size_t(d->orders_size) * 2 + 16)) || (r = c->enc_tok_blk.Ensure(ng * 1024 * 2)) ||
+      (r = c->enc_tok_info.Ensure(ng * jxlhip::kTokPerGroup * 4)) || (r = c->enc_tok_off.Ensure(ng * jxlhip::kTokPerGroup * 4)) ||
+      (r = c->enc_tok_nzmap.Ensure(ng * 3 * 1024)) || (r = c->enc_tok_small.Ensure(ng * 12)))
+    return r;
+  HIP_TRY(hipMemcpyAsync(c->enc_tok_orders.p, d->orders, size_t(d->orders_size) * 2, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->enc_tok_nzmap.p, 0, ng * 3 * 1024, c->stream));
+  jxlhip::EncTok& T = c->enc_tok;
+  memset(&T, 0, sizeof(T));
+  T.acs = F.acs;
+  T.coef_off = F.coef_off;
+  T.coeffs = F.coeffs;
+  T.xb = F.xb;
+  T.yb = F.yb;
+  T.xg = F.xg;
+  T.orders = c->enc_tok_orders.as<uint16_t>();
+  memcpy(T.order_offset, d->order_offset, sizeof(T.order_offset));
+  memcpy(T.ctx_map, d->ctx_map, sizeof(T.ctx_map));
+  T.num_ctxs = d->num_ctxs;
+  T.num_hist = d->num_hist;
+  T.nctx = d->num_ctxs * 495;
+  T.blk = c->enc_tok_blk.as<uint16_t>();
+  T.info = c->enc_tok_info.as<uint32_t>();
+  T.off = c->enc_tok_off.as<uint32_t>();
+  T.nzmap = c->enc_tok_nzmap.as<uint8_t>();
+  T.nblk = c->enc_tok_small.as<uint32_t>();
+  T.total = c->enc_tok_small.as<uint32_t>() + ng;
+  hipLaunchKernelGGL(jxlhip::k_enc_tok_count, dim3(uint32_t(ng)), dim3(jxlhip::kTokThreads), 0, c->stream, T);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(totals, T.total, ng * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->enc_tok_totals.assign(totals, totals + ng);
+  c->enc_tok_ready = true;
+  return 0;
+}
+
+int jxlhip_enc_tokens(JxlHipContext* c, const uint32_t* bases, uint32_t* tokens, size_t capacity) {
+  if (!c || !bases || !tokens) return JXLHIP_ERR_INVALID_ARGUMENT;
+  if (!c->enc_tok_ready) return JXLHIP_ERR_NO_FRAME;
+  const size_t ng = c->enc_tok_totals.size();
+  uint64_t need = 0;
+  for (size_t g = 0; g < ng; g++) {  // every group's range inside the caller's buffer (ranges may not overlap: they are a prefix sum)
+    if (uint64_t(bases[g]) + c->enc_tok_totals[g] > capacity) return JXLHIP_ERR_INVALID_ARGUMENT;
+    need = std::max<uint64_t>(need, uint64_t(bases[g]) + c->enc_tok_totals[g]);
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  int r;
+  if ((r = c->enc_tok_out.Ensure(size_t(need ? need : 1) * 8)) || (r = c->enc_tok_base.Ensure(ng * 4))) return r;
+  HIP_TRY(hipMemcpyAsync(c->enc_tok_base.p, bases, ng * 4, hipMemcpyHostToDevice, c->stream));
+  jxlhip::EncTok T = c->enc_tok;
+  T.base = c->enc_tok_base.as<uint32_t>();
+  T.tokens = c->enc_tok_out.as<uint2>();
+  hipLaunchKernelGGL(jxlhip::k_enc_tok_emit, dim3(uint32_t(ng)), dim3(jxlhip::kTokThreads), 0, c->stream, T);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(tokens, c->enc_tok_out.p, size_t(need) * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }

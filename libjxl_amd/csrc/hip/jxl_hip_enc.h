@@ -560,5 +560,186 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- tokenisation
+// The AC coefficient tokens of a frame on the device (reference lib/jxl/enc_entropy_coder.cc:153-255 TokenizeCoefficients;
+// contexts lib/jxl/ac_context.h:63-143, entropy_coder.h:25-35): the quantised coefficients of the forward path never leave
+// HBM, the host entropy coder receives (context, value) pairs in bitstream order. Unlike the decoder's walk nothing here
+// is serial: a (varblock, channel)'s non-zero count is a popcount, the predicted count comes from the finished map of
+// counts, the running "non-zeros left" of coefficient k is the count minus a prefix popcount, and a token's place in its
+// group's stream is a prefix sum of the per-(varblock, channel) token counts.
+// Two launches, one workgroup of sixteen waves per 256x256 group, a wave per (varblock, channel):
+//   k_enc_tok_count  list of the group's varblocks in raster order, per (varblock, channel) the non-zero count and the last
+//                    non-zero scan position, the map of counts per 8x8 block, token counts and their exclusive scan
+//   k_enc_tok_emit   the tokens, at the group's base (a host-side prefix sum of the 135 group totals) + that offset
+// Single pass, natural coefficient order, a block context map without thresholds (the default one): what the forward path's
+// callers use; anything else is tokenised by the host as before.
+struct EncTok {
+  const uint8_t* acs;        // per block: strategy << 1 | first (k_enc_select)
+  const uint32_t* coef_off;  // per first block: offset of its coefficients in the group's planes (k_enc_offsets)
+  const int32_t* coeffs;     // [group][3][65536]
+  uint32_t xb, yb, xg;
+  const uint16_t* orders;    // natural coefficient orders of the 13 order buckets, concatenated
+  uint32_t order_offset[13];
+  uint8_t ctx_map[39];       // block context of (channel in stream order Y, X, B -> c < 2 ? c ^ 1 : 2; order bucket)
+  uint32_t num_ctxs, num_hist, nctx;
+  // per group (kTokPerGroup = 3072 entries: 1024 varblocks x 3 channels)
+  uint16_t* blk;             // [group][1024] raster positions of the first blocks
+  uint32_t* nblk;            // [group]
+  uint32_t* info;            // [group][3072]: non-zero count | (last non-zero scan position + 1) << 16
+  uint32_t* off;             // [group][3072]: first token of the (varblock, channel) in its group's stream
+  uint8_t* nzmap;            // [group][3][1024]: ceil(count / covered blocks) per 8x8 block (the decoder's nzeros map)
+  uint32_t* total;           // [group]
+  const uint32_t* base;      // [group] (emit): first token of the group in `tokens`
+  uint2* tokens;             // (emit) {context, value}
+};
+constexpr uint32_t kTokPerGroup = 3072;
+
+constexpr uint32_t kTokThreads = 1024, kTokWaves = kTokThreads / 64;  // sixteen waves per group: the walk is latency-bound
+
+__global__ __launch_bounds__(kTokThreads) void k_enc_tok_count(EncTok P) {
+  __shared__ uint16_t l_blk[1024];
+  __shared__ uint32_t l_cnt[kTokPerGroup];
+  __shared__ uint32_t l_scan[256];
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool scanner = tid < 256;  // the two scans are the first four waves' work
+  const uint32_t bx0 = (g % P.xg) * 32, by0 = (g / P.xg) * 32;
+  const uint32_t gw = min(32u, P.xb - bx0), gh = min(32u, P.yb - by0), n = gw * gh;
+  // ---- the group's first blocks in raster order: four consecutive raster positions per thread, exclusive scan
+  uint32_t first[4] = {0, 0, 0, 0}, cnt = 0;
+  if (scanner) {
+    for (uint32_t j = 0; j < 4; j++) {
+      const uint32_t i = tid * 4 + j;
+      first[j] = (i < n && (P.acs[size_t(by0 + i / gw) * P.xb + bx0 + i % gw] & 1)) ? 1u : 0u;
+      cnt += first[j];
+    }
+    l_scan[tid] = cnt;
+  }
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const uint32_t v = (scanner && tid >= d) ? l_scan[tid - d] : 0u;
+    __syncthreads();
+    if (scanner) l_scan[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t nblk = l_scan[255];
+  if (scanner) {
+    uint32_t idx = l_scan[tid] - cnt;
+    for (uint32_t j = 0; j < 4; j++)
+      if (first[j]) {
+        l_blk[idx] = uint16_t(tid * 4 + j);
+        P.blk[size_t(g) * 1024 + idx] = uint16_t(tid * 4 + j);
+        idx++;
+      }
+  }
+  if (tid == 0) P.nblk[g] = nblk;
+  __syncthreads();
+  // ---- a wave per (varblock, channel): non-zero count beyond the lowest-frequency corner, last non-zero scan position
+  for (uint32_t e = wave; e < nblk * 3; e += kTokWaves) {
+    const uint32_t b = e / 3, ci = e % 3, c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
+    const uint32_t i = l_blk[b], lbx = i % gw, lby = i / gw;
+    const size_t cell = size_t(by0 + lby) * P.xb + bx0 + lbx;
+    const uint32_t st = P.acs[cell] >> 1, log2c = c_log2_covered[st], covered = 1u << log2c, size = covered * 64;
+    const uint16_t* order = P.orders + P.order_offset[c_strategy_order[st]];
+    const int32_t* co = P.coeffs + (size_t(g) * 3 + c) * 65536 + P.coef_off[cell];
+    uint32_t nz = 0, last = 0;
+    for (uint32_t k0 = 0; k0 < size; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const bool f = k >= covered && co[order[k]] != 0;
+      const unsigned long long m = __ballot(f);
+      nz += uint32_t(__popcll(m));
+      if (m) last = k0 + 64 - uint32_t(__clzll(m));  // last non-zero scan position + 1
+    }
+    if (lane == 0) {
+      P.info[size_t(g) * kTokPerGroup + e] = nz | last << 16;
+      l_cnt[e] = 1 + (nz ? last - covered : 0u);
+    }
+    const uint32_t cx = c_covered_x[st], cy = c_covered_y[st];
+    if (lane < cx * cy) P.nzmap[(size_t(g) * 3 + c) * 1024 + (lby + lane / cx) * 32 + lbx + lane % cx] = uint8_t((nz + covered - 1) >> log2c);
+  }
+  __syncthreads();
+  // ---- exclusive scan of the token counts in stream order (twelve per thread)
+  const uint32_t ne = nblk * 3;
+  uint32_t sum = 0;
+  if (scanner) {
+    for (uint32_t j = 0; j < 12; j++) {
+      const uint32_t e = tid * 12 + j;
+      sum += e < ne ? l_cnt[e] : 0u;
+    }
+    l_scan[tid] = sum;
+  }
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    const uint32_t v = (scanner && tid >= d) ? l_scan[tid - d] : 0u;
+    __syncthreads();
+    if (scanner) l_scan[tid] += v;
+    __syncthreads();
+  }
+  if (scanner) {
+    uint32_t o = l_scan[tid] - sum;
+    for (uint32_t j = 0; j < 12; j++) {
+      const uint32_t e = tid * 12 + j;
+      if (e < ne) {
+        P.off[size_t(g) * kTokPerGroup + e] = o;
+        o += l_cnt[e];
+      }
+    }
+  }
+  if (tid == 255) P.total[g] = l_scan[255];
+}
+
+__global__ __launch_bounds__(kTokThreads) void k_enc_tok_emit(EncTok P) {
+  const uint32_t g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t bx0 = (g % P.xg) * 32, by0 = (g / P.xg) * 32;
+  const uint32_t gw = min(32u, P.xb - bx0);
+  const uint32_t nblk = P.nblk[g];
+  const uint32_t hist_off = (g % P.num_hist) * P.nctx;
+  uint2* const out = P.tokens + P.base[g];
+  for (uint32_t e = wave; e < nblk * 3; e += kTokWaves) {
+    const uint32_t b = e / 3, ci = e % 3, c = ci == 0 ? 1u : (ci == 1 ? 0u : 2u);
+    const uint32_t i = P.blk[size_t(g) * 1024 + b], lbx = i % gw, lby = i / gw;
+    const size_t cell = size_t(by0 + lby) * P.xb + bx0 + lbx;
+    const uint32_t st = P.acs[cell] >> 1, log2c = c_log2_covered[st], covered = 1u << log2c, size = covered * 64;
+    const uint32_t ord = c_strategy_order[st];
+    const uint16_t* order = P.orders + P.order_offset[ord];
+    const int32_t* co = P.coeffs + (size_t(g) * 3 + c) * 65536 + P.coef_off[cell];
+    const uint32_t inf = P.info[size_t(g) * kTokPerGroup + e], nz = inf & 0xFFFFu, last = inf >> 16;
+    const uint32_t o = P.off[size_t(g) * kTokPerGroup + e];
+    const uint32_t bc = P.ctx_map[(c < 2 ? c ^ 1 : 2) * 13 + ord];
+    if (lane == 0) {
+      // entropy_coder.h:25-35 PredictFromTopAndLeft over the map of counts (every cell read here belongs to a varblock
+      // that comes earlier in raster order), ac_context.h:131-143 NonZeroContext
+      const uint8_t* m = P.nzmap + (size_t(g) * 3 + c) * 1024;
+      uint32_t pred;
+      if (lbx == 0) pred = lby ? m[(lby - 1) * 32] : 32u;
+      else if (lby == 0) pred = m[lbx - 1];
+      else pred = (uint32_t(m[(lby - 1) * 32 + lbx]) + m[lby * 32 + lbx - 1] + 1) >> 1;
+      uint32_t nzb = pred >= 64 ? 64 : pred;
+      nzb = nzb < 8 ? nzb : 4 + nzb / 2;
+      out[o] = make_uint2(hist_off + nzb * P.num_ctxs + bc, nz);
+    }
+    if (!nz) continue;
+    // ac_context.h:63-83 ZeroDensityContext for scan positions covered .. last - 1: non-zeros left = count - non-zeros before k
+    const uint32_t hoff = hist_off + P.num_ctxs * 37 + 458 * bc;
+    uint32_t before = 0;                            // non-zeros at scan positions [covered, k0)
+    uint32_t carry = nz > size / 16 ? 0u : 1u;      // "previous coefficient was non-zero" for the chunk's first lane
+    for (uint32_t k0 = covered & ~63u; k0 < last; k0 += 64) {
+      const uint32_t k = k0 + lane;
+      const bool in = k >= covered && k < last;
+      const int32_t v = in ? co[order[k]] : 0;
+      const unsigned long long mz = __ballot(in && v != 0);
+      if (in) {
+        const uint32_t left = nz - before - uint32_t(__popcll(mz & ((1ull << lane) - 1)));
+        const uint32_t prev = (lane == 0 || k == covered) ? carry : uint32_t((mz >> (lane - 1)) & 1);
+        const uint32_t nzl = (left + covered - 1) >> log2c;
+        const uint32_t ctx = hoff + (uint32_t(c_coeff_nnz_ctx[nzl & 63]) + c_coeff_freq_ctx[(k >> log2c) & 63]) * 2 + prev;
+        const uint32_t val = v >= 0 ? uint32_t(v) * 2 : uint32_t(-(v + 1)) * 2 + 1;
+        out[o + 1 + (k - covered)] = make_uint2(ctx, val);
+      }
+      before += uint32_t(__popcll(mz));
+      carry = uint32_t((mz >> 63) & 1);
+    }
+  }
+}
+
 }  // namespace jxlhip
 #endif  // JXL_HIP_ENC_H_

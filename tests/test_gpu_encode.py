@@ -113,3 +113,23 @@ def test_4k_encode_decodes_on_both_decoders(built):
     d = np.abs(got.astype(np.int16) - want.astype(np.int16))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3, (int(d.max()), float((d > 0).mean()))
     assert _psnr(got, img) > 36.5, _psnr(got, img)
+
+
+@pytest.mark.parametrize("size,kw", [((777, 555), {}), ((301, 143), dict(distance=0.5)), ((1024, 768), dict(num_histograms=3, distance=2.0)),
+                                     ((640, 333), dict(strategy_mode=0, cfl_fit=1)), ((256, 256), dict(distance=8.0)),
+                                     ((2048, 1111), dict(cfl_fit=1)), ((8, 8), {}), ((263, 9), dict(distance=0.3))])
+def test_device_tokenisation_writes_the_same_stream(built, size, kw):
+    """The AC tokens built on the device (enc_entropy_coder.cc:153-255 restated as two kernels: a count and an emit pass
+    per 256x256 group) against the host tokeniser on the coefficients copied back: the codestream is the same, byte for
+    byte, so histograms, clustering and every context were the same."""
+    J = built
+    img = J.synth_image(size[0], size[1], seed=size[0] + 3)
+    ctx = J.HipContext()
+    host = J.encode_rgb8_gpu(img, ctx, **kw)
+    t = {}
+    dev = J.encode_rgb8_gpu(img, ctx, timings=t, device_tokens=True, **kw)
+    again = J.encode_rgb8_gpu(img, ctx, **kw)  # the context serves both forms in any order
+    ctx.close()
+    assert host == again
+    assert dev == host, (len(dev), len(host))
+    assert t["kernels_ms"] > 0 and t["device_tokens"] >= 3 * ((size[0] + 7) // 8) * ((size[1] + 7) // 8) // 64
