@@ -805,31 +805,42 @@ def main():
     if world == 1 and args.max_clusters == 0 and args.ac_code_mode == 0 and not args.no_libjxl_tables and args.shard == "frames":
         datas128 = [make_stream(xsize, ysize, args.distance, 177 + i, 128, 0) for i in range(ndistinct)]
         frames128 = [J.Frame(d, threads=min(8, os.cpu_count() or 1)) for d in datas128]
-        # (frames per step as for `value`: with 86 KB of tables per frame only one workgroup per CU would stay resident with
-        # the tables in LDS, 256 frames per launch, and a launch lasts as long as its slowest section whatever its size:
-        # 45.8 GP/s at 256 frames per step against 53 at 640 with the tables read in place from global memory)
-        lds128 = max((f.info["num_clusters"] << f.info["log_alpha"]) * 8 + ((f.info["ctx_map_size"] + 16 + 15) & ~15) + 128 + 128 + 64 * 200
-                     for f in frames128)
-        batch128 = args.batch
+        # Frames per step: 512 (when `value` runs more). 64 KB of alias tables in the 8-byte form leave one workgroup per CU
+        # (86 KB per frame: 256 frames per launch, 45.8 GP/s); the six-byte form of jxl_hip_entropy_lanes.h (70 KB per frame) keeps
+        # two per CU resident = 512 frames per launch. More frames than that in one launch fall back to the tables read in
+        # place from global memory (the line's second figure, at `value`'s frames per step, for continuity with round 3).
+        lds128 = max(128 + 16384 + 32768 + 256 + ((f.info["ctx_map_size"] + 16 + 15) & ~15) + 128 + 64 * 200 for f in frames128)
         full_sets = sets
-        sets = [cs[:batch128] for cs in full_sets]
-        load(frames128)
-        prime()
-        for _ in range(max(1, args.warmup)):
-            step()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        el128 = time.perf_counter() - t1
-        libjxl_tables = {"value": round(batch128 * args.steps * xsize * ysize * 1e-6 / el128, 2), "unit": "MP/s",
-                         "ms_per_step": round(el128 / args.steps * 1e3, 3), "frames_per_step": batch128, "max_clusters": 128,
-                         "clusters": [f.info["num_clusters"] for f in frames128], "lds_bytes_per_frame": lds128,
+
+        def run128(batch128):
+            nonlocal sets
+            sets = [cs[:batch128] for cs in full_sets]
+            load(frames128)
+            prime()
+            for _ in range(max(1, args.warmup)):
+                step()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            el = time.perf_counter() - t1
+            return round(batch128 * args.steps * xsize * ysize * 1e-6 / el, 2), round(el / args.steps * 1e3, 3)
+
+        batch128 = min(512, args.batch)
+        v128, ms128 = run128(batch128)
+        libjxl_tables = {"value": v128, "unit": "MP/s", "ms_per_step": ms128, "frames_per_step": batch128, "max_clusters": 128,
+                         "clusters": [f.info["num_clusters"] for f in frames128], "log_alpha": [f.info["log_alpha"] for f in frames128],
+                         "lds_bytes_per_frame": lds128,
                          "bpp": round(sum(len(d) for d in datas128) / float(ndistinct) * 8.0 / (xsize * ysize), 3),
-                         "note": "same frames, schedule, frames per step and timed region as `value`; histograms clustered to libjxl's limit "
-                                 "of 128 (enc_ans.cc:931) instead of the synthetic encoder's default 64: the alias tables no longer fit "
-                                 "every frame's workgroup into LDS and are read in place from global memory (the C++ trip)"}
+                         "note": "same frames, schedule and timed region as `value`; histograms clustered to libjxl's limit of 128 "
+                                 "(enc_ans.cc:931) instead of the synthetic encoder's default 64. Their alias tables stay in LDS in a "
+                                 "six-byte form (hand-written trip, three reads per token) at two frames per CU, hence 512 frames per step"}
+        if args.batch > batch128:
+            v2, ms2 = run128(args.batch)
+            libjxl_tables["at_value_frames_per_step"] = {"value": v2, "ms_per_step": ms2, "frames_per_step": args.batch,
+                                                         "note": "more frames than stay resident with the tables in LDS: read in place "
+                                                                 "from global memory (the C++ trip), as in round 3"}
         sets = full_sets
         for f in frames128:
             f.close()

@@ -217,6 +217,7 @@ struct JxlHipContext {
   Buf batch_params, batch_map, batch_lanes;  // jxlhip_run_entropy_batch: parameter blocks, workgroup map, lane map
   uint32_t batch_wait_shift = 2, batch_lanes_per_wave = 64, batch_wpg = 4;
   bool batch_galias = false;  // the lane kernel reads its alias tables from global memory (PrepareBatch)
+  bool batch_a6 = false;      // ... or keeps them in LDS in the six-byte form (jxl_hip_entropy_lanes.h LanesLdsLayout)
   bool batch_prefix = false;  // ... decodes prefix codes
   int batch_kernel = -1;
   std::vector<uint32_t> sec_size_host, sec_sel_host, pass_clusters, pass_log_alpha;
@@ -1906,7 +1907,7 @@ static int EndDownstreamBatch(JxlHipContext* const* ctxs, size_t n, bool filter_
   return 0;
 }
 
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX = false, bool ASMT = false>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX = false, bool ASMT = false, bool A6 = false>
 static int LaunchEntropyLanesW(JxlHipContext* c0);
 template <typename CoefT, bool GALIAS, bool ASMT>
 static int LaunchEntropyLanesA(JxlHipContext* c0) {
@@ -1933,11 +1934,16 @@ static int LaunchEntropyLanes(JxlHipContext* c0) {
     return c0->batch_wpg == 1 ? LaunchEntropyLanesW<CoefT, 1, false, true, true>(c0)
                               : (c0->batch_wpg == 2 ? LaunchEntropyLanesW<CoefT, 2, false, true, true>(c0)
                                                     : LaunchEntropyLanesW<CoefT, 4, false, true, true>(c0));
+  if constexpr (sizeof(CoefT) == 2) {
+    if (c0->batch_a6)  // (PrepareBatch: one wave per workgroup, int16 coefficients; no instrumented build)
+      return EnvInt("JXLHIP_LANES_CPP", 0) ? LaunchEntropyLanesW<CoefT, 1, false, false, false, false, true>(c0)
+                                           : LaunchEntropyLanesW<CoefT, 1, false, false, false, true, true>(c0);
+  }
   return c0->batch_galias ? LaunchEntropyLanesG<CoefT, true>(c0) : LaunchEntropyLanesG<CoefT, false>(c0);
 }
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX, bool ASMT>
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS, bool PREFIX, bool ASMT, bool A6>
 static int LaunchEntropyLanesW(JxlHipContext* c0) {
-  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS, GALIAS, PREFIX, ASMT>;
+  auto k = jxlhip::k_entropy_lanes<CoefT, WPG, AIDS, GALIAS, PREFIX, ASMT, A6>;
   if (c0->batch_lds > 48 * 1024)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(c0->batch_lds)));
   jxlhip::EntropyLaneBatch b;
@@ -2167,14 +2173,20 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     // when that leaves part of the launch waiting for a second round (libjxl-sized tables: 128 clusters x 2^6 slots are
     // 64 KB), the tables stay in global memory instead: a cached global round trip on every token's serial chain, but
     // every frame resident (JXLHIP_GALIAS = 0 / 1 forces either form: measurement aid)
-    size_t lds_by_form[2] = {0, 0};
+    // Between the two, for tables of up to 128 clusters and 8192 slots (128 x 2^6: what libjxl writes for large frames): the six-byte
+    // form of the tables in LDS (70 KB per frame: two frames per CU instead of one), when THAT leaves the launch resident.
+    size_t lds_by_form[3] = {0, 0, 0};
     const size_t num_wgs = map.size() / wpg;  // (`map` holds one unit per wave)
-    for (int form = 0; form < 2; form++)
+    bool a6_ok = wpg == 1 && !c0->lane_prefix && c0->coef_bits == 16 && EnvInt("JXLHIP_A6", 1) != 0;
+    for (int form = 0; form < 3; form++)
       for (size_t wg = 0; wg < num_wgs; wg++) {
         const JxlHipContext* c = ctxs[unit_desc[size_t(map[wg * wpg]) * 4] & 0xFFFF];
         const uint32_t up = unit_desc[size_t(map[wg * wpg]) * 4 + 3];  // the unit's pass
+        if (c->pass_log_alpha[up] > 7 || c->pass_clusters[up] > jxlhip::kLanesA6Clusters ||
+            (size_t(c->pass_clusters[up]) << c->pass_log_alpha[up]) > jxlhip::kLanesA6Slots)
+          a6_ok = false;
         size_t l = jxlhip::LanesLdsLayout(1, c->ep.nctx, c->pass_clusters[up], c->pass_log_alpha[up], 0, 0, form == 0 && !c0->lane_prefix,
-                                          c0->lane_prefix).wave0;
+                                          c0->lane_prefix, form == 2).wave0;
         l += size_t(jxlhip::kLanesPerLaneBytes) * 64 * (wg_shared[wg] ? 1 : wpg);
         lds_by_form[form] = l > lds_by_form[form] ? l : lds_by_form[form];
       }
@@ -2186,12 +2198,18 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     if (forced_form == 0 && lds_by_form[0] <= kLdsBudget) galias = false;
     if (forced_form == 1) galias = true;
     if (c0->lane_prefix) galias = true;  // (prefix codes have no alias tables: the two forms are the same)
+    const size_t resident6 = size_t(dev_cus) * ((160 * 1024) / lds_by_form[2]);
+    const bool a6 = a6_ok && lds_by_form[2] <= kLdsBudget &&
+                    ((galias && forced_form != 1 && resident6 >= num_wgs) || EnvInt("JXLHIP_A6", 1) == 2);  // (2: whenever eligible; tests)
+    if (a6) galias = false;
+    c0->batch_a6 = a6;
     c0->batch_galias = galias;
     c0->batch_prefix = c0->lane_prefix;
-    lds = lds_by_form[galias ? 1 : 0];
+    lds = lds_by_form[a6 ? 2 : (galias ? 1 : 0)] + size_t(EnvInt("JXLHIP_LDS_PAD", 0));  // (measurement aid: fewer workgroups per CU)
     if (EnvInt("JXLHIP_PACK_DEBUG", 0))
-      fprintf(stderr, "[pack] units %zu sections %zu lanes(min) %zu lanes/wave %u waves/wg %u workgroups %zu lds %zu\n", units.size(),
-              total_sections, min_total, lanes_per_wave, wpg, map.size() / wpg, lds);
+      fprintf(stderr, "[pack] units %zu sections %zu lanes(min) %zu lanes/wave %u waves/wg %u workgroups %zu lds %zu tables %s\n", units.size(),
+              total_sections, min_total, lanes_per_wave, wpg, map.size() / wpg, lds,
+              c0->lane_prefix ? "prefix" : (a6 ? "lds6" : (galias ? "global" : "lds8")));
   } else {
     for (size_t i = 0; i < n; i++) {
       const uint32_t wgs = (ctxs[i]->ng + kEntropyWPG - 1) / kEntropyWPG;

@@ -85,12 +85,17 @@ constexpr uint32_t kLanesRefillEvery = 4;           // rounds (trips + pass) per
 constexpr uint32_t kLanesPerLaneBytes = kLanesNzRows + (kLanesRingWords + 2) * 4 + kLanesBlockRing * 4;
 // alias_lds = false: the alias tables stay in global memory (k_entropy_lanes<..., GALIAS = true>); prefix = true: prefix
 // codes (no alias tables at all; the per-cluster table offsets get a 1 KB region).
+// a6 = true: the six-byte form of the alias tables (jxl_hip_lanes_trip.inc, variant 6: log_alpha <= 7, at most 128 clusters
+// and 8192 slots; fixed regions of 16 KB + 32 KB + 256 B whatever the table size, so that the trip's offsets are immediates).
+constexpr uint32_t kLanesA6Clusters = 128, kLanesA6Slots = 8192, kLanesA6B = 128, kLanesA6A = kLanesA6B + kLanesA6Slots * 2,
+                   kLanesA6Cfg = kLanesA6A + kLanesA6Slots * 4, kLanesA6End = kLanesA6Cfg + kLanesA6Clusters * 2;
+static_assert(kLanesA6A == 16512 && kLanesA6Cfg == 49280, "jxl_hip_lanes_trip.inc LT_EREAD_6 has these as immediates");
 __host__ __device__ inline LanesLds LanesLdsLayout(uint32_t num_hist, uint32_t nctx, uint32_t num_clusters, uint32_t log_alpha,
-                                                   uint32_t waves, uint32_t lanes, bool alias_lds = true, bool prefix = false) {
+                                                   uint32_t waves, uint32_t lanes, bool alias_lds = true, bool prefix = false, bool a6 = false) {
   LanesLds l;
   l.f2 = 0;
   l.alias = kLanesF2Bytes;  // (jxl_hip_lanes_trip.inc: ds_read_b64 ... offset:128)
-  l.ctx = l.alias + (alias_lds ? (num_clusters << log_alpha) * 8 : 0);
+  l.ctx = a6 ? kLanesA6End : l.alias + (alias_lds ? (num_clusters << log_alpha) * 8 : 0);
   l.ctx2 = l.ctx + ((num_hist * nctx + 16 + 15) & ~15u);
   l.cfg = l.ctx2 + 64 * 2;
   l.poff = l.cfg + (prefix ? 256 * 2 : 0);  // (the rANS forms carry a cluster's uint config in its alias entries)
@@ -164,9 +169,11 @@ __device__ __forceinline__ uint32_t LaneHybrid(uint32_t tok, uint32_t cfg, uint3
 // ASMT: the hot trips are the hand-written group of jxl_hip_lanes_trip.inc (LDS alias tables, rANS, int16 coefficients only);
 // the C++ trip below is the statement of the algorithm, serves every other form and stays selectable for this one
 // (JXLHIP_LANES_CPP=1) so that the two can be held against each other bit for bit.
-template <typename CoefT, int WPG, bool AIDS, bool GALIAS = false, bool PREFIX = false, bool ASMT = false>
+// A6: the alias tables sit in LDS in the six-byte form (LanesLdsLayout): libjxl-sized tables, two frames per CU instead of one.
+template <typename CoefT, int WPG, bool AIDS, bool GALIAS = false, bool PREFIX = false, bool ASMT = false, bool A6 = false>
 __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_) {
   static_assert(!ASMT || (!GALIAS && !PREFIX && sizeof(CoefT) == 2), "the assembly trip: LDS alias tables, int16 coefficients");
+  static_assert(!A6 || (!GALIAS && !PREFIX), "the six-byte form is an LDS form of the rANS tables");
   EntropyLaneBatch B = B_;
   if (!AIDS) {
     B.prof = nullptr;
@@ -191,12 +198,24 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
   PassDev T;
   LoadParams(T, P.passes + pass);
   const uint32_t log_alpha = T.log_alpha, log_entry = 12 - log_alpha, nclusters = T.num_clusters;
-  const uint32_t entry_mask = (1u << log_entry) - 1, cl_shift = 3 + log_alpha;
+  const uint32_t entry_mask = (1u << log_entry) - 1, cl_shift = (A6 ? 1 : 3) + log_alpha;
   const uint32_t num_bctx = P.num_bctx, nctx = P.nctx, num_hist = P.num_hist;
-  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, 0, 0, !GALIAS && !PREFIX, PREFIX);
+  const LanesLds L = LanesLdsLayout(1, nctx, nclusters, log_alpha, 0, 0, !GALIAS && !PREFIX, PREFIX, A6);
   const uint2* const galias = T.alias_packed;
   const uint32_t* const ptable = T.prefix_table;
   LdsU8* const lds = (LdsU8*)lds_raw;
+  // an alias entry from LDS in the 8-byte form whatever the layout (the C++ trip, the transition pass)
+  auto alias_entry = [&](uint32_t cluster, uint32_t slot) -> LanesU32x2 {
+    if constexpr (A6) {
+      const uint32_t i = ((cluster << log_alpha) + slot) & (kLanesA6Slots - 1);
+      const uint32_t b = ((LdsU16*)(lds + kLanesA6B))[i], a = ((LdsU32*)(lds + kLanesA6A))[i];
+      const uint32_t cfg = ((LdsU16*)(lds + kLanesA6Cfg))[cluster & (kLanesA6Clusters - 1)];
+      const uint32_t cutoff = (b >> 12) << (8 - log_alpha) | a >> (24 + log_alpha);
+      return LanesU32x2{(b & 0xFFFu) | cfg << 12 | cutoff << 24, a & ((1u << (24 + log_alpha)) - 1)};
+    } else {
+      return *(LdsU32x2*)((LdsU8*)lds + kLanesF2Bytes + (cluster << cl_shift) + slot * 8);
+    }
+  };
   LdsU8* const l_ctx = lds + L.ctx;                      // context -> histogram (cluster)
   LdsU16* const l_nnz2 = (LdsU16*)(lds + L.ctx2);        // [ceil(nzeros left / covered)] -> 2 * kCoeffNumNonzeroContext
   LdsU16* const l_cfg = (LdsU16*)(lds + L.cfg);          // per cluster: split_exp | msb << 4 | lsb << 8
@@ -232,10 +251,31 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
     if (PREFIX)
       for (uint32_t i = tid; i < nclusters; i += 64 * WPG) l_poff[i] = T.prefix_offset[i];
     const uint32_t n_alias = (GALIAS || PREFIX) ? 0u : nclusters << log_alpha;
-    LdsU32x2* l_alias = (LdsU32x2*)(lds + L.alias);
-    for (uint32_t i = tid; i < n_alias; i += 64 * WPG) {
-      const uint2 e = galias[i];
-      l_alias[i] = LanesU32x2{e.x, e.y};
+    if constexpr (A6) {
+      // the six-byte form (the host picks it for log_alpha <= 7, at most kLanesA6Clusters and kLanesA6Slots only): a cutoff of
+      // 2^(12 - log_alpha) (every position of the slot is its own symbol) becomes one less, with the slot's own symbol and
+      // frequency on the other side at offset 0
+      LdsU16* const lb = (LdsU16*)(lds + kLanesA6B);
+      LdsU32* const la = (LdsU32*)(lds + kLanesA6A);
+      LdsU16* const lc = (LdsU16*)(lds + kLanesA6Cfg);
+      for (uint32_t i = tid; i < n_alias; i += 64 * WPG) {
+        const uint2 e = galias[i];
+        uint32_t cutoff = e.x >> 24, y = e.y & ((1u << (24 + log_alpha)) - 1);
+        if (cutoff > entry_mask) {
+          cutoff = entry_mask;
+          y = (e.x & 0xFFFu) | (i & ((1u << log_alpha) - 1)) << 24;
+        }
+        const uint32_t lo_bits = 8 - log_alpha;
+        lb[i] = uint16_t((e.x & 0xFFFu) | (cutoff >> lo_bits) << 12);
+        la[i] = y | (cutoff & ((1u << lo_bits) - 1)) << (24 + log_alpha);
+        if ((i & ((1u << log_alpha) - 1)) == 0) lc[i >> log_alpha] = uint16_t((e.x >> 12) & 0xFFFu);
+      }
+    } else {
+      LdsU32x2* l_alias = (LdsU32x2*)(lds + L.alias);
+      for (uint32_t i = tid; i < n_alias; i += 64 * WPG) {
+        const uint2 e = galias[i];
+        l_alias[i] = LanesU32x2{e.x, e.y};
+      }
     }
     if (tid < 64) l_nnz2[tid] = uint16_t(uint32_t(c_coeff_nnz_ctx[tid]) * 2);
     // 2 * kCoeffFreqContext(b) (ac_context.h:63-80), b = (k + 1) >> log2 covered: 1..63 in a valid stream; the entries
@@ -351,14 +391,24 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
           // (operands: the lane's decoder state and cursors; its per-run constants; the loop's lanes and threshold; the frame's constants)
           if (AIDS) {
             if (B.prof) th = __builtin_readcyclecounter();
-            JXL_LANES_TRIP_LOOP_COUNTED(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr, ring_end,
-                                        size, actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base);
+            if constexpr (A6) {
+              JXL_LANES_TRIP_LOOP6_COUNTED(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr,
+                                           ring_end, size, actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base, log_alpha);
+            } else {
+              JXL_LANES_TRIP_LOOP_COUNTED(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr,
+                                          ring_end, size, actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base, log_alpha);
+            }
             if (B.prof) t_wait += __builtin_readcyclecounter() - th;
             n_trips += groups * kLanesTrips;
             n_calls++;
           } else {
-            JXL_LANES_TRIP_LOOP(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr, ring_end, size,
-                                actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base);
+            if constexpr (A6) {
+              JXL_LANES_TRIP_LOOP6(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr, ring_end,
+                                   size, actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base, log_alpha);
+            } else {
+              JXL_LANES_TRIP_LOOP(groups, state, bitpos, k, nzeros, ctxe, addr_a, nnz_b, dst, acc_lo, acc_hi, log2c, cbase, covm2, ring_addr, ring_end,
+                                  size, actm, cont_min, log_entry, entry_mask, cl_mul, nnz2_addr, shift, coef_base, log_alpha);
+            }
           }
           // lanes of the group that finished their (block, channel), or ran past its last scan position (corrupt stream:
           // the transition pass sees non-zeros left and abandons the section)
@@ -393,7 +443,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
               pe = LanesU32x2{ge.x, ge.y};
             }
           } else {
-            pe = *(LdsU32x2*)(lds + L.alias + ((ctxe << cl_shift) + (((state & 0xFFFu) >> log_entry) << 3)));
+            pe = alias_entry(ctxe, (state & 0xFFFu) >> log_entry);
           }
           pw0 = rp[0];
           pw1 = rp[64];
@@ -564,7 +614,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
             const uint32_t slotw = (bitpos >> 5) & (kLanesRingWords - 1);
             const uint32_t w0 = ring[slotw * 64], w1 = ring[slotw * 64 + 64], w2 = ring[slotw * 64 + 128];
             const uint32_t res = state & 0xFFFu, slot = res >> log_entry, pos = res & entry_mask;
-            const LanesU32x2 e = *(LdsU32x2*)(lds + L.alias + (cluster << cl_shift) + slot * 8);
+            const LanesU32x2 e = alias_entry(cluster, slot);
             const bool gt = pos >= (e.x >> 24);
             const uint32_t x = gt ? e.y : e.x;
             uint32_t tok = gt ? (e.y >> 24) : slot;
@@ -664,7 +714,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_lanes(EntropyLaneBatch B_)
               e = LanesU32x2{ge.x, ge.y};
             }
           } else {
-            e = *(LdsU32x2*)(lds + L.alias + (cluster << cl_shift) + slot * 8);
+            e = alias_entry(cluster, slot);
           }
           const bool gt = pos >= (e.x >> 24);
           const uint32_t x = gt ? e.y : e.x;

@@ -560,6 +560,27 @@ def test_lane_kernel_with_alias_tables_in_global_memory(built, kw, monkeypatch):
     _compare(built, jxlo, built.encode_rgb8(built.synth_image(600, 420, seed=13), **kw))
 
 
+@pytest.mark.parametrize("kw,env", [(dict(max_clusters=128), {}), (dict(max_clusters=128, distance=0.5), dict(JXLHIP_LANES="64")),
+                                    (dict(max_clusters=128, distance=0.3, num_passes=2), {}), (dict(max_clusters=100, num_histograms=3, strategy_mode=2), {}),
+                                    (dict(max_clusters=128, distance=0.5, strategy_mode=0), dict(JXLHIP_LANES_CPP="1")),
+                                    (dict(max_clusters=128, distance=4.0), dict(JXLHIP_LANES_CPP="1")), (dict(), {})])
+def test_lane_kernel_with_six_byte_alias_tables(built, kw, env, monkeypatch, capfd):
+    """Alias tables of up to 128 clusters x 2^6 slots (libjxl-sized) stay in LDS in a six-byte form when that keeps a launch
+    resident (two frames per CU instead of one); JXLHIP_A6=2 picks the form whenever a frame is eligible (log_alpha 5 and 6
+    here). Same coefficients, bit for bit, from the hand-written trip and from the C++ trip over that layout."""
+    import jxlo
+    monkeypatch.setenv("JXLHIP_A6", "2")
+    monkeypatch.setenv("JXLHIP_PACK_DEBUG", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    data = built.encode_rgb8(built.synth_image(1600, 1200, seed=21), **kw)
+    f = built.Frame(data)
+    assert f.info["log_alpha"] in (5, 6) and f.info["num_clusters"] <= 128
+    f.close()
+    _compare(built, jxlo, data)
+    assert "tables lds6" in capfd.readouterr().err  # (the launch plan's own words: the form under test did run)
+
+
 def test_colour_stage_closed_forms_gpu(built):
     """The colour kernel itself (k_color_out through jxlhip_debug_color) against the definition of XYB and the reference's
     closed-form colour tests (tests/color_kat.py: opsin_image_test.cc:28-135): roundtrip of the 13 colours of
