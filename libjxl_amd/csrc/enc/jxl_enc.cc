@@ -11,6 +11,8 @@
 // image_metadata.cc:283-356, frame_header.cc:215-439, loop_filter.cc:20-100, toc.cc:29-73, dec_frame.cc:269-434,
 // dec_modular.cc:427-562, dec_group.cc:469-639, dec_ans.cc:58-376, dec_context_map.cc:48-95, dec_ma.cc:107-159.
 // This is a growth seed for the "VarDCT encoder forward path" row of SURVEY.md §8f, not a quality-tuned encoder.
+#include <omp.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -233,6 +235,38 @@ static void BuildReverseMaps(EncCode* code) {
   }
 }
 
+// OpenMP threads of the writer's loops: a container's CPU share can be far below the CPUs it sees (a 16-CPU quota of 256:
+// 256 threads then spend their time in the barriers). The smaller of the visible CPUs, the cgroup quota and 64, unless
+// OMP_NUM_THREADS or jxlenc_set_threads says otherwise; applied on entry by every encode call (the setting is per thread).
+static int g_enc_threads = 0;
+static int DefaultThreads() {
+  int n = omp_get_num_procs();
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = 0, period = 0;
+    if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) n = std::min<long long>(n, (quota + period - 1) / period);
+    fclose(f);
+  } else if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // (cgroup v1)
+    long long quota = 0, period = 100000;
+    const bool ok = fscanf(q, "%lld", &quota) == 1;
+    fclose(q);
+    if (FILE* pf = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(pf, "%lld", &period) != 1) period = 100000;
+      fclose(pf);
+    }
+    if (ok && quota > 0 && period > 0) n = std::min<long long>(n, (quota + period - 1) / period);
+  }
+  return std::max(1, std::min(n, 64));
+}
+static void UseThreads() {
+  static const int def = getenv("OMP_NUM_THREADS") ? 0 : DefaultThreads();
+  const int n = g_enc_threads > 0 ? g_enc_threads : def;
+  if (n > 0) omp_set_num_threads(n);
+}
+
+static double NowSeconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // Builds clustered, normalised histograms for a token set over `num_ctx` contexts.
 static void BuildPrefixCodes(EncCode* code, const std::vector<std::vector<double>>& csum);
 
@@ -248,15 +282,37 @@ static void BuildCode(const std::vector<const std::vector<Token>*>& streams, siz
   code->lz_len_cfg.msb = code->lz_len_cfg.lsb = 0;
   uint32_t max_tok = 0;
   std::vector<std::vector<uint32_t>> hist(num_ctx);
-  for (const auto* st : streams)
-    for (const Token& t : *st) {
+  auto count = [&](const std::vector<Token>& st, std::vector<std::vector<uint32_t>>& into, uint32_t* mx) {
+    for (const Token& t : st) {
       uint32_t tok, nb, bits;
       Symbolize(cfg, code->lz_len_cfg, t.value, &tok, &nb, &bits);
-      max_tok = std::max(max_tok, tok);
-      auto& h = hist[t.ctx];
+      *mx = std::max(*mx, tok);
+      auto& h = into[t.ctx];
       if (h.size() <= tok) h.resize(tok + 1, 0);
       h[tok]++;
     }
+  };
+  size_t total_tokens = 0;
+  for (const auto* st : streams) total_tokens += st->size();
+  if (streams.size() >= 8 && total_tokens >= (size_t(1) << 18)) {  // a large frame's AC tokens: counted per thread, then added up
+#pragma omp parallel
+    {
+      std::vector<std::vector<uint32_t>> mine(num_ctx);
+      uint32_t mx = 0;
+#pragma omp for schedule(dynamic, 4) nowait
+      for (size_t i = 0; i < streams.size(); i++) count(*streams[i], mine, &mx);
+#pragma omp critical
+      {
+        max_tok = std::max(max_tok, mx);
+        for (size_t c = 0; c < num_ctx; c++) {
+          if (hist[c].size() < mine[c].size()) hist[c].resize(mine[c].size(), 0);
+          for (size_t k = 0; k < mine[c].size(); k++) hist[c][k] += mine[c][k];
+        }
+      }
+    }
+  } else {
+    for (const auto* st : streams) count(*st, hist, &max_tok);
+  }
   code->log_alpha = code->use_prefix ? 15 : std::max(5, CeilLog2(max_tok + 1));
   if (!code->use_prefix && code->log_alpha > 8) abort();
   const size_t A = max_tok + 1;
@@ -1770,10 +1826,6 @@ struct ForwardHook {
   int32_t *cap_qf = nullptr, *cap_dc = nullptr, *cap_coeffs = nullptr;
 };
 
-static double NowSeconds() {
-  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
 // (jxlenc_encode_rgba8 -> EncodeImage: width, height, upsampling factor and shift of a subsampled alpha plane; 0 = frame sized)
 static thread_local uint32_t g_alpha_dims[4] = {0, 0, 0, 0};
 // model_only: stop before the bitstream assembly and hand the frame model out (the CPU form of the forward path).
@@ -2908,6 +2960,7 @@ static int Finish(std::vector<uint8_t>& v, uint8_t** out, size_t* n) {
 }
 
 int jxlenc_encode_rgb8(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, uint8_t** out, size_t* n) {
+  jxe::UseThreads();
   if (!rgb || !xs || !ys || !p || p->distance <= 0) return -1;
   jxe::Params q;
   static_assert(sizeof(jxe::Params) == sizeof(JxlEncParams), "param layout");
@@ -2943,6 +2996,7 @@ int jxlenc_encode_rgb8(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEn
 // call, assembly.
 int jxlenc_encode_rgb8_forward(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, jxe::ForwardFn forward, void* ctx,
                                uint8_t** out, size_t* n, double* seconds) {
+  jxe::UseThreads();
   if (!rgb || !xs || !ys || !p || p->distance <= 0 || !forward) return -1;
   jxe::Params q;
   memcpy(&q, p, sizeof(q));
@@ -2966,6 +3020,7 @@ int jxlenc_encode_rgb8_forward(const uint8_t* rgb, uint32_t xs, uint32_t ys, con
 // context map; seconds[2] receives the number of tokens the device produced (0 after that fallback).
 int jxlenc_encode_rgb8_forward_tokens(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, jxe::ForwardFn forward,
                                       jxe::TokenCountsFn tok_counts, jxe::TokensFn tok_emit, void* ctx, uint8_t** out, size_t* n, double* seconds) {
+  jxe::UseThreads();
   if (!rgb || !xs || !ys || !p || p->distance <= 0 || !forward || !tok_counts || !tok_emit) return -1;
   jxe::Params q;
   memcpy(&q, p, sizeof(q));
@@ -2991,6 +3046,7 @@ int jxlenc_encode_rgb8_forward_tokens(const uint8_t* rgb, uint32_t xs, uint32_t 
 // device path with, array by array, and what lets the hook plumbing be tested without a GPU.
 int jxlenc_forward_cpu(void*, const uint8_t* rgb, size_t stride, const JxlHipEncDesc* d, uint8_t* acs, int32_t* qf, int32_t* dc,
                        int32_t* coeffs) {
+  jxe::UseThreads();
   if (!rgb || !d || !acs || !qf || !dc || !coeffs || stride < size_t(d->xsize) * 3) return -1;
   jxe::Params q;
   memset(&q, 0, sizeof(q));
@@ -3027,6 +3083,7 @@ int jxlenc_forward_cpu(void*, const uint8_t* rgb, size_t stride, const JxlHipEnc
 // (acs / qf: yb * xb, dc: 3 * yb * xb, coeffs: groups * 3 * 65536).
 int jxlenc_forward_model(const uint8_t* rgb, uint32_t xs, uint32_t ys, const JxlEncParams* p, jxe::ForwardFn forward, void* ctx,
                          uint8_t* acs, int32_t* qf, int32_t* dc, int32_t* coeffs) {
+  jxe::UseThreads();
   if (!rgb || !xs || !ys || !p || p->distance <= 0 || !forward || !acs || !qf || !dc || !coeffs) return -1;
   jxe::Params q;
   memcpy(&q, p, sizeof(q));
@@ -3046,6 +3103,7 @@ int jxlenc_forward_model(const uint8_t* rgb, uint32_t xs, uint32_t ys, const Jxl
 
 // RGBA8 image: the colour as jxlenc_encode_rgb8, alpha (channel 3) losslessly as a Modular-coded extra channel.
 int jxlenc_encode_rgba8(const uint8_t* rgba, uint32_t xs, uint32_t ys, const JxlEncParams* p, uint8_t** out, size_t* n) {
+  jxe::UseThreads();
   if (!rgba || !xs || !ys || !p || p->distance <= 0) return -1;
   jxe::Params q;
   memcpy(&q, p, sizeof(q));
@@ -3094,6 +3152,7 @@ int jxlenc_encode_rgba8(const uint8_t* rgba, uint32_t xs, uint32_t ys, const Jxl
 // Lossless (Modular frame) stream of an interleaved 8-bit image with 1-4 channels; see jxe::EncodeLossless for `flags`.
 int jxlenc_encode_lossless(const uint8_t* px, uint32_t xs, uint32_t ys, uint32_t channels, uint32_t flags, uint32_t seed, uint8_t** out,
                            size_t* n) {
+  jxe::UseThreads();
   if (!px || !xs || !ys || channels < 1 || channels > 4) return -1;
   std::vector<uint8_t> v;
   try {
@@ -3106,6 +3165,7 @@ int jxlenc_encode_lossless(const uint8_t* px, uint32_t xs, uint32_t ys, uint32_t
 }
 
 int jxlenc_encode_random(uint32_t xs, uint32_t ys, const JxlEncParams* p, uint8_t** out, size_t* n) {
+  jxe::UseThreads();
   if (!xs || !ys || !p) return -1;
   jxe::Params q;
   memcpy(&q, p, sizeof(q));
@@ -3118,6 +3178,12 @@ int jxlenc_encode_random(uint32_t xs, uint32_t ys, const JxlEncParams* p, uint8_
   return Finish(v, out, n);
 }
 
+// 0 = back to the default
+int jxlenc_set_threads(int n) {
+  jxe::g_enc_threads = n > 0 ? n : 0;
+  jxe::UseThreads();
+  return omp_get_max_threads();
+}
 void jxlenc_free(uint8_t* p) { free(p); }
 
 // Deterministic synthetic test image: dark gradient background, seeded rectangles, discs, texture and noise

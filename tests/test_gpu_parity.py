@@ -63,6 +63,8 @@ def _compare(J, jxlo, data, check_rgb=True, crop_idct=False):
 
 @pytest.mark.parametrize("size,kw", [
     ((64, 64), dict()),                                   # single TOC entry: AC data starts mid-byte
+    ((256, 256), dict(strategy_mode=1)),                  # BASELINE.json configs[0] at its size: exactly one full 256x256 group, d1.0
+    ((256, 256), dict(strategy_mode=2, distance=2.0)),    # ... with every transform size and the second EPF iteration
     ((8, 8), dict(strategy_mode=0)),                      # one block
     ((1, 1), dict(strategy_mode=0)),
     ((257, 255), dict()),                                 # ragged groups, xsize not a multiple of 8
