@@ -2198,7 +2198,7 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
     if (forced_form == 0 && lds_by_form[0] <= kLdsBudget) galias = false;
     if (forced_form == 1) galias = true;
     if (c0->lane_prefix) galias = true;  // (prefix codes have no alias tables: the two forms are the same)
-    const size_t resident6 = size_t(dev_cus) * ((160 * 1024) / lds_by_form[2]);
+    const size_t resident6 = lds_by_form[2] ? size_t(dev_cus) * ((160 * 1024) / lds_by_form[2]) : num_wgs;
     const bool a6 = a6_ok && lds_by_form[2] <= kLdsBudget &&
                     ((galias && forced_form != 1 && resident6 >= num_wgs) || EnvInt("JXLHIP_A6", 1) == 2);  // (2: whenever eligible; tests)
     if (a6) galias = false;
