@@ -258,6 +258,10 @@ int jxlhip_set_output_format(JxlHipContext* ctx, uint32_t data_type, uint32_t nu
  * of the output are columns of the image (jxlhip_download_pixels then hands out xsize rows of ysize pixels). Call before
  * the upload. */
 int jxlhip_set_output_orientation(JxlHipContext* ctx, uint32_t orientation);
+/* 2- and 4-channel output: the colour samples are divided by max(alpha, 2^-26) as they are written, after the transfer
+ * function (what JxlDecoderSetUnpremultiplyAlpha asks of an image whose alpha is associated:
+ * render_pipeline/stage_write.cc:359-361,460-482, dec_frame.h:209-211). Call before the upload; 0 = off (the default). */
+int jxlhip_set_output_unpremultiply(JxlHipContext* ctx, int on);
 /* Alpha plane of the image (f32 in [0, 1], xsize * ysize, host memory; copied synchronously) for 2- and 4-channel output;
  * NULL = opaque again. */
 int jxlhip_set_alpha(JxlHipContext* ctx, const float* alpha, uint32_t xsize, uint32_t ysize);
@@ -478,6 +482,9 @@ int jxlhip_canvas_blend(JxlHipCanvas* canvas, JxlHipContext* frame, const JxlHip
  * host memory; rows of `stride` bytes. Synchronous. */
 int jxlhip_canvas_download(JxlHipCanvas* canvas, uint32_t data_type, uint32_t num_channels, uint32_t bits_per_sample, int big_endian,
                            uint32_t orientation, void* dst, size_t stride);
+/* jxlhip_canvas_download of a canvas with alpha hands out un-premultiplied colour (as jxlhip_set_output_unpremultiply) in its
+ * 2- and 4-channel formats; the canvas itself stays as blended. 0 = off (the default). */
+int jxlhip_canvas_set_unpremultiply(JxlHipCanvas* canvas, int on);
 /* The canvas alpha plane as floats (xsize * ysize, not oriented). Synchronous. */
 int jxlhip_canvas_download_alpha(JxlHipCanvas* canvas, float* dst, size_t n);
 

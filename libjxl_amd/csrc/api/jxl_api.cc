@@ -1198,13 +1198,20 @@ JxlDecoderStatus DeliverPixels(JxlDecoder* d, const OutFormat& of, size_t xs, si
 JxlDecoderStatus BlendIntoCanvas(JxlDecoder* d);
 const OutFormat kCanvasFormat = {0, 4, 0, 0};  // what a frame headed for the canvas is decoded into: f32 x 4, as coded
 
+// JxlDecoderSetUnpremultiplyAlpha acts on an output with alpha of an image whose (first) alpha channel is associated
+// (dec_frame.h:205-211, stage_write.cc:359-361).
+bool WantsUnpremultiply(const JxlDecoder* d, const OutFormat& of) {
+  if (!d->unpremul || !(of.nc == 2 || of.nc == 4)) return false;
+  for (const auto& e : d->ih.extra)
+    if (e.type == 0) return e.alpha_associated != 0;
+  return false;
+}
+
 JxlDecoderStatus DecodeModularPixels(JxlDecoder* d, bool to_canvas) {
   const OutFormat of = to_canvas ? kCanvasFormat : MapFormat(d, d->fmt);
-  if ((of.nc == 2 || of.nc == 4) && d->unpremul)
-    for (const auto& e : d->ih.extra)
-      if (e.type == 0 && e.alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
   if (!r) r = jxlhip_set_output_orientation(d->ctx, to_canvas ? 1 : UndoOrientation(d));
+  if (!r) r = jxlhip_set_output_unpremultiply(d->ctx, !to_canvas && WantsUnpremultiply(d, of) ? 1 : 0);
   {
     JxlAmdFramePlacement pl;
     jxlamd_modframe_placement(d->mframe, &pl);
@@ -1260,12 +1267,12 @@ JxlDecoderStatus DecodePixels(JxlDecoder* d, bool to_canvas) {
       break;
     }
   const bool want_alpha = (of.nc == 2 || of.nc == 4) && alpha_ec >= 0;
-  if (want_alpha && d->unpremul && d->ih.extra[alpha_ec].alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
   jxlamd_frame_set_linear_output(d->frame, d->want_linear >= 0 ? d->want_linear : (P.ih.linear_tf ? 1 : 0));
   const uint32_t orientation = to_canvas ? 1 : UndoOrientation(d);
   if (to_canvas && d->want_linear >= 0 && d->want_linear != (P.ih.linear_tf ? 1 : 0)) return Fail(d, "unsupported: blending with a changed transfer function");
   int r = jxlhip_set_output_format(d->ctx, of.type, of.nc, of.bits, of.big_endian);
   if (!r) r = jxlhip_set_output_orientation(d->ctx, orientation);
+  if (!r) r = jxlhip_set_output_unpremultiply(d->ctx, !to_canvas && WantsUnpremultiply(d, of) ? 1 : 0);
   if (!r) r = jxlhip_set_alpha(d->ctx, nullptr, 0, 0);
   if (!r && P.has_patches) {  // the reference frames the patches read: the XYB slots of the canvas
     const float* planes[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1416,9 +1423,7 @@ JxlDecoderStatus BlendIntoCanvas(JxlDecoder* d) {
 // The canvas in the caller's format: what DeliverPixels does for a frame decoded straight into that format.
 JxlDecoderStatus DeliverCanvas(JxlDecoder* d) {
   const OutFormat of = MapFormat(d, d->fmt);
-  if ((of.nc == 2 || of.nc == 4) && d->unpremul)
-    for (const auto& e : d->ih.extra)
-      if (e.type == 0 && e.alpha_associated) return Fail(d, "unsupported: un-premultiplying alpha");
+  if (jxlhip_canvas_set_unpremultiply(d->canvas, WantsUnpremultiply(d, of) ? 1 : 0)) return Fail(d, "canvas output");
   const uint32_t orientation = UndoOrientation(d);
   const size_t xs = OrientedXsize(d), ys = OrientedYsize(d);
   const size_t bpp = of.nc * SampleBytes(d->fmt.data_type);

@@ -253,6 +253,7 @@ struct JxlHipContext {
   jxlhip::EncFwd enc_last;     // the parameters of the last jxlhip_enc_forward (its input stays resident): jxlhip_enc_forward_rerun
   bool enc_last_gaborish = false;
   uint32_t out_orient = 0;  // jxlhip_set_output_orientation: PixelOut::orient bits (0 = the image as coded)
+  bool out_unpremul = false;  // jxlhip_set_output_unpremultiply (PixelOut::orient bit 3 for outputs that carry alpha)
   // splines (JxlHipSplines): the draw cache on the device; for a Modular frame also the float planes they are drawn over
   Buf spl_seg, spl_row_start, spl_row_seg, spl_planes;
   uint32_t spl_segments = 0;
@@ -2843,7 +2844,7 @@ static void ModularBuildOps(JxlHipContext* const* ctxs, size_t n, std::vector<ui
     o.po.alpha = nullptr;
     o.po.xsize = M.xs;
     o.po.ysize = M.ys;
-    o.po.orient = c->out_orient;
+    o.po.orient = c->out_orient | (c->out_unpremul ? 8u : 0u);
     o.po.type = c->out_type;
     o.po.nc = c->out_nc;
     o.po.bits = c->out_bits;
@@ -3130,7 +3131,7 @@ int jxlhip_run_filter_color_batch(JxlHipContext* const* ctxs, size_t n) {
       po.alpha = c->have_alpha ? (c->alpha_patched_valid ? c->alpha_patched.as<float>() : c->alpha.as<float>()) : nullptr;
       po.xsize = c->oxs;
       po.ysize = c->oys;
-      po.orient = c->out_orient;
+      po.orient = c->out_orient | (c->out_unpremul ? 8u : 0u);
       po.type = c->out_type;
       po.nc = c->out_nc;
       po.bits = c->out_bits;
@@ -3382,6 +3383,13 @@ int jxlhip_set_output_orientation(JxlHipContext* c, uint32_t orientation) {
   // EXIF numbering -> mirror x (1) | mirror y (2) | transpose (4): stage_write.cc:441-458
   static const uint8_t kBits[9] = {0, 0, 1, 3, 2, 4, 6, 7, 5};
   c->out_orient = kBits[orientation];
+  c->generation++;
+  return 0;
+}
+
+int jxlhip_set_output_unpremultiply(JxlHipContext* c, int on) {
+  if (!c) return JXLHIP_ERR_INVALID_ARGUMENT;
+  c->out_unpremul = on != 0;
   c->generation++;
   return 0;
 }
@@ -3669,7 +3677,7 @@ int jxlhip_download(JxlHipContext* c, const char* name, void* dst, size_t dst_si
 struct JxlHipCanvas {
   int device = 0;
   uint32_t xs = 0, ys = 0;
-  bool has_alpha = false, premultiplied = false;
+  bool has_alpha = false, premultiplied = false, unpremul_out = false;
   Buf cur, slot[4], pixels;
   bool slot_valid[4] = {false, false, false, false};
   // frames kept before the colour transform, [3][xyb_h][xyb_w]: 0..3 the reference slots (patch sources), 4..7 the DC
@@ -3679,6 +3687,12 @@ struct JxlHipCanvas {
   bool xyb_alpha[8] = {false, false, false, false, false, false, false, false};  // a fourth plane: the frame's alpha
   hipStream_t last_stream = nullptr;  // the stream of the last blend: later work on the canvas is ordered behind it
 };
+
+int jxlhip_canvas_set_unpremultiply(JxlHipCanvas* v, int on) {
+  if (!v) return JXLHIP_ERR_INVALID_ARGUMENT;
+  v->unpremul_out = on != 0;
+  return 0;
+}
 
 int jxlhip_canvas_create(int device, uint32_t xsize, uint32_t ysize, uint32_t has_alpha, uint32_t premultiplied, JxlHipCanvas** out) {
   if (!out || !xsize || !ysize || xsize > (1u << 18) || ysize > (1u << 18)) return JXLHIP_ERR_INVALID_ARGUMENT;
@@ -3878,7 +3892,7 @@ int jxlhip_canvas_download(JxlHipCanvas* v, uint32_t data_type, uint32_t num_cha
   po.alpha = v->has_alpha ? v->cur.as<float>() + size_t(3) * v->xs * v->ys : nullptr;
   po.xsize = v->xs;
   po.ysize = v->ys;
-  po.orient = kBits[orientation];
+  po.orient = kBits[orientation] | ((v->unpremul_out && v->has_alpha) ? 8u : 0u);
   po.type = data_type;
   po.nc = num_channels;
   po.bits = (data_type == 2 || data_type == 3) ? (bits && bits < full ? bits : full) : 0;

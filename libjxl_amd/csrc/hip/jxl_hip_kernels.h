@@ -1831,6 +1831,8 @@ struct PixelOut {
   uint32_t xsize, type, nc, bits, swap;  // bits: sample depth of the unsigned types; swap: byte-swapped (big endian) samples
   // Undoing the image's orientation (stage_write.cc:292-306,341-343,441-458,664-699): bit 0 = mirror x, bit 1 = mirror y,
   // bit 2 = transpose (rows of the output are columns of the image: ysize samples long). 0 = rows of xsize pixels.
+  // Bit 3: the colour samples of a pixel with alpha are divided by max(alpha, 2^-26) on the way out (JxlDecoderSetUnpremultiplyAlpha
+  // on an image whose alpha is associated: stage_write.cc:359-361,460-482, after the transfer function as there).
   uint32_t orient, ysize;
 };
 // Where pixel (x, y) of the decoded image goes and which dither cell it takes (the reference dithers after the flips).
@@ -1875,12 +1877,17 @@ __device__ __forceinline__ uint8_t ToU8(float v, int x, int y, int c) {
 // One pixel in any output format. Colour images hand out R (and alpha) when fewer than three channels are asked for,
 // like the reference (stage_write.cc:334-370: num_color_ = 1); 8-bit samples are dithered with the channel's interleave
 // index (stage_write.cc:266-286), wider ones are not.
+constexpr float kSmallAlphaOut = 1.0f / float(1u << 26);  // alpha.h:22 kSmallAlpha
 __device__ __forceinline__ void StorePixel(const PixelOut& o, int x, int y, float r, float g, float b) {
   const uint32_t nc = o.nc, ncol = nc < 3 ? 1u : 3u;
   float v[4] = {r, g, b, 1.0f};
   if (nc == 2 || nc == 4) {
     const float a = o.alpha ? o.alpha[size_t(y) * o.xsize + x] : 1.0f;
     v[ncol] = a;
+    if (o.orient & 8) {
+      const float m = 1.0f / fmaxf(kSmallAlphaOut, a);
+      for (uint32_t c = 0; c < ncol; c++) v[c] *= m;
+    }
   }
   int dx, dy;
   const size_t base = PixelOutIndex(o, x, y, &dx, &dy) * nc;

@@ -823,7 +823,13 @@ __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   const uint32_t nc = P.po.nc, ncol = nc < 3 ? 1u : 3u;
   float s[4];
   for (uint32_t c = 0; c < ncol; c++) s[c] = v[P.num_color == 1 ? 0 : c];  // grey images replicate into RGB output
-  if (nc == 2 || nc == 4) s[ncol] = a;
+  if (nc == 2 || nc == 4) {
+    s[ncol] = a;
+    if (P.po.orient & 8) {  // un-premultiplied on the way out (PixelOut::orient)
+      const float m = 1.0f / fmaxf(kSmallAlphaOut, a);
+      for (uint32_t c = 0; c < ncol; c++) s[c] *= m;
+    }
+  }
   int dx, dy;
   const size_t base = PixelOutIndex(P.po, int(x), int(y), &dx, &dy) * nc;
   for (uint32_t c = 0; c < nc; c++) {

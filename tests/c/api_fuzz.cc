@@ -25,6 +25,8 @@ int jxlhip_run_transform(JxlHipContext*) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_set_alpha(JxlHipContext*, const float*, uint32_t, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_set_output_format(JxlHipContext*, uint32_t, uint32_t, uint32_t, int) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_set_output_orientation(JxlHipContext*, uint32_t) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_set_output_unpremultiply(JxlHipContext*, int) { return JXLHIP_ERR_INVALID_ARGUMENT; }
+int jxlhip_canvas_set_unpremultiply(JxlHipCanvas*, int) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 int jxlhip_canvas_create(int, uint32_t, uint32_t, uint32_t, uint32_t, JxlHipCanvas**) { return JXLHIP_ERR_INVALID_ARGUMENT; }
 void jxlhip_canvas_destroy(JxlHipCanvas*) {}
 int jxlhip_canvas_blend(JxlHipCanvas*, JxlHipContext*, const JxlHipBlend*) { return JXLHIP_ERR_INVALID_ARGUMENT; }

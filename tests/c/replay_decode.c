@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
   uint32_t cur_w = 0, cur_h = 0; /* size of the frame being delivered: the image, or (layers) the frame's own */
   uint8_t* preview_pixels = NULL;
   size_t preview_bytes = 0;
+  int unpremul = 0;
   int nopreview = 0; /* nopreview: do not subscribe to JXL_DEC_PREVIEW_IMAGE (the preview frame is stepped over) */
   int flush = 0, in_frame = 0, flushes = 0; /* flush: JxlDecoderFlushImage whenever the decoder runs out of input inside a frame */
   size_t skip = 0;
@@ -84,6 +85,7 @@ int main(int argc, char** argv) {
     if (!strncmp(argv[i], "chunk=", 6)) chunk = (size_t)atol(argv[i] + 6);
     if (!strcmp(argv[i], "flush")) flush = 1;
     if (!strcmp(argv[i], "nopreview")) nopreview = 1;
+    if (!strcmp(argv[i], "unpremul")) unpremul = 1; /* JxlDecoderSetUnpremultiplyAlpha(true) */
   }
   if (JxlSignatureCheck(bytes, size) == JXL_SIG_INVALID) return 2;
   JxlMemoryManager mm = {NULL, CountingAlloc, CountingFree};
@@ -96,7 +98,7 @@ int main(int argc, char** argv) {
   if (JxlDecoderSubscribeEvents(dec, events) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetRenderSpotcolors(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetKeepOrientation(dec, keep ? JXL_TRUE : JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
-  if (JxlDecoderSetUnpremultiplyAlpha(dec, JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
+  if (JxlDecoderSetUnpremultiplyAlpha(dec, unpremul ? JXL_TRUE : JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetCoalescing(dec, layers ? JXL_FALSE : JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetDecompressBoxes(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (skip) JxlDecoderSkipFrames(dec, skip);

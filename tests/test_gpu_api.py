@@ -247,6 +247,53 @@ def test_image_with_alpha_in_group_sections(built, tmp_path):
     assert np.abs(got[..., :3].astype(int) - want[..., :3].astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("lossless", [False, True])
+@pytest.mark.parametrize("nlayers", [1, 2])
+def test_unpremultiplied_output_of_associated_alpha(built, tmp_path, lossless, nlayers):
+    """JxlDecoderSetUnpremultiplyAlpha (decode.h; stage_write.cc:359-361,460-482): the colour samples of an image whose
+    alpha is associated leave divided by max(alpha, 2^-26), after the transfer function, in the outputs that carry alpha.
+    A single VarDCT / Modular frame (the generic pixel writer, the Modular writer) and a two-layer still (the canvas
+    writer); the expectation is that division applied to the premultiplied f32 output of the same decoder. Three-channel
+    output and images with unassociated alpha are left alone."""
+    J = built
+    yy, xx = np.mgrid[0:200, 0:320]
+    alpha = np.clip((xx * 255) // 250, 0, 255).astype(np.uint8)  # 0 in the first column, 255 beyond column 250
+    alpha[:8, :] = 0
+    rgb = J.synth_image(320, 200, seed=31)
+    pre = (rgb.astype(np.uint32) * alpha[..., None] // 255).astype(np.uint8)
+    layers = [dict(img=np.dstack([pre, alpha]))]
+    if nlayers == 2:
+        patch = np.dstack([J.synth_image(64, 48, seed=32) // 2, np.full((48, 64), 128, np.uint8)])
+        layers[0]["save_as"] = 1
+        layers.append(dict(img=patch, x0=100, y0=60, mode=2, source=1))
+    data = J.encode_layers(layers, lossless=lossless, premultiplied=True)
+    rc, _, out, px = R.run(data, tmp_path, "f32", 4)
+    assert rc == 0, out
+    plain = np.frombuffer(px, np.float32).reshape(200, 320, 4)
+    rc, _, out, px = R.run(data, tmp_path, "f32", 4, "unpremul")
+    assert rc == 0, out
+    got = np.frombuffer(px, np.float32).reshape(200, 320, 4)
+    mul = np.float32(1.0) / np.maximum(np.float32(2.0 ** -26), plain[..., 3])
+    want = plain[..., :3] * mul[..., None]
+    assert np.array_equal(got[..., 3], plain[..., 3])
+    assert np.allclose(got[..., :3], want, rtol=2e-7, atol=0)
+    assert np.abs(got[..., :3] - plain[..., :3]).max() > 0.2  # (it did something)
+    # 8-bit RGBA: the same values through the 8-bit conversion
+    rc, _, out, px = R.run(data, tmp_path, "u8", 4, "unpremul")
+    assert rc == 0, out
+    got8 = np.frombuffer(px, np.uint8).reshape(200, 320, 4)
+    assert np.abs(got8[..., :3].astype(int) - np.clip(np.rint(want * 255), 0, 255).astype(int)).max() <= 1
+    # no alpha in the output: nothing to divide by
+    rc, _, out, px3 = R.run(data, tmp_path, "f32", 3, "unpremul")
+    assert rc == 0, out
+    assert np.array_equal(np.frombuffer(px3, np.float32).reshape(200, 320, 3), plain[..., :3])
+    # alpha that is not associated: the option does nothing (dec_frame.h:209)
+    data_u = J.encode_layers(layers, lossless=lossless, premultiplied=False)
+    rc, _, out, a = R.run(data_u, tmp_path, "f32", 4)
+    rc2, _, out2, b = R.run(data_u, tmp_path, "f32", 4, "unpremul")
+    assert rc == 0 and rc2 == 0 and a == b
+
+
 @pytest.mark.parametrize("ups,ecu", [(1, 2), (1, 4), (2, 2), (2, 4), (2, 8), (4, 4), (8, 8)])
 def test_extra_channel_with_an_upsampling_factor(built, tmp_path, ups, ecu):
     """An alpha channel coded at ceil(image / its own factor) (frame_header.cc:265-283, dec_modular.cc:262-271; what
