@@ -30,7 +30,7 @@ for p in sorted(glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recurs
         a[0] += 1
         a[1] += float(r["Counter_Value"])
     for k in agg:
-        if "entropy" in k or "filter_rows" in k or "idct_fast<short, 4, 4" in k or "idct_fast<short, 1, 1" in k:
+        if "entropy" in k or "modular_streams" in k or "k_enc_" in k or "filter_rows" in k or "idct_fast<short, 4, 4" in k or "idct_fast<short, 1, 1" in k:
             print(k, {c: round(v[1] / v[0]) for c, v in agg[k].items()}, "dispatches", max(v[0] for v in agg[k].values()))
 PY
 cat $R/$OUT/summary.txt
