@@ -353,7 +353,9 @@ __global__ __launch_bounds__(kThreads) void k_enc_transform(EncFwd P) {
 // broadcasts. Sums run in the CPU writer's order (x = 0.., y = 0..), products are not contracted.
 __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
 #pragma clang fp contract(off)
-  constexpr int kBasisLds = 5461;  // (4^7 - 1) / 3: levels 0..6
+  // the DCT matrices of 1..32 points in LDS ((4^6 - 1) / 3 floats: levels 0..5); the 64-point one (16 KB, only the three
+  // largest transforms use it) is read in place, which lets four workgroups share a CU instead of two
+  constexpr int kBasisLds = 1365;
   // (the level of N points starts at (N * N - 1) / 3, which is 1 mod 4: shifted by 3 floats so that rows are 16-byte aligned)
   __shared__ __attribute__((aligned(16))) float s_px[64 * 64], s_t[64 * 64], s_basis_raw[kBasisLds + 3];
   __shared__ float s_ydc[64];
@@ -406,20 +408,23 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
       const uint32_t cr = band * 2 + half, info = s_info[cr * 8 + (col >> 3)];
       if (info == 0xFFFFFFFFu) continue;
       const uint32_t ox = info & 7, C = uint32_t(c_covered_x[info >> 6]) * 8, kx = col - ox * 8;
-      const float* B = s_basis + (C * C - 1) / 3 + kx;
       const float* px = s_px + cr * 8 * 64 + ox * 8;
       float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (uint32_t x = 0; x < C; x += 4) {  // four samples of each of the 8 rows per LDS read (a broadcast within a block)
-        float4 v[8];
-        for (int j = 0; j < 8; j++) v[j] = *reinterpret_cast<const float4*>(px + j * 64 + x);
-        const float b0 = B[x * C], b1 = B[(x + 1) * C], b2 = B[(x + 2) * C], b3 = B[(x + 3) * C];
-        for (int j = 0; j < 8; j++) {
-          acc[j] += v[j].x * b0;
-          acc[j] += v[j].y * b1;
-          acc[j] += v[j].z * b2;
-          acc[j] += v[j].w * b3;
+      auto rows = [&](const float* B) {
+        for (uint32_t x = 0; x < C; x += 4) {  // four samples of each of the 8 rows per LDS read (a broadcast within a block)
+          float4 v[8];
+          for (int j = 0; j < 8; j++) v[j] = *reinterpret_cast<const float4*>(px + j * 64 + x);
+          const float b0 = B[x * C], b1 = B[(x + 1) * C], b2 = B[(x + 2) * C], b3 = B[(x + 3) * C];
+          for (int j = 0; j < 8; j++) {
+            acc[j] += v[j].x * b0;
+            acc[j] += v[j].y * b1;
+            acc[j] += v[j].z * b2;
+            acc[j] += v[j].w * b3;
+          }
         }
-      }
+      };
+      if (C == 64) rows(P.basis_t + 1365 + kx);
+      else rows(s_basis + (C * C - 1) / 3 + kx);
       for (int j = 0; j < 8; j++) s_t[(cr * 8 + j) * 64 + col] = acc[j];
     }
     __syncthreads();
@@ -429,20 +434,28 @@ __global__ __launch_bounds__(256) void k_enc_transform_tile(EncFwd P) {
       if (info == 0xFFFFFFFFu) continue;
       const uint32_t st = info >> 6, oy = (info >> 3) & 7, R = uint32_t(c_covered_y[st]) * 8, C = uint32_t(c_covered_x[st]) * 8;
       const uint32_t ky0 = (cr - oy) * 8;
-      const float* B = s_basis + (R * R - 1) / 3 + ky0;
       const float* tc = s_t + oy * 8 * 64 + col;
       float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (uint32_t y = 0; y < R; y++) {
-        const float v = tc[y * 64];
-        const float4 ba = *reinterpret_cast<const float4*>(B + y * R), bb = *reinterpret_cast<const float4*>(B + y * R + 4);
-        acc[0] += v * ba.x;
-        acc[1] += v * ba.y;
-        acc[2] += v * ba.z;
-        acc[3] += v * ba.w;
-        acc[4] += v * bb.x;
-        acc[5] += v * bb.y;
-        acc[6] += v * bb.z;
-        acc[7] += v * bb.w;
+      if (R == 64) {  // (the table in place: its rows are 4-byte aligned only)
+        const float* B = P.basis_t + 1365 + ky0;
+        for (uint32_t y = 0; y < R; y++) {
+          const float v = tc[y * 64];
+          for (int j = 0; j < 8; j++) acc[j] += v * B[y * R + j];
+        }
+      } else {
+        const float* B = s_basis + (R * R - 1) / 3 + ky0;
+        for (uint32_t y = 0; y < R; y++) {
+          const float v = tc[y * 64];
+          const float4 ba = *reinterpret_cast<const float4*>(B + y * R), bb = *reinterpret_cast<const float4*>(B + y * R + 4);
+          acc[0] += v * ba.x;
+          acc[1] += v * ba.y;
+          acc[2] += v * ba.z;
+          acc[3] += v * ba.w;
+          acc[4] += v * bb.x;
+          acc[5] += v * bb.y;
+          acc[6] += v * bb.z;
+          acc[7] += v * bb.w;
+        }
       }
       const float norm = 1.0f / (float(R) * float(C));
       for (int j = 0; j < 8; j++) s_px[(cr * 8 + j) * 64 + col] = acc[j] * norm;
