@@ -3936,9 +3936,14 @@ static int EncLaunch(JxlHipContext* c, jxlhip::EncFwd& P, bool gaborish) {
         out = out == sets[0] ? sets[1] : sets[0];
       }
       P.planes = const_cast<float*>(in);
-    } else {
+    } else if (getenv("JXLHIP_ENC_SHARPEN_TILE")) {  // the LDS-tile form of the four rounds (the row form is held against it bit for bit)
       hipLaunchKernelGGL(jxlhip::k_enc_sharpen4, dim3((P.xp + 63) / 64, (P.yp + 31) / 32, 3), dim3(256), 0, c->stream,
                          static_cast<const float*>(sets[2]), sets[0], P.xp, P.yp);
+      P.planes = sets[0];
+    } else {
+      const uint32_t strips = (P.xp + jxlhip::kSharpenCols - 1) / jxlhip::kSharpenCols;
+      hipLaunchKernelGGL(jxlhip::k_enc_sharpen_rows, dim3((strips + 3) / 4, (P.yp + jxlhip::kSharpenRows - 1) / jxlhip::kSharpenRows, 3), dim3(256), 0,
+                         c->stream, static_cast<const float*>(sets[2]), sets[0], P.xp, P.yp);
       P.planes = sets[0];
     }
   }

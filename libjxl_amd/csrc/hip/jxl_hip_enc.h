@@ -130,6 +130,88 @@ __global__ __launch_bounds__(256) void k_enc_sharpen4(const float* __restrict__ 
   }
 }
 
+// The four rounds without LDS: a wave owns 64 adjacent columns (the middle 56 are written, four of halo either side) and
+// walks down a strip of rows. Round k of row r needs rows r - 1 .. r + 1 of round k - 1, so when source row s arrives
+// round 1 forms row s - 1, round 2 row s - 2, round 3 row s - 3 and round 4, the output, row s - 4: per round a window of
+// three rows x (left, centre, right) lives in registers, the horizontal neighbours come from the adjacent lanes
+// (wave_shr / wave_shl). Rows and columns outside the image are replaced as k_enc_sharpen does it (the neighbour index is
+// clamped in image coordinates: the sample itself at an image edge); every sample sees the same operands in the same
+// order as there. Lanes / rows of the halo that lack a neighbour hold garbage that never reaches a written sample.
+constexpr int kSharpenCols = 56, kSharpenRows = 64;
+__device__ __forceinline__ float EncFromLeft(float v) {  // the value of the lane of column x - 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float EncFromRight(float v) {  // ... of column x + 1
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+struct SharpenRow {  // one row of each level j (0 = the source, j = after round j): left / centre / right neighbours
+  float L[4], C[4], R[4];
+};
+// One step: source row s enters; `c` (the oldest row's storage) receives the entering row of every level, `a` and `b` hold
+// rows r - 1 and r of the level. The three row sets take the roles in turn, so nothing is copied from step to step.
+// EDGE = false: no sample of the step lies on an image edge (no clamped neighbour to substitute).
+template <bool EDGE>
+__device__ __forceinline__ void SharpenStep(SharpenRow& a, SharpenRow& b, SharpenRow& c, float v0, const float (&osrc)[4], int s, int last,
+                                            bool left_edge, bool right_edge, bool writes, int Y0, int Y1, float* dst, uint32_t xp) {
+#pragma clang fp contract(off)
+  const float w1 = 1.1f * 0.104699568f, w2 = 1.1f * 0.055680538f, nrm = 1.0f / (1.0f + 4 * (w1 + w2));
+  float nC = v0;  // the new row of level j as it enters level j's window
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float nL = EncFromLeft(nC), nR = EncFromRight(nC);
+    c.L[j] = (EDGE && left_edge) ? nC : nL;
+    c.C[j] = nC;
+    c.R[j] = (EDGE && right_edge) ? nC : nR;
+    // round j + 1 forms row r = s - j - 1
+    const int r = s - j - 1;
+    if (EDGE && r == 0) {  // no row above: the row itself
+      a.L[j] = b.L[j]; a.C[j] = b.C[j]; a.R[j] = b.R[j];
+    }
+    if (EDGE && r == last) {  // no row below
+      c.L[j] = b.L[j]; c.C[j] = b.C[j]; c.R[j] = b.R[j];
+    }
+    const float side = b.L[j] + b.R[j] + a.C[j] + c.C[j];
+    const float corner = a.L[j] + a.R[j] + c.L[j] + c.R[j];
+    const float centre = b.C[j];
+    const float blur = (centre + w1 * side + w2 * corner) * nrm;
+    nC = centre + (osrc[j] - blur);  // row r of level j + 1
+    if (j == 3 && writes && r >= Y0 && r < Y1) dst[size_t(r) * xp] = nC;
+  }
+}
+__global__ __launch_bounds__(256) void k_enc_sharpen_rows(const float* __restrict__ orig, float* __restrict__ out, uint32_t xp, uint32_t yp) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+  const int strip_x0 = (int(blockIdx.x) * 4 + wave) * kSharpenCols - 4, gx = strip_x0 + lane;
+  const int Y0 = int(blockIdx.y) * kSharpenRows, Y1 = min(Y0 + kSharpenRows, int(yp));
+  if (strip_x0 + 4 >= int(xp)) return;  // (a wave beyond the last column strip)
+  const size_t plane = size_t(xp) * yp * blockIdx.z;
+  const bool in_x = gx >= 0 && gx < int(xp), left_edge = gx == 0, right_edge = gx == int(xp) - 1;
+  const bool x_edge = strip_x0 <= 0 || strip_x0 + 63 >= int(xp) - 1;  // (wave-uniform: the strip holds an image edge column)
+  const bool writes = lane >= 4 && lane < 4 + kSharpenCols && in_x;
+  const float* src = orig + plane + (in_x ? gx : 0);
+  float* dst = out + plane + (in_x ? gx : 0);
+  SharpenRow P, Q, R;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    P.L[j] = P.C[j] = P.R[j] = Q.L[j] = Q.C[j] = Q.R[j] = R.L[j] = R.C[j] = R.R[j] = 0.0f;
+  float osrc[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // the source's centre values of rows s - 1 .. s - 4
+  const int s_begin = max(Y0 - 4, 0), s_end = Y1 - 1 + 4, last = int(yp) - 1;
+  float next = in_x ? src[size_t(s_begin) * xp] : 0.0f;
+  // (the row sets rotate through the roles in a fixed order of three steps; up to two steps beyond s_end write nothing)
+  auto step = [&](SharpenRow& a, SharpenRow& b, SharpenRow& c, int s) {
+    const float v0 = next;  // source row s (stale beyond the image: replaced by the edge rule before anything reads it)
+    if (s + 1 <= last) next = in_x ? src[size_t(s + 1) * xp] : 0.0f;
+    // rounds 1..4 form rows s - 1 .. s - 4: one of them is the image's first or last row
+    if (x_edge || s <= 4 || s > last) SharpenStep<true>(a, b, c, v0, osrc, s, last, left_edge, right_edge, writes, Y0, Y1, dst, xp);
+    else SharpenStep<false>(a, b, c, v0, osrc, s, last, left_edge, right_edge, writes, Y0, Y1, dst, xp);
+    osrc[3] = osrc[2]; osrc[2] = osrc[1]; osrc[1] = osrc[0]; osrc[0] = v0;
+  };
+  for (int s = s_begin; s <= s_end; s += 3) {
+    step(Q, R, P, s);
+    step(R, P, Q, s + 1);
+    step(P, Q, R, s + 2);
+  }
+}
+
 // Mean absolute deviation of Y from the block mean, per 8x8 block: a wave per 8 blocks (lane = block * 8 + row).
 __global__ void k_enc_activity(EncFwd P) {
 #pragma clang fp contract(off)

@@ -133,3 +133,23 @@ def test_device_tokenisation_writes_the_same_stream(built, size, kw):
     assert host == again
     assert dev == host, (len(dev), len(host))
     assert t["kernels_ms"] > 0 and t["device_tokens"] >= 3 * ((size[0] + 7) // 8) * ((size[1] + 7) // 8) // 64
+
+
+@pytest.mark.parametrize("size", [(301, 143), (640, 333), (56, 64), (57, 65), (8, 8), (1000, 260), (113, 4)])
+def test_sharpening_forms_agree_bit_for_bit(built, size, monkeypatch):
+    """The encoder-side sharpening (four rounds of y <- y + (x - K y), enc_gaborish.cc:21-70 in its iterated form) as the
+    register-window row kernel against the LDS-tile kernel and the one-round-per-launch kernel: the same operands in the
+    same order, so every quantised coefficient, DC value, transform choice and quant-field entry is the same."""
+    J = built
+    img = J.synth_image(size[0], size[1], seed=size[0] * 7 + 1)
+    ctx = J.HipContext()
+    rows = J.enc_forward_model(img, ctx, distance=1.0)
+    monkeypatch.setenv("JXLHIP_ENC_SHARPEN_TILE", "1")
+    tile = J.enc_forward_model(img, ctx, distance=1.0)
+    monkeypatch.delenv("JXLHIP_ENC_SHARPEN_TILE")
+    monkeypatch.setenv("JXLHIP_ENC_SHARPEN_ROUNDS", "1")
+    rounds = J.enc_forward_model(img, ctx, distance=1.0)
+    ctx.close()
+    for other in (tile, rounds):
+        for key in ("acs", "qf", "dc", "coeffs"):
+            assert np.array_equal(rows[key], other[key]), key
