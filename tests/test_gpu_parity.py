@@ -635,6 +635,29 @@ def test_no_kernel_writes_outside_its_buffers(built, monkeypatch):
         finally:
             c.close()
             f.close()
+    # the forward path (sharpening row kernel, transform tiles, device tokenisation) on ragged sizes, and the six-byte table
+    # form of the lane kernel
+    for size in ((301, 143), (57, 65), (640, 333), (8, 8)):
+        c = J.HipContext()
+        try:
+            im = J.synth_image(size[0], size[1], seed=6)
+            a = J.encode_rgb8_gpu(im, c, device_tokens=True, distance=1.0, cfl_fit=1)
+            assert a == J.encode_rgb8_gpu(im, c, distance=1.0, cfl_fit=1)
+            c.sync()
+            assert c.check_guards() == 0, (size, c.check_guards())
+        finally:
+            c.close()
+    monkeypatch.setenv("JXLHIP_A6", "2")
+    f = J.Frame(J.encode_rgb8(J.synth_image(1600, 1200, seed=21), max_clusters=128, distance=0.5), threads=2)
+    c = J.HipContext()
+    try:
+        c.upload(f)
+        c.run_all()
+        c.sync()
+        assert c.check_guards() == 0, c.check_guards()
+    finally:
+        c.close()
+        f.close()
 
 
 def test_no_result_depends_on_bytes_outside_the_buffers(built, monkeypatch):
