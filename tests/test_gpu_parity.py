@@ -583,6 +583,47 @@ def test_lane_kernel_with_six_byte_alias_tables(built, kw, env, monkeypatch, cap
     assert "tables lds6" in capfd.readouterr().err  # (the launch plan's own words: the form under test did run)
 
 
+def test_six_byte_alias_tables_in_a_batched_launch(built, monkeypatch, capfd):
+    """One launch over frames of different size whose tables differ in cluster count and log_alpha (5 and 6, as the benchmark's
+    libjxl-sized streams do): every frame's workgroup stages its own tables in the six-byte form; coefficients and pixels as
+    one by one."""
+    import jxlo
+    J = built
+    monkeypatch.setenv("JXLHIP_A6", "2")
+    monkeypatch.setenv("JXLHIP_PACK_DEBUG", "1")
+    streams = [J.encode_rgb8(J.synth_image(1600, 1200, seed=21), max_clusters=128),                # log_alpha 5, 78 clusters
+               J.encode_rgb8(J.synth_image(1200, 900, seed=22), max_clusters=128, distance=0.5),    # log_alpha 6
+               J.encode_rgb8(J.synth_image(900, 700, seed=23), max_clusters=100, distance=0.3),
+               J.encode_rgb8(J.synth_image(64, 64, seed=3), max_clusters=128)]
+    frames = [J.Frame(s) for s in streams]
+    assert {f.info["log_alpha"] for f in frames} >= {5, 6}
+    ctxs = [J.HipContext() for _ in streams]
+    try:
+        for c, f in zip(ctxs, frames):
+            c.upload(f)
+        J.run_entropy_batch(ctxs)
+        J.run_transform_batch(ctxs)
+        J.run_filter_color_batch(ctxs)
+        for c, s in zip(ctxs, streams):
+            c.sync()
+            r, flags = c.errors()
+            assert r == 0 and not any(flags)
+            o = jxlo.Decoded(s)
+            co = c.download("coeffs").astype(np.int32)
+            ref = o.planes("coeffs")
+            used = _used_mask(o)
+            for g in range(o.info["num_groups"]):
+                assert np.array_equal(co[g, :, :used[g]], ref[g, :, :used[g]])
+            assert np.abs(c.rgb8().astype(int) - o.rgb8.astype(int)).max() <= 1
+            o.close()
+        assert "tables lds6" in capfd.readouterr().err
+    finally:
+        for c in ctxs:
+            c.close()
+        for f in frames:
+            f.close()
+
+
 def test_colour_stage_closed_forms_gpu(built):
     """The colour kernel itself (k_color_out through jxlhip_debug_color) against the definition of XYB and the reference's
     closed-form colour tests (tests/color_kat.py: opsin_image_test.cc:28-135): roundtrip of the 13 colours of
