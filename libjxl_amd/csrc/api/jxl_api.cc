@@ -825,6 +825,10 @@ struct JxlDecoderStruct {
   bool preview_frame = false;  // the current frame is the image's preview (decode.cc:1266-1268): its own events and buffer
   bool got_preview = false;
   bool frame_partial = false;  // d->frame was parsed from a prefix of its bytes (events only; see JxlDecoderFlushImage)
+  // JXL_DEC_FRAME_PROGRESSION (decode.cc:1421-1428,1492-1500): once per frame, when its DC image is there and its AC data is not
+  JxlProgressiveDetail prog_detail = kDC;
+  bool dc_progression_done = false;
+  size_t downsampling_target = 8;  // decode.cc:788
   bool coalescing = true;  // JxlDecoderSetCoalescing: false = every regular frame is delivered by itself, unblended
   int want_linear = -1;  // JxlDecoderSetOutputColorProfile: -1 = as coded
   JxlCmsInterface cms{};
@@ -903,6 +907,8 @@ void ResetState(JxlDecoder* d) {
   d->frame_shown = true;
   d->frame_skipped = false;
   d->frame_partial = false;
+  d->dc_progression_done = false;
+  d->downsampling_target = 8;
   d->preview_frame = d->got_preview = false;
   d->visible_index = d->nonvisible_index = 0;
   d->error = false;
@@ -1482,6 +1488,7 @@ bool NextFrame(JxlDecoder* d) {
   d->frame = nullptr;
   d->mframe = nullptr;
   d->frame_partial = false;
+  d->dc_progression_done = false;
   d->frame_pos = end;
   d->frame_index++;
   d->stage = 2;
@@ -1619,7 +1626,18 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
       }
       if (d->frame_partial) {  // the frame was announced from a prefix: the pixels need all of it
         uint32_t t[3];
-        if (d->cs.size < jxlamd_frame_end(d->frame, t) && !d->cs_complete) return 0;
+        if (d->cs.size < jxlamd_frame_end(d->frame, t) && !d->cs_complete) {
+          // the DC image is decoded and sections are missing: the one progressive step this decoder pauses at (a flush now
+          // draws exactly it plus the groups that are whole; steps by pass are not offered: decode.h says the event "is not
+          // guaranteed to trigger")
+          if ((d->events & JXL_DEC_FRAME_PROGRESSION) && d->prog_detail >= kDC && !d->dc_progression_done && !d->canvas_mode) {
+            d->dc_progression_done = true;
+            d->downsampling_target = 8;
+            *ev = JXL_DEC_FRAME_PROGRESSION;
+            return 2;
+          }
+          return 0;
+        }
         JxlAmdFrame* whole = nullptr;
         if (jxlamd_frame_parse_at(d->cs.p, d->cs.size, d->frame_pos, d->frame_index, d->runner, d->runner_opaque, &whole)) {
           const std::string w = g_last_error;
@@ -2132,8 +2150,12 @@ JxlDecoderStatus JxlDecoderSetDecompressBoxes(JxlDecoder* d, JXL_BOOL decompress
   d->decompress_boxes = decompress != 0;  // (no Brotli here: see JxlDecoderSetBoxBuffer)
   return JXL_DEC_SUCCESS;
 }
-JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder*, JxlProgressiveDetail) { return JXL_DEC_SUCCESS; }
-size_t JxlDecoderGetIntendedDownsamplingRatio(JxlDecoder*) { return 1; }
+JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* d, JxlProgressiveDetail detail) {  // decode.cc:2963-2973
+  if (detail != kDC && detail != kLastPasses && detail != kPasses) return JXL_DEC_ERROR;
+  d->prog_detail = detail;
+  return JXL_DEC_SUCCESS;
+}
+size_t JxlDecoderGetIntendedDownsamplingRatio(JxlDecoder* d) { return d->downsampling_target; }
 // decode.cc:2458-2475 / dec_frame.cc:735-795: what has arrived of the current frame, drawn into the caller's buffer. The
 // groups whose AC sections are whole are decoded; the others come from the DC image alone (the reference draws them with
 // zero passes: every AC coefficient 0). Possible between the frame's NEED_IMAGE_OUT_BUFFER and its FULL_IMAGE, once the

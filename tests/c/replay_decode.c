@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
   uint32_t cur_w = 0, cur_h = 0; /* size of the frame being delivered: the image, or (layers) the frame's own */
   uint8_t* preview_pixels = NULL;
   size_t preview_bytes = 0;
-  int unpremul = 0;
+  int unpremul = 0, progression = 0;
   int nopreview = 0; /* nopreview: do not subscribe to JXL_DEC_PREVIEW_IMAGE (the preview frame is stepped over) */
   int flush = 0, in_frame = 0, flushes = 0; /* flush: JxlDecoderFlushImage whenever the decoder runs out of input inside a frame */
   size_t skip = 0;
@@ -86,6 +86,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "flush")) flush = 1;
     if (!strcmp(argv[i], "nopreview")) nopreview = 1;
     if (!strcmp(argv[i], "unpremul")) unpremul = 1; /* JxlDecoderSetUnpremultiplyAlpha(true) */
+    if (!strcmp(argv[i], "progression")) progression = 1; /* subscribe to JXL_DEC_FRAME_PROGRESSION and flush when it comes */
   }
   if (JxlSignatureCheck(bytes, size) == JXL_SIG_INVALID) return 2;
   JxlMemoryManager mm = {NULL, CountingAlloc, CountingFree};
@@ -95,6 +96,7 @@ int main(int argc, char** argv) {
   if (JxlDecoderSetParallelRunner(dec, JxlThreadParallelRunner, runner) != JXL_DEC_SUCCESS) return 2;
   int events = JXL_DEC_BASIC_INFO | JXL_DEC_FULL_IMAGE | JXL_DEC_COLOR_ENCODING | JXL_DEC_FRAME | JXL_DEC_PREVIEW_IMAGE | JXL_DEC_BOX;
   if (nopreview) events &= ~JXL_DEC_PREVIEW_IMAGE;
+  if (progression) events |= JXL_DEC_FRAME_PROGRESSION;
   if (JxlDecoderSubscribeEvents(dec, events) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetRenderSpotcolors(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetKeepOrientation(dec, keep ? JXL_TRUE : JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
@@ -146,6 +148,19 @@ int main(int argc, char** argv) {
       printf("event NEED_MORE_INPUT consumed=%zu\n", consumed);
       if (JxlDecoderSetInput(dec, bytes + consumed, given) != JXL_DEC_SUCCESS) return 2;
       if (consumed + given == size) JxlDecoderCloseInput(dec);
+    } else if (st == JXL_DEC_FRAME_PROGRESSION) {
+      printf("event FRAME_PROGRESSION ratio=%zu bytes_given=%zu\n", JxlDecoderGetIntendedDownsamplingRatio(dec), consumed + given);
+      if (JxlDecoderFlushImage(dec) == JXL_DEC_SUCCESS) {
+        char name[1024];
+        FILE* o;
+        snprintf(name, sizeof(name), "%s.flush%d", argv[2], flushes);
+        o = fopen(name, "wb");
+        fwrite(g_pixels, 1, g_stride * cur_h, o);
+        fclose(o);
+        printf("flushed %d bytes_given=%zu\n", flushes++, consumed + given);
+      } else {
+        printf("flush refused bytes_given=%zu\n", consumed + given);
+      }
     } else if (st == JXL_DEC_BOX) {
       JxlBoxType type;
       if (have_box_buffer) JxlDecoderReleaseBoxBuffer(dec);

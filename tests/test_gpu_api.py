@@ -431,6 +431,50 @@ def test_flush_image_draws_what_has_arrived(built, tmp_path, passes):
 
 
 @pytest.mark.gpu
+def test_frame_progression_event_at_the_dc_step(built, tmp_path):
+    """JXL_DEC_FRAME_PROGRESSION (decode.h; decode.cc:1421-1428,1492-1500): subscribed, the decoder pauses ONCE per frame when
+    the frame's DC image is decoded and sections are still missing, with an intended downsampling ratio of 8; a flush at that
+    point draws exactly what has arrived (the oracle told to use the same prefix). Not subscribed, or with the whole frame
+    there, the event never comes; JxlDecoderSetProgressiveDetail takes kDC / kLastPasses / kPasses only (decode.cc:2963-2973)."""
+    import ctypes
+    import os
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(1100, 800, seed=9), num_passes=2)
+    chunk = len(data) // 7
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3, "progression", "chunk=%d" % chunk)
+    assert rc == 0 and events.count("FULL_IMAGE") == 1 and events.count("FRAME_PROGRESSION") == 1, out
+    assert events.index("FRAME") < events.index("FRAME_PROGRESSION") < events.index("FULL_IMAGE"), events
+    line = [l for l in out.splitlines() if l.startswith("event FRAME_PROGRESSION")][0]
+    assert "ratio=8" in line, line
+    given = int(line.split("bytes_given=")[1])
+    assert "flushed 0 bytes_given=%d" % given in out, out
+    got = np.fromfile(os.path.join(str(tmp_path), "out.raw.flush0"), np.uint8).reshape(800, 1100, 3)
+    want = jxlo.Decoded(data, dumps=False, prefix=given)
+    d = np.abs(got.astype(int) - want.rgb8.astype(int))
+    want.close()
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    final = np.frombuffer(px, np.uint8).reshape(800, 1100, 3)
+    assert np.abs(got.astype(int) - final.astype(int)).max() > 8  # (the step really lacked groups)
+    # the same input without the subscription, and the whole file at once with it
+    rc, events, out, _ = R.run(data, tmp_path, "u8", 3, "chunk=%d" % chunk)
+    assert rc == 0 and "FRAME_PROGRESSION" not in events
+    rc, events, out, _ = R.run(data, tmp_path, "u8", 3, "progression")
+    assert rc == 0 and "FRAME_PROGRESSION" not in events and events.count("FULL_IMAGE") == 1
+    L = J.lib()
+    L.JxlDecoderCreate.restype = ctypes.c_void_p
+    L.JxlDecoderCreate.argtypes = [ctypes.c_void_p]
+    L.JxlDecoderSetProgressiveDetail.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.JxlDecoderGetIntendedDownsamplingRatio.argtypes = [ctypes.c_void_p]
+    L.JxlDecoderGetIntendedDownsamplingRatio.restype = ctypes.c_size_t
+    L.JxlDecoderDestroy.argtypes = [ctypes.c_void_p]
+    dec = L.JxlDecoderCreate(None)
+    assert [L.JxlDecoderSetProgressiveDetail(dec, v) for v in (0, 1, 2, 3, 4, 5, 6)] == [1, 0, 0, 0, 1, 1, 1]  # (1 = JXL_DEC_ERROR)
+    assert L.JxlDecoderGetIntendedDownsamplingRatio(dec) == 8
+    L.JxlDecoderDestroy(dec)
+
+
+@pytest.mark.gpu
 def test_preview_frame_through_the_decoder_api(built, tmp_path):
     """JXL_DEC_PREVIEW_IMAGE (decode.cc:1326-1343, 1448-1450, 1554-1559, 2522-2562): the preview has its own buffer request
     and event, no FRAME event, and is stepped over when nobody subscribed to it."""
