@@ -27,11 +27,16 @@ int jxlamd_frame_parse_at(const uint8_t* data, size_t size, size_t frame_pos, si
                           void* runner_opaque, JxlAmdFrame** frame);
 /* The same from a PREFIX of the frame's bytes (what JxlDecoderFlushImage draws from; lib/jxl/dec_frame.cc:735-795 Flush,
  * decode.cc:2458-2475): succeeds once the frame header, the TOC, the DC image (DC global + DC groups) and the AC global
- * section are whole. AC groups with a missing section are marked absent and rendered from the DC image alone;
- * *groups_present = the number of groups whose AC data is there. Fails ("truncated frame") for frames coded as a single
+ * section are whole. A group is drawn from its leading passes whose sections are whole (dec_frame.cc:620-680), from the DC
+ * image alone when it has none; *groups_present = the number of groups with at least one pass. Fails ("truncated frame") for frames coded as a single
  * section and for frames with extra channels. jxlamd_frame_is_partial() tells such a frame from a whole one. */
 int jxlamd_frame_parse_partial_at(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
                                   void* runner_opaque, JxlAmdFrame** frame, uint32_t* groups_present);
+/* How many passes, from the first, EVERY group of the frame would have with `have_bytes` of the buffer there (a whole
+ * frame, or one parsed from a prefix: its table of contents is known): what FrameDecoder::NumCompletePasses reports
+ * (dec_frame.h:186-200) and JXL_DEC_FRAME_PROGRESSION steps by. info (optional, 10 values): num_passes, num_downsample,
+ * downsample[4], last_pass[4] of the frame header's Passes (frame_header.h:286-309). */
+uint32_t jxlamd_frame_complete_passes(const JxlAmdFrame* frame, size_t have_bytes, uint32_t* info);
 int jxlamd_frame_is_partial(const JxlAmdFrame* frame);
 /* Byte offset just behind the frame, and its animation fields {duration in ticks, is_last, timecode}. */
 size_t jxlamd_frame_end(const JxlAmdFrame* frame, uint32_t* duration_last_timecode);

@@ -86,6 +86,28 @@ int jxlamd_frame_parse_partial_at(const uint8_t* data, size_t size, size_t frame
   return r;
 }
 int jxlamd_frame_is_partial(const JxlAmdFrame* f) { return f && !f->plan.group_absent.empty() ? 1 : 0; }
+uint32_t jxlamd_frame_complete_passes(const JxlAmdFrame* f, size_t have_bytes, uint32_t* info) {
+  if (!f) return 0;
+  const auto& P = f->plan;
+  const uint32_t np = P.fh.num_passes;
+  if (info) {
+    info[0] = np;
+    info[1] = P.fh.num_downsample;
+    for (int i = 0; i < 4; i++) {
+      info[2 + i] = P.fh.downsample[i];
+      info[6 + i] = P.fh.last_pass[i];
+    }
+  }
+  if (P.section_end.empty()) return np;  // a whole frame
+  const size_t ng = P.dim.num_groups;
+  uint32_t complete = np;
+  for (size_t g = 0; g < ng && complete; g++) {
+    uint32_t k = 0;
+    while (k < complete && P.section_end[size_t(k) * ng + g] <= have_bytes) k++;
+    complete = k;
+  }
+  return complete;
+}
 static int ParseFrameAt(const uint8_t* data, size_t size, size_t frame_pos, size_t frame_index, JxlParallelRunner runner,
                         void* runner_opaque, bool allow_partial, JxlAmdFrame** out) {
   g_last_error.clear();
@@ -828,6 +850,7 @@ struct JxlDecoderStruct {
   // JXL_DEC_FRAME_PROGRESSION (decode.cc:1421-1428,1492-1500): once per frame, when its DC image is there and its AC data is not
   JxlProgressiveDetail prog_detail = kDC;
   bool dc_progression_done = false;
+  uint32_t passes_reported = 0;  // complete passes at the last progression step (the next pause point lies above it)
   size_t downsampling_target = 8;  // decode.cc:788
   bool coalescing = true;  // JxlDecoderSetCoalescing: false = every regular frame is delivered by itself, unblended
   int want_linear = -1;  // JxlDecoderSetOutputColorProfile: -1 = as coded
@@ -908,6 +931,7 @@ void ResetState(JxlDecoder* d) {
   d->frame_skipped = false;
   d->frame_partial = false;
   d->dc_progression_done = false;
+  d->passes_reported = 0;
   d->downsampling_target = 8;
   d->preview_frame = d->got_preview = false;
   d->visible_index = d->nonvisible_index = 0;
@@ -1489,6 +1513,7 @@ bool NextFrame(JxlDecoder* d) {
   d->mframe = nullptr;
   d->frame_partial = false;
   d->dc_progression_done = false;
+  d->passes_reported = 0;
   d->frame_pos = end;
   d->frame_index++;
   d->stage = 2;
@@ -1635,6 +1660,28 @@ int StepCodestream(JxlDecoder* d, JxlDecoderStatus* ev) {
             d->downsampling_target = 8;
             *ev = JXL_DEC_FRAME_PROGRESSION;
             return 2;
+          }
+          // ... and a step by passes (decode.cc:1502-1512, dec_frame.h:144-200): every pass (kPasses) or the last pass of every
+          // downsampling level the frame header names (kLastPasses), once every group has it
+          if ((d->events & JXL_DEC_FRAME_PROGRESSION) && d->prog_detail >= kLastPasses && !d->canvas_mode) {
+            uint32_t info[10];
+            const uint32_t complete = jxlamd_frame_complete_passes(d->frame, d->cs.size, info), np = info[0];
+            uint32_t next = np;  // the first pause point above the passes already reported
+            if (d->prog_detail >= kPasses) {
+              next = d->passes_reported + 1;
+            } else {
+              for (uint32_t i = 0; i < info[1] && i < 4; i++)
+                if (info[6 + i] + 1 > d->passes_reported && info[6 + i] + 1 < next) next = info[6 + i] + 1;
+            }
+            if (complete >= next && complete < np) {
+              d->passes_reported = complete;
+              uint32_t target = 8;  // frame_header.h:286-295
+              for (uint32_t i = 0; i < info[1] && i < 4; i++)
+                if (complete > info[6 + i] && info[2 + i] < target) target = info[2 + i];
+              d->downsampling_target = target;
+              *ev = JXL_DEC_FRAME_PROGRESSION;
+              return 2;
+            }
           }
           return 0;
         }
@@ -2157,8 +2204,8 @@ JxlDecoderStatus JxlDecoderSetProgressiveDetail(JxlDecoder* d, JxlProgressiveDet
 }
 size_t JxlDecoderGetIntendedDownsamplingRatio(JxlDecoder* d) { return d->downsampling_target; }
 // decode.cc:2458-2475 / dec_frame.cc:735-795: what has arrived of the current frame, drawn into the caller's buffer. The
-// groups whose AC sections are whole are decoded; the others come from the DC image alone (the reference draws them with
-// zero passes: every AC coefficient 0). Possible between the frame's NEED_IMAGE_OUT_BUFFER and its FULL_IMAGE, once the
+// groups are decoded from the passes they have (a group's passes are decoded in order as their sections arrive:
+// dec_frame.cc:620-680); groups with none come from the DC image alone. Possible between the frame's NEED_IMAGE_OUT_BUFFER and its FULL_IMAGE, once the
 // DC image is there (which is also when the frame is announced); JXL_DEC_ERROR = nothing was drawn, and is not fatal.
 JxlDecoderStatus JxlDecoderFlushImage(JxlDecoder* d) {
   if (!d->have_out || d->stage != 4 || !d->frame || !d->frame_partial || d->canvas_mode || d->error) return JXL_DEC_ERROR;

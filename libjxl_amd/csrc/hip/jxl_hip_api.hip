@@ -226,6 +226,7 @@ struct JxlHipContext {
   std::vector<uint32_t> group_list;
   std::vector<uint32_t> absent_groups;  // JxlHipFrameDesc::group_absent: drawn from the DC image alone
   std::vector<uint32_t> absent_blocks;  // per absent group: first block, block count
+  std::vector<uint32_t> absent_sections;  // (partial frames) passes of present groups that have not arrived: pass, first block, block count
   uint32_t band_y0 = 0, band_y1 = 0;
   uint32_t ext_y0 = 0, ext_y1 = 0;  // the pixel rows the transforms produce (the band and the group rows decoded around it)
   // upsampled frames: factor (1 = none), image size, kernels
@@ -841,6 +842,7 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
     c->band_y1 = re * 256 < d->ysize ? re * 256 : d->ysize;
     c->group_list.clear();
     c->absent_groups.clear();
+    c->absent_sections.clear();
     for (uint32_t g = ext_row0 * d->xsize_groups; g < ext_row1 * d->xsize_groups; g++) {
       if (d->group_absent && d->group_absent[g]) {
         for (uint32_t p = 0; p < d->num_passes; p++)
@@ -848,6 +850,19 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
         c->absent_groups.push_back(g);
       } else {
         c->group_list.push_back(g);
+        // a partial frame's group is drawn from its leading passes (dec_frame.cc:620-680): the missing ones have size 0,
+        // and once one is missing all later ones are
+        bool missing = false;
+        for (uint32_t p = 1; d->group_absent && p < d->num_passes; p++) {
+          const bool empty = d->section_size[size_t(p) * d->num_groups + g] == 0;
+          if (missing && !empty) return JXLHIP_ERR_INVALID_ARGUMENT;
+          missing = missing || empty;
+          if (empty) {
+            c->absent_sections.push_back(p);
+            c->absent_sections.push_back(d->group_block_begin[g]);
+            c->absent_sections.push_back(d->group_block_begin[g + 1] - d->group_block_begin[g]);
+          }
+        }
       }
     }
   }
@@ -1247,7 +1262,8 @@ int jxlhip_frame_upload(JxlHipContext* c, const JxlHipFrameDesc* d) {
   for (uint32_t p = 0; c->lanes && p < d->num_passes; p++)  // (alias tables that do not fit LDS are read in place)
     c->lanes = jxlhip::LanesLdsLayout(1, ep.nctx, c->pass_clusters[p], c->pass_log_alpha[p], kLanesWPG, 64, false, c->lane_prefix).total <= kLdsBudget;
   if (!c->lanes) c->lane_prefix = false;
-  if (!c->absent_groups.empty() && !c->lanes) return JXLHIP_ERR_INVALID_ARGUMENT;  // (only the lane kernel takes a list of groups)
+  // (sections that have not arrived: the lane kernel takes a list of the ones that have; the section-per-workgroup kernels
+  // step over a section of size 0 and leave the group's coefficients zeroed)
   c->scan_order = c->lanes && d->num_passes == 1;
   c->lane_multi = c->lanes && d->num_passes > 1;
   const size_t kend_per_pass = size_t(d->num_blocks ? d->num_blocks : 1) * 3;
@@ -2083,8 +2099,10 @@ static int PrepareBatch(JxlHipContext* c0, JxlHipContext* const* ctxs, size_t n,
         const uint32_t* sz = c->sec_size_host.data() + size_t(pass) * c->ng;    // [pass * num_groups + group]
         const uint32_t* ssel = c->sec_sel_host.data() + size_t(pass) * c->ng;
         order.clear();
-        for (uint32_t g : c->group_list)
+        for (uint32_t g : c->group_list) {
+          if (pass && sz[g] == 0 && !c->absent_sections.empty()) continue;  // (a partial frame: this pass of the group has not arrived)
           if (ssel[g] == sel || (sel == 0 && ssel[g] >= c->ep.num_hist)) order.push_back(g);
+        }
         if (order.empty()) continue;
         std::stable_sort(order.begin(), order.end(), [sz](uint32_t a, uint32_t b) { return sz[a] > sz[b]; });
         uint64_t total = 0;
@@ -2369,14 +2387,18 @@ extern "C" int jxlhip_run_entropy_batch(JxlHipContext* const* ctxs, size_t n) {
 // Groups whose AC sections have not arrived (JxlHipFrameDesc::group_absent): no coefficients at all, so that the transform
 // stage draws their blocks from the lowest frequencies (the DC image) alone. Queued in front of the entropy launch.
 static int ZeroAbsentGroups(JxlHipContext* c) {
-  if (c->absent_groups.empty()) return 0;
+  if (c->absent_groups.empty() && c->absent_sections.empty()) return 0;
   HIP_TRY(hipSetDevice(c->device));
   const size_t coef_group_bytes = size_t(3) * 65536 * (c->coef_bits / 8);
   for (size_t i = 0; i < c->absent_groups.size(); i++) {
     const uint32_t g = c->absent_groups[i], b0 = c->absent_blocks[2 * i], nb = c->absent_blocks[2 * i + 1];
     HIP_TRY(hipMemsetAsync(c->coeffs.as<uint8_t>() + size_t(g) * coef_group_bytes, 0, coef_group_bytes, c->stream));
-    for (uint32_t p = 0; p < c->np && nb; p++)
+    for (uint32_t p = 0; p < c->np && nb && c->lanes; p++)  // (the scan-order layout's counts; the other kernels zero-fill natural layout)
       HIP_TRY(hipMemsetAsync(c->kend.as<uint32_t>() + size_t(p) * c->ep.kend_pass_stride + size_t(b0) * 3, 0, size_t(nb) * 12, c->stream));
+  }
+  for (size_t i = 0; c->lanes && i + 2 < c->absent_sections.size(); i += 3) {  // passes that have not arrived add nothing (k_merge_passes)
+    const uint32_t p = c->absent_sections[i], b0 = c->absent_sections[i + 1], nb = c->absent_sections[i + 2];
+    if (nb) HIP_TRY(hipMemsetAsync(c->kend.as<uint32_t>() + size_t(p) * c->ep.kend_pass_stride + size_t(b0) * 3, 0, size_t(nb) * 12, c->stream));
   }
   return 0;
 }

@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64) void k_entropy_ans(EntropyParams P) {
   for (uint32_t pass = 0; pass < P.num_passes; pass++) {
     const PassDev& T = P.passes[pass];
     const uint32_t sec = pass * P.num_groups + g;
+    if (pass && P.sec_size[sec] == 0) break;  // (a frame drawn from a prefix of its bytes: this pass of the group has not arrived)
     __syncthreads();
     if (pass == 0) {
       // zero fill (16-byte stores)
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(64) void k_entropy_ans(EntropyParams P) {
         uint4* dst = reinterpret_cast<uint4*>(gco + size_t(c) * 65536);
         for (uint32_t i = lane; i < n16; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
       }
+      if (P.sec_size[sec] == 0) break;  // (none of the group's passes has arrived: the DC image alone)
     }
     for (uint32_t i = lane; i < 3 * 1024; i += 64) l_nz[i] = 0;
     // histogram selector is read by lane 0 first; all lanes then stage that slice of the context map
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(64) void k_entropy_generic(EntropyParams P) {
   for (uint32_t pass = 0; pass < P.num_passes; pass++) {
     const PassDev& T = P.passes[pass];
     const uint32_t sec = pass * P.num_groups + g;
+    if (P.sec_size[sec] == 0) break;  // (this pass of the group has not arrived: a frame drawn from a prefix; the group is zeroed above)
     __syncthreads();
     for (uint32_t i = lane; i < 3 * 1024; i += 64) l_nz[i] = 0;
     __threadfence_block();
@@ -644,6 +647,7 @@ __global__ __launch_bounds__(64 * WPG) void k_entropy_uni(EntropyBatch B) {
     // bit reader: the stream word for the NEXT refill is fetched with a vector load (tracked by vmcnt, so LDS waits
     // in the loop never wait for it) and moved to an SGPR only when it is consumed.
     const uint32_t sec_size = Uni(P.sec_size[sec]);
+    if (sec_size == 0) continue;  // (this pass of the group has not arrived: a frame drawn from a prefix; the group was zeroed above)
     const uint32_t* stream = P.sections + Uni(P.sec_word[sec]);
     const uint32_t nwords = (sec_size + 3) / 4;
     uint32_t idx = 0;  // words moved into buf

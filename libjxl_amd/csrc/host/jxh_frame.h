@@ -103,6 +103,8 @@ struct FramePlan {
   // A frame parsed from a prefix of its bytes (ParseFrame with allow_partial; dec_frame.cc:735-795 Flush): per group, 1 when
   // one of its AC sections is not complete in the buffer. Such groups are rendered from their DC alone. Empty = whole frame.
   std::vector<uint8_t> group_absent;
+  std::vector<uint8_t> passes_there;  // (partial frames) per group: how many of its passes, from the first, are there
+  std::vector<uint64_t> section_end;  // (partial frames) [pass * num_groups + group]: byte of the buffer where the section ends
   size_t frame_index = 0, nonvisible_index = 0;  // shown frames before this one, invisible ones since (dec_frame.cc:160-168)
   // Extra channels (alpha, ...): Modular-coded beside the VarDCT colour (dec_frame.cc:511-542, dec_modular.cc:209-425).
   // `extra` is the frame's global Modular image; channels no larger than a group are complete after the DC global
@@ -294,19 +296,26 @@ class FrameParser {
           P.section_size[p * d.num_groups + g] = toc.size[i];
         }
       if (partial) {
+        // A group is drawn from the passes that have arrived, in order (dec_frame.cc:620-680 decodes a group's passes as
+        // their sections come, decoded_passes_per_ac_group_; Flush draws with what that left): passes_there[g] = its
+        // leading passes whose sections are whole; the later ones get size 0; none at all = absent (the DC image alone).
         P.group_absent.assign(d.num_groups, 0);
-        for (size_t p = 0; p < np; p++)
-          for (size_t g = 0; g < d.num_groups; g++) {
-            const size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
-            if (base + toc.offset[i] + toc.size[i] > have) {
-              P.group_absent[g] = 1;
-              P.section_offset[p * d.num_groups + g] = base;  // (never read; kept inside the buffer)
-              P.section_size[p * d.num_groups + g] = 0;
-            }
+        P.passes_there.assign(d.num_groups, uint8_t(np));
+        P.section_end.assign(np * d.num_groups, 0);
+        for (size_t i = 0; i < np * d.num_groups; i++) P.section_end[i] = base + toc.offset[2 + d.num_dc_groups + i] + toc.size[2 + d.num_dc_groups + i];
+        for (size_t g = 0; g < d.num_groups; g++) {
+          size_t k = 0;
+          for (; k < np; k++) {
+            const size_t i = 2 + d.num_dc_groups + k * d.num_groups + g;
+            if (base + toc.offset[i] + toc.size[i] > have) break;
           }
-        for (size_t g = 0; g < d.num_groups; g++)  // (a group is drawn from all of its passes or from none)
-          if (P.group_absent[g])
-            for (size_t p = 0; p < np; p++) P.section_size[p * d.num_groups + g] = 0;
+          P.passes_there[g] = uint8_t(k);
+          P.group_absent[g] = k == 0;
+          for (size_t p = k; p < np; p++) {
+            P.section_offset[p * d.num_groups + g] = base;  // (never read; kept inside the buffer)
+            P.section_size[p * d.num_groups + g] = 0;
+          }
+        }
       }
     }
     BuildBlockLists(&P);

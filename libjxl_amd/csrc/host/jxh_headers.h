@@ -279,6 +279,7 @@ struct FrameHeader {
   uint32_t group_size_shift = 1;
   uint32_t x_qm_scale = 3, b_qm_scale = 2;
   uint32_t num_passes = 1;
+  uint32_t num_downsample = 0, downsample[4] = {0, 0, 0, 0}, last_pass[4] = {0, 0, 0, 0};  // frame_header.h:299-309 (Passes)
   uint32_t pass_shift[11] = {0};
   bool custom_size = false;
   int32_t x0 = 0, y0 = 0;
@@ -382,8 +383,9 @@ static inline void ReadFrameHeader(BitReader& br, const ImageHeader& ih, FrameHe
       JXH_CHECK(num_ds <= 4 && num_ds <= f->num_passes, "invalid num_downsample");
       for (uint32_t i = 0; i + 1 < f->num_passes; i++) f->pass_shift[i] = uint32_t(br.Read(2));
       f->pass_shift[f->num_passes - 1] = 0;
-      for (uint32_t i = 0; i < num_ds; i++) ReadU32(br, Val(1), Val(2), Val(4), Val(8));
-      for (uint32_t i = 0; i < num_ds; i++) ReadU32(br, Val(0), Val(1), Val(2), Bits(3));
+      f->num_downsample = num_ds;
+      for (uint32_t i = 0; i < num_ds; i++) f->downsample[i] = ReadU32(br, Val(1), Val(2), Val(4), Val(8));
+      for (uint32_t i = 0; i < num_ds; i++) f->last_pass[i] = ReadU32(br, Val(0), Val(1), Val(2), Bits(3));
     }
   }
   if (f->frame_type == 1) {  // frame_header.cc:310-318, frame_header.h:470-476: a DC frame has the image's size / 8^level

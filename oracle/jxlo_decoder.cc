@@ -628,16 +628,20 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       DecodeAcGlobal(r, s);
       check_section(r, "AC global");
     }
-    // A frame drawn from a prefix of its bytes (FrameDecoder::Flush, dec_frame.cc:735-795: the groups whose sections have
-    // not all arrived are drawn with zero passes, i.e. every AC coefficient 0; decode.cc:2458-2475 JxlDecoderFlushImage):
+    // A frame drawn from a prefix of its bytes (FrameDecoder::Flush, dec_frame.cc:735-795 with dec_frame.cc:620-680
+    // ProcessSections: a group's passes are decoded in order as their sections arrive, decoded_passes_per_ac_group_, and a
+    // flush draws every group from the passes it has, none = the DC image alone; decode.cc:2458-2475 JxlDecoderFlushImage):
     // g_flush_prefix = number of bytes of the codestream that are there; 0 = all.
-    std::vector<uint8_t> absent(d.num_groups, 0);
+    std::vector<uint32_t> passes_there(d.num_groups, uint32_t(np));
     if (g_flush_prefix)
-      for (size_t p = 0; p < np; p++)
-        for (size_t g = 0; g < d.num_groups; g++) {
-          const size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
-          if (base + toc.offset[i] + toc.size[i] > g_flush_prefix) absent[g] = 1;
+      for (size_t g = 0; g < d.num_groups; g++) {
+        uint32_t k = 0;
+        for (; k < np; k++) {
+          const size_t i = 2 + d.num_dc_groups + k * d.num_groups + g;
+          if (base + toc.offset[i] + toc.size[i] > g_flush_prefix) break;
         }
+        passes_there[g] = k;
+      }
     for (size_t p = 0; p < np; p++) {
       // Downsampling bracket (frame_header.h:268-284) for streams without progressive-downsampling info:
       // the last pass carries shifts 0..2, earlier passes carry no Modular data.
@@ -648,7 +652,7 @@ static void DecodeFrame(BitReader& br, const ImageHeader& ih, Decoded* out, bool
       const bool parallel = !fh.modular && s->full.ch.empty();
 #pragma omp parallel for schedule(dynamic) if (parallel)
       for (size_t g = 0; g < d.num_groups; g++) {
-        if (absent[g]) continue;
+        if (p >= passes_there[g]) continue;
         try {
           size_t i = 2 + d.num_dc_groups + p * d.num_groups + g;
           BitReader r(data + base + toc.offset[i], toc.size[i]);

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
   uint32_t cur_w = 0, cur_h = 0; /* size of the frame being delivered: the image, or (layers) the frame's own */
   uint8_t* preview_pixels = NULL;
   size_t preview_bytes = 0;
-  int unpremul = 0, progression = 0;
+  int unpremul = 0, progression = 0, detail = -1;
   int nopreview = 0; /* nopreview: do not subscribe to JXL_DEC_PREVIEW_IMAGE (the preview frame is stepped over) */
   int flush = 0, in_frame = 0, flushes = 0; /* flush: JxlDecoderFlushImage whenever the decoder runs out of input inside a frame */
   size_t skip = 0;
@@ -87,6 +87,7 @@ int main(int argc, char** argv) {
     if (!strcmp(argv[i], "nopreview")) nopreview = 1;
     if (!strcmp(argv[i], "unpremul")) unpremul = 1; /* JxlDecoderSetUnpremultiplyAlpha(true) */
     if (!strcmp(argv[i], "progression")) progression = 1; /* subscribe to JXL_DEC_FRAME_PROGRESSION and flush when it comes */
+    if (!strncmp(argv[i], "detail=", 7)) detail = atoi(argv[i] + 7); /* JxlDecoderSetProgressiveDetail */
   }
   if (JxlSignatureCheck(bytes, size) == JXL_SIG_INVALID) return 2;
   JxlMemoryManager mm = {NULL, CountingAlloc, CountingFree};
@@ -102,6 +103,7 @@ int main(int argc, char** argv) {
   if (JxlDecoderSetKeepOrientation(dec, keep ? JXL_TRUE : JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetUnpremultiplyAlpha(dec, unpremul ? JXL_TRUE : JXL_FALSE) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetCoalescing(dec, layers ? JXL_FALSE : JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
+  if (detail >= 0 && JxlDecoderSetProgressiveDetail(dec, (JxlProgressiveDetail)detail) != JXL_DEC_SUCCESS) return 2;
   if (JxlDecoderSetDecompressBoxes(dec, JXL_TRUE) != JXL_DEC_SUCCESS) return 2;
   if (skip) JxlDecoderSkipFrames(dec, skip);
   /* input in one piece, or in chunks the way a streaming caller feeds it (decode.h: unprocessed bytes are re-supplied) */
@@ -135,7 +137,10 @@ int main(int argc, char** argv) {
           fclose(o);
           printf("flushed %d bytes_given=%zu\n", flushes++, consumed + given);
         } else {
-          printf("flush refused bytes_given=%zu\n", consumed + given);
+          {
+          extern const char* jxlamd_last_error(void);
+          printf("flush refused bytes_given=%zu (%s)\n", consumed + given, jxlamd_last_error());
+        }
         }
       }
       size_t left = JxlDecoderReleaseInput(dec);
@@ -159,7 +164,10 @@ int main(int argc, char** argv) {
         fclose(o);
         printf("flushed %d bytes_given=%zu\n", flushes++, consumed + given);
       } else {
-        printf("flush refused bytes_given=%zu\n", consumed + given);
+        {
+          extern const char* jxlamd_last_error(void);
+          printf("flush refused bytes_given=%zu (%s)\n", consumed + given, jxlamd_last_error());
+        }
       }
     } else if (st == JXL_DEC_BOX) {
       JxlBoxType type;

@@ -395,8 +395,8 @@ def test_orientation_is_undone_by_the_pixel_writer(built, tmp_path, orientation)
 @pytest.mark.parametrize("passes", [1, 2, "420"])
 def test_flush_image_draws_what_has_arrived(built, tmp_path, passes):
     """JxlDecoderFlushImage (decode.cc:2458-2475, FrameDecoder::Flush dec_frame.cc:735-795): with a part of the frame's
-    bytes, the groups whose AC sections are whole are decoded and the others are drawn from the DC image alone (zero
-    passes). Expectation: the oracle told to use the same prefix of the codestream. The input comes in chunks; every time the
+    bytes, every group is drawn from its leading passes whose sections are whole (dec_frame.cc:620-680), from the DC image
+    alone when it has none. Expectation: the oracle told to use the same prefix of the codestream. The input comes in chunks; every time the
     decoder runs out inside the frame the replay program flushes and keeps the buffer."""
     import os
     import jxlo
@@ -472,6 +472,70 @@ def test_frame_progression_event_at_the_dc_step(built, tmp_path):
     assert [L.JxlDecoderSetProgressiveDetail(dec, v) for v in (0, 1, 2, 3, 4, 5, 6)] == [1, 0, 0, 0, 1, 1, 1]  # (1 = JXL_DEC_ERROR)
     assert L.JxlDecoderGetIntendedDownsamplingRatio(dec) == 8
     L.JxlDecoderDestroy(dec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("detail,passes", [(3, 2), (2, 2)])  # (this writer makes one or two passes)
+def test_frame_progression_steps_by_passes(built, tmp_path, detail, passes):
+    """JxlDecoderSetProgressiveDetail(kPasses): after the DC step the decoder pauses every time another pass is whole for
+    every group (decode.cc:1502-1512, dec_frame.h:144-200); a flush at a step draws every group from the passes it has
+    (dec_frame.cc:620-680,735-795) = the oracle told to use the same prefix, and the steps come closer to the final image.
+    kLastPasses pauses at the last pass of a downsampling level only: this writer's frame header names none, so only the DC
+    step comes (frame_header.h:286-309)."""
+    import os
+    import jxlo
+    J = built
+    data = J.encode_rgb8(J.synth_image(1100, 800, seed=9), num_passes=passes)
+    chunk = len(data) // 23
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3, "progression", "detail=%d" % detail, "chunk=%d" % chunk)
+    assert rc == 0 and events.count("FULL_IMAGE") == 1, out
+    final = np.frombuffer(px, np.uint8).reshape(800, 1100, 3).astype(int)
+    steps = [l for l in out.splitlines() if l.startswith("event FRAME_PROGRESSION")]
+    assert len(steps) == (passes if detail == 3 else 1), out  # the DC step + one per pass but the last
+    errs = []
+    for k, line in enumerate(steps):
+        assert "ratio=8" in line
+        given = int(line.split("bytes_given=")[1])
+        assert "flushed %d bytes_given=%d" % (k, given) in out, out
+        got = np.fromfile(os.path.join(str(tmp_path), "out.raw.flush%d" % k), np.uint8).reshape(800, 1100, 3)
+        want = jxlo.Decoded(data, dumps=False, prefix=given)
+        d = np.abs(got.astype(int) - want.rgb8.astype(int))
+        want.close()
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, line
+        errs.append(float(np.abs(got.astype(int) - final).mean()))
+    assert all(a > b for a, b in zip(errs, errs[1:])) and errs[-1] > 0, errs  # every step adds detail; none is the final image
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,kw", [({}, dict(ac_code_mode=3)), ({}, dict(ac_code_mode=1)), ({}, dict(ac_code_mode=2)),
+                                    (dict(JXLHIP_ENTROPY="0"), {}), (dict(JXLHIP_ENTROPY="1"), {})])
+def test_partial_passes_on_the_other_entropy_kernels(built, tmp_path, monkeypatch, env, kw):
+    """The same steps for prefix / LZ77 coded streams (the generic kernel, or the lane kernel's prefix form) and with the
+    section-per-workgroup rANS kernels (JXLHIP_ENTROPY = 0 / 1): they step over sections that have not arrived (size 0) and
+    leave such a group, or such a pass of it, out."""
+    import os
+    import jxlo
+    J = built
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    data = J.encode_rgb8(J.synth_image(900, 600, seed=19), num_passes=2, **kw)
+    chunk = len(data) // 17
+    rc, events, out, px = R.run(data, tmp_path, "u8", 3, "progression", "detail=3", "chunk=%d" % chunk)
+    assert rc == 0 and events.count("FULL_IMAGE") == 1, out
+    final = np.frombuffer(px, np.uint8).reshape(600, 900, 3)
+    o = jxlo.Decoded(data, dumps=False)
+    assert np.abs(final.astype(int) - o.rgb8.astype(int)).max() <= 1
+    o.close()
+    steps = [l for l in out.splitlines() if l.startswith("event FRAME_PROGRESSION")]
+    assert len(steps) == 2, out
+    for k, line in enumerate(steps):
+        given = int(line.split("bytes_given=")[1])
+        assert "flushed %d bytes_given=%d" % (k, given) in out, out
+        got = np.fromfile(os.path.join(str(tmp_path), "out.raw.flush%d" % k), np.uint8).reshape(600, 900, 3)
+        want = jxlo.Decoded(data, dumps=False, prefix=given)
+        d = np.abs(got.astype(int) - want.rgb8.astype(int))
+        want.close()
+        assert d.max() <= 1 and (d > 0).mean() < 2e-3, line
 
 
 @pytest.mark.gpu
