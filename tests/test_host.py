@@ -586,3 +586,41 @@ def test_oracle_and_host_read_a_preview_frame(built):
         f = J.Frame(data)  # the first frame of the codestream: the preview
         assert (f.info["xsize"], f.info["ysize"]) == (preview.shape[1], preview.shape[0])
         f.close()
+
+
+def test_partial_frame_plan_counts_the_passes_that_have_arrived(built):
+    """jxlamd_frame_parse_partial_at + jxlamd_frame_complete_passes (dec_frame.cc:620-680, dec_frame.h:186-200): from a prefix
+    of a two-pass frame every group is planned with its leading passes whose sections are whole; the count every group has
+    grows with the bytes and reaches the frame's number of passes exactly at its end; groups_present counts the groups with
+    at least one pass."""
+    import ctypes
+    J = built
+    L = J.lib()
+    data = J.encode_rgb8(J.synth_image(1100, 800, seed=9), num_passes=2)
+    L.jxlamd_frame_parse_partial_at.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32)]
+    L.jxlamd_frame_complete_passes.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
+    L.jxlamd_frame_complete_passes.restype = ctypes.c_uint32
+    L.jxlamd_frame_free.argtypes = [ctypes.c_void_p]
+    info = (ctypes.c_uint32 * 10)()
+    seen, present_seen, first_ok = [], [], None
+    for have in list(range(2000, len(data), 4000)) + [len(data) - 1]:
+        f, present = ctypes.c_void_p(), ctypes.c_uint32()
+        r = L.jxlamd_frame_parse_partial_at(data[:have], have, 0, 0, None, None, ctypes.byref(f), ctypes.byref(present))
+        if r:  # (the DC image is not whole yet)
+            assert first_ok is None, have
+            continue
+        first_ok = first_ok or have
+        complete = L.jxlamd_frame_complete_passes(f, have, info)
+        assert list(info)[:2] == [2, 0]
+        # the same plan asked about more bytes than it was parsed from: the table of contents answers
+        assert L.jxlamd_frame_complete_passes(f, len(data), info) == 2
+        assert L.jxlamd_frame_complete_passes(f, 0, info) == 0
+        seen.append(complete)
+        present_seen.append(present.value)
+        L.jxlamd_frame_free(f)
+    assert seen == sorted(seen) and seen[0] == 0 and 1 in seen and seen[-1] < 2, seen  # (one byte short of the end: the last section is cut)
+    assert present_seen == sorted(present_seen) and present_seen[0] < 20 and present_seen[-1] == 20, present_seen  # 5 x 4 groups
+    f = J.Frame(data)
+    assert L.jxlamd_frame_complete_passes(f._h, 1, info) == 2  # a whole frame: all of its passes
+    f.close()
