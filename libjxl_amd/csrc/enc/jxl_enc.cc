@@ -1192,7 +1192,8 @@ struct Params {
   int32_t zero_ac;         // random mode: leave every AC coefficient zero (DC-only stream)
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
-  int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
+  int32_t num_passes;      // 1..3; progressive: pass p of n carries the coefficient's bits above shift n - 1 - p that the passes
+                           // before it have not (shifts n - 1 .. 0); three passes also name a downsampling level (4x after pass 0)
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
   int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
   int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)
@@ -1312,7 +1313,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     std::vector<int32_t> px(w * h);
     for (size_t y = 0; y < h; y++)
       for (size_t x = 0; x < w; x++) px[y * w + x] = f.alpha[(y0 + y) * aw + x0 + x];
-    const size_t last_pass = (p.num_passes == 2 ? 2 : 1) - 1;
+    const size_t last_pass = size_t(p.num_passes >= 2 && p.num_passes <= 3 ? p.num_passes : 1) - 1;
     ModularTokens(tree, px.data(), w, h, 0, int(1 + 3 * ndc + 17 + num_groups * last_pass + g), &alpha_group_tokens[g]);
   }
   BuildCode({&tree_tokens}, 6, 6, cfg420, &tree_code);
@@ -1380,7 +1381,7 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
   };
   const size_t nctx = bctx.NumACContexts();
   const size_t num_hist = (p.num_histograms > 1 && num_groups > 1) ? std::min<size_t>(size_t(p.num_histograms), num_groups) : 1;
-  const size_t num_passes = p.num_passes == 2 ? 2 : 1;
+  const size_t num_passes = p.num_passes >= 2 && p.num_passes <= 3 ? size_t(p.num_passes) : 1;
   std::vector<std::vector<Token>> ac_tokens(num_groups * num_passes);  // [pass * num_groups + group]
   std::vector<std::vector<uint32_t>> natural(13);
   for (int s = 0; s < 27; s++)
@@ -1441,7 +1442,10 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
       continue;
     }
     // the part of a coefficient this pass carries (the decoder adds value << shift over the passes, dec_group.cc:335-338)
-    auto part = [&](int32_t v) -> int32_t { return num_passes == 1 ? v : (pass == 0 ? (v >> 1) : v - ((v >> 1) << 1)); };
+    auto part = [&](int32_t v) -> int32_t {
+      const int sh = int(num_passes - 1 - pass);  // this pass's shift; the passes before carried v >> (sh + 1)
+      return pass == 0 ? (v >> sh) : (v >> sh) - ((v >> (sh + 1)) << 1);
+    };
     const size_t bx0 = (g % xg) * 32, by0 = (g / xg) * 32;
     const size_t gw = std::min<size_t>(32, f.xb - bx0), gh = std::min<size_t>(32, f.yb - by0);
     std::vector<int32_t> nzmap(3 * 1024, 0);
@@ -1731,10 +1735,17 @@ static void Assemble(const FrameModel& f, const Params& p, std::vector<uint8_t>*
     // (frame_header.cc:303: a kReferenceOnly frame has no Passes bundle)
   } else if (num_passes == 1) {
     bw.Write(2, 0);  // one pass
-  } else {
+  } else if (num_passes == 2) {
     bw.Write(2, 1);  // two passes
     bw.Write(2, 0);  // no downsampling brackets
     bw.Write(2, 1);  // shift of pass 0 = 1 (the last pass always has shift 0)
+  } else {
+    bw.Write(2, 2);  // three passes
+    bw.Write(2, 1);  // one downsampling bracket (frame_header.h:299-309)
+    bw.Write(2, 2);  // shift of pass 0 = 2
+    bw.Write(2, 1);  // shift of pass 1 = 1
+    bw.Write(2, 2);  // downsample[0] = 4 ...
+    bw.Write(2, 0);  // ... is reached with last_pass[0] = 0
   }
   if (g_dc_frame_level > 0) bw.Write(2, uint32_t(g_dc_frame_level - 1));  // dc_level: U32(Val(1), Val(2), Val(3), Val(4))
   const bool whole = WriteCropAndBlending(bw, uint32_t(f.xs), uint32_t(f.ys), have_alpha);
@@ -1898,7 +1909,7 @@ static void EncodeImage(const uint8_t* rgb, size_t xs, size_t ys, const Params& 
     // (no zero fill and no second copy of the coefficients: 100 MB at 4K)
     std::vector<int32_t> dc(3 * nb);
     // device tokenisation: one pass, natural orders, the default block context map (what it is written for)
-    const bool dev_tok = hook->tok_counts && hook->tok_emit && !hook->cap_acs && p.num_passes != 2 && !p.custom_orders && !p.custom_bctx;
+    const bool dev_tok = hook->tok_counts && hook->tok_emit && !hook->cap_acs && !(p.num_passes >= 2 && p.num_passes <= 3) && !p.custom_orders && !p.custom_bctx;
     if (!dev_tok) f.flat_coeffs.reset(new int32_t[ng * 3 * 65536]);
     int32_t* const co = f.flat_coeffs.get();
     const int r = hook->fn(hook->ctx, rgb, xs * 3, &d, f.acs.data(), f.qf.data(), dc.data(), co);
@@ -2855,7 +2866,8 @@ struct JxlEncParams {
   int32_t max_clusters, skip_dc_smoothing, random_cmap, zero_ac;
   int32_t num_histograms;  // AC histogram sets (group g uses set g % num_histograms); 0 or 1 = one
   int32_t big_coeffs;      // random mode: sprinkle magnitudes beyond 16 bits (forces int32 coefficient storage in decoders)
-  int32_t num_passes;      // 1 or 2; 2 = progressive: pass 0 carries every coefficient >> 1 (pass shift 1), pass 1 the remaining bit
+  int32_t num_passes;      // 1..3; progressive: pass p of n carries the coefficient's bits above shift n - 1 - p that the passes
+                           // before it have not (shifts n - 1 .. 0); three passes also name a downsampling level (4x after pass 0)
   int32_t upsampling;      // 0/1, 2, 4 or 8: the frame is coded at ceil(size / upsampling) and flagged for upsampling
   int32_t custom_orders;   // 1 = code a (seeded random) custom coefficient order for every used order bucket, channel and pass
   int32_t custom_bctx;     // 1 = code a block context map with quant-field and DC thresholds (entropy_coder.cc:25-60)

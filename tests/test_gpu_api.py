@@ -475,13 +475,14 @@ def test_frame_progression_event_at_the_dc_step(built, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("detail,passes", [(3, 2), (2, 2)])  # (this writer makes one or two passes)
+@pytest.mark.parametrize("detail,passes", [(3, 2), (2, 2), (3, 3), (2, 3)])
 def test_frame_progression_steps_by_passes(built, tmp_path, detail, passes):
     """JxlDecoderSetProgressiveDetail(kPasses): after the DC step the decoder pauses every time another pass is whole for
     every group (decode.cc:1502-1512, dec_frame.h:144-200); a flush at a step draws every group from the passes it has
     (dec_frame.cc:620-680,735-795) = the oracle told to use the same prefix, and the steps come closer to the final image.
-    kLastPasses pauses at the last pass of a downsampling level only: this writer's frame header names none, so only the DC
-    step comes (frame_header.h:286-309)."""
+    kLastPasses pauses at the last pass of a downsampling level only (frame_header.h:286-309): the writer's two-pass frames
+    name none (only the DC step comes), its three-pass frames name 4x after pass 0 (one more step, and the intended
+    downsampling ratio drops from 8 to 4 there)."""
     import os
     import jxlo
     J = built
@@ -491,10 +492,10 @@ def test_frame_progression_steps_by_passes(built, tmp_path, detail, passes):
     assert rc == 0 and events.count("FULL_IMAGE") == 1, out
     final = np.frombuffer(px, np.uint8).reshape(800, 1100, 3).astype(int)
     steps = [l for l in out.splitlines() if l.startswith("event FRAME_PROGRESSION")]
-    assert len(steps) == (passes if detail == 3 else 1), out  # the DC step + one per pass but the last
+    assert len(steps) == (passes if detail == 3 else (2 if passes == 3 else 1)), out  # the DC step + one per pass but the last
     errs = []
     for k, line in enumerate(steps):
-        assert "ratio=8" in line
+        assert ("ratio=4" if passes == 3 and k >= 1 else "ratio=8") in line, line
         given = int(line.split("bytes_given=")[1])
         assert "flushed %d bytes_given=%d" % (k, given) in out, out
         got = np.fromfile(os.path.join(str(tmp_path), "out.raw.flush%d" % k), np.uint8).reshape(800, 1100, 3)

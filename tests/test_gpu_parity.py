@@ -88,6 +88,8 @@ def _compare(J, jxlo, data, check_rgb=True, crop_idct=False):
     ((520, 300), dict(custom_orders=1, num_passes=2)),    # ... and different per pass
     ((700, 520), dict(num_passes=2)),                     # progressive: two passes, pass 0 shifted by one bit
     ((200, 100), dict(num_passes=2)),                     # ... with a single group
+    ((700, 520), dict(num_passes=3)),                     # three passes (shifts 2, 1, 0) and a downsampling bracket in the frame header
+    ((1000, 700), dict(num_passes=3, num_histograms=3, custom_orders=1, distance=2.0)),
     ((1000, 700), dict(num_passes=2, num_histograms=3, distance=2.0)),
     ((520, 300), dict(color_transform=2)),                # an image that is not XYB encoded: YCbCr frame (stage_ycbcr.cc), 4:4:4
     ((777, 513), dict(color_transform=2, distance=2.0, strategy_mode=2)),
