@@ -866,7 +866,7 @@ def main():
         # summary; 2 x FETCH_SIZE + WRITE_SIZE per dispatch), only quoted when taken at the same frames per launch
         traffic, traffic_source = None, None
         try:
-            pmc_name = "r03_pmc_traffic.json"
+            pmc_name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]  # the latest round's
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             key = ["k_entropy_lanes", "k_idct_fast<short, 4, 4>", "k_filter_rows2"][dom]
             for name, v in pmc.items():

@@ -424,6 +424,8 @@ typedef struct JxlHipModFrameDesc {
   uint32_t num_ops;
   /* output: the buffers holding the final colour channels (1 or 3) and alpha (or 0xFFFFFFFF) */
   uint32_t out_buffer[4];
+  /* bits: low byte = bits per colour sample (integers: 1..31), bits 8..15 = exponent bits when the samples are floats of
+   * that width (0 = integers; image_metadata.cc BitDepth, dec_modular.cc:128-185); alpha_bits: integer alpha, 1..24 */
   uint32_t num_color, has_alpha, bits, alpha_bits;
   /* splines over the three colour channels (as floats, before the sample conversion); colour images only */
   JxlHipSplines splines;

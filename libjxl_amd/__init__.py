@@ -454,6 +454,8 @@ def _enc_lib():
         E.jxlenc_encode_rgba8.argtypes = E.jxlenc_encode_rgb8.argtypes
         E.jxlenc_encode_lossless.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_uint32, pp, ctypes.POINTER(ctypes.c_size_t)]
+        E.jxlenc_encode_lossless_samples.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, pp, ctypes.POINTER(ctypes.c_size_t)]
         E.jxlenc_encode_random.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(EncParams), pp,
                                            ctypes.POINTER(ctypes.c_size_t)]
         E.jxlenc_synth_image.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
@@ -828,6 +830,21 @@ def encode_lossless(img, flags=LOSSLESS_RCT, seed=0):
     n = ctypes.c_size_t()
     r = E.jxlenc_encode_lossless(img.tobytes(), img.shape[1], img.shape[0], img.shape[2], flags, seed, ctypes.byref(out), ctypes.byref(n))
     return _finish(E, r, out, n, "jxlenc_encode_lossless")
+
+
+def encode_lossless_samples(samples, bits, exp_bits=0, flags=0, seed=0):
+    """HxWxC int32 samples (C = 1..4) -> lossless Modular codestream of an image with `bits`-bit integer samples, or
+    (exp_bits != 0) float samples of `bits` bits whose bit patterns the integers are (32 / 8: float32 viewed as int32,
+    16 / 5: float16 viewed as uint16). An alpha channel (C = 2 or 4) stays 8-bit."""
+    E = _enc_lib()
+    a = np.ascontiguousarray(samples, np.int32)
+    if a.ndim == 2:
+        a = a[..., None]
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    n = ctypes.c_size_t()
+    r = E.jxlenc_encode_lossless_samples(a.ctypes.data, a.shape[1], a.shape[0], a.shape[2], flags, seed, bits, exp_bits,
+                                         ctypes.byref(out), ctypes.byref(n))
+    return _finish(E, r, out, n, "jxlenc_encode_lossless_samples")
 
 
 def encode_random(xsize, ysize, **kw):

@@ -696,7 +696,7 @@ int jxlamd_modframe_upload(const JxlAmdModFrame* f, JxlHipContext* ctx) {
   memcpy(d.out_buffer, P.out_buffer, sizeof(d.out_buffer));
   d.num_color = P.num_color;
   d.has_alpha = P.has_alpha;
-  d.bits = P.ih.bits;
+  d.bits = P.ih.bits | (P.ih.floating ? P.ih.exp_bits << 8 : 0u);
   d.alpha_bits = P.alpha_bits;
   FillSplines(P.has_splines, P.splines, &d.splines);
   memset(&d.patches, 0, sizeof(d.patches));

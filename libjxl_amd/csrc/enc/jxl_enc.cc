@@ -2419,7 +2419,10 @@ static void FwdSqueezeLine(const int32_t* in, ptrdiff_t si, size_t n, int32_t* a
   if (na > nr) avg[ptrdiff_t(na - 1) * sa] = in[ptrdiff_t(n - 1) * si];
 }
 
-static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, const LosslessOptions& o, std::vector<uint8_t>* out) {
+// `px`: interleaved samples as the integers the stream codes: `bits`-bit unsigned values, or (exp_bits != 0) the bit patterns
+// of floats with `bits` bits of which `exp_bits` are the exponent (dec_modular.cc:128-185 reads them back the same way).
+static void EncodeLossless(const int32_t* px, size_t xs, size_t ys, size_t nc, const LosslessOptions& o, std::vector<uint8_t>* out,
+                           uint32_t bits = 8, uint32_t exp_bits = 0) {
   const bool gray = nc <= 2, alpha = nc == 2 || nc == 4;
   const uint32_t flags = o.flags;
   const size_t gdim = 256, xg = DivCeil(xs, gdim), yg = DivCeil(ys, gdim), num_groups = xg * yg;
@@ -2440,7 +2443,7 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
     std::vector<float> planes[3];
     std::vector<uint8_t> rgb(xs * ys * 3);
     for (size_t i = 0; i < xs * ys; i++)
-      for (int c = 0; c < 3; c++) rgb[i * 3 + c] = px[i * nc + c];
+      for (int c = 0; c < 3; c++) rgb[i * 3 + c] = uint8_t(px[i * nc + c]);
     RgbToXyb(rgb.data(), xs, ys, xs, ys, planes);
     for (size_t i = 0; i < xs * ys; i++) {
       const int32_t Y = int32_t(std::lround(planes[1][i] * 512.0f));
@@ -2784,9 +2787,25 @@ static void EncodeLossless(const uint8_t* px, size_t xs, size_t ys, size_t nc, c
   WriteSizeDim(bw, g_image_w ? g_image_w : uint32_t(xs));
   bw.Write(1, 0);  // ImageMetadata not all_default
   WriteExtraFields(bw);
-  bw.Write(1, 0);  // integer samples
-  bw.Write(2, 0);  //   8 bits
-  bw.Write(1, 1);  // modular_16_bit_buffer_sufficient
+  if (exp_bits == 0) {  // image_metadata.cc BitDepth: U32(Val(8), Val(10), Val(12), BitsOffset(6, 1))
+    bw.Write(1, 0);
+    if (bits == 8 || bits == 10 || bits == 12) {
+      bw.Write(2, (bits - 8) / 2);
+    } else {
+      bw.Write(2, 3);
+      bw.Write(6, bits - 1);
+    }
+  } else {  // U32(Val(32), Val(16), Val(24), BitsOffset(6, 1)), then Bits(4) + 1 exponent bits
+    bw.Write(1, 1);
+    if (bits == 32 || bits == 16 || bits == 24) {
+      bw.Write(2, bits == 32 ? 0 : (bits == 16 ? 1 : 2));
+    } else {
+      bw.Write(2, 3);
+      bw.Write(6, bits - 1);
+    }
+    bw.Write(4, exp_bits - 1);
+  }
+  bw.Write(1, exp_bits == 0 && bits <= 12 ? 1 : 0);  // modular_16_bit_buffer_sufficient
   bw.Write(2, alpha ? 1 : 0);  // extra channels
   if (alpha) WriteAlphaChannelInfo(bw);
   const bool xyb_frame = (o.flags & 128) && !gray;
@@ -3169,7 +3188,27 @@ int jxlenc_encode_lossless(const uint8_t* px, uint32_t xs, uint32_t ys, uint32_t
   std::vector<uint8_t> v;
   try {
     jxe::LosslessOptions o{flags, seed};
-    jxe::EncodeLossless(px, xs, ys, channels, o, &v);
+    std::vector<int32_t> wide(size_t(xs) * ys * channels);
+    for (size_t i = 0; i < wide.size(); i++) wide[i] = px[i];
+    jxe::EncodeLossless(wide.data(), xs, ys, channels, o, &v);
+  } catch (...) {
+    return -2;
+  }
+  return Finish(v, out, n);
+}
+
+// The same for samples of any depth the format has: `px` holds the colour samples as the integers the stream codes --
+// `bits`-bit unsigned values (exp_bits 0, bits 1..31) or the bit patterns of floats of `bits` bits with `exp_bits` exponent
+// bits (bits 32 / exp_bits 8 = binary32 as it is, 16 / 5 = binary16); an alpha channel stays 8-bit. No XYB flag here.
+int jxlenc_encode_lossless_samples(const int32_t* px, uint32_t xs, uint32_t ys, uint32_t channels, uint32_t flags, uint32_t seed,
+                                   uint32_t bits, uint32_t exp_bits, uint8_t** out, size_t* n) {
+  jxe::UseThreads();
+  if (!px || !xs || !ys || channels < 1 || channels > 4 || (flags & 128)) return -1;
+  if (exp_bits == 0 ? (bits < 1 || bits > 31) : (exp_bits < 2 || exp_bits > 8 || bits < exp_bits + 3 || bits > exp_bits + 24 || bits > 32)) return -1;
+  std::vector<uint8_t> v;
+  try {
+    jxe::LosslessOptions o{flags, seed};
+    jxe::EncodeLossless(px, xs, ys, channels, o, &v, bits, exp_bits);
   } catch (...) {
     return -2;
   }

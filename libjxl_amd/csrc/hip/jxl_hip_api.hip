@@ -2656,7 +2656,15 @@ extern "C" int jxlhip_modular_upload(JxlHipContext* c, const JxlHipModFrameDesc*
   M.has_alpha = d->has_alpha;
   M.bits = d->bits;
   M.alpha_bits = d->alpha_bits;
-  if (!M.bits || M.bits > 24 || !M.alpha_bits || M.alpha_bits > 24) return JXLHIP_ERR_INVALID_ARGUMENT;
+  {  // sample depths: low byte = bits, bits 8..15 = exponent bits of a float type (image_metadata.cc BitDepth: 2..8, mantissa 2..23)
+    auto depth_ok = [](uint32_t d) {
+      const uint32_t bits = d & 0xFF, e = (d >> 8) & 0xFF;
+      if (d >> 16) return false;
+      if (e == 0) return bits >= 1 && bits <= 31;
+      return e >= 2 && e <= 8 && bits >= e + 3 && bits <= e + 24 && bits <= 32;
+    };
+    if (!depth_ok(M.bits) || !depth_ok(M.alpha_bits) || (M.alpha_bits >> 8) || (M.alpha_bits & 0xFF) > 24) return JXLHIP_ERR_INVALID_ARGUMENT;
+  }
   M.xs = d->xsize;
   M.ys = d->ysize;
   c->oxs = c->xs = d->xsize;

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void k_modular_palette(const ModPalette* ops) 
 struct ModOutput {
   const int32_t* ch[4];  // colour channels (1 or 3) then alpha (or NULL)
   uint32_t stride[4];
-  uint32_t num_color, has_alpha, bits, alpha_bits, w, h;
+  uint32_t num_color, has_alpha, bits, alpha_bits, w, h;  // bits / alpha_bits: ModSampleToFloat's `depth`
   PixelOut po;           // po.nc: 1 / 2 (grey, grey + alpha) or 3 / 4
   // frames with splines: fmode 1 = only write the colour samples as floats to fplanes ([3][h][w]; the splines are then
   // drawn over them), fmode 2 = take the colour from fplanes instead of the integer channels; 0 = neither
@@ -798,19 +798,50 @@ struct ModOutput {
   float xyb_factor[3];
   FilterParams color;
 };
+// One decoded integer -> the float the render pipeline starts from. `depth`: low byte = bits per sample, bits 8..15 = exponent
+// bits of a floating-point sample type (0 = integer samples).
+//  * integers (dec_modular.cc:655-690): v * 1 / (2^bits - 1), in single precision below 23 bits, in double precision from there;
+//  * floats (dec_modular.cc:128-185, int_to_float): the integer IS the sample's bit pattern in a [bits]-bit float with
+//    [exp] exponent bits: binary32 as it is; narrower types widened exactly (subnormals normalised when exp < 8, NaN /
+//    infinity keep their mantissa bits).
+__device__ __forceinline__ float ModSampleToFloat(int32_t v, uint32_t depth) {
+  const int bits = int(depth & 0xFF), exp_bits = int((depth >> 8) & 0xFF);
+  if (exp_bits == 0) {
+    if (bits < 23) return float(v) * (1.0f / float((uint64_t(1) << bits) - 1));
+    return float(double(v) * (1.0 / double((uint64_t(1) << bits) - 1)));
+  }
+  uint32_t f = uint32_t(v);
+  if (bits == 32) return __uint_as_float(f);
+  const int exp_bias = (1 << (exp_bits - 1)) - 1, sign_shift = bits - 1, mant_bits = bits - exp_bits - 1, mant_shift = 23 - mant_bits;
+  const uint32_t sign = ((f >> sign_shift) & 1u) ? 0x80000000u : 0u;
+  f &= (1u << sign_shift) - 1;
+  if (f == 0) return __uint_as_float(sign);
+  int exp = int(f >> mant_bits);
+  uint32_t mantissa = f & ((1u << mant_bits) - 1);
+  if (exp == (1 << exp_bits) - 1) return __uint_as_float(sign | (0xFFu << 23) | (mantissa << mant_shift));
+  mantissa <<= mant_shift;
+  if (exp == 0 && exp_bits < 8) {  // subnormal of the narrow type: a normal binary32 (mantissa != 0 here, so the shift ends)
+    const int up = __clz(int(mantissa)) - 8;  // places until bit 23 is set
+    mantissa <<= up;
+    exp = 1 - up;
+    mantissa &= 0x7FFFFF;
+  }
+  exp += 127 - exp_bias;
+  return __uint_as_float(sign | (uint32_t(exp) << 23) | mantissa);
+}
 __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   const ModOutput& P = ops[blockIdx.z];
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x >= P.w) return;
   for (uint32_t y = blockIdx.y; y < P.h; y += gridDim.y) {
-  const float mul = 1.0f / float((uint64_t(1) << P.bits) - 1);
   float v[4];
-  for (uint32_t c = 0; c < P.num_color; c++) v[c] = float(P.ch[c][size_t(y) * P.stride[c] + x]) * mul;
   if (P.xyb) {  // dec_modular.cc:583-631 (MultiplySum for B)
     const int32_t iy = P.ch[0][size_t(y) * P.stride[0] + x], ix = P.ch[1][size_t(y) * P.stride[1] + x], ib = P.ch[2][size_t(y) * P.stride[2] + x];
     v[0] = float(ix) * P.xyb_factor[0];
     v[1] = float(iy) * P.xyb_factor[1];
     v[2] = float(ib + iy) * P.xyb_factor[2];
+  } else {
+    for (uint32_t c = 0; c < P.num_color; c++) v[c] = ModSampleToFloat(P.ch[c][size_t(y) * P.stride[c] + x], P.bits);
   }
   if (P.fmode == 1) {
     for (uint32_t c = 0; c < 3; c++) P.fplanes[(size_t(c) * P.h + y) * P.w + x] = v[c];
@@ -819,7 +850,7 @@ __global__ __launch_bounds__(256) void k_modular_output(const ModOutput* ops) {
   if (P.fmode == 2)
     for (uint32_t c = 0; c < 3; c++) v[c] = P.fplanes[(size_t(c) * P.h + y) * P.w + x];
   if (P.xyb) XybToRgb(P.color, v[0], v[1], v[2], &v[0], &v[1], &v[2]);  // (after the splines, like every XYB frame)
-  const float a = P.has_alpha ? float(P.ch[P.num_color][size_t(y) * P.stride[P.num_color] + x]) * (1.0f / float((uint64_t(1) << P.alpha_bits) - 1)) : 1.0f;
+  const float a = P.has_alpha ? ModSampleToFloat(P.ch[P.num_color][size_t(y) * P.stride[P.num_color] + x], P.alpha_bits) : 1.0f;
   const uint32_t nc = P.po.nc, ncol = nc < 3 ? 1u : 3u;
   float s[4];
   for (uint32_t c = 0; c < ncol; c++) s[c] = v[P.num_color == 1 ? 0 : c];  // grey images replicate into RGB output

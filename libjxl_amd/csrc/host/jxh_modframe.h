@@ -83,7 +83,10 @@ class ModFrameParser {
     JXH_CHECK(fh.upsampling == 1 && fh.num_passes == 1, "unsupported: upsampled / multi-pass Modular frames");
     for (uint32_t u : fh.ec_upsampling) JXH_CHECK(u == 1, "unsupported: upsampled extra channels");
     JXH_CHECK(!(fh.flags & (FrameHeader::kNoise | FrameHeader::kUseDcFrame)), "unsupported: noise / kUseDcFrame on Modular frames");
-    JXH_CHECK(!ih.floating && ih.bits <= 16, "unsupported: float or > 16-bit samples");
+    // float and > 16-bit colour samples: the streams and transforms are 32-bit integers with 64-bit predictors whatever the
+    // depth; the pixel writer widens them (dec_modular.cc:128-185,633-690). Extra channels of such types are refused.
+    JXH_CHECK(!(ih.floating && ih.xyb_encoded), "float samples in an XYB image");
+    for (const auto& e : ih.extra) JXH_CHECK(!e.floating && e.bits <= 16, "unsupported: float or > 16-bit extra channels");
     P.dim = MakeFrameDim(fh);
     const FrameDim& d = P.dim;
     const size_t entries = d.num_groups == 1 ? 1 : 2 + d.num_dc_groups + d.num_groups;

@@ -259,3 +259,113 @@ def test_xyb_modular_frames_go_through_the_colour_stage(built, tmp_path, case):
     rc, events, out, px = R.run(data, tmp_path, "f32", 3)
     assert rc == 0, out
     assert np.abs(np.frombuffer(px, np.float32).reshape(200, 300, 3) - wantf).max() < 5e-5
+
+
+def np_sample_to_float(v, bits, exp_bits):
+    """NumPy reading of the reference's integer -> float step for Modular colour channels, written from the text of
+    dec_modular.cc:128-185 (int_to_float) and :633-690 (1 / (2^bits - 1), single precision below 23 bits, double from
+    there); shares no code with the kernel (ModSampleToFloat) or the oracle."""
+    v = np.asarray(v, np.int64)
+    if exp_bits == 0:
+        if bits < 23:
+            return v.astype(np.float32) * np.float32(1.0 / ((1 << bits) - 1))
+        return (v.astype(np.float64) * (1.0 / ((1 << bits) - 1))).astype(np.float32)
+    f = (v & 0xFFFFFFFF).astype(np.uint64)
+    if bits == 32:
+        return f.astype(np.uint32).view(np.float32)
+    bias = (1 << (exp_bits - 1)) - 1
+    mant_bits = bits - exp_bits - 1
+    mant_shift = 23 - mant_bits
+    sign = ((f >> np.uint64(bits - 1)) & np.uint64(1)).astype(np.uint64) << np.uint64(31)
+    f = f & np.uint64((1 << (bits - 1)) - 1)
+    exp = (f >> np.uint64(mant_bits)).astype(np.int64)
+    mant = (f & np.uint64((1 << mant_bits) - 1)).astype(np.int64) << mant_shift
+    out = np.zeros(f.shape, np.uint64)
+    special = exp == (1 << exp_bits) - 1
+    sub = (exp == 0) & (mant != 0) & (exp_bits < 8)
+    m, e = mant.copy(), exp.copy()
+    for _ in range(24):  # "while ((mantissa & 0x800000) == 0) { mantissa <<= 1; exp--; }" then exp++
+        go = sub & ((m & 0x800000) == 0)
+        m = np.where(go, m << 1, m)
+        e = np.where(go, e - 1, e)
+    e = np.where(sub, e + 1, e)
+    m = np.where(sub, m & 0x7FFFFF, m)
+    normal = ((e - bias + 127).astype(np.uint64) << np.uint64(23)) | m.astype(np.uint64)
+    out = np.where(special, np.uint64(0xFF << 23) | mant.astype(np.uint64), normal)
+    out = np.where(f == 0, np.uint64(0), out) | sign
+    return out.astype(np.uint32).view(np.float32)
+
+
+def _deep_samples(kind, h, w, nc, seed):
+    """(int32 samples, bits, exp_bits): smooth content plus noise so that every predictor and context sees real work."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    base = np.stack([0.5 + 0.45 * np.sin(x / (9.0 + c)) * np.cos(y / (13.0 - c)) for c in range(nc)], -1)
+    base = np.clip(base + rng.normal(0, 0.01, base.shape), 0.0, 1.0)
+    if kind == "f32":
+        f = base.astype(np.float32)
+        # zero, subnormals, values above one. (Patterns a neighbour's distance of 2^30 and more away -- infinity, the largest
+        # values -- are beyond the test encoder: the top bit of its token values marks LZ77 lengths. binary32 samples are
+        # copied as they are, so the narrower types below carry the special-value branches.)
+        f[0, :9, 0] = [0.0, 1.0, 2.5, 1.5, 1.9990234, 0.75, 1e-30, 1.4e-45, 1e-40]
+        return f.view(np.int32).copy(), 32, 8
+    if kind == "f16":
+        f = base.astype(np.float16)
+        f[0, :8, 0] = [0.0, 1.0, 6e-8, 6.1e-5, 65504.0, np.inf, 5.96e-8, 0.333]  # binary16 subnormals normalise on the way
+        return f.view(np.uint16).astype(np.int32), 16, 5
+    if kind == "f24":  # 1 + 7 + 16: a custom width (image_metadata.cc allows any 2..8 exponent / 2..23 mantissa bits)
+        u = base.astype(np.float32).view(np.uint32)
+        s = (u >> 31) & 1
+        e = ((u >> 23) & 0xFF).astype(np.int64) - 127 + 63
+        m = (u >> 7) & 0xFFFF
+        ok = (e > 0) & (e < 127)
+        v = np.where(ok, (s.astype(np.int64) << 23) | (e << 16) | m, 0)
+        v[0, :4, 0] = [0, 1, 0x7F, (127 << 16) | 5]  # two subnormals of the type and a NaN with payload
+        return v.astype(np.int32), 24, 7
+    bits = int(kind[1:])
+    return np.round(base * ((1 << bits) - 1)).astype(np.int64).astype(np.int32), bits, 0
+
+
+@pytest.mark.parametrize("kind,flags,size,nc", [
+    ("f32", 0, (300, 70), 3),            # binary32 samples as they are (lossless float: what cjxl writes for PFM / EXR input)
+    ("f32", 4 | 8, (520, 300), 3),       # + weighted predictor + Squeeze over the bit patterns, several groups
+    ("f16", 4, (300, 280), 4),           # binary16 with an 8-bit alpha channel
+    ("f16", 16 | 32, (280, 300), 1),     # grey
+    ("f24", 0, (260, 40), 3),            # a custom float width
+    ("u20", 16 | 4, (300, 280), 3),      # integers above 16 bits: single-precision scale
+    ("u24", 16 | 8, (520, 260), 3),      # double-precision scale from 23 bits on
+    ("u28", 0, (64, 48), 1),
+])
+def test_float_and_deep_integer_samples(built, kind, flags, size, nc):
+    """Modular frames whose colour samples are floats (any width the format allows) or integers of more than 16 bits
+    (dec_modular.cc:128-185,633-690; refused until round 4). Lossless: the float32 output must be, bit for bit, the NumPy
+    reading of the reference's conversion applied to the ENCODER'S INPUT -- no decoder in between; the oracle's integer
+    channels are checked against the same input on the way."""
+    J = built
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import jxlo
+    w, h = size
+    v, bits, exp_bits = _deep_samples(kind, h, w, 3 if nc >= 3 else 1, seed=len(kind) + flags)
+    if nc in (2, 4):
+        y, x = np.mgrid[0:h, 0:w]
+        v = np.dstack([v, ((x * 3 + y * 5) % 256).astype(np.int32)])
+    data = J.encode_lossless_samples(v, bits, exp_bits, flags=flags, seed=flags)
+    o = jxlo.Decoded(data, dumps=True)
+    assert o.info["bits"] == bits
+    assert np.array_equal(o.buffer("modular").reshape(nc, h, w), np.moveaxis(v, -1, 0)), "oracle integers differ from the input"
+    o.close()
+    got = J.decode_lossless(data, num_channels=nc, data_type=0)
+    assert got.shape == (h, w, nc) and got.dtype == np.float32
+    ncol = 3 if nc >= 3 else 1
+    want = np_sample_to_float(v[..., :ncol], bits, exp_bits)
+    assert np.array_equal(got[..., :ncol].view(np.uint32), want.view(np.uint32)), \
+        "%d samples differ" % int((got[..., :ncol].view(np.uint32) != want.view(np.uint32)).sum())
+    if nc in (2, 4):
+        assert np.array_equal(got[..., ncol], v[..., ncol].astype(np.float32) * np.float32(1.0 / 255))
+    if kind == "f16":  # the narrow type's own reading: NumPy's binary16 -> binary32 widening is exact
+        assert np.array_equal(want.view(np.uint32), v[..., :ncol].astype(np.uint16).view(np.float16).astype(np.float32).view(np.uint32))
+        half = J.decode_lossless(data, num_channels=nc, data_type=5)
+        assert np.array_equal(half[..., :ncol].view(np.uint16), v[..., :ncol].astype(np.uint16))
+    if kind == "u20":  # 16-bit output of deeper integers: rounded, as the reference's writer does (stage_write.cc)
+        u16 = J.decode_lossless(data, num_channels=nc, data_type=3)
+        assert np.abs(u16.astype(np.int64) - np.round(want.astype(np.float64) * 65535).astype(np.int64)).max() <= 1

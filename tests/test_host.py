@@ -624,3 +624,28 @@ def test_partial_frame_plan_counts_the_passes_that_have_arrived(built):
     f = J.Frame(data)
     assert L.jxlamd_frame_complete_passes(f._h, 1, info) == 2  # a whole frame: all of its passes
     f.close()
+
+
+def test_float_and_deep_integer_modular_streams_on_the_host(built):
+    """CPU half of tests/test_gpu_modular.py::test_float_and_deep_integer_samples: the stream writer's float / deep-integer
+    Modular streams decode (oracle) to the integers they were made from, the product's host front-end plans them (it refused
+    them before round 4), and the NumPy reading of dec_modular.cc:128-185 agrees with NumPy's own binary16 widening on all
+    65 536 patterns."""
+    import importlib.util
+    import jxlo
+    J = built
+    spec = importlib.util.spec_from_file_location("tgm", os.path.join(ROOT, "tests", "test_gpu_modular.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    every = np.arange(65536, dtype=np.int32)
+    assert np.array_equal(m.np_sample_to_float(every, 16, 5).view(np.uint32),
+                          every.astype(np.uint16).view(np.float16).astype(np.float32).view(np.uint32))
+    assert m.np_sample_to_float(np.array([0x3F800000, -(1 << 31)]), 32, 8).view(np.uint32).tolist() == [0x3F800000, 0x80000000]
+    for kind, flags, (w, h), nc in (("f32", 4, (300, 70), 3), ("f16", 16, (280, 300), 1), ("f24", 0, (260, 40), 3), ("u24", 8, (300, 260), 3)):
+        v, bits, exp_bits = m._deep_samples(kind, h, w, nc, seed=3)
+        data = J.encode_lossless_samples(v, bits, exp_bits, flags=flags)
+        o = jxlo.Decoded(data, dumps=True)
+        assert o.info["bits"] == bits
+        assert np.array_equal(o.buffer("modular").reshape(nc, h, w), np.moveaxis(v, -1, 0))
+        o.close()
+        J.ModFrame(data).close()
