@@ -869,8 +869,12 @@ def main():
             pmc_name = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))[-1]  # the latest round's
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
             key = ["k_entropy_lanes", "k_idct_fast<short, 4, 4>", "k_filter_rows2"][dom]
-            for name, v in pmc.items():
-                if key in name and pmc.get("_frames_per_launch") == args.batch:
+            # (several instantiations of a kernel may be in the summary -- the libjxl-tables leg runs others: the one this
+            # command dispatched most often is the default line's)
+            matches = sorted(((v.get("dispatches", 0), name) for name, v in pmc.items() if isinstance(v, dict) and key in name), reverse=True)[:1]
+            for _, name in matches:
+                v = pmc[name]
+                if pmc.get("_frames_per_launch") == args.batch:
                     traffic = int(v["hbm_kib_per_dispatch"] * 1024)  # FETCH_SIZE doubled (gfx950: the guide's correction) + WRITE_SIZE
                     # (PMC counters cannot be collected inside this run: the figure is the committed profile's, named with the
                     # commit it was taken at, for a launch of the same frames per launch)
